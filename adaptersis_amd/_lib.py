@@ -1,0 +1,84 @@
+"""ctypes binding of libasis_hip.so (the C ABI declared in include/asis_hip.h).
+
+The library is the product: if it is missing or fails to load, every op raises — there is no
+eager-PyTorch or CPU fallback anywhere in this package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libasis_hip.so")
+
+ASIS_F16, ASIS_BF16 = 0, 1
+ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
+
+
+class AsisError(RuntimeError):
+    pass
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p),
+        ("lda", C.c_int64), ("ldb", C.c_int64), ("ldc", C.c_int64),
+        ("strideA", C.c_int64), ("strideB", C.c_int64), ("strideC", C.c_int64),
+        ("batch", C.c_int32), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+        ("bias_n", C.c_void_p), ("bias_m", C.c_void_p), ("scale_n", C.c_void_p), ("res", C.c_void_p),
+        ("ldr", C.c_int64), ("strideR", C.c_int64),
+        ("act", C.c_int32), ("out_f32", C.c_int32), ("dtype", C.c_int32),
+        ("conv", C.c_int32),
+        ("B_", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32), ("OH", C.c_int32),
+        ("OW", C.c_int32), ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
+        ("stats", C.c_void_p),
+    ]
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load (once) and return the shared library; raise loudly if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AsisError(
+            f"{LIB_PATH} is missing: build it with `python -m adaptersis_amd.build` "
+            "(hipcc --offload-arch=gfx950). adaptersis_amd has no fallback path.")
+    _lib = C.CDLL(LIB_PATH)
+    _lib.asis_last_error.restype = C.c_char_p
+    _declare(_lib)
+    return _lib
+
+
+# name -> argtypes ; every function returns int
+_vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
+SIGNATURES = {
+    "asis_version": [],
+    "asis_device_count": [],
+    "asis_gemm": [_vp, C.POINTER(GemmDesc)],
+    "asis_gemm_tiles_m": [_i],
+    "asis_layernorm": [_vp, _i, _vp, _i64, _vp, _vp, _f, _vp, _i64, _i, _i64, _i],
+    "asis_attention_fwd": [_vp, _i, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _i, _f],
+    "asis_im2col_patch": [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i64],
+    "asis_cast_pad": [_vp, _i, _vp, _i64, _vp, _i64, _i64, _i],
+    "asis_add_cls_pos": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i],
+}
+
+
+def _declare(l: C.CDLL) -> None:
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(l, name)  # AttributeError here = header/library mismatch: fail loudly
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc == 0:
+        return
+    msg = lib().asis_last_error().decode(errors="replace")
+    if rc == -1:
+        raise ValueError(f"{what}: {msg}" if what else msg)
+    raise AsisError(f"{what}: {msg}" if what else msg)

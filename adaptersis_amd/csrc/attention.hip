@@ -1,0 +1,233 @@
+// Fused softmax attention forward for the DINOv2 blocks (head dim 64, N = 42*42 (+1 cls) tokens).
+//
+//   O = softmax(scale * Q K^T) V        dinov2/layers/attention.py:60-66
+//
+// Flash-style, scores never leave registers.  Layout chosen so that everything per QUERY is
+// lane-local on a wave64 with v_mfma_f32_32x32x16:
+//   * S^T = K Q^T        (A = K rows from LDS, B = Q^T fragments held in registers)
+//       accumulator: column (lane&31) = query, the 16 registers = keys
+//       -> row max / row sum are in-lane reductions + one lane^32 exchange.
+//   * O^T = V^T P^T      (A = V^T rows from LDS, B = P^T straight from the S^T accumulator,
+//       cdna_hip_programming.md §3 "An accumulator tile as the next MFMA's operand")
+//       accumulator: column = query again, so the online-softmax rescale and the final 1/l
+//       are lane-local too.
+//   The accumulator->operand hand-off permutes k inside each 16-key step; instead of shuffling
+//   P we load the K rows of a 32-key block in the inverse permutation (swap bits 2 and 3 of
+//   the row index), which makes the matching V^T fragment 8 contiguous keys = one ds_read_b128.
+//   V arrives already transposed ([B, H*64, ldvt], keys contiguous) from the QKV GEMM, so no
+//   transposed LDS reads are needed.
+// Workgroup = 4 waves = 128 queries of one (image, head); K / V^T tiles of 64 keys are
+// double-buffered in LDS (32 KiB, XOR-swizzled 128-B rows, conflict-free ds_read_b128), the
+// next tile's global loads are in flight during the MFMAs of the current one.
+#include "asis_common.h"
+
+namespace {
+
+constexpr int QT = 128;  // queries per workgroup
+constexpr int KT = 64;   // keys per tile
+constexpr int HD = 64;   // head dim
+
+__device__ __forceinline__ int perm23(int r) {  // swap bits 2 and 3
+  return (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, int64_t ldqk,
+                                                       const T* __restrict__ vt, int64_t ldvt, T* __restrict__ o,
+                                                       int64_t ldo, int H, int N, float scale_log2e) {
+  typedef typename T16<T>::v8 v8;
+  __shared__ __attribute__((aligned(16))) T lds[2 * 2 * KT * HD];  // [buf][K | Vt][64][64] = 32 KiB
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int q_base = blockIdx.x * QT + wid * 32;
+
+  // ---- Q^T fragments (B operand of S^T = K Q^T): lane (fr, fh) holds Q[q][16s + 8fh .. +7] ----
+  v8 qf[4];
+  {
+    const int qi = q_base + fr;
+    const T* qp = q + ((int64_t)b * N + (qi < N ? qi : 0)) * ldqk + head * HD + 8 * fh;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (qi < N) v = *reinterpret_cast<const uint4*>(qp + 16 * s);
+      qf[s] = __builtin_bit_cast(v8, v);
+    }
+  }
+
+  // ---- K / V^T tile loaders: 512 16-byte chunks each, 2 per thread ----
+  const T* kbase = k + (int64_t)b * N * ldqk + head * HD;
+  const T* vbase = vt + ((int64_t)b * H + head) * HD * ldvt;
+  uint4 rk[2], rv[2];
+  auto load_tile = [&](int key0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = tid + 256 * i;
+      const int row = c >> 3, ch = c & 7;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (key0 + row < N) v = *reinterpret_cast<const uint4*>(kbase + (int64_t)(key0 + row) * ldqk + ch * 8);
+      rk[i] = v;
+      uint4 w = make_uint4(0, 0, 0, 0);
+      const int kk = key0 + ch * 8;
+      if (kk < N) {
+        w = *reinterpret_cast<const uint4*>(vbase + (int64_t)row * ldvt + kk);
+        if (kk + 8 > N) {  // ragged tail: V^T pad columns may hold anything; force exact zeros
+          const int valid = N - kk;  // 1..7
+          uint32_t* pw = reinterpret_cast<uint32_t*>(&w);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (2 * e >= valid) pw[e] = 0;
+            else if (2 * e + 1 >= valid) pw[e] &= 0xFFFFu;
+          }
+        }
+      }
+      rv[i] = w;
+    }
+  };
+  auto store_tile = [&](int buf) {
+    T* Ks = lds + buf * (2 * KT * HD);
+    T* Vs = Ks + KT * HD;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = tid + 256 * i;
+      const int row = c >> 3, ch = c & 7;
+      const int sw = (ch ^ ((row >> 1) & 7)) << 3;
+      *reinterpret_cast<uint4*>(Ks + row * HD + sw) = rk[i];
+      *reinterpret_cast<uint4*>(Vs + row * HD + sw) = rv[i];
+    }
+  };
+
+  f32x16 oacc[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) oacc[0][r] = oacc[1][r] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;
+
+  const int nt = (N + KT - 1) / KT;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+
+  const int prow = perm23(fr);
+  for (int t = 0; t < nt; ++t) {
+    const int buf = t & 1;
+    const int key0 = t * KT;
+    if (t + 1 < nt) load_tile(key0 + KT);
+    const T* Ks = lds + buf * (2 * KT * HD);
+    const T* Vs = Ks + KT * HD;
+
+    // ---- S^T = K Q^T : 2 key blocks x 4 k-steps ----
+    f32x16 sacc[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sacc[0][r] = sacc[1][r] = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      const int row = kb * 32 + prow;
+      const int rsw = (row >> 1) & 7;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const v8 a = __builtin_bit_cast(v8, *reinterpret_cast<const uint4*>(Ks + row * HD + (((2 * s + fh) ^ rsw) << 3)));
+        sacc[kb] = T16<T>::mfma32(a, qf[s], sacc[kb]);
+      }
+    }
+
+    // ---- online softmax (scaled-by-log2e domain), lane-local per query ----
+    float mx = -1e30f;
+    const bool tail = key0 + KT > N;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float s = sacc[kb][r] * scale_log2e;
+        if (tail) {
+          const int key = key0 + kb * 32 + perm23((r & 3) + 8 * (r >> 2) + 4 * fh);
+          if (key >= N) s = -1e30f;
+        }
+        sacc[kb][r] = s;
+        mx = fmaxf(mx, s);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    float psum = 0.f;
+    v8 pf[2][2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = __builtin_amdgcn_exp2f(sacc[kb][r] - m_new);
+        psum += p;
+        pf[kb][r >> 3][r & 7] = (T)p;
+      }
+    l_run = l_run * alpha + psum;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      oacc[0][r] *= alpha;
+      oacc[1][r] *= alpha;
+    }
+
+    // ---- O^T += V^T P^T : 2 d blocks x (2 key blocks x 2 k-steps) ----
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+      const int row = db * 32 + fr;
+      const int rsw = (row >> 1) & 7;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const v8 a = __builtin_bit_cast(
+              v8, *reinterpret_cast<const uint4*>(Vs + row * HD + (((4 * kb + 2 * s2 + fh) ^ rsw) << 3)));
+          oacc[db] = T16<T>::mfma32(a, pf[kb][s2], oacc[db]);
+        }
+    }
+
+    if (t + 1 < nt) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- normalise and store: lane (fr, fh) owns query q_base+fr, d = 32db + 8g + 4fh + (0..3) ----
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  const int qi = q_base + fr;
+  if (qi < N) {
+    T* op = o + ((int64_t)b * N + qi) * ldo + head * HD + 4 * fh;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        uint2 w;
+        w.x = pack2<T>(oacc[db][4 * g + 0] * inv, oacc[db][4 * g + 1] * inv);
+        w.y = pack2<T>(oacc[db][4 * g + 2] * inv, oacc[db][4 * g + 3] * inv);
+        *reinterpret_cast<uint2*>(op + db * 32 + g * 8) = w;
+      }
+  }
+}
+
+}  // namespace
+
+extern "C" int asis_attention_fwd(void* stream, int dtype, const void* q, const void* k, int64_t ldqk, const void* vt,
+                                  int64_t ldvt, void* o, int64_t ldo, int B, int H, int N, float scale) {
+  ASIS_REQUIRE(q && k && vt && o, "asis_attention_fwd: null pointer");
+  ASIS_REQUIRE(B > 0 && H > 0 && N > 0, "asis_attention_fwd: bad shape B=%d H=%d N=%d", B, H, N);
+  ASIS_REQUIRE(B <= 65535 && H <= 65535, "asis_attention_fwd: B/H too large");
+  ASIS_REQUIRE(ldqk % 8 == 0 && ldqk >= (int64_t)H * HD, "asis_attention_fwd: ldqk=%ld must be a multiple of 8 and >= H*64", (long)ldqk);
+  ASIS_REQUIRE(ldvt % 8 == 0 && ldvt >= N, "asis_attention_fwd: ldvt=%ld must be a multiple of 8 and >= N=%d", (long)ldvt, N);
+  ASIS_REQUIRE(ldo % 4 == 0 && ldo >= (int64_t)H * HD, "asis_attention_fwd: ldo=%ld must be a multiple of 4 and >= H*64", (long)ldo);
+  ASIS_REQUIRE(asis_aligned16(q) && asis_aligned16(k) && asis_aligned16(vt) && (((uintptr_t)o) & 7) == 0,
+               "asis_attention_fwd: pointers must be 16-byte aligned");
+  ASIS_REQUIRE(dtype == ASIS_F16 || dtype == ASIS_BF16, "asis_attention_fwd: bad dtype %d", dtype);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  dim3 grid((N + QT - 1) / QT, H, B), block(256);
+  const float sl = scale * 1.4426950408889634f;
+  if (dtype == ASIS_F16)
+    hipLaunchKernelGGL((attn_fwd_kernel<f16>), grid, block, 0, s, reinterpret_cast<const f16*>(q),
+                       reinterpret_cast<const f16*>(k), ldqk, reinterpret_cast<const f16*>(vt), ldvt,
+                       reinterpret_cast<f16*>(o), ldo, H, N, sl);
+  else
+    hipLaunchKernelGGL((attn_fwd_kernel<bf16>), grid, block, 0, s, reinterpret_cast<const bf16*>(q),
+                       reinterpret_cast<const bf16*>(k), ldqk, reinterpret_cast<const bf16*>(vt), ldvt,
+                       reinterpret_cast<bf16*>(o), ldo, H, N, sl);
+  ASIS_CHECK_LAUNCH("asis_attention_fwd");
+  return ASIS_OK;
+}

@@ -1,0 +1,256 @@
+// MFMA GEMM / implicit-GEMM convolution for gfx950.
+//
+//   C[M,N] = epilogue( A[M,K] * B[N,K]^T )      16-bit operands, fp32 accumulate
+//
+// Tiling (wave64, v_mfma_f32_32x32x16_{f16,bf16}):
+//   workgroup 256 threads = 4 waves (2x2), tile 128x128x64, each wave a 64x64 sub-tile
+//   = 2x2 MFMA 32x32 accumulators (64 acc VGPRs).  A and B tiles are staged
+//   global -> VGPR -> LDS (register staging lets the A loader be an arbitrary per-lane
+//   gather with zero fill: that is what turns the same kernel into a 3x3 implicit-GEMM
+//   convolution on NHWC activations).  Two LDS buffers (64 KiB) -> 2 workgroups / CU;
+//   the global loads of tile t+1 are issued before the MFMAs of tile t and written to the
+//   other buffer after them (one barrier per K tile).
+//   LDS image: [row][64 k] (128-B rows); the 16-B chunk index is XOR-swizzled with
+//   (row>>1)&7, which makes the ds_read_b128 fragment reads (16-lane groups
+//   {0-3,12-15,20-27}...) conflict-free (MI355X_MICROARCH.md §LDS).
+//   Block ids are remapped XCD-aware so the N tiles of one M tile share an L2.
+//
+// Reference sites replaced: see include/asis_hip.h (asis_gemm).
+#include "asis_common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64, NTHREADS = 256;
+
+template <typename T, bool CONV>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const asis_gemm_desc d) {
+  typedef typename T16<T>::v8 v8;
+  __shared__ __attribute__((aligned(16))) T lds[2 * (BM + BN) * BK];  // 64 KiB
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = tid >> 6;
+  const int wr = wid >> 1, wc = wid & 1;
+
+  const int tiles_n = (d.N + BN - 1) / BN;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_m = bid / tiles_n;
+  const int tile_n = bid - tile_m * tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int bz = blockIdx.y;
+
+  const T* __restrict__ A = reinterpret_cast<const T*>(d.A) + (int64_t)bz * d.strideA;
+  const T* __restrict__ B = reinterpret_cast<const T*>(d.B) + (int64_t)bz * d.strideB;
+
+  // ---- loader geometry: thread -> (row lrow + 32*i, 16-byte chunk lchk) -----------------
+  const int lrow = tid >> 3;
+  const int lchk = tid & 7;
+  int64_t a_off[4];  // dense: element offset of row start; conv: pixel index base of image b
+  int a_ih0[4], a_iw0[4];
+  bool a_ok[4], b_ok[4];
+  int64_t b_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + lrow + 32 * i;
+    a_ok[i] = m < d.M;
+    if (CONV) {
+      const int mm = a_ok[i] ? m : 0;
+      const int ohw = d.OH * d.OW;
+      const int b = mm / ohw;
+      const int rem = mm - b * ohw;
+      const int oh = rem / d.OW;
+      const int ow = rem - oh * d.OW;
+      a_ih0[i] = oh * d.stride - d.pad;
+      a_iw0[i] = ow * d.stride - d.pad;
+      a_off[i] = (int64_t)b * d.H * d.W;
+    } else {
+      a_off[i] = (int64_t)m * d.lda;
+      a_ih0[i] = a_iw0[i] = 0;
+    }
+    const int n = n0 + lrow + 32 * i;
+    b_ok[i] = n < d.N;
+    b_off[i] = (int64_t)n * d.ldb;
+  }
+
+  uint4 ra[4], rb[4];
+  auto load_tile = [&](int k0) {
+    const int kk = k0 + lchk * 8;
+    const bool kok = kk < d.K;
+    int kh = 0, kw = 0, ci = kk;
+    if (CONV) {
+      const int tap = kk / d.Cin;
+      ci = kk - tap * d.Cin;
+      kh = tap / d.KW;
+      kw = tap - kh * d.KW;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (CONV) {
+        const int ih = a_ih0[i] + kh, iw = a_iw0[i] + kw;
+        if (a_ok[i] && kok && (unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W)
+          v = *reinterpret_cast<const uint4*>(A + (a_off[i] + (int64_t)ih * d.W + iw) * d.Cin + ci);
+      } else {
+        if (a_ok[i] && kok) v = *reinterpret_cast<const uint4*>(A + a_off[i] + kk);
+      }
+      ra[i] = v;
+      uint4 w = make_uint4(0, 0, 0, 0);
+      if (b_ok[i] && kok) w = *reinterpret_cast<const uint4*>(B + b_off[i] + kk);
+      rb[i] = w;
+    }
+  };
+  auto store_tile = [&](int buf) {
+    T* As = lds + buf * ((BM + BN) * BK);
+    T* Bs = As + BM * BK;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = lrow + 32 * i;
+      const int sw = (lchk ^ ((row >> 1) & 7)) << 3;
+      *reinterpret_cast<uint4*>(As + row * BK + sw) = ra[i];
+      *reinterpret_cast<uint4*>(Bs + row * BK + sw) = rb[i];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nt = (d.K + BK - 1) / BK;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+
+  const int fr = lane & 31, fh = lane >> 5;
+  for (int t = 0; t < nt; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < nt) load_tile((t + 1) * BK);
+    const T* As = lds + buf * ((BM + BN) * BK);
+    const T* Bs = As + BM * BK;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      v8 af[2], bf[2];
+      const int chunk = 2 * ks + fh;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int row = wr * 64 + i * 32 + fr;
+        af[i] = __builtin_bit_cast(v8, *reinterpret_cast<const uint4*>(As + row * BK + ((chunk ^ ((row >> 1) & 7)) << 3)));
+        const int col = wc * 64 + i * 32 + fr;
+        bf[i] = __builtin_bit_cast(v8, *reinterpret_cast<const uint4*>(Bs + col * BK + ((chunk ^ ((col >> 1) & 7)) << 3)));
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = T16<T>::mfma32(af[i], bf[j], acc[i][j]);
+    }
+    if (t + 1 < nt) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue ---------------------------------------------------------------------------
+  const int64_t cbase = (int64_t)bz * d.strideC;
+  const float* __restrict__ res = d.res ? d.res + (int64_t)bz * d.strideR : nullptr;
+  float csum[2] = {0.f, 0.f}, csq[2] = {0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = n0 + wc * 64 + j * 32 + fr;
+    const bool cok = col < d.N;
+    const float bn = (d.bias_n && cok) ? d.bias_n[col] : 0.f;
+    const float sc = (d.scale_n && cok) ? d.scale_n[col] : 1.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+        if (row < d.M && cok) {
+          float v = acc[i][j][r] + bn;
+          if (d.bias_m) v += d.bias_m[row];
+          if (d.act == ASIS_ACT_GELU) v = gelu_erf(v);
+          else if (d.act == ASIS_ACT_RELU) v = fmaxf(v, 0.f);
+          v *= sc;
+          if (res) v += res[(int64_t)row * d.ldr + col];
+          if (d.out_f32) reinterpret_cast<float*>(d.C)[cbase + (int64_t)row * d.ldc + col] = v;
+          else reinterpret_cast<T*>(d.C)[cbase + (int64_t)row * d.ldc + col] = to_t16<T>(v);
+          csum[j] += v;
+          csq[j] += v * v;
+        }
+      }
+    }
+  }
+  if (d.stats) {
+    // deterministic per-(tile_m, column) partial sums: lanes l / l+32 hold the same column,
+    // waves wr=0/1 the two row halves; combine through LDS (free after the last barrier).
+    float* red = reinterpret_cast<float*>(lds);  // [2 wr][2 kind][128 col]
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float s = csum[j] + __shfl_xor(csum[j], 32, 64);
+      float q = csq[j] + __shfl_xor(csq[j], 32, 64);
+      if (fh == 0) {
+        red[(wr * 2 + 0) * BN + wc * 64 + j * 32 + fr] = s;
+        red[(wr * 2 + 1) * BN + wc * 64 + j * 32 + fr] = q;
+      }
+    }
+    __syncthreads();
+    if (tid < BN) {
+      const int col = n0 + tid;
+      if (col < d.N) {
+        d.stats[((int64_t)tile_m * 2 + 0) * d.N + col] = red[0 * BN + tid] + red[2 * BN + tid];
+        d.stats[((int64_t)tile_m * 2 + 1) * d.N + col] = red[1 * BN + tid] + red[3 * BN + tid];
+      }
+    }
+  }
+}
+
+template <typename T>
+int launch(hipStream_t s, const asis_gemm_desc& d) {
+  const int tiles_m = (d.M + BM - 1) / BM, tiles_n = (d.N + BN - 1) / BN;
+  dim3 grid(tiles_m * tiles_n, d.batch), block(NTHREADS);
+  if (d.conv)
+    hipLaunchKernelGGL((gemm_kernel<T, true>), grid, block, 0, s, d);
+  else
+    hipLaunchKernelGGL((gemm_kernel<T, false>), grid, block, 0, s, d);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int asis_gemm_tiles_m(int M) { return (M + BM - 1) / BM; }
+
+extern "C" int asis_gemm(void* stream, const asis_gemm_desc* dp) {
+  ASIS_REQUIRE(dp != nullptr, "asis_gemm: null descriptor");
+  asis_gemm_desc d = *dp;
+  ASIS_REQUIRE(d.A && d.B && d.C, "asis_gemm: null operand pointer");
+  ASIS_REQUIRE(d.M > 0 && d.N > 0 && d.K > 0, "asis_gemm: M,N,K must be positive (got %d,%d,%d)", d.M, d.N, d.K);
+  ASIS_REQUIRE(d.dtype == ASIS_F16 || d.dtype == ASIS_BF16, "asis_gemm: bad dtype %d", d.dtype);
+  ASIS_REQUIRE(d.K % 8 == 0, "asis_gemm: K=%d must be a multiple of 8", d.K);
+  ASIS_REQUIRE(d.ldb % 8 == 0 && d.ldb >= d.K, "asis_gemm: ldb=%ld must be a multiple of 8 and >= K", (long)d.ldb);
+  ASIS_REQUIRE(asis_aligned16(d.A) && asis_aligned16(d.B), "asis_gemm: A and B must be 16-byte aligned");
+  ASIS_REQUIRE(d.strideA % 8 == 0 && d.strideB % 8 == 0, "asis_gemm: batch strides must be multiples of 8");
+  ASIS_REQUIRE(d.ldc >= d.N, "asis_gemm: ldc=%ld < N=%d", (long)d.ldc, d.N);
+  ASIS_REQUIRE(d.act >= 0 && d.act <= ASIS_ACT_RELU, "asis_gemm: bad act %d", d.act);
+  if (d.batch <= 0) d.batch = 1;
+  ASIS_REQUIRE(d.batch <= 65535, "asis_gemm: batch %d too large", d.batch);
+  if (d.res) ASIS_REQUIRE(d.ldr >= d.N, "asis_gemm: ldr=%ld < N", (long)d.ldr);
+  if (d.conv) {
+    ASIS_REQUIRE(d.batch == 1, "asis_gemm: conv mode needs batch == 1 (batch is folded into M)");
+    ASIS_REQUIRE(d.Cin % 8 == 0 && d.Cin > 0, "asis_gemm: conv Cin=%d must be a multiple of 8", d.Cin);
+    ASIS_REQUIRE(d.KH > 0 && d.KW > 0 && d.stride > 0 && d.pad >= 0, "asis_gemm: bad conv geometry");
+    ASIS_REQUIRE(d.K == d.KH * d.KW * d.Cin, "asis_gemm: conv K=%d != KH*KW*Cin=%d", d.K, d.KH * d.KW * d.Cin);
+    ASIS_REQUIRE(d.OH == (d.H + 2 * d.pad - d.KH) / d.stride + 1 && d.OW == (d.W + 2 * d.pad - d.KW) / d.stride + 1,
+                 "asis_gemm: conv output size mismatch");
+    ASIS_REQUIRE((int64_t)d.B_ * d.OH * d.OW == d.M, "asis_gemm: conv M=%d != B*OH*OW", d.M);
+  } else {
+    ASIS_REQUIRE(d.lda % 8 == 0 && d.lda >= d.K, "asis_gemm: lda=%ld must be a multiple of 8 and >= K", (long)d.lda);
+  }
+  if (d.stats) ASIS_REQUIRE(d.batch == 1, "asis_gemm: stats need batch == 1");
+  const int64_t tiles = (int64_t)asis_cdiv(d.M, BM) * asis_cdiv(d.N, BN);
+  ASIS_REQUIRE(tiles < (1ll << 31), "asis_gemm: too many tiles");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (d.dtype == ASIS_F16) launch<f16>(s, d);
+  else launch<bf16>(s, d);
+  ASIS_CHECK_LAUNCH("asis_gemm");
+  return ASIS_OK;
+}

@@ -1,0 +1,215 @@
+// HBM-bound row kernels: LayerNorm, cls/pos-embed add, fp32->16-bit packing, patch im2col.
+// One wave64 per row, 16-byte accesses, fp32 statistics (cdna_hip_programming.md G13).
+#include "asis_common.h"
+
+namespace {
+
+constexpr int LN_MAXC = 8;  // float4 chunks per lane -> D <= 2048
+
+template <typename T, bool OUT_F32>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int64_t ldx,
+                                                        const float* __restrict__ w, const float* __restrict__ b,
+                                                        float eps, void* __restrict__ y, int64_t ldy, int64_t rows,
+                                                        int D) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nchunk = D >> 2;
+  const float4* xr = reinterpret_cast<const float4*>(x + row * ldx);
+  float4 v[LN_MAXC];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nchunk) {
+      v[i] = xr[c];
+      s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nchunk) {
+      const float a0 = v[i].x - mean, a1 = v[i].y - mean, a2 = v[i].z - mean, a3 = v[i].w - mean;
+      q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+  const float4* w4 = reinterpret_cast<const float4*>(w);
+  const float4* b4 = reinterpret_cast<const float4*>(b);
+#pragma unroll
+  for (int i = 0; i < LN_MAXC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nchunk) {
+      const float4 ww = w4[c], bb = b4[c];
+      const float o0 = (v[i].x - mean) * rstd * ww.x + bb.x;
+      const float o1 = (v[i].y - mean) * rstd * ww.y + bb.y;
+      const float o2 = (v[i].z - mean) * rstd * ww.z + bb.z;
+      const float o3 = (v[i].w - mean) * rstd * ww.w + bb.w;
+      if (OUT_F32) {
+        reinterpret_cast<float4*>(reinterpret_cast<float*>(y) + row * ldy)[c] = make_float4(o0, o1, o2, o3);
+      } else {
+        uint2 p;
+        p.x = pack2<T>(o0, o1);
+        p.y = pack2<T>(o2, o3);
+        reinterpret_cast<uint2*>(reinterpret_cast<T*>(y) + row * ldy)[c] = p;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void add_cls_pos_kernel(const float4* __restrict__ x, const float4* __restrict__ cls,
+                                                          const float4* __restrict__ pos, float4* __restrict__ out,
+                                                          int B, int N, int D4) {
+  const int64_t total = (int64_t)B * (N + 1) * D4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % D4);
+    const int64_t r = i / D4;
+    const int t = (int)(r % (N + 1));
+    const int b = (int)(r / (N + 1));
+    const float4 p = pos[(int64_t)t * D4 + c];
+    const float4 a = (t == 0) ? cls[c] : x[((int64_t)b * N + (t - 1)) * D4 + c];
+    out[i] = make_float4(a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void cast_pad_kernel(const float* __restrict__ src, int64_t ld_src,
+                                                       T* __restrict__ dst, int64_t ld_dst, int64_t rows, int cols) {
+  const int cpr = (int)(ld_dst >> 3);  // 8-element chunks per row
+  const int64_t total = rows * cpr;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / cpr;
+    const int c0 = (int)(i - r * cpr) * 8;
+    float f[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = (c0 + j < cols) ? src[r * ld_src + c0 + j] : 0.f;
+    uint4 p;
+    p.x = pack2<T>(f[0], f[1]);
+    p.y = pack2<T>(f[2], f[3]);
+    p.z = pack2<T>(f[4], f[5]);
+    p.w = pack2<T>(f[6], f[7]);
+    *reinterpret_cast<uint4*>(dst + r * ld_dst + c0) = p;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void im2col_patch_kernel(const float* __restrict__ img, int B, int Himg, int Wimg,
+                                                           int P, T* __restrict__ out, int64_t ldk) {
+  const int gh = Himg / P, gw = Wimg / P;
+  const int cpr = (int)(ldk >> 3);
+  const int K = 3 * P * P;
+  const int64_t total = (int64_t)B * gh * gw * cpr;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / cpr;
+    const int k0 = (int)(i - r * cpr) * 8;
+    const int pw = (int)(r % gw);
+    const int ph = (int)((r / gw) % gh);
+    const int b = (int)(r / ((int64_t)gw * gh));
+    float f[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = k0 + j;
+      float v = 0.f;
+      if (k < K) {
+        const int c = k / (P * P);
+        const int rem = k - c * P * P;
+        const int ii = rem / P, jj = rem - ii * P;
+        v = img[(((int64_t)b * 3 + c) * Himg + (ph * P + ii)) * Wimg + pw * P + jj];
+      }
+      f[j] = v;
+    }
+    uint4 p;
+    p.x = pack2<T>(f[0], f[1]);
+    p.y = pack2<T>(f[2], f[3]);
+    p.z = pack2<T>(f[4], f[5]);
+    p.w = pack2<T>(f[6], f[7]);
+    *reinterpret_cast<uint4*>(out + r * ldk + k0) = p;
+  }
+}
+
+inline int grid_for(int64_t total, int block = 256, int cap = 256 * 16) {
+  int64_t g = (total + block - 1) / block;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace
+
+extern "C" int asis_layernorm(void* stream, int dtype, const float* x, int64_t ldx, const float* w, const float* b,
+                              float eps, void* y, int64_t ldy, int out_f32, int64_t rows, int D) {
+  ASIS_REQUIRE(x && w && b && y, "asis_layernorm: null pointer");
+  ASIS_REQUIRE(D > 0 && D % 4 == 0 && D <= 256 * LN_MAXC, "asis_layernorm: D=%d must be a multiple of 4 and <= %d", D,
+               256 * LN_MAXC);
+  ASIS_REQUIRE(ldx % 4 == 0 && ldx >= D && ldy % 4 == 0 && ldy >= D, "asis_layernorm: row strides must be multiples of 4 and >= D");
+  ASIS_REQUIRE(asis_aligned16(x) && asis_aligned16(w) && asis_aligned16(b) && (((uintptr_t)y) & 7) == 0,
+               "asis_layernorm: pointers must be 16-byte aligned");
+  ASIS_REQUIRE(dtype == ASIS_F16 || dtype == ASIS_BF16, "asis_layernorm: bad dtype %d", dtype);
+  if (rows <= 0) return ASIS_OK;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  dim3 grid((unsigned)asis_cdiv(rows, 4)), block(256);
+  if (out_f32)
+    hipLaunchKernelGGL((layernorm_kernel<f16, true>), grid, block, 0, s, x, ldx, w, b, eps, y, ldy, rows, D);
+  else if (dtype == ASIS_F16)
+    hipLaunchKernelGGL((layernorm_kernel<f16, false>), grid, block, 0, s, x, ldx, w, b, eps, y, ldy, rows, D);
+  else
+    hipLaunchKernelGGL((layernorm_kernel<bf16, false>), grid, block, 0, s, x, ldx, w, b, eps, y, ldy, rows, D);
+  ASIS_CHECK_LAUNCH("asis_layernorm");
+  return ASIS_OK;
+}
+
+extern "C" int asis_add_cls_pos(void* stream, const float* x, const float* cls, const float* pos, float* out, int B,
+                                int N, int D) {
+  ASIS_REQUIRE(x && cls && pos && out, "asis_add_cls_pos: null pointer");
+  ASIS_REQUIRE(D % 4 == 0 && B > 0 && N > 0, "asis_add_cls_pos: bad shape B=%d N=%d D=%d", B, N, D);
+  ASIS_REQUIRE(asis_aligned16(x) && asis_aligned16(cls) && asis_aligned16(pos) && asis_aligned16(out),
+               "asis_add_cls_pos: pointers must be 16-byte aligned");
+  const int64_t total = (int64_t)B * (N + 1) * (D / 4);
+  hipLaunchKernelGGL(add_cls_pos_kernel, dim3(grid_for(total)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     reinterpret_cast<const float4*>(x), reinterpret_cast<const float4*>(cls),
+                     reinterpret_cast<const float4*>(pos), reinterpret_cast<float4*>(out), B, N, D / 4);
+  ASIS_CHECK_LAUNCH("asis_add_cls_pos");
+  return ASIS_OK;
+}
+
+extern "C" int asis_cast_pad(void* stream, int dtype, const float* src, int64_t ld_src, void* dst, int64_t ld_dst,
+                             int64_t rows, int cols) {
+  ASIS_REQUIRE(src && dst, "asis_cast_pad: null pointer");
+  ASIS_REQUIRE(ld_dst % 8 == 0 && ld_dst >= cols && ld_src >= cols, "asis_cast_pad: bad leading dims");
+  ASIS_REQUIRE(asis_aligned16(dst), "asis_cast_pad: dst must be 16-byte aligned");
+  ASIS_REQUIRE(dtype == ASIS_F16 || dtype == ASIS_BF16, "asis_cast_pad: bad dtype %d", dtype);
+  if (rows <= 0) return ASIS_OK;
+  const int64_t total = rows * (ld_dst / 8);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == ASIS_F16)
+    hipLaunchKernelGGL((cast_pad_kernel<f16>), dim3(grid_for(total)), dim3(256), 0, s, src, ld_src,
+                       reinterpret_cast<f16*>(dst), ld_dst, rows, cols);
+  else
+    hipLaunchKernelGGL((cast_pad_kernel<bf16>), dim3(grid_for(total)), dim3(256), 0, s, src, ld_src,
+                       reinterpret_cast<bf16*>(dst), ld_dst, rows, cols);
+  ASIS_CHECK_LAUNCH("asis_cast_pad");
+  return ASIS_OK;
+}
+
+extern "C" int asis_im2col_patch(void* stream, int dtype, const float* img, int B, int Himg, int Wimg, int P, void* out,
+                                 int64_t ldk) {
+  ASIS_REQUIRE(img && out, "asis_im2col_patch: null pointer");
+  ASIS_REQUIRE(P > 0 && Himg % P == 0 && Wimg % P == 0,
+               "Input image size %dx%d is not a multiple of patch size %d", Himg, Wimg, P);
+  ASIS_REQUIRE(ldk % 8 == 0 && ldk >= 3 * P * P, "asis_im2col_patch: ldk=%ld must be a multiple of 8 and >= 3*P*P", (long)ldk);
+  ASIS_REQUIRE(asis_aligned16(out), "asis_im2col_patch: out must be 16-byte aligned");
+  ASIS_REQUIRE(dtype == ASIS_F16 || dtype == ASIS_BF16, "asis_im2col_patch: bad dtype %d", dtype);
+  const int64_t total = (int64_t)B * (Himg / P) * (Wimg / P) * (ldk / 8);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == ASIS_F16)
+    hipLaunchKernelGGL((im2col_patch_kernel<f16>), dim3(grid_for(total)), dim3(256), 0, s, img, B, Himg, Wimg, P,
+                       reinterpret_cast<f16*>(out), ldk);
+  else
+    hipLaunchKernelGGL((im2col_patch_kernel<bf16>), dim3(grid_for(total)), dim3(256), 0, s, img, B, Himg, Wimg, P,
+                       reinterpret_cast<bf16*>(out), ldk);
+  ASIS_CHECK_LAUNCH("asis_im2col_patch");
+  return ASIS_OK;
+}

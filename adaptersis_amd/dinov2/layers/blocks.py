@@ -1,0 +1,220 @@
+"""HIP-backed DINOv2 layers: same class names, ctor arguments and ``state_dict`` keys as
+`dinov2/layers/{patch_embed,attention,mlp,swiglu_ffn,layer_scale,block}.py`; forward runs the
+gfx950 kernels of libasis_hip.so (no eager fallback).
+
+Data flow of one eval-mode block (`block.py:111-113`), residual stream fp32 [B*N, D]:
+
+    LN1 (fp32 stats) -> 16-bit xn
+    QK  GEMM  xn W_qk^T + b           -> 16-bit [B*N, 2D]
+    V^T GEMM  W_v xn_b^T + b (per image) -> 16-bit [B, D, ldvt]   (already transposed for PV)
+    fused softmax attention            -> 16-bit o [B*N, D]
+    proj GEMM, epilogue x + ls1*(.+b)  -> fp32 residual
+    LN2 -> fc1 GEMM + bias + erf-GELU (16-bit) -> fc2 GEMM, epilogue x + ls2*(.+b) -> fp32
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Tuple, Union
+
+import torch
+from torch import nn
+
+from ... import config, ops
+
+
+def _pack(cache: dict, key: str, param: torch.Tensor, fn: Callable[[torch.Tensor], torch.Tensor]):
+    """Cache a derived (16-bit / re-laid-out) copy of a parameter until the parameter changes."""
+    tag = (param.data_ptr(), param._version, config.operand_dtype, param.device)
+    hit = cache.get(key)
+    if hit is None or hit[0] != tag:
+        with torch.no_grad():
+            cache[key] = (tag, fn(param.detach()))
+    return cache[key][1]
+
+
+class _Packed(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self._cache = {}
+
+    def _w16(self, key: str, param: torch.Tensor) -> torch.Tensor:
+        return _pack(self._cache, key, param,
+                     lambda p: ops.cast_pad(p.reshape(p.shape[0], -1).contiguous().float(), dtype=config.operand_dtype))
+
+    def _f32(self, key: str, param: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+        if param is None:
+            return None
+        return _pack(self._cache, key, param, lambda p: p.float().contiguous())
+
+
+def make_2tuple(x):
+    if isinstance(x, tuple):
+        assert len(x) == 2
+        return x
+    assert isinstance(x, int)
+    return (x, x)
+
+
+class PatchEmbed(_Packed):
+    """`dinov2/layers/patch_embed.py:26-81`: Conv2d(k=s=P) as im2col + MFMA GEMM -> (B, N, D) fp32."""
+
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=768, norm_layer=None,
+                 flatten_embedding=True):
+        super().__init__()
+        image_HW, patch_HW = make_2tuple(img_size), make_2tuple(patch_size)
+        if in_chans != 3 or patch_HW[0] != patch_HW[1]:
+            raise ValueError("PatchEmbed: only 3-channel images and square patches are supported")
+        self.img_size, self.patch_size = image_HW, patch_HW
+        self.patches_resolution = (image_HW[0] // patch_HW[0], image_HW[1] // patch_HW[1])
+        self.num_patches = self.patches_resolution[0] * self.patches_resolution[1]
+        self.in_chans, self.embed_dim, self.flatten_embedding = in_chans, embed_dim, flatten_embedding
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_HW, stride=patch_HW)
+        self.norm = norm_layer(embed_dim) if norm_layer else nn.Identity()
+        if norm_layer:
+            raise ValueError("PatchEmbed: norm_layer is not used on this path (vision_transformer.py:104)")
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        B, _, H, W = x.shape
+        P = self.patch_size[0]
+        assert H % P == 0, f"Input image height {H} is not a multiple of patch height {P}"
+        assert W % P == 0, f"Input image width {W} is not a multiple of patch width: {P}"
+        K = 3 * P * P
+        ldk = (K + 7) // 8 * 8
+        w16 = _pack(self._cache, "w", self.proj.weight,
+                    lambda p: ops.cast_pad(p.reshape(p.shape[0], -1).contiguous().float(), ldk, config.operand_dtype))
+        a = ops.im2col_patch(x.contiguous().float(), P, ldk, config.operand_dtype)
+        out = ops.gemm(a, w16, out_f32=True, bias_n=self._f32("b", self.proj.bias))
+        out = out.view(B, (H // P) * (W // P), self.embed_dim)
+        if not self.flatten_embedding:
+            out = out.reshape(-1, H // P, W // P, self.embed_dim)
+        return out
+
+
+class LayerScale(nn.Module):
+    """`dinov2/layers/layer_scale.py:16-27`; fused into the GEMM epilogue inside ``Block``."""
+
+    def __init__(self, dim: int, init_values: Union[float, torch.Tensor] = 1e-5, inplace: bool = False):
+        super().__init__()
+        self.inplace = inplace
+        self.gamma = nn.Parameter(init_values * torch.ones(dim))
+
+
+class Attention(_Packed):
+    """`dinov2/layers/attention.py:33-69` (p_drop = 0 on this path)."""
+
+    def __init__(self, dim, num_heads=8, qkv_bias=False, proj_bias=True, attn_drop=0.0, proj_drop=0.0):
+        super().__init__()
+        if dim % num_heads or dim // num_heads != 64:
+            raise ValueError("attention kernel supports head dim 64 (every DINOv2 arch): "
+                             f"got dim={dim}, heads={num_heads}")
+        if attn_drop or proj_drop:
+            raise ValueError("dropout is 0 on the AdapterSIS path (models/__init__.py:14-29)")
+        self.num_heads = num_heads
+        self.scale = (dim // num_heads) ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim, bias=proj_bias)
+
+    def attend(self, xn: torch.Tensor, B: int, N: int) -> torch.Tensor:
+        """xn: 16-bit [B*N, D] (already normalised) -> 16-bit attention output [B*N, D] (before proj)."""
+        D = xn.shape[1]
+        w = self._w16("qkv", self.qkv.weight)  # [3D, D] rows q | k | v
+        bias = self._f32("qkv_b", self.qkv.bias)
+        qk = ops.gemm(xn, w[: 2 * D], bias_n=None if bias is None else bias[: 2 * D])
+        ldvt = (N + 63) // 64 * 64
+        vt = torch.empty((B, D, ldvt), device=xn.device, dtype=xn.dtype)
+        ops.gemm(w[2 * D:], xn.view(B, N, D), out=vt.as_strided((B, D, N), (D * ldvt, ldvt, 1)),
+                 bias_m=None if bias is None else bias[2 * D:])
+        return ops.attention_fwd(qk[:, :D], qk[:, D:], vt, B, self.num_heads, N, self.scale)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        raise RuntimeError("Attention is driven by Block.forward (LayerNorm / LayerScale / residual are fused around it)")
+
+
+class MemEffAttention(Attention):
+    """`attention.py:72-89`: same maths as ``Attention``; here both are the fused flash kernel."""
+
+
+class Mlp(_Packed):
+    """`dinov2/layers/mlp.py:17-40` (erf GELU fused into the fc1 epilogue)."""
+
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.0, bias=True):
+        super().__init__()
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        self.fc1 = nn.Linear(in_features, hidden_features, bias=bias)
+        self.fc2 = nn.Linear(hidden_features, out_features, bias=bias)
+
+
+class SwiGLUFFN(_Packed):
+    """`dinov2/layers/swiglu_ffn.py:14-34`."""
+
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=None, drop=0.0, bias=True):
+        super().__init__()
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        self.w12 = nn.Linear(in_features, 2 * hidden_features, bias=bias)
+        self.w3 = nn.Linear(hidden_features, out_features, bias=bias)
+
+
+class SwiGLUFFNFused(SwiGLUFFN):
+    """`swiglu_ffn.py:54-72`: hidden = (int(h*2/3)+7)//8*8."""
+
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=None, drop=0.0, bias=True):
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        hidden_features = (int(hidden_features * 2 / 3) + 7) // 8 * 8
+        super().__init__(in_features, hidden_features, out_features, bias=bias)
+
+
+class Block(_Packed):
+    """`dinov2/layers/block.py:38-114`, eval branch (`:111-113`); drop_path is 0 on this path."""
+
+    def __init__(self, dim, num_heads, mlp_ratio=4.0, qkv_bias=False, proj_bias=True, ffn_bias=True, drop=0.0,
+                 attn_drop=0.0, init_values=None, drop_path=0.0, act_layer=nn.GELU, norm_layer=nn.LayerNorm,
+                 attn_class=Attention, ffn_layer=Mlp):
+        super().__init__()
+        if drop_path or drop:
+            raise ValueError("stochastic depth / dropout are 0 on the AdapterSIS path")
+        self.norm1 = norm_layer(dim)
+        self.attn = attn_class(dim, num_heads=num_heads, qkv_bias=qkv_bias, proj_bias=proj_bias)
+        self.ls1 = LayerScale(dim, init_values=init_values) if init_values else nn.Identity()
+        self.norm2 = norm_layer(dim)
+        self.mlp = ffn_layer(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, bias=ffn_bias)
+        self.ls2 = LayerScale(dim, init_values=init_values) if init_values else nn.Identity()
+        self.sample_drop_ratio = drop_path
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """x fp32 (B, N, D) -> fp32 (B, N, D); out of place like the reference."""
+        B, N, D = x.shape
+        dt = config.operand_dtype
+        x2 = x.reshape(B * N, D)
+        if x2.dtype != torch.float32 or not x2.is_contiguous():
+            x2 = x2.float().contiguous()
+        g1 = self._f32("g1", self.ls1.gamma) if isinstance(self.ls1, LayerScale) else None
+        g2 = self._f32("g2", self.ls2.gamma) if isinstance(self.ls2, LayerScale) else None
+        xn = ops.layernorm(x2, self._f32("n1w", self.norm1.weight), self._f32("n1b", self.norm1.bias),
+                           self.norm1.eps, dt)
+        o = self.attn.attend(xn, B, N)
+        x1 = ops.gemm(o, self.attn._w16("proj", self.attn.proj.weight), out_f32=True,
+                      bias_n=self.attn._f32("proj_b", self.attn.proj.bias), scale_n=g1, res=x2)
+        xn2 = ops.layernorm(x1, self._f32("n2w", self.norm2.weight), self._f32("n2b", self.norm2.bias),
+                            self.norm2.eps, dt)
+        m = self.mlp
+        if isinstance(m, Mlp):
+            h = ops.gemm(xn2, m._w16("fc1", m.fc1.weight), bias_n=m._f32("fc1_b", m.fc1.bias), act=ops.ACT_GELU)
+            x3 = ops.gemm(h, m._w16("fc2", m.fc2.weight), out_f32=True, bias_n=m._f32("fc2_b", m.fc2.bias),
+                          scale_n=g2, res=x1)
+        else:
+            h12 = ops.gemm(xn2, m._w16("w12", m.w12.weight), out_f32=True, bias_n=m._f32("w12_b", m.w12.bias))
+            h = ops.swiglu(h12, dt)
+            x3 = ops.gemm(h, m._w16("w3", m.w3.weight), out_f32=True, bias_n=m._f32("w3_b", m.w3.bias),
+                          scale_n=g2, res=x1)
+        return x3.view(B, N, D)
+
+
+class NestedTensorBlock(Block):
+    """`block.py:165-254`: list (nested-tensor) inputs need xformers in the reference; tensors only here."""
+
+    def forward(self, x_or_x_list):
+        if isinstance(x_or_x_list, torch.Tensor):
+            return super().forward(x_or_x_list)
+        raise AssertionError("xFormers is required for using nested tensors")

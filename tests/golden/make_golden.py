@@ -1,0 +1,380 @@
+"""Generate golden fixtures by importing the REFERENCE's modules (build container only).
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [--full]
+
+The reference (`/root/reference`, read-only) cannot travel to the GPU box and has
+no tests or golden vectors of its own, so parity is pinned by
+the tensors this script commits under ``tests/golden/``:
+
+* the same deterministic ``state_dict`` (``adaptersis_amd.utils.weights``) is
+  loaded into the imported reference modules and into the CPU oracle;
+* the reference's outputs are stored (sub-sampled for the big ones, plus
+  sum / sum-of-squares checksums of the full tensor);
+* the oracle is asserted equal to the reference here (fp32, rtol ~1e-5) and
+  again, without the reference, in ``tests/test_oracle_golden.py``.
+
+Only data is written: inputs are regenerated from the seed, outputs are tensors.
+``--full`` adds the ViT-L/14 588x588 cases (a few minutes of CPU).
+"""
+import argparse
+import os
+import sys
+import warnings
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+warnings.filterwarnings("ignore")
+
+REF = os.environ.get("ASIS_REFERENCE", "/root/reference")
+
+from adaptersis_amd.utils import weights as W  # noqa: E402
+from oracle import ref_torch as O  # noqa: E402
+
+
+def sub(t: torch.Tensor, max_elems: int = 20000):
+    """Deterministic strided sub-sample of a tensor + full-tensor checksums."""
+    flat = t.detach().float().reshape(-1)
+    n = flat.numel()
+    step = max(1, n // max_elems)
+    # an odd step co-prime with typical power-of-two row lengths visits every column
+    if step > 1 and step % 2 == 0:
+        step += 1
+    return {
+        "shape": torch.tensor(t.shape),
+        "step": torch.tensor(step),
+        "vals": flat[::step].clone(),
+        "sum": flat.double().sum().float(),
+        "sumsq": (flat.double() ** 2).sum().float(),
+    }
+
+
+def close(a, b, tol, what):
+    err = float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+    print(f"  oracle vs reference  {what:38s} rel-L2 {err:.3e}")
+    assert err < tol, (what, err)
+
+
+def import_reference():
+    sys.path.insert(0, REF)
+    from dinov2.models import vision_transformer as vits
+    from backbones.encoders import FeatureEncoder
+    from backbones.adapter_blocks import CAViT, CACNN, deform_inputs
+    from backbones.decoders import FeatureDecoder, DecoderMLA
+    from backbones.unet_parts import UNet
+    from backbones.ops.modules.ms_deform_attn import ms_deform_attn_core_pytorch
+    from segloss.dice import DC
+    from segloss.dice_loss import SoftDiceLoss, DC_and_CE_loss
+    from segloss.ND_Crossentropy import CrossentropyND
+    from segloss.iou_multi import iou_loss
+    return dict(vits=vits, FeatureEncoder=FeatureEncoder, CAViT=CAViT, CACNN=CACNN, deform_inputs=deform_inputs,
+                FeatureDecoder=FeatureDecoder, DecoderMLA=DecoderMLA, UNet=UNet,
+                msda_core=ms_deform_attn_core_pytorch, DC=DC, SoftDiceLoss=SoftDiceLoss,
+                DC_and_CE_loss=DC_and_CE_loss, CrossentropyND=CrossentropyND, iou_loss=iou_loss)
+
+
+def build_ref_vit(R, arch, sd):
+    D, depth, heads, ffn = W.VIT_CONFIGS[arch]
+    m = R["vits"].DinoVisionTransformer(img_size=518, patch_size=14, embed_dim=D, depth=depth, num_heads=heads,
+                                        mlp_ratio=4, init_values=1e-5, ffn_layer=ffn, block_chunks=0)
+    missing = m.load_state_dict(sd, strict=True)
+    return m.eval()
+
+
+def from_partial():
+    from functools import partial
+    import torch.nn as nn
+    return partial(nn.LayerNorm, eps=1e-6)
+
+
+def vit_case(R, arch, size, batch, out, tag):
+    D, depth, heads, _ = W.VIT_CONFIGS[arch]
+    sd = W.make_vit_state_dict(arch)
+    m = build_ref_vit(R, arch, sd)
+    img, _ = W.synthetic_batch(batch, size)
+    with torch.no_grad():
+        feats = m.get_intermediate_layers(img, 4, return_class_token=True)
+        xb = m.patch_embed(img)
+        for blk in m.blocks:
+            xb = blk(xb)
+        ofe = O.get_intermediate_layers(img, sd, heads, 4)
+        oxb = O.patch_embed(img, sd)
+        for i in range(depth):
+            oxb = O.block(oxb, sd, f"blocks.{i}", heads)
+    for i, ((f, c), (of, oc)) in enumerate(zip(feats, ofe)):
+        close(of, f, 2e-5, f"{tag} passA feat[{i}]")
+        close(oc, c, 2e-5, f"{tag} passA cls[{i}]")
+        out[f"{tag}.passA.feat{i}"] = sub(f)
+        out[f"{tag}.passA.cls{i}"] = sub(c)
+    close(oxb, xb, 2e-5, f"{tag} passB all blocks (no cls/pos)")
+    out[f"{tag}.passB.x"] = sub(xb)
+
+
+def adapter_case(R, out, D=1024, size=588, batch=1, tag="adapter588"):
+    """CAViT / CACNN at the only geometry the reference supports (fact 3)."""
+    csd = W.make_cavit_state_dict(D)
+    nsd = W.make_cacnn_state_dict(D)
+    ln = from_partial()
+    cv = R["CAViT"](dim=D, n_levels=3, num_heads=8, init_values=0.0, n_points=4, norm_layer=ln,
+                    deform_ratio=1.0, with_cp=False)
+    cv.load_state_dict(csd, strict=True)
+    cn = R["CACNN"](dim=D, n_levels=1, num_heads=8, n_points=4, norm_layer=ln, with_cffn=True, cffn_ratio=0.25,
+                    deform_ratio=1.0, drop=0.0, drop_path=0.0, with_cp=False)
+    cn.load_state_dict(nsd, strict=True)
+    img = torch.zeros(batch, 3, size, size)
+    d1, d2 = R["deform_inputs"](img, 14)
+    od1, od2 = O.deform_inputs(size, size, 14)
+    for a, b in zip(d1 + d2, od1 + od2):
+        assert torch.equal(a, b), "deform_inputs mismatch"
+    n_vit = (size // 14) ** 2
+    n_cnn = int(d1[1].prod(1).sum())
+    x = W.tensor(f"{tag}.x", (batch, n_vit, D), 1.0)
+    c = W.tensor(f"{tag}.c", (batch, n_cnn, D), 1.0)
+    grids = [tuple(int(v) for v in s) for s in d1[1]]
+    with torch.no_grad():
+        x1 = cv(query=x, reference_points=d1[0], feat=c, spatial_shapes=d1[1], level_start_index=d1[2])
+        c1 = cn(query=c, reference_points=d2[0], feat=x1, spatial_shapes=d2[1], level_start_index=d2[2],
+                H=size // 16, W=size // 16)
+        ox1 = O.cavit(x, od1[0], c, od1[1], csd)
+        oc1 = O.cacnn(c, od2[0], ox1, od2[1], grids, nsd)
+    close(ox1, x1, 2e-5, f"{tag} CAViT")
+    close(oc1, c1, 2e-5, f"{tag} CACNN")
+    out[f"{tag}.cavit"] = sub(x1)
+    out[f"{tag}.cacnn"] = sub(c1)
+
+
+def msda_core_case(R, out):
+    """Core sampling incl. out-of-range locations, plus its autograd gradients."""
+    B, M, Dh, Lq, L, P = 2, 4, 16, 37, 3, 4
+    shapes = torch.tensor([[9, 7], [5, 4], [3, 2]])
+    S = int(shapes.prod(1).sum())
+    value = W.tensor("msda.value", (B, S, M, Dh), 1.0).requires_grad_()
+    loc = W.tensor("msda.loc", (B, Lq, M, L, P, 2), 0.75, 0.5).requires_grad_()  # range [-0.25, 1.25]
+    aw = torch.softmax(W.tensor("msda.aw", (B, Lq, M, L * P), 2.0), -1).view(B, Lq, M, L, P).requires_grad_()
+    o = R["msda_core"](value, shapes, loc, aw)
+    g = W.tensor("msda.go", tuple(o.shape), 1.0)
+    o.backward(g)
+    oo = O.ms_deform_attn_core(value.detach(), shapes, loc.detach(), aw.detach())
+    close(oo, o.detach(), 1e-6, "msda core fwd")
+    out["msda.out"] = sub(o)
+    out["msda.dvalue"] = sub(value.grad)
+    out["msda.dloc"] = sub(loc.grad)
+    out["msda.daw"] = sub(aw.grad)
+
+
+def encoder_case(R, out, size, batch, D, tag):
+    sd = W.make_encoder_state_dict(D)
+    m = R["FeatureEncoder"](embed_dim=D)
+    m.load_state_dict(sd, strict=True)
+    m.train()
+    img, _ = W.synthetic_batch(batch, size)
+    with torch.no_grad():
+        c1, c2, c3, c4 = m(img)
+    osd = {k: v.clone() for k, v in sd.items()}
+    oc1, oc2, oc3, oc4, shapes = O.feature_encoder(img, osd, update_bn=True)
+    for n, a, b in (("c1", oc1, c1), ("c2", oc2, c2), ("c3", oc3, c3), ("c4", oc4, c4)):
+        close(a, b, 2e-5, f"{tag} {n}")
+        out[f"{tag}.{n}"] = sub(b)
+    for k in ("stem.1.running_mean", "stem.1.running_var", "conv4.1.running_mean", "conv4.1.running_var"):
+        close(osd[k], m.state_dict()[k], 1e-5, f"{tag} {k}")
+        out[f"{tag}.{k}"] = m.state_dict()[k].clone()
+    out[f"{tag}.shapes"] = torch.tensor(shapes)
+
+
+def decoder_case(R, out, D, hw, batch, tag, num_classes=2):
+    sd = W.make_feature_decoder_state_dict(D, num_classes, features=(D, 512, 256, 128, 64) if D >= 384 else (D, 32, 16, 16, 8))
+    feats = [D, 512, 256, 128, 64] if D >= 384 else [D, 32, 16, 16, 8]
+    m = R["FeatureDecoder"](embed_dim=D, num_classes=num_classes, features=feats)
+    m.load_state_dict(sd, strict=True)
+    m.train()
+    x = W.tensor(f"{tag}.x", (batch, 3 * D, hw, hw), 1.0)
+    size = hw * 14
+    tgt = W.synthetic_batch(batch, size, num_classes)[1]
+    logits = m(x)
+    o = torch.nn.functional.interpolate(logits, size=(size, size), mode="bilinear")
+    o = torch.softmax(o, 1)
+    loss = R["DC"](num_classes)(o, O.one_hot(tgt, num_classes))
+    loss.backward()
+    osd = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sd.items()}
+    taps = {}
+    oloss = O.train_step_loss(x, tgt, osd, num_classes, taps)
+    oloss.backward()
+    close(taps["logits"].detach(), logits.detach(), 2e-5, f"{tag} logits")
+    close(oloss.detach(), loss.detach(), 1e-5, f"{tag} loss")
+    out[f"{tag}.logits"] = sub(logits)
+    out[f"{tag}.loss"] = loss.detach().clone()
+    for k, p in m.named_parameters():
+        close(osd[k].grad, p.grad, 5e-4, f"{tag} grad {k}")
+        out[f"{tag}.grad.{k}"] = sub(p.grad, 4000)
+
+
+def mla_unet_case(R, out):
+    D, hw, B = 64, 12, 2
+    sd = W.make_decoder_mla_state_dict(D, 16)
+    m = R["DecoderMLA"](img_size=hw * 14, mla_channels=D, mlahead_channels=16)
+    # reference hard-wires 4*mlahead -> 256 -> 128 -> 64 (decoders.py:64-80)
+    m.load_state_dict(sd, strict=True)
+    m.train()
+    ins = [W.tensor(f"mla.i{i}", (B, D, hw, hw), 1.0) for i in range(4)]
+    with torch.no_grad():
+        y = m(*ins)
+        oy = O.decoder_mla(*ins, sd={k: v.clone() for k, v in sd.items()}, img_size=hw * 14)
+    close(oy, y, 2e-5, "DecoderMLA")
+    out["mla.out"] = sub(y)
+    usd = W.make_unet_state_dict(384, 2)
+    u = R["UNet"](384, 2, bilinear=False)
+    u.load_state_dict(usd, strict=True)
+    u.train()
+    x = W.tensor("unet.x", (1, 384, 16, 16), 1.0)
+    with torch.no_grad():
+        y = u(x)
+        oy = O.unet(x, {k: v.clone() for k, v in usd.items()})
+    close(oy, y, 2e-5, "UNet(384)")
+    out["unet.out"] = sub(y)
+
+
+def loss_case(R, out):
+    B, C, H = 3, 2, 40
+    lg = W.tensor("loss.logits", (B, C, H, H), 3.0)
+    tg = W.synthetic_batch(B, H, 2)[1]
+    oh = O.one_hot(tg, C)
+    out["loss.dc"] = R["DC"](C)(lg, oh)
+    out["loss.softdice"] = R["SoftDiceLoss"]()(torch.softmax(lg, 1), tg.unsqueeze(1))
+    out["loss.ce"] = R["CrossentropyND"]()(lg, tg)
+    out["loss.ce_weighted"] = torch.nn.CrossEntropyLoss(weight=torch.tensor([0.1, 10.0]))(lg, tg)
+    out["loss.dc_ce"] = R["DC_and_CE_loss"]()(lg, tg.unsqueeze(1))
+    C11 = 11
+    lg11 = W.tensor("loss.logits11", (B, C11, H, H), 3.0)
+    tg11 = W.synthetic_batch(B, H, C11)[1]
+    out["loss.iou11"] = R["iou_loss"](lg11, tg11, num_classes=C11)
+    close(O.dc_loss(lg, oh), out["loss.dc"], 1e-6, "DC")
+    close(O.soft_dice_loss(torch.softmax(lg, 1), oh), out["loss.softdice"], 1e-6, "SoftDice")
+    close(O.cross_entropy_nd(lg, tg), out["loss.ce"], 1e-6, "CE")
+    close(O.cross_entropy_nd(lg, tg, torch.tensor([0.1, 10.0])), out["loss.ce_weighted"], 1e-6, "CE weighted")
+    close(O.dc_and_ce_loss(lg, tg, oh), out["loss.dc_ce"], 1e-6, "DC+CE")
+    close(O.iou_loss(lg11, tg11, num_classes=C11), out["loss.iou11"], 1e-6, "iou_loss(11)")
+
+
+def step_case(R, out, arch, mode, tag, batch=1):
+    """Whole `train.py:268-436` step re-executed with the imported reference modules."""
+    import torch.nn.functional as F
+    D, depth, heads, _ = W.VIT_CONFIGS[arch]
+    vsd = W.make_vit_state_dict(arch, layerscale=("kernel" if mode == "kernel" else "init"))
+    esd = W.make_encoder_state_dict(D)
+    csd = W.make_cavit_state_dict(D, mode=mode)
+    nsd = W.make_cacnn_state_dict(D, mode=mode)
+    dsd = W.make_feature_decoder_state_dict(D, 2, features=(D, 512, 256, 128, 64))
+    ln = from_partial()
+    model = build_ref_vit(R, arch, vsd)
+    enc = R["FeatureEncoder"](embed_dim=D); enc.load_state_dict(esd)
+    cv = R["CAViT"](dim=D, n_levels=3, num_heads=8, init_values=0.0, n_points=4, norm_layer=ln); cv.load_state_dict(csd)
+    cn = R["CACNN"](dim=D, n_levels=1, num_heads=8, n_points=4, norm_layer=ln, with_cffn=True, cffn_ratio=0.25); cn.load_state_dict(nsd)
+    dec = R["FeatureDecoder"](embed_dim=D, num_classes=2, features=[D, 512, 256, 128, 64]); dec.load_state_dict(dsd)
+    dec.train()
+    inp, target = W.synthetic_batch(batch, 588)
+    H, Wd = 588, 588
+    d1, d2 = R["deform_inputs"](inp, 14)
+    H_c, W_c = 588 // 16, 588 // 16
+    c1, c2, c3, c4 = enc(inp)
+    c = torch.cat([c2, c3, c4], dim=1)
+    with torch.no_grad():
+        feats = model.get_intermediate_layers(inp, 4, return_class_token=True)
+        outs = [f for f, _ in feats]
+        x = model.patch_embed(inp)
+        for blk in model.blocks[0:-3]:
+            x = blk(x)
+    stages = [None, model.blocks[-3], model.blocks[-2], model.blocks[-1]]
+    for s in range(4):
+        if s:
+            with torch.no_grad():
+                x = stages[s](x)
+        x = cv(query=x, reference_points=d1[0], feat=c, spatial_shapes=d1[1], level_start_index=d1[2])
+        c = cn(query=c, reference_points=d2[0], feat=x, spatial_shapes=d2[1], level_start_index=d2[2], H=H_c, W=W_c)
+        x = x + outs[s]
+    with torch.no_grad():
+        a = x.transpose(1, 2).reshape(batch, D, 42, 42)
+        v = outs[-1].transpose(1, 2).reshape(batch, D, 42, 42)
+        cc = c4.transpose(1, 2).reshape(batch, D, 18, 18)
+        cc = F.pad(cc, [12, 12, 12, 12])
+        cat = torch.cat((a, cc, v), dim=1)
+    logits = dec(cat)
+    o = F.interpolate(logits, size=(H, Wd), mode="bilinear")
+    o = torch.softmax(o, 1)
+    loss = R["DC"](2)(o, O.one_hot(target, 2))
+    loss.backward()
+    # oracle
+    with torch.no_grad():
+        ocat = O.adapter_forward(inp, vsd, {k: t.clone() for k, t in esd.items()}, csd, nsd, heads)
+    close(ocat, cat, 5e-5, f"{tag} output_last_cat")
+    osd = {k: t.clone().requires_grad_(t.is_floating_point() and "running" not in k) for k, t in dsd.items()}
+    taps = {}
+    oloss = O.train_step_loss(ocat, target, osd, 2, taps)
+    oloss.backward()
+    close(taps["logits"].detach(), logits.detach(), 1e-4, f"{tag} logits")
+    close(oloss.detach(), loss.detach(), 1e-5, f"{tag} loss")
+    out[f"{tag}.cat"] = sub(cat)
+    out[f"{tag}.x_final"] = sub(x)
+    out[f"{tag}.c_final"] = sub(c)
+    out[f"{tag}.logits"] = sub(logits)
+    out[f"{tag}.loss"] = loss.detach().clone()
+    for k, p in dec.named_parameters():
+        close(osd[k].grad, p.grad, 2e-3, f"{tag} grad {k}")
+        out[f"{tag}.grad.{k}"] = sub(p.grad, 4000)
+    n_adapter_grads = sum(p.grad is not None for m in (cv, cn, enc) for p in m.parameters())
+    print(f"  adapter/encoder params with grad in the reference step: {n_adapter_grads} (graph cut, fact 1)")
+    out[f"{tag}.n_adapter_grads"] = torch.tensor(n_adapter_grads)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--full", action="store_true", help="also generate the ViT-L/14 588x588 cases")
+    ap.add_argument("--only", default="", help="comma separated case names")
+    args = ap.parse_args()
+    torch.set_num_threads(os.cpu_count() or 8)
+    R = import_reference()
+    only = set(filter(None, args.only.split(",")))
+
+    def want(n):
+        return not only or n in only
+
+    def save(name, out):
+        path = os.path.join(HERE, name + ".pt")
+        torch.save(out, path)
+        print(f"wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+    if want("small"):
+        out = {}
+        print("[vit_tiny_test 224 B=2]"); vit_case(R, "vit_tiny_test", 224, 2, out, "tiny224")
+        print("[vit_tiny_test 588 B=1]"); vit_case(R, "vit_tiny_test", 588, 1, out, "tiny588")
+        print("[vit_small 224 B=2]  (BASELINE config 1 backbone)"); vit_case(R, "vit_small", 224, 2, out, "small224")
+        print("[msda core]"); msda_core_case(R, out)
+        print("[losses]"); loss_case(R, out)
+        print("[encoder 224 B=2 D=128]"); encoder_case(R, out, 224, 2, 128, "enc224")
+        print("[decoder D=32 hw=6 B=2]"); decoder_case(R, out, 32, 6, 2, "dec_small")
+        print("[MLA / UNet]"); mla_unet_case(R, out)
+        save("small", out)
+    if want("adapter"):
+        out = {}
+        print("[adapter 588 D=1024 B=1]"); adapter_case(R, out)
+        print("[encoder 588 B=2 D=1024]"); encoder_case(R, out, 588, 2, 1024, "enc588")
+        save("adapter", out)
+    if want("step_tiny"):
+        # D=1024 is forced by the reference's DWConv/train.py constants; depth is free
+        pass
+    if args.full or want("vitl"):
+        if args.full or "vitl" in only:
+            out = {}
+            print("[vit_large 588 B=1]"); vit_case(R, "vit_large", 588, 1, out, "large588")
+            save("vitl", out)
+    if args.full or "step" in only:
+        out = {}
+        print("[step ViT-L 588 B=1 reference_exact (init mode)]"); step_case(R, out, "vit_large", "init", "step_exact")
+        print("[step ViT-L 588 B=1 kernel-mode weights]"); step_case(R, out, "vit_large", "kernel", "step_kernel")
+        save("step", out)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,194 @@
+"""GPU parity of the individual HIP kernels (through the C ABI) against the CPU oracle / plain
+fp32 torch maths on the same seeded inputs.  Tolerances: fp32-accumulate vs fp32 reference on
+identical 16-bit-rounded operands is ~1e-6; against unrounded fp32 it is bounded by operand
+rounding (fp16 2^-11 per element)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from adaptersis_amd import ops
+from adaptersis_amd.utils import weights as W
+from tests.conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+DT = [torch.float16, torch.bfloat16]
+
+
+def rnd(t, dt):
+    return t.to(dt).float()
+
+
+def test_library_loads_and_sees_gpu(dev):
+    assert ops.lib().asis_version() >= 100
+    assert ops.lib().asis_device_count() >= 1
+
+
+def test_cpu_tensor_is_refused():
+    a = torch.zeros(8, 8, dtype=torch.float16)
+    with pytest.raises(Exception):
+        ops.gemm(a, a)
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_gemm_identity_asymmetric(dev, dt):
+    """A = I with an asymmetric B catches a transposed C/D fragment map (cdna guide §3)."""
+    n = 128
+    a = torch.eye(n, device=dev, dtype=dt)
+    b = (torch.arange(n * n, device=dev, dtype=torch.float32).reshape(n, n) % 251 - 125).to(dt)  # exact ints
+    c = ops.gemm(a, b, out_f32=True)
+    assert torch.equal(c, b.float().t())
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 72), (1, 8, 8), (257, 129, 1024), (1765 * 2, 288, 384),
+                                   (64, 3072, 128), (4100, 64, 576)])
+def test_gemm_shapes(dev, dt, M, N, K):
+    a = W.tensor(f"g.a{M}", (M, K), 1.0).to(dev).to(dt)
+    b = W.tensor(f"g.b{N}", (N, K), 1.0).to(dev).to(dt)
+    ref = a.float() @ b.float().t()
+    c = ops.gemm(a, b, out_f32=True)
+    assert rel_l2(c, ref) < 2e-6
+    c16 = ops.gemm(a, b)
+    assert c16.dtype == dt
+    assert rel_l2(c16, ref) < (1e-3 if dt == torch.float16 else 6e-3)
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_gemm_epilogue(dev, dt):
+    M, N, K = 333, 200, 136
+    a = W.tensor("e.a", (M, K), 1.0).to(dev).to(dt)
+    b = W.tensor("e.b", (N, K), 1.0).to(dev).to(dt)
+    bn = W.tensor("e.bn", (N,), 1.0).to(dev)
+    bm = W.tensor("e.bm", (M,), 1.0).to(dev)
+    sc = W.tensor("e.sc", (N,), 1.0).to(dev)
+    res = W.tensor("e.res", (M, N), 3.0).to(dev)
+    acc = a.float() @ b.float().t()
+    ref = F.gelu(acc + bn[None] + bm[:, None]) * sc[None] + res
+    c = ops.gemm(a, b, out_f32=True, bias_n=bn, bias_m=bm, scale_n=sc, res=res, act=ops.ACT_GELU)
+    assert rel_l2(c, ref) < 3e-6
+    ref2 = F.relu(acc + bn[None])
+    c2 = ops.gemm(a, b, out_f32=True, bias_n=bn, act=ops.ACT_RELU)
+    assert rel_l2(c2, ref2) < 3e-6
+    # strided (padded) output and residual rows
+    big = torch.full((M, N + 24), 7.0, device=dev)
+    ops.gemm(a, b, out=big[:, :N], bias_n=bn)
+    assert rel_l2(big[:, :N], acc + bn[None]) < 3e-6
+    assert torch.all(big[:, N:] == 7.0)
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_gemm_batched_shared_a(dev, dt):
+    """The V^T GEMM of attention: A = W_v shared, B = tokens of image b, C = V^T[b] with row pitch ldvt."""
+    Bn, D, N = 3, 128, 257
+    ldvt = 320
+    wv = W.tensor("bt.w", (D, D), 0.1).to(dev).to(dt)
+    x = W.tensor("bt.x", (Bn, N, D), 1.0).to(dev).to(dt)
+    bias = W.tensor("bt.b", (D,), 1.0).to(dev)
+    vt = torch.full((Bn, D, ldvt), 5.0, device=dev, dtype=dt)
+    ops.gemm(wv, x, out=vt.as_strided((Bn, D, N), (D * ldvt, ldvt, 1)), bias_m=bias)
+    ref = torch.einsum("fd,bnd->bfn", wv.float(), x.float()) + bias[None, :, None]
+    assert rel_l2(vt[:, :, :N], ref) < (1e-3 if dt == torch.float16 else 6e-3)
+    assert torch.all(vt[:, :, N:] == 5.0)
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("Cin,Cout,H,Wd,stride,pad", [(8, 16, 9, 7, 1, 1), (64, 128, 21, 21, 2, 0), (72, 40, 12, 13, 2, 1),
+                                                      (128, 64, 30, 30, 1, 1), (16, 2, 33, 31, 1, 1)])
+def test_conv_implicit_gemm(dev, dt, Cin, Cout, H, Wd, stride, pad):
+    Bn = 2
+    x = W.tensor(f"cv.x{Cin}", (Bn, Cin, H, Wd), 1.0).to(dev)
+    w = W.tensor(f"cv.w{Cin}", (Cout, Cin, 3, 3), 0.2).to(dev)
+    bias = W.tensor(f"cv.b{Cin}", (Cout,), 1.0).to(dev)
+    x16 = x.permute(0, 2, 3, 1).contiguous().to(dt)
+    wp = w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous().to(dt)
+    ref = F.conv2d(rnd(x, dt), rnd(w, dt), bias, stride=stride, padding=pad).permute(0, 2, 3, 1)
+    tiles = ops.gemm_tiles_m(ref.shape[0] * ref.shape[1] * ref.shape[2])
+    stats = torch.zeros(tiles, 2, Cout, device=dev)
+    y = ops.conv_gemm(x16, wp, 3, 3, stride, pad, bias_n=bias, stats=stats)
+    assert y.shape == ref.shape
+    assert rel_l2(y, ref) < 3e-6
+    s = stats.sum(0)
+    assert rel_l2(s[0], ref.sum((0, 1, 2))) < 1e-4
+    assert rel_l2(s[1], (ref * ref).sum((0, 1, 2))) < 1e-5
+
+
+def test_gemm_rejects_bad_args(dev):
+    a = torch.zeros(16, 12, device=dev, dtype=torch.float16)
+    with pytest.raises(ValueError):
+        ops.gemm(a, a)  # K=12 not a multiple of 8
+    b = torch.zeros(16, 16, device=dev, dtype=torch.bfloat16)
+    with pytest.raises(ValueError):
+        ops.gemm(torch.zeros(16, 16, device=dev, dtype=torch.float16), b)
+
+
+@pytest.mark.parametrize("D", [128, 384, 1024, 1536])
+def test_layernorm(dev, D):
+    rows = 777
+    x = W.tensor(f"ln.x{D}", (rows, D), 3.0, 0.5).to(dev)
+    w = W.tensor(f"ln.w{D}", (D,), 0.5, 1.0).to(dev)
+    b = W.tensor(f"ln.b{D}", (D,), 0.5).to(dev)
+    ref = F.layer_norm(x, (D,), w, b, 1e-6)
+    y = ops.layernorm(x, w, b, 1e-6, torch.float32)
+    assert rel_l2(y, ref) < 1e-6
+    for dt in DT:
+        y16 = ops.layernorm(x, w, b, 1e-6, dt)
+        assert y16.dtype == dt
+        assert torch.equal(y16, y.to(dt)) or rel_l2(y16, ref) < (5e-4 if dt == torch.float16 else 4e-3)
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("B,H,N", [(1, 1, 64), (2, 2, 257), (1, 3, 1764), (2, 2, 1765), (1, 1, 100)])
+def test_attention_fwd(dev, dt, B, H, N):
+    D = H * 64
+    q = W.tensor(f"at.q{N}", (B, N, H, 64), 2.0).to(dev).to(dt)
+    k = W.tensor(f"at.k{N}", (B, N, H, 64), 2.0).to(dev).to(dt)
+    v = W.tensor(f"at.v{N}", (B, N, H, 64), 1.0).to(dev).to(dt)
+    qk = torch.cat([q.reshape(B * N, D), k.reshape(B * N, D)], dim=1).contiguous()
+    ldvt = (N + 63) // 64 * 64
+    vt = torch.full((B, D, ldvt), float("nan"), device=dev, dtype=dt)  # pad columns hold garbage on purpose
+    vt[:, :, :N] = v.reshape(B, N, D).transpose(1, 2)
+    o = ops.attention_fwd(qk[:, :D], qk[:, D:], vt, B, H, N, 0.125)
+    qf, kf, vf = (t.float().permute(0, 2, 1, 3) for t in (q, k, v))
+    p = torch.softmax((qf * 0.125) @ kf.transpose(-1, -2), -1)
+    ref = (p @ vf).permute(0, 2, 1, 3).reshape(B * N, D)
+    assert torch.isfinite(o.float()).all()
+    assert rel_l2(o, ref) < (1.5e-3 if dt == torch.float16 else 1e-2)
+
+
+def test_attention_forces_online_softmax_rescale(dev):
+    """A key spike in a late tile makes the running max jump: the rescale branch must be exact
+    (cdna guide §5.4 rule 26: force the rare branch)."""
+    B, H, N = 1, 1, 300
+    q = W.tensor("sp.q", (B, N, H, 64), 1.0)
+    k = W.tensor("sp.k", (B, N, H, 64), 1.0)
+    v = W.tensor("sp.v", (B, N, H, 64), 1.0)
+    k[0, 250] = 6.0 * q[0, 17]  # huge score for query 17 at key 250 (4th tile)
+    k[0, 70] = 3.0 * q[0, 18]
+    q, k, v = (t.to(dev).half() for t in (q, k, v))
+    ldvt = 320
+    vt = torch.zeros((B, 64, ldvt), device=dev, dtype=torch.float16)
+    vt[:, :, :N] = v.reshape(B, N, 64).transpose(1, 2)
+    qk = torch.cat([q.reshape(N, 64), k.reshape(N, 64)], dim=1).contiguous()
+    o = ops.attention_fwd(qk[:, :64], qk[:, 64:], vt, B, H, N, 0.125)
+    qf, kf, vf = (t.float().reshape(N, 64) for t in (q, k, v))
+    ref = torch.softmax((qf * 0.125) @ kf.t(), -1) @ vf
+    assert rel_l2(o, ref) < 1.5e-3
+    assert rel_l2(o[17], ref[17]) < 2e-3
+
+
+def test_im2col_and_cls_pos(dev):
+    img, _ = W.synthetic_batch(2, 56)
+    img = img.to(dev)
+    P, D = 14, 128
+    a = ops.im2col_patch(img, P, 592, torch.float16)
+    ref = F.unfold(img, P, stride=P).transpose(1, 2).reshape(-1, 3 * P * P)
+    assert torch.equal(a[:, : 3 * P * P], ref.half())
+    assert torch.all(a[:, 3 * P * P:] == 0)
+    x = W.tensor("cp.x", (2, 16, D), 1.0).to(dev)
+    cls = W.tensor("cp.c", (D,), 1.0).to(dev)
+    pos = W.tensor("cp.p", (17, D), 1.0).to(dev)
+    out = ops.add_cls_pos(x, cls, pos)
+    ref = torch.cat([cls.expand(2, 1, D), x], 1) + pos[None]
+    assert torch.equal(out, ref)

@@ -1,0 +1,86 @@
+"""GPU parity of the HIP-backed DINOv2 ViT (both passes the reference runs per step:
+`train.py:287` get_intermediate_layers with cls+pos-embed, and `train.py:300-302` raw
+patch_embed tokens through the blocks) against the CPU oracle and the committed goldens that
+were generated from the imported reference.
+
+Tolerance: north_star's 1e-3 relative (rel-L2 over the tensor), written here as TOL."""
+import pytest
+import torch
+
+from adaptersis_amd.dinov2.models import vision_transformer as vits
+from adaptersis_amd.utils import weights as W
+from oracle import ref_torch as O
+from tests.conftest import golden_err, load_golden, rel_l2
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+def build(arch, dev):
+    sd = W.make_vit_state_dict(arch)
+    m = vits.__dict__[arch](patch_size=14, img_size=518, init_values=1e-5,
+                            ffn_layer=W.VIT_CONFIGS[arch][3], block_chunks=0)
+    m.load_state_dict(sd, strict=True)
+    return m.to(dev).eval(), sd
+
+
+def test_block_vs_oracle(dev):
+    m, sd = build("vit_tiny_test", dev)
+    x = W.tensor("blk.x", (2, 257, 128), 1.0)
+    ref = O.block(x, sd, "blocks.0", 2)
+    y = m.blocks[0](x.to(dev))
+    assert rel_l2(y, ref) < TOL / 4
+
+
+def test_patch_embed_vs_oracle(dev):
+    m, sd = build("vit_tiny_test", dev)
+    img, _ = W.synthetic_batch(2, 224)
+    ref = O.patch_embed(img, sd)
+    y = m.patch_embed(img.to(dev))
+    assert rel_l2(y, ref) < TOL / 4
+    with pytest.raises(AssertionError):
+        m.patch_embed(torch.zeros(1, 3, 225, 224, device=dev))
+
+
+@pytest.mark.parametrize("arch,size,batch,tag", [("vit_tiny_test", 224, 2, "tiny224"), ("vit_tiny_test", 588, 1, "tiny588"),
+                                                 ("vit_small", 224, 2, "small224")])
+def test_vit_vs_golden(dev, arch, size, batch, tag):
+    g = load_golden("small")
+    m, sd = build(arch, dev)
+    img, _ = W.synthetic_batch(batch, size)
+    feats = m.get_intermediate_layers(img.to(dev), 4, return_class_token=True)
+    for i, (f, c) in enumerate(feats):
+        assert golden_err(f, g[f"{tag}.passA.feat{i}"]) < TOL, (tag, i)
+        assert golden_err(c, g[f"{tag}.passA.cls{i}"]) < TOL, (tag, i)
+    x = m.patch_embed(img.to(dev))
+    for blk in m.blocks:
+        x = blk(x)
+    assert golden_err(x, g[f"{tag}.passB.x"]) < TOL
+
+
+def test_vit_tiny_vs_oracle_full_tensor(dev):
+    """Full-tensor comparison (not sub-sampled) incl. forward_features."""
+    m, sd = build("vit_tiny_test", dev)
+    img, _ = W.synthetic_batch(1, 588)
+    ref = O.forward_features(img, sd, 2)
+    out = m(img.to(dev), is_training=True)
+    for k in ("x_norm_clstoken", "x_norm_patchtokens", "x_prenorm"):
+        assert rel_l2(out[k], ref[k]) < TOL, k
+
+
+def test_vit_large_588_vs_golden(dev):
+    """ViT-L/14 at 588x588 (the BASELINE config): 24 blocks, both passes, vs reference goldens."""
+    g = load_golden("vitl")
+    m, sd = build("vit_large", dev)
+    img, _ = W.synthetic_batch(1, 588)
+    feats = m.get_intermediate_layers(img.to(dev), 4, return_class_token=True)
+    errs = []
+    for i, (f, c) in enumerate(feats):
+        errs.append(golden_err(f, g[f"large588.passA.feat{i}"]))
+        errs.append(golden_err(c, g[f"large588.passA.cls{i}"]))
+    x = m.patch_embed(img.to(dev))
+    for blk in m.blocks:
+        x = blk(x)
+    errs.append(golden_err(x, g["large588.passB.x"]))
+    print("ViT-L 588 rel-L2 vs reference goldens:", ["%.2e" % e for e in errs])
+    assert max(errs) < TOL, errs
