@@ -35,6 +35,17 @@ class GemmDesc(C.Structure):
     ]
 
 
+class WgradDesc(C.Structure):
+    _fields_ = [
+        ("dy", C.c_void_p), ("x", C.c_void_p), ("out", C.c_void_p),
+        ("ld_dy", C.c_int64), ("P", C.c_int64),
+        ("dtype", C.c_int32), ("Cout", C.c_int32), ("CoP", C.c_int32), ("Cin", C.c_int32),
+        ("B_", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("OH", C.c_int32), ("OW", C.c_int32),
+        ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
+        ("splits", C.c_int32), ("k_per_split", C.c_int64),
+    ]
+
+
 _lib = None
 
 
@@ -54,7 +65,7 @@ def lib() -> C.CDLL:
 
 
 # name -> argtypes ; every function returns int
-_vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
+_vp, _i, _i64, _f, _d = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double
 SIGNATURES = {
     "asis_version": [],
     "asis_device_count": [],
@@ -65,6 +76,32 @@ SIGNATURES = {
     "asis_im2col_patch": [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i64],
     "asis_cast_pad": [_vp, _i, _vp, _i64, _vp, _i64, _i64, _i],
     "asis_add_cls_pos": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i],
+    "asis_msda_fwd": [_vp, _i, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i],
+    "asis_dwconv_gelu": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i],
+    "asis_conv3x3_c3": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i],
+    "asis_colstats_nparts": [_i64],
+    "asis_colstats": [_vp, _vp, _i64, _i, _vp],
+    "asis_reduce_partials": [_vp, _vp, _i, _i, _vp],
+    "asis_bn_finalize": [_vp, _vp, _d, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "asis_bn_act": [_vp, _i, _vp, _vp, _vp, _i, _vp, _i64, _i],
+    "asis_bn_relu_maxpool": [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i],
+    "asis_bn_relu_upsample": [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i],
+    "asis_pack_conv_weight": [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i64],
+    "asis_decoder_input": [_vp, _i, _vp, _vp, _i64, _vp, _vp, _i, _i, _i, _i, _i, _i],
+    "asis_add_f32": [_vp, _vp, _vp, _vp, _i64],
+    "asis_dice_nblk": [_i, _i],
+    "asis_dice_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp],
+    "asis_dice_bwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "asis_resize_bwd_nblk": [_i64],
+    "asis_resize_bilinear_bwd": [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp],
+    "asis_reduce_rows": [_vp, _vp, _i, _i, _f, _vp],
+    "asis_ew_blocks": [_i64],
+    "asis_upsample_bn_relu_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i],
+    "asis_bn_bwd_apply": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _vp, _vp, _i64, _i],
+    "asis_wgrad_splits": [_i64, _i, _i],
+    "asis_wgrad": [_vp, C.POINTER(WgradDesc)],
+    "asis_sgd_momentum": [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i],
+    "asis_scale_f32": [_vp, _vp, _i64, _f],
 }
 
 

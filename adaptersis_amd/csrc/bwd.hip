@@ -1,0 +1,214 @@
+// Backward companions of the decoder's conv -> BatchNorm(train) -> ReLU -> bilinear-upsample
+// stages (backbones/decoders.py:109-135) and the SGD step (train.py:178-191).
+//
+// Stage backward, given dU = dL/d(upsampled output) [B, fH, fW, C] (fp32, from the next conv's
+// dgrad GEMM):
+//   1. asis_upsample_bn_relu_bwd:  g = relu'(bn(x)) * upsample^T(dU)     (gather form: every input
+//      pixel sums the <= (2f+1)^2 output pixels whose taps touch it -> deterministic, no atomics)
+//      + per-block partial sums of  sum g  and  sum g*xhat   (BatchNorm dbeta / dgamma)
+//   2. asis_bn_bwd_apply:  dx = gamma*invstd * (g - dbeta/n - xhat*dgamma/n)  -> 16-bit operand of
+//      the conv dgrad / wgrad GEMMs, + partial column sums of dx (conv bias gradient)
+#include "asis_common.h"
+
+namespace {
+
+inline int grid_for(int64_t total, int block = 256, int cap = 256 * 16) {
+  int64_t g = (total + block - 1) / block;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+// source taps of output index o for align_corners=True (as upsample kernel in convmisc.hip)
+__device__ __forceinline__ void tap_ac_true(int o, float r, int in, int& i0, int& i1, float& l0, float& l1) {
+  const float s = r * (float)o;
+  i0 = (int)s;
+  i1 = i0 + ((i0 < in - 1) ? 1 : 0);
+  l1 = s - (float)i0;
+  l0 = 1.f - l1;
+}
+
+__global__ __launch_bounds__(256) void upsample_bn_relu_bwd_kernel(const float* __restrict__ dU, const float* __restrict__ x,
+                                                                   const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                   const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                   float* __restrict__ g, float* __restrict__ partial, int B,
+                                                                   int H, int W, int OH, int OW, int C) {
+  __shared__ float red[2][256 * 4];
+  const int cpt = C >> 2;
+  const float rh = OH > 1 ? (float)(H - 1) / (float)(OH - 1) : 0.f;
+  const float rw = OW > 1 ? (float)(W - 1) / (float)(OW - 1) : 0.f;
+  const float irh = rh > 0.f ? 1.f / rh : 0.f, irw = rw > 0.f ? 1.f / rw : 0.f;
+  const int64_t total = (int64_t)B * H * W * cpt;
+  // gridDim*256 is a multiple of cpt (host guarantees 256 % cpt == 0): a thread keeps its channel chunk
+  const int c = threadIdx.x % cpt;
+  const float4 sc = reinterpret_cast<const float4*>(scale)[c], sh = reinterpret_cast<const float4*>(shift)[c];
+  const float4 mu = reinterpret_cast<const float4*>(mean)[c], is = reinterpret_cast<const float4*>(invstd)[c];
+  float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t pix = i / cpt;
+    const int iw = (int)(pix % W);
+    const int ih = (int)((pix / W) % H);
+    const int b = (int)(pix / ((int64_t)W * H));
+    int oy_lo, oy_hi, ox_lo, ox_hi;
+    if (rh > 0.f) {
+      oy_lo = (int)floorf(((float)ih - 1.f) * irh) - 1;
+      oy_hi = (int)ceilf(((float)ih + 1.f) * irh) + 1;
+    } else { oy_lo = 0; oy_hi = OH - 1; }
+    if (rw > 0.f) {
+      ox_lo = (int)floorf(((float)iw - 1.f) * irw) - 1;
+      ox_hi = (int)ceilf(((float)iw + 1.f) * irw) + 1;
+    } else { ox_lo = 0; ox_hi = OW - 1; }
+    if (oy_lo < 0) oy_lo = 0;
+    if (ox_lo < 0) ox_lo = 0;
+    if (oy_hi > OH - 1) oy_hi = OH - 1;
+    if (ox_hi > OW - 1) ox_hi = OW - 1;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+      int a0, a1; float l0, l1;
+      tap_ac_true(oy, rh, H, a0, a1, l0, l1);
+      const float wy = ((a0 == ih) ? l0 : 0.f) + ((a1 == ih) ? l1 : 0.f);
+      if (wy == 0.f) continue;
+      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+        int b0, b1; float m0, m1;
+        tap_ac_true(ox, rw, W, b0, b1, m0, m1);
+        const float wx = ((b0 == iw) ? m0 : 0.f) + ((b1 == iw) ? m1 : 0.f);
+        if (wx == 0.f) continue;
+        const float4 v = reinterpret_cast<const float4*>(dU + (((int64_t)b * OH + oy) * OW + ox) * C)[c];
+        const float wt = wy * wx;
+        acc.x += wt * v.x; acc.y += wt * v.y; acc.z += wt * v.z; acc.w += wt * v.w;
+      }
+    }
+    const float4 xv = reinterpret_cast<const float4*>(x)[i];
+    float4 gg;
+    gg.x = (xv.x * sc.x + sh.x > 0.f) ? acc.x : 0.f;
+    gg.y = (xv.y * sc.y + sh.y > 0.f) ? acc.y : 0.f;
+    gg.z = (xv.z * sc.z + sh.z > 0.f) ? acc.z : 0.f;
+    gg.w = (xv.w * sc.w + sh.w > 0.f) ? acc.w : 0.f;
+    reinterpret_cast<float4*>(g)[i] = gg;
+    s1.x += gg.x; s1.y += gg.y; s1.z += gg.z; s1.w += gg.w;
+    s2.x += gg.x * (xv.x - mu.x) * is.x;
+    s2.y += gg.y * (xv.y - mu.y) * is.y;
+    s2.z += gg.z * (xv.z - mu.z) * is.z;
+    s2.w += gg.w * (xv.w - mu.w) * is.w;
+  }
+  reinterpret_cast<float4*>(red[0])[threadIdx.x] = s1;
+  reinterpret_cast<float4*>(red[1])[threadIdx.x] = s2;
+  __syncthreads();
+  if ((int)threadIdx.x < cpt) {
+    for (int t = threadIdx.x + cpt; t < 256; t += cpt) {
+      const float4 a = reinterpret_cast<const float4*>(red[0])[t], bq = reinterpret_cast<const float4*>(red[1])[t];
+      s1.x += a.x; s1.y += a.y; s1.z += a.z; s1.w += a.w;
+      s2.x += bq.x; s2.y += bq.y; s2.z += bq.z; s2.w += bq.w;
+    }
+    reinterpret_cast<float4*>(partial + ((int64_t)blockIdx.x * 2 + 0) * C)[c] = s1;
+    reinterpret_cast<float4*>(partial + ((int64_t)blockIdx.x * 2 + 1) * C)[c] = s2;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma, const float* __restrict__ dgamma,
+                                                           const float* __restrict__ dbeta, float inv_n, T* __restrict__ out,
+                                                           float* __restrict__ partial, int64_t R, int C) {
+  __shared__ float red[256 * 4];
+  const int cpt = C >> 2;
+  const int c = threadIdx.x % cpt;
+  const float4 mu = reinterpret_cast<const float4*>(mean)[c], is = reinterpret_cast<const float4*>(invstd)[c];
+  const float4 ga = reinterpret_cast<const float4*>(gamma)[c];
+  const float4 dg = reinterpret_cast<const float4*>(dgamma)[c], db = reinterpret_cast<const float4*>(dbeta)[c];
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int64_t total = R * cpt;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 gv = reinterpret_cast<const float4*>(g)[i], xv = reinterpret_cast<const float4*>(x)[i];
+    float4 o;
+    o.x = ga.x * is.x * (gv.x - db.x * inv_n - (xv.x - mu.x) * is.x * dg.x * inv_n);
+    o.y = ga.y * is.y * (gv.y - db.y * inv_n - (xv.y - mu.y) * is.y * dg.y * inv_n);
+    o.z = ga.z * is.z * (gv.z - db.z * inv_n - (xv.z - mu.z) * is.z * dg.z * inv_n);
+    o.w = ga.w * is.w * (gv.w - db.w * inv_n - (xv.w - mu.w) * is.w * dg.w * inv_n);
+    uint2 pk;
+    pk.x = pack2<T>(o.x, o.y);
+    pk.y = pack2<T>(o.z, o.w);
+    reinterpret_cast<uint2*>(out)[i] = pk;
+    s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+  }
+  reinterpret_cast<float4*>(red)[threadIdx.x] = s;
+  __syncthreads();
+  if ((int)threadIdx.x < cpt) {
+    for (int t = threadIdx.x + cpt; t < 256; t += cpt) {
+      const float4 a = reinterpret_cast<const float4*>(red)[t];
+      s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+    }
+    reinterpret_cast<float4*>(partial + (int64_t)blockIdx.x * C)[c] = s;
+  }
+}
+
+// torch.optim.SGD (dampening 0, no Nesterov): g' = g*inv_scale + wd*p ; buf = first ? g' : mom*buf + g' ; p -= lr*buf
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
+                                                  int64_t n, float lr, float momentum, float wd, float inv_scale, int first) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float pv = p[i];
+    const float gv = g[i] * inv_scale + wd * pv;
+    const float bv = first ? gv : momentum * buf[i] + gv;
+    buf[i] = bv;
+    p[i] = pv - lr * bv;
+  }
+}
+
+__global__ __launch_bounds__(256) void scale_kernel(float* __restrict__ x, int64_t n, float a) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) x[i] *= a;
+}
+
+}  // namespace
+
+extern "C" int asis_ew_blocks(int64_t total_chunks) { return grid_for(total_chunks); }
+
+extern "C" int asis_upsample_bn_relu_bwd(void* stream, const float* dU, const float* x, const float* scale,
+                                         const float* shift, const float* mean, const float* invstd, float* g,
+                                         float* partial, int B, int H, int W, int C, int factor) {
+  ASIS_REQUIRE(dU && x && scale && shift && mean && invstd && g && partial, "asis_upsample_bn_relu_bwd: null pointer");
+  ASIS_REQUIRE(C % 4 == 0 && C >= 4 && 256 % (C / 4) == 0, "asis_upsample_bn_relu_bwd: C=%d must be 4*2^k <= 1024", C);
+  ASIS_REQUIRE(factor >= 1, "asis_upsample_bn_relu_bwd: bad factor");
+  const int64_t total = (int64_t)B * H * W * (C / 4);
+  hipLaunchKernelGGL(upsample_bn_relu_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     dU, x, scale, shift, mean, invstd, g, partial, B, H, W, H * factor, W * factor, C);
+  ASIS_CHECK_LAUNCH("asis_upsample_bn_relu_bwd");
+  return ASIS_OK;
+}
+
+extern "C" int asis_bn_bwd_apply(void* stream, int dtype, const float* g, const float* x, const float* mean,
+                                 const float* invstd, const float* gamma, const float* dgamma, const float* dbeta,
+                                 double count, void* out, float* partial, int64_t R, int C) {
+  ASIS_REQUIRE(g && x && mean && invstd && gamma && dgamma && dbeta && out && partial, "asis_bn_bwd_apply: null pointer");
+  ASIS_REQUIRE(C % 4 == 0 && C >= 4 && 256 % (C / 4) == 0, "asis_bn_bwd_apply: C=%d must be 4*2^k <= 1024", C);
+  ASIS_REQUIRE(dtype == ASIS_F16 || dtype == ASIS_BF16, "asis_bn_bwd_apply: bad dtype %d", dtype);
+  const int64_t total = R * (C / 4);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const float inv_n = (float)(1.0 / count);
+  if (dtype == ASIS_F16)
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<f16>), dim3(grid_for(total)), dim3(256), 0, s, g, x, mean, invstd, gamma, dgamma,
+                       dbeta, inv_n, reinterpret_cast<f16*>(out), partial, R, C);
+  else
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16>), dim3(grid_for(total)), dim3(256), 0, s, g, x, mean, invstd, gamma, dgamma,
+                       dbeta, inv_n, reinterpret_cast<bf16*>(out), partial, R, C);
+  ASIS_CHECK_LAUNCH("asis_bn_bwd_apply");
+  return ASIS_OK;
+}
+
+extern "C" int asis_sgd_momentum(void* stream, float* p, const float* g, float* buf, int64_t n, float lr, float momentum,
+                                 float weight_decay, float inv_scale, int first_step) {
+  ASIS_REQUIRE(p && g && buf && n >= 0, "asis_sgd_momentum: bad arguments");
+  if (n == 0) return ASIS_OK;
+  hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p, g, buf, n, lr,
+                     momentum, weight_decay, inv_scale, first_step);
+  ASIS_CHECK_LAUNCH("asis_sgd_momentum");
+  return ASIS_OK;
+}
+
+extern "C" int asis_scale_f32(void* stream, float* x, int64_t n, float a) {
+  ASIS_REQUIRE(x && n >= 0, "asis_scale_f32: bad arguments");
+  if (n == 0) return ASIS_OK;
+  hipLaunchKernelGGL(scale_kernel, dim3(grid_for(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, n, a);
+  ASIS_CHECK_LAUNCH("asis_scale_f32");
+  return ASIS_OK;
+}

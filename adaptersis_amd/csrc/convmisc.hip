@@ -1,0 +1,472 @@
+// HBM-bound companions of the implicit-GEMM convolutions: stem conv (Cin=3), BatchNorm
+// (train-mode batch statistics) finalisation and fused apply kernels, weight packing, and the
+// decoder-input assembly.  All tensors between kernels are NHWC; one thread owns 4-8 contiguous
+// channels so every access is 16 bytes.
+//
+// Reference sites: backbones/encoders.py:9-47 (stem / SyncBatchNorm / ReLU / MaxPool),
+// backbones/decoders.py:109-135 (conv -> BatchNorm2d -> ReLU -> Upsample(2, bilinear,
+// align_corners=True)), train.py:389-406 (rearrange + pad + concat).
+#include "asis_common.h"
+
+namespace {
+
+inline int grid_for(int64_t total, int block = 256, int cap = 256 * 32) {
+  int64_t g = (total + block - 1) / block;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+// ---- stem conv: img fp32 NCHW [B,3,H,W] -> fp32 NHWC [B,OH,OW,Cout]; w [Cout,3,3,3] ----------
+__global__ __launch_bounds__(256) void conv3x3_c3_kernel(const float* __restrict__ img, const float* __restrict__ w,
+                                                         float* __restrict__ out, int B, int H, int W, int OH, int OW,
+                                                         int Cout, int stride, int pad) {
+  extern __shared__ __attribute__((aligned(16))) float wl[];  // [27][Cout]
+  for (int i = threadIdx.x; i < 27 * Cout; i += blockDim.x) {
+    const int co = i % Cout, k = i / Cout;  // k = ci*9 + kh*3 + kw
+    wl[i] = w[co * 27 + k];
+  }
+  __syncthreads();
+  const int cpp = Cout >> 2;
+  const int64_t total = (int64_t)B * OH * OW * cpp;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cpp);
+    const int64_t pix = i / cpp;
+    const int ow = (int)(pix % OW);
+    const int oh = (int)((pix / OW) % OH);
+    const int b = (int)(pix / ((int64_t)OW * OH));
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int ih = oh * stride - pad + kh, iw = ow * stride - pad + kw;
+          if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) {
+            const float v = img[(((int64_t)b * 3 + ci) * H + ih) * W + iw];
+            const float4 ww = reinterpret_cast<const float4*>(wl + (ci * 9 + kh * 3 + kw) * Cout)[c];
+            acc.x += v * ww.x;
+            acc.y += v * ww.y;
+            acc.z += v * ww.z;
+            acc.w += v * ww.w;
+          }
+        }
+    reinterpret_cast<float4*>(out + pix * Cout)[c] = acc;
+  }
+}
+
+// ---- column statistics of an fp32 [R, C] matrix: partial[blk][{sum,sumsq}][C] ------------------
+__global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__ x, int64_t R, int C,
+                                                       int64_t rows_per_block, float* __restrict__ partial) {
+  __shared__ float red[2][256 * 4];
+  const int cpt = C >> 2;
+  const int cw = cpt < 256 ? cpt : 256;
+  const int nrg = 256 / cw;
+  const int rg = threadIdx.x / cw, cl = threadIdx.x - rg * cw;
+  const bool active = rg < nrg;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = (r0 + rows_per_block < R) ? r0 + rows_per_block : R;
+  for (int cb = 0; cb < cpt; cb += cw) {
+    const int c = cb + cl;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = s;
+    if (active && c < cpt) {
+      for (int64_t r = r0 + rg; r < r1; r += nrg) {
+        const float4 v = reinterpret_cast<const float4*>(x + r * C)[c];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        q.x += v.x * v.x; q.y += v.y * v.y; q.z += v.z * v.z; q.w += v.w * v.w;
+      }
+    }
+    reinterpret_cast<float4*>(red[0])[threadIdx.x] = s;
+    reinterpret_cast<float4*>(red[1])[threadIdx.x] = q;
+    __syncthreads();
+    if (rg == 0 && c < cpt) {
+      for (int g = 1; g < nrg; ++g) {
+        const float4 a = reinterpret_cast<const float4*>(red[0])[g * cw + cl];
+        const float4 bq = reinterpret_cast<const float4*>(red[1])[g * cw + cl];
+        s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+        q.x += bq.x; q.y += bq.y; q.z += bq.z; q.w += bq.w;
+      }
+      reinterpret_cast<float4*>(partial + ((int64_t)blockIdx.x * 2 + 0) * C)[c] = s;
+      reinterpret_cast<float4*>(partial + ((int64_t)blockIdx.x * 2 + 1) * C)[c] = q;
+    }
+    __syncthreads();
+  }
+}
+
+// ---- reduce partial[nparts][2][C] -> sums[2][C] (double accumulate, fp32 result pairs hi/lo) ----
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, int nparts, int C,
+                                                              double* __restrict__ sums) {
+  __shared__ double red[2][256];
+  const int c = blockIdx.x;
+  double s = 0.0, q = 0.0;
+  for (int p = threadIdx.x; p < nparts; p += 256) {
+    s += (double)partial[((int64_t)p * 2 + 0) * C + c];
+    q += (double)partial[((int64_t)p * 2 + 1) * C + c];
+  }
+  red[0][threadIdx.x] = s;
+  red[1][threadIdx.x] = q;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + o];
+      red[1][threadIdx.x] += red[1][threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    sums[c] = red[0][0];
+    sums[C + c] = red[1][0];
+  }
+}
+
+// ---- BatchNorm train-mode finalisation from global sums ---------------------------------------
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, double count, int C, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float eps, float momentum,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var,
+                                   int64_t* __restrict__ nbt, float* __restrict__ scale, float* __restrict__ shift,
+                                   float* __restrict__ mean_out, float* __restrict__ invstd_out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && nbt) *nbt += 1;
+  if (c >= C) return;
+  const double mean = sums[c] / count;
+  double var = sums[C + c] / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float g = gamma ? gamma[c] : 1.f, bb = beta ? beta[c] : 0.f;
+  scale[c] = g * invstd;
+  shift[c] = bb - (float)mean * g * invstd;
+  if (mean_out) mean_out[c] = (float)mean;
+  if (invstd_out) invstd_out[c] = invstd;
+  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+  if (running_var) {
+    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
+// ---- y = [relu](x*scale + shift) -> 16-bit --------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                     const float* __restrict__ shift, int relu, T* __restrict__ out,
+                                                     int64_t R, int C) {
+  const int cpt = C >> 2;
+  const int64_t total = R * cpt;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cpt);
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    const float4 sc = reinterpret_cast<const float4*>(scale)[c], sh = reinterpret_cast<const float4*>(shift)[c];
+    float a0 = v.x * sc.x + sh.x, a1 = v.y * sc.y + sh.y, a2 = v.z * sc.z + sh.z, a3 = v.w * sc.w + sh.w;
+    if (relu) {
+      a0 = fmaxf(a0, 0.f); a1 = fmaxf(a1, 0.f); a2 = fmaxf(a2, 0.f); a3 = fmaxf(a3, 0.f);
+    }
+    uint2 o;
+    o.x = pack2<T>(a0, a1);
+    o.y = pack2<T>(a2, a3);
+    reinterpret_cast<uint2*>(out)[i] = o;
+  }
+}
+
+// ---- BN + ReLU + MaxPool(3, stride 2, pad 1) ------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                              const float* __restrict__ shift, T* __restrict__ out,
+                                                              int B, int H, int W, int OH, int OW, int C) {
+  const int cpt = C >> 2;
+  const int64_t total = (int64_t)B * OH * OW * cpt;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cpt);
+    const int64_t pix = i / cpt;
+    const int ow = (int)(pix % OW);
+    const int oh = (int)((pix / OW) % OH);
+    const int b = (int)(pix / ((int64_t)OW * OH));
+    const float4 sc = reinterpret_cast<const float4*>(scale)[c], sh = reinterpret_cast<const float4*>(shift)[c];
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int ih = oh * 2 - 1 + kh, iw = ow * 2 - 1 + kw;
+        if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) {
+          const float4 v = reinterpret_cast<const float4*>(x + (((int64_t)b * H + ih) * W + iw) * C)[c];
+          m.x = fmaxf(m.x, fmaxf(v.x * sc.x + sh.x, 0.f));
+          m.y = fmaxf(m.y, fmaxf(v.y * sc.y + sh.y, 0.f));
+          m.z = fmaxf(m.z, fmaxf(v.z * sc.z + sh.z, 0.f));
+          m.w = fmaxf(m.w, fmaxf(v.w * sc.w + sh.w, 0.f));
+        }
+      }
+    uint2 o;
+    o.x = pack2<T>(m.x, m.y);
+    o.y = pack2<T>(m.z, m.w);
+    reinterpret_cast<uint2*>(out + pix * C)[c] = o;
+  }
+}
+
+// ---- BN + ReLU + bilinear upsample (align_corners=True), integer factor ---------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_upsample_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                               const float* __restrict__ shift, T* __restrict__ out,
+                                                               int B, int H, int W, int OH, int OW, int C) {
+  const int cpt = C >> 2;
+  const float rh = OH > 1 ? (float)(H - 1) / (float)(OH - 1) : 0.f;
+  const float rw = OW > 1 ? (float)(W - 1) / (float)(OW - 1) : 0.f;
+  const int64_t total = (int64_t)B * OH * OW * cpt;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cpt);
+    const int64_t pix = i / cpt;
+    const int ow = (int)(pix % OW);
+    const int oh = (int)((pix / OW) % OH);
+    const int b = (int)(pix / ((int64_t)OW * OH));
+    const float h1r = rh * oh, w1r = rw * ow;
+    const int h1 = (int)h1r, w1 = (int)w1r;
+    const int h1p = (h1 < H - 1) ? 1 : 0, w1p = (w1 < W - 1) ? 1 : 0;
+    const float hl = h1r - h1, wl = w1r - w1;
+    const float4 sc = reinterpret_cast<const float4*>(scale)[c], sh = reinterpret_cast<const float4*>(shift)[c];
+    const float* base = x + (((int64_t)b * H + h1) * W + w1) * C;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int dh = (t >> 1) ? h1p : 0, dw = (t & 1) ? w1p : 0;
+      const float wt = ((t >> 1) ? hl : 1.f - hl) * ((t & 1) ? wl : 1.f - wl);
+      const float4 v = reinterpret_cast<const float4*>(base + ((int64_t)dh * W + dw) * C)[c];
+      acc.x += wt * fmaxf(v.x * sc.x + sh.x, 0.f);
+      acc.y += wt * fmaxf(v.y * sc.y + sh.y, 0.f);
+      acc.z += wt * fmaxf(v.z * sc.z + sh.z, 0.f);
+      acc.w += wt * fmaxf(v.w * sc.w + sh.w, 0.f);
+    }
+    uint2 o;
+    o.x = pack2<T>(acc.x, acc.y);
+    o.y = pack2<T>(acc.z, acc.w);
+    reinterpret_cast<uint2*>(out + pix * C)[c] = o;
+  }
+}
+
+// ---- conv weight packing: fp32 [Cout,Cin,KH,KW] -> 16-bit GEMM B operand --------------------------
+// mode 0 (forward):  out[co][(kh*KW+kw)*Cin + ci]                       rows Cout, ld = ldo
+// mode 1 (dgrad):    out[ci][((KH-1-kh)*KW + (KW-1-kw))*CoP + co]       rows Cin,  CoP = Cout padded to 8
+template <typename T>
+__global__ __launch_bounds__(256) void pack_conv_weight_kernel(const float* __restrict__ w, T* __restrict__ out,
+                                                               int Cout, int Cin, int KH, int KW, int mode, int CoP,
+                                                               int64_t ldo, int rows) {
+  const int64_t total = (int64_t)rows * ldo;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / ldo);
+    const int k = (int)(i - (int64_t)r * ldo);
+    float v = 0.f;
+    if (mode == 0) {
+      if (k < KH * KW * Cin) {
+        const int tap = k / Cin, ci = k - tap * Cin;
+        const int kh = tap / KW, kw = tap - kh * KW;
+        v = w[(((int64_t)r * Cin + ci) * KH + kh) * KW + kw];
+      }
+    } else {
+      if (k < KH * KW * CoP) {
+        const int tap = k / CoP, co = k - tap * CoP;
+        const int kh = KH - 1 - tap / KW, kw = KW - 1 - (tap % KW);
+        if (co < Cout) v = w[(((int64_t)co * Cin + r) * KH + kh) * KW + kw];
+      }
+    }
+    out[i] = to_t16<T>(v);
+  }
+}
+
+// ---- decoder input: [adapter-stream tokens | zero-padded c4 | pass-A tokens] -> NHWC 16-bit -------
+template <typename T>
+__global__ __launch_bounds__(256) void decoder_input_kernel(const float* __restrict__ xs, const float* __restrict__ c4,
+                                                            int64_t c4_bstride, const float* __restrict__ vit,
+                                                            T* __restrict__ out, int B, int h, int w, int h4, int w4,
+                                                            int D) {
+  const int cpt = (3 * D) >> 2;
+  const int dq = D >> 2;
+  const int py = (h - h4) / 2, px = (w - w4) / 2;  // F.pad([dx//2, dx-dx//2, dy//2, dy-dy//2])
+  const int64_t total = (int64_t)B * h * w * cpt;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cpt);
+    const int64_t pix = i / cpt;
+    const int x = (int)(pix % w);
+    const int y = (int)((pix / w) % h);
+    const int b = (int)(pix / ((int64_t)w * h));
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int seg = c / dq, cc = c - seg * dq;
+    if (seg == 0) v = reinterpret_cast<const float4*>(xs + pix * D)[cc];
+    else if (seg == 2) v = reinterpret_cast<const float4*>(vit + pix * D)[cc];
+    else {
+      const int yy = y - py, xx = x - px;
+      if ((unsigned)yy < (unsigned)h4 && (unsigned)xx < (unsigned)w4)
+        v = reinterpret_cast<const float4*>(c4 + (int64_t)b * c4_bstride + ((int64_t)yy * w4 + xx) * D)[cc];
+    }
+    uint2 o;
+    o.x = pack2<T>(v.x, v.y);
+    o.y = pack2<T>(v.z, v.w);
+    reinterpret_cast<uint2*>(out + pix * 3 * D)[c] = o;
+  }
+}
+
+// out[i] = a[i] + b[i] (fp32, float4)
+__global__ __launch_bounds__(256) void add_f32_kernel(const float4* __restrict__ a, const float4* __restrict__ b,
+                                                      float4* __restrict__ out, int64_t n4) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 x = a[i], y = b[i];
+    out[i] = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+  }
+}
+
+}  // namespace
+
+#define DT_OK(dtype, name) ASIS_REQUIRE((dtype) == ASIS_F16 || (dtype) == ASIS_BF16, name ": bad dtype %d", dtype)
+
+extern "C" int asis_conv3x3_c3(void* stream, const float* img, const float* w, float* out, int B, int H, int W, int Cout,
+                               int stride, int pad) {
+  ASIS_REQUIRE(img && w && out, "asis_conv3x3_c3: null pointer");
+  ASIS_REQUIRE(Cout % 4 == 0 && Cout > 0 && Cout <= 512, "asis_conv3x3_c3: Cout=%d must be a multiple of 4, <= 512", Cout);
+  ASIS_REQUIRE(stride > 0 && pad >= 0 && H + 2 * pad >= 3 && W + 2 * pad >= 3, "asis_conv3x3_c3: bad geometry");
+  ASIS_REQUIRE(asis_aligned16(out), "asis_conv3x3_c3: out must be 16-byte aligned");
+  const int OH = (H + 2 * pad - 3) / stride + 1, OW = (W + 2 * pad - 3) / stride + 1;
+  const int64_t total = (int64_t)B * OH * OW * (Cout / 4);
+  hipLaunchKernelGGL(conv3x3_c3_kernel, dim3(grid_for(total)), dim3(256), 27 * Cout * sizeof(float),
+                     reinterpret_cast<hipStream_t>(stream), img, w, out, B, H, W, OH, OW, Cout, stride, pad);
+  ASIS_CHECK_LAUNCH("asis_conv3x3_c3");
+  return ASIS_OK;
+}
+
+extern "C" int asis_colstats_nparts(int64_t R) {
+  int64_t n = asis_cdiv(R, 256);
+  if (n > 2048) n = 2048;
+  if (n < 1) n = 1;
+  return (int)n;
+}
+
+extern "C" int asis_colstats(void* stream, const float* x, int64_t R, int C, float* partial) {
+  ASIS_REQUIRE(x && partial, "asis_colstats: null pointer");
+  ASIS_REQUIRE(C % 4 == 0 && C > 0 && R > 0, "asis_colstats: bad shape R=%ld C=%d", (long)R, C);
+  ASIS_REQUIRE(asis_aligned16(x) && asis_aligned16(partial), "asis_colstats: pointers must be 16-byte aligned");
+  const int nparts = asis_colstats_nparts(R);
+  const int64_t rpb = asis_cdiv(R, nparts);
+  hipLaunchKernelGGL(colstats_kernel, dim3(nparts), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, R, C, rpb,
+                     partial);
+  ASIS_CHECK_LAUNCH("asis_colstats");
+  return ASIS_OK;
+}
+
+extern "C" int asis_reduce_partials(void* stream, const float* partial, int nparts, int C, double* sums) {
+  ASIS_REQUIRE(partial && sums && nparts > 0 && C > 0, "asis_reduce_partials: bad arguments");
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(C), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), partial,
+                     nparts, C, sums);
+  ASIS_CHECK_LAUNCH("asis_reduce_partials");
+  return ASIS_OK;
+}
+
+extern "C" int asis_bn_finalize(void* stream, const double* sums, double count, int C, const float* gamma,
+                                const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                                int64_t* num_batches_tracked, float* scale, float* shift, float* mean_out,
+                                float* invstd_out) {
+  ASIS_REQUIRE(sums && scale && shift && C > 0 && count > 0, "asis_bn_finalize: bad arguments");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     sums, count, C, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, scale,
+                     shift, mean_out, invstd_out);
+  ASIS_CHECK_LAUNCH("asis_bn_finalize");
+  return ASIS_OK;
+}
+
+extern "C" int asis_bn_act(void* stream, int dtype, const float* x, const float* scale, const float* shift, int relu,
+                           void* out, int64_t R, int C) {
+  ASIS_REQUIRE(x && scale && shift && out, "asis_bn_act: null pointer");
+  ASIS_REQUIRE(C % 4 == 0 && C > 0, "asis_bn_act: C=%d must be a multiple of 4", C);
+  DT_OK(dtype, "asis_bn_act");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int64_t total = R * (C / 4);
+  if (dtype == ASIS_F16)
+    hipLaunchKernelGGL((bn_act_kernel<f16>), dim3(grid_for(total)), dim3(256), 0, s, x, scale, shift, relu,
+                       reinterpret_cast<f16*>(out), R, C);
+  else
+    hipLaunchKernelGGL((bn_act_kernel<bf16>), dim3(grid_for(total)), dim3(256), 0, s, x, scale, shift, relu,
+                       reinterpret_cast<bf16*>(out), R, C);
+  ASIS_CHECK_LAUNCH("asis_bn_act");
+  return ASIS_OK;
+}
+
+extern "C" int asis_bn_relu_maxpool(void* stream, int dtype, const float* x, const float* scale, const float* shift,
+                                    void* out, int B, int H, int W, int C) {
+  ASIS_REQUIRE(x && scale && shift && out, "asis_bn_relu_maxpool: null pointer");
+  ASIS_REQUIRE(C % 4 == 0 && C > 0, "asis_bn_relu_maxpool: C=%d must be a multiple of 4", C);
+  DT_OK(dtype, "asis_bn_relu_maxpool");
+  const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int64_t total = (int64_t)B * OH * OW * (C / 4);
+  if (dtype == ASIS_F16)
+    hipLaunchKernelGGL((bn_relu_maxpool_kernel<f16>), dim3(grid_for(total)), dim3(256), 0, s, x, scale, shift,
+                       reinterpret_cast<f16*>(out), B, H, W, OH, OW, C);
+  else
+    hipLaunchKernelGGL((bn_relu_maxpool_kernel<bf16>), dim3(grid_for(total)), dim3(256), 0, s, x, scale, shift,
+                       reinterpret_cast<bf16*>(out), B, H, W, OH, OW, C);
+  ASIS_CHECK_LAUNCH("asis_bn_relu_maxpool");
+  return ASIS_OK;
+}
+
+extern "C" int asis_bn_relu_upsample(void* stream, int dtype, const float* x, const float* scale, const float* shift,
+                                     void* out, int B, int H, int W, int C, int factor) {
+  ASIS_REQUIRE(x && scale && shift && out, "asis_bn_relu_upsample: null pointer");
+  ASIS_REQUIRE(C % 4 == 0 && C > 0 && factor >= 1, "asis_bn_relu_upsample: bad C=%d / factor=%d", C, factor);
+  DT_OK(dtype, "asis_bn_relu_upsample");
+  const int OH = H * factor, OW = W * factor;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int64_t total = (int64_t)B * OH * OW * (C / 4);
+  if (dtype == ASIS_F16)
+    hipLaunchKernelGGL((bn_relu_upsample_kernel<f16>), dim3(grid_for(total)), dim3(256), 0, s, x, scale, shift,
+                       reinterpret_cast<f16*>(out), B, H, W, OH, OW, C);
+  else
+    hipLaunchKernelGGL((bn_relu_upsample_kernel<bf16>), dim3(grid_for(total)), dim3(256), 0, s, x, scale, shift,
+                       reinterpret_cast<bf16*>(out), B, H, W, OH, OW, C);
+  ASIS_CHECK_LAUNCH("asis_bn_relu_upsample");
+  return ASIS_OK;
+}
+
+extern "C" int asis_pack_conv_weight(void* stream, int dtype, const float* w, void* out, int Cout, int Cin, int KH,
+                                     int KW, int mode, int64_t ldo) {
+  ASIS_REQUIRE(w && out, "asis_pack_conv_weight: null pointer");
+  ASIS_REQUIRE(mode == 0 || mode == 1, "asis_pack_conv_weight: bad mode %d", mode);
+  DT_OK(dtype, "asis_pack_conv_weight");
+  const int CoP = (Cout + 7) / 8 * 8;
+  const int rows = mode == 0 ? Cout : Cin;
+  const int K = mode == 0 ? KH * KW * Cin : KH * KW * CoP;
+  ASIS_REQUIRE(ldo >= K && ldo % 8 == 0, "asis_pack_conv_weight: ldo=%ld must be a multiple of 8 and >= %d", (long)ldo, K);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int64_t total = (int64_t)rows * ldo;
+  if (dtype == ASIS_F16)
+    hipLaunchKernelGGL((pack_conv_weight_kernel<f16>), dim3(grid_for(total)), dim3(256), 0, s, w,
+                       reinterpret_cast<f16*>(out), Cout, Cin, KH, KW, mode, CoP, ldo, rows);
+  else
+    hipLaunchKernelGGL((pack_conv_weight_kernel<bf16>), dim3(grid_for(total)), dim3(256), 0, s, w,
+                       reinterpret_cast<bf16*>(out), Cout, Cin, KH, KW, mode, CoP, ldo, rows);
+  ASIS_CHECK_LAUNCH("asis_pack_conv_weight");
+  return ASIS_OK;
+}
+
+extern "C" int asis_decoder_input(void* stream, int dtype, const float* xs, const float* c4, int64_t c4_bstride,
+                                  const float* vit, void* out, int B, int h, int w, int h4, int w4, int D) {
+  ASIS_REQUIRE(xs && c4 && vit && out, "asis_decoder_input: null pointer");
+  ASIS_REQUIRE(D % 4 == 0 && h4 <= h && w4 <= w, "asis_decoder_input: bad shape");
+  ASIS_REQUIRE(c4_bstride % 4 == 0 && asis_aligned16(xs) && asis_aligned16(c4) && asis_aligned16(vit),
+               "asis_decoder_input: alignment");
+  DT_OK(dtype, "asis_decoder_input");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int64_t total = (int64_t)B * h * w * (3 * D / 4);
+  if (dtype == ASIS_F16)
+    hipLaunchKernelGGL((decoder_input_kernel<f16>), dim3(grid_for(total)), dim3(256), 0, s, xs, c4, c4_bstride, vit,
+                       reinterpret_cast<f16*>(out), B, h, w, h4, w4, D);
+  else
+    hipLaunchKernelGGL((decoder_input_kernel<bf16>), dim3(grid_for(total)), dim3(256), 0, s, xs, c4, c4_bstride, vit,
+                       reinterpret_cast<bf16*>(out), B, h, w, h4, w4, D);
+  ASIS_CHECK_LAUNCH("asis_decoder_input");
+  return ASIS_OK;
+}
+
+extern "C" int asis_add_f32(void* stream, const float* a, const float* b, float* out, int64_t n) {
+  ASIS_REQUIRE(a && b && out, "asis_add_f32: null pointer");
+  ASIS_REQUIRE(n % 4 == 0 && asis_aligned16(a) && asis_aligned16(b) && asis_aligned16(out), "asis_add_f32: alignment");
+  hipLaunchKernelGGL(add_f32_kernel, dim3(grid_for(n / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     reinterpret_cast<const float4*>(a), reinterpret_cast<const float4*>(b),
+                     reinterpret_cast<float4*>(out), n / 4);
+  ASIS_CHECK_LAUNCH("asis_add_f32");
+  return ASIS_OK;
+}

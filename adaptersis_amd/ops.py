@@ -192,3 +192,262 @@ def add_cls_pos(x: torch.Tensor, cls: torch.Tensor, pos: torch.Tensor) -> torch.
     check(lib().asis_add_cls_pos(_stream(), _f32c(x).data_ptr(), _f32c(cls).data_ptr(), _f32c(pos).data_ptr(),
                                  out.data_ptr(), B, N, D), "asis_add_cls_pos")
     return out
+
+
+# --------------------------------------------------------------------------------------------
+# adapters
+# --------------------------------------------------------------------------------------------
+def msda_fwd(value: torch.Tensor, offaw: torch.Tensor, ref: torch.Tensor, shapes_i32: torch.Tensor,
+             starts_i32: torch.Tensor, B: int, Lq: int, M: int, L: int, P: int) -> torch.Tensor:
+    """value 16-bit [B, Lin, D]; offaw fp32 [B*Lq, >= M*L*P*3]; ref fp32 [Lq, 2] -> out 16-bit [B*Lq, D]."""
+    _dev(value, offaw, ref, shapes_i32, starts_i32)
+    Lin, D = value.shape[1], value.shape[2]
+    if not value.is_contiguous() or offaw.stride(1) != 1:
+        raise ValueError("msda_fwd: value must be contiguous and offaw contiguous in its last dim")
+    out = torch.empty((B * Lq, D), device=value.device, dtype=value.dtype)
+    check(lib().asis_msda_fwd(_stream(), _dt(value.dtype), value.data_ptr(), offaw.data_ptr(), offaw.stride(0),
+                              _f32c(ref).data_ptr(), shapes_i32.data_ptr(), starts_i32.data_ptr(), out.data_ptr(), B, Lq,
+                              Lin, M, L, P, D // M), "asis_msda_fwd")
+    return out
+
+
+def dwconv_gelu(x: torch.Tensor, w9: torch.Tensor, bias: torch.Tensor, shapes_i32: torch.Tensor,
+                starts_i32: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """x fp32 [B, Ntok, C] -> gelu(dwconv3x3(x)) 16-bit [B, Ntok, C] over the L token grids."""
+    _dev(x, w9, bias, shapes_i32, starts_i32)
+    B, Ntok, Cc = x.shape
+    out = torch.empty((B, Ntok, Cc), device=x.device, dtype=dtype)
+    check(lib().asis_dwconv_gelu(_stream(), _dt(dtype), _f32c(x).data_ptr(), _f32c(w9).data_ptr(), _f32c(bias).data_ptr(),
+                                 shapes_i32.data_ptr(), starts_i32.data_ptr(), shapes_i32.shape[0], out.data_ptr(), B,
+                                 Ntok, Cc), "asis_dwconv_gelu")
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# CNN encoder / decoder companions
+# --------------------------------------------------------------------------------------------
+def conv3x3_c3(img: torch.Tensor, w: torch.Tensor, stride: int, pad: int) -> torch.Tensor:
+    _dev(img, w)
+    B, _, H, W = img.shape
+    Cout = w.shape[0]
+    OH, OW = (H + 2 * pad - 3) // stride + 1, (W + 2 * pad - 3) // stride + 1
+    out = torch.empty((B, OH, OW, Cout), device=img.device, dtype=torch.float32)
+    check(lib().asis_conv3x3_c3(_stream(), _f32c(img).data_ptr(), _f32c(w).data_ptr(), out.data_ptr(), B, H, W, Cout,
+                                stride, pad), "asis_conv3x3_c3")
+    return out
+
+
+def colstats(x: torch.Tensor) -> torch.Tensor:
+    """fp32 [..., C] -> partial [nparts, 2, C] column sums / sums of squares."""
+    _dev(x)
+    Cc = x.shape[-1]
+    R = x.numel() // Cc
+    nparts = lib().asis_colstats_nparts(R)
+    partial = torch.empty((nparts, 2, Cc), device=x.device, dtype=torch.float32)
+    check(lib().asis_colstats(_stream(), _f32c(x).data_ptr(), R, Cc, partial.data_ptr()), "asis_colstats")
+    return partial
+
+
+def reduce_partials(partial: torch.Tensor) -> torch.Tensor:
+    """partial fp32 [nparts, 2, C] -> sums float64 [2, C]."""
+    _dev(partial)
+    nparts, _, Cc = partial.shape
+    sums = torch.empty((2, Cc), device=partial.device, dtype=torch.float64)
+    check(lib().asis_reduce_partials(_stream(), _f32c(partial).data_ptr(), nparts, Cc, sums.data_ptr()),
+          "asis_reduce_partials")
+    return sums
+
+
+def bn_finalize(sums: torch.Tensor, count: float, gamma, beta, eps: float, momentum: float, running_mean=None,
+                running_var=None, num_batches_tracked=None):
+    """-> (scale, shift, mean, invstd) fp32 [C]; updates the running buffers in place when given."""
+    _dev(sums, gamma, beta, running_mean, running_var, num_batches_tracked)
+    Cc = sums.shape[1]
+    out = torch.empty((4, Cc), device=sums.device, dtype=torch.float32)
+    check(lib().asis_bn_finalize(_stream(), sums.data_ptr(), float(count), Cc, _p(_f32c(gamma)), _p(_f32c(beta)),
+                                 float(eps), float(momentum), _p(running_mean), _p(running_var), _p(num_batches_tracked),
+                                 out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr()),
+          "asis_bn_finalize")
+    return out[0], out[1], out[2], out[3]
+
+
+def bn_act(x: torch.Tensor, scale, shift, relu: bool, dtype: torch.dtype) -> torch.Tensor:
+    _dev(x, scale, shift)
+    Cc = x.shape[-1]
+    out = torch.empty(x.shape, device=x.device, dtype=dtype)
+    check(lib().asis_bn_act(_stream(), _dt(dtype), _f32c(x).data_ptr(), scale.data_ptr(), shift.data_ptr(), int(relu),
+                            out.data_ptr(), x.numel() // Cc, Cc), "asis_bn_act")
+    return out
+
+
+def bn_relu_maxpool(x: torch.Tensor, scale, shift, dtype: torch.dtype) -> torch.Tensor:
+    _dev(x, scale, shift)
+    B, H, W, Cc = x.shape
+    out = torch.empty((B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, Cc), device=x.device, dtype=dtype)
+    check(lib().asis_bn_relu_maxpool(_stream(), _dt(dtype), _f32c(x).data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                     out.data_ptr(), B, H, W, Cc), "asis_bn_relu_maxpool")
+    return out
+
+
+def bn_relu_upsample(x: torch.Tensor, scale, shift, factor: int, dtype: torch.dtype) -> torch.Tensor:
+    _dev(x, scale, shift)
+    B, H, W, Cc = x.shape
+    out = torch.empty((B, H * factor, W * factor, Cc), device=x.device, dtype=dtype)
+    check(lib().asis_bn_relu_upsample(_stream(), _dt(dtype), _f32c(x).data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                      out.data_ptr(), B, H, W, Cc, factor), "asis_bn_relu_upsample")
+    return out
+
+
+def pack_conv_weight(w: torch.Tensor, mode: int, dtype: torch.dtype) -> torch.Tensor:
+    """fp32 [Cout,Cin,KH,KW] -> mode 0: [Cout, KH*KW*Cin]; mode 1 (dgrad): [Cin, KH*KW*CoP]."""
+    _dev(w)
+    Cout, Cin, KH, KW = w.shape
+    CoP = (Cout + 7) // 8 * 8
+    rows, K = (Cout, KH * KW * Cin) if mode == 0 else (Cin, KH * KW * CoP)
+    ld = (K + 7) // 8 * 8
+    out = torch.empty((rows, ld), device=w.device, dtype=dtype)
+    check(lib().asis_pack_conv_weight(_stream(), _dt(dtype), _f32c(w).data_ptr(), out.data_ptr(), Cout, Cin, KH, KW,
+                                      mode, ld), "asis_pack_conv_weight")
+    return out[:, :K] if ld != K else out
+
+
+def decoder_input(xs: torch.Tensor, c4: torch.Tensor, vit: torch.Tensor, hw, c4_hw, dtype: torch.dtype) -> torch.Tensor:
+    """train.py:389-406: xs, vit fp32 [B, h*w, D]; c4 fp32 [B, h4*w4, D] (batch stride free) -> [B,h,w,3D]."""
+    _dev(xs, c4, vit)
+    B, _, D = xs.shape
+    h, w = hw
+    h4, w4 = c4_hw
+    if c4.stride(2) != 1 or c4.stride(1) != D:
+        raise ValueError("decoder_input: c4 rows must be contiguous")
+    out = torch.empty((B, h, w, 3 * D), device=xs.device, dtype=dtype)
+    check(lib().asis_decoder_input(_stream(), _dt(dtype), _f32c(xs).data_ptr(), c4.data_ptr(), c4.stride(0),
+                                   _f32c(vit).data_ptr(), out.data_ptr(), B, h, w, h4, w4, D), "asis_decoder_input")
+    return out
+
+
+def add_f32(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _dev(a, b, out)
+    if out is None:
+        out = torch.empty_like(a)
+    check(lib().asis_add_f32(_stream(), _f32c(a).data_ptr(), _f32c(b).data_ptr(), out.data_ptr(), a.numel()),
+          "asis_add_f32")
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# loss
+# --------------------------------------------------------------------------------------------
+def dice_fwd(logits: torch.Tensor, target: torch.Tensor, n_softmax: int, eps: float = 1e-19, grad_scale: float = 1.0):
+    """logits fp32 NHWC [B,h,w,C]; target int64 [B,H,W] -> (loss [1], coef [B,C,2], sums [B,C,3])."""
+    _dev(logits, target)
+    B, h, w, Cc = logits.shape
+    H, W = target.shape[-2:]
+    if target.dtype != torch.int64 or not target.is_contiguous():
+        raise ValueError("dice_fwd: target must be contiguous int64 [B,H,W]")
+    nblk = lib().asis_dice_nblk(H, W)
+    partial = torch.empty((B, nblk, Cc * 3), device=logits.device, dtype=torch.float32)
+    sums = torch.empty((B, Cc, 3), device=logits.device, dtype=torch.float32)
+    loss = torch.empty((1,), device=logits.device, dtype=torch.float32)
+    coef = torch.empty((B, Cc, 2), device=logits.device, dtype=torch.float32)
+    check(lib().asis_dice_fwd(_stream(), _f32c(logits).data_ptr(), target.data_ptr(), B, h, w, H, W, Cc, n_softmax,
+                              float(eps), float(grad_scale), partial.data_ptr(), sums.data_ptr(), loss.data_ptr(),
+                              coef.data_ptr()), "asis_dice_fwd")
+    return loss, coef, sums
+
+
+def dice_bwd(logits: torch.Tensor, target: torch.Tensor, coef: torch.Tensor, n_softmax: int) -> torch.Tensor:
+    _dev(logits, target, coef)
+    B, h, w, Cc = logits.shape
+    H, W = target.shape[-2:]
+    dz = torch.empty((B, H, W, Cc), device=logits.device, dtype=torch.float32)
+    check(lib().asis_dice_bwd(_stream(), _f32c(logits).data_ptr(), target.data_ptr(), coef.data_ptr(), B, h, w, H, W, Cc,
+                              n_softmax, dz.data_ptr()), "asis_dice_bwd")
+    return dz
+
+
+def resize_bilinear_bwd(dz: torch.Tensor, h: int, w: int, dtype: torch.dtype):
+    """dz fp32 [B,H,W,C] -> (d 16-bit [B,h,w,CP], partial [nblk, C])."""
+    _dev(dz)
+    B, H, W, Cc = dz.shape
+    CP = (Cc + 7) // 8 * 8
+    nblk = lib().asis_resize_bwd_nblk(B * h * w)
+    out = torch.empty((B, h, w, CP), device=dz.device, dtype=dtype)
+    partial = torch.empty((nblk, Cc), device=dz.device, dtype=torch.float32)
+    check(lib().asis_resize_bilinear_bwd(_stream(), _dt(dtype), _f32c(dz).data_ptr(), B, H, W, h, w, Cc, CP,
+                                         out.data_ptr(), partial.data_ptr()), "asis_resize_bilinear_bwd")
+    return out, partial
+
+
+def reduce_rows(partial: torch.Tensor, scale: float = 1.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """partial fp32 [n, K] -> out fp32 [K] = scale * column sums (double accumulate, fixed order)."""
+    _dev(partial, out)
+    n, K = partial.shape[0], partial.numel() // partial.shape[0]
+    if out is None:
+        out = torch.empty((K,), device=partial.device, dtype=torch.float32)
+    check(lib().asis_reduce_rows(_stream(), _f32c(partial).data_ptr(), n, K, float(scale), out.data_ptr()),
+          "asis_reduce_rows")
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# backward / optimizer
+# --------------------------------------------------------------------------------------------
+def upsample_bn_relu_bwd(dU: torch.Tensor, x: torch.Tensor, scale, shift, mean, invstd, factor: int):
+    """-> (g fp32 [B,H,W,C], partial [nblk, 2, C])."""
+    _dev(dU, x)
+    B, H, W, Cc = x.shape
+    nblk = lib().asis_ew_blocks(B * H * W * (Cc // 4))
+    g = torch.empty_like(x)
+    partial = torch.empty((nblk, 2, Cc), device=x.device, dtype=torch.float32)
+    check(lib().asis_upsample_bn_relu_bwd(_stream(), _f32c(dU).data_ptr(), _f32c(x).data_ptr(), scale.data_ptr(),
+                                          shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(), g.data_ptr(),
+                                          partial.data_ptr(), B, H, W, Cc, factor), "asis_upsample_bn_relu_bwd")
+    return g, partial
+
+
+def bn_bwd_apply(g: torch.Tensor, x: torch.Tensor, mean, invstd, gamma, dgamma, dbeta, count: float,
+                 dtype: torch.dtype):
+    """-> (dx 16-bit same shape as x, partial [nblk, C] column sums of dx)."""
+    _dev(g, x)
+    Cc = x.shape[-1]
+    R = x.numel() // Cc
+    nblk = lib().asis_ew_blocks(R * (Cc // 4))
+    out = torch.empty(x.shape, device=x.device, dtype=dtype)
+    partial = torch.empty((nblk, Cc), device=x.device, dtype=torch.float32)
+    check(lib().asis_bn_bwd_apply(_stream(), _dt(dtype), _f32c(g).data_ptr(), _f32c(x).data_ptr(), mean.data_ptr(),
+                                  invstd.data_ptr(), _f32c(gamma).data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+                                  float(count), out.data_ptr(), partial.data_ptr(), R, Cc), "asis_bn_bwd_apply")
+    return out, partial
+
+
+def wgrad(dy: torch.Tensor, x_nhwc: torch.Tensor, Cout: int, KH: int, KW: int, stride: int, pad: int,
+          inv_scale: float = 1.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dy 16-bit [B,OH,OW,CoP]; x 16-bit [B,H,W,Cin] -> dW fp32 [Cout,Cin,KH,KW] (scaled by inv_scale)."""
+    _dev(dy, x_nhwc, out)
+    if not dy.is_contiguous() or not x_nhwc.is_contiguous():
+        raise ValueError("wgrad: dy and x must be contiguous NHWC")
+    Bn, H, W, Cin = x_nhwc.shape
+    _, OH, OW, CoP = dy.shape
+    P = Bn * OH * OW
+    Ntot = KH * KW * Cin
+    splits = lib().asis_wgrad_splits(P, Cout, Ntot)
+    slabs = torch.empty((splits, Cout * Ntot), device=dy.device, dtype=torch.float32)
+    d = _lib.WgradDesc()
+    d.dy, d.x, d.out = dy.data_ptr(), x_nhwc.data_ptr(), slabs.data_ptr()
+    d.ld_dy, d.P, d.dtype = CoP, P, _dt(dy.dtype)
+    d.Cout, d.CoP, d.Cin = Cout, CoP, Cin
+    d.B_, d.H, d.W, d.OH, d.OW, d.KH, d.KW, d.stride, d.pad = Bn, H, W, OH, OW, KH, KW, stride, pad
+    d.splits = splits
+    check(lib().asis_wgrad(_stream(), C.byref(d)), "asis_wgrad")
+    if out is None:
+        out = torch.empty((Cout, Cin, KH, KW), device=dy.device, dtype=torch.float32)
+    reduce_rows(slabs, inv_scale, out.view(-1))
+    return out
+
+
+def sgd_momentum(p: torch.Tensor, g: torch.Tensor, buf: torch.Tensor, lr: float, momentum: float, weight_decay: float,
+                 inv_scale: float, first_step: bool) -> None:
+    _dev(p, g, buf)
+    check(lib().asis_sgd_momentum(_stream(), _f32c(p).data_ptr(), _f32c(g).data_ptr(), _f32c(buf).data_ptr(), p.numel(),
+                                  float(lr), float(momentum), float(weight_decay), float(inv_scale), int(first_step)),
+          "asis_sgd_momentum")

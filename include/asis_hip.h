@@ -129,6 +129,126 @@ int asis_cast_pad(void* stream, int dtype, const float* src, int64_t ld_src, voi
 int asis_add_cls_pos(void* stream, const float* x, const float* cls, const float* pos, float* out, int B, int N,
                      int D);
 
+/* ---------------------------------------------------------------------------------------------
+ * Multi-scale deformable attention core (backbones/ops/modules/ms_deform_attn.py:33-54 and the
+ * location / softmax arithmetic of MSDeformAttn.forward :155-166), forward.
+ * value: 16-bit [B, Lin, M*Dh] (output of value_proj; head m at columns m*Dh..)
+ * offaw: fp32 [B*Lq, ld_offaw]: columns [0, M*L*P*2) = sampling_offsets(query) in the reference's
+ *        (m, l, p, xy) order, columns [M*L*P*2, M*L*P*3) = attention_weights(query) logits (m, l, p)
+ * ref:   fp32 [Lq, 2] reference points (x, y) in [0,1] (one reference level, broadcast over L:
+ *        adapter_blocks.py:9-22);  shapes int32 [L,2] = (H_l, W_l);  starts int32 [L]
+ * out:   16-bit [B*Lq, M*Dh]  (input of output_proj).   Dh % 8 == 0, L*P <= 16.
+ * ------------------------------------------------------------------------------------------- */
+int asis_msda_fwd(void* stream, int dtype, const void* value, const float* offaw, int64_t ld_offaw, const float* ref,
+                  const int32_t* shapes, const int32_t* starts, void* out, int B, int Lq, int Lin, int M, int L, int P,
+                  int Dh);
+
+/* DWConv 3x3 depthwise (pad 1, bias) over the token grids of each pyramid level + erf GELU
+ * (backbones/adapter_blocks.py:67-80,95-97).  x fp32 [B, Ntok, C]; w9 fp32 [9][C]
+ * (w9[kh*3+kw][c] = weight[c,0,kh,kw]); shapes/starts describe the L grids; out 16-bit. */
+int asis_dwconv_gelu(void* stream, int dtype, const float* x, const float* w9, const float* bias,
+                     const int32_t* shapes, const int32_t* starts, int L, void* out, int B, int Ntok, int C);
+
+/* ---------------------------------------------------------------------------------------------
+ * CNN encoder / decoder companions (backbones/encoders.py:9-47, backbones/decoders.py:109-135).
+ * BatchNorm is in TRAIN mode everywhere on this path (batch statistics):
+ *   conv (asis_gemm conv=1, fp32 out, per-tile stats) -> asis_reduce_partials -> [all-reduce of
+ *   the 2C sums across ranks = SyncBatchNorm] -> asis_bn_finalize -> fused apply kernel.
+ * ------------------------------------------------------------------------------------------- */
+/* stem conv, Cin = 3: img fp32 NCHW [B,3,H,W], w fp32 [Cout,3,3,3] -> out fp32 NHWC [B,OH,OW,Cout] */
+int asis_conv3x3_c3(void* stream, const float* img, const float* w, float* out, int B, int H, int W, int Cout,
+                    int stride, int pad);
+/* column sums / sums of squares of fp32 [R, C] -> partial[nparts][2][C], nparts = asis_colstats_nparts(R) */
+int asis_colstats_nparts(int64_t R);
+int asis_colstats(void* stream, const float* x, int64_t R, int C, float* partial);
+/* partial[nparts][2][C] (fp32) -> sums[2][C] (double) */
+int asis_reduce_partials(void* stream, const float* partial, int nparts, int C, double* sums);
+/* scale = gamma*invstd, shift = beta - mean*scale; optional running-stat update (momentum, unbiased var)
+ * and num_batches_tracked += 1 (nn.BatchNorm2d / SyncBatchNorm train-mode semantics). */
+int asis_bn_finalize(void* stream, const double* sums, double count, int C, const float* gamma, const float* beta,
+                     float eps, float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                     float* scale, float* shift, float* mean_out, float* invstd_out);
+/* out(16-bit) = [relu](x*scale + shift), x fp32 [R, C] */
+int asis_bn_act(void* stream, int dtype, const float* x, const float* scale, const float* shift, int relu, void* out,
+                int64_t R, int C);
+/* BN + ReLU + MaxPool2d(3, stride 2, pad 1): x fp32 NHWC [B,H,W,C] -> 16-bit [B,OH,OW,C] (encoders.py:19) */
+int asis_bn_relu_maxpool(void* stream, int dtype, const float* x, const float* scale, const float* shift, void* out,
+                         int B, int H, int W, int C);
+/* BN + ReLU + bilinear upsample xfactor, align_corners=True (decoders.py:112-113; MLAHead :38-45 with factor 4) */
+int asis_bn_relu_upsample(void* stream, int dtype, const float* x, const float* scale, const float* shift, void* out,
+                          int B, int H, int W, int C, int factor);
+/* conv weight fp32 [Cout,Cin,KH,KW] -> 16-bit GEMM operand.
+ * mode 0 (forward): out[co][(kh*KW+kw)*Cin+ci], rows Cout.
+ * mode 1 (dgrad):   out[ci][((KH-1-kh)*KW+(KW-1-kw))*CoP+co], rows Cin, CoP = Cout rounded up to 8. */
+int asis_pack_conv_weight(void* stream, int dtype, const float* w, void* out, int Cout, int Cin, int KH, int KW,
+                          int mode, int64_t ldo);
+/* decoder input (train.py:389-406): [xs | zero-padded c4 | vit] fp32 tokens -> 16-bit NHWC [B,h,w,3D] */
+int asis_decoder_input(void* stream, int dtype, const float* xs, const float* c4, int64_t c4_bstride, const float* vit,
+                       void* out, int B, int h, int w, int h4, int w4, int D);
+/* out = a + b (fp32; train.py:320,343,365,387 residual adds with the pass-A features) */
+int asis_add_f32(void* stream, const float* a, const float* b, float* out, int64_t n);
+
+/* ---------------------------------------------------------------------------------------------
+ * Loss (train.py:422-428 + segloss/dice.py:22-33), fused with the bilinear resize (h,w)->(H,W):
+ *   n_softmax = 2 : training (softmax at train.py:424 then again inside DC)
+ *   n_softmax = 1 : validation dice = 1 - DC(logits) (train.py:618)
+ * logits fp32 NHWC [B,h,w,C]; target int64 [B,H,W]; partial: asis_dice_nblk(H,W)*B*C*3 floats;
+ * sums (optional) [B,C,3] = sum p t, sum p, sum t; loss 1 float; coef [B,C,2] feeds asis_dice_bwd
+ * (already multiplied by grad_scale = the static loss scale).
+ * ------------------------------------------------------------------------------------------- */
+int asis_dice_nblk(int H, int W);
+int asis_dice_fwd(void* stream, const float* logits, const int64_t* target, int B, int h, int w, int H, int W, int C,
+                  int n_softmax, float eps, float grad_scale, float* partial, float* sums, float* loss, float* coef);
+/* dz fp32 [B,H,W,C] = d loss / d resized-logits */
+int asis_dice_bwd(void* stream, const float* logits, const int64_t* target, const float* coef, int B, int h, int w,
+                  int H, int W, int C, int n_softmax, float* dz);
+/* transpose of F.interpolate(bilinear, align_corners=False): dz [B,H,W,C] -> 16-bit [B,h,w,CP] (CP = C
+ * rounded up to 8, pad channels zero) + partial[asis_resize_bwd_nblk(B*h*w)][C] column sums */
+int asis_resize_bwd_nblk(int64_t total_pixels);
+int asis_resize_bilinear_bwd(void* stream, int dtype, const float* dz, int B, int H, int W, int h, int w, int C, int CP,
+                             void* out, float* partial);
+/* out[k] = scale * sum_n partial[n][k], summed in double in a fixed order */
+int asis_reduce_rows(void* stream, const float* partial, int n, int K, float scale, float* out);
+
+/* ---------------------------------------------------------------------------------------------
+ * Backward of conv -> BN(train) -> ReLU -> upsample stages, weight gradients, optimizer.
+ * ------------------------------------------------------------------------------------------- */
+/* grid size the element-wise backward kernels use for `total_chunks` float4 chunks (partials rows) */
+int asis_ew_blocks(int64_t total_chunks);
+/* g = relu'(bn(x)) * upsample^T(dU); partial[asis_ew_blocks(B*H*W*C/4)][2][C] = sum g, sum g*xhat */
+int asis_upsample_bn_relu_bwd(void* stream, const float* dU, const float* x, const float* scale, const float* shift,
+                              const float* mean, const float* invstd, float* g, float* partial, int B, int H, int W,
+                              int C, int factor);
+/* dx(16-bit) = gamma*invstd*(g - dbeta/n - xhat*dgamma/n); partial[asis_ew_blocks(R*C/4)][C] = sum dx */
+int asis_bn_bwd_apply(void* stream, int dtype, const float* g, const float* x, const float* mean, const float* invstd,
+                      const float* gamma, const float* dgamma, const float* dbeta, double count, void* out,
+                      float* partial, int64_t R, int C);
+
+/* Weight gradient dW[Cout,Cin,KH,KW] = sum_p dy[p,co] * x[b, oh*s+kh-pad, ow*s+kw-pad, ci]
+ * (conv2d; KH=KW=1 gives the nn.Linear weight grad).  dy 16-bit [P, ld_dy] with CoP (multiple of 8)
+ * valid-or-zero channels; x 16-bit NHWC [B,H,W,Cin].  out: `splits` fp32 slabs of Cout*Cin*KH*KW,
+ * to be summed with asis_reduce_rows(out, splits, Cout*Cin*KH*KW, 1/loss_scale, grad). */
+typedef struct asis_wgrad_desc {
+  const void* dy;
+  const void* x;
+  float* out;
+  int64_t ld_dy;
+  int64_t P;
+  int32_t dtype;
+  int32_t Cout, CoP, Cin;
+  int32_t B_, H, W, OH, OW, KH, KW, stride, pad;
+  int32_t splits;
+  int64_t k_per_split; /* filled by asis_wgrad */
+} asis_wgrad_desc;
+int asis_wgrad_splits(int64_t P, int Cout, int Ntot);
+int asis_wgrad(void* stream, const asis_wgrad_desc* d);
+
+/* torch.optim.SGD step (train.py:178-191: momentum, weight decay, dampening 0, no Nesterov) on a flat
+ * fp32 parameter buffer; g is multiplied by inv_scale (1/loss_scale) first. */
+int asis_sgd_momentum(void* stream, float* p, const float* g, float* buf, int64_t n, float lr, float momentum,
+                      float weight_decay, float inv_scale, int first_step);
+int asis_scale_f32(void* stream, float* x, int64_t n, float a);
+
 #ifdef __cplusplus
 }
 #endif

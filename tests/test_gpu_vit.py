@@ -29,7 +29,7 @@ def test_block_vs_oracle(dev):
     x = W.tensor("blk.x", (2, 257, 128), 1.0)
     ref = O.block(x, sd, "blocks.0", 2)
     y = m.blocks[0](x.to(dev))
-    assert rel_l2(y, ref) < TOL / 4
+    assert rel_l2(y, ref) < TOL / 2
 
 
 def test_patch_embed_vs_oracle(dev):
@@ -37,7 +37,7 @@ def test_patch_embed_vs_oracle(dev):
     img, _ = W.synthetic_batch(2, 224)
     ref = O.patch_embed(img, sd)
     y = m.patch_embed(img.to(dev))
-    assert rel_l2(y, ref) < TOL / 4
+    assert rel_l2(y, ref) < TOL / 2
     with pytest.raises(AssertionError):
         m.patch_embed(torch.zeros(1, 3, 225, 224, device=dev))
 
