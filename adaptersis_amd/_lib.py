@@ -74,7 +74,7 @@ SIGNATURES = {
     "asis_layernorm": [_vp, _i, _vp, _i64, _vp, _vp, _f, _vp, _i64, _i, _i64, _i],
     "asis_attention_fwd": [_vp, _i, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _i, _f],
     "asis_im2col_patch": [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i64],
-    "asis_cast_pad": [_vp, _i, _vp, _i64, _vp, _i64, _i64, _i],
+    "asis_cast_pad": [_vp, _i, _vp, _i64, _vp, _i64, _i64, _i, _f],
     "asis_add_cls_pos": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i],
     "asis_msda_fwd": [_vp, _i, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i],
     "asis_dwconv_gelu": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i],

@@ -1,0 +1,163 @@
+"""HIP-backed decode heads — API / ``state_dict`` mirror of `backbones/decoders.py`.
+
+``FeatureDecoder`` (`decoders.py:92-164`, the head `train.py` trains):
+    4 x [conv3x3(+bias) -> BatchNorm2d (TRAIN mode) -> ReLU -> bilinear x2 align_corners=True] -> conv3x3
+
+Forward per stage: implicit-GEMM MFMA conv on NHWC 16-bit input, fp32 output with BatchNorm
+statistics from the GEMM epilogue, then one fused BN+ReLU+upsample kernel that writes the next
+conv's 16-bit operand.  Backward per stage (the only gradients the reference step produces,
+SURVEY.md fact 1): upsample^T + ReLU mask + BN partial sums, BN backward apply, conv dgrad
+(implicit GEMM with flipped weights) and conv wgrad (transposed-read split-K GEMM).
+
+The same functional core serves two front-ends:
+  * ``forward(x)`` — reference-shaped ``nn.Module`` call on an NCHW fp32 tensor, differentiable
+    through a ``torch.autograd.Function`` whose backward runs the HIP backward;
+  * ``SegEngine`` — the fused training step, which feeds NHWC 16-bit input and writes gradients
+    straight into the flat gradient bucket.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from .. import config, ops
+from ..dinov2.layers.blocks import _Packed, _pack
+from . import _bn
+
+
+class _Stage:
+    """Saved tensors of one conv -> BN -> ReLU -> upsample stage."""
+    __slots__ = ("x16", "raw", "scale", "shift", "mean", "invstd", "count", "factor")
+
+
+def conv_bn_relu_up_forward(owner: _Packed, key: str, x16, conv: nn.Conv2d, bn: nn.BatchNorm2d, factor: int,
+                            sync_bn: bool, save: bool):
+    dt = config.operand_dtype
+    B, H, W, _ = x16.shape
+    w16 = _pack(owner._cache, key + ".w", conv.weight, lambda p: ops.pack_conv_weight(p.float().contiguous(), 0, dt))
+    stats = torch.empty((ops.gemm_tiles_m(B * H * W), 2, conv.out_channels), device=x16.device, dtype=torch.float32)
+    raw = ops.conv_gemm(x16, w16, 3, 3, 1, 1, bias_n=owner._f32(key + ".b", conv.bias), stats=stats)
+    scale, shift, mean, invstd, count = _bn.finalize(stats, B * H * W, bn, sync_bn)
+    up = ops.bn_relu_upsample(raw, scale, shift, factor, dt) if factor > 1 else ops.bn_act(raw, scale, shift, True, dt)
+    st = None
+    if save:
+        st = _Stage()
+        st.x16, st.raw, st.scale, st.shift, st.mean, st.invstd, st.count, st.factor = \
+            x16, raw, scale, shift, mean, invstd, count, factor
+    return up, st
+
+
+def conv_bn_relu_up_backward(owner: _Packed, key: str, st: _Stage, dU, conv: nn.Conv2d, bn: nn.BatchNorm2d,
+                             inv_scale: float, grads: Dict[str, torch.Tensor], prefix: str, need_dx: bool,
+                             sync_bn: bool):
+    """dU fp32 [B, fH, fW, C] (scaled by the loss scale) -> grads[...] (unscaled) and dX fp32 or None."""
+    import torch.distributed as dist
+    dt = config.operand_dtype
+    C = conv.out_channels
+    g, partial = ops.upsample_bn_relu_bwd(dU, st.raw, st.scale, st.shift, st.mean, st.invstd, st.factor)
+    red = ops.reduce_rows(partial.view(partial.shape[0], 2 * C))  # [2C]: sum g | sum g*xhat (scaled)
+    if sync_bn and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(red)  # SyncBatchNorm backward: 2C floats
+    dbeta_s, dgamma_s = red[:C], red[C:]
+    dx16, bpart = ops.bn_bwd_apply(g, st.raw, st.mean, st.invstd, owner._f32(key + ".g", bn.weight), dgamma_s, dbeta_s,
+                                   st.count, dt)
+    ops.reduce_rows(dbeta_s.view(1, C), inv_scale, grads[prefix + ".1.bias"])      # unscale (n = 1 row)
+    ops.reduce_rows(dgamma_s.view(1, C), inv_scale, grads[prefix + ".1.weight"])
+    if conv.bias is not None:
+        ops.reduce_rows(bpart, inv_scale, grads[prefix + ".0.bias"])
+    ops.wgrad(dx16, st.x16, C, 3, 3, 1, 1, inv_scale, out=grads[prefix + ".0.weight"])
+    if not need_dx:
+        return None
+    wdg = _pack(owner._cache, key + ".wd", conv.weight, lambda p: ops.pack_conv_weight(p.float().contiguous(), 1, dt))
+    return ops.conv_gemm(dx16, wdg, 3, 3, 1, 1)
+
+
+class _DecoderFn(torch.autograd.Function):
+    """autograd bridge: forward/backward are the HIP pipelines of the owning module."""
+
+    @staticmethod
+    def forward(ctx, module, x, *params):
+        logits, saved = module._forward_core(module._to_nhwc16(x), save=True)
+        ctx.module, ctx.saved = module, saved
+        ctx.names = [n for n, _ in module.named_parameters()]
+        return logits.permute(0, 3, 1, 2)  # NCHW view of the NHWC buffer
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        m = ctx.module
+        dt = config.operand_dtype
+        S = config.loss_scale
+        B, C, h, w = dlogits.shape
+        d = dlogits.permute(0, 2, 3, 1).contiguous().float().view(B * h * w, C)
+        CP = (C + 7) // 8 * 8
+        d16 = ops.cast_pad(d, CP, dt, scale=S).view(B, h, w, CP)
+        grads = {n: torch.empty_like(p) for n, p in m.named_parameters()}
+        m._backward_core(ctx.saved, d16, None, 1.0 / S, grads, dlogits_f32=d)
+        ctx.saved = None
+        return (None, None) + tuple(grads[n] for n in ctx.names)
+
+
+class FeatureDecoder(_Packed):
+    def __init__(self, img_size=588, inplanes=64, embed_dim=1024, num_classes=2, features=[1024, 512, 256, 128, 64]):
+        super().__init__()
+        self.img_size, self.features, self.inplanes = img_size, list(features), inplanes
+        self.embed_dim, self.num_classes = embed_dim, num_classes
+        chans = [features[0] * 3, features[1], features[2], features[3], features[4]]
+        for c in chans:
+            if c % 8:
+                raise ValueError("FeatureDecoder channel counts must be multiples of 8")
+        for i in range(4):
+            setattr(self, f"decoder_{i + 1}", nn.Sequential(
+                nn.Conv2d(chans[i], chans[i + 1], 3, padding=1), nn.BatchNorm2d(chans[i + 1]), nn.ReLU(inplace=True),
+                nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True)))
+        self.final_out = nn.Conv2d(chans[4], num_classes, 3, padding=1)
+        self.sync_bn = False  # plain nn.BatchNorm2d in the reference decoder (per-GPU statistics)
+
+    # ---- functional core ---------------------------------------------------------------------------
+    def _to_nhwc16(self, x):
+        """NCHW fp32 (reference call convention) -> NHWC 16-bit operand."""
+        B, C, H, W = x.shape
+        x2 = x.detach().permute(0, 2, 3, 1).contiguous().float().view(B * H * W, C)
+        return ops.cast_pad(x2, C, config.operand_dtype).view(B, H, W, C)
+
+    def _forward_core(self, x16, save: bool):
+        dt = config.operand_dtype
+        saved: List = []
+        a = x16
+        for i in range(1, 5):
+            seq = getattr(self, f"decoder_{i}")
+            a, st = conv_bn_relu_up_forward(self, f"d{i}", a, seq[0], seq[1], 2, self.sync_bn, save)
+            saved.append(st)
+        wf = _pack(self._cache, "final.w", self.final_out.weight,
+                   lambda p: ops.pack_conv_weight(p.float().contiguous(), 0, dt))
+        logits = ops.conv_gemm(a, wf, 3, 3, 1, 1, bias_n=self._f32("final.b", self.final_out.bias))
+        saved.append(a if save else None)
+        return logits, saved
+
+    def _backward_core(self, saved, d16, bias_partial, inv_scale, grads, dlogits_f32=None):
+        """d16: 16-bit [B,h,w,CP] = loss_scale * dL/dlogits (pad channels zero)."""
+        dt = config.operand_dtype
+        C = self.num_classes
+        x5 = saved[4]
+        if bias_partial is not None:
+            ops.reduce_rows(bias_partial, inv_scale, grads["final_out.bias"])
+        else:  # compatibility path: column sums of the fp32 dlogits [P, C]
+            ops.reduce_rows(dlogits_f32, 1.0, grads["final_out.bias"])
+        ops.wgrad(d16, x5, C, 3, 3, 1, 1, inv_scale, out=grads["final_out.weight"])
+        wdg = _pack(self._cache, "final.wd", self.final_out.weight,
+                    lambda p: ops.pack_conv_weight(p.float().contiguous(), 1, dt))
+        dU = ops.conv_gemm(d16, wdg, 3, 3, 1, 1)
+        for i in range(4, 0, -1):
+            seq = getattr(self, f"decoder_{i}")
+            dU = conv_bn_relu_up_backward(self, f"d{i}", saved[i - 1], dU, seq[0], seq[1], inv_scale, grads,
+                                          f"decoder_{i}", need_dx=(i > 1), sync_bn=self.sync_bn)
+
+    # ---- reference-shaped entry point ----------------------------------------------------------------
+    def forward(self, x):
+        """`decoders.py:137-164`: (B, 3*embed, h, w) fp32 -> logits (B, classes, 16h, 16w) fp32."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return _DecoderFn.apply(self, x, *list(self.parameters()))
+        logits, _ = self._forward_core(self._to_nhwc16(x), save=False)
+        return logits.permute(0, 3, 1, 2)

@@ -1,0 +1,109 @@
+"""HIP-backed ``FeatureEncoder`` (spatial-prior CNN) — API / ``state_dict`` mirror of
+`backbones/encoders.py:4-74`.
+
+torch ``nn.Conv2d`` / ``nn.BatchNorm2d`` modules are kept only as parameter containers (same
+``state_dict`` keys as the reference, incl. ``running_mean/var/num_batches_tracked``); the forward
+is: stem conv (Cin=3) direct kernel, every other 3x3 conv an implicit-GEMM MFMA kernel on NHWC
+16-bit activations with BatchNorm statistics taken from its epilogue, BN(+ReLU)(+MaxPool) fused
+apply kernels, and the 1x1 ``fc*`` projections as GEMMs that write straight into the
+``[B, 5329+1296+324, D]`` token buffer the adapters consume (`train.py:283` concat is free).
+
+BatchNorm runs in TRAIN mode (batch statistics, running-stat update) exactly like the reference,
+which never calls ``.eval()`` on the encoder; with an initialised process group the statistics are
+all-reduced (SyncBatchNorm).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .. import config, ops
+from ..dinov2.layers.blocks import _Packed, _pack
+from . import _bn
+
+
+class FeatureEncoder(_Packed):
+    def __init__(self, inplanes=64, embed_dim=1024, with_cp=False):
+        super().__init__()
+        if inplanes % 8:
+            raise ValueError("inplanes must be a multiple of 8")
+        self.with_cp = with_cp
+        self.inplanes, self.embed_dim = inplanes, embed_dim
+        self.compute_c1 = True  # the reference computes c1 although train.py never uses it
+        BN = nn.BatchNorm2d  # same state_dict keys as nn.SyncBatchNorm
+        self.stem = nn.Sequential(
+            nn.Conv2d(3, inplanes, kernel_size=3, stride=2, padding=1, bias=False), BN(inplanes), nn.ReLU(inplace=True),
+            nn.Conv2d(inplanes, inplanes, kernel_size=3, stride=1, padding=1, bias=False), BN(inplanes), nn.ReLU(inplace=True),
+            nn.Conv2d(inplanes, inplanes, kernel_size=3, stride=1, padding=1, bias=False), BN(inplanes), nn.ReLU(inplace=True),
+            nn.MaxPool2d(kernel_size=3, stride=2, padding=1))
+        self.conv2 = nn.Sequential(nn.Conv2d(inplanes, 2 * inplanes, kernel_size=3, stride=2, padding=0, bias=False),
+                                   BN(2 * inplanes), nn.ReLU(inplace=True))
+        self.conv3 = nn.Sequential(nn.Conv2d(2 * inplanes, 4 * inplanes, kernel_size=3, stride=2, padding=0, bias=False),
+                                   BN(4 * inplanes), nn.ReLU(inplace=True))
+        self.conv4 = nn.Sequential(nn.Conv2d(4 * inplanes, 8 * inplanes, kernel_size=3, stride=2, padding=1, bias=False),
+                                   BN(8 * inplanes), nn.ReLU(inplace=True))
+        self.fc1 = nn.Conv2d(inplanes, embed_dim, kernel_size=1, stride=1, padding=0, bias=True)
+        self.fc2 = nn.Conv2d(2 * inplanes, embed_dim, kernel_size=1, stride=1, padding=0, bias=True)
+        self.fc3 = nn.Conv2d(4 * inplanes, embed_dim, kernel_size=1, stride=1, padding=0, bias=True)
+        self.fc4 = nn.Conv2d(8 * inplanes, embed_dim, kernel_size=1, stride=1, padding=0, bias=True)
+
+    # -- helpers ---------------------------------------------------------------------------------
+    def _wconv(self, key, conv):
+        return _pack(self._cache, key, conv.weight, lambda p: ops.pack_conv_weight(p.float().contiguous(), 0,
+                                                                                    config.operand_dtype))
+
+    def _conv_bn(self, x16, key, conv, bn, sync):
+        """x16 NHWC 16-bit -> (raw fp32 NHWC, scale, shift)."""
+        B, H, W, _ = x16.shape
+        s, p = conv.stride[0], conv.padding[0]
+        OH, OW = (H + 2 * p - 3) // s + 1, (W + 2 * p - 3) // s + 1
+        stats = torch.empty((ops.gemm_tiles_m(B * OH * OW), 2, conv.out_channels), device=x16.device, dtype=torch.float32)
+        raw = ops.conv_gemm(x16, self._wconv(key, conv), 3, 3, s, p, stats=stats)
+        scale, shift, _, _, _ = _bn.finalize(stats, B * OH * OW, bn, sync)
+        return raw, scale, shift
+
+    def forward_tokens(self, x, need_c1=False, sync_bn=True):
+        """-> (c1 NHWC fp32 or None, c tokens fp32 [B, n2+n3+n4, D], [(h2,w2),(h3,w3),(h4,w4)])."""
+        dt = config.operand_dtype
+        x = x.float().contiguous()
+        B = x.shape[0]
+        D = self.embed_dim
+        st = self.stem
+        raw = ops.conv3x3_c3(x, self._f32("stem0", st[0].weight), 2, 1)
+        scale, shift, _, _, _ = _bn.finalize(ops.colstats(raw), raw.numel() // raw.shape[-1], st[1], sync_bn)
+        a = ops.bn_act(raw, scale, shift, True, dt)
+        raw, scale, shift = self._conv_bn(a, "stem3", st[3], st[4], sync_bn)
+        a = ops.bn_act(raw, scale, shift, True, dt)
+        raw, scale, shift = self._conv_bn(a, "stem6", st[6], st[7], sync_bn)
+        s1 = ops.bn_relu_maxpool(raw, scale, shift, dt)  # [B,147,147,C]
+        raw, scale, shift = self._conv_bn(s1, "conv2", self.conv2[0], self.conv2[1], sync_bn)
+        s2 = ops.bn_act(raw, scale, shift, True, dt)
+        raw, scale, shift = self._conv_bn(s2, "conv3", self.conv3[0], self.conv3[1], sync_bn)
+        s3 = ops.bn_act(raw, scale, shift, True, dt)
+        raw, scale, shift = self._conv_bn(s3, "conv4", self.conv4[0], self.conv4[1], sync_bn)
+        s4 = ops.bn_act(raw, scale, shift, True, dt)
+        shapes = [tuple(t.shape[1:3]) for t in (s2, s3, s4)]
+        sizes = [h * w for h, w in shapes]
+        ntok = sum(sizes)
+        c = torch.empty((B, ntok, D), device=x.device, dtype=torch.float32)
+        off = 0
+        for i, (s, fc) in enumerate(((s2, self.fc2), (s3, self.fc3), (s4, self.fc4))):
+            n = sizes[i]
+            ops.gemm(s.view(B, n, s.shape[-1]), self._w16(f"fc{i + 2}", fc.weight), out=c[:, off:off + n],
+                     bias_n=self._f32(f"fc{i + 2}_b", fc.bias))
+            off += n
+        c1 = None
+        if need_c1:
+            h1, w1 = s1.shape[1:3]
+            c1 = ops.gemm(s1.view(B * h1 * w1, s1.shape[-1]), self._w16("fc1", self.fc1.weight), out_f32=True,
+                          bias_n=self._f32("fc1_b", self.fc1.bias)).view(B, h1, w1, D)
+        return c1, c, shapes
+
+    def forward(self, x):
+        """`encoders.py:49-74`: returns (c1 map (B,D,H/4,W/4), c2, c3, c4 token tensors)."""
+        c1, c, shapes = self.forward_tokens(x, need_c1=self.compute_c1)
+        n2, n3 = shapes[0][0] * shapes[0][1], shapes[1][0] * shapes[1][1]
+        c2, c3, c4 = c[:, :n2], c[:, n2:n2 + n3], c[:, n2 + n3:]
+        self.last_shapes = shapes
+        self.last_tokens = c  # the concatenated buffer (train.py:283) for callers that want to skip torch.cat
+        return (c1.permute(0, 3, 1, 2) if c1 is not None else None), c2, c3, c4

@@ -1,0 +1,125 @@
+"""HIP-backed ``MSDeformAttn`` — API / ``state_dict`` mirror of
+`backbones/ops/modules/ms_deform_attn.py:63-185`.
+
+value_proj, (sampling_offsets | attention_weights) and output_proj are MFMA GEMMs; the softmax
+over L*P, the sampling-location arithmetic and the bilinear gather are one HIP kernel
+(``asis_msda_fwd``).  Unlike the reference, whose ``MSDeformAttnFunction`` has no backward
+(`ms_deform_attn.py:17-30`), this module is forward-only *by declaration*: gradients for the
+trainable-adapter mode are a later row of SURVEY.md §8.
+"""
+from __future__ import annotations
+
+import math
+import warnings
+
+import torch
+from torch import nn
+from torch.nn.init import constant_, xavier_uniform_
+
+from .... import config, ops
+from ....dinov2.layers.blocks import _Packed
+
+
+def _is_power_of_2(n):
+    if (not isinstance(n, int)) or (n < 0):
+        raise ValueError("invalid input for _is_power_of_2: {} (type: {})".format(n, type(n)))
+    return (n & (n - 1) == 0) and n != 0
+
+
+class MSDeformAttn(_Packed):
+    def __init__(self, d_model=256, n_levels=4, n_heads=8, n_points=4, ratio=1.0):
+        super().__init__()
+        if d_model % n_heads != 0:
+            raise ValueError("d_model must be divisible by n_heads, but got {} and {}".format(d_model, n_heads))
+        if ratio != 1.0:
+            raise ValueError("only ratio=1.0 is used on the AdapterSIS path (train.py:92,107)")
+        _d_per_head = d_model // n_heads
+        if _d_per_head % 8:
+            raise ValueError(f"head dim {_d_per_head} must be a multiple of 8 (16-byte channel chunks)")
+        if n_levels * n_points > 16:
+            raise ValueError("n_levels*n_points must be <= 16")
+        if not _is_power_of_2(_d_per_head):
+            warnings.warn("You'd better set d_model in MSDeformAttn to make the dimension of each attention head a "
+                          "power of 2 which is more efficient in our CUDA implementation.")
+        self.im2col_step = 64
+        self.d_model, self.n_levels, self.n_heads, self.n_points, self.ratio = d_model, n_levels, n_heads, n_points, ratio
+        self.sampling_offsets = nn.Linear(d_model, n_heads * n_levels * n_points * 2)
+        self.attention_weights = nn.Linear(d_model, n_heads * n_levels * n_points)
+        self.value_proj = nn.Linear(d_model, int(d_model * ratio))
+        self.output_proj = nn.Linear(int(d_model * ratio), d_model)
+        self._reset_parameters()
+
+    def _reset_parameters(self):
+        """`ms_deform_attn.py:99-118`."""
+        constant_(self.sampling_offsets.weight.data, 0.0)
+        thetas = torch.arange(self.n_heads, dtype=torch.float32) * (2.0 * math.pi / self.n_heads)
+        grid_init = torch.stack([thetas.cos(), thetas.sin()], -1)
+        grid_init = (grid_init / grid_init.abs().max(-1, keepdim=True)[0]).view(self.n_heads, 1, 1, 2).repeat(
+            1, self.n_levels, self.n_points, 1)
+        for i in range(self.n_points):
+            grid_init[:, :, i, :] *= i + 1
+        with torch.no_grad():
+            self.sampling_offsets.bias = nn.Parameter(grid_init.view(-1))
+        constant_(self.attention_weights.weight.data, 0.0)
+        constant_(self.attention_weights.bias.data, 0.0)
+        xavier_uniform_(self.value_proj.weight.data)
+        constant_(self.value_proj.bias.data, 0.0)
+        xavier_uniform_(self.output_proj.weight.data)
+        constant_(self.output_proj.bias.data, 0.0)
+
+    # ---- fused path used by CAViT / CACNN: 16-bit, already-normalised inputs ------------------
+    def forward16(self, q16, feat16, ref, shapes_i32, starts_i32, B, Lq, Lin, *, res=None, scale_n=None):
+        """q16 [B*Lq, D], feat16 [B*Lin, D] (16-bit) -> fp32 [B*Lq, D] = res + scale_n * output_proj(msda)."""
+        dt = config.operand_dtype
+        M, L, P = self.n_heads, self.n_levels, self.n_points
+
+        srcs = (self.sampling_offsets.weight, self.attention_weights.weight, self.sampling_offsets.bias,
+                self.attention_weights.bias)
+        tag = tuple((t.data_ptr(), t._version) for t in srcs) + (dt,)
+        if self._cache.get("oa_tag") != tag:  # offsets and attention logits come from ONE GEMM: [M*L*P*3, D]
+            with torch.no_grad():
+                w = torch.cat([srcs[0].detach(), srcs[1].detach()], 0).float().contiguous()
+                self._cache["w_oa"] = ops.cast_pad(w, dtype=dt)
+                self._cache["b_oa"] = torch.cat([srcs[2].detach(), srcs[3].detach()]).float().contiguous()
+            self._cache["oa_tag"] = tag
+        w_oa = self._cache["w_oa"]
+        value = ops.gemm(feat16, self._w16("wv", self.value_proj.weight), bias_n=self._f32("bv", self.value_proj.bias))
+        offaw = ops.gemm(q16, w_oa, out_f32=True, bias_n=self._cache["b_oa"])
+        samp = ops.msda_fwd(value.view(B, Lin, self.d_model), offaw, ref, shapes_i32, starts_i32, B, Lq, M, L, P)
+        return ops.gemm(samp, self._w16("wo", self.output_proj.weight), out_f32=True,
+                        bias_n=self._f32("bo", self.output_proj.bias), scale_n=scale_n, res=res)
+
+    # ---- reference-shaped entry point ---------------------------------------------------------------
+    def forward(self, query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index,
+                input_padding_mask=None):
+        """`ms_deform_attn.py:120-185`: fp32 (N, Lq, C) / (N, Lin, C) tensors in, fp32 (N, Lq, C) out."""
+        if input_padding_mask is not None:
+            raise ValueError("input_padding_mask is always None on the AdapterSIS path (adapter_blocks.py:133,173)")
+        N, Len_q, C = query.shape
+        _, Len_in, _ = input_flatten.shape
+        assert int((input_spatial_shapes[:, 0] * input_spatial_shapes[:, 1]).sum()) == Len_in
+        ref, shapes_i32, starts_i32 = prepare_msda_geometry(reference_points, input_spatial_shapes,
+                                                            input_level_start_index, Len_q, query.device)
+        dt = config.operand_dtype
+        q16 = ops.cast_pad(query.reshape(N * Len_q, C).float().contiguous(), dtype=dt)
+        f16 = ops.cast_pad(input_flatten.reshape(N * Len_in, C).float().contiguous(), dtype=dt)
+        return self.forward16(q16, f16, ref, shapes_i32, starts_i32, N, Len_q, Len_in).view(N, Len_q, C)
+
+
+def prepare_msda_geometry(reference_points, spatial_shapes, level_start_index, Lq, device):
+    """(1|N, Lq, 1|L, 2) reference points -> fp32 [Lq, 2]; int32 shapes / starts on the device."""
+    if reference_points.shape[-1] != 2:
+        raise ValueError("Last dim of reference_points must be 2 or 4, but get {} instead.".format(
+            reference_points.shape[-1]) if reference_points.shape[-1] != 4 else
+            "reference boxes (last dim 4) are not used on the AdapterSIS path")
+    rp = reference_points
+    if rp.dim() != 4 or rp.shape[1] != Lq:
+        raise ValueError(f"reference_points must be (N, {Lq}, n_levels, 2), got {tuple(rp.shape)}")
+    if rp.shape[0] != 1 and not bool((rp == rp[:1]).all()):
+        raise ValueError("per-sample reference points are not used on the AdapterSIS path (adapter_blocks.py:9-22)")
+    if rp.shape[2] != 1 and not bool((rp == rp[:, :, :1]).all()):
+        raise ValueError("per-level reference points are not used on the AdapterSIS path (adapter_blocks.py:21)")
+    ref = rp[0, :, 0, :].to(device=device, dtype=torch.float32).contiguous()
+    shapes_i32 = spatial_shapes.to(device=device, dtype=torch.int32).contiguous()
+    starts_i32 = level_start_index.to(device=device, dtype=torch.int32).contiguous()
+    return ref, shapes_i32, starts_i32

@@ -67,7 +67,7 @@ template <> struct T16<bf16> {
   }
 };
 
-template <typename T> __device__ __forceinline__ T to_t16(float x) { return (T)x; }   // RNE; fp16 saturates to inf
+template <typename T> __device__ __forceinline__ T to_t16(float x) { return (T)x; }  // T = float passes through   // RNE; fp16 saturates to inf
 template <typename T> __device__ __forceinline__ float from_t16(T x) { return (float)x; }
 
 // pack two floats into one 32-bit word of two T (lo = first)

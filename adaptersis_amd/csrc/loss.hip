@@ -310,16 +310,20 @@ extern "C" int asis_resize_bwd_nblk(int64_t total_pixels) {
 extern "C" int asis_resize_bilinear_bwd(void* stream, int dtype, const float* dz, int B, int H, int W, int h, int w, int C,
                                         int CP, void* out, float* partial) {
   ASIS_REQUIRE(dz && out && partial, "asis_resize_bilinear_bwd: null pointer");
-  ASIS_REQUIRE(C >= 1 && C <= MAXC && CP >= C && CP % 8 == 0 && CP <= MAXC, "asis_resize_bilinear_bwd: bad C=%d CP=%d", C, CP);
-  ASIS_REQUIRE(dtype == ASIS_F16 || dtype == ASIS_BF16, "asis_resize_bilinear_bwd: bad dtype %d", dtype);
+  ASIS_REQUIRE(C >= 1 && C <= MAXC && CP >= C && CP <= MAXC, "asis_resize_bilinear_bwd: bad C=%d CP=%d", C, CP);
+  ASIS_REQUIRE(dtype == ASIS_F16 || dtype == ASIS_BF16 || dtype == ASIS_F32, "asis_resize_bilinear_bwd: bad dtype %d", dtype);
+  ASIS_REQUIRE(dtype == ASIS_F32 || CP % 8 == 0, "asis_resize_bilinear_bwd: 16-bit output needs CP %% 8 == 0");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int nblk = asis_resize_bwd_nblk((int64_t)B * h * w);
   if (dtype == ASIS_F16)
     hipLaunchKernelGGL((resize_bwd_kernel<f16>), dim3(nblk), dim3(256), 0, s, dz, B, H, W, h, w, C, CP,
                        reinterpret_cast<f16*>(out), partial);
-  else
+  else if (dtype == ASIS_BF16)
     hipLaunchKernelGGL((resize_bwd_kernel<bf16>), dim3(nblk), dim3(256), 0, s, dz, B, H, W, h, w, C, CP,
                        reinterpret_cast<bf16*>(out), partial);
+  else
+    hipLaunchKernelGGL((resize_bwd_kernel<float>), dim3(nblk), dim3(256), 0, s, dz, B, H, W, h, w, C, CP,
+                       reinterpret_cast<float*>(out), partial);
   ASIS_CHECK_LAUNCH("asis_resize_bilinear_bwd");
   return ASIS_OK;
 }

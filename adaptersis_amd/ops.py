@@ -171,7 +171,8 @@ def im2col_patch(img: torch.Tensor, P: int, ldk: int, dtype: torch.dtype = T16_D
     return out
 
 
-def cast_pad(src: torch.Tensor, ld_dst: Optional[int] = None, dtype: torch.dtype = T16_DEFAULT) -> torch.Tensor:
+def cast_pad(src: torch.Tensor, ld_dst: Optional[int] = None, dtype: torch.dtype = T16_DEFAULT,
+             scale: float = 1.0) -> torch.Tensor:
     """float32 [rows, cols] -> 16-bit [rows, ld_dst] with zero-filled pad columns (weight packing)."""
     _dev(src)
     if src.dtype != torch.float32 or src.dim() != 2 or src.stride(1) != 1:
@@ -179,7 +180,8 @@ def cast_pad(src: torch.Tensor, ld_dst: Optional[int] = None, dtype: torch.dtype
     rows, cols = src.shape
     ld = ld_dst if ld_dst is not None else (cols + 7) // 8 * 8
     out = torch.empty((rows, ld), device=src.device, dtype=dtype)
-    check(lib().asis_cast_pad(_stream(), _dt(dtype), src.data_ptr(), src.stride(0), out.data_ptr(), ld, rows, cols),
+    check(lib().asis_cast_pad(_stream(), _dt(dtype), src.data_ptr(), src.stride(0), out.data_ptr(), ld, rows, cols,
+                              float(scale)),
           "asis_cast_pad")
     return out
 
@@ -369,11 +371,12 @@ def resize_bilinear_bwd(dz: torch.Tensor, h: int, w: int, dtype: torch.dtype):
     """dz fp32 [B,H,W,C] -> (d 16-bit [B,h,w,CP], partial [nblk, C])."""
     _dev(dz)
     B, H, W, Cc = dz.shape
-    CP = (Cc + 7) // 8 * 8
+    f32 = dtype == torch.float32
+    CP = Cc if f32 else (Cc + 7) // 8 * 8
     nblk = lib().asis_resize_bwd_nblk(B * h * w)
     out = torch.empty((B, h, w, CP), device=dz.device, dtype=dtype)
     partial = torch.empty((nblk, Cc), device=dz.device, dtype=torch.float32)
-    check(lib().asis_resize_bilinear_bwd(_stream(), _dt(dtype), _f32c(dz).data_ptr(), B, H, W, h, w, Cc, CP,
+    check(lib().asis_resize_bilinear_bwd(_stream(), 2 if f32 else _dt(dtype), _f32c(dz).data_ptr(), B, H, W, h, w, Cc, CP,
                                          out.data_ptr(), partial.data_ptr()), "asis_resize_bilinear_bwd")
     return out, partial
 

@@ -37,6 +37,7 @@ extern "C" {
 
 #define ASIS_F16 0
 #define ASIS_BF16 1
+#define ASIS_F32 2 /* only where a function says it accepts an fp32 output */
 
 #define ASIS_ACT_NONE 0
 #define ASIS_ACT_GELU 1 /* exact erf GELU: dinov2/layers/mlp.py:35 (nn.GELU default) */
@@ -119,10 +120,10 @@ int asis_attention_fwd(void* stream, int dtype, const void* q, const void* k, in
 int asis_im2col_patch(void* stream, int dtype, const float* img, int B, int Himg, int Wimg, int P, void* out,
                       int64_t ldk);
 
-/* fp32 -> 16-bit cast with optional zero-padded columns: src [rows, cols] (ld_src) -> dst [rows, ld_dst],
- * columns cols..ld_dst-1 are written as zero.  Used to pack weights once. */
+/* fp32 -> 16-bit cast (x scale) with optional zero-padded columns: src [rows, cols] (ld_src) ->
+ * dst [rows, ld_dst], columns cols..ld_dst-1 are written as zero.  Used to pack weights once. */
 int asis_cast_pad(void* stream, int dtype, const float* src, int64_t ld_src, void* dst, int64_t ld_dst, int64_t rows,
-                  int cols);
+                  int cols, float scale);
 
 /* tokens_A[b, 0, :] = cls + pos[0];  tokens_A[b, 1+t, :] = x[b, t, :] + pos[1+t]
  * (vision_transformer.py:196-197 with the interpolated pos-embed cached per (H,W)). fp32. */
@@ -203,7 +204,8 @@ int asis_dice_fwd(void* stream, const float* logits, const int64_t* target, int 
 int asis_dice_bwd(void* stream, const float* logits, const int64_t* target, const float* coef, int B, int h, int w,
                   int H, int W, int C, int n_softmax, float* dz);
 /* transpose of F.interpolate(bilinear, align_corners=False): dz [B,H,W,C] -> 16-bit [B,h,w,CP] (CP = C
- * rounded up to 8, pad channels zero) + partial[asis_resize_bwd_nblk(B*h*w)][C] column sums */
+ * rounded up to 8, pad channels zero; dtype ASIS_F32: fp32 output, any CP >= C)
+ * + partial[asis_resize_bwd_nblk(B*h*w)][C] column sums */
 int asis_resize_bwd_nblk(int64_t total_pixels);
 int asis_resize_bilinear_bwd(void* stream, int dtype, const float* dz, int B, int H, int W, int h, int w, int C, int CP,
                              void* out, float* partial);

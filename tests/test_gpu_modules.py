@@ -1,0 +1,117 @@
+"""GPU parity of the HIP-backed modules (reference-shaped ``nn.Module`` API) against the goldens
+generated from the imported reference and against the CPU oracle.  TOL = north_star's 1e-3."""
+import pytest
+import torch
+
+from adaptersis_amd.backbones.adapter_blocks import CACNN, CAViT, deform_inputs
+from adaptersis_amd.backbones.decoders import FeatureDecoder
+from adaptersis_amd.backbones.encoders import FeatureEncoder
+from adaptersis_amd.segloss.dice import DC, resize_softmax_dc
+from adaptersis_amd.utils import weights as W
+from oracle import ref_torch as O
+from tests.conftest import golden_err, load_golden, rel_l2
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+def test_deform_inputs_match_oracle():
+    x = torch.zeros(1, 3, 588, 588)
+    d1, d2 = deform_inputs(x, 14)
+    o1, o2 = O.deform_inputs(588, 588, 14)
+    for a, b in zip(d1 + d2, o1 + o2):
+        assert torch.equal(a, b)
+
+
+def test_adapters_588_vs_golden_and_oracle(dev):
+    """CAViT / CACNN at the reference's only geometry (588^2, D=1024), kernel-mode weights (gamma != 0)."""
+    g = load_golden("adapter")
+    D, size, B = 1024, 588, 1
+    csd, nsd = W.make_cavit_state_dict(D), W.make_cacnn_state_dict(D)
+    cv = CAViT(dim=D, n_levels=3, num_heads=8, init_values=0.0, n_points=4)
+    cv.load_state_dict(csd)
+    cn = CACNN(dim=D, n_levels=1, num_heads=8, n_points=4, with_cffn=True, cffn_ratio=0.25)
+    cn.load_state_dict(nsd)
+    cv, cn = cv.to(dev), cn.to(dev)
+    d1, d2 = deform_inputs(torch.zeros(B, 3, size, size), 14)
+    x = W.tensor("adapter588.x", (B, 1764, D), 1.0)
+    c = W.tensor("adapter588.c", (B, 6949, D), 1.0)
+    x1 = cv(query=x.to(dev), reference_points=d1[0], feat=c.to(dev), spatial_shapes=d1[1], level_start_index=d1[2])
+    c1 = cn(query=c.to(dev), reference_points=d2[0], feat=x1, spatial_shapes=d2[1], level_start_index=d2[2],
+            H=size // 16, W=size // 16)
+    assert golden_err(x1, g["adapter588.cavit"]) < TOL
+    assert golden_err(c1, g["adapter588.cacnn"]) < TOL
+    o1, o2 = O.deform_inputs(size, size, 14)
+    ox1 = O.cavit(x, o1[0], c, o1[1], csd)
+    assert rel_l2(x1, ox1) < TOL
+    # the adapter's own contribution (not hidden behind the residual) must also be right
+    assert rel_l2(x1.cpu() - x, ox1 - x) < 3 * TOL
+
+
+def test_msdeformattn_errors(dev):
+    from adaptersis_amd.backbones.ops.modules import MSDeformAttn
+    with pytest.raises(ValueError):
+        MSDeformAttn(d_model=100, n_heads=8)
+    m = MSDeformAttn(d_model=64, n_levels=1, n_heads=8, n_points=4).to(dev)
+    q = torch.zeros(1, 4, 64, device=dev)
+    shapes = torch.tensor([[2, 2]])
+    with pytest.raises(ValueError):
+        m(q, torch.zeros(1, 4, 1, 3), q, shapes, torch.tensor([0]))
+    with pytest.raises(AssertionError):
+        m(q, torch.zeros(1, 4, 1, 2), torch.zeros(1, 5, 64, device=dev), shapes, torch.tensor([0]))
+
+
+@pytest.mark.parametrize("size,B,D,tag,file", [(224, 2, 128, "enc224", "small"), (588, 2, 1024, "enc588", "adapter")])
+def test_feature_encoder_vs_golden(dev, size, B, D, tag, file):
+    g = load_golden(file)
+    m = FeatureEncoder(embed_dim=D)
+    m.load_state_dict(W.make_encoder_state_dict(D))
+    m = m.to(dev)
+    img, _ = W.synthetic_batch(B, size)
+    c1, c2, c3, c4 = m(img.to(dev))
+    for n, t in (("c1", c1), ("c2", c2), ("c3", c3), ("c4", c4)):
+        assert golden_err(t, g[f"{tag}.{n}"]) < TOL, n
+    assert m.last_shapes == [tuple(s) for s in g[f"{tag}.shapes"].tolist()]
+    sd = m.state_dict()
+    for k in ("stem.1.running_mean", "stem.1.running_var", "conv4.1.running_mean", "conv4.1.running_var"):
+        assert rel_l2(sd[k], g[f"{tag}.{k}"]) < TOL, k
+    assert int(sd["stem.1.num_batches_tracked"]) == 1
+
+
+def test_feature_decoder_small_forward_backward_vs_golden(dev):
+    """Decoder + resize + double-softmax Dice, forward and ALL parameter gradients, through torch autograd."""
+    g = load_golden("small")
+    D, hw, B = 32, 6, 2
+    feats = [D, 32, 16, 16, 8]
+    m = FeatureDecoder(embed_dim=D, num_classes=2, features=feats)
+    m.load_state_dict(W.make_feature_decoder_state_dict(D, 2, features=tuple(feats)))
+    m = m.to(dev).train()
+    x = W.tensor("dec_small.x", (B, 3 * D, hw, hw), 1.0).to(dev)
+    tgt = W.synthetic_batch(B, hw * 14, 2)[1].to(dev)
+    logits = m(x)
+    assert golden_err(logits, g["dec_small.logits"]) < TOL
+    loss = resize_softmax_dc(logits, tgt)
+    assert abs(float(loss) - float(g["dec_small.loss"])) < 1e-4
+    loss.backward()
+    worst = 0.0
+    for k, p in m.named_parameters():
+        assert p.grad is not None, k
+        gold = g[f"dec_small.grad.{k}"]
+        if float(gold["sumsq"]) < 1e-20:  # conv bias feeding a train-mode BN: analytically zero gradient
+            assert float(p.grad.abs().max()) < 1e-6, k
+            continue
+        e = golden_err(p.grad, gold)
+        worst = max(worst, e)
+        assert e < 5e-3, (k, e)
+    print("decoder grads worst rel-L2 vs reference autograd:", worst)
+
+
+def test_dc_module_matches_oracle(dev):
+    B, C, H = 3, 2, 40
+    lg = W.tensor("loss.logits", (B, C, H, H), 3.0)
+    tg = W.synthetic_batch(B, H, 2)[1]
+    g = load_golden("small")
+    out = DC(C)(lg.to(dev), O.one_hot(tg, C).to(dev))
+    assert abs(float(out) - float(g["loss.dc"])) < 2e-6
+    out2 = DC(C)(lg.to(dev), tg.unsqueeze(1).to(dev))
+    assert abs(float(out2) - float(g["loss.dc"])) < 2e-6
