@@ -87,8 +87,8 @@ SIGNATURES = {
     "asis_bn_relu_maxpool": [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i],
     "asis_bn_relu_upsample": [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i],
     "asis_pack_conv_weight": [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i64],
-    "asis_decoder_input": [_vp, _i, _vp, _vp, _i64, _vp, _vp, _i, _i, _i, _i, _i, _i],
-    "asis_add_f32": [_vp, _vp, _vp, _vp, _i64],
+    "asis_decoder_input": [_vp, _i, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i, _i, _i, _i, _i, _i],
+    "asis_add_f32": [_vp, _vp, _vp, _vp, _i64, _i, _i64, _i64, _i64],
     "asis_dice_nblk": [_i, _i],
     "asis_dice_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp],
     "asis_dice_bwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],

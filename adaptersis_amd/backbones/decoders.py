@@ -136,8 +136,10 @@ class FeatureDecoder(_Packed):
         saved.append(a if save else None)
         return logits, saved
 
-    def _backward_core(self, saved, d16, bias_partial, inv_scale, grads, dlogits_f32=None):
-        """d16: 16-bit [B,h,w,CP] = loss_scale * dL/dlogits (pad channels zero)."""
+    def _backward_core(self, saved, d16, bias_partial, inv_scale, grads, dlogits_f32=None, stage_done=None):
+        """d16: 16-bit [B,h,w,CP] = loss_scale * dL/dlogits (pad channels zero).  ``stage_done()`` is
+        called after the final conv and after each decoder stage (4,3,2,1) once its gradients are
+        enqueued — the engine launches that stage's gradient all-reduce from it."""
         dt = config.operand_dtype
         C = self.num_classes
         x5 = saved[4]
@@ -149,10 +151,14 @@ class FeatureDecoder(_Packed):
         wdg = _pack(self._cache, "final.wd", self.final_out.weight,
                     lambda p: ops.pack_conv_weight(p.float().contiguous(), 1, dt))
         dU = ops.conv_gemm(d16, wdg, 3, 3, 1, 1)
+        if stage_done is not None:
+            stage_done()
         for i in range(4, 0, -1):
             seq = getattr(self, f"decoder_{i}")
             dU = conv_bn_relu_up_backward(self, f"d{i}", saved[i - 1], dU, seq[0], seq[1], inv_scale, grads,
                                           f"decoder_{i}", need_dx=(i > 1), sync_bn=self.sync_bn)
+            if stage_done is not None:
+                stage_done()
 
     # ---- reference-shaped entry point ----------------------------------------------------------------
     def forward(self, x):

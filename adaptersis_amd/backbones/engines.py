@@ -1,0 +1,207 @@
+"""Engine entry points of the MI355X build (the reference's `backbones/engines.py` only holds the
+unused ``pre_vit`` patch-embed clone, which is kept here for API parity).
+
+``SegEngine`` is the fused form of the step body that the reference writes inline in
+`train.py:268-436` (and copies into `validate_network`, `train.py:465-612`):
+
+    encoder -> ViT pass A (cls + pos-embed, last-4 normed features) -> ViT pass B (raw patch tokens,
+    blocks[0:-3]) -> 4 x [block, CAViT, CACNN, + pass-A feature] -> decoder input assembly ->
+    FeatureDecoder -> resize + softmax + DC (softmax again) -> backward of the decoder (the only
+    part of the graph that receives gradients: SURVEY.md fact 1) -> gradient all-reduce (RCCL,
+    launched per decoder stage on a side stream as soon as that stage's gradients exist) -> SGD.
+
+Everything is a HIP kernel from libasis_hip.so; torch provides device memory, streams and
+``torch.distributed``.  No autograd graph is built: the engine calls the same functional cores
+(`FeatureDecoder._forward_core/_backward_core`) that the reference-shaped modules wrap in
+``torch.autograd.Function``.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+from torch import nn
+
+from .. import config, ops
+from ..dinov2.layers.blocks import _Packed, _pack
+from ..optim import SGD, FlatBucket
+from .adapter_blocks import CACNN, CAViT, deform_inputs
+
+
+class pre_vit(_Packed):
+    """`backbones/engines.py:4-60`: (B, C, H, W) -> (B, N, D) patch embedding, Conv2d(k = s = patch).
+    Unused by every reference script; implemented as an implicit-GEMM conv for completeness."""
+
+    def __init__(self, img_size=84, patch_size=14, in_chans=256, embed_dim=384, norm_layer=None, flatten_embedding=True):
+        super().__init__()
+        if norm_layer is not None:
+            raise ValueError("pre_vit: norm_layer is never set in the reference")
+        self.img_size, self.patch_size = img_size, patch_size
+        self.patches_resolution = (img_size // patch_size, img_size // patch_size)
+        self.num_patches = self.patches_resolution[0] * self.patches_resolution[1]
+        self.in_chans, self.embed_dim, self.flatten_embedding = in_chans, embed_dim, flatten_embedding
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
+        self.norm = nn.Identity()
+
+    def forward(self, x):
+        B, C, H, W = x.shape
+        P = self.patch_size
+        assert H % P == 0, f"Input image height {H} is not a multiple of patch height {P}"
+        assert W % P == 0, f"Input image width {W} is not a multiple of patch width: {P}"
+        dt = config.operand_dtype
+        x16 = ops.cast_pad(x.permute(0, 2, 3, 1).contiguous().float().view(B * H * W, C), C, dt).view(B, H, W, C)
+        w16 = _pack(self._cache, "w", self.proj.weight, lambda p: ops.pack_conv_weight(p.float().contiguous(), 0, dt))
+        out = ops.conv_gemm(x16, w16, P, P, P, 0, bias_n=self._f32("b", self.proj.bias))
+        out = out.view(B, (H // P) * (W // P), self.embed_dim)
+        if not self.flatten_embedding:
+            out = out.reshape(-1, H // P, W // P, self.embed_dim)
+        return out
+
+
+class SegEngine(nn.Module):
+    """One object owning the frozen ViT, the CNN encoder, the adapters, the decode head and the optimizer.
+
+    mode="reference_exact" reproduces `train.py` as written: adapters/encoder run forward only (graph
+    cut at `train.py:389-406`), ``level_embed`` is a fresh zero tensor (no-op), the loss applies
+    softmax twice, only the decoder is optimised (momentum 0.99, wd 3e-5: `train.py:178-191`).
+    """
+
+    def __init__(self, model, backbone_encoder, cross_vit: CAViT, cross_cnn: CACNN, seg_decoder, *,
+                 n_last_blocks: int = 4, num_classes: int = 2, lr: float = 0.01, momentum: float = 0.99,
+                 weight_decay: float = 3e-5, mode: str = "reference_exact", process_group=None):
+        super().__init__()
+        if mode != "reference_exact":
+            raise NotImplementedError("only mode='reference_exact' is built in this round (SURVEY.md §8 row C3)")
+        self.model, self.backbone_encoder = model, backbone_encoder
+        self.cross_vit, self.cross_cnn, self.seg_decoder = cross_vit, cross_cnn, seg_decoder
+        self.n_last_blocks, self.num_classes, self.mode = n_last_blocks, num_classes, mode
+        self.patch = model.patch_size
+        self.heads = model.num_heads
+        self.process_group = process_group
+        for p in list(model.parameters()) + list(backbone_encoder.parameters()) + list(cross_vit.parameters()) + \
+                list(cross_cnn.parameters()):
+            p.requires_grad_(False)  # no gradient reaches them in the reference step
+        # gradient-ready order of the decoder backward: final conv first, decoder_1 last
+        order = ["final_out"] + [f"decoder_{i}" for i in (4, 3, 2, 1)]
+        named = dict(seg_decoder.named_parameters())
+        ordered = [(n, named[n]) for pre in order for n in named if n.startswith(pre + ".")]
+        assert len(ordered) == len(named)
+        self.bucket = FlatBucket(ordered)
+        self.stage_ranges = [self.bucket.range_of([n for n in named if n.startswith(pre + ".")]) for pre in order]
+        self.optimizer = SGD([self.bucket], lr=lr, momentum=momentum, weight_decay=weight_decay)
+        self._geom = {}
+        self._comm_stream = None
+
+    # ------------------------------------------------------------------------------------------
+    def _geometry(self, H, W, shapes, dev):
+        key = (H, W, tuple(shapes), dev)
+        g = self._geom.get(key)
+        if g is None:
+            d1, d2 = deform_inputs(torch.zeros(1, 3, H, W), self.patch, shapes)
+            g = {"ref1": d1[0][0, :, 0, :].contiguous().to(dev), "shapes1": d1[1].to(torch.int32).to(dev),
+                 "starts1": d1[2].to(torch.int32).to(dev), "ref2": d2[0][0, :, 0, :].contiguous().to(dev),
+                 "shapes2": d2[1].to(torch.int32).to(dev), "starts2": d2[2].to(torch.int32).to(dev)}
+            self._geom = {key: g}
+        return g
+
+    def _cavit(self, x2, c2, g, B, Lq, Lin):
+        cv = self.cross_vit
+        return cv.attn.forward16(cv._ln16("query_norm", x2), cv._ln16("feat_norm", c2), g["ref1"], g["shapes1"],
+                                 g["starts1"], B, Lq, Lin, res=x2, scale_n=cv._f32("gamma", cv.gamma))
+
+    def _cacnn(self, c2, x2, g, B, Lq, Lin, grids):
+        cn = self.cross_cnn
+        out = cn.attn.forward16(cn._ln16("query_norm", c2), cn._ln16("feat_norm", x2), g["ref2"], g["shapes2"],
+                                g["starts2"], B, Lq, Lin, res=c2)
+        return cn.ffn.forward16(cn._ln16("ffn_norm", out), out, B, Lq, grids) if cn.with_cffn else out
+
+    @torch.no_grad()
+    def features(self, inp: torch.Tensor, taps: Optional[dict] = None) -> torch.Tensor:
+        """`train.py:275-406`: image batch -> decoder input, NHWC 16-bit [B, h, w, 3D]."""
+        m = self.model
+        B, _, H, W = inp.shape
+        inp = inp.float().contiguous()
+        D = m.embed_dim
+        h, w = H // self.patch, W // self.patch
+        N = h * w
+        nb = len(m.blocks)
+        nl = self.n_last_blocks
+        _, c, shapes = self.backbone_encoder.forward_tokens(inp, need_c1=False)
+        c_orig = c
+        Lc = c.shape[1]
+        g = self._geometry(H, W, shapes, inp.device)
+        # ---- pass A (train.py:287): cls + pos-embed, all blocks, final norm on the last n outputs ----
+        tokens = m.patch_embed(inp)                       # shared by both passes: same conv on the same input
+        pos = m._pos_for(N, H, W)
+        xa = ops.add_cls_pos(tokens, m.cls_token.detach().reshape(-1).float().contiguous(),
+                             pos.detach().reshape(-1, D).float().contiguous())
+        feats = []
+        for i, blk in enumerate(m.blocks):
+            xa = blk(xa)
+            if i >= nb - nl:
+                feats.append(m._final_norm(xa)[:, 1:])    # [B, N, D] view, batch stride (N+1)*D
+        # ---- pass B (train.py:300-302): raw patch tokens through blocks[0:-3] ----
+        x = tokens
+        for blk in m.blocks[: nb - (nl - 1)]:
+            x = blk(x)
+        if taps is not None:
+            taps.update(c=c, feats=feats, x_b0=x, shapes=shapes)
+        c2d = c.view(B * Lc, D)
+        for s in range(nl):
+            if s > 0:
+                x = m.blocks[nb - (nl - 1) + s - 1](x)
+            x2 = x.view(B * N, D)
+            x2 = self._cavit(x2, c2d, g, B, N, Lc)
+            c2d = self._cacnn(c2d, x2, g, B, Lc, N, shapes)
+            x = ops.add_f32(x2.view(B, N, D), feats[s])
+        n4 = shapes[2][0] * shapes[2][1]
+        cat = ops.decoder_input(x, c_orig[:, Lc - n4:], feats[-1], (h, w), shapes[2], config.operand_dtype)
+        if taps is not None:
+            taps.update(x_final=x, c_final=c2d.view(B, Lc, D), cat=cat)
+        return cat
+
+    # ------------------------------------------------------------------------------------------
+    def _allreduce_range(self, lo, hi, ev):
+        """RCCL all-reduce of grad[lo:hi] on the side stream once the producing kernels (event) are done."""
+        if self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream()
+        self._comm_stream.wait_event(ev)
+        with torch.cuda.stream(self._comm_stream):
+            dist.all_reduce(self.bucket.grad[lo:hi], group=self.process_group)
+
+    @torch.no_grad()
+    def train_step(self, inp: torch.Tensor, target: torch.Tensor, taps: Optional[dict] = None) -> torch.Tensor:
+        """One `train.py:268-436` iteration; returns the loss as a 0-dim device tensor (no host sync)."""
+        dec = self.seg_decoder
+        S = config.loss_scale
+        cat = self.features(inp, taps)
+        logits, saved = dec._forward_core(cat, save=True)
+        target = target.long().contiguous()
+        loss, coef, _ = ops.dice_fwd(logits, target, 2, 10e-20, S)
+        dz = ops.dice_bwd(logits, target, coef, 2)
+        B, hh, ww, C = logits.shape
+        d16, bpart = ops.resize_bilinear_bwd(dz, hh, ww, config.operand_dtype)
+        world = dist.get_world_size(self.process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        inv = 1.0 / (S * world)  # gradient mean over ranks folded into the un-scaling (DDP semantics)
+        hook = None
+        if world > 1:
+            stages = iter(self.stage_ranges)
+
+            def hook():
+                lo, hi = next(stages)
+                ev = torch.cuda.Event()
+                ev.record()
+                self._allreduce_range(lo, hi, ev)
+        dec._backward_core(saved, d16, bpart, inv, self.bucket.views, stage_done=hook)
+        if world > 1:
+            torch.cuda.current_stream().wait_stream(self._comm_stream)
+        self.optimizer.step(1.0)
+        if taps is not None:
+            taps.update(logits=logits, loss=loss)
+        return loss.view(())
+
+    @torch.no_grad()
+    def eval_logits(self, inp: torch.Tensor) -> torch.Tensor:
+        logits, _ = self.seg_decoder._forward_core(self.features(inp), save=False)
+        return logits  # NHWC fp32

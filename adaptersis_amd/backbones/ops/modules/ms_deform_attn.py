@@ -75,7 +75,7 @@ class MSDeformAttn(_Packed):
 
         srcs = (self.sampling_offsets.weight, self.attention_weights.weight, self.sampling_offsets.bias,
                 self.attention_weights.bias)
-        tag = tuple((t.data_ptr(), t._version) for t in srcs) + (dt,)
+        tag = tuple((t.data_ptr(), t._version, getattr(t, "_asis_gen", 0)) for t in srcs) + (dt,)
         if self._cache.get("oa_tag") != tag:  # offsets and attention logits come from ONE GEMM: [M*L*P*3, D]
             with torch.no_grad():
                 w = torch.cat([srcs[0].detach(), srcs[1].detach()], 0).float().contiguous()

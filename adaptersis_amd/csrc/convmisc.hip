@@ -272,8 +272,9 @@ __global__ __launch_bounds__(256) void pack_conv_weight_kernel(const float* __re
 
 // ---- decoder input: [adapter-stream tokens | zero-padded c4 | pass-A tokens] -> NHWC 16-bit -------
 template <typename T>
-__global__ __launch_bounds__(256) void decoder_input_kernel(const float* __restrict__ xs, const float* __restrict__ c4,
-                                                            int64_t c4_bstride, const float* __restrict__ vit,
+__global__ __launch_bounds__(256) void decoder_input_kernel(const float* __restrict__ xs, int64_t xs_bstride,
+                                                            const float* __restrict__ c4, int64_t c4_bstride,
+                                                            const float* __restrict__ vit, int64_t vit_bstride,
                                                             T* __restrict__ out, int B, int h, int w, int h4, int w4,
                                                             int D) {
   const int cpt = (3 * D) >> 2;
@@ -288,8 +289,9 @@ __global__ __launch_bounds__(256) void decoder_input_kernel(const float* __restr
     const int b = (int)(pix / ((int64_t)w * h));
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     const int seg = c / dq, cc = c - seg * dq;
-    if (seg == 0) v = reinterpret_cast<const float4*>(xs + pix * D)[cc];
-    else if (seg == 2) v = reinterpret_cast<const float4*>(vit + pix * D)[cc];
+    const int64_t pin = (int64_t)y * w + x;
+    if (seg == 0) v = reinterpret_cast<const float4*>(xs + (int64_t)b * xs_bstride + pin * D)[cc];
+    else if (seg == 2) v = reinterpret_cast<const float4*>(vit + (int64_t)b * vit_bstride + pin * D)[cc];
     else {
       const int yy = y - py, xx = x - px;
       if ((unsigned)yy < (unsigned)h4 && (unsigned)xx < (unsigned)w4)
@@ -302,12 +304,15 @@ __global__ __launch_bounds__(256) void decoder_input_kernel(const float* __restr
   }
 }
 
-// out[i] = a[i] + b[i] (fp32, float4)
+// out[b][i] = a[b][i] + c[b][i] (fp32, float4), each operand with its own batch stride (in float4 units)
 __global__ __launch_bounds__(256) void add_f32_kernel(const float4* __restrict__ a, const float4* __restrict__ b,
-                                                      float4* __restrict__ out, int64_t n4) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-    const float4 x = a[i], y = b[i];
-    out[i] = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+                                                      float4* __restrict__ out, int64_t n4, int batch, int64_t sa,
+                                                      int64_t sb, int64_t so) {
+  const int64_t total = n4 * batch;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t bi = i / n4, j = i - bi * n4;
+    const float4 x = a[bi * sa + j], y = b[bi * sb + j];
+    out[bi * so + j] = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
   }
 }
 
@@ -442,31 +447,34 @@ extern "C" int asis_pack_conv_weight(void* stream, int dtype, const float* w, vo
   return ASIS_OK;
 }
 
-extern "C" int asis_decoder_input(void* stream, int dtype, const float* xs, const float* c4, int64_t c4_bstride,
-                                  const float* vit, void* out, int B, int h, int w, int h4, int w4, int D) {
+extern "C" int asis_decoder_input(void* stream, int dtype, const float* xs, int64_t xs_bstride, const float* c4,
+                                  int64_t c4_bstride, const float* vit, int64_t vit_bstride, void* out, int B, int h,
+                                  int w, int h4, int w4, int D) {
   ASIS_REQUIRE(xs && c4 && vit && out, "asis_decoder_input: null pointer");
   ASIS_REQUIRE(D % 4 == 0 && h4 <= h && w4 <= w, "asis_decoder_input: bad shape");
-  ASIS_REQUIRE(c4_bstride % 4 == 0 && asis_aligned16(xs) && asis_aligned16(c4) && asis_aligned16(vit),
-               "asis_decoder_input: alignment");
+  ASIS_REQUIRE(c4_bstride % 4 == 0 && xs_bstride % 4 == 0 && vit_bstride % 4 == 0 && asis_aligned16(xs) &&
+                   asis_aligned16(c4) && asis_aligned16(vit), "asis_decoder_input: alignment");
   DT_OK(dtype, "asis_decoder_input");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int64_t total = (int64_t)B * h * w * (3 * D / 4);
   if (dtype == ASIS_F16)
-    hipLaunchKernelGGL((decoder_input_kernel<f16>), dim3(grid_for(total)), dim3(256), 0, s, xs, c4, c4_bstride, vit,
-                       reinterpret_cast<f16*>(out), B, h, w, h4, w4, D);
+    hipLaunchKernelGGL((decoder_input_kernel<f16>), dim3(grid_for(total)), dim3(256), 0, s, xs, xs_bstride, c4, c4_bstride, vit,
+                       vit_bstride, reinterpret_cast<f16*>(out), B, h, w, h4, w4, D);
   else
-    hipLaunchKernelGGL((decoder_input_kernel<bf16>), dim3(grid_for(total)), dim3(256), 0, s, xs, c4, c4_bstride, vit,
-                       reinterpret_cast<bf16*>(out), B, h, w, h4, w4, D);
+    hipLaunchKernelGGL((decoder_input_kernel<bf16>), dim3(grid_for(total)), dim3(256), 0, s, xs, xs_bstride, c4, c4_bstride, vit,
+                       vit_bstride, reinterpret_cast<bf16*>(out), B, h, w, h4, w4, D);
   ASIS_CHECK_LAUNCH("asis_decoder_input");
   return ASIS_OK;
 }
 
-extern "C" int asis_add_f32(void* stream, const float* a, const float* b, float* out, int64_t n) {
+extern "C" int asis_add_f32(void* stream, const float* a, const float* b, float* out, int64_t n, int batch,
+                            int64_t stride_a, int64_t stride_b, int64_t stride_out) {
   ASIS_REQUIRE(a && b && out, "asis_add_f32: null pointer");
-  ASIS_REQUIRE(n % 4 == 0 && asis_aligned16(a) && asis_aligned16(b) && asis_aligned16(out), "asis_add_f32: alignment");
-  hipLaunchKernelGGL(add_f32_kernel, dim3(grid_for(n / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+  ASIS_REQUIRE(n % 4 == 0 && batch >= 1 && stride_a % 4 == 0 && stride_b % 4 == 0 && stride_out % 4 == 0 &&
+                   asis_aligned16(a) && asis_aligned16(b) && asis_aligned16(out), "asis_add_f32: alignment");
+  hipLaunchKernelGGL(add_f32_kernel, dim3(grid_for(n / 4 * batch)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                      reinterpret_cast<const float4*>(a), reinterpret_cast<const float4*>(b),
-                     reinterpret_cast<float4*>(out), n / 4);
+                     reinterpret_cast<float4*>(out), n / 4, batch, stride_a / 4, stride_b / 4, stride_out / 4);
   ASIS_CHECK_LAUNCH("asis_add_f32");
   return ASIS_OK;
 }

@@ -23,7 +23,7 @@ from ... import config, ops
 
 def _pack(cache: dict, key: str, param: torch.Tensor, fn: Callable[[torch.Tensor], torch.Tensor]):
     """Cache a derived (16-bit / re-laid-out) copy of a parameter until the parameter changes."""
-    tag = (param.data_ptr(), param._version, config.operand_dtype, param.device)
+    tag = (param.data_ptr(), param._version, getattr(param, "_asis_gen", 0), config.operand_dtype, param.device)
     hit = cache.get(key)
     if hit is None or hit[0] != tag:
         with torch.no_grad():

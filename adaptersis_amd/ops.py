@@ -313,26 +313,36 @@ def pack_conv_weight(w: torch.Tensor, mode: int, dtype: torch.dtype) -> torch.Te
     return out[:, :K] if ld != K else out
 
 
+def _rows3(t: torch.Tensor, D: int, what: str):
+    if t.dtype != torch.float32 or t.dim() != 3 or t.stride(2) != 1 or t.stride(1) != D:
+        raise ValueError(f"{what}: expected float32 [B, n, {D}] with contiguous rows (batch stride free)")
+
+
 def decoder_input(xs: torch.Tensor, c4: torch.Tensor, vit: torch.Tensor, hw, c4_hw, dtype: torch.dtype) -> torch.Tensor:
-    """train.py:389-406: xs, vit fp32 [B, h*w, D]; c4 fp32 [B, h4*w4, D] (batch stride free) -> [B,h,w,3D]."""
+    """train.py:389-406: xs, vit fp32 [B, h*w, D]; c4 fp32 [B, h4*w4, D] (batch strides free) -> [B,h,w,3D]."""
     _dev(xs, c4, vit)
     B, _, D = xs.shape
     h, w = hw
     h4, w4 = c4_hw
-    if c4.stride(2) != 1 or c4.stride(1) != D:
-        raise ValueError("decoder_input: c4 rows must be contiguous")
+    for t, n in ((xs, "xs"), (c4, "c4"), (vit, "vit")):
+        _rows3(t, D, "decoder_input " + n)
     out = torch.empty((B, h, w, 3 * D), device=xs.device, dtype=dtype)
-    check(lib().asis_decoder_input(_stream(), _dt(dtype), _f32c(xs).data_ptr(), c4.data_ptr(), c4.stride(0),
-                                   _f32c(vit).data_ptr(), out.data_ptr(), B, h, w, h4, w4, D), "asis_decoder_input")
+    check(lib().asis_decoder_input(_stream(), _dt(dtype), xs.data_ptr(), xs.stride(0), c4.data_ptr(), c4.stride(0),
+                                   vit.data_ptr(), vit.stride(0), out.data_ptr(), B, h, w, h4, w4, D),
+          "asis_decoder_input")
     return out
 
 
 def add_f32(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = a + b for float32 [B, n, D] tensors with contiguous rows and free batch strides."""
     _dev(a, b, out)
+    B, n, D = a.shape
     if out is None:
-        out = torch.empty_like(a)
-    check(lib().asis_add_f32(_stream(), _f32c(a).data_ptr(), _f32c(b).data_ptr(), out.data_ptr(), a.numel()),
-          "asis_add_f32")
+        out = torch.empty((B, n, D), device=a.device, dtype=torch.float32)
+    for t, nm in ((a, "a"), (b, "b"), (out, "out")):
+        _rows3(t, D, "add_f32 " + nm)
+    check(lib().asis_add_f32(_stream(), a.data_ptr(), b.data_ptr(), out.data_ptr(), n * D, B, a.stride(0), b.stride(0),
+                             out.stride(0)), "asis_add_f32")
     return out
 
 

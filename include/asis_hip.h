@@ -183,11 +183,15 @@ int asis_bn_relu_upsample(void* stream, int dtype, const float* x, const float* 
  * mode 1 (dgrad):   out[ci][((KH-1-kh)*KW+(KW-1-kw))*CoP+co], rows Cin, CoP = Cout rounded up to 8. */
 int asis_pack_conv_weight(void* stream, int dtype, const float* w, void* out, int Cout, int Cin, int KH, int KW,
                           int mode, int64_t ldo);
-/* decoder input (train.py:389-406): [xs | zero-padded c4 | vit] fp32 tokens -> 16-bit NHWC [B,h,w,3D] */
-int asis_decoder_input(void* stream, int dtype, const float* xs, const float* c4, int64_t c4_bstride, const float* vit,
-                       void* out, int B, int h, int w, int h4, int w4, int D);
-/* out = a + b (fp32; train.py:320,343,365,387 residual adds with the pass-A features) */
-int asis_add_f32(void* stream, const float* a, const float* b, float* out, int64_t n);
+/* decoder input (train.py:389-406): [xs | zero-padded c4 | vit] fp32 tokens -> 16-bit NHWC [B,h,w,3D];
+ * every source has its own batch stride (elements) so token slices need no copies */
+int asis_decoder_input(void* stream, int dtype, const float* xs, int64_t xs_bstride, const float* c4,
+                       int64_t c4_bstride, const float* vit, int64_t vit_bstride, void* out, int B, int h, int w, int h4,
+                       int w4, int D);
+/* out[b] = a[b] + b_[b] over n floats per batch element, each operand with its own batch stride
+ * (fp32; train.py:320,343,365,387 residual adds with the cls-stripped pass-A features) */
+int asis_add_f32(void* stream, const float* a, const float* b, float* out, int64_t n, int batch, int64_t stride_a,
+                 int64_t stride_b, int64_t stride_out);
 
 /* ---------------------------------------------------------------------------------------------
  * Loss (train.py:422-428 + segloss/dice.py:22-33), fused with the bilinear resize (h,w)->(H,W):
