@@ -74,7 +74,7 @@ SIGNATURES = {
     "asis_layernorm": [_vp, _i, _vp, _i64, _vp, _vp, _f, _vp, _i64, _i, _i64, _i],
     "asis_attention_fwd": [_vp, _i, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _i, _f],
     "asis_im2col_patch": [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i64],
-    "asis_cast_pad": [_vp, _i, _vp, _i64, _vp, _i64, _i64, _i, _f],
+    "asis_cast_pad": [_vp, _i, _vp, _i64, _vp, _i64, _i64, _i, _f, _i],
     "asis_add_cls_pos": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i],
     "asis_msda_fwd": [_vp, _i, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i],
     "asis_dwconv_gelu": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i],
@@ -83,11 +83,11 @@ SIGNATURES = {
     "asis_colstats": [_vp, _vp, _i64, _i, _vp],
     "asis_reduce_partials": [_vp, _vp, _i, _i, _vp],
     "asis_bn_finalize": [_vp, _vp, _d, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
-    "asis_bn_act": [_vp, _i, _vp, _vp, _vp, _i, _vp, _i64, _i],
-    "asis_bn_relu_maxpool": [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i],
-    "asis_bn_relu_upsample": [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i],
-    "asis_pack_conv_weight": [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i64],
-    "asis_decoder_input": [_vp, _i, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i, _i, _i, _i, _i, _i],
+    "asis_bn_act": [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _i64, _i],
+    "asis_bn_relu_maxpool": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i],
+    "asis_bn_relu_upsample": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i],
+    "asis_pack_conv_weight": [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i64, _i],
+    "asis_decoder_input": [_vp, _i, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i, _i, _i, _i, _i, _i],
     "asis_add_f32": [_vp, _vp, _vp, _vp, _i64, _i, _i64, _i64, _i64],
     "asis_dice_nblk": [_i, _i],
     "asis_dice_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp],

@@ -32,15 +32,32 @@ class _Stage:
     __slots__ = ("x16", "raw", "scale", "shift", "mean", "invstd", "count", "factor")
 
 
-def conv_bn_relu_up_forward(owner: _Packed, key: str, x16, conv: nn.Conv2d, bn: nn.BatchNorm2d, factor: int,
-                            sync_bn: bool, save: bool):
+def _conv_weights(owner: _Packed, key: str, conv: nn.Conv2d, split: bool):
     dt = config.operand_dtype
+    w_hi = _pack(owner._cache, key + ".w", conv.weight, lambda p: ops.pack_conv_weight(p.float().contiguous(), 0, dt))
+    w_lo = _pack(owner._cache, key + ".wlo", conv.weight,
+                 lambda p: ops.pack_conv_weight(p.float().contiguous(), 0, dt, 1)) if split else None
+    return w_hi, w_lo
+
+
+def conv_bn_relu_up_forward(owner: _Packed, key: str, x16, x_lo, conv: nn.Conv2d, bn: nn.BatchNorm2d, factor: int,
+                            sync_bn: bool, save: bool):
+    """(x16, x_lo|None) NHWC -> ((up_hi, up_lo|None), saved stage)."""
+    dt = config.operand_dtype
+    split = x_lo is not None
     B, H, W, _ = x16.shape
-    w16 = _pack(owner._cache, key + ".w", conv.weight, lambda p: ops.pack_conv_weight(p.float().contiguous(), 0, dt))
+    w_hi, w_lo = _conv_weights(owner, key, conv, split)
     stats = torch.empty((ops.gemm_tiles_m(B * H * W), 2, conv.out_channels), device=x16.device, dtype=torch.float32)
-    raw = ops.conv_gemm(x16, w16, 3, 3, 1, 1, bias_n=owner._f32(key + ".b", conv.bias), stats=stats)
+    bias = owner._f32(key + ".b", conv.bias)
+    if split:
+        raw = ops.conv_gemm_split(x16, x_lo, w_hi, w_lo, 3, 3, 1, 1, bias_n=bias, stats=stats)
+    else:
+        raw = ops.conv_gemm(x16, w_hi, 3, 3, 1, 1, bias_n=bias, stats=stats)
     scale, shift, mean, invstd, count = _bn.finalize(stats, B * H * W, bn, sync_bn)
-    up = ops.bn_relu_upsample(raw, scale, shift, factor, dt) if factor > 1 else ops.bn_act(raw, scale, shift, True, dt)
+    up = ops.bn_relu_upsample(raw, scale, shift, factor, dt, split) if factor > 1 else \
+        ops.bn_act(raw, scale, shift, True, dt, split)
+    if not split:
+        up = (up, None)
     st = None
     if save:
         st = _Stage()
@@ -79,7 +96,7 @@ class _DecoderFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, module, x, *params):
-        logits, saved = module._forward_core(module._to_nhwc16(x), save=True)
+        logits, saved = module._forward_core(*module._to_nhwc16(x), save=True)
         ctx.module, ctx.saved = module, saved
         ctx.names = [n for n, _ in module.named_parameters()]
         return logits.permute(0, 3, 1, 2)  # NCHW view of the NHWC buffer
@@ -120,20 +137,25 @@ class FeatureDecoder(_Packed):
         """NCHW fp32 (reference call convention) -> NHWC 16-bit operand."""
         B, C, H, W = x.shape
         x2 = x.detach().permute(0, 2, 3, 1).contiguous().float().view(B * H * W, C)
-        return ops.cast_pad(x2, C, config.operand_dtype).view(B, H, W, C)
+        hi = ops.cast_pad(x2, C, config.operand_dtype).view(B, H, W, C)
+        lo = ops.cast_pad(x2, C, config.operand_dtype, part=1).view(B, H, W, C) if config.split_conv else None
+        return hi, lo
 
-    def _forward_core(self, x16, save: bool):
-        dt = config.operand_dtype
+    def _forward_core(self, x16, x_lo, save: bool):
+        """(x16, x_lo|None): NHWC 16-bit decoder input (x_lo = rounding residual for split precision)."""
         saved: List = []
-        a = x16
+        a = (x16, x_lo)
         for i in range(1, 5):
             seq = getattr(self, f"decoder_{i}")
-            a, st = conv_bn_relu_up_forward(self, f"d{i}", a, seq[0], seq[1], 2, self.sync_bn, save)
+            a, st = conv_bn_relu_up_forward(self, f"d{i}", a[0], a[1], seq[0], seq[1], 2, self.sync_bn, save)
             saved.append(st)
-        wf = _pack(self._cache, "final.w", self.final_out.weight,
-                   lambda p: ops.pack_conv_weight(p.float().contiguous(), 0, dt))
-        logits = ops.conv_gemm(a, wf, 3, 3, 1, 1, bias_n=self._f32("final.b", self.final_out.bias))
-        saved.append(a if save else None)
+        w_hi, w_lo = _conv_weights(self, "final", self.final_out, a[1] is not None)
+        bias = self._f32("final.b", self.final_out.bias)
+        if a[1] is not None:
+            logits = ops.conv_gemm_split(a[0], a[1], w_hi, w_lo, 3, 3, 1, 1, bias_n=bias)
+        else:
+            logits = ops.conv_gemm(a[0], w_hi, 3, 3, 1, 1, bias_n=bias)
+        saved.append(a[0] if save else None)
         return logits, saved
 
     def _backward_core(self, saved, d16, bias_partial, inv_scale, grads, dlogits_f32=None, stage_done=None):
@@ -165,5 +187,5 @@ class FeatureDecoder(_Packed):
         """`decoders.py:137-164`: (B, 3*embed, h, w) fp32 -> logits (B, classes, 16h, 16w) fp32."""
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             return _DecoderFn.apply(self, x, *list(self.parameters()))
-        logits, _ = self._forward_core(self._to_nhwc16(x), save=False)
+        logits, _ = self._forward_core(*self._to_nhwc16(x), save=False)
         return logits.permute(0, 3, 1, 2)

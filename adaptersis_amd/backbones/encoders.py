@@ -48,55 +48,77 @@ class FeatureEncoder(_Packed):
         self.fc4 = nn.Conv2d(8 * inplanes, embed_dim, kernel_size=1, stride=1, padding=0, bias=True)
 
     # -- helpers ---------------------------------------------------------------------------------
-    def _wconv(self, key, conv):
-        return _pack(self._cache, key, conv.weight, lambda p: ops.pack_conv_weight(p.float().contiguous(), 0,
-                                                                                    config.operand_dtype))
+    def _wconv(self, key, conv, part=0):
+        return _pack(self._cache, f"{key}.p{part}", conv.weight,
+                     lambda p: ops.pack_conv_weight(p.float().contiguous(), 0, config.operand_dtype, part))
 
-    def _conv_bn(self, x16, key, conv, bn, sync):
-        """x16 NHWC 16-bit -> (raw fp32 NHWC, scale, shift)."""
+    def _conv_bn(self, a, key, conv, bn, sync):
+        """a = (hi, lo|None) NHWC 16-bit -> (raw fp32 NHWC, scale, shift)."""
+        x16, x_lo = a
         B, H, W, _ = x16.shape
         s, p = conv.stride[0], conv.padding[0]
         OH, OW = (H + 2 * p - 3) // s + 1, (W + 2 * p - 3) // s + 1
         stats = torch.empty((ops.gemm_tiles_m(B * OH * OW), 2, conv.out_channels), device=x16.device, dtype=torch.float32)
-        raw = ops.conv_gemm(x16, self._wconv(key, conv), 3, 3, s, p, stats=stats)
+        if x_lo is not None:
+            raw = ops.conv_gemm_split(x16, x_lo, self._wconv(key, conv), self._wconv(key, conv, 1), 3, 3, s, p, stats=stats)
+        else:
+            raw = ops.conv_gemm(x16, self._wconv(key, conv), 3, 3, s, p, stats=stats)
         scale, shift, _, _, _ = _bn.finalize(stats, B * OH * OW, bn, sync)
         return raw, scale, shift
+
+    @staticmethod
+    def _pair(r, split):
+        return r if split else (r, None)
+
+    def _fc(self, i, fc, a, out):
+        """1x1 conv as a (split-precision) GEMM writing into its slice of the token buffer."""
+        hi, lo = a
+        B, h, w, Cs = hi.shape
+        w_hi = self._w16(f"fc{i}", fc.weight)
+        bias = self._f32(f"fc{i}_b", fc.bias)
+        if lo is not None:
+            w_lo = _pack(self._cache, f"fc{i}.lo", fc.weight,
+                         lambda p: ops.cast_pad(p.reshape(p.shape[0], -1).contiguous().float(),
+                                                dtype=config.operand_dtype, part=1))
+            ops.gemm_split(hi.view(B, h * w, Cs), lo.view(B, h * w, Cs), w_hi, w_lo, out=out, bias_n=bias)
+        else:
+            ops.gemm(hi.view(B, h * w, Cs), w_hi, out=out, bias_n=bias)
 
     def forward_tokens(self, x, need_c1=False, sync_bn=True):
         """-> (c1 NHWC fp32 or None, c tokens fp32 [B, n2+n3+n4, D], [(h2,w2),(h3,w3),(h4,w4)])."""
         dt = config.operand_dtype
+        sp = config.split_conv
         x = x.float().contiguous()
         B = x.shape[0]
         D = self.embed_dim
         st = self.stem
         raw = ops.conv3x3_c3(x, self._f32("stem0", st[0].weight), 2, 1)
         scale, shift, _, _, _ = _bn.finalize(ops.colstats(raw), raw.numel() // raw.shape[-1], st[1], sync_bn)
-        a = ops.bn_act(raw, scale, shift, True, dt)
+        a = self._pair(ops.bn_act(raw, scale, shift, True, dt, sp), sp)
         raw, scale, shift = self._conv_bn(a, "stem3", st[3], st[4], sync_bn)
-        a = ops.bn_act(raw, scale, shift, True, dt)
+        a = self._pair(ops.bn_act(raw, scale, shift, True, dt, sp), sp)
         raw, scale, shift = self._conv_bn(a, "stem6", st[6], st[7], sync_bn)
-        s1 = ops.bn_relu_maxpool(raw, scale, shift, dt)  # [B,147,147,C]
+        s1 = self._pair(ops.bn_relu_maxpool(raw, scale, shift, dt, sp), sp)  # [B,147,147,C]
         raw, scale, shift = self._conv_bn(s1, "conv2", self.conv2[0], self.conv2[1], sync_bn)
-        s2 = ops.bn_act(raw, scale, shift, True, dt)
+        s2 = self._pair(ops.bn_act(raw, scale, shift, True, dt, sp), sp)
         raw, scale, shift = self._conv_bn(s2, "conv3", self.conv3[0], self.conv3[1], sync_bn)
-        s3 = ops.bn_act(raw, scale, shift, True, dt)
+        s3 = self._pair(ops.bn_act(raw, scale, shift, True, dt, sp), sp)
         raw, scale, shift = self._conv_bn(s3, "conv4", self.conv4[0], self.conv4[1], sync_bn)
-        s4 = ops.bn_act(raw, scale, shift, True, dt)
-        shapes = [tuple(t.shape[1:3]) for t in (s2, s3, s4)]
+        s4 = self._pair(ops.bn_act(raw, scale, shift, True, dt, sp), sp)
+        shapes = [tuple(t[0].shape[1:3]) for t in (s2, s3, s4)]
         sizes = [h * w for h, w in shapes]
         ntok = sum(sizes)
         c = torch.empty((B, ntok, D), device=x.device, dtype=torch.float32)
         off = 0
         for i, (s, fc) in enumerate(((s2, self.fc2), (s3, self.fc3), (s4, self.fc4))):
-            n = sizes[i]
-            ops.gemm(s.view(B, n, s.shape[-1]), self._w16(f"fc{i + 2}", fc.weight), out=c[:, off:off + n],
-                     bias_n=self._f32(f"fc{i + 2}_b", fc.bias))
-            off += n
+            self._fc(i + 2, fc, s, c[:, off:off + sizes[i]])
+            off += sizes[i]
         c1 = None
         if need_c1:
-            h1, w1 = s1.shape[1:3]
-            c1 = ops.gemm(s1.view(B * h1 * w1, s1.shape[-1]), self._w16("fc1", self.fc1.weight), out_f32=True,
-                          bias_n=self._f32("fc1_b", self.fc1.bias)).view(B, h1, w1, D)
+            h1, w1 = s1[0].shape[1:3]
+            c1 = torch.empty((B, h1 * w1, D), device=x.device, dtype=torch.float32)
+            self._fc(1, self.fc1, s1, c1)
+            c1 = c1.view(B, h1, w1, D)
         return c1, c, shapes
 
     def forward(self, x):

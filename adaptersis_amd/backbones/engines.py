@@ -117,8 +117,8 @@ class SegEngine(nn.Module):
         return cn.ffn.forward16(cn._ln16("ffn_norm", out), out, B, Lq, grids) if cn.with_cffn else out
 
     @torch.no_grad()
-    def features(self, inp: torch.Tensor, taps: Optional[dict] = None) -> torch.Tensor:
-        """`train.py:275-406`: image batch -> decoder input, NHWC 16-bit [B, h, w, 3D]."""
+    def features(self, inp: torch.Tensor, taps: Optional[dict] = None):
+        """`train.py:275-406`: image batch -> decoder input, NHWC 16-bit [B, h, w, 3D] as (hi, lo|None)."""
         m = self.model
         B, _, H, W = inp.shape
         inp = inp.float().contiguous()
@@ -156,9 +156,12 @@ class SegEngine(nn.Module):
             c2d = self._cacnn(c2d, x2, g, B, Lc, N, shapes)
             x = ops.add_f32(x2.view(B, N, D), feats[s])
         n4 = shapes[2][0] * shapes[2][1]
-        cat = ops.decoder_input(x, c_orig[:, Lc - n4:], feats[-1], (h, w), shapes[2], config.operand_dtype)
+        cat = ops.decoder_input(x, c_orig[:, Lc - n4:], feats[-1], (h, w), shapes[2], config.operand_dtype,
+                                config.split_conv)
+        if not config.split_conv:
+            cat = (cat, None)
         if taps is not None:
-            taps.update(x_final=x, c_final=c2d.view(B, Lc, D), cat=cat)
+            taps.update(x_final=x, c_final=c2d.view(B, Lc, D), cat=cat[0])
         return cat
 
     # ------------------------------------------------------------------------------------------
@@ -176,7 +179,7 @@ class SegEngine(nn.Module):
         dec = self.seg_decoder
         S = config.loss_scale
         cat = self.features(inp, taps)
-        logits, saved = dec._forward_core(cat, save=True)
+        logits, saved = dec._forward_core(cat[0], cat[1], save=True)
         target = target.long().contiguous()
         loss, coef, _ = ops.dice_fwd(logits, target, 2, 10e-20, S)
         dz = ops.dice_bwd(logits, target, coef, 2)
@@ -203,5 +206,5 @@ class SegEngine(nn.Module):
 
     @torch.no_grad()
     def eval_logits(self, inp: torch.Tensor) -> torch.Tensor:
-        logits, _ = self.seg_decoder._forward_core(self.features(inp), save=False)
+        logits, _ = self.seg_decoder._forward_core(*self.features(inp), save=False)
         return logits  # NHWC fp32

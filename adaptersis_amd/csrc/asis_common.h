@@ -67,7 +67,9 @@ template <> struct T16<bf16> {
   }
 };
 
-template <typename T> __device__ __forceinline__ T to_t16(float x) { return (T)x; }  // T = float passes through   // RNE; fp16 saturates to inf
+template <typename T> __device__ __forceinline__ T to_t16(float x) { return (T)x; }  // RNE (fp16 saturates to inf); T = float passes through
+// residual of the 16-bit rounding: x ~= (float)hi + (float)lo with ~22 significant bits (split-precision GEMM operands)
+template <typename T> __device__ __forceinline__ float lo_part(float x) { return x - (float)((T)x); }
 template <typename T> __device__ __forceinline__ float from_t16(T x) { return (float)x; }
 
 // pack two floats into one 32-bit word of two T (lo = first)

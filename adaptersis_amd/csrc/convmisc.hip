@@ -149,7 +149,7 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, double count
 template <typename T>
 __global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                                      const float* __restrict__ shift, int relu, T* __restrict__ out,
-                                                     int64_t R, int C) {
+                                                     T* __restrict__ out_lo, int64_t R, int C) {
   const int cpt = C >> 2;
   const int64_t total = R * cpt;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -164,6 +164,11 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ x
     o.x = pack2<T>(a0, a1);
     o.y = pack2<T>(a2, a3);
     reinterpret_cast<uint2*>(out)[i] = o;
+    if (out_lo) {
+      o.x = pack2<T>(lo_part<T>(a0), lo_part<T>(a1));
+      o.y = pack2<T>(lo_part<T>(a2), lo_part<T>(a3));
+      reinterpret_cast<uint2*>(out_lo)[i] = o;
+    }
   }
 }
 
@@ -171,7 +176,8 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ x
 template <typename T>
 __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                                               const float* __restrict__ shift, T* __restrict__ out,
-                                                              int B, int H, int W, int OH, int OW, int C) {
+                                                              T* __restrict__ out_lo, int B, int H, int W, int OH,
+                                                              int OW, int C) {
   const int cpt = C >> 2;
   const int64_t total = (int64_t)B * OH * OW * cpt;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -199,6 +205,11 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const float* __res
     o.x = pack2<T>(m.x, m.y);
     o.y = pack2<T>(m.z, m.w);
     reinterpret_cast<uint2*>(out + pix * C)[c] = o;
+    if (out_lo) {
+      o.x = pack2<T>(lo_part<T>(m.x), lo_part<T>(m.y));
+      o.y = pack2<T>(lo_part<T>(m.z), lo_part<T>(m.w));
+      reinterpret_cast<uint2*>(out_lo + pix * C)[c] = o;
+    }
   }
 }
 
@@ -206,7 +217,8 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const float* __res
 template <typename T>
 __global__ __launch_bounds__(256) void bn_relu_upsample_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                                                const float* __restrict__ shift, T* __restrict__ out,
-                                                               int B, int H, int W, int OH, int OW, int C) {
+                                                               T* __restrict__ out_lo, int B, int H, int W, int OH,
+                                                               int OW, int C) {
   const int cpt = C >> 2;
   const float rh = OH > 1 ? (float)(H - 1) / (float)(OH - 1) : 0.f;
   const float rw = OW > 1 ? (float)(W - 1) / (float)(OW - 1) : 0.f;
@@ -238,6 +250,11 @@ __global__ __launch_bounds__(256) void bn_relu_upsample_kernel(const float* __re
     o.x = pack2<T>(acc.x, acc.y);
     o.y = pack2<T>(acc.z, acc.w);
     reinterpret_cast<uint2*>(out + pix * C)[c] = o;
+    if (out_lo) {
+      o.x = pack2<T>(lo_part<T>(acc.x), lo_part<T>(acc.y));
+      o.y = pack2<T>(lo_part<T>(acc.z), lo_part<T>(acc.w));
+      reinterpret_cast<uint2*>(out_lo + pix * C)[c] = o;
+    }
   }
 }
 
@@ -247,7 +264,7 @@ __global__ __launch_bounds__(256) void bn_relu_upsample_kernel(const float* __re
 template <typename T>
 __global__ __launch_bounds__(256) void pack_conv_weight_kernel(const float* __restrict__ w, T* __restrict__ out,
                                                                int Cout, int Cin, int KH, int KW, int mode, int CoP,
-                                                               int64_t ldo, int rows) {
+                                                               int64_t ldo, int rows, int part) {
   const int64_t total = (int64_t)rows * ldo;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int r = (int)(i / ldo);
@@ -266,7 +283,7 @@ __global__ __launch_bounds__(256) void pack_conv_weight_kernel(const float* __re
         if (co < Cout) v = w[(((int64_t)co * Cin + r) * KH + kh) * KW + kw];
       }
     }
-    out[i] = to_t16<T>(v);
+    out[i] = to_t16<T>(part ? lo_part<T>(v) : v);
   }
 }
 
@@ -275,8 +292,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void decoder_input_kernel(const float* __restrict__ xs, int64_t xs_bstride,
                                                             const float* __restrict__ c4, int64_t c4_bstride,
                                                             const float* __restrict__ vit, int64_t vit_bstride,
-                                                            T* __restrict__ out, int B, int h, int w, int h4, int w4,
-                                                            int D) {
+                                                            T* __restrict__ out, T* __restrict__ out_lo, int B, int h,
+                                                            int w, int h4, int w4, int D) {
   const int cpt = (3 * D) >> 2;
   const int dq = D >> 2;
   const int py = (h - h4) / 2, px = (w - w4) / 2;  // F.pad([dx//2, dx-dx//2, dy//2, dy-dy//2])
@@ -301,6 +318,11 @@ __global__ __launch_bounds__(256) void decoder_input_kernel(const float* __restr
     o.x = pack2<T>(v.x, v.y);
     o.y = pack2<T>(v.z, v.w);
     reinterpret_cast<uint2*>(out + pix * 3 * D)[c] = o;
+    if (out_lo) {
+      o.x = pack2<T>(lo_part<T>(v.x), lo_part<T>(v.y));
+      o.y = pack2<T>(lo_part<T>(v.z), lo_part<T>(v.w));
+      reinterpret_cast<uint2*>(out_lo + pix * 3 * D)[c] = o;
+    }
   }
 }
 
@@ -374,7 +396,7 @@ extern "C" int asis_bn_finalize(void* stream, const double* sums, double count, 
 }
 
 extern "C" int asis_bn_act(void* stream, int dtype, const float* x, const float* scale, const float* shift, int relu,
-                           void* out, int64_t R, int C) {
+                           void* out, void* out_lo, int64_t R, int C) {
   ASIS_REQUIRE(x && scale && shift && out, "asis_bn_act: null pointer");
   ASIS_REQUIRE(C % 4 == 0 && C > 0, "asis_bn_act: C=%d must be a multiple of 4", C);
   DT_OK(dtype, "asis_bn_act");
@@ -382,16 +404,16 @@ extern "C" int asis_bn_act(void* stream, int dtype, const float* x, const float*
   const int64_t total = R * (C / 4);
   if (dtype == ASIS_F16)
     hipLaunchKernelGGL((bn_act_kernel<f16>), dim3(grid_for(total)), dim3(256), 0, s, x, scale, shift, relu,
-                       reinterpret_cast<f16*>(out), R, C);
+                       reinterpret_cast<f16*>(out), reinterpret_cast<f16*>(out_lo), R, C);
   else
     hipLaunchKernelGGL((bn_act_kernel<bf16>), dim3(grid_for(total)), dim3(256), 0, s, x, scale, shift, relu,
-                       reinterpret_cast<bf16*>(out), R, C);
+                       reinterpret_cast<bf16*>(out), reinterpret_cast<bf16*>(out_lo), R, C);
   ASIS_CHECK_LAUNCH("asis_bn_act");
   return ASIS_OK;
 }
 
 extern "C" int asis_bn_relu_maxpool(void* stream, int dtype, const float* x, const float* scale, const float* shift,
-                                    void* out, int B, int H, int W, int C) {
+                                    void* out, void* out_lo, int B, int H, int W, int C) {
   ASIS_REQUIRE(x && scale && shift && out, "asis_bn_relu_maxpool: null pointer");
   ASIS_REQUIRE(C % 4 == 0 && C > 0, "asis_bn_relu_maxpool: C=%d must be a multiple of 4", C);
   DT_OK(dtype, "asis_bn_relu_maxpool");
@@ -400,16 +422,16 @@ extern "C" int asis_bn_relu_maxpool(void* stream, int dtype, const float* x, con
   const int64_t total = (int64_t)B * OH * OW * (C / 4);
   if (dtype == ASIS_F16)
     hipLaunchKernelGGL((bn_relu_maxpool_kernel<f16>), dim3(grid_for(total)), dim3(256), 0, s, x, scale, shift,
-                       reinterpret_cast<f16*>(out), B, H, W, OH, OW, C);
+                       reinterpret_cast<f16*>(out), reinterpret_cast<f16*>(out_lo), B, H, W, OH, OW, C);
   else
     hipLaunchKernelGGL((bn_relu_maxpool_kernel<bf16>), dim3(grid_for(total)), dim3(256), 0, s, x, scale, shift,
-                       reinterpret_cast<bf16*>(out), B, H, W, OH, OW, C);
+                       reinterpret_cast<bf16*>(out), reinterpret_cast<bf16*>(out_lo), B, H, W, OH, OW, C);
   ASIS_CHECK_LAUNCH("asis_bn_relu_maxpool");
   return ASIS_OK;
 }
 
 extern "C" int asis_bn_relu_upsample(void* stream, int dtype, const float* x, const float* scale, const float* shift,
-                                     void* out, int B, int H, int W, int C, int factor) {
+                                     void* out, void* out_lo, int B, int H, int W, int C, int factor) {
   ASIS_REQUIRE(x && scale && shift && out, "asis_bn_relu_upsample: null pointer");
   ASIS_REQUIRE(C % 4 == 0 && C > 0 && factor >= 1, "asis_bn_relu_upsample: bad C=%d / factor=%d", C, factor);
   DT_OK(dtype, "asis_bn_relu_upsample");
@@ -418,16 +440,16 @@ extern "C" int asis_bn_relu_upsample(void* stream, int dtype, const float* x, co
   const int64_t total = (int64_t)B * OH * OW * (C / 4);
   if (dtype == ASIS_F16)
     hipLaunchKernelGGL((bn_relu_upsample_kernel<f16>), dim3(grid_for(total)), dim3(256), 0, s, x, scale, shift,
-                       reinterpret_cast<f16*>(out), B, H, W, OH, OW, C);
+                       reinterpret_cast<f16*>(out), reinterpret_cast<f16*>(out_lo), B, H, W, OH, OW, C);
   else
     hipLaunchKernelGGL((bn_relu_upsample_kernel<bf16>), dim3(grid_for(total)), dim3(256), 0, s, x, scale, shift,
-                       reinterpret_cast<bf16*>(out), B, H, W, OH, OW, C);
+                       reinterpret_cast<bf16*>(out), reinterpret_cast<bf16*>(out_lo), B, H, W, OH, OW, C);
   ASIS_CHECK_LAUNCH("asis_bn_relu_upsample");
   return ASIS_OK;
 }
 
 extern "C" int asis_pack_conv_weight(void* stream, int dtype, const float* w, void* out, int Cout, int Cin, int KH,
-                                     int KW, int mode, int64_t ldo) {
+                                     int KW, int mode, int64_t ldo, int part) {
   ASIS_REQUIRE(w && out, "asis_pack_conv_weight: null pointer");
   ASIS_REQUIRE(mode == 0 || mode == 1, "asis_pack_conv_weight: bad mode %d", mode);
   DT_OK(dtype, "asis_pack_conv_weight");
@@ -439,17 +461,17 @@ extern "C" int asis_pack_conv_weight(void* stream, int dtype, const float* w, vo
   const int64_t total = (int64_t)rows * ldo;
   if (dtype == ASIS_F16)
     hipLaunchKernelGGL((pack_conv_weight_kernel<f16>), dim3(grid_for(total)), dim3(256), 0, s, w,
-                       reinterpret_cast<f16*>(out), Cout, Cin, KH, KW, mode, CoP, ldo, rows);
+                       reinterpret_cast<f16*>(out), Cout, Cin, KH, KW, mode, CoP, ldo, rows, part);
   else
     hipLaunchKernelGGL((pack_conv_weight_kernel<bf16>), dim3(grid_for(total)), dim3(256), 0, s, w,
-                       reinterpret_cast<bf16*>(out), Cout, Cin, KH, KW, mode, CoP, ldo, rows);
+                       reinterpret_cast<bf16*>(out), Cout, Cin, KH, KW, mode, CoP, ldo, rows, part);
   ASIS_CHECK_LAUNCH("asis_pack_conv_weight");
   return ASIS_OK;
 }
 
 extern "C" int asis_decoder_input(void* stream, int dtype, const float* xs, int64_t xs_bstride, const float* c4,
-                                  int64_t c4_bstride, const float* vit, int64_t vit_bstride, void* out, int B, int h,
-                                  int w, int h4, int w4, int D) {
+                                  int64_t c4_bstride, const float* vit, int64_t vit_bstride, void* out, void* out_lo,
+                                  int B, int h, int w, int h4, int w4, int D) {
   ASIS_REQUIRE(xs && c4 && vit && out, "asis_decoder_input: null pointer");
   ASIS_REQUIRE(D % 4 == 0 && h4 <= h && w4 <= w, "asis_decoder_input: bad shape");
   ASIS_REQUIRE(c4_bstride % 4 == 0 && xs_bstride % 4 == 0 && vit_bstride % 4 == 0 && asis_aligned16(xs) &&
@@ -459,10 +481,10 @@ extern "C" int asis_decoder_input(void* stream, int dtype, const float* xs, int6
   const int64_t total = (int64_t)B * h * w * (3 * D / 4);
   if (dtype == ASIS_F16)
     hipLaunchKernelGGL((decoder_input_kernel<f16>), dim3(grid_for(total)), dim3(256), 0, s, xs, xs_bstride, c4, c4_bstride, vit,
-                       vit_bstride, reinterpret_cast<f16*>(out), B, h, w, h4, w4, D);
+                       vit_bstride, reinterpret_cast<f16*>(out), reinterpret_cast<f16*>(out_lo), B, h, w, h4, w4, D);
   else
     hipLaunchKernelGGL((decoder_input_kernel<bf16>), dim3(grid_for(total)), dim3(256), 0, s, xs, xs_bstride, c4, c4_bstride, vit,
-                       vit_bstride, reinterpret_cast<bf16*>(out), B, h, w, h4, w4, D);
+                       vit_bstride, reinterpret_cast<bf16*>(out), reinterpret_cast<bf16*>(out_lo), B, h, w, h4, w4, D);
   ASIS_CHECK_LAUNCH("asis_decoder_input");
   return ASIS_OK;
 }

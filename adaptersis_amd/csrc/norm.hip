@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void add_cls_pos_kernel(const float4* __restri
 
 template <typename T>
 __global__ __launch_bounds__(256) void cast_pad_kernel(const float* __restrict__ src, int64_t ld_src,
-                                                       T* __restrict__ dst, int64_t ld_dst, int64_t rows, int cols, float scale) {
+                                                       T* __restrict__ dst, int64_t ld_dst, int64_t rows, int cols, float scale, int part) {
   const int cpr = (int)(ld_dst >> 3);  // 8-element chunks per row
   const int64_t total = rows * cpr;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -85,7 +85,10 @@ __global__ __launch_bounds__(256) void cast_pad_kernel(const float* __restrict__
     const int c0 = (int)(i - r * cpr) * 8;
     float f[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) f[j] = (c0 + j < cols) ? src[r * ld_src + c0 + j] * scale : 0.f;
+    for (int j = 0; j < 8; ++j) {
+      f[j] = (c0 + j < cols) ? src[r * ld_src + c0 + j] * scale : 0.f;
+      if (part) f[j] = lo_part<T>(f[j]);
+    }
     uint4 p;
     p.x = pack2<T>(f[0], f[1]);
     p.y = pack2<T>(f[2], f[3]);
@@ -176,7 +179,7 @@ extern "C" int asis_add_cls_pos(void* stream, const float* x, const float* cls, 
 }
 
 extern "C" int asis_cast_pad(void* stream, int dtype, const float* src, int64_t ld_src, void* dst, int64_t ld_dst,
-                             int64_t rows, int cols, float scale) {
+                             int64_t rows, int cols, float scale, int part) {
   ASIS_REQUIRE(src && dst, "asis_cast_pad: null pointer");
   ASIS_REQUIRE(ld_dst % 8 == 0 && ld_dst >= cols && ld_src >= cols, "asis_cast_pad: bad leading dims");
   ASIS_REQUIRE(asis_aligned16(dst), "asis_cast_pad: dst must be 16-byte aligned");
@@ -186,10 +189,10 @@ extern "C" int asis_cast_pad(void* stream, int dtype, const float* src, int64_t 
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (dtype == ASIS_F16)
     hipLaunchKernelGGL((cast_pad_kernel<f16>), dim3(grid_for(total)), dim3(256), 0, s, src, ld_src,
-                       reinterpret_cast<f16*>(dst), ld_dst, rows, cols, scale);
+                       reinterpret_cast<f16*>(dst), ld_dst, rows, cols, scale, part);
   else
     hipLaunchKernelGGL((cast_pad_kernel<bf16>), dim3(grid_for(total)), dim3(256), 0, s, src, ld_src,
-                       reinterpret_cast<bf16*>(dst), ld_dst, rows, cols, scale);
+                       reinterpret_cast<bf16*>(dst), ld_dst, rows, cols, scale, part);
   ASIS_CHECK_LAUNCH("asis_cast_pad");
   return ASIS_OK;
 }

@@ -100,7 +100,7 @@ def gemm_tiles_m(M: int) -> int:
 
 def conv_gemm(x_nhwc: torch.Tensor, w_packed: torch.Tensor, KH: int, KW: int, stride: int, pad: int, *,
               out: Optional[torch.Tensor] = None, out_f32: bool = True, bias_n: Optional[torch.Tensor] = None,
-              act: int = ACT_NONE, stats: Optional[torch.Tensor] = None) -> torch.Tensor:
+              act: int = ACT_NONE, stats: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
     """Implicit-GEMM convolution: x [B,H,W,Cin] (16-bit NHWC), w_packed [Cout, KH*KW*Cin] ->
     out [B,OH,OW,Cout] (fp32 by default: BatchNorm statistics are taken on it)."""
     _dev(x_nhwc, w_packed, out, bias_n, stats)
@@ -117,11 +117,33 @@ def conv_gemm(x_nhwc: torch.Tensor, w_packed: torch.Tensor, KH: int, KW: int, st
     d.lda, d.ldb, d.ldc = K, w_packed.stride(0), Cout
     d.batch, d.M, d.N, d.K = 1, Bn * OH * OW, Cout, K
     d.bias_n = _p(_f32c(bias_n))
+    if accumulate:  # out += conv(x, w): the epilogue adds the previous fp32 contents (same element, same thread)
+        if out.dtype != torch.float32:
+            raise ValueError("conv_gemm: accumulate needs an fp32 output")
+        d.res, d.ldr = out.data_ptr(), Cout
     d.act, d.out_f32, d.dtype = act, int(out.dtype == torch.float32), _dt(x_nhwc.dtype)
     d.conv, d.B_, d.H, d.W, d.Cin, d.OH, d.OW = 1, Bn, H, W, Cin, OH, OW
     d.KH, d.KW, d.stride, d.pad = KH, KW, stride, pad
     d.stats = _p(stats)
     check(lib().asis_gemm(_stream(), C.byref(d)), "asis_gemm(conv)")
+    return out
+
+
+def conv_gemm_split(x_hi, x_lo, w_hi, w_lo, KH: int, KW: int, stride: int, pad: int, *, bias_n=None, stats=None):
+    """Split-precision convolution: x ~= x_hi + x_lo, w ~= w_hi + w_lo (16-bit halves), fp32 out =
+    x_hi*w_hi + x_lo*w_hi + x_hi*w_lo (+ bias) as three MFMA passes accumulating in fp32 (the dropped
+    x_lo*w_lo term is ~2^-22 relative).  BatchNorm statistics are taken on the last pass."""
+    out = conv_gemm(x_hi, w_hi, KH, KW, stride, pad, bias_n=bias_n)
+    conv_gemm(x_lo, w_hi, KH, KW, stride, pad, out=out, accumulate=True)
+    conv_gemm(x_hi, w_lo, KH, KW, stride, pad, out=out, accumulate=True, stats=stats)
+    return out
+
+
+def gemm_split(a_hi, a_lo, b_hi, b_lo, *, out: torch.Tensor, bias_n=None):
+    """Split-precision ``out = (a_hi + a_lo) @ (b_hi + b_lo).T + bias`` into an fp32 ``out`` (three passes)."""
+    gemm(a_hi, b_hi, out=out, bias_n=bias_n)
+    gemm(a_lo, b_hi, out=out, res=out)
+    gemm(a_hi, b_lo, out=out, res=out)
     return out
 
 
@@ -172,7 +194,7 @@ def im2col_patch(img: torch.Tensor, P: int, ldk: int, dtype: torch.dtype = T16_D
 
 
 def cast_pad(src: torch.Tensor, ld_dst: Optional[int] = None, dtype: torch.dtype = T16_DEFAULT,
-             scale: float = 1.0) -> torch.Tensor:
+             scale: float = 1.0, part: int = 0) -> torch.Tensor:
     """float32 [rows, cols] -> 16-bit [rows, ld_dst] with zero-filled pad columns (weight packing)."""
     _dev(src)
     if src.dtype != torch.float32 or src.dim() != 2 or src.stride(1) != 1:
@@ -181,7 +203,7 @@ def cast_pad(src: torch.Tensor, ld_dst: Optional[int] = None, dtype: torch.dtype
     ld = ld_dst if ld_dst is not None else (cols + 7) // 8 * 8
     out = torch.empty((rows, ld), device=src.device, dtype=dtype)
     check(lib().asis_cast_pad(_stream(), _dt(dtype), src.data_ptr(), src.stride(0), out.data_ptr(), ld, rows, cols,
-                              float(scale)),
+                              float(scale), int(part)),
           "asis_cast_pad")
     return out
 
@@ -273,35 +295,44 @@ def bn_finalize(sums: torch.Tensor, count: float, gamma, beta, eps: float, momen
     return out[0], out[1], out[2], out[3]
 
 
-def bn_act(x: torch.Tensor, scale, shift, relu: bool, dtype: torch.dtype) -> torch.Tensor:
+def _lo(out: torch.Tensor, split: bool):
+    return torch.empty_like(out) if split else None
+
+
+def bn_act(x: torch.Tensor, scale, shift, relu: bool, dtype: torch.dtype, split: bool = False):
+    """-> out (and (out, out_lo) when split: the two halves of a split-precision operand)."""
     _dev(x, scale, shift)
     Cc = x.shape[-1]
     out = torch.empty(x.shape, device=x.device, dtype=dtype)
+    lo = _lo(out, split)
     check(lib().asis_bn_act(_stream(), _dt(dtype), _f32c(x).data_ptr(), scale.data_ptr(), shift.data_ptr(), int(relu),
-                            out.data_ptr(), x.numel() // Cc, Cc), "asis_bn_act")
-    return out
+                            out.data_ptr(), _p(lo), x.numel() // Cc, Cc), "asis_bn_act")
+    return (out, lo) if split else out
 
 
-def bn_relu_maxpool(x: torch.Tensor, scale, shift, dtype: torch.dtype) -> torch.Tensor:
+def bn_relu_maxpool(x: torch.Tensor, scale, shift, dtype: torch.dtype, split: bool = False):
     _dev(x, scale, shift)
     B, H, W, Cc = x.shape
     out = torch.empty((B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, Cc), device=x.device, dtype=dtype)
+    lo = _lo(out, split)
     check(lib().asis_bn_relu_maxpool(_stream(), _dt(dtype), _f32c(x).data_ptr(), scale.data_ptr(), shift.data_ptr(),
-                                     out.data_ptr(), B, H, W, Cc), "asis_bn_relu_maxpool")
-    return out
+                                     out.data_ptr(), _p(lo), B, H, W, Cc), "asis_bn_relu_maxpool")
+    return (out, lo) if split else out
 
 
-def bn_relu_upsample(x: torch.Tensor, scale, shift, factor: int, dtype: torch.dtype) -> torch.Tensor:
+def bn_relu_upsample(x: torch.Tensor, scale, shift, factor: int, dtype: torch.dtype, split: bool = False):
     _dev(x, scale, shift)
     B, H, W, Cc = x.shape
     out = torch.empty((B, H * factor, W * factor, Cc), device=x.device, dtype=dtype)
+    lo = _lo(out, split)
     check(lib().asis_bn_relu_upsample(_stream(), _dt(dtype), _f32c(x).data_ptr(), scale.data_ptr(), shift.data_ptr(),
-                                      out.data_ptr(), B, H, W, Cc, factor), "asis_bn_relu_upsample")
-    return out
+                                      out.data_ptr(), _p(lo), B, H, W, Cc, factor), "asis_bn_relu_upsample")
+    return (out, lo) if split else out
 
 
-def pack_conv_weight(w: torch.Tensor, mode: int, dtype: torch.dtype) -> torch.Tensor:
-    """fp32 [Cout,Cin,KH,KW] -> mode 0: [Cout, KH*KW*Cin]; mode 1 (dgrad): [Cin, KH*KW*CoP]."""
+def pack_conv_weight(w: torch.Tensor, mode: int, dtype: torch.dtype, part: int = 0) -> torch.Tensor:
+    """fp32 [Cout,Cin,KH,KW] -> mode 0: [Cout, KH*KW*Cin]; mode 1 (dgrad): [Cin, KH*KW*CoP].
+    part=1 returns the rounding residual (second half of a split-precision operand)."""
     _dev(w)
     Cout, Cin, KH, KW = w.shape
     CoP = (Cout + 7) // 8 * 8
@@ -309,7 +340,7 @@ def pack_conv_weight(w: torch.Tensor, mode: int, dtype: torch.dtype) -> torch.Te
     ld = (K + 7) // 8 * 8
     out = torch.empty((rows, ld), device=w.device, dtype=dtype)
     check(lib().asis_pack_conv_weight(_stream(), _dt(dtype), _f32c(w).data_ptr(), out.data_ptr(), Cout, Cin, KH, KW,
-                                      mode, ld), "asis_pack_conv_weight")
+                                      mode, ld, int(part)), "asis_pack_conv_weight")
     return out[:, :K] if ld != K else out
 
 
@@ -318,7 +349,8 @@ def _rows3(t: torch.Tensor, D: int, what: str):
         raise ValueError(f"{what}: expected float32 [B, n, {D}] with contiguous rows (batch stride free)")
 
 
-def decoder_input(xs: torch.Tensor, c4: torch.Tensor, vit: torch.Tensor, hw, c4_hw, dtype: torch.dtype) -> torch.Tensor:
+def decoder_input(xs: torch.Tensor, c4: torch.Tensor, vit: torch.Tensor, hw, c4_hw, dtype: torch.dtype,
+                  split: bool = False):
     """train.py:389-406: xs, vit fp32 [B, h*w, D]; c4 fp32 [B, h4*w4, D] (batch strides free) -> [B,h,w,3D]."""
     _dev(xs, c4, vit)
     B, _, D = xs.shape
@@ -327,10 +359,11 @@ def decoder_input(xs: torch.Tensor, c4: torch.Tensor, vit: torch.Tensor, hw, c4_
     for t, n in ((xs, "xs"), (c4, "c4"), (vit, "vit")):
         _rows3(t, D, "decoder_input " + n)
     out = torch.empty((B, h, w, 3 * D), device=xs.device, dtype=dtype)
+    lo = _lo(out, split)
     check(lib().asis_decoder_input(_stream(), _dt(dtype), xs.data_ptr(), xs.stride(0), c4.data_ptr(), c4.stride(0),
-                                   vit.data_ptr(), vit.stride(0), out.data_ptr(), B, h, w, h4, w4, D),
+                                   vit.data_ptr(), vit.stride(0), out.data_ptr(), _p(lo), B, h, w, h4, w4, D),
           "asis_decoder_input")
-    return out
+    return (out, lo) if split else out
 
 
 def add_f32(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -121,9 +121,13 @@ int asis_im2col_patch(void* stream, int dtype, const float* img, int B, int Himg
                       int64_t ldk);
 
 /* fp32 -> 16-bit cast (x scale) with optional zero-padded columns: src [rows, cols] (ld_src) ->
- * dst [rows, ld_dst], columns cols..ld_dst-1 are written as zero.  Used to pack weights once. */
+ * dst [rows, ld_dst], columns cols..ld_dst-1 are written as zero.  Used to pack weights once.
+ * part = 0: hi = (dtype)v;  part = 1: lo = (dtype)(v - (float)hi)  — the two halves of a split-precision
+ * operand: v ~= hi + lo to ~22 bits.  The conv chains (encoder, decoder forward) run
+ * A_hi W_hi + A_lo W_hi + A_hi W_lo as three asis_gemm passes (res = previous pass) because five 16-bit
+ * conv layers in a row exceed the 1e-3 logits tolerance on their own (Numerics). */
 int asis_cast_pad(void* stream, int dtype, const float* src, int64_t ld_src, void* dst, int64_t ld_dst, int64_t rows,
-                  int cols, float scale);
+                  int cols, float scale, int part);
 
 /* tokens_A[b, 0, :] = cls + pos[0];  tokens_A[b, 1+t, :] = x[b, t, :] + pos[1+t]
  * (vision_transformer.py:196-197 with the interpolated pos-embed cached per (H,W)). fp32. */
@@ -169,25 +173,26 @@ int asis_reduce_partials(void* stream, const float* partial, int nparts, int C, 
 int asis_bn_finalize(void* stream, const double* sums, double count, int C, const float* gamma, const float* beta,
                      float eps, float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked,
                      float* scale, float* shift, float* mean_out, float* invstd_out);
-/* out(16-bit) = [relu](x*scale + shift), x fp32 [R, C] */
+/* out(16-bit) = [relu](x*scale + shift), x fp32 [R, C].  Every fused apply kernel below optionally
+ * also writes out_lo (NULL = skip): the rounding residual of out, second half of a split operand. */
 int asis_bn_act(void* stream, int dtype, const float* x, const float* scale, const float* shift, int relu, void* out,
-                int64_t R, int C);
+                void* out_lo, int64_t R, int C);
 /* BN + ReLU + MaxPool2d(3, stride 2, pad 1): x fp32 NHWC [B,H,W,C] -> 16-bit [B,OH,OW,C] (encoders.py:19) */
 int asis_bn_relu_maxpool(void* stream, int dtype, const float* x, const float* scale, const float* shift, void* out,
-                         int B, int H, int W, int C);
+                         void* out_lo, int B, int H, int W, int C);
 /* BN + ReLU + bilinear upsample xfactor, align_corners=True (decoders.py:112-113; MLAHead :38-45 with factor 4) */
 int asis_bn_relu_upsample(void* stream, int dtype, const float* x, const float* scale, const float* shift, void* out,
-                          int B, int H, int W, int C, int factor);
+                          void* out_lo, int B, int H, int W, int C, int factor);
 /* conv weight fp32 [Cout,Cin,KH,KW] -> 16-bit GEMM operand.
  * mode 0 (forward): out[co][(kh*KW+kw)*Cin+ci], rows Cout.
  * mode 1 (dgrad):   out[ci][((KH-1-kh)*KW+(KW-1-kw))*CoP+co], rows Cin, CoP = Cout rounded up to 8. */
 int asis_pack_conv_weight(void* stream, int dtype, const float* w, void* out, int Cout, int Cin, int KH, int KW,
-                          int mode, int64_t ldo);
+                          int mode, int64_t ldo, int part);
 /* decoder input (train.py:389-406): [xs | zero-padded c4 | vit] fp32 tokens -> 16-bit NHWC [B,h,w,3D];
  * every source has its own batch stride (elements) so token slices need no copies */
 int asis_decoder_input(void* stream, int dtype, const float* xs, int64_t xs_bstride, const float* c4,
-                       int64_t c4_bstride, const float* vit, int64_t vit_bstride, void* out, int B, int h, int w, int h4,
-                       int w4, int D);
+                       int64_t c4_bstride, const float* vit, int64_t vit_bstride, void* out, void* out_lo, int B, int h,
+                       int w, int h4, int w4, int D);
 /* out[b] = a[b] + b_[b] over n floats per batch element, each operand with its own batch stride
  * (fp32; train.py:320,343,365,387 residual adds with the cls-stripped pass-A features) */
 int asis_add_f32(void* stream, const float* a, const float* b, float* out, int64_t n, int batch, int64_t stride_a,

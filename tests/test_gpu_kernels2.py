@@ -213,3 +213,23 @@ def test_sgd_momentum_matches_torch(dev):
         opt.step()
         ops.sgd_momentum(p, (g * 64.0).to(dev), buf, 0.01, 0.99, 3e-5, 1.0 / 64.0, i == 0)
     assert rel_l2(p, pt.detach()) < 1e-6
+
+
+def test_split_precision_conv_matches_fp32(dev):
+    """hi/lo split operands (3 MFMA passes) reproduce the UNROUNDED fp32 convolution to ~1e-6."""
+    Bn, Cin, Cout, H = 2, 32, 48, 19
+    x = W.tensor("sp.x", (Bn, Cin, H, H), 1.0)
+    w = W.tensor("sp.w", (Cout, Cin, 3, 3), 0.2)
+    bias = W.tensor("sp.b", (Cout,), 0.5)
+    ref = F.conv2d(x, w, bias, padding=1).permute(0, 2, 3, 1)
+    xn = x.permute(0, 2, 3, 1).contiguous().view(-1, Cin).to(dev)
+    x_hi = ops.cast_pad(xn, Cin, torch.float16).view(Bn, H, H, Cin)
+    x_lo = ops.cast_pad(xn, Cin, torch.float16, part=1).view(Bn, H, H, Cin)
+    w_hi = ops.pack_conv_weight(w.to(dev), 0, torch.float16)
+    w_lo = ops.pack_conv_weight(w.to(dev), 0, torch.float16, 1)
+    stats = torch.empty(ops.gemm_tiles_m(Bn * H * H), 2, Cout, device=dev)
+    y = ops.conv_gemm_split(x_hi, x_lo, w_hi, w_lo, 3, 3, 1, 1, bias_n=bias.to(dev), stats=stats)
+    assert rel_l2(y, ref) < 3e-6
+    assert rel_l2(stats.sum(0)[0], ref.sum((0, 1, 2))) < 1e-4
+    y1 = ops.conv_gemm(x_hi, w_hi, 3, 3, 1, 1, bias_n=bias.to(dev))
+    assert rel_l2(y1, ref) > 1e-4  # single pass is limited by the 16-bit rounding of the operands
