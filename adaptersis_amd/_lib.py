@@ -93,11 +93,11 @@ SIGNATURES = {
     "asis_dice_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp],
     "asis_dice_bwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "asis_resize_bwd_nblk": [_i64],
-    "asis_resize_bilinear_bwd": [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp],
+    "asis_resize_bilinear_bwd": [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp],
     "asis_reduce_rows": [_vp, _vp, _i, _i, _f, _vp],
     "asis_ew_blocks": [_i64],
     "asis_upsample_bn_relu_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i],
-    "asis_bn_bwd_apply": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _vp, _vp, _i64, _i],
+    "asis_bn_bwd_apply": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _vp, _vp, _vp, _i64, _i],
     "asis_wgrad_splits": [_i64, _i, _i],
     "asis_wgrad": [_vp, C.POINTER(WgradDesc)],
     "asis_sgd_momentum": [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i],

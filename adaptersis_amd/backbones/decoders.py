@@ -78,8 +78,10 @@ def conv_bn_relu_up_backward(owner: _Packed, key: str, st: _Stage, dU, conv: nn.
     if sync_bn and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(red)  # SyncBatchNorm backward: 2C floats
     dbeta_s, dgamma_s = red[:C], red[C:]
-    dx16, bpart = ops.bn_bwd_apply(g, st.raw, st.mean, st.invstd, owner._f32(key + ".g", bn.weight), dgamma_s, dbeta_s,
-                                   st.count, dt)
+    split = config.split_conv and need_dx
+    r = ops.bn_bwd_apply(g, st.raw, st.mean, st.invstd, owner._f32(key + ".g", bn.weight), dgamma_s, dbeta_s,
+                         st.count, dt, split)
+    dx16, dx_lo, bpart = r if split else (r[0], None, r[1])
     ops.reduce_rows(dbeta_s.view(1, C), inv_scale, grads[prefix + ".1.bias"])      # unscale (n = 1 row)
     ops.reduce_rows(dgamma_s.view(1, C), inv_scale, grads[prefix + ".1.weight"])
     if conv.bias is not None:
@@ -87,8 +89,19 @@ def conv_bn_relu_up_backward(owner: _Packed, key: str, st: _Stage, dU, conv: nn.
     ops.wgrad(dx16, st.x16, C, 3, 3, 1, 1, inv_scale, out=grads[prefix + ".0.weight"])
     if not need_dx:
         return None
-    wdg = _pack(owner._cache, key + ".wd", conv.weight, lambda p: ops.pack_conv_weight(p.float().contiguous(), 1, dt))
-    return ops.conv_gemm(dx16, wdg, 3, 3, 1, 1)
+    return _dgrad(owner, key, conv, dx16, dx_lo)
+
+
+def _dgrad(owner: _Packed, key: str, conv: nn.Conv2d, d16, d_lo):
+    """dX = conv_transpose(dY): implicit GEMM on dY with flipped weights; split precision when d_lo is given
+    (the next stage's BatchNorm backward subtracts means: 16-bit rounding noise would be amplified)."""
+    dt = config.operand_dtype
+    wd = _pack(owner._cache, key + ".wd", conv.weight, lambda p: ops.pack_conv_weight(p.float().contiguous(), 1, dt))
+    if d_lo is None:
+        return ops.conv_gemm(d16, wd, 3, 3, 1, 1)
+    wd_lo = _pack(owner._cache, key + ".wdlo", conv.weight,
+                  lambda p: ops.pack_conv_weight(p.float().contiguous(), 1, dt, 1))
+    return ops.conv_gemm_split(d16, d_lo, wd, wd_lo, 3, 3, 1, 1)
 
 
 class _DecoderFn(torch.autograd.Function):
@@ -110,8 +123,9 @@ class _DecoderFn(torch.autograd.Function):
         d = dlogits.permute(0, 2, 3, 1).contiguous().float().view(B * h * w, C)
         CP = (C + 7) // 8 * 8
         d16 = ops.cast_pad(d, CP, dt, scale=S).view(B, h, w, CP)
+        d_lo = ops.cast_pad(d, CP, dt, scale=S, part=1).view(B, h, w, CP) if config.split_conv else None
         grads = {n: torch.empty_like(p) for n, p in m.named_parameters()}
-        m._backward_core(ctx.saved, d16, None, 1.0 / S, grads, dlogits_f32=d)
+        m._backward_core(ctx.saved, d16, None, 1.0 / S, grads, dlogits_f32=d, d_lo=d_lo)
         ctx.saved = None
         return (None, None) + tuple(grads[n] for n in ctx.names)
 
@@ -158,7 +172,7 @@ class FeatureDecoder(_Packed):
         saved.append(a[0] if save else None)
         return logits, saved
 
-    def _backward_core(self, saved, d16, bias_partial, inv_scale, grads, dlogits_f32=None, stage_done=None):
+    def _backward_core(self, saved, d16, bias_partial, inv_scale, grads, dlogits_f32=None, stage_done=None, d_lo=None):
         """d16: 16-bit [B,h,w,CP] = loss_scale * dL/dlogits (pad channels zero).  ``stage_done()`` is
         called after the final conv and after each decoder stage (4,3,2,1) once its gradients are
         enqueued — the engine launches that stage's gradient all-reduce from it."""
@@ -170,9 +184,7 @@ class FeatureDecoder(_Packed):
         else:  # compatibility path: column sums of the fp32 dlogits [P, C]
             ops.reduce_rows(dlogits_f32, 1.0, grads["final_out.bias"])
         ops.wgrad(d16, x5, C, 3, 3, 1, 1, inv_scale, out=grads["final_out.weight"])
-        wdg = _pack(self._cache, "final.wd", self.final_out.weight,
-                    lambda p: ops.pack_conv_weight(p.float().contiguous(), 1, dt))
-        dU = ops.conv_gemm(d16, wdg, 3, 3, 1, 1)
+        dU = _dgrad(self, "final", self.final_out, d16, d_lo)
         if stage_done is not None:
             stage_done()
         for i in range(4, 0, -1):

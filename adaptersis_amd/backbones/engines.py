@@ -184,7 +184,8 @@ class SegEngine(nn.Module):
         loss, coef, _ = ops.dice_fwd(logits, target, 2, 10e-20, S)
         dz = ops.dice_bwd(logits, target, coef, 2)
         B, hh, ww, C = logits.shape
-        d16, bpart = ops.resize_bilinear_bwd(dz, hh, ww, config.operand_dtype)
+        r = ops.resize_bilinear_bwd(dz, hh, ww, config.operand_dtype, config.split_conv)
+        d16, d_lo, bpart = r if config.split_conv else (r[0], None, r[1])
         world = dist.get_world_size(self.process_group) if (dist.is_available() and dist.is_initialized()) else 1
         inv = 1.0 / (S * world)  # gradient mean over ranks folded into the un-scaling (DDP semantics)
         hook = None
@@ -196,7 +197,7 @@ class SegEngine(nn.Module):
                 ev = torch.cuda.Event()
                 ev.record()
                 self._allreduce_range(lo, hi, ev)
-        dec._backward_core(saved, d16, bpart, inv, self.bucket.views, stage_done=hook)
+        dec._backward_core(saved, d16, bpart, inv, self.bucket.views, stage_done=hook, d_lo=d_lo)
         if world > 1:
             torch.cuda.current_stream().wait_stream(self._comm_stream)
         self.optimizer.step(1.0)

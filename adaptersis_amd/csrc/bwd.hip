@@ -110,7 +110,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
                                                            const float* __restrict__ gamma, const float* __restrict__ dgamma,
                                                            const float* __restrict__ dbeta, float inv_n, T* __restrict__ out,
-                                                           float* __restrict__ partial, int64_t R, int C) {
+                                                           T* __restrict__ out_lo, float* __restrict__ partial, int64_t R,
+                                                           int C) {
   __shared__ float red[256 * 4];
   const int cpt = C >> 2;
   const int c = threadIdx.x % cpt;
@@ -130,6 +131,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     pk.x = pack2<T>(o.x, o.y);
     pk.y = pack2<T>(o.z, o.w);
     reinterpret_cast<uint2*>(out)[i] = pk;
+    if (out_lo) {
+      pk.x = pack2<T>(lo_part<T>(o.x), lo_part<T>(o.y));
+      pk.y = pack2<T>(lo_part<T>(o.z), lo_part<T>(o.w));
+      reinterpret_cast<uint2*>(out_lo)[i] = pk;
+    }
     s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
   }
   reinterpret_cast<float4*>(red)[threadIdx.x] = s;
@@ -178,7 +184,7 @@ extern "C" int asis_upsample_bn_relu_bwd(void* stream, const float* dU, const fl
 
 extern "C" int asis_bn_bwd_apply(void* stream, int dtype, const float* g, const float* x, const float* mean,
                                  const float* invstd, const float* gamma, const float* dgamma, const float* dbeta,
-                                 double count, void* out, float* partial, int64_t R, int C) {
+                                 double count, void* out, void* out_lo, float* partial, int64_t R, int C) {
   ASIS_REQUIRE(g && x && mean && invstd && gamma && dgamma && dbeta && out && partial, "asis_bn_bwd_apply: null pointer");
   ASIS_REQUIRE(C % 4 == 0 && C >= 4 && 256 % (C / 4) == 0, "asis_bn_bwd_apply: C=%d must be 4*2^k <= 1024", C);
   ASIS_REQUIRE(dtype == ASIS_F16 || dtype == ASIS_BF16, "asis_bn_bwd_apply: bad dtype %d", dtype);
@@ -187,10 +193,10 @@ extern "C" int asis_bn_bwd_apply(void* stream, int dtype, const float* g, const 
   const float inv_n = (float)(1.0 / count);
   if (dtype == ASIS_F16)
     hipLaunchKernelGGL((bn_bwd_apply_kernel<f16>), dim3(grid_for(total)), dim3(256), 0, s, g, x, mean, invstd, gamma, dgamma,
-                       dbeta, inv_n, reinterpret_cast<f16*>(out), partial, R, C);
+                       dbeta, inv_n, reinterpret_cast<f16*>(out), reinterpret_cast<f16*>(out_lo), partial, R, C);
   else
     hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16>), dim3(grid_for(total)), dim3(256), 0, s, g, x, mean, invstd, gamma, dgamma,
-                       dbeta, inv_n, reinterpret_cast<bf16*>(out), partial, R, C);
+                       dbeta, inv_n, reinterpret_cast<bf16*>(out), reinterpret_cast<bf16*>(out_lo), partial, R, C);
   ASIS_CHECK_LAUNCH("asis_bn_bwd_apply");
   return ASIS_OK;
 }

@@ -194,7 +194,8 @@ __global__ __launch_bounds__(256) void dice_bwd_kernel(const float* __restrict__
 // (conv bias gradient): partial[blk][C].
 template <typename T>
 __global__ __launch_bounds__(256) void resize_bwd_kernel(const float* __restrict__ dz, int B, int H, int W, int h, int w,
-                                                         int C, int CP, T* __restrict__ out, float* __restrict__ partial) {
+                                                         int C, int CP, T* __restrict__ out, T* __restrict__ out_lo,
+                                                         float* __restrict__ partial) {
   __shared__ float red[4][MAXC];
   const float sh = (float)h / (float)H, sw = (float)w / (float)W;
   const float ish = (float)H / (float)h, isw = (float)W / (float)w;
@@ -233,7 +234,11 @@ __global__ __launch_bounds__(256) void resize_bwd_kernel(const float* __restrict
     T* o = out + i * CP;
 #pragma unroll
     for (int c = 0; c < MAXC; ++c)
-      if (c < CP) o[c] = to_t16<T>(c < C ? acc[c] : 0.f);
+      if (c < CP) {
+        const float v = c < C ? acc[c] : 0.f;
+        o[c] = to_t16<T>(v);
+        if (out_lo) out_lo[i * CP + c] = to_t16<T>(lo_part<T>(v));
+      }
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) csum[c] += acc[c];
   }
@@ -308,7 +313,7 @@ extern "C" int asis_resize_bwd_nblk(int64_t total_pixels) {
 }
 
 extern "C" int asis_resize_bilinear_bwd(void* stream, int dtype, const float* dz, int B, int H, int W, int h, int w, int C,
-                                        int CP, void* out, float* partial) {
+                                        int CP, void* out, void* out_lo, float* partial) {
   ASIS_REQUIRE(dz && out && partial, "asis_resize_bilinear_bwd: null pointer");
   ASIS_REQUIRE(C >= 1 && C <= MAXC && CP >= C && CP <= MAXC, "asis_resize_bilinear_bwd: bad C=%d CP=%d", C, CP);
   ASIS_REQUIRE(dtype == ASIS_F16 || dtype == ASIS_BF16 || dtype == ASIS_F32, "asis_resize_bilinear_bwd: bad dtype %d", dtype);
@@ -317,13 +322,13 @@ extern "C" int asis_resize_bilinear_bwd(void* stream, int dtype, const float* dz
   const int nblk = asis_resize_bwd_nblk((int64_t)B * h * w);
   if (dtype == ASIS_F16)
     hipLaunchKernelGGL((resize_bwd_kernel<f16>), dim3(nblk), dim3(256), 0, s, dz, B, H, W, h, w, C, CP,
-                       reinterpret_cast<f16*>(out), partial);
+                       reinterpret_cast<f16*>(out), reinterpret_cast<f16*>(out_lo), partial);
   else if (dtype == ASIS_BF16)
     hipLaunchKernelGGL((resize_bwd_kernel<bf16>), dim3(nblk), dim3(256), 0, s, dz, B, H, W, h, w, C, CP,
-                       reinterpret_cast<bf16*>(out), partial);
+                       reinterpret_cast<bf16*>(out), reinterpret_cast<bf16*>(out_lo), partial);
   else
     hipLaunchKernelGGL((resize_bwd_kernel<float>), dim3(nblk), dim3(256), 0, s, dz, B, H, W, h, w, C, CP,
-                       reinterpret_cast<float*>(out), partial);
+                       reinterpret_cast<float*>(out), (float*)nullptr, partial);
   ASIS_CHECK_LAUNCH("asis_resize_bilinear_bwd");
   return ASIS_OK;
 }

@@ -410,8 +410,8 @@ def dice_bwd(logits: torch.Tensor, target: torch.Tensor, coef: torch.Tensor, n_s
     return dz
 
 
-def resize_bilinear_bwd(dz: torch.Tensor, h: int, w: int, dtype: torch.dtype):
-    """dz fp32 [B,H,W,C] -> (d 16-bit [B,h,w,CP], partial [nblk, C])."""
+def resize_bilinear_bwd(dz: torch.Tensor, h: int, w: int, dtype: torch.dtype, split: bool = False):
+    """dz fp32 [B,H,W,C] -> (d 16-bit [B,h,w,CP], partial [nblk, C]) (+ d_lo inserted second when split)."""
     _dev(dz)
     B, H, W, Cc = dz.shape
     f32 = dtype == torch.float32
@@ -419,9 +419,10 @@ def resize_bilinear_bwd(dz: torch.Tensor, h: int, w: int, dtype: torch.dtype):
     nblk = lib().asis_resize_bwd_nblk(B * h * w)
     out = torch.empty((B, h, w, CP), device=dz.device, dtype=dtype)
     partial = torch.empty((nblk, Cc), device=dz.device, dtype=torch.float32)
+    lo = _lo(out, split and not f32)
     check(lib().asis_resize_bilinear_bwd(_stream(), 2 if f32 else _dt(dtype), _f32c(dz).data_ptr(), B, H, W, h, w, Cc, CP,
-                                         out.data_ptr(), partial.data_ptr()), "asis_resize_bilinear_bwd")
-    return out, partial
+                                         out.data_ptr(), _p(lo), partial.data_ptr()), "asis_resize_bilinear_bwd")
+    return (out, lo, partial) if split else (out, partial)
 
 
 def reduce_rows(partial: torch.Tensor, scale: float = 1.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -452,18 +453,19 @@ def upsample_bn_relu_bwd(dU: torch.Tensor, x: torch.Tensor, scale, shift, mean, 
 
 
 def bn_bwd_apply(g: torch.Tensor, x: torch.Tensor, mean, invstd, gamma, dgamma, dbeta, count: float,
-                 dtype: torch.dtype):
-    """-> (dx 16-bit same shape as x, partial [nblk, C] column sums of dx)."""
+                 dtype: torch.dtype, split: bool = False):
+    """-> (dx 16-bit same shape as x, [dx_lo when split,] partial [nblk, C] column sums of dx)."""
     _dev(g, x)
     Cc = x.shape[-1]
     R = x.numel() // Cc
     nblk = lib().asis_ew_blocks(R * (Cc // 4))
     out = torch.empty(x.shape, device=x.device, dtype=dtype)
     partial = torch.empty((nblk, Cc), device=x.device, dtype=torch.float32)
+    lo = _lo(out, split)
     check(lib().asis_bn_bwd_apply(_stream(), _dt(dtype), _f32c(g).data_ptr(), _f32c(x).data_ptr(), mean.data_ptr(),
                                   invstd.data_ptr(), _f32c(gamma).data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
-                                  float(count), out.data_ptr(), partial.data_ptr(), R, Cc), "asis_bn_bwd_apply")
-    return out, partial
+                                  float(count), out.data_ptr(), _p(lo), partial.data_ptr(), R, Cc), "asis_bn_bwd_apply")
+    return (out, lo, partial) if split else (out, partial)
 
 
 def wgrad(dy: torch.Tensor, x_nhwc: torch.Tensor, Cout: int, KH: int, KW: int, stride: int, pad: int,

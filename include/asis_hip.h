@@ -217,7 +217,7 @@ int asis_dice_bwd(void* stream, const float* logits, const int64_t* target, cons
  * + partial[asis_resize_bwd_nblk(B*h*w)][C] column sums */
 int asis_resize_bwd_nblk(int64_t total_pixels);
 int asis_resize_bilinear_bwd(void* stream, int dtype, const float* dz, int B, int H, int W, int h, int w, int C, int CP,
-                             void* out, float* partial);
+                             void* out, void* out_lo, float* partial);
 /* out[k] = scale * sum_n partial[n][k], summed in double in a fixed order */
 int asis_reduce_rows(void* stream, const float* partial, int n, int K, float scale, float* out);
 
@@ -230,10 +230,12 @@ int asis_ew_blocks(int64_t total_chunks);
 int asis_upsample_bn_relu_bwd(void* stream, const float* dU, const float* x, const float* scale, const float* shift,
                               const float* mean, const float* invstd, float* g, float* partial, int B, int H, int W,
                               int C, int factor);
-/* dx(16-bit) = gamma*invstd*(g - dbeta/n - xhat*dgamma/n); partial[asis_ew_blocks(R*C/4)][C] = sum dx */
+/* dx(16-bit) = gamma*invstd*(g - dbeta/n - xhat*dgamma/n); partial[asis_ew_blocks(R*C/4)][C] = sum dx.
+ * out_lo (optional) = rounding residual of dx: the dgrad GEMM chain runs split-precision because the
+ * mean subtraction of the next BatchNorm backward amplifies 16-bit rounding noise (Numerics). */
 int asis_bn_bwd_apply(void* stream, int dtype, const float* g, const float* x, const float* mean, const float* invstd,
                       const float* gamma, const float* dgamma, const float* dbeta, double count, void* out,
-                      float* partial, int64_t R, int C);
+                      void* out_lo, float* partial, int64_t R, int C);
 
 /* Weight gradient dW[Cout,Cin,KH,KW] = sum_p dy[p,co] * x[b, oh*s+kh-pad, ow*s+kw-pad, ci]
  * (conv2d; KH=KW=1 gives the nn.Linear weight grad).  dy 16-bit [P, ld_dy] with CoP (multiple of 8)
