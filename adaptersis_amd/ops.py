@@ -16,6 +16,21 @@ from ._lib import ACT_GELU, ACT_NONE, ACT_RELU, GemmDesc, check, lib  # noqa: F4
 
 T16_DEFAULT = torch.float16
 
+# bench.py sets this to a list to time every GEMM launch with HIP events recorded on the launch stream:
+# entries are (kind, algorithmic_flops, start_event, end_event).  None = no instrumentation.
+PROFILE = None
+
+
+def _launch_timed(kind: str, flops: float, fn):
+    if PROFILE is None:
+        return fn()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    rc = fn()
+    e.record()
+    PROFILE.append((kind, flops, s, e))
+    return rc
+
 
 def _dt(dtype: torch.dtype) -> int:
     if dtype == torch.float16:
@@ -90,7 +105,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, out: Optional[torch.Tensor] = None
         d.strideR = res.stride(0) if res.dim() == 3 else 0
     d.act, d.out_f32, d.dtype = act, int(out_f32), _dt(a.dtype)
     d.stats = _p(stats)
-    check(lib().asis_gemm(_stream(), C.byref(d)), "asis_gemm")
+    check(_launch_timed("gemm", 2.0 * batch * M * N * K, lambda: lib().asis_gemm(_stream(), C.byref(d))), "asis_gemm")
     return out
 
 
@@ -125,7 +140,8 @@ def conv_gemm(x_nhwc: torch.Tensor, w_packed: torch.Tensor, KH: int, KW: int, st
     d.conv, d.B_, d.H, d.W, d.Cin, d.OH, d.OW = 1, Bn, H, W, Cin, OH, OW
     d.KH, d.KW, d.stride, d.pad = KH, KW, stride, pad
     d.stats = _p(stats)
-    check(lib().asis_gemm(_stream(), C.byref(d)), "asis_gemm(conv)")
+    check(_launch_timed("conv", 2.0 * d.M * Cout * K, lambda: lib().asis_gemm(_stream(), C.byref(d))),
+          "asis_gemm(conv)")
     return out
 
 

@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""Headline benchmark: training images/sec of the ViT-L/14 588x588 adapter fine-tune step on MI355X.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one `train.py:268-436` iteration on a batch of 12 synthetic 588x588 images per
+GPU, already resident in HBM: CNN encoder, ViT-L pass A (24 blocks, cls+pos) + pass B (21 blocks), 4 x [block,
+CAViT, CACNN], decoder forward, resize+softmax+Dice, decoder backward, gradient all-reduce (N > 1), SGD.
+Nothing is skipped or cached between steps.  Weights are random-init of the named architecture
+(no network: `adaptersis_amd.utils.weights`), data is synthetic of the named shape.
+
+Output: ONE JSON line on rank 0 (see README / DESIGN.md for the fields).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+MFMA_F16_DENSE_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16/f16 (no sparsity)
+
+
+def build_engine(arch: str, dev, lr: float):
+    from adaptersis_amd.backbones.adapter_blocks import CACNN, CAViT
+    from adaptersis_amd.backbones.decoders import FeatureDecoder
+    from adaptersis_amd.backbones.encoders import FeatureEncoder
+    from adaptersis_amd.backbones.engines import SegEngine
+    from adaptersis_amd.dinov2.models import vision_transformer as vits
+    from adaptersis_amd.utils import weights as W
+
+    D, depth, heads, ffn = W.VIT_CONFIGS[arch]
+    model = vits.__dict__[arch](patch_size=14, img_size=518, init_values=1e-5, ffn_layer=ffn, block_chunks=0)
+    model.load_state_dict(W.make_vit_state_dict(arch, layerscale="kernel"))
+    enc = FeatureEncoder(embed_dim=D)
+    enc.load_state_dict(W.make_encoder_state_dict(D))
+    cv = CAViT(dim=D, n_levels=3, num_heads=8, init_values=0.0, n_points=4)
+    cv.load_state_dict(W.make_cavit_state_dict(D, mode="kernel"))
+    cn = CACNN(dim=D, n_levels=1, num_heads=8, n_points=4, with_cffn=True, cffn_ratio=0.25)
+    cn.load_state_dict(W.make_cacnn_state_dict(D, mode="kernel"))
+    dec = FeatureDecoder(embed_dim=D, num_classes=2, features=[D, 512, 256, 128, 64])
+    dec.load_state_dict(W.make_feature_decoder_state_dict(D, 2, features=(D, 512, 256, 128, 64)))
+    return SegEngine(model.to(dev).eval(), enc.to(dev), cv.to(dev), cn.to(dev), dec.to(dev), lr=lr)
+
+
+def synthetic(batch: int, size: int, rank: int, dev):
+    """images U[0,1) (no mean/std normalisation), binary masks ~30 % foreground, one
+    all-background image per batch (Dice epsilon path); generator seeded 0 + rank."""
+    g = torch.Generator(device="cpu").manual_seed(rank)
+    img = torch.rand(batch, 3, size, size, generator=g)
+    tgt = (torch.rand(batch, size, size, generator=g) > 0.7).long()
+    tgt[-1].zero_()
+    return img.to(dev), tgt.to(dev)
+
+
+def cpu_baseline(arch: str, size: int):
+    """Reference CPU path (the fp32 eager oracle restatement, parity-pinned to the imported reference) timed on
+    this box's host cores on a bounded sample of the same step at batch 1, extrapolated to one image."""
+    from adaptersis_amd.utils import weights as W
+    from oracle import ref_torch as O  # cpu_baseline leg only
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    D, depth, heads, _ = W.VIT_CONFIGS[arch]
+    vsd = W.make_vit_state_dict(arch, layerscale="kernel")
+    esd, csd, nsd = W.make_encoder_state_dict(D), W.make_cavit_state_dict(D), W.make_cacnn_state_dict(D)
+    dsd = W.make_feature_decoder_state_dict(D, 2, features=(D, 512, 256, 128, 64))
+    img, tgt = W.synthetic_batch(1, size)
+    N = (size // 14) ** 2
+
+    def t(fn, reps=1):
+        fn()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            out = fn()
+        return (time.perf_counter() - t0) / reps, out
+
+    with torch.no_grad():
+        xa = W.tensor("cb.xa", (1, N + 1, D), 1.0)
+        xb = xa[:, 1:].contiguous()
+        t_a, _ = t(lambda: O.block(xa, vsd, "blocks.0", heads))
+        t_b, _ = t(lambda: O.block(xb, vsd, "blocks.1", heads))
+        t_enc, (c1, c2, c3, c4, shapes) = t(lambda: O.feature_encoder(img, esd))
+        c = torch.cat([c2, c3, c4], 1)
+        d1, d2 = O.deform_inputs(size, size, 14, shapes)
+
+        def stage():
+            x1 = O.cavit(xb, d1[0], c, d1[1], csd)
+            return O.cacnn(c, d2[0], x1, d2[1], shapes, nsd)
+        t_ad, _ = t(stage)
+        cat = O.assemble_decoder_input(xb, c4, xb, (size // 14, size // 14), shapes[2])
+    params = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in dsd.items()}
+
+    def dec_step():
+        for p in params.values():
+            p.grad = None
+        O.train_step_loss(cat, tgt, params, 2).backward()
+    t_dec, _ = t(dec_step)
+    nb = depth
+    per_img = nb * t_a + (nb - 3) * t_b + 3 * t_b + 4 * t_ad + t_enc + t_dec
+    return {
+        "value": round(1.0 / per_img, 5), "unit": "img/s", "cores": cores, "kind": "port",
+        "sample": (f"batch 1: one {arch} block at N={N + 1} ({t_a:.2f}s) and at N={N} ({t_b:.2f}s), one CAViT+CACNN "
+                   f"stage ({t_ad:.2f}s), encoder ({t_enc:.2f}s), decoder fwd+loss+bwd ({t_dec:.2f}s); step time = "
+                   f"{nb}*A + {nb}*B + 4*adapter + encoder + decoder = {per_img:.1f}s/img (fp32 eager torch {torch.__version__})"),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=12, help="images per GPU (README.md:45-61 of the reference)")
+    ap.add_argument("--arch", default="vit_large")
+    ap.add_argument("--size", type=int, default=588)
+    ap.add_argument("--operand", default=None, choices=[None, "f16", "bf16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (HIP device); there is no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # "nccl" == RCCL on ROCm
+
+    from adaptersis_amd import config, ops
+    from adaptersis_amd.build import build_library
+    build_library()
+    if a.operand:
+        config.set_operand_dtype(torch.float16 if a.operand == "f16" else torch.bfloat16)
+        config.loss_scale = 65536.0 if a.operand == "f16" else 1.0
+
+    eng = build_engine(a.arch, dev, lr=0.01)
+    img, tgt = synthetic(a.batch, a.size, rank, dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        eng.train_step(img, tgt)
+    barrier()
+    prof = None if a.no_kernel_timing else []
+    ops.PROFILE = prof
+    t0 = time.perf_counter()
+    loss = None
+    for _ in range(a.steps):
+        loss = eng.train_step(img, tgt)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ops.PROFILE = None
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el)
+    loss_v = float(loss)
+
+    # ---- roofline of the dominant kernel: the dense MFMA GEMM (asis gemm_kernel<T,false>) ----------------
+    roof = None
+    if prof:
+        dense = [(f, s.elapsed_time(e)) for (kind, f, s, e) in prof if kind == "gemm"]
+        n = len(dense)
+        flops = sum(f for f, _ in dense) / n
+        avg_ms = sum(t for _, t in dense) / n
+        conv = [(f, s.elapsed_time(e)) for (kind, f, s, e) in prof if kind == "conv"]
+        achieved = flops / (avg_ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": "gemm_kernel<f16,false> (all dense GEMM launches of the step)",
+                "achieved": round(achieved, 1), "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / MFMA_F16_DENSE_PEAK_TFLOPS, 4), "traffic": None,
+                "launches_per_step": n // a.steps, "avg_launch_ms": round(avg_ms, 4),
+                "gflop_per_launch": round(flops / 1e9, 2),
+                "share_of_step_time": round(sum(t for _, t in dense) / a.steps / (elapsed / a.steps * 1e3), 3),
+                "conv_gemm_share_of_step_time": round(sum(t for _, t in conv) / a.steps / (elapsed / a.steps * 1e3), 3)}
+
+    if rank == 0:
+        global_batch = a.batch * world
+        out = {
+            "metric": "training images/sec, ViT-L/14 588^2 adapter fine-tune",
+            "value": round(global_batch * a.steps / elapsed, 3), "unit": "img/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16" if config.operand_dtype == torch.float16 else "bf16", "data": "synthetic",
+            "config": {"workload": f"{a.arch}/14 frozen + CAViT/CACNN adapters (n_last_blocks=4) + FeatureDecoder, "
+                                   f"{a.size}x{a.size}, batch {a.batch}/GPU, reference_exact train.py step "
+                                   "(fwd + decoder bwd + all-reduce + SGD), random-init weights",
+                       "global_batch": global_batch, "image_size": a.size, "parallelism": f"dp{world}",
+                       "split_precision_convs": bool(config.split_conv), "loss": loss_v},
+        }
+        if roof:
+            out["roofline"] = roof
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.arch, a.size)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -13,7 +13,7 @@ from tests.conftest import golden_err, load_golden, rel_l2
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-3
-GRAD_TOL = 2e-2  # gradients pass through ~10 16-bit GEMMs (5 fwd + 5 bwd); no tolerance is stated upstream
+GRAD_TOL = 1e-3  # exact input: forward convs and the dgrad chain run split-precision, wgrad sums average the 16-bit noise
 
 
 def test_deform_inputs_match_oracle():
