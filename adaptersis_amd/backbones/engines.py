@@ -26,6 +26,7 @@ from torch import nn
 from .. import config, ops
 from ..dinov2.layers.blocks import _Packed, _pack
 from ..optim import SGD, FlatBucket
+from ..parallel import StageReducer, world_size
 from .adapter_blocks import CACNN, CAViT, deform_inputs
 
 
@@ -90,8 +91,8 @@ class SegEngine(nn.Module):
         self.bucket = FlatBucket(ordered)
         self.stage_ranges = [self.bucket.range_of([n for n in named if n.startswith(pre + ".")]) for pre in order]
         self.optimizer = SGD([self.bucket], lr=lr, momentum=momentum, weight_decay=weight_decay)
+        self.reducer = StageReducer(self.bucket.grad, self.stage_ranges, process_group)
         self._geom = {}
-        self._comm_stream = None
 
     # ------------------------------------------------------------------------------------------
     def _geometry(self, H, W, shapes, dev):
@@ -165,14 +166,6 @@ class SegEngine(nn.Module):
         return cat
 
     # ------------------------------------------------------------------------------------------
-    def _allreduce_range(self, lo, hi, ev):
-        """RCCL all-reduce of grad[lo:hi] on the side stream once the producing kernels (event) are done."""
-        if self._comm_stream is None:
-            self._comm_stream = torch.cuda.Stream()
-        self._comm_stream.wait_event(ev)
-        with torch.cuda.stream(self._comm_stream):
-            dist.all_reduce(self.bucket.grad[lo:hi], group=self.process_group)
-
     @torch.no_grad()
     def train_step(self, inp: torch.Tensor, target: torch.Tensor, taps: Optional[dict] = None) -> torch.Tensor:
         """One `train.py:268-436` iteration; returns the loss as a 0-dim device tensor (no host sync)."""
@@ -186,20 +179,11 @@ class SegEngine(nn.Module):
         B, hh, ww, C = logits.shape
         r = ops.resize_bilinear_bwd(dz, hh, ww, config.operand_dtype, config.split_conv)
         d16, d_lo, bpart = r if config.split_conv else (r[0], None, r[1])
-        world = dist.get_world_size(self.process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        world = world_size(self.process_group)
         inv = 1.0 / (S * world)  # gradient mean over ranks folded into the un-scaling (DDP semantics)
-        hook = None
-        if world > 1:
-            stages = iter(self.stage_ranges)
-
-            def hook():
-                lo, hi = next(stages)
-                ev = torch.cuda.Event()
-                ev.record()
-                self._allreduce_range(lo, hi, ev)
-        dec._backward_core(saved, d16, bpart, inv, self.bucket.views, stage_done=hook, d_lo=d_lo)
-        if world > 1:
-            torch.cuda.current_stream().wait_stream(self._comm_stream)
+        self.reducer.begin()
+        dec._backward_core(saved, d16, bpart, inv, self.bucket.views, stage_done=self.reducer.stage_done, d_lo=d_lo)
+        self.reducer.finish()
         self.optimizer.step(1.0)
         if taps is not None:
             taps.update(logits=logits, loss=loss)

@@ -271,6 +271,16 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
   if (threadIdx.x == 0) out[k] = (float)(red[0] * (double)scale);
 }
 
+// few rows, many columns (split-K slabs of the weight gradients): one thread per column, coalesced rows
+__global__ __launch_bounds__(256) void reduce_rows_wide_kernel(const float* __restrict__ partial, int n, int64_t K,
+                                                               float scale, float* __restrict__ out) {
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < K; k += (int64_t)gridDim.x * blockDim.x) {
+    double s = 0.0;
+    for (int i = 0; i < n; ++i) s += (double)partial[(int64_t)i * K + k];
+    out[k] = (float)(s * (double)scale);
+  }
+}
+
 }  // namespace
 
 extern "C" int asis_dice_nblk(int H, int W) {
@@ -335,8 +345,15 @@ extern "C" int asis_resize_bilinear_bwd(void* stream, int dtype, const float* dz
 
 extern "C" int asis_reduce_rows(void* stream, const float* partial, int n, int K, float scale, float* out) {
   ASIS_REQUIRE(partial && out && n > 0 && K > 0, "asis_reduce_rows: bad arguments");
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3(K), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), partial, n, K,
-                     scale, out);
+  if (n <= 64 || K > 65535) {
+    int64_t g = ((int64_t)K + 255) / 256;
+    if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(reduce_rows_wide_kernel, dim3((unsigned)g), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       partial, n, (int64_t)K, scale, out);
+  } else {
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3(K), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), partial, n, K,
+                       scale, out);
+  }
   ASIS_CHECK_LAUNCH("asis_reduce_rows");
   return ASIS_OK;
 }

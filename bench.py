@@ -69,7 +69,7 @@ def cpu_baseline(arch: str, size: int):
     from oracle import ref_torch as O  # cpu_baseline leg only
 
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = min(cores, int(os.environ.get("ASIS_CPU_THREADS", cores)))
+    cores = min(cores, int(os.environ.get("ASIS_CPU_THREADS", 16)))  # a 1-GPU box owns a 16-core share of the host
     torch.set_num_threads(cores)
     D, depth, heads, _ = W.VIT_CONFIGS[arch]
     vsd = W.make_vit_state_dict(arch, layerscale="kernel")
