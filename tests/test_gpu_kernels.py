@@ -43,7 +43,8 @@ def test_gemm_identity_asymmetric(dev, dt):
 
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 72), (1, 8, 8), (257, 129, 1024), (1765 * 2, 288, 384),
-                                   (64, 3072, 128), (4100, 64, 576)])
+                                   (64, 3072, 128), (4100, 64, 576), (256, 256, 64), (512, 512, 128), (1000, 1024, 256),
+                                   (777, 640, 192), (1764 * 3, 2048, 1024), (2000, 1024, 4096)])
 def test_gemm_shapes(dev, dt, M, N, K):
     a = W.tensor(f"g.a{M}", (M, K), 1.0).to(dev).to(dt)
     b = W.tensor(f"g.b{N}", (N, K), 1.0).to(dev).to(dt)
@@ -112,6 +113,32 @@ def test_conv_implicit_gemm(dev, dt, Cin, Cout, H, Wd, stride, pad):
     s = stats.sum(0)
     assert rel_l2(s[0], ref.sum((0, 1, 2))) < 1e-4
     assert rel_l2(s[1], (ref * ref).sum((0, 1, 2))) < 1e-5
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_gemm_big_tile_epilogue_and_batch(dev, dt):
+    """Shapes that take the 256-row LDS-DMA kernel: full epilogue, strided output, shared-A batch (V^T form)."""
+    M, N, K = 700, 600, 256
+    a = W.tensor("be.a", (M, K), 1.0).to(dev).to(dt)
+    b = W.tensor("be.b", (N, K), 1.0).to(dev).to(dt)
+    bn, bm, sc = W.tensor("be.bn", (N,), 1.0).to(dev), W.tensor("be.bm", (M,), 1.0).to(dev), W.tensor("be.sc", (N,), 1.0).to(dev)
+    res = W.tensor("be.res", (M, N), 3.0).to(dev)
+    acc = a.float() @ b.float().t()
+    ref = F.gelu(acc + bn[None] + bm[:, None]) * sc[None] + res
+    c = ops.gemm(a, b, out_f32=True, bias_n=bn, bias_m=bm, scale_n=sc, res=res, act=ops.ACT_GELU)
+    assert rel_l2(c, ref) < 3e-6
+    big = torch.full((M, N + 8), 7.0, device=dev, dtype=dt)
+    ops.gemm(a, b, out=big[:, :N], bias_n=bn)
+    assert rel_l2(big[:, :N], acc + bn[None]) < (1e-3 if dt == torch.float16 else 6e-3)
+    assert torch.all(big[:, N:] == 7.0)
+    Bn, D, Nt = 2, 512, 777
+    wv = W.tensor("bb.w", (D, D), 0.1).to(dev).to(dt)
+    x = W.tensor("bb.x", (Bn, Nt, D), 1.0).to(dev).to(dt)
+    vt = torch.full((Bn, D, 832), 5.0, device=dev, dtype=dt)
+    ops.gemm(wv, x, out=vt.as_strided((Bn, D, Nt), (D * 832, 832, 1)), bias_m=bm[:D].contiguous())
+    refv = torch.einsum("fd,bnd->bfn", wv.float(), x.float()) + bm[:D][None, :, None]
+    assert rel_l2(vt[:, :, :Nt], refv) < (1e-3 if dt == torch.float16 else 6e-3)
+    assert torch.all(vt[:, :, Nt:] == 5.0)
 
 
 def test_gemm_rejects_bad_args(dev):
