@@ -206,149 +206,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const asis_gemm_desc 
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Large-tile dense GEMM: 256 x (256|128) x 64 tile, 8 waves, LDS-DMA (global_load_lds_dwordx4) staging
-// with NS LDS stages and a counted vmcnt so NS-1 K tiles stay in flight across the one barrier per
-// K tile.  The 128^2 register-staged kernel above is latency/inflow bound (~10 B/clk/CU reach the CU
-// while one 32 KB tile per workgroup is in flight: 64 FLOP/B x 10 B/clk = ~15 % of the MFMA peak,
-// which is what it measures); this kernel doubles the FLOP per staged byte and keeps 2 tiles
-// (96-128 KB per CU) in flight.  LDS image = the same XOR-swizzled 128-B rows; since LDS-DMA writes
-// lane-linear (base + lane*16) the swizzle is applied to the per-lane SOURCE address instead
-// (cdna_hip_programming.md rule 21).  Rows/cols beyond M/N are clamped on load and masked on store.
-// ------------------------------------------------------------------------------------------------
-template <typename T, int WM, int WN, int TM, int TN, int NS>
-__global__ __launch_bounds__(512, 2) void gemm_big_kernel(const asis_gemm_desc d) {
-  typedef typename T16<T>::v8 v8;
-  constexpr int BM2 = WM * TM * 32, BN2 = WN * TN * 32;
-  constexpr int STAGE = (BM2 + BN2) * BK;           // elements per stage
-  constexpr int GA = BM2 / 64, GB = BN2 / 64;        // LDS-DMA wave-instructions per wave and K tile
-  constexpr int G = GA + GB;
-  __shared__ __attribute__((aligned(16))) T lds[NS * STAGE];
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wid / WN, wn = wid - wm * WN;
-  const int tiles_n = (d.N + BN2 - 1) / BN2;
-  const int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
-  const int m0 = tile_m * BM2, n0 = tile_n * BN2;
-  const int bz = blockIdx.y;
-  const T* __restrict__ A = reinterpret_cast<const T*>(d.A) + (int64_t)bz * d.strideA;
-  const T* __restrict__ B = reinterpret_cast<const T*>(d.B) + (int64_t)bz * d.strideB;
-
-  // per-lane source pointers (row clamped, chunk pre-swizzled) for this wave's DMA instructions
-  const T* asrc[GA];
-  const T* bsrc[GB];
-  const int lr = lane >> 3, lc = lane & 7;
-#pragma unroll
-  for (int j = 0; j < GA; ++j) {
-    const int row = (wid * GA + j) * 8 + lr;
-    int gr = m0 + row;
-    gr = gr < d.M ? gr : d.M - 1;
-    asrc[j] = A + (int64_t)gr * d.lda + ((lc ^ ((row >> 1) & 7)) << 3);
-  }
-#pragma unroll
-  for (int j = 0; j < GB; ++j) {
-    const int row = (wid * GB + j) * 8 + lr;
-    int gr = n0 + row;
-    gr = gr < d.N ? gr : d.N - 1;
-    bsrc[j] = B + (int64_t)gr * d.ldb + ((lc ^ ((row >> 1) & 7)) << 3);
-  }
-  typedef __attribute__((address_space(3))) void* lds_ptr;
-  typedef const __attribute__((address_space(1))) void* glb_ptr;
-  auto issue = [&](int t) {
-    T* st = lds + (t % NS) * STAGE;
-    const int k0 = t * BK;
-#pragma unroll
-    for (int j = 0; j < GA; ++j)
-      __builtin_amdgcn_global_load_lds((glb_ptr)(asrc[j] + k0), (lds_ptr)(st + ((wid * GA + j) * 8) * BK), 16, 0, 0);
-#pragma unroll
-    for (int j = 0; j < GB; ++j)
-      __builtin_amdgcn_global_load_lds((glb_ptr)(bsrc[j] + k0), (lds_ptr)(st + BM2 * BK + ((wid * GB + j) * 8) * BK), 16, 0, 0);
-  };
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int nt = d.K / BK;
-#pragma unroll
-  for (int s = 0; s < NS - 1; ++s)
-    if (s < nt) issue(s);
-
-  const int fr = lane & 31, fh = lane >> 5;
-  for (int t = 0; t < nt; ++t) {
-    // tile t has landed once at most (NS-2) newer tiles of this wave are still outstanding
-    if (nt - t - 1 >= NS - 2) {
-      if (NS == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
-    if (t + NS - 1 < nt) issue(t + NS - 1);
-    const T* As = lds + (t % NS) * STAGE;
-    const T* Bs = As + BM2 * BK;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      v8 af[TM], bf[TN];
-      const int chunk = 2 * ks + fh;
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int row = (wm * TM + i) * 32 + fr;
-        af[i] = __builtin_bit_cast(v8, *reinterpret_cast<const uint4*>(As + row * BK + ((chunk ^ ((row >> 1) & 7)) << 3)));
-      }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int col = (wn * TN + j) * 32 + fr;
-        bf[j] = __builtin_bit_cast(v8, *reinterpret_cast<const uint4*>(Bs + col * BK + ((chunk ^ ((col >> 1) & 7)) << 3)));
-      }
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = T16<T>::mfma32(af[i], bf[j], acc[i][j]);
-    }
-  }
-
-  // ---- epilogue (same semantics as gemm_kernel) ----
-  const int64_t cbase = (int64_t)bz * d.strideC;
-  const float* __restrict__ res = d.res ? d.res + (int64_t)bz * d.strideR : nullptr;
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int col = n0 + (wn * TN + j) * 32 + fr;
-    const bool cok = col < d.N;
-    const float bn = (d.bias_n && cok) ? d.bias_n[col] : 0.f;
-    const float sc = (d.scale_n && cok) ? d.scale_n[col] : 1.f;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-        if (row < d.M && cok) {
-          float v = acc[i][j][r] + bn;
-          if (d.bias_m) v += d.bias_m[row];
-          if (d.act == ASIS_ACT_GELU) v = gelu_erf(v);
-          else if (d.act == ASIS_ACT_RELU) v = fmaxf(v, 0.f);
-          v *= sc;
-          if (res) v += res[(int64_t)row * d.ldr + col];
-          if (d.out_f32) reinterpret_cast<float*>(d.C)[cbase + (int64_t)row * d.ldc + col] = v;
-          else reinterpret_cast<T*>(d.C)[cbase + (int64_t)row * d.ldc + col] = to_t16<T>(v);
-        }
-      }
-    }
-  }
-}
+#include "gemm_big.h"
 
 template <typename T>
 int launch(hipStream_t s, const asis_gemm_desc& d) {
   // large-tile LDS-DMA kernel for the big dense GEMMs; variant via ASIS_GEMM_BIG=0|1(256x256)|2(256x128)
   static const int big_mode = [] { const char* e = getenv("ASIS_GEMM_BIG"); return e ? atoi(e) : 1; }();
   if (big_mode && !d.conv && !d.stats && d.K % BK == 0 && d.M >= 256 && d.N >= 128) {
-    const bool wide = big_mode == 1 && d.N >= 256;
+    const bool wide = big_mode == 1 && d.N >= 2048;  // 256x256 for wide outputs, 256x128 (3 stages) otherwise
     const int bm = 256, bn = wide ? 256 : 128;
     dim3 grid(((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn), d.batch), block(512);
     if (wide) hipLaunchKernelGGL((gemm_big_kernel<T, 2, 4, 4, 2, 2>), grid, block, 0, s, d);

@@ -1,0 +1,222 @@
+// Large-tile LDS-DMA GEMM kernel (included by gemm.hip and by scripts/gemm_lab.hip).
+#pragma once
+#include "asis_common.h"
+
+namespace {
+#ifndef ASIS_GEMM_BK
+#define ASIS_GEMM_BK 64
+#endif
+constexpr int BKB = ASIS_GEMM_BK;
+
+// ------------------------------------------------------------------------------------------------
+// Large-tile dense GEMM: 256 x (256|128) x 64 tile, 8 waves, LDS-DMA (global_load_lds_dwordx4) staging
+// with NS LDS stages and a counted vmcnt so NS-1 K tiles stay in flight across the one barrier per
+// K tile.  The 128^2 register-staged kernel above is latency/inflow bound (~10 B/clk/CU reach the CU
+// while one 32 KB tile per workgroup is in flight: 64 FLOP/B x 10 B/clk = ~15 % of the MFMA peak,
+// which is what it measures); this kernel doubles the FLOP per staged byte and keeps 2 tiles
+// (96-128 KB per CU) in flight.  LDS image = the same XOR-swizzled 128-B rows; since LDS-DMA writes
+// lane-linear (base + lane*16) the swizzle is applied to the per-lane SOURCE address instead
+// (cdna_hip_programming.md rule 21).  Rows/cols beyond M/N are clamped on load and masked on store.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int WM, int WN, int TM, int TN, int NS, int DBG = 0>
+__global__ __launch_bounds__(512, 2) void gemm_big_kernel(const asis_gemm_desc d) {
+  typedef typename T16<T>::v8 v8;
+  constexpr int BM2 = WM * TM * 32, BN2 = WN * TN * 32;
+  constexpr int STAGE = (BM2 + BN2) * BKB;           // elements per stage
+  constexpr int GA = BM2 / 64, GB = BN2 / 64;        // LDS-DMA wave-instructions per wave and K tile
+  constexpr int G = GA + GB;
+  __shared__ __attribute__((aligned(16))) T lds[NS * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid / WN, wn = wid - wm * WN;
+  const int tiles_n = (d.N + BN2 - 1) / BN2;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
+  const int m0 = tile_m * BM2, n0 = tile_n * BN2;
+  const int bz = blockIdx.y;
+  const T* __restrict__ A = reinterpret_cast<const T*>(d.A) + (int64_t)bz * d.strideA;
+  const T* __restrict__ B = reinterpret_cast<const T*>(d.B) + (int64_t)bz * d.strideB;
+
+  // per-lane source pointers (row clamped, chunk pre-swizzled) for this wave's DMA instructions
+  const T* asrc[GA];
+  const T* bsrc[GB];
+  const int lr = lane >> 3, lc = lane & 7;
+#pragma unroll
+  for (int j = 0; j < GA; ++j) {
+    const int row = (wid * GA + j) * 8 + lr;
+    int gr = m0 + row;
+    gr = gr < d.M ? gr : d.M - 1;
+    asrc[j] = A + (int64_t)gr * d.lda + ((lc ^ ((row >> 1) & 7)) << 3);
+  }
+#pragma unroll
+  for (int j = 0; j < GB; ++j) {
+    const int row = (wid * GB + j) * 8 + lr;
+    int gr = n0 + row;
+    gr = gr < d.N ? gr : d.N - 1;
+    bsrc[j] = B + (int64_t)gr * d.ldb + ((lc ^ ((row >> 1) & 7)) << 3);
+  }
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  typedef const __attribute__((address_space(1))) void* glb_ptr;
+  auto issue = [&](int t) {
+    T* st = lds + (t % NS) * STAGE;
+    const int k0 = t * BKB;
+#pragma unroll
+    for (int j = 0; j < GA; ++j)
+      __builtin_amdgcn_global_load_lds((glb_ptr)(asrc[j] + k0), (lds_ptr)(st + ((wid * GA + j) * 8) * BKB), 16, 0, 0);
+#pragma unroll
+    for (int j = 0; j < GB; ++j)
+      __builtin_amdgcn_global_load_lds((glb_ptr)(bsrc[j] + k0), (lds_ptr)(st + BM2 * BKB + ((wid * GB + j) * 8) * BKB), 16, 0, 0);
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nt = d.K / BKB;
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s)
+    if (s < nt) issue(s);
+
+  const int fr = lane & 31, fh = lane >> 5;
+  for (int t = 0; t < nt; ++t) {
+    // tile t has landed once at most (NS-2) newer tiles of this wave are still outstanding
+    if (nt - t - 1 >= NS - 2) {
+      if (NS == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (!(DBG & 1) && t + NS - 1 < nt) issue(t + NS - 1);
+    const T* As = lds + (t % NS) * STAGE;
+    const T* Bs = As + BM2 * BKB;
+    if (!(DBG & 2))
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      v8 af[TM], bf[TN];
+      const int chunk = 2 * ks + fh;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int row = (wm * TM + i) * 32 + fr;
+        af[i] = __builtin_bit_cast(v8, *reinterpret_cast<const uint4*>(As + row * BKB + ((chunk ^ ((row >> 1) & 7)) << 3)));
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = (wn * TN + j) * 32 + fr;
+        bf[j] = __builtin_bit_cast(v8, *reinterpret_cast<const uint4*>(Bs + col * BKB + ((chunk ^ ((col >> 1) & 7)) << 3)));
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = T16<T>::mfma32(bf[j], af[i], acc[i][j]);  // D[n][m]: lane = output row
+    }
+  }
+
+  // ---- epilogue (same semantics as gemm_kernel) ----
+  if (DBG & 4) {  // lab only: keep the accumulators live, store one value per lane
+    float z = 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z += acc[i][j][r];
+    if (z == 123.456f) reinterpret_cast<float*>(d.C)[tid] = z;
+    return;
+  }
+  // Accumulators are C^T tiles (mfma(B, A)): lane (fr, fh) owns output row m = ..+fr and, per register
+  // group g, the 4 consecutive columns n = 8g + 4fh + (0..3): vector loads of bias / LayerScale / residual
+  // and 8- or 16-byte stores instead of 2-byte ones (the 2-byte form cost as much as the whole K loop).
+  const int64_t cbase = (int64_t)bz * d.strideC;
+  const float* __restrict__ res = d.res ? d.res + (int64_t)bz * d.strideR : nullptr;
+  const bool vec = ((d.N & 3) == 0) && ((d.ldc & 3) == 0) && ((cbase & 3) == 0) && (!res || (d.ldr & 3) == 0) &&
+                   ((reinterpret_cast<uintptr_t>(d.C) & 15) == 0) && (!res || (reinterpret_cast<uintptr_t>(res) & 15) == 0) &&
+                   (!d.bias_n || (reinterpret_cast<uintptr_t>(d.bias_n) & 15) == 0) &&
+                   (!d.scale_n || (reinterpret_cast<uintptr_t>(d.scale_n) & 15) == 0);
+  if (vec) {
+    // Transpose each 32 x (TN*32) slab of the wave tile through a private LDS slab so that global
+    // accesses are full lines: TN*8 consecutive lanes cover one row (16 B = 4 columns per lane).
+    constexpr int SW = TN * 32 + 4;                    // padded slab row (floats): conflict-free b128 writes
+    constexpr int LPR = TN * 8;                        // lanes per row when reading back
+    constexpr int RPP = 64 / LPR;                      // rows per pass
+    __syncthreads();                                   // every wave is done with the staging buffers
+    float* slab = reinterpret_cast<float*>(lds) + wid * (32 * SW);
+    const int rr = lane / LPR, ch = lane - rr * LPR;
+    const int col = n0 + wn * TN * 32 + ch * 4;
+    const bool cok = col < d.N;
+    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f), s4 = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (cok && d.bias_n) b4 = *reinterpret_cast<const float4*>(d.bias_n + col);
+    if (cok && d.scale_n) s4 = *reinterpret_cast<const float4*>(d.scale_n + col);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<float4*>(slab + fr * SW + 32 * j + 8 * g + 4 * fh) =
+              make_float4(acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+#pragma unroll
+      for (int p = 0; p < 32 / RPP; ++p) {
+        const int lrow = p * RPP + rr;
+        const int row = m0 + (wm * TM + i) * 32 + lrow;
+        float4 v = *reinterpret_cast<const float4*>(slab + lrow * SW + ch * 4);
+        if (row < d.M && cok) {
+          const float bmv = d.bias_m ? d.bias_m[row] : 0.f;
+          v.x += b4.x + bmv; v.y += b4.y + bmv; v.z += b4.z + bmv; v.w += b4.w + bmv;
+          if (d.act == ASIS_ACT_GELU) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
+          else if (d.act == ASIS_ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+          v.x *= s4.x; v.y *= s4.y; v.z *= s4.z; v.w *= s4.w;
+          if (res) {
+            const float4 r4 = *reinterpret_cast<const float4*>(res + (int64_t)row * d.ldr + col);
+            v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
+          }
+          if (d.out_f32) {
+            *reinterpret_cast<float4*>(reinterpret_cast<float*>(d.C) + cbase + (int64_t)row * d.ldc + col) = v;
+          } else {
+            uint2 pk;
+            pk.x = pack2<T>(v.x, v.y);
+            pk.y = pack2<T>(v.z, v.w);
+            *reinterpret_cast<uint2*>(reinterpret_cast<T*>(d.C) + cbase + (int64_t)row * d.ldc + col) = pk;
+          }
+        }
+      }
+    }
+    return;
+  }
+  // scalar fallback (N or a leading dimension not a multiple of 4)
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int row = m0 + (wm * TM + i) * 32 + fr;
+    const bool rok = row < d.M;
+    const float bmv = (d.bias_m && rok) ? d.bias_m[row] : 0.f;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int col = n0 + (wn * TN + j) * 32 + 8 * g + 4 * fh;
+        if (!rok || col >= d.N) continue;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int c = col + e;
+          if (c < d.N) {
+            float x = acc[i][j][4 * g + e] + (d.bias_n ? d.bias_n[c] : 0.f) + bmv;
+            if (d.act == ASIS_ACT_GELU) x = gelu_erf(x);
+            else if (d.act == ASIS_ACT_RELU) x = fmaxf(x, 0.f);
+            if (d.scale_n) x *= d.scale_n[c];
+            if (res) x += res[(int64_t)row * d.ldr + c];
+            if (d.out_f32) reinterpret_cast<float*>(d.C)[cbase + (int64_t)row * d.ldc + c] = x;
+            else reinterpret_cast<T*>(d.C)[cbase + (int64_t)row * d.ldc + c] = to_t16<T>(x);
+          }
+        }
+      }
+    }
+  }
+}
+
+
+}  // namespace
