@@ -163,8 +163,13 @@ class FeatureDecoder(_Packed):
             seq = getattr(self, f"decoder_{i}")
             a, st = conv_bn_relu_up_forward(self, f"d{i}", a[0], a[1], seq[0], seq[1], 2, self.sync_bn, save)
             saved.append(st)
-        w_hi, w_lo = _conv_weights(self, "final", self.final_out, a[1] is not None)
         bias = self._f32("final.b", self.final_out.bias)
+        fo = self.final_out
+        if fo.out_channels <= 16 and fo.in_channels <= 112:  # few classes: direct fp32 kernel, no MFMA tile waste
+            logits = ops.conv3x3_smallcout_fwd(a[0], a[1], self._f32("final.wf", fo.weight), bias)
+            saved.append(a[0] if save else None)
+            return logits, saved
+        w_hi, w_lo = _conv_weights(self, "final", self.final_out, a[1] is not None)
         if a[1] is not None:
             logits = ops.conv_gemm_split(a[0], a[1], w_hi, w_lo, 3, 3, 1, 1, bias_n=bias)
         else:
@@ -184,7 +189,11 @@ class FeatureDecoder(_Packed):
         else:  # compatibility path: column sums of the fp32 dlogits [P, C]
             ops.reduce_rows(dlogits_f32, 1.0, grads["final_out.bias"])
         ops.wgrad(d16, x5, C, 3, 3, 1, 1, inv_scale, out=grads["final_out.weight"])
-        dU = _dgrad(self, "final", self.final_out, d16, d_lo)
+        fo = self.final_out
+        if fo.out_channels <= 8 and fo.in_channels <= 224:
+            dU = ops.conv3x3_smallcout_dgrad(d16, d_lo, self._f32("final.wf", fo.weight))
+        else:
+            dU = _dgrad(self, "final", fo, d16, d_lo)
         if stage_done is not None:
             stage_done()
         for i in range(4, 0, -1):

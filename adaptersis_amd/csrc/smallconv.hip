@@ -1,0 +1,178 @@
+// Direct 3x3 convolution (stride 1, pad 1) for layers with a handful of output channels — the decode
+// heads' final classifier conv (backbones/decoders.py:135: 64 -> num_classes at 672x672) and its input
+// gradient.  As an MFMA implicit GEMM these layers waste a 128-wide tile on 2..11 columns (the forward
+// cost 2.3 ms per pass at B=12); they are L2/HBM-bound gathers with ~1 FLOP per byte, so they run on the
+// vector ALUs in fp32: x is rebuilt as hi+lo (exact to ~22 bits), weights stay fp32, every lane owns one
+// pixel (forward) or one pixel x 8 input channels (dgrad), weights are broadcast from LDS.
+#include "asis_common.h"
+
+namespace {
+
+constexpr int MAXCO = 16;
+
+template <typename T>
+__device__ __forceinline__ void load8(const T* p, float* f) {
+  const uint4 raw = *reinterpret_cast<const uint4*>(p);
+  const uint32_t* w = reinterpret_cast<const uint32_t*>(&raw);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) unpack2<T>(w[e], f[2 * e], f[2 * e + 1]);
+}
+
+// out[b,y,x,co] = bias[co] + sum_{kh,kw,ci} (xh+xl)[b,y+kh-1,x+kw-1,ci] * w[co,ci,kh,kw]
+template <typename T, int CO>
+__global__ __launch_bounds__(256) void smallcout_fwd_kernel(const T* __restrict__ xh, const T* __restrict__ xl,
+                                                            const float* __restrict__ w, const float* __restrict__ bias,
+                                                            float* __restrict__ out, int B, int H, int W, int Cin, int Cout) {
+  extern __shared__ __attribute__((aligned(16))) float wl[];  // [tap][ci][CO]
+  for (int i = threadIdx.x; i < 9 * Cin * CO; i += blockDim.x) {
+    const int co = i % CO, ci = (i / CO) % Cin, tap = i / (CO * Cin);
+    wl[i] = co < Cout ? w[((int64_t)co * Cin + ci) * 9 + tap] : 0.f;
+  }
+  __syncthreads();
+  const int64_t total = (int64_t)B * H * W;
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (int64_t)gridDim.x * blockDim.x) {
+    const int x = (int)(p % W);
+    const int y = (int)((p / W) % H);
+    float acc[CO];
+#pragma unroll
+    for (int c = 0; c < CO; ++c) acc[c] = (bias && c < Cout) ? bias[c] : 0.f;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int yy = y + kh - 1, xx = x + kw - 1;
+        if ((unsigned)yy >= (unsigned)H || (unsigned)xx >= (unsigned)W) continue;
+        const int64_t q = p + (int64_t)(kh - 1) * W + (kw - 1);
+        const float* wt = wl + (kh * 3 + kw) * Cin * CO;
+        for (int c8 = 0; c8 < Cin; c8 += 8) {
+          float f[8], g[8];
+          load8<T>(xh + q * Cin + c8, f);
+          if (xl) {
+            load8<T>(xl + q * Cin + c8, g);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] += g[e];
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+#pragma unroll
+            for (int c = 0; c < CO; ++c) acc[c] += f[e] * wt[(c8 + e) * CO + c];
+        }
+      }
+    for (int c = 0; c < Cout; ++c) out[p * Cout + c] = acc[c];
+  }
+}
+
+// dx[b,y,x,ci] = sum_{kh,kw,co} (dh+dl)[b, y-(kh-1), x-(kw-1), co] * w[co,ci,kh,kw]; dy has CoP (>= Cout) channels
+template <typename T, int CO>
+__global__ __launch_bounds__(256) void smallcout_dgrad_kernel(const T* __restrict__ dh, const T* __restrict__ dl, int CoP,
+                                                              const float* __restrict__ w, float* __restrict__ dx, int B,
+                                                              int H, int W, int Cin, int Cout) {
+  extern __shared__ __attribute__((aligned(16))) float wl[];  // [tap][co][ci]
+  for (int i = threadIdx.x; i < 9 * CO * Cin; i += blockDim.x) {
+    const int ci = i % Cin, co = (i / Cin) % CO, tap = i / (Cin * CO);
+    wl[i] = co < Cout ? w[((int64_t)co * Cin + ci) * 9 + tap] : 0.f;
+  }
+  __syncthreads();
+  const int cpp = Cin >> 3;
+  const int64_t total = (int64_t)B * H * W * cpp;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c8 = (int)(i % cpp) * 8;
+    const int64_t p = i / cpp;
+    const int x = (int)(p % W);
+    const int y = (int)((p / W) % H);
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int yy = y - (kh - 1), xx = x - (kw - 1);
+        if ((unsigned)yy >= (unsigned)H || (unsigned)xx >= (unsigned)W) continue;
+        const int64_t q = p - (int64_t)(kh - 1) * W - (kw - 1);
+        float d[8], g[8];
+        load8<T>(dh + q * CoP, d);  // CO <= 8 channels live in the first 16 bytes
+        if (dl) {
+          load8<T>(dl + q * CoP, g);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) d[e] += g[e];
+        }
+        const float* wt = wl + (kh * 3 + kw) * CO * Cin + c8;
+#pragma unroll
+        for (int c = 0; c < CO; ++c) {
+          const float4 w0 = *reinterpret_cast<const float4*>(wt + c * Cin);
+          const float4 w1 = *reinterpret_cast<const float4*>(wt + c * Cin + 4);
+          acc[0] += d[c] * w0.x; acc[1] += d[c] * w0.y; acc[2] += d[c] * w0.z; acc[3] += d[c] * w0.w;
+          acc[4] += d[c] * w1.x; acc[5] += d[c] * w1.y; acc[6] += d[c] * w1.z; acc[7] += d[c] * w1.w;
+        }
+      }
+    float4* o = reinterpret_cast<float4*>(dx + p * Cin + c8);
+    o[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    o[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+  }
+}
+
+inline int grid_for(int64_t total, int cap = 256 * 32) {
+  int64_t g = (total + 255) / 256;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+template <typename T>
+int launch_fwd(hipStream_t s, const void* xh, const void* xl, const float* w, const float* bias, float* out, int B, int H,
+               int W, int Cin, int Cout) {
+  const int64_t total = (int64_t)B * H * W;
+  const T* a = reinterpret_cast<const T*>(xh);
+  const T* b = reinterpret_cast<const T*>(xl);
+#define FWD(CO)                                                                                                    \
+  hipLaunchKernelGGL((smallcout_fwd_kernel<T, CO>), dim3(grid_for(total)), dim3(256), 9 * Cin * CO * sizeof(float), s, \
+                     a, b, w, bias, out, B, H, W, Cin, Cout)
+  if (Cout <= 2) FWD(2);
+  else if (Cout <= 4) FWD(4);
+  else if (Cout <= 8) FWD(8);
+  else FWD(16);
+#undef FWD
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int asis_conv3x3_smallcout_fwd(void* stream, int dtype, const void* x_hi, const void* x_lo, const float* w,
+                                          const float* bias, float* out, int B, int H, int W, int Cin, int Cout) {
+  ASIS_REQUIRE(x_hi && w && out, "asis_conv3x3_smallcout_fwd: null pointer");
+  ASIS_REQUIRE(Cout >= 1 && Cout <= MAXCO, "asis_conv3x3_smallcout_fwd: Cout=%d must be in 1..%d", Cout, MAXCO);
+  ASIS_REQUIRE(Cin % 8 == 0 && Cin > 0 && 9 * Cin * 16 * 4 <= 64 * 1024, "asis_conv3x3_smallcout_fwd: Cin=%d must be a multiple of 8, <= 112", Cin);
+  ASIS_REQUIRE(asis_aligned16(x_hi) && (!x_lo || asis_aligned16(x_lo)), "asis_conv3x3_smallcout_fwd: alignment");
+  ASIS_REQUIRE(dtype == ASIS_F16 || dtype == ASIS_BF16, "asis_conv3x3_smallcout_fwd: bad dtype %d", dtype);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == ASIS_F16) launch_fwd<f16>(s, x_hi, x_lo, w, bias, out, B, H, W, Cin, Cout);
+  else launch_fwd<bf16>(s, x_hi, x_lo, w, bias, out, B, H, W, Cin, Cout);
+  ASIS_CHECK_LAUNCH("asis_conv3x3_smallcout_fwd");
+  return ASIS_OK;
+}
+
+extern "C" int asis_conv3x3_smallcout_dgrad(void* stream, int dtype, const void* dy_hi, const void* dy_lo, int CoP,
+                                            const float* w, float* dx, int B, int H, int W, int Cin, int Cout) {
+  ASIS_REQUIRE(dy_hi && w && dx, "asis_conv3x3_smallcout_dgrad: null pointer");
+  ASIS_REQUIRE(Cout >= 1 && Cout <= 8 && CoP >= 8 && CoP % 8 == 0, "asis_conv3x3_smallcout_dgrad: Cout=%d (<= 8), CoP=%d", Cout, CoP);
+  ASIS_REQUIRE(Cin % 8 == 0 && Cin > 0 && 9 * 8 * Cin * 4 <= 64 * 1024, "asis_conv3x3_smallcout_dgrad: Cin=%d must be a multiple of 8, <= 224", Cin);
+  ASIS_REQUIRE(asis_aligned16(dy_hi) && (!dy_lo || asis_aligned16(dy_lo)) && asis_aligned16(dx),
+               "asis_conv3x3_smallcout_dgrad: alignment");
+  ASIS_REQUIRE(dtype == ASIS_F16 || dtype == ASIS_BF16, "asis_conv3x3_smallcout_dgrad: bad dtype %d", dtype);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int64_t total = (int64_t)B * H * W * (Cin / 8);
+  const int CO = Cout <= 2 ? 2 : (Cout <= 4 ? 4 : 8);
+  const size_t shm = (size_t)9 * CO * Cin * sizeof(float);
+#define DG(T, C)                                                                                                  \
+  hipLaunchKernelGGL((smallcout_dgrad_kernel<T, C>), dim3(grid_for(total)), dim3(256), shm, s,                    \
+                     reinterpret_cast<const T*>(dy_hi), reinterpret_cast<const T*>(dy_lo), CoP, w, dx, B, H, W, Cin, Cout)
+  if (dtype == ASIS_F16) {
+    if (CO == 2) DG(f16, 2); else if (CO == 4) DG(f16, 4); else DG(f16, 8);
+  } else {
+    if (CO == 2) DG(bf16, 2); else if (CO == 4) DG(bf16, 4); else DG(bf16, 8);
+  }
+#undef DG
+  ASIS_CHECK_LAUNCH("asis_conv3x3_smallcout_dgrad");
+  return ASIS_OK;
+}

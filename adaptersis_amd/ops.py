@@ -277,6 +277,31 @@ def conv3x3_c3(img: torch.Tensor, w: torch.Tensor, stride: int, pad: int) -> tor
     return out
 
 
+def conv3x3_smallcout_fwd(x_hi: torch.Tensor, x_lo: Optional[torch.Tensor], w: torch.Tensor,
+                          bias: Optional[torch.Tensor]) -> torch.Tensor:
+    """Direct fp32 3x3/s1/p1 conv for <= 16 output channels: x (hi [+lo]) 16-bit NHWC, w fp32 [Cout,Cin,3,3]."""
+    _dev(x_hi, x_lo, w, bias)
+    B, H, W, Cin = x_hi.shape
+    Cout = w.shape[0]
+    out = torch.empty((B, H, W, Cout), device=x_hi.device, dtype=torch.float32)
+    check(lib().asis_conv3x3_smallcout_fwd(_stream(), _dt(x_hi.dtype), x_hi.data_ptr(), _p(x_lo), _f32c(w).data_ptr(),
+                                           _p(_f32c(bias)), out.data_ptr(), B, H, W, Cin, Cout),
+          "asis_conv3x3_smallcout_fwd")
+    return out
+
+
+def conv3x3_smallcout_dgrad(dy_hi: torch.Tensor, dy_lo: Optional[torch.Tensor], w: torch.Tensor) -> torch.Tensor:
+    """Input gradient of the small-Cout conv: dy 16-bit [B,H,W,CoP] (hi [+lo]) -> dx fp32 [B,H,W,Cin]."""
+    _dev(dy_hi, dy_lo, w)
+    B, H, W, CoP = dy_hi.shape
+    Cout, Cin = w.shape[0], w.shape[1]
+    dx = torch.empty((B, H, W, Cin), device=dy_hi.device, dtype=torch.float32)
+    check(lib().asis_conv3x3_smallcout_dgrad(_stream(), _dt(dy_hi.dtype), dy_hi.data_ptr(), _p(dy_lo), CoP,
+                                             _f32c(w).data_ptr(), dx.data_ptr(), B, H, W, Cin, Cout),
+          "asis_conv3x3_smallcout_dgrad")
+    return dx
+
+
 def colstats(x: torch.Tensor) -> torch.Tensor:
     """fp32 [..., C] -> partial [nparts, 2, C] column sums / sums of squares."""
     _dev(x)

@@ -163,6 +163,15 @@ int asis_dwconv_gelu(void* stream, int dtype, const float* x, const float* w9, c
 /* stem conv, Cin = 3: img fp32 NCHW [B,3,H,W], w fp32 [Cout,3,3,3] -> out fp32 NHWC [B,OH,OW,Cout] */
 int asis_conv3x3_c3(void* stream, const float* img, const float* w, float* out, int B, int H, int W, int Cout,
                     int stride, int pad);
+/* Direct fp32 3x3 conv (stride 1, pad 1) for layers with <= 16 output channels (the decode heads' final
+ * classifier conv, decoders.py:135 / :80): x = x_hi (+ x_lo, optional split half) 16-bit NHWC [B,H,W,Cin],
+ * w fp32 [Cout,Cin,3,3] (the parameter itself), out fp32 NHWC [B,H,W,Cout].  Cin % 8 == 0, Cin <= 112. */
+int asis_conv3x3_smallcout_fwd(void* stream, int dtype, const void* x_hi, const void* x_lo, const float* w,
+                               const float* bias, float* out, int B, int H, int W, int Cin, int Cout);
+/* its input gradient: dy = dy_hi (+ dy_lo) 16-bit [B,H,W,CoP] (CoP >= 8, first Cout channels valid, Cout <= 8)
+ * -> dx fp32 NHWC [B,H,W,Cin] */
+int asis_conv3x3_smallcout_dgrad(void* stream, int dtype, const void* dy_hi, const void* dy_lo, int CoP, const float* w,
+                                 float* dx, int B, int H, int W, int Cin, int Cout);
 /* column sums / sums of squares of fp32 [R, C] -> partial[nparts][2][C], nparts = asis_colstats_nparts(R) */
 int asis_colstats_nparts(int64_t R);
 int asis_colstats(void* stream, const float* x, int64_t R, int C, float* partial);
