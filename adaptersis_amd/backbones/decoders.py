@@ -165,7 +165,7 @@ class FeatureDecoder(_Packed):
             saved.append(st)
         bias = self._f32("final.b", self.final_out.bias)
         fo = self.final_out
-        if fo.out_channels <= 16 and fo.in_channels <= 112:  # few classes: direct fp32 kernel, no MFMA tile waste
+        if fo.out_channels <= 16 and fo.in_channels in (8, 16, 32, 64):  # few classes: direct fp32 kernel, no MFMA tile waste
             logits = ops.conv3x3_smallcout_fwd(a[0], a[1], self._f32("final.wf", fo.weight), bias)
             saved.append(a[0] if save else None)
             return logits, saved

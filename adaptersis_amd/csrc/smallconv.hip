@@ -19,6 +19,8 @@ __device__ __forceinline__ void load8(const T* p, float* f) {
 }
 
 // out[b,y,x,co] = bias[co] + sum_{kh,kw,ci} (xh+xl)[b,y+kh-1,x+kw-1,ci] * w[co,ci,kh,kw]
+// thread = (pixel, 8-channel chunk): the Cin/8 lanes of a pixel read its 16-byte chunks side by side (full
+// lines), accumulate their channels over the 9 taps, and are summed with xor-shuffles (Cin/8 a power of two).
 template <typename T, int CO>
 __global__ __launch_bounds__(256) void smallcout_fwd_kernel(const T* __restrict__ xh, const T* __restrict__ xl,
                                                             const float* __restrict__ w, const float* __restrict__ bias,
@@ -29,13 +31,18 @@ __global__ __launch_bounds__(256) void smallcout_fwd_kernel(const T* __restrict_
     wl[i] = co < Cout ? w[((int64_t)co * Cin + ci) * 9 + tap] : 0.f;
   }
   __syncthreads();
-  const int64_t total = (int64_t)B * H * W;
-  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (int64_t)gridDim.x * blockDim.x) {
+  const int cpp = Cin >> 3;  // lanes per pixel (power of two, <= 64)
+  const int64_t total = (int64_t)B * H * W * cpp;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  // every lane of a wave runs the same number of iterations (total and stride are multiples of 64)
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int c8 = (int)(i & (cpp - 1)) * 8;
+    const int64_t p = i / cpp;
     const int x = (int)(p % W);
     const int y = (int)((p / W) % H);
     float acc[CO];
 #pragma unroll
-    for (int c = 0; c < CO; ++c) acc[c] = (bias && c < Cout) ? bias[c] : 0.f;
+    for (int c = 0; c < CO; ++c) acc[c] = 0.f;
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
@@ -43,22 +50,24 @@ __global__ __launch_bounds__(256) void smallcout_fwd_kernel(const T* __restrict_
         const int yy = y + kh - 1, xx = x + kw - 1;
         if ((unsigned)yy >= (unsigned)H || (unsigned)xx >= (unsigned)W) continue;
         const int64_t q = p + (int64_t)(kh - 1) * W + (kw - 1);
-        const float* wt = wl + (kh * 3 + kw) * Cin * CO;
-        for (int c8 = 0; c8 < Cin; c8 += 8) {
-          float f[8], g[8];
-          load8<T>(xh + q * Cin + c8, f);
-          if (xl) {
-            load8<T>(xl + q * Cin + c8, g);
+        float f[8], g[8];
+        load8<T>(xh + q * Cin + c8, f);
+        if (xl) {
+          load8<T>(xl + q * Cin + c8, g);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) f[e] += g[e];
-          }
-#pragma unroll
-          for (int e = 0; e < 8; ++e)
-#pragma unroll
-            for (int c = 0; c < CO; ++c) acc[c] += f[e] * wt[(c8 + e) * CO + c];
+          for (int e = 0; e < 8; ++e) f[e] += g[e];
         }
+        const float* wt = wl + ((kh * 3 + kw) * Cin + c8) * CO;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+#pragma unroll
+          for (int c = 0; c < CO; ++c) acc[c] += f[e] * wt[e * CO + c];
       }
-    for (int c = 0; c < Cout; ++c) out[p * Cout + c] = acc[c];
+    for (int o = 1; o < cpp; o <<= 1)
+#pragma unroll
+      for (int c = 0; c < CO; ++c) acc[c] += __shfl_xor(acc[c], o, 64);
+    if (c8 == 0)
+      for (int c = 0; c < Cout; ++c) out[p * Cout + c] = acc[c] + (bias ? bias[c] : 0.f);
   }
 }
 
@@ -122,7 +131,7 @@ inline int grid_for(int64_t total, int cap = 256 * 32) {
 template <typename T>
 int launch_fwd(hipStream_t s, const void* xh, const void* xl, const float* w, const float* bias, float* out, int B, int H,
                int W, int Cin, int Cout) {
-  const int64_t total = (int64_t)B * H * W;
+  const int64_t total = (int64_t)B * H * W * (Cin / 8);
   const T* a = reinterpret_cast<const T*>(xh);
   const T* b = reinterpret_cast<const T*>(xl);
 #define FWD(CO)                                                                                                    \
@@ -142,7 +151,7 @@ extern "C" int asis_conv3x3_smallcout_fwd(void* stream, int dtype, const void* x
                                           const float* bias, float* out, int B, int H, int W, int Cin, int Cout) {
   ASIS_REQUIRE(x_hi && w && out, "asis_conv3x3_smallcout_fwd: null pointer");
   ASIS_REQUIRE(Cout >= 1 && Cout <= MAXCO, "asis_conv3x3_smallcout_fwd: Cout=%d must be in 1..%d", Cout, MAXCO);
-  ASIS_REQUIRE(Cin % 8 == 0 && Cin > 0 && 9 * Cin * 16 * 4 <= 64 * 1024, "asis_conv3x3_smallcout_fwd: Cin=%d must be a multiple of 8, <= 112", Cin);
+  ASIS_REQUIRE(Cin >= 8 && Cin <= 64 && (Cin & (Cin - 1)) == 0, "asis_conv3x3_smallcout_fwd: Cin=%d must be 8, 16, 32 or 64", Cin);
   ASIS_REQUIRE(asis_aligned16(x_hi) && (!x_lo || asis_aligned16(x_lo)), "asis_conv3x3_smallcout_fwd: alignment");
   ASIS_REQUIRE(dtype == ASIS_F16 || dtype == ASIS_BF16, "asis_conv3x3_smallcout_fwd: bad dtype %d", dtype);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);

@@ -165,7 +165,7 @@ int asis_conv3x3_c3(void* stream, const float* img, const float* w, float* out, 
                     int stride, int pad);
 /* Direct fp32 3x3 conv (stride 1, pad 1) for layers with <= 16 output channels (the decode heads' final
  * classifier conv, decoders.py:135 / :80): x = x_hi (+ x_lo, optional split half) 16-bit NHWC [B,H,W,Cin],
- * w fp32 [Cout,Cin,3,3] (the parameter itself), out fp32 NHWC [B,H,W,Cout].  Cin % 8 == 0, Cin <= 112. */
+ * w fp32 [Cout,Cin,3,3] (the parameter itself), out fp32 NHWC [B,H,W,Cout].  Cin in {8,16,32,64}. */
 int asis_conv3x3_smallcout_fwd(void* stream, int dtype, const void* x_hi, const void* x_lo, const float* w,
                                const float* bias, float* out, int B, int H, int W, int Cin, int Cout);
 /* its input gradient: dy = dy_hi (+ dy_lo) 16-bit [B,H,W,CoP] (CoP >= 8, first Cout channels valid, Cout <= 8)
