@@ -19,6 +19,8 @@
 // Workgroup = 4 waves = 128 queries of one (image, head); K / V^T tiles of 64 keys are
 // double-buffered in LDS (32 KiB, XOR-swizzled 128-B rows, conflict-free ds_read_b128), the
 // next tile's global loads are in flight during the MFMAs of the current one.
+#include <type_traits>
+
 #include "asis_common.h"
 
 namespace {
@@ -32,7 +34,7 @@ __device__ __forceinline__ int perm23(int r) {  // swap bits 2 and 3
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, int64_t ldqk,
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, int64_t ldqk,
                                                        const T* __restrict__ vt, int64_t ldvt, T* __restrict__ o,
                                                        int64_t ldo, int H, int N, float scale_log2e) {
   typedef typename T16<T>::v8 v8;
@@ -109,14 +111,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ q, 
   __syncthreads();
 
   const int prow = perm23(fr);
-  for (int t = 0; t < nt; ++t) {
-    const int buf = t & 1;
-    const int key0 = t * KT;
-    if (t + 1 < nt) load_tile(key0 + KT);
-    const T* Ks = lds + buf * (2 * KT * HD);
-    const T* Vs = Ks + KT * HD;
-
-    // ---- S^T = K Q^T : 2 key blocks x 4 k-steps ----
+  // One K/V tile: S^T = K Q^T, online softmax, O^T += V^T P^T.  TAIL masks keys >= N (last tile only, so
+  // the full tiles carry no compare/select work).  The running max is only raised when it grows by more than
+  // RESCALE_THR (log2 units): P stays <= 2^THR (exact in fp32 sums, same relative precision in fp16) and the
+  // 32-register O rescale is skipped on most tiles (cdna_hip_programming.md T13).
+  constexpr float RESCALE_THR = 6.0f;
+  auto tile = [&](const T* Ks, const T* Vs, int key0, auto tail_tag) {
+    constexpr bool TAIL = decltype(tail_tag)::value;
     f32x16 sacc[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) sacc[0][r] = sacc[1][r] = 0.f;
@@ -130,44 +131,40 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ q, 
         sacc[kb] = T16<T>::mfma32(a, qf[s], sacc[kb]);
       }
     }
-
-    // ---- online softmax (scaled-by-log2e domain), lane-local per query ----
     float mx = -1e30f;
-    const bool tail = key0 + KT > N;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        float s = sacc[kb][r] * scale_log2e;
-        if (tail) {
+        if (TAIL) {
           const int key = key0 + kb * 32 + perm23((r & 3) + 8 * (r >> 2) + 4 * fh);
-          if (key >= N) s = -1e30f;
+          if (key >= N) sacc[kb][r] = -1e30f;
         }
-        sacc[kb][r] = s;
-        mx = fmaxf(mx, s);
+        mx = fmaxf(mx, sacc[kb][r]);
       }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    m_run = m_new;
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * scale_log2e;  // scale > 0: max commutes with the scaling
+    if (__any(mx > m_run + RESCALE_THR)) {
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        oacc[0][r] *= alpha;
+        oacc[1][r] *= alpha;
+      }
+    }
     float psum = 0.f;
     v8 pf[2][2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = __builtin_amdgcn_exp2f(sacc[kb][r] - m_new);
+        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[kb][r], scale_log2e, -m_run));
         psum += p;
         pf[kb][r >> 3][r & 7] = (T)p;
       }
-    l_run = l_run * alpha + psum;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      oacc[0][r] *= alpha;
-      oacc[1][r] *= alpha;
-    }
-
-    // ---- O^T += V^T P^T : 2 d blocks x (2 key blocks x 2 k-steps) ----
+    l_run += psum;
 #pragma unroll
     for (int db = 0; db < 2; ++db) {
       const int row = db * 32 + fr;
@@ -181,7 +178,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ q, 
           oacc[db] = T16<T>::mfma32(a, pf[kb][s2], oacc[db]);
         }
     }
+  };
 
+  for (int t = 0; t < nt; ++t) {
+    const int buf = t & 1;
+    const int key0 = t * KT;
+    if (t + 1 < nt) load_tile(key0 + KT);
+    const T* Ks = lds + buf * (2 * KT * HD);
+    const T* Vs = Ks + KT * HD;
+    if (key0 + KT > N) tile(Ks, Vs, key0, std::true_type{});
+    else tile(Ks, Vs, key0, std::false_type{});
     if (t + 1 < nt) store_tile(buf ^ 1);
     __syncthreads();
   }
