@@ -210,14 +210,24 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const asis_gemm_desc 
 
 template <typename T>
 int launch(hipStream_t s, const asis_gemm_desc& d) {
-  // large-tile LDS-DMA kernel for the big dense GEMMs; variant via ASIS_GEMM_BIG=0|1(256x256)|2(256x128)
+  // large-tile LDS-DMA kernel (gemm_big.h); ASIS_GEMM_BIG=0 forces the 128x128 register-staged kernel
   static const int big_mode = [] { const char* e = getenv("ASIS_GEMM_BIG"); return e ? atoi(e) : 1; }();
+  const bool vec_ok = (d.N % 4 == 0) && (d.ldc % 4 == 0);
   if (big_mode && !d.conv && !d.stats && d.K % BK == 0 && d.M >= 256 && d.N >= 128) {
     const bool wide = big_mode == 1 && d.N >= 2048;  // 256x256 for wide outputs, 256x128 (3 stages) otherwise
     const int bm = 256, bn = wide ? 256 : 128;
     dim3 grid(((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn), d.batch), block(512);
     if (wide) hipLaunchKernelGGL((gemm_big_kernel<T, 2, 4, 4, 2, 2>), grid, block, 0, s, d);
     else hipLaunchKernelGGL((gemm_big_kernel<T, 4, 2, 2, 2, 3>), grid, block, 0, s, d);
+    return 0;
+  }
+  // implicit-GEMM convolution on the same kernel: K tiles must lie inside one tap, and BatchNorm statistics
+  // come from the vectorised epilogue
+  if (big_mode && d.conv && d.Cin % BK == 0 && d.M >= 256 && d.N >= 32 && vec_ok && d.out_f32) {
+    const int bm = 256, bn = d.N > 64 ? 128 : 64;
+    dim3 grid(((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn), 1), block(512);
+    if (bn == 128) hipLaunchKernelGGL((gemm_big_kernel<T, 4, 2, 2, 2, 3, 0, true>), grid, block, 0, s, d);
+    else hipLaunchKernelGGL((gemm_big_kernel<T, 8, 1, 1, 2, 3, 0, true>), grid, block, 0, s, d);
     return 0;
   }
   const int tiles_m = (d.M + BM - 1) / BM, tiles_n = (d.N + BN - 1) / BN;

@@ -18,7 +18,10 @@ constexpr int BKB = ASIS_GEMM_BK;
 // lane-linear (base + lane*16) the swizzle is applied to the per-lane SOURCE address instead
 // (cdna_hip_programming.md rule 21).  Rows/cols beyond M/N are clamped on load and masked on store.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int WM, int WN, int TM, int TN, int NS, int DBG = 0>
+// 16 zero bytes: the LDS-DMA source of implicit-im2col lanes that fall into the conv padding
+__device__ __attribute__((aligned(16))) uint4 g_zero_page[1];
+
+template <typename T, int WM, int WN, int TM, int TN, int NS, int DBG = 0, bool CONV = false>
 __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const asis_gemm_desc d) {
   typedef typename T16<T>::v8 v8;
   constexpr int BM2 = WM * TM * 32, BN2 = WN * TN * 32;
@@ -41,13 +44,25 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const asis_gemm_desc d
   // per-lane source pointers (row clamped, chunk pre-swizzled) for this wave's DMA instructions
   const T* asrc[GA];
   const T* bsrc[GB];
+  int a_ih0[GA], a_iw0[GA];  // CONV: top-left input pixel of this lane's output pixel
   const int lr = lane >> 3, lc = lane & 7;
 #pragma unroll
   for (int j = 0; j < GA; ++j) {
     const int row = (wid * GA + j) * 8 + lr;
     int gr = m0 + row;
     gr = gr < d.M ? gr : d.M - 1;
-    asrc[j] = A + (int64_t)gr * d.lda + ((lc ^ ((row >> 1) & 7)) << 3);
+    if (CONV) {  // implicit im2col: A is NHWC [B,H,W,Cin]; a K tile (64) lies inside one tap (Cin % 64 == 0)
+      const int ohw = d.OH * d.OW;
+      const int b = gr / ohw;
+      const int rem = gr - b * ohw;
+      const int oh = rem / d.OW, ow = rem - oh * d.OW;
+      a_ih0[j] = oh * d.stride - d.pad;
+      a_iw0[j] = ow * d.stride - d.pad;
+      asrc[j] = A + (int64_t)b * d.H * d.W * d.Cin + ((lc ^ ((row >> 1) & 7)) << 3);
+    } else {
+      a_ih0[j] = a_iw0[j] = 0;
+      asrc[j] = A + (int64_t)gr * d.lda + ((lc ^ ((row >> 1) & 7)) << 3);
+    }
   }
 #pragma unroll
   for (int j = 0; j < GB; ++j) {
@@ -61,9 +76,22 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const asis_gemm_desc d
   auto issue = [&](int t) {
     T* st = lds + (t % NS) * STAGE;
     const int k0 = t * BKB;
+    if (CONV) {
+      const int tap = k0 / d.Cin, ci0 = k0 - tap * d.Cin;
+      const int kh = tap / d.KW, kw = tap - kh * d.KW;
 #pragma unroll
-    for (int j = 0; j < GA; ++j)
-      __builtin_amdgcn_global_load_lds((glb_ptr)(asrc[j] + k0), (lds_ptr)(st + ((wid * GA + j) * 8) * BKB), 16, 0, 0);
+      for (int j = 0; j < GA; ++j) {
+        const int ih = a_ih0[j] + kh, iw = a_iw0[j] + kw;
+        const T* src = ((unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W)
+                           ? asrc[j] + ((int64_t)ih * d.W + iw) * d.Cin + ci0
+                           : reinterpret_cast<const T*>(g_zero_page);
+        __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(st + ((wid * GA + j) * 8) * BKB), 16, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < GA; ++j)
+        __builtin_amdgcn_global_load_lds((glb_ptr)(asrc[j] + k0), (lds_ptr)(st + ((wid * GA + j) * 8) * BKB), 16, 0, 0);
+    }
 #pragma unroll
     for (int j = 0; j < GB; ++j)
       __builtin_amdgcn_global_load_lds((glb_ptr)(bsrc[j] + k0), (lds_ptr)(st + BM2 * BKB + ((wid * GB + j) * 8) * BKB), 16, 0, 0);
@@ -152,6 +180,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const asis_gemm_desc d
     float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f), s4 = make_float4(1.f, 1.f, 1.f, 1.f);
     if (cok && d.bias_n) b4 = *reinterpret_cast<const float4*>(d.bias_n + col);
     if (cok && d.scale_n) s4 = *reinterpret_cast<const float4*>(d.scale_n + col);
+    float4 st_s = make_float4(0.f, 0.f, 0.f, 0.f), st_q = st_s;  // BatchNorm partial sums of this lane's columns
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -183,6 +212,41 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const asis_gemm_desc d
             pk.y = pack2<T>(v.z, v.w);
             *reinterpret_cast<uint2*>(reinterpret_cast<T*>(d.C) + cbase + (int64_t)row * d.ldc + col) = pk;
           }
+          st_s.x += v.x; st_s.y += v.y; st_s.z += v.z; st_s.w += v.w;
+          st_q.x += v.x * v.x; st_q.y += v.y * v.y; st_q.z += v.z * v.z; st_q.w += v.w * v.w;
+        }
+      }
+    }
+    if (d.stats) {
+      // lanes ch + LPR*rr hold the same columns: fold rr with xor-shuffles, then the WM row blocks through LDS.
+      // stats rows are per 128 rows (asis_gemm_tiles_m): this 256-row tile writes row 2*tile_m and zeroes 2*tile_m+1.
+      for (int o = LPR; o < 64; o <<= 1) {
+        st_s.x += __shfl_xor(st_s.x, o, 64); st_s.y += __shfl_xor(st_s.y, o, 64);
+        st_s.z += __shfl_xor(st_s.z, o, 64); st_s.w += __shfl_xor(st_s.w, o, 64);
+        st_q.x += __shfl_xor(st_q.x, o, 64); st_q.y += __shfl_xor(st_q.y, o, 64);
+        st_q.z += __shfl_xor(st_q.z, o, 64); st_q.w += __shfl_xor(st_q.w, o, 64);
+      }
+      __syncthreads();  // slabs are dead; reuse the head of LDS: red[wm][2][BN2]
+      float* red = reinterpret_cast<float*>(lds);
+      if (rr == 0) {
+        *reinterpret_cast<float4*>(red + (wm * 2 + 0) * BN2 + wn * TN * 32 + ch * 4) = st_s;
+        *reinterpret_cast<float4*>(red + (wm * 2 + 1) * BN2 + wn * TN * 32 + ch * 4) = st_q;
+      }
+      __syncthreads();
+      if (tid < BN2 && n0 + tid < d.N) {
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int w2 = 0; w2 < WM; ++w2) {
+          s += red[(w2 * 2 + 0) * BN2 + tid];
+          q += red[(w2 * 2 + 1) * BN2 + tid];
+        }
+        const int c = n0 + tid;
+        const int64_t r0 = (int64_t)tile_m * 2;
+        d.stats[(r0 * 2 + 0) * d.N + c] = s;
+        d.stats[(r0 * 2 + 1) * d.N + c] = q;
+        if ((r0 + 1) * 128 < d.M) {
+          d.stats[((r0 + 1) * 2 + 0) * d.N + c] = 0.f;
+          d.stats[((r0 + 1) * 2 + 1) * d.N + c] = 0.f;
         }
       }
     }

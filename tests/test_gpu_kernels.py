@@ -96,7 +96,9 @@ def test_gemm_batched_shared_a(dev, dt):
 
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("Cin,Cout,H,Wd,stride,pad", [(8, 16, 9, 7, 1, 1), (64, 128, 21, 21, 2, 0), (72, 40, 12, 13, 2, 1),
-                                                      (128, 64, 30, 30, 1, 1), (16, 2, 33, 31, 1, 1)])
+                                                      (128, 64, 30, 30, 1, 1), (16, 2, 33, 31, 1, 1),
+                                                      (64, 128, 40, 37, 1, 1), (64, 64, 41, 40, 2, 1), (192, 512, 20, 20, 1, 1),
+                                                      (128, 256, 33, 35, 2, 0)])
 def test_conv_implicit_gemm(dev, dt, Cin, Cout, H, Wd, stride, pad):
     Bn = 2
     x = W.tensor(f"cv.x{Cin}", (Bn, Cin, H, Wd), 1.0).to(dev)
