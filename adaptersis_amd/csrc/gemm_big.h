@@ -123,25 +123,32 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const asis_gemm_desc d
     if (!(DBG & 1) && t + NS - 1 < nt) issue(t + NS - 1);
     const T* As = lds + (t % NS) * STAGE;
     const T* Bs = As + BM2 * BKB;
-    if (!(DBG & 2))
+    if (!(DBG & 2)) {
+      // fragments of k-step ks+1 are fetched from LDS while the MFMAs of k-step ks run (register double buffer)
+      v8 af[2][TM], bf[2][TN];
+      auto fetch = [&](int ks, int slot) {
+        const int chunk = 2 * ks + fh;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      v8 af[TM], bf[TN];
-      const int chunk = 2 * ks + fh;
+        for (int i = 0; i < TM; ++i) {
+          const int row = (wm * TM + i) * 32 + fr;
+          af[slot][i] = __builtin_bit_cast(v8, *reinterpret_cast<const uint4*>(As + row * BKB + ((chunk ^ ((row >> 1) & 7)) << 3)));
+        }
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int row = (wm * TM + i) * 32 + fr;
-        af[i] = __builtin_bit_cast(v8, *reinterpret_cast<const uint4*>(As + row * BKB + ((chunk ^ ((row >> 1) & 7)) << 3)));
+        for (int j = 0; j < TN; ++j) {
+          const int col = (wn * TN + j) * 32 + fr;
+          bf[slot][j] = __builtin_bit_cast(v8, *reinterpret_cast<const uint4*>(Bs + col * BKB + ((chunk ^ ((col >> 1) & 7)) << 3)));
+        }
+      };
+      fetch(0, 0);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        if (ks < 3) fetch(ks + 1, (ks + 1) & 1);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = T16<T>::mfma32(bf[ks & 1][j], af[ks & 1][i], acc[i][j]);  // D[n][m]: lane = output row
       }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int col = (wn * TN + j) * 32 + fr;
-        bf[j] = __builtin_bit_cast(v8, *reinterpret_cast<const uint4*>(Bs + col * BKB + ((chunk ^ ((col >> 1) & 7)) << 3)));
-      }
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = T16<T>::mfma32(bf[j], af[i], acc[i][j]);  // D[n][m]: lane = output row
     }
   }
 
