@@ -32,6 +32,7 @@ class GemmDesc(C.Structure):
         ("B_", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32), ("OH", C.c_int32),
         ("OW", C.c_int32), ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
         ("stats", C.c_void_p),
+        ("A_lo", C.c_void_p), ("B_lo", C.c_void_p),
     ]
 
 

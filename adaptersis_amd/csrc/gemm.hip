@@ -213,6 +213,21 @@ int launch(hipStream_t s, const asis_gemm_desc& d) {
   // large-tile LDS-DMA kernel (gemm_big.h); ASIS_GEMM_BIG=0 forces the 128x128 register-staged kernel
   static const int big_mode = [] { const char* e = getenv("ASIS_GEMM_BIG"); return e ? atoi(e) : 1; }();
   const bool vec_ok = (d.N % 4 == 0) && (d.ldc % 4 == 0);
+  const bool split = d.A_lo != nullptr;
+  if (split) {  // one pass over the virtual 3K reduction; only on the large-tile kernel
+    const bool ok = big_mode && d.K % BK == 0 && d.M >= 256 && d.N >= 32 && vec_ok && d.out_f32 && (!d.conv || d.Cin % BK == 0);
+    if (!ok) return ASIS_EINVAL;
+    const int bm = 256, bn = d.N > 64 ? 128 : 64;
+    dim3 grid(((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn), d.batch), block(512);
+    if (d.conv) {
+      if (bn == 128) hipLaunchKernelGGL((gemm_big_kernel<T, 4, 2, 2, 2, 3, 0, true, true>), grid, block, 0, s, d);
+      else hipLaunchKernelGGL((gemm_big_kernel<T, 8, 1, 1, 2, 3, 0, true, true>), grid, block, 0, s, d);
+    } else {
+      if (bn == 128) hipLaunchKernelGGL((gemm_big_kernel<T, 4, 2, 2, 2, 3, 0, false, true>), grid, block, 0, s, d);
+      else hipLaunchKernelGGL((gemm_big_kernel<T, 8, 1, 1, 2, 3, 0, false, true>), grid, block, 0, s, d);
+    }
+    return 0;
+  }
   if (big_mode && !d.conv && !d.stats && d.K % BK == 0 && d.M >= 256 && d.N >= 128) {
     const bool wide = big_mode == 1 && d.N >= 2048;  // 256x256 for wide outputs, 256x128 (3 stages) otherwise
     const int bm = 256, bn = wide ? 256 : 128;
@@ -273,8 +288,11 @@ extern "C" int asis_gemm(void* stream, const asis_gemm_desc* dp) {
   const int64_t tiles = (int64_t)asis_cdiv(d.M, BM) * asis_cdiv(d.N, BN);
   ASIS_REQUIRE(tiles < (1ll << 31), "asis_gemm: too many tiles");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (d.dtype == ASIS_F16) launch<f16>(s, d);
-  else launch<bf16>(s, d);
+  ASIS_REQUIRE((d.A_lo == nullptr) == (d.B_lo == nullptr), "asis_gemm: A_lo and B_lo must be given together");
+  if (d.A_lo) ASIS_REQUIRE(asis_aligned16(d.A_lo) && asis_aligned16(d.B_lo), "asis_gemm: split halves must be 16-byte aligned");
+  const int rc = (d.dtype == ASIS_F16) ? launch<f16>(s, d) : launch<bf16>(s, d);
+  if (rc != 0) ASIS_FAIL(ASIS_EINVAL, "asis_gemm: split-precision operands need the large-tile path (K %% 64 == 0, M >= 256, N >= 32, "
+                                        "N and ldc multiples of 4, fp32 output; conv: Cin %% 64 == 0)");
   ASIS_CHECK_LAUNCH("asis_gemm");
   return ASIS_OK;
 }

@@ -21,7 +21,7 @@ constexpr int BKB = ASIS_GEMM_BK;
 // 16 zero bytes: the LDS-DMA source of implicit-im2col lanes that fall into the conv padding
 __device__ __attribute__((aligned(16))) uint4 g_zero_page[1];
 
-template <typename T, int WM, int WN, int TM, int TN, int NS, int DBG = 0, bool CONV = false>
+template <typename T, int WM, int WN, int TM, int TN, int NS, int DBG = 0, bool CONV = false, bool SPLIT = false>
 __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const asis_gemm_desc d) {
   typedef typename T16<T>::v8 v8;
   constexpr int BM2 = WM * TM * 32, BN2 = WN * TN * 32;
@@ -71,11 +71,24 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const asis_gemm_desc d
     gr = gr < d.N ? gr : d.N - 1;
     bsrc[j] = B + (int64_t)gr * d.ldb + ((lc ^ ((row >> 1) & 7)) << 3);
   }
+  // SPLIT: the reduction runs over three K-long parts: (A, B), (A_lo, B), (A, B_lo); the lo halves share the
+  // layout of the hi ones, so a part only changes the base pointers by a constant element offset.
+  const int64_t a_lo_off = SPLIT ? (reinterpret_cast<const T*>(d.A_lo) - reinterpret_cast<const T*>(d.A)) : 0;
+  const int64_t b_lo_off = SPLIT ? (reinterpret_cast<const T*>(d.B_lo) - reinterpret_cast<const T*>(d.B)) : 0;
+  const int nt1 = d.K / BKB;
   typedef __attribute__((address_space(3))) void* lds_ptr;
   typedef const __attribute__((address_space(1))) void* glb_ptr;
   auto issue = [&](int t) {
     T* st = lds + (t % NS) * STAGE;
-    const int k0 = t * BKB;
+    int kt = t;
+    int64_t aoff = 0, boff = 0;
+    if (SPLIT) {
+      const int part = t / nt1;
+      kt = t - part * nt1;
+      aoff = part == 1 ? a_lo_off : 0;
+      boff = part == 2 ? b_lo_off : 0;
+    }
+    const int k0 = kt * BKB;
     if (CONV) {
       const int tap = k0 / d.Cin, ci0 = k0 - tap * d.Cin;
       const int kh = tap / d.KW, kw = tap - kh * d.KW;
@@ -83,18 +96,18 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const asis_gemm_desc d
       for (int j = 0; j < GA; ++j) {
         const int ih = a_ih0[j] + kh, iw = a_iw0[j] + kw;
         const T* src = ((unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W)
-                           ? asrc[j] + ((int64_t)ih * d.W + iw) * d.Cin + ci0
+                           ? asrc[j] + aoff + ((int64_t)ih * d.W + iw) * d.Cin + ci0
                            : reinterpret_cast<const T*>(g_zero_page);
         __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(st + ((wid * GA + j) * 8) * BKB), 16, 0, 0);
       }
     } else {
 #pragma unroll
       for (int j = 0; j < GA; ++j)
-        __builtin_amdgcn_global_load_lds((glb_ptr)(asrc[j] + k0), (lds_ptr)(st + ((wid * GA + j) * 8) * BKB), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_ptr)(asrc[j] + aoff + k0), (lds_ptr)(st + ((wid * GA + j) * 8) * BKB), 16, 0, 0);
     }
 #pragma unroll
     for (int j = 0; j < GB; ++j)
-      __builtin_amdgcn_global_load_lds((glb_ptr)(bsrc[j] + k0), (lds_ptr)(st + BM2 * BKB + ((wid * GB + j) * 8) * BKB), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_ptr)(bsrc[j] + boff + k0), (lds_ptr)(st + BM2 * BKB + ((wid * GB + j) * 8) * BKB), 16, 0, 0);
   };
 
   f32x16 acc[TM][TN];
@@ -105,7 +118,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const asis_gemm_desc d
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nt = d.K / BKB;
+  const int nt = SPLIT ? 3 * nt1 : nt1;
 #pragma unroll
   for (int s = 0; s < NS - 1; ++s)
     if (s < nt) issue(s);

@@ -7,6 +7,7 @@ tensors allocated with ``torch.empty``.  A CPU tensor, a missing library or a ba
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional
 
 import torch
@@ -66,7 +67,8 @@ def _f32c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
 def gemm(a: torch.Tensor, b: torch.Tensor, *, out: Optional[torch.Tensor] = None, out_f32: bool = False,
          bias_n: Optional[torch.Tensor] = None, bias_m: Optional[torch.Tensor] = None,
          scale_n: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None, act: int = ACT_NONE,
-         stats: Optional[torch.Tensor] = None) -> torch.Tensor:
+         stats: Optional[torch.Tensor] = None, a_lo: Optional[torch.Tensor] = None,
+         b_lo: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``out = epilogue(a @ b.T)``; a [M,K] or [batch,M,K], b [N,K] or [batch,N,K] (16-bit, K contiguous).
 
     A 2-D operand next to a 3-D one is shared by every batch element.  Row strides may exceed K.
@@ -105,7 +107,13 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, out: Optional[torch.Tensor] = None
         d.strideR = res.stride(0) if res.dim() == 3 else 0
     d.act, d.out_f32, d.dtype = act, int(out_f32), _dt(a.dtype)
     d.stats = _p(stats)
-    check(_launch_timed("gemm", 2.0 * batch * M * N * K, lambda: lib().asis_gemm(_stream(), C.byref(d))), "asis_gemm")
+    flops = 2.0 * batch * M * N * K
+    if a_lo is not None:
+        if a_lo.stride() != a.stride() or b_lo.stride() != b.stride():
+            raise ValueError("gemm: split halves must share the layout of their hi parts")
+        d.A_lo, d.B_lo = a_lo.data_ptr(), b_lo.data_ptr()
+        flops *= 3
+    check(_launch_timed("gemm", flops, lambda: lib().asis_gemm(_stream(), C.byref(d))), "asis_gemm")
     return out
 
 
@@ -115,7 +123,8 @@ def gemm_tiles_m(M: int) -> int:
 
 def conv_gemm(x_nhwc: torch.Tensor, w_packed: torch.Tensor, KH: int, KW: int, stride: int, pad: int, *,
               out: Optional[torch.Tensor] = None, out_f32: bool = True, bias_n: Optional[torch.Tensor] = None,
-              act: int = ACT_NONE, stats: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
+              act: int = ACT_NONE, stats: Optional[torch.Tensor] = None, accumulate: bool = False,
+              x_lo: Optional[torch.Tensor] = None, w_lo: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Implicit-GEMM convolution: x [B,H,W,Cin] (16-bit NHWC), w_packed [Cout, KH*KW*Cin] ->
     out [B,OH,OW,Cout] (fp32 by default: BatchNorm statistics are taken on it)."""
     _dev(x_nhwc, w_packed, out, bias_n, stats)
@@ -140,15 +149,23 @@ def conv_gemm(x_nhwc: torch.Tensor, w_packed: torch.Tensor, KH: int, KW: int, st
     d.conv, d.B_, d.H, d.W, d.Cin, d.OH, d.OW = 1, Bn, H, W, Cin, OH, OW
     d.KH, d.KW, d.stride, d.pad = KH, KW, stride, pad
     d.stats = _p(stats)
-    check(_launch_timed("conv", 2.0 * d.M * Cout * K, lambda: lib().asis_gemm(_stream(), C.byref(d))),
-          "asis_gemm(conv)")
+    flops = 2.0 * d.M * Cout * K
+    if x_lo is not None:
+        d.A_lo, d.B_lo = x_lo.data_ptr(), w_lo.data_ptr()
+        flops *= 3
+    check(_launch_timed("conv", flops, lambda: lib().asis_gemm(_stream(), C.byref(d))), "asis_gemm(conv)")
     return out
 
 
 def conv_gemm_split(x_hi, x_lo, w_hi, w_lo, KH: int, KW: int, stride: int, pad: int, *, bias_n=None, stats=None):
     """Split-precision convolution: x ~= x_hi + x_lo, w ~= w_hi + w_lo (16-bit halves), fp32 out =
-    x_hi*w_hi + x_lo*w_hi + x_hi*w_lo (+ bias) as three MFMA passes accumulating in fp32 (the dropped
-    x_lo*w_lo term is ~2^-22 relative).  BatchNorm statistics are taken on the last pass."""
+    x_hi*w_hi + x_lo*w_hi + x_hi*w_lo (+ bias), accumulated in fp32 (the dropped x_lo*w_lo term is ~2^-22
+    relative): one launch over a virtual 3K reduction on the large-tile kernel, else three accumulate passes."""
+    Bn, H, W, Cin = x_hi.shape
+    OH, OW = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+    Cout = w_hi.shape[0]
+    if Cin % 64 == 0 and Bn * OH * OW >= 256 and Cout >= 32 and Cout % 4 == 0 and os.environ.get("ASIS_GEMM_BIG", "1") != "0":
+        return conv_gemm(x_hi, w_hi, KH, KW, stride, pad, bias_n=bias_n, stats=stats, x_lo=x_lo, w_lo=w_lo)
     out = conv_gemm(x_hi, w_hi, KH, KW, stride, pad, bias_n=bias_n)
     conv_gemm(x_lo, w_hi, KH, KW, stride, pad, out=out, accumulate=True)
     conv_gemm(x_hi, w_lo, KH, KW, stride, pad, out=out, accumulate=True, stats=stats)
@@ -156,7 +173,10 @@ def conv_gemm_split(x_hi, x_lo, w_hi, w_lo, KH: int, KW: int, stride: int, pad: 
 
 
 def gemm_split(a_hi, a_lo, b_hi, b_lo, *, out: torch.Tensor, bias_n=None):
-    """Split-precision ``out = (a_hi + a_lo) @ (b_hi + b_lo).T + bias`` into an fp32 ``out`` (three passes)."""
+    """Split-precision ``out = (a_hi + a_lo) @ (b_hi + b_lo).T + bias`` into an fp32 ``out``."""
+    M, K, N = a_hi.shape[-2], a_hi.shape[-1], b_hi.shape[-2]
+    if K % 64 == 0 and M >= 256 and N >= 32 and N % 4 == 0 and os.environ.get("ASIS_GEMM_BIG", "1") != "0":
+        return gemm(a_hi, b_hi, out=out, bias_n=bias_n, a_lo=a_lo, b_lo=b_lo)
     gemm(a_hi, b_hi, out=out, bias_n=bias_n)
     gemm(a_lo, b_hi, out=out, res=out)
     gemm(a_hi, b_lo, out=out, res=out)

@@ -88,6 +88,12 @@ typedef struct asis_gemm_desc {
   /* optional fp32 per-column partial statistics of the fp32 output (BatchNorm train mode):
    * stats[(tile_m * 2 + {0,1}) * N + n] = sum / sum of squares over the tile's valid rows. */
   float* stats;
+  /* optional split-precision halves (both or neither): A ~= A + A_lo, B ~= B + B_lo (rounding residuals, see
+   * asis_cast_pad part=1).  The kernel then accumulates A*B + A_lo*B + A*B_lo in ONE pass over a virtual
+   * 3K-long reduction (same layouts/strides as A and B).  Needs the large-tile path: K % 64 == 0, M >= 256,
+   * N >= 32 (conv: Cin % 64 == 0); otherwise ASIS_EINVAL — callers then run three accumulate passes. */
+  const void* A_lo;
+  const void* B_lo;
 } asis_gemm_desc;
 int asis_gemm(void* stream, const asis_gemm_desc* d);
 /* number of M tiles asis_gemm uses for M rows (size of the stats buffer = tiles*2*N floats) */

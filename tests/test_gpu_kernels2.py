@@ -258,3 +258,38 @@ def test_smallcout_direct_conv_fwd_and_dgrad(dev, Cout):
         d_lo = ops.cast_pad(dn, 8, torch.float16, part=1).view(Bn, H, Wd, 8)
         dx = ops.conv3x3_smallcout_dgrad(d_hi, d_lo, w.to(dev))
         assert rel_l2(dx, x.grad.permute(0, 2, 3, 1)) < 2e-6
+
+
+@pytest.mark.parametrize("Cin,Cout,H,stride,pad", [(64, 48, 19, 1, 1), (128, 128, 24, 1, 1), (64, 64, 37, 2, 0)])
+def test_fused_split_conv_single_launch(dev, Cin, Cout, H, stride, pad):
+    """Cin % 64 == 0 takes the one-launch form (virtual 3K reduction on the large-tile kernel), incl. BN stats."""
+    Bn = 2
+    x = W.tensor(f"fs.x{Cin}", (Bn, Cin, H, H), 1.0)
+    w = W.tensor(f"fs.w{Cin}", (Cout, Cin, 3, 3), 0.2)
+    bias = W.tensor(f"fs.b{Cin}", (Cout,), 0.5)
+    ref = F.conv2d(x, w, bias, stride=stride, padding=pad).permute(0, 2, 3, 1)
+    xn = x.permute(0, 2, 3, 1).contiguous().view(-1, Cin).to(dev)
+    x_hi = ops.cast_pad(xn, Cin, torch.float16).view(Bn, H, H, Cin)
+    x_lo = ops.cast_pad(xn, Cin, torch.float16, part=1).view(Bn, H, H, Cin)
+    w_hi = ops.pack_conv_weight(w.to(dev), 0, torch.float16)
+    w_lo = ops.pack_conv_weight(w.to(dev), 0, torch.float16, 1)
+    M = ref.shape[0] * ref.shape[1] * ref.shape[2]
+    stats = torch.full((ops.gemm_tiles_m(M), 2, Cout), float("nan"), device=dev)
+    y = ops.conv_gemm_split(x_hi, x_lo, w_hi, w_lo, 3, 3, stride, pad, bias_n=bias.to(dev), stats=stats)
+    assert rel_l2(y, ref) < 3e-6
+    assert rel_l2(stats.sum(0)[0], ref.sum((0, 1, 2))) < 1e-4
+    assert rel_l2(stats.sum(0)[1], (ref * ref).sum((0, 1, 2))) < 1e-5
+
+
+def test_fused_split_dense_gemm(dev):
+    M, N, K = 1300, 384, 256
+    a = W.tensor("fd.a", (2, M, K), 1.0).to(dev)
+    b = W.tensor("fd.b", (N, K), 0.2).to(dev)
+    bias = W.tensor("fd.bias", (N,), 0.5).to(dev)
+    a_hi = ops.cast_pad(a.view(-1, K), K, torch.float16).view(2, M, K)
+    a_lo = ops.cast_pad(a.view(-1, K), K, torch.float16, part=1).view(2, M, K)
+    b_hi, b_lo = ops.cast_pad(b, K, torch.float16), ops.cast_pad(b, K, torch.float16, part=1)
+    out = torch.empty(2, M, N + 16, device=dev)[:, :, :N]
+    ops.gemm_split(a_hi, a_lo, b_hi, b_lo, out=out, bias_n=bias)
+    ref = a @ b.t() + bias
+    assert rel_l2(out, ref) < 3e-6
