@@ -157,6 +157,9 @@ def conv_gemm(x_nhwc: torch.Tensor, w_packed: torch.Tensor, KH: int, KW: int, st
     return out
 
 
+_FUSED_SPLIT = os.environ.get("ASIS_GEMM_BIG", "1") != "0" and os.environ.get("ASIS_SPLIT_FUSED", "1") != "0"
+
+
 def conv_gemm_split(x_hi, x_lo, w_hi, w_lo, KH: int, KW: int, stride: int, pad: int, *, bias_n=None, stats=None):
     """Split-precision convolution: x ~= x_hi + x_lo, w ~= w_hi + w_lo (16-bit halves), fp32 out =
     x_hi*w_hi + x_lo*w_hi + x_hi*w_lo (+ bias), accumulated in fp32 (the dropped x_lo*w_lo term is ~2^-22
@@ -164,7 +167,7 @@ def conv_gemm_split(x_hi, x_lo, w_hi, w_lo, KH: int, KW: int, stride: int, pad: 
     Bn, H, W, Cin = x_hi.shape
     OH, OW = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
     Cout = w_hi.shape[0]
-    if Cin % 64 == 0 and Bn * OH * OW >= 256 and Cout >= 32 and Cout % 4 == 0 and os.environ.get("ASIS_GEMM_BIG", "1") != "0":
+    if Cin % 64 == 0 and Bn * OH * OW >= 256 and Cout >= 32 and Cout % 4 == 0 and _FUSED_SPLIT:
         return conv_gemm(x_hi, w_hi, KH, KW, stride, pad, bias_n=bias_n, stats=stats, x_lo=x_lo, w_lo=w_lo)
     out = conv_gemm(x_hi, w_hi, KH, KW, stride, pad, bias_n=bias_n)
     conv_gemm(x_lo, w_hi, KH, KW, stride, pad, out=out, accumulate=True)
@@ -175,7 +178,7 @@ def conv_gemm_split(x_hi, x_lo, w_hi, w_lo, KH: int, KW: int, stride: int, pad: 
 def gemm_split(a_hi, a_lo, b_hi, b_lo, *, out: torch.Tensor, bias_n=None):
     """Split-precision ``out = (a_hi + a_lo) @ (b_hi + b_lo).T + bias`` into an fp32 ``out``."""
     M, K, N = a_hi.shape[-2], a_hi.shape[-1], b_hi.shape[-2]
-    if K % 64 == 0 and M >= 256 and N >= 32 and N % 4 == 0 and os.environ.get("ASIS_GEMM_BIG", "1") != "0":
+    if K % 64 == 0 and M >= 256 and N >= 32 and N % 4 == 0 and _FUSED_SPLIT:
         return gemm(a_hi, b_hi, out=out, bias_n=bias_n, a_lo=a_lo, b_lo=b_lo)
     gemm(a_hi, b_hi, out=out, bias_n=bias_n)
     gemm(a_lo, b_hi, out=out, res=out)
