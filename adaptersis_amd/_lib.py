@@ -86,6 +86,7 @@ SIGNATURES = {
     "asis_colstats": [_vp, _vp, _i64, _i, _vp],
     "asis_reduce_partials": [_vp, _vp, _i, _i, _vp],
     "asis_bn_finalize": [_vp, _vp, _d, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "asis_bn_eval_affine": [_vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _vp],
     "asis_bn_act": [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _i64, _i],
     "asis_bn_relu_maxpool": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i],
     "asis_bn_relu_upsample": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i],
@@ -95,6 +96,8 @@ SIGNATURES = {
     "asis_dice_nblk": [_i, _i],
     "asis_dice_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp],
     "asis_dice_bwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "asis_ce_acc_nblk": [_i64],
+    "asis_ce_acc": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "asis_resize_bwd_nblk": [_i64],
     "asis_resize_bilinear_bwd": [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp],
     "asis_reduce_rows": [_vp, _vp, _i, _i, _f, _vp],

@@ -41,19 +41,26 @@ def _conv_weights(owner: _Packed, key: str, conv: nn.Conv2d, split: bool):
 
 
 def conv_bn_relu_up_forward(owner: _Packed, key: str, x16, x_lo, conv: nn.Conv2d, bn: nn.BatchNorm2d, factor: int,
-                            sync_bn: bool, save: bool):
-    """(x16, x_lo|None) NHWC -> ((up_hi, up_lo|None), saved stage)."""
+                            sync_bn: bool, save: bool, training: bool = True):
+    """(x16, x_lo|None) NHWC -> ((up_hi, up_lo|None), saved stage).  training=False: BatchNorm uses its running
+    statistics (``seg_decoder.eval()`` in validate_network, train.py:451) and nothing is saved."""
     dt = config.operand_dtype
     split = x_lo is not None
     B, H, W, _ = x16.shape
     w_hi, w_lo = _conv_weights(owner, key, conv, split)
-    stats = torch.empty((ops.gemm_tiles_m(B * H * W), 2, conv.out_channels), device=x16.device, dtype=torch.float32)
+    stats = torch.empty((ops.gemm_tiles_m(B * H * W), 2, conv.out_channels), device=x16.device,
+                        dtype=torch.float32) if training else None
     bias = owner._f32(key + ".b", conv.bias)
     if split:
         raw = ops.conv_gemm_split(x16, x_lo, w_hi, w_lo, 3, 3, 1, 1, bias_n=bias, stats=stats)
     else:
         raw = ops.conv_gemm(x16, w_hi, 3, 3, 1, 1, bias_n=bias, stats=stats)
-    scale, shift, mean, invstd, count = _bn.finalize(stats, B * H * W, bn, sync_bn)
+    if training:
+        scale, shift, mean, invstd, count = _bn.finalize(stats, B * H * W, bn, sync_bn)
+    else:
+        scale, shift = ops.bn_eval_affine(bn)
+        mean = invstd = count = None
+        save = False
     up = ops.bn_relu_upsample(raw, scale, shift, factor, dt, split) if factor > 1 else \
         ops.bn_act(raw, scale, shift, True, dt, split)
     if not split:
@@ -155,13 +162,14 @@ class FeatureDecoder(_Packed):
         lo = ops.cast_pad(x2, C, config.operand_dtype, part=1).view(B, H, W, C) if config.split_conv else None
         return hi, lo
 
-    def _forward_core(self, x16, x_lo, save: bool):
+    def _forward_core(self, x16, x_lo, save: bool, training: Optional[bool] = None):
         """(x16, x_lo|None): NHWC 16-bit decoder input (x_lo = rounding residual for split precision)."""
+        training = self.training if training is None else training
         saved: List = []
         a = (x16, x_lo)
         for i in range(1, 5):
             seq = getattr(self, f"decoder_{i}")
-            a, st = conv_bn_relu_up_forward(self, f"d{i}", a[0], a[1], seq[0], seq[1], 2, self.sync_bn, save)
+            a, st = conv_bn_relu_up_forward(self, f"d{i}", a[0], a[1], seq[0], seq[1], 2, self.sync_bn, save, training)
             saved.append(st)
         bias = self._f32("final.b", self.final_out.bias)
         fo = self.final_out
@@ -206,7 +214,7 @@ class FeatureDecoder(_Packed):
     # ---- reference-shaped entry point ----------------------------------------------------------------
     def forward(self, x):
         """`decoders.py:137-164`: (B, 3*embed, h, w) fp32 -> logits (B, classes, 16h, 16w) fp32."""
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             return _DecoderFn.apply(self, x, *list(self.parameters()))
         logits, _ = self._forward_core(*self._to_nhwc16(x), save=False)
         return logits.permute(0, 3, 1, 2)

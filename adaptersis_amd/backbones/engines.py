@@ -172,7 +172,7 @@ class SegEngine(nn.Module):
         dec = self.seg_decoder
         S = config.loss_scale
         cat = self.features(inp, taps)
-        logits, saved = dec._forward_core(cat[0], cat[1], save=True)
+        logits, saved = dec._forward_core(cat[0], cat[1], save=True, training=True)
         target = target.long().contiguous()
         loss, coef, _ = ops.dice_fwd(logits, target, 2, 10e-20, S)
         dz = ops.dice_bwd(logits, target, coef, 2)
@@ -191,5 +191,20 @@ class SegEngine(nn.Module):
 
     @torch.no_grad()
     def eval_logits(self, inp: torch.Tensor) -> torch.Tensor:
+        """Decoder logits, NHWC fp32, with the decoder's BatchNorm in its current train/eval mode."""
         logits, _ = self.seg_decoder._forward_core(*self.features(inp), save=False)
-        return logits  # NHWC fp32
+        return logits
+
+    @torch.no_grad()
+    def validate_step(self, inp: torch.Tensor, target: torch.Tensor, ce_weight: Optional[torch.Tensor] = None):
+        """`train.py:465-642` for one batch: -> device tensor [4] = (weighted CE, dice, pixel accuracy, n_images).
+        The decoder runs in eval mode (running BatchNorm statistics, `train.py:451`); the encoder's SyncBatchNorm
+        stays in train mode exactly like the reference."""
+        was = self.seg_decoder.training
+        self.seg_decoder.eval()
+        logits = self.eval_logits(inp)
+        self.seg_decoder.train(was)
+        target = target.long().contiguous()
+        m = ops.ce_acc(logits, target, ce_weight)
+        loss1, _, _ = ops.dice_fwd(logits, target, 1, 10e-20, 1.0)
+        return m, loss1

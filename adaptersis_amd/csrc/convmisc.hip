@@ -145,6 +145,18 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, double count
   }
 }
 
+// ---- BatchNorm eval-mode affine from the running statistics (decoders in validate_network, train.py:451) ----
+__global__ void bn_eval_affine_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                      const float* __restrict__ rm, const float* __restrict__ rv, float eps, int C,
+                                      float* __restrict__ scale, float* __restrict__ shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float is = 1.0f / sqrtf(rv[c] + eps);
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  scale[c] = g * is;
+  shift[c] = b - rm[c] * g * is;
+}
+
 // ---- y = [relu](x*scale + shift) -> 16-bit --------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ x, const float* __restrict__ scale,
@@ -392,6 +404,15 @@ extern "C" int asis_bn_finalize(void* stream, const double* sums, double count, 
                      sums, count, C, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, scale,
                      shift, mean_out, invstd_out);
   ASIS_CHECK_LAUNCH("asis_bn_finalize");
+  return ASIS_OK;
+}
+
+extern "C" int asis_bn_eval_affine(void* stream, const float* gamma, const float* beta, const float* running_mean,
+                                   const float* running_var, float eps, int C, float* scale, float* shift) {
+  ASIS_REQUIRE(running_mean && running_var && scale && shift && C > 0, "asis_bn_eval_affine: bad arguments");
+  hipLaunchKernelGGL(bn_eval_affine_kernel, dim3((C + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     gamma, beta, running_mean, running_var, eps, C, scale, shift);
+  ASIS_CHECK_LAUNCH("asis_bn_eval_affine");
   return ASIS_OK;
 }
 

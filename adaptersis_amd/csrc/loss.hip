@@ -271,6 +271,50 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
   if (threadIdx.x == 0) out[k] = (float)(red[0] * (double)scale);
 }
 
+// Validation metrics of train.py:616-642 in one pass over the (resized) logits: class-weighted cross entropy
+// numerator / denominator (nn.CrossEntropyLoss(weight) = sum w[t]*nll / sum w[t]) and the number of pixels
+// whose argmax equals the target.  partial[blk][3] = {sum w*nll, sum w, correct}.
+__global__ __launch_bounds__(256) void ce_acc_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target,
+                                                     const float* __restrict__ weight, int B, int h, int w, int H, int W,
+                                                     int C, float* __restrict__ partial) {
+  __shared__ float red[4][3];
+  const float sh = (float)h / (float)H, sw = (float)w / (float)W;
+  const int64_t total = (int64_t)B * H * W;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int x = (int)(i % W);
+    const int y = (int)((i / W) % H);
+    const int b = (int)(i / ((int64_t)W * H));
+    float z[MAXC];
+    sample_logits(logits + (int64_t)b * h * w * C, h, w, C, y, x, sh, sw, z);
+    float m = -INFINITY;
+    int am = 0;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+      if (c < C && z[c] > m) { m = z[c]; am = c; }
+    float se = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+      if (c < C) se += __expf(z[c] - m);
+    const int t = (int)target[i];
+    float zt = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+      if (c == t) zt = z[c];
+    const float wt = weight ? weight[t] : 1.f;
+    a0 += wt * (m + __logf(se) - zt);
+    a1 += wt;
+    a2 += (am == t) ? 1.f : 0.f;
+  }
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2);
+  if (lane == 0) { red[wid][0] = a0; red[wid][1] = a1; red[wid][2] = a2; }
+  __syncthreads();
+  if (threadIdx.x < 3)
+    partial[(int64_t)blockIdx.x * 3 + threadIdx.x] =
+        (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
 // few rows, many columns (split-K slabs of the weight gradients): one thread per column, coalesced rows
 __global__ __launch_bounds__(256) void reduce_rows_wide_kernel(const float* __restrict__ partial, int n, int64_t K,
                                                                float scale, float* __restrict__ out) {
@@ -312,6 +356,23 @@ extern "C" int asis_dice_bwd(void* stream, const float* logits, const int64_t* t
   hipLaunchKernelGGL(dice_bwd_kernel, dim3(asis_dice_nblk(H, W), B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                      logits, target, coef, h, w, H, W, C, n_softmax, dz);
   ASIS_CHECK_LAUNCH("asis_dice_bwd");
+  return ASIS_OK;
+}
+
+extern "C" int asis_ce_acc_nblk(int64_t total_pixels) {
+  int64_t n = (total_pixels + 256 * 8 - 1) / (256 * 8);
+  if (n > 2048) n = 2048;
+  if (n < 1) n = 1;
+  return (int)n;
+}
+
+extern "C" int asis_ce_acc(void* stream, const float* logits, const int64_t* target, const float* weight, int B, int h,
+                           int w, int H, int W, int C, float* partial) {
+  ASIS_REQUIRE(logits && target && partial, "asis_ce_acc: null pointer");
+  ASIS_REQUIRE(C >= 1 && C <= MAXC, "asis_ce_acc: C=%d must be in 1..%d", C, MAXC);
+  hipLaunchKernelGGL(ce_acc_kernel, dim3(asis_ce_acc_nblk((int64_t)B * H * W)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), logits, target, weight, B, h, w, H, W, C, partial);
+  ASIS_CHECK_LAUNCH("asis_ce_acc");
   return ASIS_OK;
 }
 

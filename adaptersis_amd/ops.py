@@ -363,6 +363,18 @@ def _lo(out: torch.Tensor, split: bool):
     return torch.empty_like(out) if split else None
 
 
+def bn_eval_affine(bn) -> tuple:
+    """(scale, shift) of an eval-mode nn.BatchNorm2d from its running statistics."""
+    Cc = bn.running_mean.numel()
+    _dev(bn.running_mean)
+    out = torch.empty((2, Cc), device=bn.running_mean.device, dtype=torch.float32)
+    check(lib().asis_bn_eval_affine(_stream(), _p(bn.weight.detach() if bn.weight is not None else None),
+                                    _p(bn.bias.detach() if bn.bias is not None else None), bn.running_mean.data_ptr(),
+                                    bn.running_var.data_ptr(), float(bn.eps), Cc, out[0].data_ptr(), out[1].data_ptr()),
+          "asis_bn_eval_affine")
+    return out[0], out[1]
+
+
 def bn_act(x: torch.Tensor, scale, shift, relu: bool, dtype: torch.dtype, split: bool = False):
     """-> out (and (out, out_lo) when split: the two halves of a split-precision operand)."""
     _dev(x, scale, shift)
@@ -462,6 +474,18 @@ def dice_fwd(logits: torch.Tensor, target: torch.Tensor, n_softmax: int, eps: fl
                               float(eps), float(grad_scale), partial.data_ptr(), sums.data_ptr(), loss.data_ptr(),
                               coef.data_ptr()), "asis_dice_fwd")
     return loss, coef, sums
+
+
+def ce_acc(logits: torch.Tensor, target: torch.Tensor, weight: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """logits fp32 NHWC [B,h,w,C], target int64 [B,H,W] -> fp32 [3] = (sum w*nll, sum w, #correct)."""
+    _dev(logits, target, weight)
+    B, h, w, Cc = logits.shape
+    H, W = target.shape[-2:]
+    nblk = lib().asis_ce_acc_nblk(B * H * W)
+    partial = torch.empty((nblk, 3), device=logits.device, dtype=torch.float32)
+    check(lib().asis_ce_acc(_stream(), _f32c(logits).data_ptr(), target.data_ptr(), _p(_f32c(weight)), B, h, w, H, W, Cc,
+                            partial.data_ptr()), "asis_ce_acc")
+    return reduce_rows(partial)
 
 
 def dice_bwd(logits: torch.Tensor, target: torch.Tensor, coef: torch.Tensor, n_softmax: int) -> torch.Tensor:

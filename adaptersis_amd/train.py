@@ -1,0 +1,216 @@
+"""Drop-in for the reference's `train.py`: same CLI (`train.py:654-683`), same function signatures
+(`train_seg` :63, `train` :260, `validate_network` :449), same checkpoint / log formats (:244-255) — the step
+body runs on the HIP engine (`backbones.engines.SegEngine`) instead of eager PyTorch modules.
+
+    python -m adaptersis_amd.train --arch vit_large --patch_size 14 --imsize 588 --batch_size_per_gpu 12 \
+        --data_path synthetic --epochs 1 --output_dir /tmp/out
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m adaptersis_amd.train ...
+
+Differences forced by the environment (no network, no torchvision/albumentations/omegaconf here): the four
+`configs/eval/vit*14_pretrain.yaml` files reduce to the arch table below; `--data_path synthetic` (default when the
+path does not exist) trains on the synthetic set of SURVEY.md §8d; `--data_path <dir>` expects ``images.npy``
+(N,3,H,W float in [0,1]) and ``masks.npy`` (N,H,W int) per split directory (``train/``, ``validation/``).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+from pathlib import Path
+
+import torch
+from torch import nn
+
+from .backbones.adapter_blocks import CACNN, CAViT
+from .backbones.decoders import FeatureDecoder
+from .backbones.encoders import FeatureEncoder
+from .backbones.engines import SegEngine
+from .dinov2.models import vision_transformer as vits
+from .utils import misc as utils
+from .utils import weights as W
+
+ARCH_FFN = {"vit_tiny_test": "mlp", "vit_small": "mlp", "vit_base": "mlp", "vit_large": "mlp", "vit_giant2": "swiglufused"}
+_ENGINES = {}
+
+
+class _SegData(torch.utils.data.Dataset):
+    """(img float[0,1] CHW, mask long HW, index) like `tools/dataset.py:127-167`."""
+
+    def __init__(self, path, split, imsize, n_synth=24):
+        d = os.path.join(path, split)
+        if os.path.isfile(os.path.join(d, "images.npy")):
+            import numpy as np
+            self.img = torch.from_numpy(np.load(os.path.join(d, "images.npy"))).float()
+            self.msk = torch.from_numpy(np.load(os.path.join(d, "masks.npy"))).long()
+        else:
+            self.img, self.msk = W.synthetic_batch(n_synth, imsize, 2, seed=1 if split == "train" else 2)
+
+    def __len__(self):
+        return self.img.shape[0]
+
+    def __getitem__(self, i):
+        return self.img[i], self.msk[i], i
+
+
+def _engine_for(model, backbone_encoder, cross_vit, cross_cnn, seg_decoder, lr=0.01):
+    key = id(seg_decoder)
+    if key not in _ENGINES:
+        _ENGINES[key] = SegEngine(model, backbone_encoder, cross_vit, cross_cnn, seg_decoder, lr=lr)
+    return _ENGINES[key]
+
+
+def train_seg(args):
+    utils.init_distributed_mode(args)
+    print("\n".join("%s: %s" % (k, str(v)) for k, v in sorted(dict(vars(args)).items())))
+    dev = torch.device("cuda", args.gpu)
+    arch = args.arch if args.arch in ARCH_FFN else "vit_large"
+    D = W.VIT_CONFIGS[arch][0]
+    # dinov2/eval/setup.py:62-75 + models/__init__.py:14-29 (teacher, img_size 518, layerscale 1e-5, block_chunks 0)
+    model = vits.__dict__[arch](patch_size=args.patch_size, img_size=518, init_values=1e-5, ffn_layer=ARCH_FFN[arch],
+                                block_chunks=0)
+    if args.pretrained_weights and os.path.isfile(args.pretrained_weights):
+        sd = torch.load(args.pretrained_weights, map_location="cpu")
+        sd = sd.get(args.checkpoint_key, sd) if isinstance(sd, dict) else sd
+        sd = {k.replace("module.", "").replace("backbone.", ""): v for k, v in sd.items()}  # dinov2/utils/utils.py:20-33
+        print("Pretrained weights loaded with msg:", model.load_state_dict(sd, strict=False))
+    else:
+        model.load_state_dict(W.make_vit_state_dict(arch, patch_size=args.patch_size, layerscale="init"))
+        print("No pretrained weights: deterministic synthetic initialisation (adaptersis_amd.utils.weights)")
+    model = model.to(dev).eval()
+    feature_model = model  # ModelWithIntermediateLayers(model, 4, autocast) collapses into the engine's pass A
+    backbone_encoder = FeatureEncoder(embed_dim=D).to(dev)
+    cross_vit = CAViT(dim=D, n_levels=3, num_heads=8, init_values=0.0, n_points=4).to(dev)
+    cross_cnn = CACNN(dim=D, n_levels=1, num_heads=8, n_points=4, with_cffn=True, cffn_ratio=0.25).to(dev)
+    seg_decoder = FeatureDecoder(embed_dim=D, num_classes=2, features=[D, 512, 256, 128, 64]).to(dev)
+    engine = _engine_for(model, backbone_encoder, cross_vit, cross_cnn, seg_decoder, lr=args.lr)
+    optimizer = engine.optimizer  # SGD(lr, momentum 0.99, wd 3e-5): train.py:178-191
+
+    dataset_val = _SegData(args.data_path, "validation", args.imsize)
+    val_loader = torch.utils.data.DataLoader(dataset_val, batch_size=args.batch_size_per_gpu, num_workers=0, pin_memory=True)
+    dataset_train = _SegData(args.data_path, "train", args.imsize)
+    sampler = torch.utils.data.distributed.DistributedSampler(dataset_train, num_replicas=utils.get_world_size(),
+                                                               rank=utils.get_rank())
+    train_loader = torch.utils.data.DataLoader(dataset_train, sampler=sampler, batch_size=args.batch_size_per_gpu,
+                                               num_workers=0, pin_memory=True, drop_last=True)
+    print(f"Data loaded with {len(dataset_train)} train and {len(dataset_val)} val imgs.")
+
+    class _Cosine:  # torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, epochs, eta_min=0), stepped per epoch
+        def __init__(self, opt, T):
+            self.opt, self.T, self.e = opt, T, 0
+            self.base = [g["lr"] for g in opt.param_groups]
+
+        def step(self):
+            self.e += 1
+            for g, b in zip(self.opt.param_groups, self.base):
+                g["lr"] = b * (1 + math.cos(math.pi * self.e / self.T)) / 2
+
+        def state_dict(self):
+            return {"last_epoch": self.e, "base_lrs": self.base, "T_max": self.T}
+
+        def load_state_dict(self, sd):
+            self.e = sd["last_epoch"]
+            for g, b in zip(self.opt.param_groups, self.base):
+                g["lr"] = b * (1 + math.cos(math.pi * self.e / self.T)) / 2
+
+    scheduler = _Cosine(optimizer, args.epochs)
+    to_restore = {"epoch": 0, "best_acc": 0.0}
+    utils.restart_from_checkpoint(os.path.join(args.output_dir, "checkpoint.pth.tar"), run_variables=to_restore,
+                                  state_dict=seg_decoder, optimizer=optimizer, scheduler=scheduler)
+    start_epoch, best_acc = to_restore["epoch"], to_restore["best_acc"]
+    if args.evaluate:
+        stats = validate_network(val_loader, model, feature_model, backbone_encoder, cross_vit, cross_cnn, seg_decoder,
+                                 args.n_last_blocks, args.avgpool_patchtokens)
+        print(f"Accuracy of the network on the {len(dataset_val)} test images: {stats['acc1']:.1f}%")
+        return stats
+    log_stats = {}
+    for epoch in range(start_epoch, args.epochs):
+        train_loader.sampler.set_epoch(epoch)
+        train_stats = train(model, feature_model, backbone_encoder, cross_vit, cross_cnn, seg_decoder, optimizer,
+                            train_loader, epoch, args.n_last_blocks, args.avgpool_patchtokens)
+        scheduler.step()
+        log_stats = {**{f"train_{k}": v for k, v in train_stats.items()}, "epoch": epoch}
+        if epoch % args.val_freq == 0 or epoch == args.epochs - 1:
+            test_stats = validate_network(val_loader, model, feature_model, backbone_encoder, cross_vit, cross_cnn,
+                                          seg_decoder, args.n_last_blocks, args.avgpool_patchtokens)
+            print(f"Accuracy at epoch {epoch} of the network on the {len(dataset_val)} test images: {test_stats['acc1']:.1f}%")
+            best_acc = max(best_acc, test_stats["acc1"])
+            print(f"Max accuracy so far: {best_acc:.2f}%")
+            log_stats = {**log_stats, **{f"test_{k}": v for k, v in test_stats.items()}}
+        if utils.is_main_process():
+            Path(args.output_dir).mkdir(parents=True, exist_ok=True)
+            with (Path(args.output_dir) / "log.txt").open("a") as f:
+                f.write(json.dumps(log_stats) + "\n")
+            torch.save({"epoch": epoch + 1,
+                        "state_dict": {"module." + k: v for k, v in seg_decoder.state_dict().items()},  # DDP prefix kept
+                        "optimizer": optimizer.state_dict(), "scheduler": scheduler.state_dict(), "best_acc": best_acc},
+                       os.path.join(args.output_dir, "checkpoint.pth.tar"))
+    print("Training of the supervised linear classifier on frozen features completed.\n"
+          "Top-1 test accuracy: {acc:.1f}".format(acc=best_acc))
+    return log_stats
+
+
+def train(model, feature_model, backbone_encoder, cross_vit, cross_cnn, seg_decoder, optimizer, loader, epoch, n, avgpool):
+    """`train.py:260-445`; the body of the loop is ``SegEngine.train_step``."""
+    seg_decoder.train()
+    engine = _engine_for(model, backbone_encoder, cross_vit, cross_cnn, seg_decoder)
+    if optimizer is not engine.optimizer:
+        raise ValueError("train(): pass the engine's optimizer (adaptersis_amd.optim.SGD over the flat bucket)")
+    metric_logger = utils.MetricLogger(delimiter="  ")
+    metric_logger.add_meter("lr", utils.SmoothedValue(window_size=1, fmt="{value:.6f}"))
+    for (inp, target, idx) in metric_logger.log_every(loader, 20, "Epoch: [{}]".format(epoch)):
+        loss = engine.train_step(inp.cuda(non_blocking=True), target.cuda(non_blocking=True))
+        torch.cuda.synchronize()  # the reference syncs and reads the loss every step (train.py:439-440)
+        metric_logger.update(loss=loss.item())
+        metric_logger.update(lr=optimizer.param_groups[0]["lr"])
+    metric_logger.synchronize_between_processes()
+    print("Averaged stats:", metric_logger)
+    return {k: meter.global_avg for k, meter in metric_logger.meters.items()}
+
+
+@torch.no_grad()
+def validate_network(val_loader, model, feature_model, backbone_encoder, cross_vit, cross_cnn, seg_decoder, n, avgpool):
+    """`train.py:448-651`: weighted CE ([0.1, 10]), dice = 1 - DC(logits), pixel accuracy; decoder in eval mode."""
+    engine = _engine_for(model, backbone_encoder, cross_vit, cross_cnn, seg_decoder)
+    metric_logger = utils.MetricLogger(delimiter="  ")
+    wt = torch.tensor([0.1, 10.0], device=next(seg_decoder.parameters()).device)
+    for (inp, target, idx) in metric_logger.log_every(val_loader, 20, "Test:"):
+        inp, target = inp.cuda(non_blocking=True), target.cuda(non_blocking=True)
+        m, dloss = engine.validate_step(inp, target, wt)
+        m = m.cpu()
+        bs = inp.shape[0]
+        metric_logger.update(loss=float(m[0] / m[1]))
+        metric_logger.meters["acc1"].update(float(m[2]) / target.numel(), n=bs)
+        metric_logger.meters["dice"].update(1.0 - float(dloss), n=bs)
+    print("* Acc@1 {top1.global_avg:.3f} loss {losses.global_avg:.3f} Dice {dice.global_avg:.3f}".format(
+        top1=metric_logger.acc1, losses=metric_logger.loss, dice=metric_logger.meters["dice"]))
+    return {k: meter.global_avg for k, meter in metric_logger.meters.items()}
+
+
+def get_args_parser():
+    p = argparse.ArgumentParser("Evaluation with semantic segmentation on RobustMIS2019")
+    p.add_argument("--n_last_blocks", default=4, type=int)
+    p.add_argument("--avgpool_patchtokens", default=False, type=utils.bool_flag)
+    p.add_argument("--arch", default="vit_large", type=str)
+    p.add_argument("--patch_size", default=14, type=int)
+    p.add_argument("--imsize", default=588, type=int)
+    p.add_argument("--checkpoint_key", default="teacher", type=str)
+    p.add_argument("--epochs", default=100, type=int)
+    p.add_argument("--lr", default=0.01, type=float)
+    p.add_argument("--batch_size_per_gpu", default=12, type=int)
+    p.add_argument("--dist_url", default="env://", type=str)
+    p.add_argument("--local-rank", default=0, type=int)
+    p.add_argument("--data_path", default="synthetic", type=str)
+    p.add_argument("--num_workers", default=10, type=int)
+    p.add_argument("--val_freq", default=1, type=int)
+    p.add_argument("--output_dir", default=".")
+    p.add_argument("--opts", default=[], nargs=argparse.REMAINDER)
+    p.add_argument("--num_labels", default=1000, type=int)
+    p.add_argument("--evaluate", dest="evaluate", action="store_true")
+    p.add_argument("--config_file", type=str)
+    p.add_argument("--pretrained_weights", type=str)
+    return p
+
+
+if __name__ == "__main__":
+    train_seg(get_args_parser().parse_args())

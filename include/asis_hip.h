@@ -188,6 +188,9 @@ int asis_reduce_partials(void* stream, const float* partial, int nparts, int C, 
 int asis_bn_finalize(void* stream, const double* sums, double count, int C, const float* gamma, const float* beta,
                      float eps, float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked,
                      float* scale, float* shift, float* mean_out, float* invstd_out);
+/* eval-mode BatchNorm: scale = gamma/sqrt(running_var+eps), shift = beta - running_mean*scale (train.py:451) */
+int asis_bn_eval_affine(void* stream, const float* gamma, const float* beta, const float* running_mean,
+                        const float* running_var, float eps, int C, float* scale, float* shift);
 /* out(16-bit) = [relu](x*scale + shift), x fp32 [R, C].  Every fused apply kernel below optionally
  * also writes out_lo (NULL = skip): the rounding residual of out, second half of a split operand. */
 int asis_bn_act(void* stream, int dtype, const float* x, const float* scale, const float* shift, int relu, void* out,
@@ -224,6 +227,11 @@ int asis_add_f32(void* stream, const float* a, const float* b, float* out, int64
 int asis_dice_nblk(int H, int W);
 int asis_dice_fwd(void* stream, const float* logits, const int64_t* target, int B, int h, int w, int H, int W, int C,
                   int n_softmax, float eps, float grad_scale, float* partial, float* sums, float* loss, float* coef);
+/* Validation metrics (train.py:616-617,642) fused with the resize: partial[asis_ce_acc_nblk(B*H*W)][3] =
+ * {sum w[t]*nll, sum w[t], #(argmax == t)}; weight NULL = 1.  CE = col0/col1, accuracy = col2/(B*H*W). */
+int asis_ce_acc_nblk(int64_t total_pixels);
+int asis_ce_acc(void* stream, const float* logits, const int64_t* target, const float* weight, int B, int h, int w,
+                int H, int W, int C, float* partial);
 /* dz fp32 [B,H,W,C] = d loss / d resized-logits */
 int asis_dice_bwd(void* stream, const float* logits, const int64_t* target, const float* coef, int B, int h, int w,
                   int H, int W, int C, int n_softmax, float* dz);

@@ -295,14 +295,19 @@ def feature_encoder(img, sd: SD, p: str = "", update_bn: bool = False):
     return c1, c2, c3, c4, shapes
 
 
-def feature_decoder(x, sd: SD, p: str = "", update_bn: bool = False):
-    """`backbones/decoders.py:109-164`: 4x [conv3x3 -> BN(train) -> ReLU ->
-    bilinear x2 align_corners=True] -> conv3x3."""
+def feature_decoder(x, sd: SD, p: str = "", update_bn: bool = False, training: bool = True):
+    """`backbones/decoders.py:109-164`: 4x [conv3x3 -> BN -> ReLU -> bilinear x2 align_corners=True] ->
+    conv3x3.  BN uses batch statistics in training (`train.py:262`) and the running statistics under
+    ``seg_decoder.eval()`` (`train.py:451`)."""
     pre = p + "." if p else ""
     for i in range(1, 5):
         q = f"{pre}decoder_{i}"
         x = F.conv2d(x, sd[q + ".0.weight"], sd[q + ".0.bias"], padding=1)
-        x = F.relu(batch_norm_train(x, sd, q + ".1", update=update_bn))
+        if training:
+            x = F.relu(batch_norm_train(x, sd, q + ".1", update=update_bn))
+        else:
+            x = F.relu(F.batch_norm(x, sd[q + ".1.running_mean"], sd[q + ".1.running_var"], sd[q + ".1.weight"],
+                                    sd[q + ".1.bias"], False, 0.1, 1e-5))
         x = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
     return F.conv2d(x, sd[pre + "final_out.weight"], sd[pre + "final_out.bias"], padding=1)
 
@@ -468,6 +473,18 @@ def train_step_loss(cat, target, dec_sd: SD, num_classes: int = 2, taps: Optiona
     if taps is not None:
         taps.update(logits=logits, logits_resized=out, loss=loss)
     return loss
+
+
+def validate_metrics(cat, target, dec_sd: SD, num_classes: int = 2):
+    """`train.py:612-642`: decoder in eval mode -> resize -> weighted CE ([0.1, 10]), dice = 1 - DC(logits),
+    pixel accuracy."""
+    H, W = target.shape[-2:]
+    out = F.interpolate(feature_decoder(cat, dec_sd, training=False), size=(H, W), mode="bilinear")
+    wt = torch.tensor([0.1, 10.0]) if num_classes == 2 else None
+    loss = F.cross_entropy(out, target.long(), weight=wt)
+    dice = 1 - dc_loss(out, one_hot(target, num_classes))
+    acc = (out.argmax(1) == target).float().mean()
+    return loss, dice, acc
 
 
 def sgd_momentum_step(params: Dict[str, torch.Tensor], grads: Dict[str, torch.Tensor],

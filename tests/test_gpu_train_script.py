@@ -1,0 +1,50 @@
+"""GPU: the drop-in training script (`adaptersis_amd.train` = reference `train.py` API) and the validation
+metrics path (`validate_network`, train.py:448-651) against the oracle."""
+import json
+import os
+
+import pytest
+import torch
+
+from adaptersis_amd import train as T
+from adaptersis_amd.utils import weights as W
+from oracle import ref_torch as O
+from tests.test_gpu_step import build_engine
+
+pytestmark = pytest.mark.gpu
+
+
+def test_validate_step_vs_oracle(dev):
+    eng, sds = build_engine("vit_tiny_test", "kernel", dev, (128, 32, 16, 16, 8))
+    img, tgt = W.synthetic_batch(2, 224, seed=3)
+    wt = torch.tensor([0.1, 10.0], device=dev)
+    m, dloss = eng.validate_step(img.to(dev), tgt.to(dev), wt)
+    osd = {k: {n: t.clone() for n, t in v.items()} for k, v in sds.items()}
+    with torch.no_grad():
+        cat = O.adapter_forward(img, osd["vit"], osd["enc"], osd["cv"], osd["cn"], 2)
+        loss, dice, acc = O.validate_metrics(cat, tgt, osd["dec"])
+    m = m.cpu()
+    assert abs(float(m[0] / m[1]) - float(loss)) < 2e-3 * max(1.0, abs(float(loss)))
+    assert abs((1.0 - float(dloss)) - float(dice)) < 1e-3
+    assert abs(float(m[2]) / tgt.numel() - float(acc)) < 2e-3
+    assert eng.seg_decoder.training  # mode restored
+
+
+def test_train_seg_end_to_end(dev, tmp_path):
+    """One epoch of the drop-in script on the synthetic set: loss decreases, log + checkpoint in reference format,
+    resume works."""
+    args = T.get_args_parser().parse_args(["--arch", "vit_tiny_test", "--imsize", "224", "--batch_size_per_gpu", "4",
+                                           "--epochs", "2", "--lr", "0.05", "--data_path", "synthetic",
+                                           "--output_dir", str(tmp_path)])
+    T._ENGINES.clear()
+    stats = T.train_seg(args)
+    lines = [json.loads(l) for l in open(os.path.join(tmp_path, "log.txt"))]
+    assert len(lines) == 2 and {"train_loss", "train_lr", "test_loss", "test_acc1", "test_dice", "epoch"} <= set(lines[0])
+    assert lines[1]["train_loss"] < lines[0]["train_loss"]
+    ck = torch.load(os.path.join(tmp_path, "checkpoint.pth.tar"), map_location="cpu")
+    assert set(ck) == {"epoch", "state_dict", "optimizer", "scheduler", "best_acc"} and ck["epoch"] == 2
+    assert all(k.startswith("module.") for k in ck["state_dict"])
+    T._ENGINES.clear()
+    args.evaluate = True
+    ev = T.train_seg(args)  # resumes from the checkpoint and only validates
+    assert abs(ev["acc1"] - lines[1]["test_acc1"]) < 1e-6
