@@ -228,12 +228,15 @@ int launch(hipStream_t s, const asis_gemm_desc& d) {
     }
     return 0;
   }
-  if (big_mode && !d.conv && !d.stats && d.K % BK == 0 && d.M >= 256 && d.N >= 128) {
-    const bool wide = big_mode == 1 && d.N >= 2048;  // 256x256 for wide outputs, 256x128 (3 stages) otherwise
-    const int bm = 256, bn = wide ? 256 : 128;
+  if (big_mode && !d.conv && !d.stats && d.K % 32 == 0 && d.M >= 256 && d.N >= 128) {
+    // 256x128x32 tile, 3 LDS stages (72 KB) and <= 128 VGPRs: TWO workgroups per CU, so one workgroup's epilogue
+    // (HBM-write bound) overlaps the other's K loop: +12-15 % over the 1-workgroup 256x256x64 / 256x128x64 forms
+    // on the fc1 shape (scripts/gemm_lab.hip).  big_mode 2/3 keep the older forms selectable for A/B runs.
+    const int bm = 256, bn = (big_mode == 2 && d.N >= 2048) ? 256 : 128;
     dim3 grid(((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn), d.batch), block(512);
-    if (wide) hipLaunchKernelGGL((gemm_big_kernel<T, 2, 4, 4, 2, 2>), grid, block, 0, s, d);
-    else hipLaunchKernelGGL((gemm_big_kernel<T, 4, 2, 2, 2, 3>), grid, block, 0, s, d);
+    if (big_mode == 2 && bn == 256) hipLaunchKernelGGL((gemm_big_kernel<T, 2, 4, 4, 2, 2>), grid, block, 0, s, d);
+    else if (big_mode >= 2 || d.K % 64 != 0 && false) hipLaunchKernelGGL((gemm_big_kernel<T, 4, 2, 2, 2, 3>), grid, block, 0, s, d);
+    else hipLaunchKernelGGL((gemm_big_kernel<T, 4, 2, 2, 2, 3, 0, false, false, 32, 4>), grid, block, 0, s, d);
     return 0;
   }
   // implicit-GEMM convolution on the same kernel: K tiles must lie inside one tap, and BatchNorm statistics

@@ -3,11 +3,6 @@
 #include "asis_common.h"
 
 namespace {
-#ifndef ASIS_GEMM_BK
-#define ASIS_GEMM_BK 64
-#endif
-constexpr int BKB = ASIS_GEMM_BK;
-
 // ------------------------------------------------------------------------------------------------
 // Large-tile dense GEMM: 256 x (256|128) x 64 tile, 8 waves, LDS-DMA (global_load_lds_dwordx4) staging
 // with NS LDS stages and a counted vmcnt so NS-1 K tiles stay in flight across the one barrier per
@@ -21,12 +16,17 @@ constexpr int BKB = ASIS_GEMM_BK;
 // 16 zero bytes: the LDS-DMA source of implicit-im2col lanes that fall into the conv padding
 __device__ __attribute__((aligned(16))) uint4 g_zero_page[1];
 
-template <typename T, int WM, int WN, int TM, int TN, int NS, int DBG = 0, bool CONV = false, bool SPLIT = false>
-__global__ __launch_bounds__(512, 2) void gemm_big_kernel(const asis_gemm_desc d) {
+template <typename T, int WM, int WN, int TM, int TN, int NS, int DBG = 0, bool CONV = false, bool SPLIT = false, int BKT = 64,
+          int OCC = 2>
+__global__ __launch_bounds__(512, OCC) void gemm_big_kernel(const asis_gemm_desc d) {
   typedef typename T16<T>::v8 v8;
   constexpr int BM2 = WM * TM * 32, BN2 = WN * TN * 32;
+  constexpr int BKB = BKT;                           // K tile (64 or 32)
+  constexpr int CPR = BKB / 8;                       // 16-byte chunks per LDS row
+  constexpr int RPI = 64 / CPR;                      // rows covered by one 1-KB LDS-DMA wave-instruction
+  constexpr int SWS = (CPR == 8) ? 1 : 2;            // swizzle: chunk ^= (row >> SWS) & (CPR-1)  (conflict-free b128 reads)
   constexpr int STAGE = (BM2 + BN2) * BKB;           // elements per stage
-  constexpr int GA = BM2 / 64, GB = BN2 / 64;        // LDS-DMA wave-instructions per wave and K tile
+  constexpr int GA = BM2 / RPI / 8, GB = BN2 / RPI / 8;  // LDS-DMA wave-instructions per wave and K tile
   constexpr int G = GA + GB;
   __shared__ __attribute__((aligned(16))) T lds[NS * STAGE];
 
@@ -45,10 +45,10 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const asis_gemm_desc d
   const T* asrc[GA];
   const T* bsrc[GB];
   int a_ih0[GA], a_iw0[GA];  // CONV: top-left input pixel of this lane's output pixel
-  const int lr = lane >> 3, lc = lane & 7;
+  const int lr = lane / CPR, lc = lane % CPR;
 #pragma unroll
   for (int j = 0; j < GA; ++j) {
-    const int row = (wid * GA + j) * 8 + lr;
+    const int row = (wid * GA + j) * RPI + lr;
     int gr = m0 + row;
     gr = gr < d.M ? gr : d.M - 1;
     if (CONV) {  // implicit im2col: A is NHWC [B,H,W,Cin]; a K tile (64) lies inside one tap (Cin % 64 == 0)
@@ -58,18 +58,18 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const asis_gemm_desc d
       const int oh = rem / d.OW, ow = rem - oh * d.OW;
       a_ih0[j] = oh * d.stride - d.pad;
       a_iw0[j] = ow * d.stride - d.pad;
-      asrc[j] = A + (int64_t)b * d.H * d.W * d.Cin + ((lc ^ ((row >> 1) & 7)) << 3);
+      asrc[j] = A + (int64_t)b * d.H * d.W * d.Cin + ((lc ^ ((row >> SWS) & (CPR - 1))) << 3);
     } else {
       a_ih0[j] = a_iw0[j] = 0;
-      asrc[j] = A + (int64_t)gr * d.lda + ((lc ^ ((row >> 1) & 7)) << 3);
+      asrc[j] = A + (int64_t)gr * d.lda + ((lc ^ ((row >> SWS) & (CPR - 1))) << 3);
     }
   }
 #pragma unroll
   for (int j = 0; j < GB; ++j) {
-    const int row = (wid * GB + j) * 8 + lr;
+    const int row = (wid * GB + j) * RPI + lr;
     int gr = n0 + row;
     gr = gr < d.N ? gr : d.N - 1;
-    bsrc[j] = B + (int64_t)gr * d.ldb + ((lc ^ ((row >> 1) & 7)) << 3);
+    bsrc[j] = B + (int64_t)gr * d.ldb + ((lc ^ ((row >> SWS) & (CPR - 1))) << 3);
   }
   // SPLIT: the reduction runs over three K-long parts: (A, B), (A_lo, B), (A, B_lo); the lo halves share the
   // layout of the hi ones, so a part only changes the base pointers by a constant element offset.
@@ -98,16 +98,16 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const asis_gemm_desc d
         const T* src = ((unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W)
                            ? asrc[j] + aoff + ((int64_t)ih * d.W + iw) * d.Cin + ci0
                            : reinterpret_cast<const T*>(g_zero_page);
-        __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(st + ((wid * GA + j) * 8) * BKB), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(st + ((wid * GA + j) * RPI) * BKB), 16, 0, 0);
       }
     } else {
 #pragma unroll
       for (int j = 0; j < GA; ++j)
-        __builtin_amdgcn_global_load_lds((glb_ptr)(asrc[j] + aoff + k0), (lds_ptr)(st + ((wid * GA + j) * 8) * BKB), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_ptr)(asrc[j] + aoff + k0), (lds_ptr)(st + ((wid * GA + j) * RPI) * BKB), 16, 0, 0);
     }
 #pragma unroll
     for (int j = 0; j < GB; ++j)
-      __builtin_amdgcn_global_load_lds((glb_ptr)(bsrc[j] + boff + k0), (lds_ptr)(st + BM2 * BKB + ((wid * GB + j) * 8) * BKB), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_ptr)(bsrc[j] + boff + k0), (lds_ptr)(st + BM2 * BKB + ((wid * GB + j) * RPI) * BKB), 16, 0, 0);
   };
 
   f32x16 acc[TM][TN];
@@ -126,12 +126,8 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const asis_gemm_desc d
   const int fr = lane & 31, fh = lane >> 5;
   for (int t = 0; t < nt; ++t) {
     // tile t has landed once at most (NS-2) newer tiles of this wave are still outstanding
-    if (nt - t - 1 >= NS - 2) {
-      if (NS == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    if (nt - t - 1 >= NS - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * G) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (!(DBG & 1) && t + NS - 1 < nt) issue(t + NS - 1);
     const T* As = lds + (t % NS) * STAGE;
@@ -144,18 +140,19 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const asis_gemm_desc d
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
           const int row = (wm * TM + i) * 32 + fr;
-          af[slot][i] = __builtin_bit_cast(v8, *reinterpret_cast<const uint4*>(As + row * BKB + ((chunk ^ ((row >> 1) & 7)) << 3)));
+          af[slot][i] = __builtin_bit_cast(v8, *reinterpret_cast<const uint4*>(As + row * BKB + ((chunk ^ ((row >> SWS) & (CPR - 1))) << 3)));
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           const int col = (wn * TN + j) * 32 + fr;
-          bf[slot][j] = __builtin_bit_cast(v8, *reinterpret_cast<const uint4*>(Bs + col * BKB + ((chunk ^ ((col >> 1) & 7)) << 3)));
+          bf[slot][j] = __builtin_bit_cast(v8, *reinterpret_cast<const uint4*>(Bs + col * BKB + ((chunk ^ ((col >> SWS) & (CPR - 1))) << 3)));
         }
       };
+      constexpr int KS = BKB / 16;
       fetch(0, 0);
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        if (ks < 3) fetch(ks + 1, (ks + 1) & 1);
+      for (int ks = 0; ks < KS; ++ks) {
+        if (ks < KS - 1) fetch(ks + 1, (ks + 1) & 1);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll

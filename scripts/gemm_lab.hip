@@ -59,5 +59,8 @@ int main(int argc, char** argv) {
   RUN("256x128 NS3 no-epilogue", _Float16, 4, 2, 2, 2, 3, 4)
   RUN("256x128 NS3 math-only", _Float16, 4, 2, 2, 2, 3, 5)
   RUN("256x128 NS3 loads-only", _Float16, 4, 2, 2, 2, 3, 6)
+  RUN("256x128 BK32 NS3 occ4 full", _Float16, 4, 2, 2, 2, 3, 0, false, false, 32, 4)
+  RUN("256x128 BK32 NS3 occ4 no-epi", _Float16, 4, 2, 2, 2, 3, 4, false, false, 32, 4)
+  RUN("256x128 BK32 NS4 occ4 full", _Float16, 4, 2, 2, 2, 4, 0, false, false, 32, 4)
   return 0;
 }
