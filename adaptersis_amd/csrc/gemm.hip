@@ -219,8 +219,10 @@ int launch(hipStream_t s, const asis_gemm_desc& d) {
     if (!ok) return ASIS_EINVAL;
     const int bm = 256, bn = d.N > 64 ? 128 : 64;
     dim3 grid(((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn), d.batch), block(512);
+    static const int conv32 = [] { const char* e = getenv("ASIS_CONV_BK32"); return e ? atoi(e) : 0; }();
     if (d.conv) {
-      if (bn == 128) hipLaunchKernelGGL((gemm_big_kernel<T, 4, 2, 2, 2, 3, 0, true, true>), grid, block, 0, s, d);
+      if (conv32 && bn == 128) hipLaunchKernelGGL((gemm_big_kernel<T, 4, 2, 2, 2, 3, 0, true, true, 32, 4>), grid, block, 0, s, d);
+      else if (bn == 128) hipLaunchKernelGGL((gemm_big_kernel<T, 4, 2, 2, 2, 3, 0, true, true>), grid, block, 0, s, d);
       else hipLaunchKernelGGL((gemm_big_kernel<T, 8, 1, 1, 2, 3, 0, true, true>), grid, block, 0, s, d);
     } else {
       if (bn == 128) hipLaunchKernelGGL((gemm_big_kernel<T, 4, 2, 2, 2, 3, 0, false, true>), grid, block, 0, s, d);
