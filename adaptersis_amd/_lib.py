@@ -92,12 +92,15 @@ SIGNATURES = {
     "asis_bn_relu_upsample": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i],
     "asis_pack_conv_weight": [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i64, _i],
     "asis_decoder_input": [_vp, _i, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i, _i, _i, _i, _i, _i],
+    "asis_swiglu": [_vp, _i, _vp, _vp, _i64, _i],
+    "asis_copy_channels": [_vp, _vp, _i64, _vp, _i64, _i64, _i64],
     "asis_add_f32": [_vp, _vp, _vp, _vp, _i64, _i, _i64, _i64, _i64],
     "asis_dice_nblk": [_i, _i],
-    "asis_dice_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp],
+    "asis_dice_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _f, _vp, _vp, _vp, _vp],
     "asis_dice_bwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "asis_ce_acc_nblk": [_i64],
     "asis_ce_acc": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "asis_resize_bilinear_fwd": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "asis_resize_bwd_nblk": [_i64],
     "asis_resize_bilinear_bwd": [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp],
     "asis_reduce_rows": [_vp, _vp, _i, _i, _f, _vp],

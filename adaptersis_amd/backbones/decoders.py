@@ -75,8 +75,11 @@ def conv_bn_relu_up_forward(owner: _Packed, key: str, x16, x_lo, conv: nn.Conv2d
 
 def conv_bn_relu_up_backward(owner: _Packed, key: str, st: _Stage, dU, conv: nn.Conv2d, bn: nn.BatchNorm2d,
                              inv_scale: float, grads: Dict[str, torch.Tensor], prefix: str, need_dx: bool,
-                             sync_bn: bool):
-    """dU fp32 [B, fH, fW, C] (scaled by the loss scale) -> grads[...] (unscaled) and dX fp32 or None."""
+                             sync_bn: bool, conv_name: Optional[str] = None, bn_name: Optional[str] = None):
+    """dU fp32 [B, fH, fW, C] (scaled by the loss scale) -> grads[...] (unscaled) and dX fp32 or None.
+    Parameter names default to ``prefix.0`` (conv) / ``prefix.1`` (BatchNorm)."""
+    conv_name = conv_name or prefix + ".0"
+    bn_name = bn_name or prefix + ".1"
     import torch.distributed as dist
     dt = config.operand_dtype
     C = conv.out_channels
@@ -89,11 +92,11 @@ def conv_bn_relu_up_backward(owner: _Packed, key: str, st: _Stage, dU, conv: nn.
     r = ops.bn_bwd_apply(g, st.raw, st.mean, st.invstd, owner._f32(key + ".g", bn.weight), dgamma_s, dbeta_s,
                          st.count, dt, split)
     dx16, dx_lo, bpart = r if split else (r[0], None, r[1])
-    ops.reduce_rows(dbeta_s.view(1, C), inv_scale, grads[prefix + ".1.bias"])      # unscale (n = 1 row)
-    ops.reduce_rows(dgamma_s.view(1, C), inv_scale, grads[prefix + ".1.weight"])
+    ops.reduce_rows(dbeta_s.view(1, C), inv_scale, grads[bn_name + ".bias"])      # unscale (n = 1 row)
+    ops.reduce_rows(dgamma_s.view(1, C), inv_scale, grads[bn_name + ".weight"])
     if conv.bias is not None:
-        ops.reduce_rows(bpart, inv_scale, grads[prefix + ".0.bias"])
-    ops.wgrad(dx16, st.x16, C, 3, 3, 1, 1, inv_scale, out=grads[prefix + ".0.weight"])
+        ops.reduce_rows(bpart, inv_scale, grads[conv_name + ".bias"])
+    ops.wgrad(dx16, st.x16, C, 3, 3, 1, 1, inv_scale, out=grads[conv_name + ".weight"])
     if not need_dx:
         return None
     return _dgrad(owner, key, conv, dx16, dx_lo)
@@ -152,6 +155,8 @@ class FeatureDecoder(_Packed):
                 nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True)))
         self.final_out = nn.Conv2d(chans[4], num_classes, 3, padding=1)
         self.sync_bn = False  # plain nn.BatchNorm2d in the reference decoder (per-GPU statistics)
+
+    GRAD_ORDER = ("final_out", "decoder_4", "decoder_3", "decoder_2", "decoder_1")  # gradient-ready order of the backward
 
     # ---- functional core ---------------------------------------------------------------------------
     def _to_nhwc16(self, x):
@@ -218,3 +223,152 @@ class FeatureDecoder(_Packed):
             return _DecoderFn.apply(self, x, *list(self.parameters()))
         logits, _ = self._forward_core(*self._to_nhwc16(x), save=False)
         return logits.permute(0, 3, 1, 2)
+
+
+class _MLAFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, module, i0, i1, i2, i3, *params):
+        ins = [module._to_nhwc16(t) for t in (i0, i1, i2, i3)]
+        logits, saved = module._forward_core(ins, save=True)
+        ctx.module, ctx.saved = module, saved
+        ctx.names = [n for n, _ in module.named_parameters()]
+        B, h, w, C = logits.shape
+        out = ops.resize_bilinear_fwd(logits, module.img_size, module.img_size)
+        return out.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, dout):
+        m = ctx.module
+        dt = config.operand_dtype
+        S = config.loss_scale
+        B, C, H, W = dout.shape
+        dz = dout.permute(0, 2, 3, 1).contiguous().float()
+        h = m._last_hw
+        d32, bpart = ops.resize_bilinear_bwd(dz, h, h, torch.float32)
+        d2 = d32.view(B * h * h, C)
+        CP = (C + 7) // 8 * 8
+        d16 = ops.cast_pad(d2, CP, dt, scale=S).view(B, h, h, CP)
+        d_lo = ops.cast_pad(d2, CP, dt, scale=S, part=1).view(B, h, h, CP) if config.split_conv else None
+        grads = {n: torch.empty_like(p) for n, p in m.named_parameters()}
+        m._backward_core(ctx.saved, d16, None, 1.0 / S, grads, dlogits_f32=d2, d_lo=d_lo)
+        ctx.saved = None
+        return (None, None, None, None, None) + tuple(grads[n] for n in ctx.names)
+
+
+class MLAHead(nn.Module):
+    """`backbones/decoders.py:7-46` parameter container (4 x [conv-BN-ReLU, conv-BN-ReLU], no conv bias)."""
+
+    def __init__(self, mla_channels=1024, mlahead_channels=128, norm_cfg=None):
+        super().__init__()
+        for h in ("head2", "head3", "head4", "head5"):
+            setattr(self, h, nn.Sequential(
+                nn.Conv2d(mla_channels, mlahead_channels, 3, padding=1, bias=False), nn.BatchNorm2d(mlahead_channels), nn.ReLU(),
+                nn.Conv2d(mlahead_channels, mlahead_channels, 3, padding=1, bias=False), nn.BatchNorm2d(mlahead_channels),
+                nn.ReLU()))
+
+
+class DecoderMLA(_Packed):
+    """`backbones/decoders.py:48-89` (the `train_mla.py` head).  Unlike the reference, ``num_classes`` is honoured
+    (the reference hard-codes 2, `decoders.py:59`; BASELINE config 5 needs 11)."""
+
+    def __init__(self, img_size=588, mla_channels=1024, mlahead_channels=128, norm_layer=nn.BatchNorm2d, num_classes=2,
+                 norm_cfg=None):
+        super().__init__()
+        if mla_channels % 8 or mlahead_channels % 8:
+            raise ValueError("DecoderMLA channel counts must be multiples of 8")
+        self.img_size, self.norm_cfg, self.mla_channels = img_size, norm_cfg, mla_channels
+        self.BatchNorm, self.mlahead_channels, self.num_classes = norm_layer, mlahead_channels, num_classes
+        self.mlahead = MLAHead(mla_channels, mlahead_channels, norm_cfg)
+        self.cls = nn.Sequential(nn.Conv2d(4 * mlahead_channels, 256, 3, padding=1), nn.BatchNorm2d(256), nn.ReLU(inplace=True))
+        self.cls_1 = nn.Sequential(nn.Conv2d(256, 128, 3, padding=1), nn.BatchNorm2d(128), nn.ReLU(inplace=True))
+        self.cls_2 = nn.Sequential(nn.Conv2d(128, 64, 3, padding=1), nn.BatchNorm2d(64), nn.ReLU(inplace=True))
+        self.cls_3 = nn.Conv2d(64, num_classes, 3, padding=1)
+        self.sync_bn = False
+        self._last_hw = None
+
+    _HEADS = ("head2", "head3", "head4", "head5")
+    GRAD_ORDER = ("cls_3", "cls_2", "cls_1", "cls", "mlahead")
+
+    def _to_nhwc16(self, x):
+        B, C, H, W = x.shape
+        x2 = x.detach().permute(0, 2, 3, 1).contiguous().float().view(B * H * W, C)
+        hi = ops.cast_pad(x2, C, config.operand_dtype).view(B, H, W, C)
+        lo = ops.cast_pad(x2, C, config.operand_dtype, part=1).view(B, H, W, C) if config.split_conv else None
+        return hi, lo
+
+    def _forward_core(self, ins, save: bool, training: Optional[bool] = None):
+        """ins: 4 x (hi, lo|None) NHWC 16-bit maps [B,h,w,mla_channels] -> logits fp32 NHWC at 4h x 4w."""
+        training = self.training if training is None else training
+        dt = config.operand_dtype
+        split = ins[0][1] is not None
+        Cm = self.mlahead_channels
+        B, h, w, _ = ins[0][0].shape
+        cat_hi = torch.empty((B, 4 * h, 4 * w, 4 * Cm), device=ins[0][0].device, dtype=dt)
+        cat_lo = torch.empty_like(cat_hi) if split else None
+        saved = {"heads": []}
+        for k, (hn, (xh, xl)) in enumerate(zip(self._HEADS, ins)):
+            seq = getattr(self.mlahead, hn)
+            a, s1 = conv_bn_relu_up_forward(self, hn + "a", xh, xl, seq[0], seq[1], 1, self.sync_bn, save, training)
+            u, s2 = conv_bn_relu_up_forward(self, hn + "b", a[0], a[1], seq[3], seq[4], 4, self.sync_bn, save, training)
+            ops.copy_channels(u[0].view(-1, Cm), cat_hi.view(-1, 4 * Cm)[:, k * Cm:(k + 1) * Cm])
+            if split:
+                ops.copy_channels(u[1].view(-1, Cm), cat_lo.view(-1, 4 * Cm)[:, k * Cm:(k + 1) * Cm])
+            saved["heads"].append((s1, s2))
+        a = (cat_hi, cat_lo)
+        saved["cls"] = []
+        for name in ("cls", "cls_1", "cls_2"):
+            seq = getattr(self, name)
+            a, st = conv_bn_relu_up_forward(self, name, a[0], a[1], seq[0], seq[1], 1, self.sync_bn, save, training)
+            saved["cls"].append(st)
+        fo = self.cls_3
+        bias = self._f32("cls3.b", fo.bias)
+        if fo.out_channels <= 16:
+            logits = ops.conv3x3_smallcout_fwd(a[0], a[1], self._f32("cls3.wf", fo.weight), bias)
+        else:
+            w_hi, w_lo = _conv_weights(self, "cls3", fo, split)
+            logits = ops.conv_gemm_split(a[0], a[1], w_hi, w_lo, 3, 3, 1, 1, bias_n=bias) if split else \
+                ops.conv_gemm(a[0], w_hi, 3, 3, 1, 1, bias_n=bias)
+        saved["x_last"] = a[0] if save else None
+        self._last_hw = 4 * h
+        return logits, saved
+
+    def _backward_core(self, saved, d16, bias_partial, inv_scale, grads, dlogits_f32=None, stage_done=None, d_lo=None):
+        fo = self.cls_3
+        C = self.num_classes
+        Cm = self.mlahead_channels
+        if bias_partial is not None:
+            ops.reduce_rows(bias_partial, inv_scale, grads["cls_3.bias"])
+        else:
+            ops.reduce_rows(dlogits_f32, 1.0, grads["cls_3.bias"])
+        ops.wgrad(d16, saved["x_last"], C, 3, 3, 1, 1, inv_scale, out=grads["cls_3.weight"])
+        if fo.out_channels <= 8:
+            dU = ops.conv3x3_smallcout_dgrad(d16, d_lo, self._f32("cls3.wf", fo.weight))
+        else:
+            dU = _dgrad(self, "cls3", fo, d16, d_lo)
+        if stage_done is not None:
+            stage_done()
+        for name, st in zip(("cls_2", "cls_1", "cls"), reversed(saved["cls"])):
+            seq = getattr(self, name)
+            dU = conv_bn_relu_up_backward(self, name, st, dU, seq[0], seq[1], inv_scale, grads, name, True, self.sync_bn)
+            if stage_done is not None:
+                stage_done()
+        B, H, W, _ = dU.shape
+        for k, hn in enumerate(self._HEADS):
+            seq = getattr(self.mlahead, hn)
+            s1, s2 = saved["heads"][k]
+            dh = torch.empty((B, H, W, Cm), device=dU.device, dtype=torch.float32)
+            ops.copy_channels(dU.view(-1, 4 * Cm)[:, k * Cm:(k + 1) * Cm], dh.view(-1, Cm))
+            p = f"mlahead.{hn}"
+            dx = conv_bn_relu_up_backward(self, hn + "b", s2, dh, seq[3], seq[4], inv_scale, grads, p, True, self.sync_bn,
+                                          conv_name=p + ".3", bn_name=p + ".4")
+            conv_bn_relu_up_backward(self, hn + "a", s1, dx, seq[0], seq[1], inv_scale, grads, p, False, self.sync_bn,
+                                     conv_name=p + ".0", bn_name=p + ".1")
+        if stage_done is not None:
+            stage_done()
+
+    def forward(self, input, input1, input2, input3):
+        """`decoders.py:82-89`: four (B, C, h, w) maps -> logits resized to (B, classes, img_size, img_size)."""
+        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return _MLAFn.apply(self, input, input1, input2, input3, *list(self.parameters()))
+        logits, _ = self._forward_core([self._to_nhwc16(t) for t in (input, input1, input2, input3)], save=False)
+        return ops.resize_bilinear_fwd(logits, self.img_size, self.img_size).permute(0, 3, 1, 2)

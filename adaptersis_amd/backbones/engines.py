@@ -70,10 +70,18 @@ class SegEngine(nn.Module):
 
     def __init__(self, model, backbone_encoder, cross_vit: CAViT, cross_cnn: CACNN, seg_decoder, *,
                  n_last_blocks: int = 4, num_classes: int = 2, lr: float = 0.01, momentum: float = 0.99,
-                 weight_decay: float = 3e-5, mode: str = "reference_exact", process_group=None):
+                 weight_decay: float = 3e-5, mode: str = "reference_exact", process_group=None, loss: str = "dice"):
+        """``seg_decoder``: ``FeatureDecoder`` -> the `train.py` flow; ``DecoderMLA`` -> the `train_mla.py` flow
+        (block -> CACNN -> CAViT order, the four adapter-stream maps feed the MLA head, `blocks[-2]` is evaluated
+        twice and `blocks[-1]` never: `train_mla.py:318,340`).  ``loss``: "dice" (`segloss/dice.py`, both scripts) or
+        "iou" (`segloss/iou_multi.py`, `train_multi_class.py:391-393`)."""
         super().__init__()
         if mode != "reference_exact":
             raise NotImplementedError("only mode='reference_exact' is built in this round (SURVEY.md §8 row C3)")
+        if loss not in ("dice", "iou"):
+            raise ValueError("loss must be 'dice' or 'iou'")
+        self.loss_kind = loss
+        self.is_mla = type(seg_decoder).__name__ == "DecoderMLA"
         self.model, self.backbone_encoder = model, backbone_encoder
         self.cross_vit, self.cross_cnn, self.seg_decoder = cross_vit, cross_cnn, seg_decoder
         self.n_last_blocks, self.num_classes, self.mode = n_last_blocks, num_classes, mode
@@ -84,7 +92,7 @@ class SegEngine(nn.Module):
                 list(cross_cnn.parameters()):
             p.requires_grad_(False)  # no gradient reaches them in the reference step
         # gradient-ready order of the decoder backward: final conv first, decoder_1 last
-        order = ["final_out"] + [f"decoder_{i}" for i in (4, 3, 2, 1)]
+        order = list(seg_decoder.GRAD_ORDER)
         named = dict(seg_decoder.named_parameters())
         ordered = [(n, named[n]) for pre in order for n in named if n.startswith(pre + ".")]
         assert len(ordered) == len(named)
@@ -167,14 +175,65 @@ class SegEngine(nn.Module):
 
     # ------------------------------------------------------------------------------------------
     @torch.no_grad()
+    def features_mla(self, inp: torch.Tensor, taps: Optional[dict] = None):
+        """`train_mla.py:266-383`: -> the four MLA inputs [(hi, lo|None)] in decoder argument order
+        (output_last, output_last_2, output_last_3, output_last_4), each NHWC 16-bit [B, h, w, D]."""
+        m = self.model
+        B, _, H, W = inp.shape
+        inp = inp.float().contiguous()
+        D = m.embed_dim
+        h, w = H // self.patch, W // self.patch
+        N = h * w
+        nb = len(m.blocks)
+        _, c, shapes = self.backbone_encoder.forward_tokens(inp, need_c1=False)
+        Lc = c.shape[1]
+        g = self._geometry(H, W, shapes, inp.device)
+        tokens = m.patch_embed(inp)
+        x = tokens
+        for blk in m.blocks[: nb - 3]:
+            x = blk(x)
+        c2d = c.view(B * Lc, D)
+        x2 = self._cavit(x.view(B * N, D), c2d, g, B, N, Lc)
+        outs = [x2]
+        for blk in (m.blocks[nb - 3], m.blocks[nb - 2], m.blocks[nb - 2]):  # the reference's repeated [-2:-1]
+            x2 = blk(x2.view(B, N, D)).view(B * N, D)
+            c2d = self._cacnn(c2d, x2, g, B, Lc, N, shapes)
+            x2 = self._cavit(x2, c2d, g, B, N, Lc)
+            outs.append(x2)
+        # pass A afterwards, only its last layer is used (train_mla.py:361-366)
+        xa = ops.add_cls_pos(tokens, m.cls_token.detach().reshape(-1).float().contiguous(),
+                             m._pos_for(N, H, W).detach().reshape(-1, D).float().contiguous())
+        for blk in m.blocks:
+            xa = blk(xa)
+        vit_last = m._final_norm(xa)[:, 1:]
+        last = ops.add_f32(outs[3].view(B, N, D), vit_last)
+        maps = [last.view(B * N, D), outs[2], outs[1], outs[0]]
+        dt = config.operand_dtype
+        res = []
+        for t in maps:
+            hi = ops.cast_pad(t, D, dt).view(B, h, w, D)
+            lo = ops.cast_pad(t, D, dt, part=1).view(B, h, w, D) if config.split_conv else None
+            res.append((hi, lo))
+        if taps is not None:
+            taps.update(mla_inputs=[t.view(B, N, D) for t in maps])
+        return res
+
+    @torch.no_grad()
     def train_step(self, inp: torch.Tensor, target: torch.Tensor, taps: Optional[dict] = None) -> torch.Tensor:
-        """One `train.py:268-436` iteration; returns the loss as a 0-dim device tensor (no host sync)."""
+        """One `train.py:268-436` (or `train_mla.py:260-407`) iteration; returns the loss as a 0-dim device
+        tensor (no host sync)."""
         dec = self.seg_decoder
         S = config.loss_scale
-        cat = self.features(inp, taps)
-        logits, saved = dec._forward_core(cat[0], cat[1], save=True, training=True)
+        if self.is_mla:
+            logits, saved = dec._forward_core(self.features_mla(inp, taps), save=True, training=True)
+        else:
+            cat = self.features(inp, taps)
+            logits, saved = dec._forward_core(cat[0], cat[1], save=True, training=True)
         target = target.long().contiguous()
-        loss, coef, _ = ops.dice_fwd(logits, target, 2, 10e-20, S)
+        if self.loss_kind == "dice":
+            loss, coef, _ = ops.dice_fwd(logits, target, 2, 10e-20, S)
+        else:
+            loss, coef, _ = ops.dice_fwd(logits, target, 2, 1e-6, S, mode=1)
         dz = ops.dice_bwd(logits, target, coef, 2)
         B, hh, ww, C = logits.shape
         r = ops.resize_bilinear_bwd(dz, hh, ww, config.operand_dtype, config.split_conv)
@@ -192,7 +251,10 @@ class SegEngine(nn.Module):
     @torch.no_grad()
     def eval_logits(self, inp: torch.Tensor) -> torch.Tensor:
         """Decoder logits, NHWC fp32, with the decoder's BatchNorm in its current train/eval mode."""
-        logits, _ = self.seg_decoder._forward_core(*self.features(inp), save=False)
+        if self.is_mla:
+            logits, _ = self.seg_decoder._forward_core(self.features_mla(inp), save=False)
+        else:
+            logits, _ = self.seg_decoder._forward_core(*self.features(inp), save=False)
         return logits
 
     @torch.no_grad()

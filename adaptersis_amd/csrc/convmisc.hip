@@ -338,6 +338,34 @@ __global__ __launch_bounds__(256) void decoder_input_kernel(const float* __restr
   }
 }
 
+// SwiGLU gate (dinov2/layers/swiglu_ffn.py:30-34): x12 fp32 [R, 2*Hd] -> silu(x1) * x2 as 16-bit [R, Hd]
+template <typename T>
+__global__ __launch_bounds__(256) void swiglu_kernel(const float* __restrict__ x12, T* __restrict__ out, int64_t R, int Hd) {
+  const int cpr = Hd >> 2;
+  const int64_t total = R * cpr;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / cpr;
+    const int c = (int)(i - r * cpr);
+    const float4 a = reinterpret_cast<const float4*>(x12 + r * 2 * Hd)[c];
+    const float4 b = reinterpret_cast<const float4*>(x12 + r * 2 * Hd + Hd)[c];
+    uint2 o;
+    o.x = pack2<T>(a.x / (1.f + __expf(-a.x)) * b.x, a.y / (1.f + __expf(-a.y)) * b.y);
+    o.y = pack2<T>(a.z / (1.f + __expf(-a.z)) * b.z, a.w / (1.f + __expf(-a.w)) * b.w);
+    reinterpret_cast<uint2*>(out + r * Hd)[c] = o;
+  }
+}
+
+// strided channel-slice copy (torch.cat / split along channels of NHWC tensors): 16-byte units
+__global__ __launch_bounds__(256) void copy_channels_kernel(const uint4* __restrict__ src, int64_t src_ld, const uint4* unused,
+                                                            uint4* __restrict__ dst, int64_t dst_ld, int64_t rows, int n16) {
+  const int64_t total = rows * n16;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / n16;
+    const int c = (int)(i - r * n16);
+    dst[r * dst_ld + c] = src[r * src_ld + c];
+  }
+}
+
 // out[b][i] = a[b][i] + c[b][i] (fp32, float4), each operand with its own batch stride (in float4 units)
 __global__ __launch_bounds__(256) void add_f32_kernel(const float4* __restrict__ a, const float4* __restrict__ b,
                                                       float4* __restrict__ out, int64_t n4, int batch, int64_t sa,
@@ -507,6 +535,31 @@ extern "C" int asis_decoder_input(void* stream, int dtype, const float* xs, int6
     hipLaunchKernelGGL((decoder_input_kernel<bf16>), dim3(grid_for(total)), dim3(256), 0, s, xs, xs_bstride, c4, c4_bstride, vit,
                        vit_bstride, reinterpret_cast<bf16*>(out), reinterpret_cast<bf16*>(out_lo), B, h, w, h4, w4, D);
   ASIS_CHECK_LAUNCH("asis_decoder_input");
+  return ASIS_OK;
+}
+
+extern "C" int asis_swiglu(void* stream, int dtype, const float* x12, void* out, int64_t R, int Hd) {
+  ASIS_REQUIRE(x12 && out && Hd % 4 == 0 && Hd > 0, "asis_swiglu: bad arguments");
+  ASIS_REQUIRE(asis_aligned16(x12) && (((uintptr_t)out) & 7) == 0, "asis_swiglu: alignment");
+  DT_OK(dtype, "asis_swiglu");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int64_t total = R * (Hd / 4);
+  if (dtype == ASIS_F16) hipLaunchKernelGGL((swiglu_kernel<f16>), dim3(grid_for(total)), dim3(256), 0, s, x12, reinterpret_cast<f16*>(out), R, Hd);
+  else hipLaunchKernelGGL((swiglu_kernel<bf16>), dim3(grid_for(total)), dim3(256), 0, s, x12, reinterpret_cast<bf16*>(out), R, Hd);
+  ASIS_CHECK_LAUNCH("asis_swiglu");
+  return ASIS_OK;
+}
+
+extern "C" int asis_copy_channels(void* stream, const void* src, int64_t src_ld_bytes, void* dst, int64_t dst_ld_bytes,
+                                  int64_t rows, int64_t row_bytes) {
+  ASIS_REQUIRE(src && dst, "asis_copy_channels: null pointer");
+  ASIS_REQUIRE(row_bytes % 16 == 0 && src_ld_bytes % 16 == 0 && dst_ld_bytes % 16 == 0 && asis_aligned16(src) && asis_aligned16(dst),
+               "asis_copy_channels: everything must be 16-byte granular");
+  const int64_t total = rows * (row_bytes / 16);
+  hipLaunchKernelGGL(copy_channels_kernel, dim3(grid_for(total)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     reinterpret_cast<const uint4*>(src), src_ld_bytes / 16, (const uint4*)nullptr, reinterpret_cast<uint4*>(dst),
+                     dst_ld_bytes / 16, rows, (int)(row_bytes / 16));
+  ASIS_CHECK_LAUNCH("asis_copy_channels");
   return ASIS_OK;
 }
 

@@ -108,7 +108,9 @@ __global__ __launch_bounds__(256) void dice_fwd_kernel(const float* __restrict__
 }
 
 // sums[b][c][3] (fp32, from double accumulation), loss, and the backward coefficients coef[b][c][2]
-__global__ void dice_finalize_kernel(const float* __restrict__ partial, int nblk, int B, int C, float eps,
+// mode 0: Dice (segloss/dice.py:27-33)  loss = 1 - mean_{b,c} 2I/(Sp+St+eps)
+// mode 1: soft IoU (segloss/iou_multi.py:38-49, eps = smooth)  loss = mean_c mean_b [1 - (I+eps)/(Sp+St-I+eps)]
+__global__ void dice_finalize_kernel(const float* __restrict__ partial, int nblk, int B, int C, float eps, int mode,
                                      float grad_scale, float* __restrict__ sums, float* __restrict__ loss,
                                      float* __restrict__ coef) {
   __shared__ double dsum[256];
@@ -123,16 +125,23 @@ __global__ void dice_finalize_kernel(const float* __restrict__ partial, int nblk
       s1 += p[1];
       s2 += p[2];
     }
-    const double S = s1 + s2 + (double)eps;
-    dice = 2.0 * s0 / S;
     if (sums) {
       sums[i * 3 + 0] = (float)s0;
       sums[i * 3 + 1] = (float)s1;
       sums[i * 3 + 2] = (float)s2;
     }
     const double bc = (double)B * C;
-    coef[i * 2 + 0] = (float)(-2.0 / (bc * S) * grad_scale);      // multiplies t
-    coef[i * 2 + 1] = (float)(2.0 * s0 / (bc * S * S) * grad_scale);  // constant term
+    if (mode == 0) {
+      const double S = s1 + s2 + (double)eps;
+      dice = 2.0 * s0 / S;
+      coef[i * 2 + 0] = (float)(-2.0 / (bc * S) * grad_scale);          // multiplies t
+      coef[i * 2 + 1] = (float)(2.0 * s0 / (bc * S * S) * grad_scale);  // constant term
+    } else {
+      const double In = s0 + (double)eps, U = s1 + s2 - s0 + (double)eps;
+      dice = In / U;  // d(-In/U)/dp = t * (-(U + In)/U^2) + In/U^2
+      coef[i * 2 + 0] = (float)(-(U + In) / (U * U) / bc * grad_scale);
+      coef[i * 2 + 1] = (float)(In / (U * U) / bc * grad_scale);
+    }
   }
   dsum[i] = dice;
   __syncthreads();
@@ -271,6 +280,23 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
   if (threadIdx.x == 0) out[k] = (float)(red[0] * (double)scale);
 }
 
+// F.interpolate(x, size=(H, W), mode="bilinear") (align_corners=False) on NHWC fp32 (decoders.py:88, train.py:422)
+__global__ __launch_bounds__(256) void resize_fwd_kernel(const float* __restrict__ x, int B, int h, int w, int H, int W, int C,
+                                                         float* __restrict__ out) {
+  const float sh = (float)h / (float)H, sw = (float)w / (float)W;
+  const int64_t total = (int64_t)B * H * W;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int xx = (int)(i % W);
+    const int yy = (int)((i / W) % H);
+    const int b = (int)(i / ((int64_t)W * H));
+    float z[MAXC];
+    sample_logits(x + (int64_t)b * h * w * C, h, w, C, yy, xx, sh, sw, z);
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+      if (c < C) out[i * C + c] = z[c];
+  }
+}
+
 // Validation metrics of train.py:616-642 in one pass over the (resized) logits: class-weighted cross entropy
 // numerator / denominator (nn.CrossEntropyLoss(weight) = sum w[t]*nll / sum w[t]) and the number of pixels
 // whose argmax equals the target.  partial[blk][3] = {sum w*nll, sum w, correct}.
@@ -335,16 +361,17 @@ extern "C" int asis_dice_nblk(int H, int W) {
 }
 
 extern "C" int asis_dice_fwd(void* stream, const float* logits, const int64_t* target, int B, int h, int w, int H, int W,
-                             int C, int n_softmax, float eps, float grad_scale, float* partial, float* sums,
+                             int C, int n_softmax, float eps, int mode, float grad_scale, float* partial, float* sums,
                              float* loss, float* coef) {
   ASIS_REQUIRE(logits && target && partial && loss && coef, "asis_dice_fwd: null pointer");
   ASIS_REQUIRE(C >= 1 && C <= MAXC, "asis_dice_fwd: C=%d must be in 1..%d", C, MAXC);
   ASIS_REQUIRE(B * C <= 256 && B <= 65535, "asis_dice_fwd: B*C=%d must be <= 256", B * C);
   ASIS_REQUIRE(n_softmax >= 0 && n_softmax <= 2, "asis_dice_fwd: n_softmax must be 0, 1 or 2");
+  ASIS_REQUIRE(mode == 0 || mode == 1, "asis_dice_fwd: mode must be 0 (Dice) or 1 (soft IoU)");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int nblk = asis_dice_nblk(H, W);
   hipLaunchKernelGGL(dice_fwd_kernel, dim3(nblk, B), dim3(256), 0, s, logits, target, h, w, H, W, C, n_softmax, partial);
-  hipLaunchKernelGGL(dice_finalize_kernel, dim3(1), dim3(256), 0, s, partial, nblk, B, C, eps, grad_scale, sums, loss, coef);
+  hipLaunchKernelGGL(dice_finalize_kernel, dim3(1), dim3(256), 0, s, partial, nblk, B, C, eps, mode, grad_scale, sums, loss, coef);
   ASIS_CHECK_LAUNCH("asis_dice_fwd");
   return ASIS_OK;
 }
@@ -356,6 +383,16 @@ extern "C" int asis_dice_bwd(void* stream, const float* logits, const int64_t* t
   hipLaunchKernelGGL(dice_bwd_kernel, dim3(asis_dice_nblk(H, W), B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                      logits, target, coef, h, w, H, W, C, n_softmax, dz);
   ASIS_CHECK_LAUNCH("asis_dice_bwd");
+  return ASIS_OK;
+}
+
+extern "C" int asis_resize_bilinear_fwd(void* stream, const float* x, int B, int h, int w, int H, int W, int C, float* out) {
+  ASIS_REQUIRE(x && out && C >= 1 && C <= MAXC, "asis_resize_bilinear_fwd: bad arguments (C <= %d)", MAXC);
+  int64_t g = ((int64_t)B * H * W + 255) / 256;
+  if (g > 8192) g = 8192;
+  hipLaunchKernelGGL(resize_fwd_kernel, dim3((unsigned)g), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, B, h, w, H,
+                     W, C, out);
+  ASIS_CHECK_LAUNCH("asis_resize_bilinear_fwd");
   return ASIS_OK;
 }
 

@@ -150,6 +150,18 @@ def vit_tiny_test(patch_size=14, **kwargs):
                                  block_fn=partial(Block, attn_class=MemEffAttention), **kwargs)
 
 
+def vit_tiny_swiglu(patch_size=14, **kwargs):
+    """Test-only: SwiGLU FFN (ViT-g style) at D=128."""
+    return DinoVisionTransformer(patch_size=patch_size, embed_dim=128, depth=4, num_heads=2, mlp_ratio=4,
+                                 block_fn=partial(Block, attn_class=MemEffAttention), **kwargs)
+
+
+def vit_large_d4(patch_size=14, **kwargs):
+    """Test-only: ViT-L width with 4 blocks."""
+    return DinoVisionTransformer(patch_size=patch_size, embed_dim=1024, depth=4, num_heads=16, mlp_ratio=4,
+                                 block_fn=partial(Block, attn_class=MemEffAttention), **kwargs)
+
+
 def vit_small(patch_size=16, **kwargs):
     return DinoVisionTransformer(patch_size=patch_size, embed_dim=384, depth=12, num_heads=6, mlp_ratio=4,
                                  block_fn=partial(Block, attn_class=MemEffAttention), **kwargs)

@@ -442,6 +442,26 @@ def decoder_input(xs: torch.Tensor, c4: torch.Tensor, vit: torch.Tensor, hw, c4_
     return (out, lo) if split else out
 
 
+def swiglu(x12: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """fp32 [R, 2*Hd] = [x1 | x2] -> 16-bit [R, Hd] = silu(x1) * x2 (dinov2/layers/swiglu_ffn.py:30-34)."""
+    _dev(x12)
+    R, two = x12.shape
+    out = torch.empty((R, two // 2), device=x12.device, dtype=dtype)
+    check(lib().asis_swiglu(_stream(), _dt(dtype), _f32c(x12).data_ptr(), out.data_ptr(), R, two // 2), "asis_swiglu")
+    return out
+
+
+def copy_channels(src: torch.Tensor, dst: torch.Tensor) -> None:
+    """dst[..., :] = src[..., :] for 2-D views [rows, C] whose rows are contiguous but strided (concat / split)."""
+    _dev(src, dst)
+    if src.dim() != 2 or dst.dim() != 2 or src.shape != dst.shape or src.stride(1) != 1 or dst.stride(1) != 1 \
+            or src.dtype != dst.dtype:
+        raise ValueError("copy_channels: expected matching 2-D row views")
+    es = src.element_size()
+    check(lib().asis_copy_channels(_stream(), src.data_ptr(), src.stride(0) * es, dst.data_ptr(), dst.stride(0) * es,
+                                   src.shape[0], src.shape[1] * es), "asis_copy_channels")
+
+
 def add_f32(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out = a + b for float32 [B, n, D] tensors with contiguous rows and free batch strides."""
     _dev(a, b, out)
@@ -458,8 +478,10 @@ def add_f32(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None
 # --------------------------------------------------------------------------------------------
 # loss
 # --------------------------------------------------------------------------------------------
-def dice_fwd(logits: torch.Tensor, target: torch.Tensor, n_softmax: int, eps: float = 1e-19, grad_scale: float = 1.0):
-    """logits fp32 NHWC [B,h,w,C]; target int64 [B,H,W] -> (loss [1], coef [B,C,2], sums [B,C,3])."""
+def dice_fwd(logits: torch.Tensor, target: torch.Tensor, n_softmax: int, eps: float = 1e-19, grad_scale: float = 1.0,
+             mode: int = 0):
+    """logits fp32 NHWC [B,h,w,C]; target int64 [B,H,W] -> (loss [1], coef [B,C,2], sums [B,C,3]).
+    mode 0 = Dice (segloss/dice.py), mode 1 = soft IoU (segloss/iou_multi.py, eps = smooth)."""
     _dev(logits, target)
     B, h, w, Cc = logits.shape
     H, W = target.shape[-2:]
@@ -471,7 +493,7 @@ def dice_fwd(logits: torch.Tensor, target: torch.Tensor, n_softmax: int, eps: fl
     loss = torch.empty((1,), device=logits.device, dtype=torch.float32)
     coef = torch.empty((B, Cc, 2), device=logits.device, dtype=torch.float32)
     check(lib().asis_dice_fwd(_stream(), _f32c(logits).data_ptr(), target.data_ptr(), B, h, w, H, W, Cc, n_softmax,
-                              float(eps), float(grad_scale), partial.data_ptr(), sums.data_ptr(), loss.data_ptr(),
+                              float(eps), int(mode), float(grad_scale), partial.data_ptr(), sums.data_ptr(), loss.data_ptr(),
                               coef.data_ptr()), "asis_dice_fwd")
     return loss, coef, sums
 
@@ -496,6 +518,16 @@ def dice_bwd(logits: torch.Tensor, target: torch.Tensor, coef: torch.Tensor, n_s
     check(lib().asis_dice_bwd(_stream(), _f32c(logits).data_ptr(), target.data_ptr(), coef.data_ptr(), B, h, w, H, W, Cc,
                               n_softmax, dz.data_ptr()), "asis_dice_bwd")
     return dz
+
+
+def resize_bilinear_fwd(x: torch.Tensor, H: int, W: int) -> torch.Tensor:
+    """fp32 NHWC [B,h,w,C] -> [B,H,W,C], F.interpolate(mode="bilinear", align_corners=False)."""
+    _dev(x)
+    B, h, w, Cc = x.shape
+    out = torch.empty((B, H, W, Cc), device=x.device, dtype=torch.float32)
+    check(lib().asis_resize_bilinear_fwd(_stream(), _f32c(x).data_ptr(), B, h, w, H, W, Cc, out.data_ptr()),
+          "asis_resize_bilinear_fwd")
+    return out
 
 
 def resize_bilinear_bwd(dz: torch.Tensor, h: int, w: int, dtype: torch.dtype, split: bool = False):

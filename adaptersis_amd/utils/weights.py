@@ -28,6 +28,8 @@ import torch
 VIT_CONFIGS = {
     # name: (embed_dim, depth, heads, ffn)   dinov2/models/vision_transformer.py:305-357
     "vit_tiny_test": (128, 4, 2, "mlp"),  # test-only geometry (head dim 64 like all real archs)
+    "vit_tiny_swiglu": (128, 4, 2, "swiglufused"),  # test-only: the ViT-g FFN at toy width
+    "vit_large_d4": (1024, 4, 16, "mlp"),  # test-only: ViT-L width (the only D the reference adapters accept), 4 blocks
     "vit_small": (384, 12, 6, "mlp"),
     "vit_base": (768, 12, 12, "mlp"),
     "vit_large": (1024, 24, 16, "mlp"),

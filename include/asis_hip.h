@@ -211,6 +211,11 @@ int asis_pack_conv_weight(void* stream, int dtype, const float* w, void* out, in
 int asis_decoder_input(void* stream, int dtype, const float* xs, int64_t xs_bstride, const float* c4,
                        int64_t c4_bstride, const float* vit, int64_t vit_bstride, void* out, void* out_lo, int B, int h,
                        int w, int h4, int w4, int D);
+/* SwiGLU gate (dinov2/layers/swiglu_ffn.py:30-34): x12 fp32 [R, 2*Hd] = [x1 | x2] -> out 16-bit [R, Hd] = silu(x1)*x2 */
+int asis_swiglu(void* stream, int dtype, const float* x12, void* out, int64_t R, int Hd);
+/* strided row copy in bytes (channel concat / split of NHWC tensors: torch.cat(dim=1), decoders.py:47) */
+int asis_copy_channels(void* stream, const void* src, int64_t src_ld_bytes, void* dst, int64_t dst_ld_bytes, int64_t rows,
+                       int64_t row_bytes);
 /* out[b] = a[b] + b_[b] over n floats per batch element, each operand with its own batch stride
  * (fp32; train.py:320,343,365,387 residual adds with the cls-stripped pass-A features) */
 int asis_add_f32(void* stream, const float* a, const float* b, float* out, int64_t n, int batch, int64_t stride_a,
@@ -225,8 +230,11 @@ int asis_add_f32(void* stream, const float* a, const float* b, float* out, int64
  * (already multiplied by grad_scale = the static loss scale).
  * ------------------------------------------------------------------------------------------- */
 int asis_dice_nblk(int H, int W);
+/* mode 0: Dice, loss = 1 - mean 2I/(Sp+St+eps) (segloss/dice.py:27-33);
+ * mode 1: soft IoU, loss = mean [1 - (I+eps)/(Sp+St-I+eps)] (segloss/iou_multi.py:9-49, eps = smooth 1e-6) */
 int asis_dice_fwd(void* stream, const float* logits, const int64_t* target, int B, int h, int w, int H, int W, int C,
-                  int n_softmax, float eps, float grad_scale, float* partial, float* sums, float* loss, float* coef);
+                  int n_softmax, float eps, int mode, float grad_scale, float* partial, float* sums, float* loss,
+                  float* coef);
 /* Validation metrics (train.py:616-617,642) fused with the resize: partial[asis_ce_acc_nblk(B*H*W)][3] =
  * {sum w[t]*nll, sum w[t], #(argmax == t)}; weight NULL = 1.  CE = col0/col1, accuracy = col2/(B*H*W). */
 int asis_ce_acc_nblk(int64_t total_pixels);
@@ -235,6 +243,9 @@ int asis_ce_acc(void* stream, const float* logits, const int64_t* target, const 
 /* dz fp32 [B,H,W,C] = d loss / d resized-logits */
 int asis_dice_bwd(void* stream, const float* logits, const int64_t* target, const float* coef, int B, int h, int w,
                   int H, int W, int C, int n_softmax, float* dz);
+/* F.interpolate(x, size=(H,W), mode="bilinear") (align_corners=False): fp32 NHWC [B,h,w,C] -> [B,H,W,C], C <= 16
+ * (decoders.py:88; the training loss fuses this into asis_dice_fwd instead) */
+int asis_resize_bilinear_fwd(void* stream, const float* x, int B, int h, int w, int H, int W, int C, float* out);
 /* transpose of F.interpolate(bilinear, align_corners=False): dz [B,H,W,C] -> 16-bit [B,h,w,CP] (CP = C
  * rounded up to 8, pad channels zero; dtype ASIS_F32: fp32 output, any CP >= C)
  * + partial[asis_resize_bwd_nblk(B*h*w)][C] column sums */

@@ -461,6 +461,50 @@ def adapter_forward(img, vit_sd: SD, enc_sd: SD, cavit_sd: SD, cacnn_sd: SD, num
     return cat
 
 
+def mla_forward(img, vit_sd: SD, enc_sd: SD, cavit_sd: SD, cacnn_sd: SD, num_heads: int, patch: int = 14,
+                msda_heads: int = 8, update_bn: bool = False):
+    """`train_mla.py:266-383`: the four MLA inputs as NCHW maps (output_last, output_last_2, _3, _4).
+    Order per stage is block -> CACNN -> CAViT; ``blocks[-2:-1]`` is evaluated twice and ``blocks[-1]`` never
+    (`train_mla.py:318,340`); pass A runs last and only its last layer is added to the final map."""
+    B, _, H, W = img.shape
+    c1, c2, c3, c4, shapes = feature_encoder(img, enc_sd, update_bn=update_bn)
+    d1, d2 = deform_inputs(H, W, patch, shapes)
+    c = torch.cat([c2, c3, c4], dim=1)
+    depth = vit_depth(vit_sd)
+    x = patch_embed(img, vit_sd, patch)
+    for i in range(depth - 3):
+        x = block(x, vit_sd, f"blocks.{i}", num_heads)
+    n_lvl = len(shapes)
+    x = cavit(x, d1[0], c, d1[1], cavit_sd, n_heads=msda_heads, n_levels=n_lvl)
+    outs = [x]
+    for bi in (depth - 3, depth - 2, depth - 2):
+        x = block(x, vit_sd, f"blocks.{bi}", num_heads)
+        c = cacnn(c, d2[0], x, d2[1], shapes, cacnn_sd, n_heads=msda_heads, n_levels=1)
+        x = cavit(x, d1[0], c, d1[1], cavit_sd, n_heads=msda_heads, n_levels=n_lvl)
+        outs.append(x)
+    vit_last = get_intermediate_layers(img, vit_sd, num_heads, n=4, patch=patch)[-1][0]
+    last = vit_last + outs[3]
+    h, w = H // patch, W // patch
+    D = x.shape[-1]
+    return [t.transpose(1, 2).reshape(B, D, h, w) for t in (last, outs[2], outs[1], outs[0])]
+
+
+def train_step_loss_mla(maps, target, dec_sd: SD, num_classes: int = 2, loss: str = "dice", taps: Optional[dict] = None,
+                        update_bn: bool = False):
+    """`train_mla.py:385-395` (DC) / `train_multi_class.py:391-393` (iou_loss): decoder (resizes to the image
+    size itself, `decoders.py:88`) -> softmax -> loss (which applies softmax again)."""
+    H = target.shape[-1]
+    out = decoder_mla(*maps, sd=dec_sd, img_size=H, update_bn=update_bn)
+    prob = torch.softmax(out, 1)
+    if loss == "dice":
+        val = dc_loss(prob, one_hot(target, num_classes))
+    else:
+        val = iou_loss(prob, target, num_classes=num_classes)
+    if taps is not None:
+        taps.update(out=out, loss=val)
+    return val
+
+
 def train_step_loss(cat, target, dec_sd: SD, num_classes: int = 2, taps: Optional[dict] = None,
                     update_bn: bool = False):
     """`train.py:421-428`: decoder -> bilinear resize to (H,W) -> softmax -> DC

@@ -328,6 +328,62 @@ def step_case(R, out, arch, mode, tag, batch=1):
     out[f"{tag}.n_adapter_grads"] = torch.tensor(n_adapter_grads)
 
 
+def mla_step_case(R, out, mode, tag, arch="vit_large_d4"):
+    """`train_mla.py:260-407` re-executed with the imported reference modules (binary DecoderMLA, DC loss)."""
+    import torch.nn.functional as F
+    D, depth, heads, _ = W.VIT_CONFIGS[arch]
+    vsd = W.make_vit_state_dict(arch, layerscale=("kernel" if mode == "kernel" else "init"))
+    esd, csd, nsd = W.make_encoder_state_dict(D), W.make_cavit_state_dict(D, mode=mode), W.make_cacnn_state_dict(D, mode=mode)
+    dsd = W.make_decoder_mla_state_dict(D, 128, 2)
+    ln = from_partial()
+    model = build_ref_vit(R, arch, vsd)
+    enc = R["FeatureEncoder"](embed_dim=D); enc.load_state_dict(esd)
+    cv = R["CAViT"](dim=D, n_levels=3, num_heads=8, init_values=0.0, n_points=4, norm_layer=ln); cv.load_state_dict(csd)
+    cn = R["CACNN"](dim=D, n_levels=1, num_heads=8, n_points=4, norm_layer=ln, with_cffn=True, cffn_ratio=0.25); cn.load_state_dict(nsd)
+    dec = R["DecoderMLA"](img_size=588, mla_channels=D, mlahead_channels=128); dec.load_state_dict(dsd)
+    dec.train()
+    inp, target = W.synthetic_batch(1, 588)
+    d1, d2 = R["deform_inputs"](inp, 14)
+    c1, c2, c3, c4 = enc(inp)
+    c = torch.cat([c2, c3, c4], dim=1)
+    with torch.no_grad():
+        x = model.patch_embed(inp)
+        for blk in model.blocks[0:-3]:
+            x = blk(x)
+    x = cv(query=x, reference_points=d1[0], feat=c, spatial_shapes=d1[1], level_start_index=d1[2])
+    outs = [x]
+    for sl in (slice(-3, -2), slice(-2, -1), slice(-2, -1)):
+        with torch.no_grad():
+            for blk in model.blocks[sl]:
+                x = blk(x)
+        c = cn(query=c, reference_points=d2[0], feat=x, spatial_shapes=d2[1], level_start_index=d2[2], H=36, W=36)
+        x = cv(query=x, reference_points=d1[0], feat=c, spatial_shapes=d1[1], level_start_index=d1[2])
+        outs.append(x)
+    with torch.no_grad():
+        feats = model.get_intermediate_layers(inp, 4, return_class_token=True)
+        last = feats[-1][0] + outs[3]
+        maps = [t.transpose(1, 2).reshape(1, D, 42, 42) for t in (last, outs[2], outs[1], outs[0])]
+    output = dec(*maps)
+    loss = R["DC"](2)(torch.softmax(output, 1), O.one_hot(target, 2))
+    loss.backward()
+    with torch.no_grad():
+        omaps = O.mla_forward(inp, vsd, {k: t.clone() for k, t in esd.items()}, csd, nsd, heads)
+    for i, (a, b) in enumerate(zip(omaps, maps)):
+        close(a, b, 5e-5, f"{tag} mla input {i}")
+        out[f"{tag}.in{i}"] = sub(b)
+    osd = {k: t.clone().requires_grad_(t.is_floating_point() and "running" not in k) for k, t in dsd.items()}
+    taps = {}
+    oloss = O.train_step_loss_mla(omaps, target, osd, 2, "dice", taps)
+    oloss.backward()
+    close(taps["out"].detach(), output.detach(), 1e-4, f"{tag} output")
+    close(oloss.detach(), loss.detach(), 1e-5, f"{tag} loss")
+    out[f"{tag}.output"] = sub(output)
+    out[f"{tag}.loss"] = loss.detach().clone()
+    for k, p in dec.named_parameters():
+        close(osd[k].grad, p.grad, 2e-3, f"{tag} grad {k}")
+        out[f"{tag}.grad.{k}"] = sub(p.grad, 3000)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true", help="also generate the ViT-L/14 588x588 cases")
@@ -369,6 +425,10 @@ def main():
             out = {}
             print("[vit_large 588 B=1]"); vit_case(R, "vit_large", 588, 1, out, "large588")
             save("vitl", out)
+    if want("mla"):
+        out = {}
+        print("[train_mla step, ViT-L width x 4 blocks, 588 B=1, kernel-mode weights]"); mla_step_case(R, out, "kernel", "mla_kernel")
+        save("mla", out)
     if args.full or "step" in only:
         out = {}
         print("[step ViT-L 588 B=1 reference_exact (init mode)]"); step_case(R, out, "vit_large", "init", "step_exact")
