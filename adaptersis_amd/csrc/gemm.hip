@@ -211,6 +211,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const asis_gemm_desc 
 template <typename T>
 int launch(hipStream_t s, const asis_gemm_desc& d) {
   // large-tile LDS-DMA kernel (gemm_big.h); ASIS_GEMM_BIG=0 forces the 128x128 register-staged kernel
+  static const int group_m = [] { const char* e = getenv("ASIS_GEMM_GROUPM"); return e && atoi(e) > 0 ? atoi(e) : 8; }();
   static const int big_mode = [] { const char* e = getenv("ASIS_GEMM_BIG"); return e ? atoi(e) : 1; }();
   const bool vec_ok = (d.N % 4 == 0) && (d.ldc % 4 == 0);
   const bool split = d.A_lo != nullptr;
@@ -221,12 +222,12 @@ int launch(hipStream_t s, const asis_gemm_desc& d) {
     dim3 grid(((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn), d.batch), block(512);
     static const int conv32 = [] { const char* e = getenv("ASIS_CONV_BK32"); return e ? atoi(e) : 0; }();
     if (d.conv) {
-      if (conv32 && bn == 128) hipLaunchKernelGGL((gemm_big_kernel<T, 4, 2, 2, 2, 3, 0, true, true, 32, 4>), grid, block, 0, s, d);
-      else if (bn == 128) hipLaunchKernelGGL((gemm_big_kernel<T, 4, 2, 2, 2, 3, 0, true, true>), grid, block, 0, s, d);
-      else hipLaunchKernelGGL((gemm_big_kernel<T, 8, 1, 1, 2, 3, 0, true, true>), grid, block, 0, s, d);
+      if (conv32 && bn == 128) hipLaunchKernelGGL((gemm_big_kernel<T, 4, 2, 2, 2, 3, 0, true, true, 32, 4>), grid, block, 0, s, d, group_m);
+      else if (bn == 128) hipLaunchKernelGGL((gemm_big_kernel<T, 4, 2, 2, 2, 3, 0, true, true>), grid, block, 0, s, d, group_m);
+      else hipLaunchKernelGGL((gemm_big_kernel<T, 8, 1, 1, 2, 3, 0, true, true>), grid, block, 0, s, d, group_m);
     } else {
-      if (bn == 128) hipLaunchKernelGGL((gemm_big_kernel<T, 4, 2, 2, 2, 3, 0, false, true>), grid, block, 0, s, d);
-      else hipLaunchKernelGGL((gemm_big_kernel<T, 8, 1, 1, 2, 3, 0, false, true>), grid, block, 0, s, d);
+      if (bn == 128) hipLaunchKernelGGL((gemm_big_kernel<T, 4, 2, 2, 2, 3, 0, false, true>), grid, block, 0, s, d, group_m);
+      else hipLaunchKernelGGL((gemm_big_kernel<T, 8, 1, 1, 2, 3, 0, false, true>), grid, block, 0, s, d, group_m);
     }
     return 0;
   }
@@ -236,9 +237,9 @@ int launch(hipStream_t s, const asis_gemm_desc& d) {
     // on the fc1 shape (scripts/gemm_lab.hip).  big_mode 2/3 keep the older forms selectable for A/B runs.
     const int bm = 256, bn = (big_mode == 2 && d.N >= 2048) ? 256 : 128;
     dim3 grid(((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn), d.batch), block(512);
-    if (big_mode == 2 && bn == 256) hipLaunchKernelGGL((gemm_big_kernel<T, 2, 4, 4, 2, 2>), grid, block, 0, s, d);
-    else if (big_mode >= 2 || d.K % 64 != 0 && false) hipLaunchKernelGGL((gemm_big_kernel<T, 4, 2, 2, 2, 3>), grid, block, 0, s, d);
-    else hipLaunchKernelGGL((gemm_big_kernel<T, 4, 2, 2, 2, 3, 0, false, false, 32, 4>), grid, block, 0, s, d);
+    if (big_mode == 2 && bn == 256) hipLaunchKernelGGL((gemm_big_kernel<T, 2, 4, 4, 2, 2>), grid, block, 0, s, d, group_m);
+    else if (big_mode >= 2 || d.K % 64 != 0 && false) hipLaunchKernelGGL((gemm_big_kernel<T, 4, 2, 2, 2, 3>), grid, block, 0, s, d, group_m);
+    else hipLaunchKernelGGL((gemm_big_kernel<T, 4, 2, 2, 2, 3, 0, false, false, 32, 4>), grid, block, 0, s, d, group_m);
     return 0;
   }
   // implicit-GEMM convolution on the same kernel: K tiles must lie inside one tap, and BatchNorm statistics
@@ -246,8 +247,8 @@ int launch(hipStream_t s, const asis_gemm_desc& d) {
   if (big_mode && d.conv && d.Cin % BK == 0 && d.M >= 256 && d.N >= 32 && vec_ok && d.out_f32) {
     const int bm = 256, bn = d.N > 64 ? 128 : 64;
     dim3 grid(((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn), 1), block(512);
-    if (bn == 128) hipLaunchKernelGGL((gemm_big_kernel<T, 4, 2, 2, 2, 3, 0, true>), grid, block, 0, s, d);
-    else hipLaunchKernelGGL((gemm_big_kernel<T, 8, 1, 1, 2, 3, 0, true>), grid, block, 0, s, d);
+    if (bn == 128) hipLaunchKernelGGL((gemm_big_kernel<T, 4, 2, 2, 2, 3, 0, true>), grid, block, 0, s, d, group_m);
+    else hipLaunchKernelGGL((gemm_big_kernel<T, 8, 1, 1, 2, 3, 0, true>), grid, block, 0, s, d, group_m);
     return 0;
   }
   const int tiles_m = (d.M + BM - 1) / BM, tiles_n = (d.N + BN - 1) / BN;

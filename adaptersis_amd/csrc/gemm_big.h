@@ -18,11 +18,10 @@ __device__ __attribute__((aligned(16))) uint4 g_zero_page[1];
 
 template <typename T, int WM, int WN, int TM, int TN, int NS, int DBG = 0, bool CONV = false, bool SPLIT = false, int BKT = 64,
           int OCC = 2>
-__global__ __launch_bounds__(512, OCC) void gemm_big_kernel(const asis_gemm_desc d) {
+__global__ __launch_bounds__(512, OCC) void gemm_big_kernel(const asis_gemm_desc d, const int GROUP_M) {
   typedef typename T16<T>::v8 v8;
   constexpr int BM2 = WM * TM * 32, BN2 = WN * TN * 32;
   constexpr int BKB = BKT;                           // K tile (64 or 32)
-  constexpr int GROUP_M = 8;                         // row tiles per raster band
   constexpr int CPR = BKB / 8;                       // 16-byte chunks per LDS row
   constexpr int RPI = 64 / CPR;                      // rows covered by one 1-KB LDS-DMA wave-instruction
   constexpr int SWS = (CPR == 8) ? 1 : 2;            // swizzle: chunk ^= (row >> SWS) & (CPR-1)  (conflict-free b128 reads)

@@ -44,7 +44,7 @@ int main(int argc, char** argv) {
   {                                                                                           \
     const int bm = 256, bn = BNV;                                                             \
     dim3 grid(((M + bm - 1) / bm) * ((N + bn - 1) / bn)), block(512);                         \
-    float ms = time_kernel([&]() { hipLaunchKernelGGL((gemm_big_kernel<__VA_ARGS__>), grid, block, 0, 0, d); }); \
+    float ms = time_kernel([&]() { hipLaunchKernelGGL((gemm_big_kernel<__VA_ARGS__>), grid, block, 0, 0, d, 8); }); \
     CK(hipGetLastError());                                                                    \
     printf("%-34s %8.3f ms  %7.1f TFLOP/s\n", name, ms, fl / ms / 1e9);                     \
   }
