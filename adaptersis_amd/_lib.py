@@ -96,9 +96,12 @@ SIGNATURES = {
     "asis_copy_channels": [_vp, _vp, _i64, _vp, _i64, _i64, _i64],
     "asis_add_f32": [_vp, _vp, _vp, _vp, _i64, _i, _i64, _i64, _i64],
     "asis_dice_nblk": [_i, _i],
+    "asis_seg_loss_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _f, _vp, _vp, _vp, _vp],
+    "asis_seg_loss_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "asis_dice_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _f, _vp, _vp, _vp, _vp],
     "asis_dice_bwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "asis_ce_acc_nblk": [_i64],
+    "asis_ce_acc_counts": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "asis_ce_acc": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "asis_resize_bilinear_fwd": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "asis_resize_bwd_nblk": [_i64],

@@ -68,18 +68,29 @@ class SegEngine(nn.Module):
     softmax twice, only the decoder is optimised (momentum 0.99, wd 3e-5: `train.py:178-191`).
     """
 
+    # loss name -> (n_region, region mode, eps / smooth, n_ce) of asis_seg_loss_fwd, all on softmax(resize(logits))
+    # as the scripts apply `nn.Softmax(1)` before the loss (`train.py:424`) — except "ce_dc", which the decoder-only
+    # scripts apply to the raw resized logits (`eval/eval_dinov2_unet.py:291-297`)
+    LOSSES = {
+        "dice": (2, ops.LOSS_DICE, 10e-20, 0),          # train.py:427-428  DC(2)(softmax(out))
+        "iou": (2, ops.LOSS_IOU, 1e-6, 0),              # train_multi_class.py:390-393
+        "softdice": (1, ops.LOSS_SOFTDICE, 1.0, 0),     # train.py:425 (commented alternative)
+        "dc_and_ce": (1, ops.LOSS_SOFTDICE, 1.0, 2),    # train.py:426 (commented alternative)
+        "tversky": (1, ops.LOSS_TVERSKY, 1.0, 0),       # train.py:50 import
+        "ce_dc": (1, ops.LOSS_DICE, 10e-20, 1),         # eval/eval_dinov2_unet.py:291-297, eval_dinov2_setr_cross_ete.py:334-340
+    }
+
     def __init__(self, model, backbone_encoder, cross_vit: CAViT, cross_cnn: CACNN, seg_decoder, *,
                  n_last_blocks: int = 4, num_classes: int = 2, lr: float = 0.01, momentum: float = 0.99,
                  weight_decay: float = 3e-5, mode: str = "reference_exact", process_group=None, loss: str = "dice"):
         """``seg_decoder``: ``FeatureDecoder`` -> the `train.py` flow; ``DecoderMLA`` -> the `train_mla.py` flow
         (block -> CACNN -> CAViT order, the four adapter-stream maps feed the MLA head, `blocks[-2]` is evaluated
-        twice and `blocks[-1]` never: `train_mla.py:318,340`).  ``loss``: "dice" (`segloss/dice.py`, both scripts) or
-        "iou" (`segloss/iou_multi.py`, `train_multi_class.py:391-393`)."""
+        twice and `blocks[-1]` never: `train_mla.py:318,340`).  ``loss``: a key of ``SegEngine.LOSSES``."""
         super().__init__()
         if mode != "reference_exact":
             raise NotImplementedError("only mode='reference_exact' is built in this round (SURVEY.md §8 row C3)")
-        if loss not in ("dice", "iou"):
-            raise ValueError("loss must be 'dice' or 'iou'")
+        if loss not in self.LOSSES:
+            raise ValueError(f"loss must be one of {sorted(self.LOSSES)}")
         self.loss_kind = loss
         self.is_mla = type(seg_decoder).__name__ == "DecoderMLA"
         self.model, self.backbone_encoder = model, backbone_encoder
@@ -230,11 +241,9 @@ class SegEngine(nn.Module):
             cat = self.features(inp, taps)
             logits, saved = dec._forward_core(cat[0], cat[1], save=True, training=True)
         target = target.long().contiguous()
-        if self.loss_kind == "dice":
-            loss, coef, _ = ops.dice_fwd(logits, target, 2, 10e-20, S)
-        else:
-            loss, coef, _ = ops.dice_fwd(logits, target, 2, 1e-6, S, mode=1)
-        dz = ops.dice_bwd(logits, target, coef, 2)
+        n_region, lmode, eps, n_ce = self.LOSSES[self.loss_kind]
+        loss, coef, _ = ops.seg_loss_fwd(logits, target, n_region, lmode, eps, n_ce, None, S)
+        dz = ops.seg_loss_bwd(logits, target, coef, n_region, lmode, n_ce, None)
         B, hh, ww, C = logits.shape
         r = ops.resize_bilinear_bwd(dz, hh, ww, config.operand_dtype, config.split_conv)
         d16, d_lo, bpart = r if config.split_conv else (r[0], None, r[1])

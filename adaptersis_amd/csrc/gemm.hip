@@ -211,7 +211,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const asis_gemm_desc 
 template <typename T>
 int launch(hipStream_t s, const asis_gemm_desc& d) {
   // large-tile LDS-DMA kernel (gemm_big.h); ASIS_GEMM_BIG=0 forces the 128x128 register-staged kernel
-  static const int group_m = [] { const char* e = getenv("ASIS_GEMM_GROUPM"); return e && atoi(e) > 0 ? atoi(e) : 8; }();
+  static const int group_m = [] { const char* e = getenv("ASIS_GEMM_GROUPM"); return e && atoi(e) > 0 ? atoi(e) : 4; }();
   static const int big_mode = [] { const char* e = getenv("ASIS_GEMM_BIG"); return e ? atoi(e) : 1; }();
   const bool vec_ok = (d.N % 4 == 0) && (d.ldc % 4 == 0);
   const bool split = d.A_lo != nullptr;

@@ -66,61 +66,95 @@ __device__ __forceinline__ void softmax_c(float* z, int C) {
     if (c < C) z[c] *= inv;
 }
 
-// partial[(b * nblk + blk) * C*3 + c*3 + {0: sum p t, 1: sum p, 2: sum t}]
-__global__ __launch_bounds__(256) void dice_fwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target,
-                                                       int h, int w, int H, int W, int C, int n_softmax,
-                                                       float* __restrict__ partial) {
-  __shared__ float red[4][MAXC * 3];
+// One generalised pass for every loss of segloss/: with x0 = resized logits, x1 = softmax(x0), x2 = softmax(x1)
+//   region term on q = x_{n_region}:  per (b, c) sums I = sum q t, Sp = sum q, St = sum t   (tp = I, fp = Sp - I, fn = St - I)
+//   CE term (n_ce >= 1): nll = -log softmax(x_{n_ce-1})[t], weighted mean with optional class weights
+// partial[(b * nblk + blk) * (C*3 + 2) + {c*3 + {0,1,2}: I, Sp, St ; C*3: sum w nll ; C*3+1: sum w}]
+__global__ __launch_bounds__(256) void seg_loss_fwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target,
+                                                           const float* __restrict__ ce_w, int h, int w, int H, int W, int C,
+                                                           int n_region, int n_ce, float* __restrict__ partial) {
+  __shared__ float red[4][MAXC * 3 + 2];
   const int b = blockIdx.y, nblk = gridDim.x;
   const float* lg = logits + (int64_t)b * h * w * C;
   const int64_t* tg = target + (int64_t)b * H * W;
   const float sh = (float)h / (float)H, sw = (float)w / (float)W;
-  float acc[MAXC * 3];
+  float acc[MAXC * 3 + 2];
 #pragma unroll
-  for (int i = 0; i < MAXC * 3; ++i) acc[i] = 0.f;
+  for (int i = 0; i < MAXC * 3 + 2; ++i) acc[i] = 0.f;
   const int npix = H * W;
+  const int nmax = n_region > n_ce ? n_region : n_ce;
   for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += nblk * blockDim.x) {
     const int y = p / W, x = p - y * W;
     float z[MAXC];
     sample_logits(lg, h, w, C, y, x, sh, sw, z);
-    for (int k = 0; k < n_softmax; ++k) softmax_c(z, C);
     const int t = (int)tg[p];
+    for (int k = 0; k <= nmax; ++k) {
+      if (k == n_region) {
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c)
-      if (c < C) {
-        const float tt = (t == c) ? 1.f : 0.f;
-        acc[c * 3 + 0] += z[c] * tt;
-        acc[c * 3 + 1] += z[c];
-        acc[c * 3 + 2] += tt;
+        for (int c = 0; c < MAXC; ++c)
+          if (c < C) {
+            const float tt = (t == c) ? 1.f : 0.f;
+            acc[c * 3 + 0] += z[c] * tt;
+            acc[c * 3 + 1] += z[c];
+            acc[c * 3 + 2] += tt;
+          }
       }
+      if (k + 1 == n_ce) {  // log-sum-exp on the input of the CE's own softmax
+        float m = -INFINITY, zt = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c)
+          if (c < C) {
+            m = fmaxf(m, z[c]);
+            if (c == t) zt = z[c];
+          }
+        float se = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c)
+          if (c < C) se += expf(z[c] - m);
+        const float wt = (ce_w && t >= 0 && t < C) ? ce_w[t] : 1.f;
+        acc[MAXC * 3 + 0] += wt * (logf(se) - (zt - m));
+        acc[MAXC * 3 + 1] += wt;
+      }
+      if (k < nmax) softmax_c(z, C);
+    }
   }
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 #pragma unroll
-  for (int i = 0; i < MAXC * 3; ++i)
-    if (i < C * 3) {
+  for (int i = 0; i < MAXC * 3 + 2; ++i)
+    if (i < C * 3 || i >= MAXC * 3) {
       const float v = wave_sum(acc[i]);
       if (lane == 0) red[wid][i] = v;
     }
   __syncthreads();
-  if (threadIdx.x < C * 3)
-    partial[((int64_t)b * nblk + blockIdx.x) * C * 3 + threadIdx.x] =
-        (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+  const int tx = threadIdx.x;
+  if (tx < C * 3 + 2) {
+    const int src = tx < C * 3 ? tx : MAXC * 3 + (tx - C * 3);
+    partial[((int64_t)b * nblk + blockIdx.x) * (C * 3 + 2) + tx] = (red[0][src] + red[1][src]) + (red[2][src] + red[3][src]);
+  }
 }
 
-// sums[b][c][3] (fp32, from double accumulation), loss, and the backward coefficients coef[b][c][2]
-// mode 0: Dice (segloss/dice.py:27-33)  loss = 1 - mean_{b,c} 2I/(Sp+St+eps)
-// mode 1: soft IoU (segloss/iou_multi.py:38-49, eps = smooth)  loss = mean_c mean_b [1 - (I+eps)/(Sp+St-I+eps)]
-__global__ void dice_finalize_kernel(const float* __restrict__ partial, int nblk, int B, int C, float eps, int mode,
-                                     float grad_scale, float* __restrict__ sums, float* __restrict__ loss,
-                                     float* __restrict__ coef) {
+// sums[b][c][3] (fp32, from double accumulation), loss, and the backward coefficients:
+//   coef[(b*C + c)*2 + {0,1}] : d region / d q[b,c,pix] = coef0 * t + coef1     (times grad_scale)
+//   coef[B*C*2]               : grad_scale / sum of CE weights (0 without a CE term)
+// region modes (all derive from I, Sp, St):
+//   0 Dice      segloss/dice.py:27-33            1 - mean 2I/(Sp+St+eps)
+//   1 soft IoU  segloss/iou_multi.py:38-49       mean [1 - (I+eps)/(Sp+St-I+eps)]
+//   2 SoftDice  segloss/dice_loss.py:255-291     -mean (2I+eps)/(Sp+St+eps)            (2tp+fp+fn = Sp+St)
+//   3 Tversky   segloss/dice_loss.py:333-372     -mean (I+eps)/((1-a-b)I + a Sp + b St + eps),  a=.3, b=.7
+//   4 none      (CE only, segloss/ND_Crossentropy.py:11-32)
+__global__ void seg_loss_finalize_kernel(const float* __restrict__ partial, int nblk, int B, int C, float eps, int mode,
+                                         int n_ce, float grad_scale, float* __restrict__ sums, float* __restrict__ loss,
+                                         float* __restrict__ coef) {
   __shared__ double dsum[256];
+  __shared__ double ce_tot[2];
   const int i = threadIdx.x;  // one thread per (b, c)
-  double dice = 0.0;
+  const int PS = C * 3 + 2;
+  double term = 0.0;
   if (i < B * C) {
     const int b = i / C, c = i - b * C;
     double s0 = 0, s1 = 0, s2 = 0;
     for (int k = 0; k < nblk; ++k) {
-      const float* p = partial + ((int64_t)b * nblk + k) * C * 3 + c * 3;
+      const float* p = partial + ((int64_t)b * nblk + k) * PS + c * 3;
       s0 += p[0];
       s1 += p[1];
       s2 += p[2];
@@ -130,70 +164,119 @@ __global__ void dice_finalize_kernel(const float* __restrict__ partial, int nblk
       sums[i * 3 + 1] = (float)s1;
       sums[i * 3 + 2] = (float)s2;
     }
-    const double bc = (double)B * C;
+    const double bc = (double)B * C, e = (double)eps;
+    double c0 = 0.0, c1 = 0.0;
     if (mode == 0) {
-      const double S = s1 + s2 + (double)eps;
-      dice = 2.0 * s0 / S;
-      coef[i * 2 + 0] = (float)(-2.0 / (bc * S) * grad_scale);          // multiplies t
-      coef[i * 2 + 1] = (float)(2.0 * s0 / (bc * S * S) * grad_scale);  // constant term
-    } else {
-      const double In = s0 + (double)eps, U = s1 + s2 - s0 + (double)eps;
-      dice = In / U;  // d(-In/U)/dp = t * (-(U + In)/U^2) + In/U^2
-      coef[i * 2 + 0] = (float)(-(U + In) / (U * U) / bc * grad_scale);
-      coef[i * 2 + 1] = (float)(In / (U * U) / bc * grad_scale);
+      const double S = s1 + s2 + e;
+      term = 2.0 * s0 / S;
+      c0 = -2.0 / (bc * S);
+      c1 = 2.0 * s0 / (bc * S * S);
+    } else if (mode == 1) {
+      const double In = s0 + e, U = s1 + s2 - s0 + e;
+      term = In / U;  // d(-In/U)/dq = t * (-(U + In)/U^2) + In/U^2
+      c0 = -(U + In) / (U * U) / bc;
+      c1 = In / (U * U) / bc;
+    } else if (mode == 2) {
+      const double Nn = 2.0 * s0 + e, S = s1 + s2 + e;
+      term = Nn / S;
+      c0 = -2.0 / (bc * S);
+      c1 = Nn / (bc * S * S);
+    } else if (mode == 3) {
+      const double al = 0.3, be = 0.7, g = 1.0 - al - be;
+      const double Nn = s0 + e, Dn = g * s0 + al * s1 + be * s2 + e;
+      term = Nn / Dn;  // d(-Nn/Dn)/dq = -(t Dn - Nn (g t + al)) / Dn^2
+      c0 = -(Dn - Nn * g) / (Dn * Dn) / bc;
+      c1 = Nn * al / (Dn * Dn) / bc;
     }
+    coef[i * 2 + 0] = (float)(c0 * grad_scale);
+    coef[i * 2 + 1] = (float)(c1 * grad_scale);
   }
-  dsum[i] = dice;
+  dsum[i] = term;
+  if (i < 2) {
+    double s = 0.0;
+    if (n_ce > 0)
+      for (int k = 0; k < B * nblk; ++k) s += partial[(int64_t)k * PS + C * 3 + i];
+    ce_tot[i] = s;
+  }
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
     if (i < o) dsum[i] += dsum[i + o];
     __syncthreads();
   }
-  if (i == 0) *loss = (float)(1.0 - dsum[0] / ((double)B * C));
+  if (i == 0) {
+    const double mean = dsum[0] / ((double)B * C);
+    double l = (mode == 0 || mode == 1) ? 1.0 - mean : (mode == 4 ? 0.0 : -mean);
+    if (n_ce > 0) l += ce_tot[0] / ce_tot[1];
+    *loss = (float)l;
+    coef[B * C * 2] = n_ce > 0 ? (float)((double)grad_scale / ce_tot[1]) : 0.f;
+  }
+}
+
+__device__ __forceinline__ void softmax_bwd_c(float* g, const float* p, int C) {  // g <- p * (g - <g, p>)
+  float dot = 0.f;
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c)
+    if (c < C) dot += g[c] * p[c];
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c)
+    if (c < C) g[c] = p[c] * (g[c] - dot);
 }
 
 // dz[b, y, x, c] = d loss / d (resized logits), fp32 at (H, W)
-__global__ __launch_bounds__(256) void dice_bwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target,
-                                                       const float* __restrict__ coef, int h, int w, int H, int W, int C,
-                                                       int n_softmax, float* __restrict__ dz) {
+__global__ __launch_bounds__(256) void seg_loss_bwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target,
+                                                           const float* __restrict__ coef, const float* __restrict__ ce_w,
+                                                           int B, int h, int w, int H, int W, int C, int n_region, int n_ce,
+                                                           int mode, float* __restrict__ dz) {
   const int b = blockIdx.y;
   const float* lg = logits + (int64_t)b * h * w * C;
   const int64_t* tg = target + (int64_t)b * H * W;
   float* out = dz + (int64_t)b * H * W * C;
   const float sh = (float)h / (float)H, sw = (float)w / (float)W;
   const int npix = H * W;
+  const float ce_scale = coef[B * C * 2];
+  const int nmax = n_region > n_ce ? n_region : n_ce;
   for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += gridDim.x * blockDim.x) {
     const int y = p / W, x = p - y * W;
-    float z[MAXC], p1[MAXC];
-    sample_logits(lg, h, w, C, y, x, sh, sw, z);
-    softmax_c(z, C);
+    float p1[MAXC], p2[MAXC];
+    sample_logits(lg, h, w, C, y, x, sh, sw, p1);
+    if (nmax >= 1) softmax_c(p1, C);
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c) p1[c] = z[c];
-    if (n_softmax > 1) softmax_c(z, C);  // z = p2
+    for (int c = 0; c < MAXC; ++c) p2[c] = p1[c];
+    if (nmax >= 2) softmax_c(p2, C);
     const int t = (int)tg[p];
-    float g[MAXC];
-    float dot = 0.f;
+    float r[MAXC];  // region gradient wrt q
 #pragma unroll
     for (int c = 0; c < MAXC; ++c)
-      if (c < C) {
-        g[c] = coef[(b * C + c) * 2 + 0] * ((t == c) ? 1.f : 0.f) + coef[(b * C + c) * 2 + 1];
-        dot += g[c] * z[c];
+      r[c] = (c < C && mode != 4) ? coef[(b * C + c) * 2 + 0] * ((t == c) ? 1.f : 0.f) + coef[(b * C + c) * 2 + 1] : 0.f;
+    const float cw = n_ce > 0 ? ce_scale * ((ce_w && t >= 0 && t < C) ? ce_w[t] : 1.f) : 0.f;
+    float g[MAXC];
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) g[c] = 0.f;
+    if (nmax >= 2) {  // level x1: softmax2 backward of the region term + region at x1 + CE over softmax(x1)
+      if (n_region == 2) {
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) g[c] = r[c];
+        softmax_bwd_c(g, p2, C);
       }
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c)
-      if (c < C) g[c] = z[c] * (g[c] - dot);  // through the last softmax
-    if (n_softmax > 1) {
-      float dot1 = 0.f;
-#pragma unroll
       for (int c = 0; c < MAXC; ++c)
-        if (c < C) dot1 += g[c] * p1[c];
+        if (c < C) {
+          if (n_region == 1) g[c] += r[c];
+          if (n_ce == 2) g[c] += cw * (p2[c] - ((t == c) ? 1.f : 0.f));
+        }
+      softmax_bwd_c(g, p1, C);
+    } else if (nmax == 1 && n_region == 1) {
 #pragma unroll
-      for (int c = 0; c < MAXC; ++c)
-        if (c < C) g[c] = p1[c] * (g[c] - dot1);
+      for (int c = 0; c < MAXC; ++c) g[c] = r[c];
+      softmax_bwd_c(g, p1, C);
     }
 #pragma unroll
     for (int c = 0; c < MAXC; ++c)
-      if (c < C) out[(int64_t)p * C + c] = g[c];
+      if (c < C) {
+        if (n_region == 0) g[c] += r[c];
+        if (n_ce == 1) g[c] += cw * (p1[c] - ((t == c) ? 1.f : 0.f));
+        out[(int64_t)p * C + c] = g[c];
+      }
   }
 }
 
@@ -302,8 +385,13 @@ __global__ __launch_bounds__(256) void resize_fwd_kernel(const float* __restrict
 // whose argmax equals the target.  partial[blk][3] = {sum w*nll, sum w, correct}.
 __global__ __launch_bounds__(256) void ce_acc_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target,
                                                      const float* __restrict__ weight, int B, int h, int w, int H, int W,
-                                                     int C, float* __restrict__ partial) {
+                                                     int C, float* __restrict__ partial, int* __restrict__ counts) {
   __shared__ float red[4][3];
+  __shared__ int cnt[MAXC * 3];  // per class: #(target == c), #(argmax == c), #(both)  (ch_iou / isi_iou inputs)
+  if (counts) {
+    if (threadIdx.x < MAXC * 3) cnt[threadIdx.x] = 0;
+    __syncthreads();
+  }
   const float sh = (float)h / (float)H, sw = (float)w / (float)W;
   const int64_t total = (int64_t)B * H * W;
   float a0 = 0.f, a1 = 0.f, a2 = 0.f;
@@ -331,6 +419,15 @@ __global__ __launch_bounds__(256) void ce_acc_kernel(const float* __restrict__ l
     a0 += wt * (m + __logf(se) - zt);
     a1 += wt;
     a2 += (am == t) ? 1.f : 0.f;
+    if (counts) {
+      if (t >= 0 && t < C) atomicAdd(&cnt[t * 3 + 0], 1);
+      atomicAdd(&cnt[am * 3 + 1], 1);
+      if (am == t) atomicAdd(&cnt[am * 3 + 2], 1);
+    }
+  }
+  if (counts) {
+    __syncthreads();
+    if (threadIdx.x < C * 3 && cnt[threadIdx.x]) atomicAdd(&counts[threadIdx.x], cnt[threadIdx.x]);
   }
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2);
@@ -360,30 +457,51 @@ extern "C" int asis_dice_nblk(int H, int W) {
   return n;
 }
 
+extern "C" int asis_seg_loss_fwd(void* stream, const float* logits, const int64_t* target, const float* ce_weight, int B,
+                                 int h, int w, int H, int W, int C, int n_region, int mode, float eps, int n_ce,
+                                 float grad_scale, float* partial, float* sums, float* loss, float* coef) {
+  ASIS_REQUIRE(logits && target && partial && loss && coef, "asis_seg_loss_fwd: null pointer");
+  ASIS_REQUIRE(C >= 1 && C <= MAXC, "asis_seg_loss_fwd: C=%d must be in 1..%d", C, MAXC);
+  ASIS_REQUIRE(B * C <= 256 && B <= 65535, "asis_seg_loss_fwd: B*C=%d must be <= 256", B * C);
+  ASIS_REQUIRE(n_region >= 0 && n_region <= 2, "asis_seg_loss_fwd: n_region must be 0, 1 or 2");
+  ASIS_REQUIRE(n_ce >= 0 && n_ce <= 2, "asis_seg_loss_fwd: n_ce must be 0 (no CE term), 1 or 2");
+  ASIS_REQUIRE(mode >= 0 && mode <= 4, "asis_seg_loss_fwd: mode must be 0..4");
+  ASIS_REQUIRE(mode != 4 || n_ce > 0, "asis_seg_loss_fwd: mode 4 (no region term) needs a CE term");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int nblk = asis_dice_nblk(H, W);
+  hipLaunchKernelGGL(seg_loss_fwd_kernel, dim3(nblk, B), dim3(256), 0, s, logits, target, ce_weight, h, w, H, W, C, n_region,
+                     n_ce, partial);
+  hipLaunchKernelGGL(seg_loss_finalize_kernel, dim3(1), dim3(256), 0, s, partial, nblk, B, C, eps, mode, n_ce, grad_scale,
+                     sums, loss, coef);
+  ASIS_CHECK_LAUNCH("asis_seg_loss_fwd");
+  return ASIS_OK;
+}
+
+extern "C" int asis_seg_loss_bwd(void* stream, const float* logits, const int64_t* target, const float* coef,
+                                 const float* ce_weight, int B, int h, int w, int H, int W, int C, int n_region, int mode,
+                                 int n_ce, float* dz) {
+  ASIS_REQUIRE(logits && target && coef && dz, "asis_seg_loss_bwd: null pointer");
+  ASIS_REQUIRE(C >= 1 && C <= MAXC && n_region >= 0 && n_region <= 2 && n_ce >= 0 && n_ce <= 2 && mode >= 0 && mode <= 4,
+               "asis_seg_loss_bwd: bad C / n_region / n_ce / mode");
+  hipLaunchKernelGGL(seg_loss_bwd_kernel, dim3(asis_dice_nblk(H, W), B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     logits, target, coef, ce_weight, B, h, w, H, W, C, n_region, n_ce, mode, dz);
+  ASIS_CHECK_LAUNCH("asis_seg_loss_bwd");
+  return ASIS_OK;
+}
+
+// the two-mode entry points of the train.py / train_mla.py losses (region term only)
 extern "C" int asis_dice_fwd(void* stream, const float* logits, const int64_t* target, int B, int h, int w, int H, int W,
                              int C, int n_softmax, float eps, int mode, float grad_scale, float* partial, float* sums,
                              float* loss, float* coef) {
-  ASIS_REQUIRE(logits && target && partial && loss && coef, "asis_dice_fwd: null pointer");
-  ASIS_REQUIRE(C >= 1 && C <= MAXC, "asis_dice_fwd: C=%d must be in 1..%d", C, MAXC);
-  ASIS_REQUIRE(B * C <= 256 && B <= 65535, "asis_dice_fwd: B*C=%d must be <= 256", B * C);
-  ASIS_REQUIRE(n_softmax >= 0 && n_softmax <= 2, "asis_dice_fwd: n_softmax must be 0, 1 or 2");
   ASIS_REQUIRE(mode == 0 || mode == 1, "asis_dice_fwd: mode must be 0 (Dice) or 1 (soft IoU)");
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const int nblk = asis_dice_nblk(H, W);
-  hipLaunchKernelGGL(dice_fwd_kernel, dim3(nblk, B), dim3(256), 0, s, logits, target, h, w, H, W, C, n_softmax, partial);
-  hipLaunchKernelGGL(dice_finalize_kernel, dim3(1), dim3(256), 0, s, partial, nblk, B, C, eps, mode, grad_scale, sums, loss, coef);
-  ASIS_CHECK_LAUNCH("asis_dice_fwd");
-  return ASIS_OK;
+  return asis_seg_loss_fwd(stream, logits, target, nullptr, B, h, w, H, W, C, n_softmax, mode, eps, 0, grad_scale, partial,
+                           sums, loss, coef);
 }
 
 extern "C" int asis_dice_bwd(void* stream, const float* logits, const int64_t* target, const float* coef, int B, int h,
                              int w, int H, int W, int C, int n_softmax, float* dz) {
-  ASIS_REQUIRE(logits && target && coef && dz, "asis_dice_bwd: null pointer");
-  ASIS_REQUIRE(C >= 1 && C <= MAXC && n_softmax >= 1 && n_softmax <= 2, "asis_dice_bwd: bad C / n_softmax");
-  hipLaunchKernelGGL(dice_bwd_kernel, dim3(asis_dice_nblk(H, W), B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                     logits, target, coef, h, w, H, W, C, n_softmax, dz);
-  ASIS_CHECK_LAUNCH("asis_dice_bwd");
-  return ASIS_OK;
+  ASIS_REQUIRE(n_softmax >= 1 && n_softmax <= 2, "asis_dice_bwd: bad n_softmax");
+  return asis_seg_loss_bwd(stream, logits, target, coef, nullptr, B, h, w, H, W, C, n_softmax, 0, 0, dz);
 }
 
 extern "C" int asis_resize_bilinear_fwd(void* stream, const float* x, int B, int h, int w, int H, int W, int C, float* out) {
@@ -403,14 +521,22 @@ extern "C" int asis_ce_acc_nblk(int64_t total_pixels) {
   return (int)n;
 }
 
-extern "C" int asis_ce_acc(void* stream, const float* logits, const int64_t* target, const float* weight, int B, int h,
-                           int w, int H, int W, int C, float* partial) {
+extern "C" int asis_ce_acc_counts(void* stream, const float* logits, const int64_t* target, const float* weight, int B,
+                                  int h, int w, int H, int W, int C, float* partial, int32_t* counts) {
   ASIS_REQUIRE(logits && target && partial, "asis_ce_acc: null pointer");
   ASIS_REQUIRE(C >= 1 && C <= MAXC, "asis_ce_acc: C=%d must be in 1..%d", C, MAXC);
-  hipLaunchKernelGGL(ce_acc_kernel, dim3(asis_ce_acc_nblk((int64_t)B * H * W)), dim3(256), 0,
-                     reinterpret_cast<hipStream_t>(stream), logits, target, weight, B, h, w, H, W, C, partial);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (counts && hipMemsetAsync(counts, 0, sizeof(int32_t) * C * 3, s) != hipSuccess)
+    ASIS_FAIL(ASIS_ELAUNCH, "asis_ce_acc_counts: hipMemsetAsync failed");
+  hipLaunchKernelGGL(ce_acc_kernel, dim3(asis_ce_acc_nblk((int64_t)B * H * W)), dim3(256), 0, s, logits, target, weight, B,
+                     h, w, H, W, C, partial, counts);
   ASIS_CHECK_LAUNCH("asis_ce_acc");
   return ASIS_OK;
+}
+
+extern "C" int asis_ce_acc(void* stream, const float* logits, const int64_t* target, const float* weight, int B, int h,
+                           int w, int H, int W, int C, float* partial) {
+  return asis_ce_acc_counts(stream, logits, target, weight, B, h, w, H, W, C, partial, nullptr);
 }
 
 extern "C" int asis_resize_bwd_nblk(int64_t total_pixels) {

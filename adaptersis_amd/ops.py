@@ -18,18 +18,20 @@ from ._lib import ACT_GELU, ACT_NONE, ACT_RELU, GemmDesc, check, lib  # noqa: F4
 T16_DEFAULT = torch.float16
 
 # bench.py sets this to a list to time every GEMM launch with HIP events recorded on the launch stream:
-# entries are (kind, algorithmic_flops, start_event, end_event).  None = no instrumentation.
+# entries are (kind, algorithmic_flops, start_event, end_event, algorithmic_bytes).  None = no instrumentation.
+# Algorithmic = 2*M*N*K and one read of each operand + one write of the output, also for split-precision launches
+# (their two extra products are this build's precision choice, not work the reference asks for).
 PROFILE = None
 
 
-def _launch_timed(kind: str, flops: float, fn):
+def _launch_timed(kind: str, flops: float, fn, nbytes: float = 0.0):
     if PROFILE is None:
         return fn()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     rc = fn()
     e.record()
-    PROFILE.append((kind, flops, s, e))
+    PROFILE.append((kind, flops, s, e, nbytes))
     return rc
 
 
@@ -112,8 +114,8 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, out: Optional[torch.Tensor] = None
         if a_lo.stride() != a.stride() or b_lo.stride() != b.stride():
             raise ValueError("gemm: split halves must share the layout of their hi parts")
         d.A_lo, d.B_lo = a_lo.data_ptr(), b_lo.data_ptr()
-        flops *= 3
-    check(_launch_timed("gemm", flops, lambda: lib().asis_gemm(_stream(), C.byref(d))), "asis_gemm")
+    nbytes = batch * (2.0 * (M * K + N * K) + M * N * ((4 if out_f32 else 2) + (4 if res is not None else 0)))
+    check(_launch_timed("gemm", flops, lambda: lib().asis_gemm(_stream(), C.byref(d)), nbytes), "asis_gemm")
     return out
 
 
@@ -152,7 +154,6 @@ def conv_gemm(x_nhwc: torch.Tensor, w_packed: torch.Tensor, KH: int, KW: int, st
     flops = 2.0 * d.M * Cout * K
     if x_lo is not None:
         d.A_lo, d.B_lo = x_lo.data_ptr(), w_lo.data_ptr()
-        flops *= 3
     check(_launch_timed("conv", flops, lambda: lib().asis_gemm(_stream(), C.byref(d))), "asis_gemm(conv)")
     return out
 
@@ -478,46 +479,70 @@ def add_f32(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None
 # --------------------------------------------------------------------------------------------
 # loss
 # --------------------------------------------------------------------------------------------
-def dice_fwd(logits: torch.Tensor, target: torch.Tensor, n_softmax: int, eps: float = 1e-19, grad_scale: float = 1.0,
-             mode: int = 0):
-    """logits fp32 NHWC [B,h,w,C]; target int64 [B,H,W] -> (loss [1], coef [B,C,2], sums [B,C,3]).
-    mode 0 = Dice (segloss/dice.py), mode 1 = soft IoU (segloss/iou_multi.py, eps = smooth)."""
-    _dev(logits, target)
+LOSS_DICE, LOSS_IOU, LOSS_SOFTDICE, LOSS_TVERSKY, LOSS_NONE = 0, 1, 2, 3, 4
+
+
+def seg_loss_fwd(logits: torch.Tensor, target: torch.Tensor, n_region: int, mode: int = LOSS_DICE, eps: float = 1e-19,
+                 n_ce: int = 0, ce_weight: Optional[torch.Tensor] = None, grad_scale: float = 1.0):
+    """logits fp32 NHWC [B,h,w,C]; target int64 [B,H,W] -> (loss [1], coef [B*C*2+1], sums [B,C,3]).
+    Region term `mode` on softmax^n_region(resize(logits)) plus (n_ce > 0) the cross entropy of
+    log softmax(softmax^(n_ce-1)(resize(logits))) — see include/asis_hip.h for the reference losses each case is."""
+    _dev(logits, target, ce_weight)
     B, h, w, Cc = logits.shape
     H, W = target.shape[-2:]
     if target.dtype != torch.int64 or not target.is_contiguous():
-        raise ValueError("dice_fwd: target must be contiguous int64 [B,H,W]")
+        raise ValueError("seg_loss_fwd: target must be contiguous int64 [B,H,W]")
+    if ce_weight is not None and (ce_weight.numel() != Cc or ce_weight.dtype != torch.float32):
+        raise ValueError("seg_loss_fwd: ce_weight must be float32 [C]")
     nblk = lib().asis_dice_nblk(H, W)
-    partial = torch.empty((B, nblk, Cc * 3), device=logits.device, dtype=torch.float32)
+    partial = torch.empty((B, nblk, Cc * 3 + 2), device=logits.device, dtype=torch.float32)
     sums = torch.empty((B, Cc, 3), device=logits.device, dtype=torch.float32)
     loss = torch.empty((1,), device=logits.device, dtype=torch.float32)
-    coef = torch.empty((B, Cc, 2), device=logits.device, dtype=torch.float32)
-    check(lib().asis_dice_fwd(_stream(), _f32c(logits).data_ptr(), target.data_ptr(), B, h, w, H, W, Cc, n_softmax,
-                              float(eps), int(mode), float(grad_scale), partial.data_ptr(), sums.data_ptr(), loss.data_ptr(),
-                              coef.data_ptr()), "asis_dice_fwd")
+    coef = torch.empty((B * Cc * 2 + 1,), device=logits.device, dtype=torch.float32)
+    check(lib().asis_seg_loss_fwd(_stream(), _f32c(logits).data_ptr(), target.data_ptr(), _p(_f32c(ce_weight)), B, h, w, H, W,
+                                  Cc, int(n_region), int(mode), float(eps), int(n_ce), float(grad_scale), partial.data_ptr(),
+                                  sums.data_ptr(), loss.data_ptr(), coef.data_ptr()), "asis_seg_loss_fwd")
     return loss, coef, sums
 
 
-def ce_acc(logits: torch.Tensor, target: torch.Tensor, weight: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """logits fp32 NHWC [B,h,w,C], target int64 [B,H,W] -> fp32 [3] = (sum w*nll, sum w, #correct)."""
+def seg_loss_bwd(logits: torch.Tensor, target: torch.Tensor, coef: torch.Tensor, n_region: int, mode: int = LOSS_DICE,
+                 n_ce: int = 0, ce_weight: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """-> dz fp32 [B,H,W,C] = d loss / d resized logits (times the grad_scale given to the forward)."""
+    _dev(logits, target, coef, ce_weight)
+    B, h, w, Cc = logits.shape
+    H, W = target.shape[-2:]
+    if coef.numel() != B * Cc * 2 + 1:
+        raise ValueError("seg_loss_bwd: coef must be the B*C*2+1 floats of seg_loss_fwd")
+    dz = torch.empty((B, H, W, Cc), device=logits.device, dtype=torch.float32)
+    check(lib().asis_seg_loss_bwd(_stream(), _f32c(logits).data_ptr(), target.data_ptr(), coef.data_ptr(),
+                                  _p(_f32c(ce_weight)), B, h, w, H, W, Cc, int(n_region), int(mode), int(n_ce),
+                                  dz.data_ptr()), "asis_seg_loss_bwd")
+    return dz
+
+
+def dice_fwd(logits: torch.Tensor, target: torch.Tensor, n_softmax: int, eps: float = 1e-19, grad_scale: float = 1.0,
+             mode: int = 0):
+    """Region-only shorthand: mode 0 = Dice (segloss/dice.py), mode 1 = soft IoU (segloss/iou_multi.py, eps = smooth)."""
+    return seg_loss_fwd(logits, target, n_softmax, mode, eps, 0, None, grad_scale)
+
+
+def ce_acc(logits: torch.Tensor, target: torch.Tensor, weight: Optional[torch.Tensor] = None, counts: bool = False):
+    """logits fp32 NHWC [B,h,w,C], target int64 [B,H,W] -> fp32 [3] = (sum w*nll, sum w, #correct); with ``counts``
+    also int32 [C,3] = #(target == c), #(argmax == c), #(both) (the inputs of ch_iou / isi_iou)."""
     _dev(logits, target, weight)
     B, h, w, Cc = logits.shape
     H, W = target.shape[-2:]
     nblk = lib().asis_ce_acc_nblk(B * H * W)
     partial = torch.empty((nblk, 3), device=logits.device, dtype=torch.float32)
-    check(lib().asis_ce_acc(_stream(), _f32c(logits).data_ptr(), target.data_ptr(), _p(_f32c(weight)), B, h, w, H, W, Cc,
-                            partial.data_ptr()), "asis_ce_acc")
-    return reduce_rows(partial)
+    cnt = torch.empty((Cc, 3), device=logits.device, dtype=torch.int32) if counts else None
+    check(lib().asis_ce_acc_counts(_stream(), _f32c(logits).data_ptr(), target.data_ptr(), _p(_f32c(weight)), B, h, w, H, W,
+                                   Cc, partial.data_ptr(), _p(cnt)), "asis_ce_acc")
+    red = reduce_rows(partial)
+    return (red, cnt) if counts else red
 
 
 def dice_bwd(logits: torch.Tensor, target: torch.Tensor, coef: torch.Tensor, n_softmax: int) -> torch.Tensor:
-    _dev(logits, target, coef)
-    B, h, w, Cc = logits.shape
-    H, W = target.shape[-2:]
-    dz = torch.empty((B, H, W, Cc), device=logits.device, dtype=torch.float32)
-    check(lib().asis_dice_bwd(_stream(), _f32c(logits).data_ptr(), target.data_ptr(), coef.data_ptr(), B, h, w, H, W, Cc,
-                              n_softmax, dz.data_ptr()), "asis_dice_bwd")
-    return dz
+    return seg_loss_bwd(logits, target, coef, n_softmax, LOSS_DICE, 0, None)
 
 
 def resize_bilinear_fwd(x: torch.Tensor, H: int, W: int) -> torch.Tensor:

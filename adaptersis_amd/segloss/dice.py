@@ -24,23 +24,40 @@ def _labels(target: torch.Tensor, out_shape) -> torch.Tensor:
     return target.long().contiguous()
 
 
-class _DiceFn(torch.autograd.Function):
+class _SegLossFn(torch.autograd.Function):
+    """loss(logits NCHW, labels [B,H,W]) through ``asis_seg_loss_fwd/bwd`` (+ the resize transpose when H,W differ)."""
+
     @staticmethod
-    def forward(ctx, logits_nchw, labels, n_softmax, eps):
+    def forward(ctx, logits_nchw, labels, n_region, mode, eps, n_ce, ce_weight):
         lg = logits_nchw.detach().permute(0, 2, 3, 1).contiguous().float()  # no copy when it is an NHWC buffer view
-        loss, coef, _ = ops.dice_fwd(lg, labels, n_softmax, eps, 1.0)
-        ctx.lg, ctx.labels, ctx.coef, ctx.n_softmax = lg, labels, coef, n_softmax
+        loss, coef, _ = ops.seg_loss_fwd(lg, labels, n_region, mode, eps, n_ce, ce_weight, 1.0)
+        ctx.lg, ctx.labels, ctx.coef, ctx.cfg, ctx.ce_weight = lg, labels, coef, (n_region, mode, n_ce), ce_weight
         return loss.view(())
 
     @staticmethod
     def backward(ctx, gout):
         lg = ctx.lg
         B, h, w, C = lg.shape
-        dz = ops.dice_bwd(lg, ctx.labels, ctx.coef, ctx.n_softmax)
+        n_region, mode, n_ce = ctx.cfg
+        dz = ops.seg_loss_bwd(lg, ctx.labels, ctx.coef, n_region, mode, n_ce, ctx.ce_weight)
         H, W = ctx.labels.shape[-2:]
         if (H, W) != (h, w):
             dz, _ = ops.resize_bilinear_bwd(dz, h, w, torch.float32)
-        return dz.permute(0, 3, 1, 2) * gout, None, None, None
+        return dz.permute(0, 3, 1, 2) * gout, None, None, None, None, None, None
+
+
+def seg_loss(logits: torch.Tensor, target: torch.Tensor, n_region: int, mode: int, eps: float, n_ce: int = 0,
+             ce_weight=None) -> torch.Tensor:
+    """Generic fused segmentation loss on NCHW logits (resized to the target's H x W when they differ)."""
+    if ce_weight is not None:
+        ce_weight = ce_weight.detach().float().contiguous().to(logits.device)
+    return _SegLossFn.apply(logits, _labels(target, logits.shape), n_region, mode, eps, n_ce, ce_weight)
+
+
+class _DiceFn:
+    @staticmethod
+    def apply(logits_nchw, labels, n_softmax, eps):
+        return _SegLossFn.apply(logits_nchw, labels, n_softmax, ops.LOSS_DICE, eps, 0, None)
 
 
 def resize_softmax_dc(logits: torch.Tensor, target: torch.Tensor, n_softmax: int = 2, eps: float = 10e-20):

@@ -116,6 +116,21 @@ def cpu_baseline(arch: str, size: int):
     }
 
 
+def pmc_traffic(kernel: str, variant: str):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
+    WRITE_SIZE in separate runs of this very command, gfx950 read-side doubling applied: scripts/pmc_traffic.py).
+    PMC counters cannot be collected from inside the timed run, so this is the figure of the last profiled run."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        rows = json.load(f)["kernels"]
+    for name, v in rows.items():
+        if kernel in name and variant in name:
+            return round(v["hbm_bytes_per_launch"])
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -176,17 +191,18 @@ def main():
     # ---- roofline of the dominant kernel: the dense MFMA GEMM (asis gemm_kernel<T,false>) ----------------
     roof = None
     if prof:
-        dense = [(f, s.elapsed_time(e)) for (kind, f, s, e) in prof if kind == "gemm"]
+        dense = [(f, s.elapsed_time(e)) for (kind, f, s, e, _) in prof if kind == "gemm"]
+        alg_bytes = sum(nb for (kind, _, _, _, nb) in prof if kind == "gemm") / len(dense)
         n = len(dense)
         flops = sum(f for f, _ in dense) / n
         avg_ms = sum(t for _, t in dense) / n
-        conv = [(f, s.elapsed_time(e)) for (kind, f, s, e) in prof if kind == "conv"]
+        conv = [(f, s.elapsed_time(e)) for (kind, f, s, e, _) in prof if kind == "conv"]
         achieved = flops / (avg_ms * 1e-3) / 1e12
         roof = {"bound": "mfma", "kernel": "gemm_kernel<f16,false> (all dense GEMM launches of the step)",
                 "achieved": round(achieved, 1), "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / MFMA_F16_DENSE_PEAK_TFLOPS, 4), "traffic": None,
+                "frac": round(achieved / MFMA_F16_DENSE_PEAK_TFLOPS, 4), "traffic": pmc_traffic("gemm_big_kernel", "Lb0ELb0ELi32ELi4E"),
                 "launches_per_step": n // a.steps, "avg_launch_ms": round(avg_ms, 4),
-                "gflop_per_launch": round(flops / 1e9, 2),
+                "gflop_per_launch": round(flops / 1e9, 2), "algorithmic_bytes_per_launch": round(alg_bytes),
                 "share_of_step_time": round(sum(t for _, t in dense) / a.steps / (elapsed / a.steps * 1e3), 3),
                 "conv_gemm_share_of_step_time": round(sum(t for _, t in conv) / a.steps / (elapsed / a.steps * 1e3), 3)}
 

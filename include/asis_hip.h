@@ -222,16 +222,32 @@ int asis_add_f32(void* stream, const float* a, const float* b, float* out, int64
                  int64_t stride_b, int64_t stride_out);
 
 /* ---------------------------------------------------------------------------------------------
- * Loss (train.py:422-428 + segloss/dice.py:22-33), fused with the bilinear resize (h,w)->(H,W):
- *   n_softmax = 2 : training (softmax at train.py:424 then again inside DC)
- *   n_softmax = 1 : validation dice = 1 - DC(logits) (train.py:618)
- * logits fp32 NHWC [B,h,w,C]; target int64 [B,H,W]; partial: asis_dice_nblk(H,W)*B*C*3 floats;
- * sums (optional) [B,C,3] = sum p t, sum p, sum t; loss 1 float; coef [B,C,2] feeds asis_dice_bwd
- * (already multiplied by grad_scale = the static loss scale).
+ * Segmentation losses, fused with the bilinear resize (h,w)->(H,W) of the logits (align_corners=False).
+ * With x0 = resized logits, x1 = softmax_C(x0), x2 = softmax_C(x1):
+ *   region term on q = x_{n_region} from the per-(b,c) sums I = sum q t, Sp = sum q, St = sum t:
+ *     mode 0  Dice      1 - mean 2I/(Sp+St+eps)                      segloss/dice.py:22-33 (eps 1e-19)
+ *     mode 1  soft IoU  mean [1 - (I+eps)/(Sp+St-I+eps)]             segloss/iou_multi.py:9-49 (eps = smooth 1e-6)
+ *     mode 2  SoftDice  -mean (2I+eps)/(Sp+St+eps)                   segloss/dice_loss.py:255-291,31-81 (smooth 1)
+ *     mode 3  Tversky   -mean (I+eps)/(I + .3 fp + .7 fn + eps)      segloss/dice_loss.py:333-372
+ *     mode 4  none
+ *   CE term (n_ce = 1 or 2; 0 = none): weighted-mean nll of log softmax(x_{n_ce-1})
+ *     (segloss/ND_Crossentropy.py:11-32, nn.CrossEntropyLoss of eval/eval_dinov2_unet.py:291, train.py:616-617);
+ *     ce_weight fp32 [C] or NULL.  loss = region + CE (DC_and_CE_loss, segloss/dice_loss.py:445-459).
+ * Examples: train.py:422-428 = (n_region 2, mode 0); train_mla.py:385-389 = (2, mode 1);
+ *   eval_dinov2_unet.py:291-297 CE + DC(2) on the raw resized logits = (n_region 1, mode 0, n_ce 1);
+ *   DC_and_CE_loss()(softmaxed output) = (n_region 1, mode 2, n_ce 2).
+ * logits fp32 NHWC [B,h,w,C], C <= 16, B*C <= 256; target int64 [B,H,W];
+ * partial: asis_dice_nblk(H,W)*B*(C*3+2) floats; sums (optional) [B,C,3] = I, Sp, St; loss 1 float;
+ * coef B*C*2+1 floats feeds the backward (already multiplied by grad_scale = the static loss scale).
  * ------------------------------------------------------------------------------------------- */
 int asis_dice_nblk(int H, int W);
-/* mode 0: Dice, loss = 1 - mean 2I/(Sp+St+eps) (segloss/dice.py:27-33);
- * mode 1: soft IoU, loss = mean [1 - (I+eps)/(Sp+St-I+eps)] (segloss/iou_multi.py:9-49, eps = smooth 1e-6) */
+int asis_seg_loss_fwd(void* stream, const float* logits, const int64_t* target, const float* ce_weight, int B, int h,
+                      int w, int H, int W, int C, int n_region, int mode, float eps, int n_ce, float grad_scale,
+                      float* partial, float* sums, float* loss, float* coef);
+/* dz fp32 [B,H,W,C] = d loss / d resized-logits (asis_resize_bilinear_bwd carries it back to (h,w)) */
+int asis_seg_loss_bwd(void* stream, const float* logits, const int64_t* target, const float* coef, const float* ce_weight,
+                      int B, int h, int w, int H, int W, int C, int n_region, int mode, int n_ce, float* dz);
+/* region-only shorthands (mode 0 / 1, n_region = n_softmax); same buffer sizes as above */
 int asis_dice_fwd(void* stream, const float* logits, const int64_t* target, int B, int h, int w, int H, int W, int C,
                   int n_softmax, float eps, int mode, float grad_scale, float* partial, float* sums, float* loss,
                   float* coef);
@@ -240,7 +256,11 @@ int asis_dice_fwd(void* stream, const float* logits, const int64_t* target, int 
 int asis_ce_acc_nblk(int64_t total_pixels);
 int asis_ce_acc(void* stream, const float* logits, const int64_t* target, const float* weight, int B, int h, int w,
                 int H, int W, int C, float* partial);
-/* dz fp32 [B,H,W,C] = d loss / d resized-logits */
+/* same pass + per-class pixel counts for `ch_iou` / `isi_iou` (segloss/iou_multi.py:51-88, called on the argmax of
+ * the batch at train_multi_class.py:582-589): counts int32 [C][3] = #(target == c), #(argmax == c), #(both);
+ * zeroed by the call; argmax ties go to the lowest class like torch.max */
+int asis_ce_acc_counts(void* stream, const float* logits, const int64_t* target, const float* weight, int B, int h, int w,
+                       int H, int W, int C, float* partial, int32_t* counts);
 int asis_dice_bwd(void* stream, const float* logits, const int64_t* target, const float* coef, int B, int h, int w,
                   int H, int W, int C, int n_softmax, float* dz);
 /* F.interpolate(x, size=(H,W), mode="bilinear") (align_corners=False): fp32 NHWC [B,h,w,C] -> [B,H,W,C], C <= 16

@@ -387,6 +387,42 @@ def soft_dice_loss(x, target_onehot, smooth: float = 1.0):
     return -((2 * tp + smooth) / (2 * tp + fp + fn + smooth)).mean()
 
 
+def tversky_loss(x, target_onehot, smooth: float = 1.0, alpha: float = 0.3, beta: float = 0.7):
+    """`segloss/dice_loss.py:333-372` (no nonlin, do_bg, batch_dice=False)."""
+    axes = list(range(2, x.dim()))
+    tp = (x * target_onehot).sum(axes)
+    fp = (x * (1 - target_onehot)).sum(axes)
+    fn = ((1 - x) * target_onehot).sum(axes)
+    return -((tp + smooth) / (tp + alpha * fp + beta * fn + smooth)).mean()
+
+
+def _iou_bool(a, b):
+    """`segloss/iou_multi.py:4-7` on boolean masks."""
+    inter = float((a & b).sum())
+    union = float(a.sum()) + float(b.sum()) - inter
+    return (inter + 1e-6) / (union + 1e-6)
+
+
+def ch_iou(y_true, y_pred):
+    """`segloss/iou_multi.py:51-65` (numpy label arrays): mean IoU over the non-zero classes present in y_true."""
+    import numpy as np
+    if y_true.sum() == 0:
+        return 1 if y_pred.sum() == 0 else 0
+    res = [_iou_bool(y_true == k, y_pred == k) for k in set(y_true.flatten().tolist()) if k != 0]
+    return float(np.mean(res))
+
+
+def isi_iou(y_true, y_pred, problem_type: str = "instruments"):
+    """`segloss/iou_multi.py:67-88`: classes 1..type_number-1 that occur in y_true or y_pred."""
+    import numpy as np
+    n = {"binary": 2, "parts": 4, "instruments": 8}[problem_type]
+    if y_true.sum() == 0:
+        return 1 if y_pred.sum() == 0 else 0
+    res = [_iou_bool(y_true == k, y_pred == k) for k in range(1, n)
+           if (y_true == k).sum() != 0 or (y_pred == k).sum() != 0]
+    return float(np.mean(res))
+
+
 def cross_entropy_nd(logits, target, weight=None):
     """`segloss/ND_Crossentropy.py:11-32`; with class weights it is the val
     loss of `train.py:616-617`."""

@@ -67,13 +67,17 @@ def import_reference():
     from backbones.unet_parts import UNet
     from backbones.ops.modules.ms_deform_attn import ms_deform_attn_core_pytorch
     from segloss.dice import DC
-    from segloss.dice_loss import SoftDiceLoss, DC_and_CE_loss
+    from segloss.dice_loss import SoftDiceLoss, DC_and_CE_loss, TverskyLoss
     from segloss.ND_Crossentropy import CrossentropyND
-    from segloss.iou_multi import iou_loss
+    from segloss.iou_multi import iou_loss, ch_iou, isi_iou
+    import segloss.iou_multi as _im
+    import numpy as _np
+    _im.np = _np  # work-around: the reference module uses np.mean without importing numpy (iou_multi.py:1-2,65,88)
     return dict(vits=vits, FeatureEncoder=FeatureEncoder, CAViT=CAViT, CACNN=CACNN, deform_inputs=deform_inputs,
                 FeatureDecoder=FeatureDecoder, DecoderMLA=DecoderMLA, UNet=UNet,
                 msda_core=ms_deform_attn_core_pytorch, DC=DC, SoftDiceLoss=SoftDiceLoss,
-                DC_and_CE_loss=DC_and_CE_loss, CrossentropyND=CrossentropyND, iou_loss=iou_loss)
+                DC_and_CE_loss=DC_and_CE_loss, CrossentropyND=CrossentropyND, iou_loss=iou_loss,
+                TverskyLoss=TverskyLoss, ch_iou=ch_iou, isi_iou=isi_iou)
 
 
 def build_ref_vit(R, arch, sd):
@@ -258,6 +262,71 @@ def loss_case(R, out):
     close(O.iou_loss(lg11, tg11, num_classes=C11), out["loss.iou11"], 1e-6, "iou_loss(11)")
 
 
+def loss2_case(R, out):
+    """Every loss the scripts can select, at a resized geometry (logits 20x20 -> target 28x28, as the decoders'
+    outputs are resized to the label size), with gradients wrt the low-resolution logits; plus ch_iou / isi_iou."""
+    import torch.nn.functional as F
+    B, h, H = 3, 20, 28
+    for C in (2, 8):
+        lg0 = W.tensor(f"loss2.logits{C}", (B, C, h, h), 3.0)
+        tg = W.synthetic_batch(B, H, C)[1]
+        tg[0] = 0  # one all-background image (Dice / IoU epsilon paths, iou_multi.py:54-58)
+        oh = O.one_hot(tg, C)
+        wts = torch.linspace(0.1, 2.0, C)
+        cases = {
+            # train.py:422-428
+            "dc_sm": lambda o: R["DC"](C)(torch.softmax(o, 1), oh),
+            # eval/eval_dinov2_unet.py:291-297: CE + DC on the raw resized logits
+            "ce_dc": lambda o: torch.nn.CrossEntropyLoss()(o, tg) + R["DC"](C)(o, oh),
+            # train.py:425-426 (commented alternatives): on the softmaxed output
+            "softdice_sm": lambda o: R["SoftDiceLoss"]()(torch.softmax(o, 1), tg.unsqueeze(1)),
+            "dc_and_ce_sm": lambda o: R["DC_and_CE_loss"]()(torch.softmax(o, 1), tg.unsqueeze(1)),
+            "tversky_sm": lambda o: R["TverskyLoss"]()(torch.softmax(o, 1), tg.unsqueeze(1)),
+            "dc_and_ce_raw": lambda o: R["DC_and_CE_loss"]()(o, tg.unsqueeze(1)),
+            "ce": lambda o: R["CrossentropyND"]()(o, tg),
+            "ce_weighted": lambda o: torch.nn.CrossEntropyLoss(weight=wts)(o, tg),
+            # train_multi_class.py:390-393
+            "iou_sm": lambda o: R["iou_loss"](torch.softmax(o, 1), tg, num_classes=C),
+        }
+        ocases = {
+            "dc_sm": lambda o: O.dc_loss(torch.softmax(o, 1), oh),
+            "ce_dc": lambda o: O.cross_entropy_nd(o, tg) + O.dc_loss(o, oh),
+            "softdice_sm": lambda o: O.soft_dice_loss(torch.softmax(o, 1), oh),
+            "dc_and_ce_sm": lambda o: O.dc_and_ce_loss(torch.softmax(o, 1), tg, oh),
+            "tversky_sm": lambda o: O.tversky_loss(torch.softmax(o, 1), oh),
+            "dc_and_ce_raw": lambda o: O.dc_and_ce_loss(o, tg, oh),
+            "ce": lambda o: O.cross_entropy_nd(o, tg),
+            "ce_weighted": lambda o: O.cross_entropy_nd(o, tg, wts),
+            "iou_sm": lambda o: O.iou_loss(torch.softmax(o, 1), tg, num_classes=C),
+        }
+        for name, fn in cases.items():
+            lg = lg0.clone().requires_grad_(True)
+            loss = fn(F.interpolate(lg, size=(H, H), mode="bilinear"))
+            loss.backward()
+            lo = lg0.clone().requires_grad_(True)
+            oloss = ocases[name](F.interpolate(lo, size=(H, H), mode="bilinear"))
+            oloss.backward()
+            close(oloss.detach(), loss.detach(), 1e-6, f"C={C} {name}")
+            close(lo.grad, lg.grad, 1e-5, f"C={C} {name} grad")
+            out[f"loss2.c{C}.{name}"] = loss.detach().clone()
+            out[f"loss2.c{C}.{name}.grad"] = lg.grad.clone()
+    # validation IoU metrics on label arrays (train_multi_class.py:582-589)
+    import numpy as np
+    for k, C in enumerate((2, 8, 11)):
+        yt = W.synthetic_batch(2, 56, C, seed=10 + k)[1].numpy()
+        yp = W.synthetic_batch(2, 56, C, seed=20 + k)[1].numpy()
+        yp = np.where(W.synthetic_batch(2, 56, 2, seed=30 + k)[1].numpy() > 0, yt, yp)  # partly correct predictions
+        out[f"loss2.ch_iou{C}"] = torch.tensor(float(R["ch_iou"](yt, yp)), dtype=torch.float64)
+        out[f"loss2.isi_iou{C}"] = torch.tensor(float(R["isi_iou"](yt, yp)), dtype=torch.float64)
+        assert abs(O.ch_iou(yt, yp) - float(out[f"loss2.ch_iou{C}"])) < 1e-12
+        assert abs(O.isi_iou(yt, yp) - float(out[f"loss2.isi_iou{C}"])) < 1e-12
+    z = np.zeros((2, 8, 8), dtype=np.int64)
+    o1 = z.copy(); o1[0, 0, 0] = 1
+    out["loss2.ch_iou_empty"] = torch.tensor([float(R["ch_iou"](z, z)), float(R["ch_iou"](z, o1)), float(R["isi_iou"](z, z)),
+                                              float(R["isi_iou"](z, o1))])
+    assert [O.ch_iou(z, z), O.ch_iou(z, o1), O.isi_iou(z, z), O.isi_iou(z, o1)] == out["loss2.ch_iou_empty"].tolist()
+
+
 def step_case(R, out, arch, mode, tag, batch=1):
     """Whole `train.py:268-436` step re-executed with the imported reference modules."""
     import torch.nn.functional as F
@@ -412,6 +481,10 @@ def main():
         print("[decoder D=32 hw=6 B=2]"); decoder_case(R, out, 32, 6, 2, "dec_small")
         print("[MLA / UNet]"); mla_unet_case(R, out)
         save("small", out)
+    if want("loss2"):
+        out = {}
+        print("[losses 2: all selectable losses with gradients, IoU metrics]"); loss2_case(R, out)
+        save("loss2", out)
     if want("adapter"):
         out = {}
         print("[adapter 588 D=1024 B=1]"); adapter_case(R, out)

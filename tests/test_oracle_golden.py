@@ -174,3 +174,50 @@ def test_vit_large_588_and_full_step():
     loss = O.train_step_loss(cat, tgt, dsd, 2, taps)
     assert golden_err(taps["logits"], gs["step_exact.logits"]) < 1e-4
     assert abs(float(loss) - float(gs["step_exact.loss"])) < 1e-6
+
+
+def _loss2_oracle_cases(C, tg, oh, wts):
+    return {
+        "dc_sm": lambda o: O.dc_loss(torch.softmax(o, 1), oh),
+        "ce_dc": lambda o: O.cross_entropy_nd(o, tg) + O.dc_loss(o, oh),
+        "softdice_sm": lambda o: O.soft_dice_loss(torch.softmax(o, 1), oh),
+        "dc_and_ce_sm": lambda o: O.dc_and_ce_loss(torch.softmax(o, 1), tg, oh),
+        "tversky_sm": lambda o: O.tversky_loss(torch.softmax(o, 1), oh),
+        "dc_and_ce_raw": lambda o: O.dc_and_ce_loss(o, tg, oh),
+        "ce": lambda o: O.cross_entropy_nd(o, tg),
+        "ce_weighted": lambda o: O.cross_entropy_nd(o, tg, wts),
+        "iou_sm": lambda o: O.iou_loss(torch.softmax(o, 1), tg, num_classes=C),
+    }
+
+
+def test_all_selectable_losses_with_gradients():
+    """Oracle vs the imported reference's losses (values and d/d low-res logits) — tests/golden/loss2.pt."""
+    import torch.nn.functional as F
+    g = load_golden("loss2")
+    B, h, H = 3, 20, 28
+    for C in (2, 8):
+        lg0 = W.tensor(f"loss2.logits{C}", (B, C, h, h), 3.0)
+        tg = W.synthetic_batch(B, H, C)[1]
+        tg[0] = 0
+        oh = O.one_hot(tg, C)
+        for name, fn in _loss2_oracle_cases(C, tg, oh, torch.linspace(0.1, 2.0, C)).items():
+            lo = lg0.clone().requires_grad_(True)
+            loss = fn(F.interpolate(lo, size=(H, H), mode="bilinear"))
+            loss.backward()
+            assert abs(float(loss) - float(g[f"loss2.c{C}.{name}"])) < 1e-6, (C, name)
+            assert rel_l2(lo.grad, g[f"loss2.c{C}.{name}.grad"]) < 1e-5, (C, name)
+
+
+def test_iou_metrics():
+    import numpy as np
+    g = load_golden("loss2")
+    for k, C in enumerate((2, 8, 11)):
+        yt = W.synthetic_batch(2, 56, C, seed=10 + k)[1].numpy()
+        yp = W.synthetic_batch(2, 56, C, seed=20 + k)[1].numpy()
+        yp = np.where(W.synthetic_batch(2, 56, 2, seed=30 + k)[1].numpy() > 0, yt, yp)
+        assert abs(O.ch_iou(yt, yp) - float(g[f"loss2.ch_iou{C}"])) < 1e-12
+        assert abs(O.isi_iou(yt, yp) - float(g[f"loss2.isi_iou{C}"])) < 1e-12
+    z = np.zeros((2, 8, 8), dtype=np.int64)
+    o1 = z.copy()
+    o1[0, 0, 0] = 1
+    assert [O.ch_iou(z, z), O.ch_iou(z, o1), O.isi_iou(z, z), O.isi_iou(z, o1)] == g["loss2.ch_iou_empty"].tolist()
