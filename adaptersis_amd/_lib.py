@@ -95,6 +95,12 @@ SIGNATURES = {
     "asis_swiglu": [_vp, _i, _vp, _vp, _i64, _i],
     "asis_copy_channels": [_vp, _vp, _i64, _vp, _i64, _i64, _i64],
     "asis_add_f32": [_vp, _vp, _vp, _vp, _i64, _i, _i64, _i64, _i64],
+    "asis_maxpool2_fwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i],
+    "asis_maxpool2_bwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i],
+    "asis_convt2x2_scatter": [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i],
+    "asis_convt2x2_gather": [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i],
+    "asis_convt2x2_bias_nblk": [_i64],
+    "asis_convt2x2_bias_grad": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i],
     "asis_dice_nblk": [_i, _i],
     "asis_seg_loss_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _f, _vp, _vp, _vp, _vp],
     "asis_seg_loss_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],

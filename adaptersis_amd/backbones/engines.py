@@ -93,6 +93,8 @@ class SegEngine(nn.Module):
             raise ValueError(f"loss must be one of {sorted(self.LOSSES)}")
         self.loss_kind = loss
         self.is_mla = type(seg_decoder).__name__ == "DecoderMLA"
+        # UNet head (BASELINE config 2): fed with the adapter-stream map alone, (B, h, w, D)
+        self.stream_only = type(seg_decoder).__name__ == "UNet"
         self.model, self.backbone_encoder = model, backbone_encoder
         self.cross_vit, self.cross_cnn, self.seg_decoder = cross_vit, cross_cnn, seg_decoder
         self.n_last_blocks, self.num_classes, self.mode = n_last_blocks, num_classes, mode
@@ -175,6 +177,13 @@ class SegEngine(nn.Module):
             x2 = self._cavit(x2, c2d, g, B, N, Lc)
             c2d = self._cacnn(c2d, x2, g, B, Lc, N, shapes)
             x = ops.add_f32(x2.view(B, N, D), feats[s])
+        if self.stream_only:
+            xs = x.reshape(B * N, D)
+            hi = ops.cast_pad(xs, D, config.operand_dtype).view(B, h, w, D)
+            lo = ops.cast_pad(xs, D, config.operand_dtype, part=1).view(B, h, w, D) if config.split_conv else None
+            if taps is not None:
+                taps.update(x_final=x, c_final=c2d.view(B, Lc, D), cat=hi)
+            return hi, lo
         n4 = shapes[2][0] * shapes[2][1]
         cat = ops.decoder_input(x, c_orig[:, Lc - n4:], feats[-1], (h, w), shapes[2], config.operand_dtype,
                                 config.split_conv)

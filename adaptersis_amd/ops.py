@@ -479,6 +479,60 @@ def add_f32(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None
 # --------------------------------------------------------------------------------------------
 # loss
 # --------------------------------------------------------------------------------------------
+def maxpool2_fwd(x: torch.Tensor, x_lo: Optional[torch.Tensor], save_idx: bool = True):
+    """MaxPool2d(2) on a split-precision NHWC map: (hi, lo|None) [B,H,W,C] -> (hi, lo|None) [B,H/2,W/2,C], idx uint8."""
+    _dev(x, x_lo)
+    B, H, W, Cc = x.shape
+    if not x.is_contiguous() or (x_lo is not None and (not x_lo.is_contiguous() or x_lo.shape != x.shape)):
+        raise ValueError("maxpool2_fwd: contiguous NHWC operands of one shape expected")
+    out = torch.empty((B, H // 2, W // 2, Cc), device=x.device, dtype=x.dtype)
+    out_lo = torch.empty_like(out) if x_lo is not None else None
+    idx = torch.empty((B, H // 2, W // 2, Cc), device=x.device, dtype=torch.uint8) if save_idx else None
+    check(lib().asis_maxpool2_fwd(_stream(), _dt(x.dtype), x.data_ptr(), _p(x_lo), out.data_ptr(), _p(out_lo), _p(idx), B, H,
+                                  W, Cc), "asis_maxpool2_fwd")
+    return out, out_lo, idx
+
+
+def maxpool2_bwd(dy: torch.Tensor, idx: torch.Tensor, dx: torch.Tensor) -> torch.Tensor:
+    """dx fp32 [B,H,W,C] += scatter of dy fp32 [B,H/2,W/2,C] at the saved argmax."""
+    _dev(dy, idx, dx)
+    B, H, W, Cc = dx.shape
+    if dy.shape != (B, H // 2, W // 2, Cc) or idx.shape != dy.shape or not dx.is_contiguous():
+        raise ValueError("maxpool2_bwd: shape mismatch")
+    check(lib().asis_maxpool2_bwd(_stream(), _f32c(dy).data_ptr(), idx.data_ptr(), _f32c(dx).data_ptr(), B, H, W, Cc),
+          "asis_maxpool2_bwd")
+    return dx
+
+
+def convt2x2_scatter(G: torch.Tensor, dst: torch.Tensor, dst_lo: Optional[torch.Tensor], B: int, H: int, W: int, coff: int,
+                     padT: int = 0, padL: int = 0) -> None:
+    """G fp32 [B*H*W, 4*Cout] (ConvTranspose2d k=2 s=2 as a GEMM) -> channels [coff, coff+Cout) of the NHWC 16-bit
+    buffer(s) dst [B,H2,W2,Ctot] at pixel offset (padT, padL)."""
+    _dev(G, dst, dst_lo)
+    Cout = G.shape[1] // 4
+    _, H2, W2, Ctot = dst.shape
+    if G.shape[0] != B * H * W or not dst.is_contiguous():
+        raise ValueError("convt2x2_scatter: shape mismatch")
+    check(lib().asis_convt2x2_scatter(_stream(), _dt(dst.dtype), _f32c(G).data_ptr(), dst.data_ptr(), _p(dst_lo), B, H, W,
+                                      Cout, H2, W2, Ctot, coff, padT, padL), "asis_convt2x2_scatter")
+
+
+def convt2x2_gather(dcat: torch.Tensor, B: int, H: int, W: int, Cout: int, coff: int, padT: int, padL: int,
+                    dtype: torch.dtype, split: bool):
+    """d cat fp32 [B,H2,W2,Ctot] -> (dG hi, dG lo|None 16-bit [B*H*W, 4*Cout], d bias partial sums fp32 [nblk, Cout])."""
+    _dev(dcat)
+    _, H2, W2, Ctot = dcat.shape
+    dG = torch.empty((B * H * W, 4 * Cout), device=dcat.device, dtype=dtype)
+    dG_lo = torch.empty_like(dG) if split else None
+    check(lib().asis_convt2x2_gather(_stream(), _dt(dtype), _f32c(dcat).data_ptr(), dG.data_ptr(), _p(dG_lo), B, H, W, Cout,
+                                     H2, W2, Ctot, coff, padT, padL), "asis_convt2x2_gather")
+    nblk = lib().asis_convt2x2_bias_nblk(B * 4 * H * W)
+    partial = torch.empty((nblk, Cout), device=dcat.device, dtype=torch.float32)
+    check(lib().asis_convt2x2_bias_grad(_stream(), dcat.data_ptr(), partial.data_ptr(), B, H, W, Cout, H2, W2, Ctot, coff,
+                                        padT, padL), "asis_convt2x2_bias_grad")
+    return dG, dG_lo, partial
+
+
 LOSS_DICE, LOSS_IOU, LOSS_SOFTDICE, LOSS_TVERSKY, LOSS_NONE = 0, 1, 2, 3, 4
 
 

@@ -222,6 +222,33 @@ int asis_add_f32(void* stream, const float* a, const float* b, float* out, int64
                  int64_t stride_b, int64_t stride_out);
 
 /* ---------------------------------------------------------------------------------------------
+ * UNet decode head data movement (backbones/unet_parts.py:26-104; the 3x3 convs, BatchNorm and ReLU of DoubleConv are
+ * asis_gemm(conv) + asis_bn_act, the 1x1 OutConv and the ConvTranspose2d products are asis_gemm).
+ * MaxPool2d(2) (unet_parts.py:31-33), floor mode, on split-precision NHWC maps: x/x_lo 16-bit [B,H,W,C] (x_lo NULL =
+ * single precision) -> out/out_lo [B,H/2,W/2,C] and idx uint8 [B,H/2,W/2,C] (argmax 0..3 = di*2+dj, first maximum
+ * wins like ATen; optional).  Backward ACCUMULATES: dx[b,2i+di,2j+dj,c] += dy[b,i,j,c] at the argmax — dx fp32
+ * [B,H,W,C] already holds the tensor's other gradient path (the skip connection) or zeros.  C % 8 == 0.
+ * ------------------------------------------------------------------------------------------- */
+int asis_maxpool2_fwd(void* stream, int dtype, const void* x, const void* x_lo, void* out, void* out_lo, uint8_t* idx,
+                      int B, int H, int W, int C);
+int asis_maxpool2_bwd(void* stream, const float* dy, const uint8_t* idx, float* dx, int B, int H, int W, int C);
+/* nn.ConvTranspose2d(Cin, Cout, kernel_size=2, stride=2) (unet_parts.py:50,77) as one GEMM + a pixel shuffle:
+ *   G[p, co*4 + di*2 + dj] = bias[co] + sum_ci x[p, ci] * w[ci, co, di, dj],   p = (b, i, j)
+ * scatter: G fp32 [B*H*W, 4*Cout] -> dst/dst_lo 16-bit [B,H2,W2,Ctot], channels [coff, coff+Cout), pixel
+ *   (padT + 2i + di, padL + 2j + dj) — i.e. straight into the F.pad + torch.cat([x2, x1], dim=1) buffer of
+ *   Up.forward (unet_parts.py:54-63); the caller zero-fills the pad border.
+ * gather: the transpose, d cat fp32 [B,H2,W2,Ctot] -> dG/dG_lo 16-bit [B*H*W, 4*Cout].
+ * bias_grad: partial[asis_convt2x2_bias_nblk(B*2H*2W)][Cout] column sums of the same slice (sum rows -> d bias).
+ * Cout, Ctot, coff multiples of 8. */
+int asis_convt2x2_scatter(void* stream, int dtype, const float* G, void* dst, void* dst_lo, int B, int H, int W, int Cout,
+                          int H2, int W2, int Ctot, int coff, int padT, int padL);
+int asis_convt2x2_gather(void* stream, int dtype, const float* dcat, void* dG, void* dG_lo, int B, int H, int W, int Cout,
+                         int H2, int W2, int Ctot, int coff, int padT, int padL);
+int asis_convt2x2_bias_nblk(int64_t rows);
+int asis_convt2x2_bias_grad(void* stream, const float* dcat, float* partial, int B, int H, int W, int Cout, int H2, int W2,
+                            int Ctot, int coff, int padT, int padL);
+
+/* ---------------------------------------------------------------------------------------------
  * Segmentation losses, fused with the bilinear resize (h,w)->(H,W) of the logits (align_corners=False).
  * With x0 = resized logits, x1 = softmax_C(x0), x2 = softmax_C(x1):
  *   region term on q = x_{n_region} from the per-(b,c) sums I = sum q t, Sp = sum q, St = sum t:

@@ -240,6 +240,41 @@ def mla_unet_case(R, out):
     out["unet.out"] = sub(y)
 
 
+def unet_step_case(R, out):
+    """`eval/eval_dinov2_unet.py:265-304` decoder-side step with the reference UNet(384): forward at an odd pooled size
+    (10 -> 5 -> 2 -> 4, padded back to 5: the F.pad branch of Up.forward), resize to the label size, CE + DC(2) on the
+    raw logits, gradients of every parameter, running statistics after the step."""
+    import torch.nn.functional as F
+    B, hw, HW = 2, 10, 56
+    usd = W.make_unet_state_dict(384, 2)
+    u = R["UNet"](384, 2, bilinear=False)
+    u.load_state_dict(usd, strict=True)
+    u.train()
+    x = W.tensor("unet.step.x", (B, 384, hw, hw), 1.0)
+    tg = W.synthetic_batch(B, HW, 2)[1]
+    oh = O.one_hot(tg, 2)
+    y = u(x)
+    o = F.interpolate(y, size=(HW, HW), mode="bilinear")
+    loss = torch.nn.CrossEntropyLoss()(o, tg) + R["DC"](2)(o, oh)
+    loss.backward()
+    osd = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in usd.items()}
+    oy = O.unet(x, osd, update_bn=True)
+    oo = F.interpolate(oy, size=(HW, HW), mode="bilinear")
+    oloss = O.cross_entropy_nd(oo, tg) + O.dc_loss(oo, oh)
+    oloss.backward()
+    close(oy.detach(), y.detach(), 2e-5, "UNet step logits")
+    close(oloss.detach(), loss.detach(), 1e-5, "UNet step loss")
+    out["unet_step.logits"] = sub(y)
+    out["unet_step.loss"] = loss.detach().clone()
+    for k, p in u.named_parameters():
+        close(osd[k].grad, p.grad, 5e-3, f"grad {k}")
+        out[f"unet_step.grad.{k}"] = sub(p.grad, 4000)
+    for k, v in u.state_dict().items():
+        if "running" in k:
+            close(osd[k], v, 1e-5, k)
+            out[f"unet_step.buf.{k}"] = v.clone()
+
+
 def loss_case(R, out):
     B, C, H = 3, 2, 40
     lg = W.tensor("loss.logits", (B, C, H, H), 3.0)
@@ -481,6 +516,10 @@ def main():
         print("[decoder D=32 hw=6 B=2]"); decoder_case(R, out, 32, 6, 2, "dec_small")
         print("[MLA / UNet]"); mla_unet_case(R, out)
         save("small", out)
+    if want("unet"):
+        out = {}
+        print("[UNet(384) decoder step with gradients]"); unet_step_case(R, out)
+        save("unet", out)
     if want("loss2"):
         out = {}
         print("[losses 2: all selectable losses with gradients, IoU metrics]"); loss2_case(R, out)

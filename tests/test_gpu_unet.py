@@ -1,0 +1,113 @@
+"""GPU: UNet decode head (backbones/unet_parts.py) — data-movement kernels against torch, the module against the
+golden captured from the imported reference UNet(384) (tests/golden/unet.pt), and the engine step with the UNet head
+(BASELINE config 2 flow) against the oracle."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from adaptersis_amd import config, ops
+from adaptersis_amd.backbones.unet_parts import UNet
+from adaptersis_amd.segloss.dice import seg_loss
+from adaptersis_amd.utils import weights as W
+from oracle import ref_torch as O
+from tests.conftest import golden_err, load_golden, rel_l2
+
+pytestmark = pytest.mark.gpu
+DT = torch.float16
+
+
+def _split(x):
+    hi = x.to(DT)
+    lo = (x - hi.float()).to(DT)
+    return hi, lo
+
+
+@pytest.mark.parametrize("shape", [(2, 10, 10, 16), (1, 21, 21, 64), (3, 7, 9, 8)])
+def test_maxpool2_fwd_bwd(dev, shape):
+    B, H, Wd, C = shape
+    x = W.tensor(f"mp.x{shape}", shape, 1.0).to(dev)
+    hi, lo = _split(x)
+    oh, ol, idx = ops.maxpool2_fwd(hi, lo)
+    val = hi.float() + lo.float()
+    ref, ridx = F.max_pool2d(val.permute(0, 3, 1, 2), 2, return_indices=True)
+    assert torch.equal((oh.float() + ol.float()).permute(0, 3, 1, 2), ref)
+    # single-precision form
+    o1, _, _ = ops.maxpool2_fwd(hi, None)
+    assert torch.equal(o1.permute(0, 3, 1, 2), F.max_pool2d(hi.permute(0, 3, 1, 2), 2))
+    dy = W.tensor(f"mp.dy{shape}", (B, H // 2, Wd // 2, C), 1.0).to(dev)
+    base = W.tensor(f"mp.base{shape}", shape, 1.0).to(dev)
+    dx = ops.maxpool2_bwd(dy, idx, base.clone())
+    v = val.permute(0, 3, 1, 2).clone().requires_grad_(True)
+    F.max_pool2d(v, 2).backward(dy.permute(0, 3, 1, 2))
+    assert torch.allclose(dx, base + v.grad.permute(0, 2, 3, 1), atol=0, rtol=0)
+
+
+@pytest.mark.parametrize("case", [(2, 5, 5, 32, 16, 0, 0, 0), (1, 10, 10, 64, 32, 32, 0, 0), (2, 2, 2, 16, 8, 24, 0, 0),
+                                  (2, 2, 3, 16, 8, 8, 1, 2)])
+def test_convtranspose2x2_as_gemm(dev, case):
+    """GEMM + scatter == F.conv_transpose2d written into the (padded) concat buffer; gather/bias == its transpose."""
+    B, H, Wd, Cin, Cout, coff, padB, padR = case
+    x = W.tensor(f"ct.x{case}", (B, H, Wd, Cin), 1.0).to(dev)
+    w = W.tensor(f"ct.w{case}", (Cin, Cout, 2, 2), 0.2).to(dev)
+    bias = W.tensor(f"ct.b{case}", (Cout,), 0.1).to(dev)
+    xh, xl = _split(x)
+    wf = w.reshape(Cin, -1).t().contiguous()
+    wfh, wfl = ops.cast_pad(wf, dtype=DT), ops.cast_pad(wf, dtype=DT, part=1)
+    G = torch.empty((B * H * Wd, 4 * Cout), device=dev, dtype=torch.float32)
+    ops.gemm_split(xh.view(-1, Cin), xl.view(-1, Cin), wfh, wfl, out=G, bias_n=bias.repeat_interleave(4).contiguous())
+    H2, W2, Ct = 2 * H + padB, 2 * Wd + padR, coff + Cout
+    padT, padL = padB // 2, padR // 2
+    cat_hi = torch.zeros((B, H2, W2, Ct), device=dev, dtype=DT)
+    cat_lo = torch.zeros_like(cat_hi)
+    ops.convt2x2_scatter(G, cat_hi, cat_lo, B, H, Wd, coff, padT, padL)
+    ref = F.conv_transpose2d(x.permute(0, 3, 1, 2), w, bias, stride=2)
+    ref = F.pad(ref, [padL, padR - padL, padT, padB - padT]).permute(0, 2, 3, 1)
+    got = (cat_hi.float() + cat_lo.float())[..., coff:]
+    assert rel_l2(got, ref) < 1e-5
+    assert float(cat_hi[..., :coff].abs().sum()) == 0
+    # transpose
+    dcat = W.tensor(f"ct.d{case}", (B, H2, W2, Ct), 1.0).to(dev)
+    dG, dGl, bpart = ops.convt2x2_gather(dcat, B, H, Wd, Cout, coff, padT, padL, DT, True)
+    up = dcat[:, padT:padT + 2 * H, padL:padL + 2 * Wd, coff:]
+    dG_ref = up.reshape(B, H, 2, Wd, 2, Cout).permute(0, 1, 3, 5, 2, 4).reshape(B * H * Wd, 4 * Cout)
+    assert rel_l2(dG.float() + dGl.float(), dG_ref) < 1e-6
+    assert rel_l2(ops.reduce_rows(bpart), up.reshape(-1, Cout).sum(0)) < 1e-6
+
+
+def test_unet_module_vs_reference_golden(dev):
+    g = load_golden("unet")
+    B, hw, HW = 2, 10, 56
+    usd = W.make_unet_state_dict(384, 2)
+    u = UNet(384, 2).to(dev)
+    u.load_state_dict(usd, strict=True)
+    u.train()
+    x = W.tensor("unet.step.x", (B, 384, hw, hw), 1.0).to(dev)
+    tg = W.synthetic_batch(B, HW, 2)[1].to(dev)
+    y = u(x)
+    e = golden_err(y, g["unet_step.logits"])
+    loss = seg_loss(y, tg, 1, ops.LOSS_DICE, 10e-20, n_ce=1)
+    loss.backward()
+    print("UNet logits rel-L2", e, "loss", float(loss), float(g["unet_step.loss"]))
+    assert e < 1e-3
+    assert abs(float(loss) - float(g["unet_step.loss"])) < 1e-4
+    errs = {k: golden_err(p.grad, g[f"unet_step.grad.{k}"]) for k, p in u.named_parameters()}
+    print("UNet grads:", {k: f"{v:.1e}" for k, v in errs.items()})
+    assert max(errs.values()) < 2e-2, errs
+    for k, v in u.state_dict().items():
+        if "running" in k:
+            assert rel_l2(v, g[f"unet_step.buf.{k}"]) < 1e-3, k
+
+
+def test_unet_eval_mode_and_no_grad(dev):
+    usd = W.make_unet_state_dict(32, 3)
+    u = UNet(32, 3).to(dev)
+    u.load_state_dict(usd, strict=True)
+    u.eval()
+    x = W.tensor("unet.eval.x", (2, 32, 12, 12), 1.0)
+    with torch.no_grad():
+        y = u(x.to(dev))
+    sd = {k: v.clone() for k, v in usd.items()}
+    ref = O.unet_eval(x, sd) if hasattr(O, "unet_eval") else None
+    assert y.shape == (2, 3, 48, 48)
+    if ref is not None:
+        assert rel_l2(y, ref) < 1e-3

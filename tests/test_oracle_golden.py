@@ -221,3 +221,26 @@ def test_iou_metrics():
     o1 = z.copy()
     o1[0, 0, 0] = 1
     assert [O.ch_iou(z, z), O.ch_iou(z, o1), O.isi_iou(z, z), O.isi_iou(z, o1)] == g["loss2.ch_iou_empty"].tolist()
+
+
+def test_unet_decoder_step():
+    """Oracle UNet (width-generic restatement) == the imported reference UNet(384): logits, CE + DC loss, gradients
+    of every parameter and the BatchNorm running statistics after one step (tests/golden/unet.pt)."""
+    g = load_golden("unet")
+    B, hw, HW = 2, 10, 56
+    usd = W.make_unet_state_dict(384, 2)
+    x = W.tensor("unet.step.x", (B, 384, hw, hw), 1.0)
+    tg = W.synthetic_batch(B, HW, 2)[1]
+    oh = O.one_hot(tg, 2)
+    osd = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in usd.items()}
+    oy = O.unet(x, osd, update_bn=True)
+    oo = F.interpolate(oy, size=(HW, HW), mode="bilinear")
+    loss = O.cross_entropy_nd(oo, tg) + O.dc_loss(oo, oh)
+    loss.backward()
+    assert golden_err(oy, g["unet_step.logits"]) < 1e-5
+    assert abs(float(loss) - float(g["unet_step.loss"])) < 1e-6
+    for k, v in osd.items():
+        if v.requires_grad:
+            assert golden_err(v.grad, g[f"unet_step.grad.{k}"]) < 1e-4, k
+        elif "running" in k:
+            assert rel_l2(v, g[f"unet_step.buf.{k}"]) < 1e-5, k
