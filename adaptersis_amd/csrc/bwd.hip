@@ -32,20 +32,23 @@ __global__ __launch_bounds__(256) void upsample_bn_relu_bwd_kernel(const float* 
                                                                    const float* __restrict__ scale, const float* __restrict__ shift,
                                                                    const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                    float* __restrict__ g, float* __restrict__ partial, int B,
-                                                                   int H, int W, int OH, int OW, int C) {
+                                                                   int H, int W, int OH, int OW, int C, int CW, int RW) {
   __shared__ float red[2][256 * 4];
   const int cpt = C >> 2;
   const float rh = OH > 1 ? (float)(H - 1) / (float)(OH - 1) : 0.f;
   const float rw = OW > 1 ? (float)(W - 1) / (float)(OW - 1) : 0.f;
   const float irh = rh > 0.f ? 1.f / rh : 0.f, irw = rw > 0.f ? 1.f / rw : 0.f;
-  const int64_t total = (int64_t)B * H * W * cpt;
-  // gridDim*256 is a multiple of cpt (host guarantees 256 % cpt == 0): a thread keeps its channel chunk
-  const int c = threadIdx.x % cpt;
-  const float4 sc = reinterpret_cast<const float4*>(scale)[c], sh = reinterpret_cast<const float4*>(shift)[c];
-  const float4 mu = reinterpret_cast<const float4*>(mean)[c], is = reinterpret_cast<const float4*>(invstd)[c];
+  const int64_t rows = (int64_t)B * H * W;
+  // block = CW channel chunks (blockIdx.y picks the channel tile) x RW pixel rows: a thread keeps its channel chunk
+  const int cx = threadIdx.x % CW, ry = threadIdx.x / CW;
+  const int c = blockIdx.y * CW + cx;
+  const bool live = c < cpt;
+  const int cc = live ? c : 0;
+  const float4 sc = reinterpret_cast<const float4*>(scale)[cc], sh = reinterpret_cast<const float4*>(shift)[cc];
+  const float4 mu = reinterpret_cast<const float4*>(mean)[cc], is = reinterpret_cast<const float4*>(invstd)[cc];
   float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t pix = i / cpt;
+  for (int64_t pix = (int64_t)blockIdx.x * RW + ry; live && pix < rows; pix += (int64_t)gridDim.x * RW) {
+    const int64_t i = pix * cpt + c;
     const int iw = (int)(pix % W);
     const int ih = (int)((pix / W) % H);
     const int b = (int)(pix / ((int64_t)W * H));
@@ -94,8 +97,8 @@ __global__ __launch_bounds__(256) void upsample_bn_relu_bwd_kernel(const float* 
   reinterpret_cast<float4*>(red[0])[threadIdx.x] = s1;
   reinterpret_cast<float4*>(red[1])[threadIdx.x] = s2;
   __syncthreads();
-  if ((int)threadIdx.x < cpt) {
-    for (int t = threadIdx.x + cpt; t < 256; t += cpt) {
+  if (ry == 0 && live) {
+    for (int t = cx + CW; t < CW * RW; t += CW) {
       const float4 a = reinterpret_cast<const float4*>(red[0])[t], bq = reinterpret_cast<const float4*>(red[1])[t];
       s1.x += a.x; s1.y += a.y; s1.z += a.z; s1.w += a.w;
       s2.x += bq.x; s2.y += bq.y; s2.z += bq.z; s2.w += bq.w;
@@ -111,16 +114,19 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ gamma, const float* __restrict__ dgamma,
                                                            const float* __restrict__ dbeta, float inv_n, T* __restrict__ out,
                                                            T* __restrict__ out_lo, float* __restrict__ partial, int64_t R,
-                                                           int C) {
+                                                           int C, int CW, int RW) {
   __shared__ float red[256 * 4];
   const int cpt = C >> 2;
-  const int c = threadIdx.x % cpt;
-  const float4 mu = reinterpret_cast<const float4*>(mean)[c], is = reinterpret_cast<const float4*>(invstd)[c];
-  const float4 ga = reinterpret_cast<const float4*>(gamma)[c];
-  const float4 dg = reinterpret_cast<const float4*>(dgamma)[c], db = reinterpret_cast<const float4*>(dbeta)[c];
+  const int cx = threadIdx.x % CW, ry = threadIdx.x / CW;
+  const int c = blockIdx.y * CW + cx;
+  const bool live = c < cpt;
+  const int cc = live ? c : 0;
+  const float4 mu = reinterpret_cast<const float4*>(mean)[cc], is = reinterpret_cast<const float4*>(invstd)[cc];
+  const float4 ga = reinterpret_cast<const float4*>(gamma)[cc];
+  const float4 dg = reinterpret_cast<const float4*>(dgamma)[cc], db = reinterpret_cast<const float4*>(dbeta)[cc];
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-  const int64_t total = R * cpt;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+  for (int64_t row = (int64_t)blockIdx.x * RW + ry; live && row < R; row += (int64_t)gridDim.x * RW) {
+    const int64_t i = row * cpt + c;
     const float4 gv = reinterpret_cast<const float4*>(g)[i], xv = reinterpret_cast<const float4*>(x)[i];
     float4 o;
     o.x = ga.x * is.x * (gv.x - db.x * inv_n - (xv.x - mu.x) * is.x * dg.x * inv_n);
@@ -140,8 +146,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   }
   reinterpret_cast<float4*>(red)[threadIdx.x] = s;
   __syncthreads();
-  if ((int)threadIdx.x < cpt) {
-    for (int t = threadIdx.x + cpt; t < 256; t += cpt) {
+  if (ry == 0 && live) {
+    for (int t = cx + CW; t < CW * RW; t += CW) {
       const float4 a = reinterpret_cast<const float4*>(red)[t];
       s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
     }
@@ -169,15 +175,44 @@ __global__ __launch_bounds__(256) void scale_kernel(float* __restrict__ x, int64
 
 extern "C" int asis_ew_blocks(int64_t total_chunks) { return grid_for(total_chunks); }
 
+// block shape of the BatchNorm-backward kernels: CW channel chunks (4 channels each) x RW rows, CW*RW <= 256.
+// CW = C/4 when that divides 256 (every power-of-two width), else the largest divisor of C/4 that is <= 64
+// (UNet widths 96..1536), so each thread keeps one channel chunk for its whole row loop.
+static void bn_bwd_shape(int C, int* CW, int* RW, int* tiles) {
+  const int cpt = C / 4;
+  int cw = 0;
+  if (cpt <= 256 && 256 % cpt == 0) cw = cpt;
+  else
+    for (int k = cpt < 64 ? cpt : 64; k >= 1; --k)
+      if (cpt % k == 0) { cw = k; break; }
+  if (cw < 8 && cpt > 64) cw = 64;  // awkward widths: partial last tile, guarded in the kernel
+  *CW = cw;
+  *RW = 256 / cw;
+  *tiles = (cpt + cw - 1) / cw;
+}
+// gridDim.x of those kernels = number of partial-sum rows they write
+extern "C" int asis_bn_bwd_nblk(int64_t rows, int C) {
+  int CW, RW, tiles;
+  if (C < 4 || C % 4) return 1;
+  bn_bwd_shape(C, &CW, &RW, &tiles);
+  int64_t g = (rows + RW - 1) / RW;
+  const int64_t cap = 4096 / tiles > 64 ? 4096 / tiles : 64;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
 extern "C" int asis_upsample_bn_relu_bwd(void* stream, const float* dU, const float* x, const float* scale,
                                          const float* shift, const float* mean, const float* invstd, float* g,
                                          float* partial, int B, int H, int W, int C, int factor) {
   ASIS_REQUIRE(dU && x && scale && shift && mean && invstd && g && partial, "asis_upsample_bn_relu_bwd: null pointer");
-  ASIS_REQUIRE(C % 4 == 0 && C >= 4 && 256 % (C / 4) == 0, "asis_upsample_bn_relu_bwd: C=%d must be 4*2^k <= 1024", C);
+  ASIS_REQUIRE(C % 4 == 0 && C >= 4, "asis_upsample_bn_relu_bwd: C=%d must be a positive multiple of 4", C);
   ASIS_REQUIRE(factor >= 1, "asis_upsample_bn_relu_bwd: bad factor");
-  const int64_t total = (int64_t)B * H * W * (C / 4);
-  hipLaunchKernelGGL(upsample_bn_relu_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                     dU, x, scale, shift, mean, invstd, g, partial, B, H, W, H * factor, W * factor, C);
+  int CW, RW, tiles;
+  bn_bwd_shape(C, &CW, &RW, &tiles);
+  const int nblk = asis_bn_bwd_nblk((int64_t)B * H * W, C);
+  hipLaunchKernelGGL(upsample_bn_relu_bwd_kernel, dim3(nblk, tiles), dim3(CW * RW), 0, reinterpret_cast<hipStream_t>(stream),
+                     dU, x, scale, shift, mean, invstd, g, partial, B, H, W, H * factor, W * factor, C, CW, RW);
   ASIS_CHECK_LAUNCH("asis_upsample_bn_relu_bwd");
   return ASIS_OK;
 }
@@ -186,17 +221,19 @@ extern "C" int asis_bn_bwd_apply(void* stream, int dtype, const float* g, const 
                                  const float* invstd, const float* gamma, const float* dgamma, const float* dbeta,
                                  double count, void* out, void* out_lo, float* partial, int64_t R, int C) {
   ASIS_REQUIRE(g && x && mean && invstd && gamma && dgamma && dbeta && out && partial, "asis_bn_bwd_apply: null pointer");
-  ASIS_REQUIRE(C % 4 == 0 && C >= 4 && 256 % (C / 4) == 0, "asis_bn_bwd_apply: C=%d must be 4*2^k <= 1024", C);
+  ASIS_REQUIRE(C % 4 == 0 && C >= 4, "asis_bn_bwd_apply: C=%d must be a positive multiple of 4", C);
   ASIS_REQUIRE(dtype == ASIS_F16 || dtype == ASIS_BF16, "asis_bn_bwd_apply: bad dtype %d", dtype);
-  const int64_t total = R * (C / 4);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const float inv_n = (float)(1.0 / count);
+  int CW, RW, tiles;
+  bn_bwd_shape(C, &CW, &RW, &tiles);
+  const int nblk = asis_bn_bwd_nblk(R, C);
   if (dtype == ASIS_F16)
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<f16>), dim3(grid_for(total)), dim3(256), 0, s, g, x, mean, invstd, gamma, dgamma,
-                       dbeta, inv_n, reinterpret_cast<f16*>(out), reinterpret_cast<f16*>(out_lo), partial, R, C);
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<f16>), dim3(nblk, tiles), dim3(CW * RW), 0, s, g, x, mean, invstd, gamma, dgamma,
+                       dbeta, inv_n, reinterpret_cast<f16*>(out), reinterpret_cast<f16*>(out_lo), partial, R, C, CW, RW);
   else
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16>), dim3(grid_for(total)), dim3(256), 0, s, g, x, mean, invstd, gamma, dgamma,
-                       dbeta, inv_n, reinterpret_cast<bf16*>(out), reinterpret_cast<bf16*>(out_lo), partial, R, C);
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16>), dim3(nblk, tiles), dim3(CW * RW), 0, s, g, x, mean, invstd, gamma, dgamma,
+                       dbeta, inv_n, reinterpret_cast<bf16*>(out), reinterpret_cast<bf16*>(out_lo), partial, R, C, CW, RW);
   ASIS_CHECK_LAUNCH("asis_bn_bwd_apply");
   return ASIS_OK;
 }

@@ -642,7 +642,7 @@ def upsample_bn_relu_bwd(dU: torch.Tensor, x: torch.Tensor, scale, shift, mean, 
     """-> (g fp32 [B,H,W,C], partial [nblk, 2, C])."""
     _dev(dU, x)
     B, H, W, Cc = x.shape
-    nblk = lib().asis_ew_blocks(B * H * W * (Cc // 4))
+    nblk = lib().asis_bn_bwd_nblk(B * H * W, Cc)
     g = torch.empty_like(x)
     partial = torch.empty((nblk, 2, Cc), device=x.device, dtype=torch.float32)
     check(lib().asis_upsample_bn_relu_bwd(_stream(), _f32c(dU).data_ptr(), _f32c(x).data_ptr(), scale.data_ptr(),
@@ -657,7 +657,7 @@ def bn_bwd_apply(g: torch.Tensor, x: torch.Tensor, mean, invstd, gamma, dgamma, 
     _dev(g, x)
     Cc = x.shape[-1]
     R = x.numel() // Cc
-    nblk = lib().asis_ew_blocks(R * (Cc // 4))
+    nblk = lib().asis_bn_bwd_nblk(R, Cc)
     out = torch.empty(x.shape, device=x.device, dtype=dtype)
     partial = torch.empty((nblk, Cc), device=x.device, dtype=torch.float32)
     lo = _lo(out, split)

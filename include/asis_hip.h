@@ -307,11 +307,13 @@ int asis_reduce_rows(void* stream, const float* partial, int n, int K, float sca
  * ------------------------------------------------------------------------------------------- */
 /* grid size the element-wise backward kernels use for `total_chunks` float4 chunks (partials rows) */
 int asis_ew_blocks(int64_t total_chunks);
-/* g = relu'(bn(x)) * upsample^T(dU); partial[asis_ew_blocks(B*H*W*C/4)][2][C] = sum g, sum g*xhat */
+/* rows of partial sums the two BatchNorm-backward kernels below write for `rows` pixels of C channels (C % 4 == 0) */
+int asis_bn_bwd_nblk(int64_t rows, int C);
+/* g = relu'(bn(x)) * upsample^T(dU); partial[asis_bn_bwd_nblk(B*H*W, C)][2][C] = sum g, sum g*xhat */
 int asis_upsample_bn_relu_bwd(void* stream, const float* dU, const float* x, const float* scale, const float* shift,
                               const float* mean, const float* invstd, float* g, float* partial, int B, int H, int W,
                               int C, int factor);
-/* dx(16-bit) = gamma*invstd*(g - dbeta/n - xhat*dgamma/n); partial[asis_ew_blocks(R*C/4)][C] = sum dx.
+/* dx(16-bit) = gamma*invstd*(g - dbeta/n - xhat*dgamma/n); partial[asis_bn_bwd_nblk(R, C)][C] = sum dx.
  * out_lo (optional) = rounding residual of dx: the dgrad GEMM chain runs split-precision because the
  * mean subtraction of the next BatchNorm backward amplifies 16-bit rounding noise (Numerics). */
 int asis_bn_bwd_apply(void* stream, int dtype, const float* g, const float* x, const float* mean, const float* invstd,
