@@ -1,0 +1,54 @@
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, torch.nn.functional as F
+from adaptersis_amd import ops, config
+from adaptersis_amd.backbones.unet_parts import UNet
+from adaptersis_amd.segloss.dice import seg_loss
+from adaptersis_amd.utils import weights as W
+from oracle import ref_torch as O
+dev = torch.device("cuda:0")
+B, hw, HW = 2, 10, 56
+usd = W.make_unet_state_dict(384, 2)
+x = W.tensor("unet.step.x", (B, 384, hw, hw), 1.0)
+tg = W.synthetic_batch(B, HW, 2)[1]; oh = O.one_hot(tg, 2)
+# --- oracle on CPU with captured conv-output grads
+osd = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in usd.items()}
+rec = []
+orig = F.conv2d
+def conv2d(inp, w, b=None, **kw):
+    out = orig(inp, w, b, **kw)
+    if w.shape[-1] == 3:
+        out.retain_grad(); inp.retain_grad() if inp.requires_grad else None; rec.append((inp, w, out))
+    return out
+F.conv2d = conv2d
+oy = O.unet(x, osd)
+F.conv2d = orig
+oo = F.interpolate(oy, size=(HW, HW), mode="bilinear")
+(O.cross_entropy_nd(oo, tg) + O.dc_loss(oo, oh)).backward()
+# --- HIP with recorded bn_bwd_apply outputs and upsample_bn_relu_bwd inputs
+u = UNet(384, 2).to(dev); u.load_state_dict(usd); u.train()
+calls = []
+o1, o2 = ops.bn_bwd_apply, ops.upsample_bn_relu_bwd
+def rec_apply(g, xr, *a, **k):
+    r = o1(g, xr, *a, **k); calls.append(("dx", r, g)); return r
+def rec_up(dU, *a, **k):
+    calls.append(("dU", dU.clone())); return o2(dU, *a, **k)
+import adaptersis_amd.backbones.decoders as D
+ops.bn_bwd_apply = rec_apply; ops.upsample_bn_relu_bwd = rec_up
+y = u(x.to(dev))
+loss = seg_loss(y, tg.to(dev), 1, ops.LOSS_DICE, 10e-20, n_ce=1)
+loss.backward()
+S = config.loss_scale
+rl = lambda a, b: float((a.float().cpu() - b.float()).norm() / b.float().norm())
+# order of HIP backward stages: up4.b, up4.a, up3.b, up3.a, ... ; oracle rec order is forward: d3a d3b d4a d4b u1a u1b u2a u2b u3a u3b u4a u4b
+names = ["d3a","d3b","d4a","d4b","u1a","u1b","u2a","u2b","u3a","u3b","u4a","u4b"]
+orc = {n: r for n, r in zip(names, rec)}
+hip_order = ["u4b","u4a","u3b","u3a","u2b","u2a","u1b","u1a","d4b","d4a","d3b","d3a"]
+dxs = [c for c in calls if c[0] == "dx"]; dUs = [c for c in calls if c[0] == "dU"]
+for n, cdx, cdu in zip(hip_order, dxs, dUs):
+    inp, w, out = orc[n]
+    r = cdx[1]
+    hi = r[0].float().permute(0, 3, 1, 2) / S
+    full = (r[0].float() + r[1].float()).permute(0, 3, 1, 2) / S if len(r) == 3 else hi
+    print(n, "dy(hi+lo)", f"{rl(full, out.grad):.2e}", "dy(hi)", f"{rl(hi, out.grad):.2e}", " max|dy16|", f"{float(r[0].abs().max()):.3g}",
+          "rms", f"{float(r[0].float().pow(2).mean().sqrt()):.3g}")
