@@ -14,11 +14,14 @@ tg = W.synthetic_batch(B, HW, 2)[1]; oh = O.one_hot(tg, 2)
 # --- oracle on CPU with captured conv-output grads
 osd = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in usd.items()}
 rec = []
+last = []
 orig = F.conv2d
 def conv2d(inp, w, b=None, **kw):
     out = orig(inp, w, b, **kw)
     if w.shape[-1] == 3:
         out.retain_grad(); inp.retain_grad() if inp.requires_grad else None; rec.append((inp, w, out))
+    else:
+        inp.retain_grad(); out.retain_grad(); last.append((inp, out))
     return out
 F.conv2d = conv2d
 oy = O.unet(x, osd)
@@ -36,6 +39,7 @@ def rec_up(dU, *a, **k):
 import adaptersis_amd.backbones.decoders as D
 ops.bn_bwd_apply = rec_apply; ops.upsample_bn_relu_bwd = rec_up
 y = u(x.to(dev))
+y.retain_grad()
 loss = seg_loss(y, tg.to(dev), 1, ops.LOSS_DICE, 10e-20, n_ce=1)
 loss.backward()
 S = config.loss_scale
@@ -52,3 +56,8 @@ for n, cdx, cdu in zip(hip_order, dxs, dUs):
     full = (r[0].float() + r[1].float()).permute(0, 3, 1, 2) / S if len(r) == 3 else hi
     print(n, "dy(hi+lo)", f"{rl(full, out.grad):.2e}", "dy(hi)", f"{rl(hi, out.grad):.2e}", " max|dy16|", f"{float(r[0].abs().max()):.3g}",
           "rms", f"{float(r[0].float().pow(2).mean().sqrt()):.3g}")
+
+print("dlogits", rl(y.grad, last[0][1].grad), "dU(outc dgrad)", rl(dUs[0][1].permute(0,3,1,2)/S, last[0][0].grad))
+for n, cdu in zip(hip_order, dUs):
+    pass
+# g of last stage vs oracle: relu mask * dU
