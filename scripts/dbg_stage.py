@@ -16,7 +16,7 @@ for factor in (1, 2):
         conv.weight.copy_(W.tensor("dbg.w", tuple(conv.weight.shape), (2.0 / (Cin * 9)) ** 0.5).to(dev))
         bn.weight.copy_(1.0 + W.tensor("dbg.g", (Cout,), 0.2).to(dev)); bn.bias.copy_(W.tensor("dbg.b", (Cout,), 0.2).to(dev))
     x = F.relu(W.tensor(f"dbg.x{H}", (B, Cin, H, H), 1.0)).to(dev)
-    R = W.tensor(f"dbg.r{H}{factor}", (B, Cout, H * factor, H * factor), 1.0).to(dev)
+    R = W.tensor(f"dbg.r{H}{factor}", (B, Cout, H * factor, H * factor), 1.0).to(dev) + 0.7
     xr = x.clone().requires_grad_(True)
     raw = conv(xr); raw.retain_grad()
     y = F.relu(F.batch_norm(raw, None, None, bn.weight, bn.bias, True, 0.1, 1e-5))
@@ -35,6 +35,13 @@ for factor in (1, 2):
     red = ops.reduce_rows(partial.view(partial.shape[0], 2 * Cout))
     r = ops.bn_bwd_apply(g, st.raw, st.mean, st.invstd, bn.weight.detach().float().contiguous(), red[Cout:], red[:Cout], st.count, torch.float16, True)
     dx = (r[0].float() + r[1].float()).permute(0, 3, 1, 2) / S
+    # torch formula on the same device inputs
+    n = float(B * H * H)
+    xhat = (st.raw - st.mean) * st.invstd
+    dbeta, dgamma = red[:Cout], red[Cout:]
+    ref_dx = bn.weight.detach() * st.invstd * (g - dbeta / n - xhat * dgamma / n)
+    print("   kernel vs formula", rl(r[0].float() + r[1].float(), ref_dx), " dbeta", rl(dbeta / S, bn.bias.grad), "dgamma", rl(dgamma / S, bn.weight.grad),
+          "mean", rl(st.mean, raw.detach().mean((0, 2, 3))), "invstd", rl(st.invstd, 1 / torch.sqrt(raw.detach().var((0, 2, 3), unbiased=False) + 1e-5)), "count", st.count)
     dX = conv_bn_relu_up_backward(owner, "s", st, dU, conv, bn, 1.0 / S, grads, "p", True, False)
     print(f"factor {factor} H {H}: fwd {rl(yy, y):.2e}  dy(hi+lo) {rl(dx, raw.grad):.2e} dy(hi) {rl(r[0].float().permute(0,3,1,2)/S, raw.grad):.2e} "
           f"dW {rl(grads['p.0.weight'], conv.weight.grad):.2e} dgamma {rl(grads['p.1.weight'], bn.weight.grad):.2e} dX {rl(dX.permute(0,3,1,2)/S, xr.grad):.2e}"
