@@ -61,3 +61,18 @@ print("dlogits", rl(y.grad, last[0][1].grad), "dU(outc dgrad)", rl(dUs[0][1].per
 for n, cdu in zip(hip_order, dUs):
     pass
 # g of last stage vs oracle: relu mask * dU
+
+n, cdx, cdu = hip_order[0], dxs[0], dUs[0]
+inp, w, out = orc[n]
+full = ((cdx[1][0].float() + cdx[1][1].float()).permute(0, 3, 1, 2) / S).cpu()
+ref = out.grad
+alpha = float((full * ref).sum() / (ref * ref).sum())
+print("best-fit scale", alpha, "residual after scaling", rl(full / alpha, ref))
+err_c = ((full - ref).pow(2).sum((0, 2, 3)).sqrt() / ref.pow(2).sum((0, 2, 3)).sqrt())
+print("per-channel err: min %.2e median %.2e max %.2e" % (float(err_c.min()), float(err_c.median()), float(err_c.max())))
+d = (full - ref)
+print("err mean per channel / ref rms:", float(d.mean((0,2,3)).abs().mean() / ref.pow(2).mean().sqrt()))
+# g check: oracle g = grad wrt BN output * relu mask: reconstruct from oracle: grad wrt stage output = dUs ref?
+g_hip = cdx[2].permute(0, 3, 1, 2).cpu() / S
+# oracle g: need grad wrt bn output: recompute: ref dy -> can't invert; instead compare sums
+print("sum g hip per-ch vs oracle bias grad:", rl(g_hip.sum((0, 2, 3)), osd["up4.conv.double_conv.4.bias"].grad))
