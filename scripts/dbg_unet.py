@@ -76,3 +76,15 @@ print("err mean per channel / ref rms:", float(d.mean((0,2,3)).abs().mean() / re
 g_hip = cdx[2].permute(0, 3, 1, 2).cpu() / S
 # oracle g: need grad wrt bn output: recompute: ref dy -> can't invert; instead compare sums
 print("sum g hip per-ch vs oracle bias grad:", rl(g_hip.sum((0, 2, 3)), osd["up4.conv.double_conv.4.bias"].grad))
+
+c = int(err_c.argmax())
+dch = d[:, c]; rch = ref[:, c]
+print("worst channel", c, "err", float(err_c[c]), "ref rms", float(rch.pow(2).mean().sqrt()), "n big diffs", int((dch.abs() > 1e-2 * rch.pow(2).mean().sqrt()).sum()), "of", dch.numel())
+print("diff mean", float(dch.mean()), "diff std", float(dch.std()), "corr(diff, ref)", float((dch * rch).sum() / (dch.norm() * rch.norm())))
+bnw = osd["up4.conv.double_conv.4.weight"].detach(); bnb = osd["up4.conv.double_conv.4.bias"].detach()
+raw_o = out.detach()[:, c]
+mu, var = raw_o.mean(), raw_o.var(unbiased=False)
+act = ((raw_o - mu) / (var + 1e-5).sqrt() * bnw[c] + bnb[c])
+print("gamma", float(bnw[c]), "beta", float(bnb[c]), "frac active", float((act > 0).float().mean()), "min |act|", float(act.abs().min()), "var", float(var))
+top = err_c.topk(6)
+print("top err channels", top.indices.tolist(), [f"{v:.1e}" for v in top.values.tolist()], "gammas", [f"{float(bnw[i]):.3f}" for i in top.indices], "var", [f"{float(out.detach()[:, i].var()):.2e}" for i in top.indices])
