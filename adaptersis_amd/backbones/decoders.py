@@ -225,6 +225,27 @@ class FeatureDecoder(_Packed):
         return logits.permute(0, 3, 1, 2)
 
 
+class DecoderSETR(FeatureDecoder):
+    """`backbones/decoders.py:167-203`: the SETR-style progressive-upsampling head — the same four
+    conv3x3+BN+ReLU+bilinear x2 stages and final conv3x3 as ``FeatureDecoder`` (identical ``state_dict`` keys), fed by
+    ``in_channels`` instead of the 3*embed concat."""
+
+    def __init__(self, in_channels, out_channels, features=[512, 256, 128, 64]):
+        _Packed.__init__(self)
+        chans = [in_channels] + list(features)
+        for c in chans:
+            if c % 8:
+                raise ValueError("DecoderSETR channel counts must be multiples of 8")
+        self.in_channels, self.out_channels, self.features = in_channels, out_channels, list(features)
+        self.num_classes = out_channels
+        for i in range(4):
+            setattr(self, f"decoder_{i + 1}", nn.Sequential(
+                nn.Conv2d(chans[i], chans[i + 1], 3, padding=1), nn.BatchNorm2d(chans[i + 1]), nn.ReLU(inplace=True),
+                nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True)))
+        self.final_out = nn.Conv2d(chans[4], out_channels, 3, padding=1)
+        self.sync_bn = False
+
+
 class _MLAFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module, i0, i1, i2, i3, *params):

@@ -36,7 +36,8 @@ __device__ __forceinline__ int perm23(int r) {  // swap bits 2 and 3
 template <typename T>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, int64_t ldqk,
                                                        const T* __restrict__ vt, int64_t ldvt, T* __restrict__ o,
-                                                       int64_t ldo, int H, int N, float scale_log2e) {
+                                                       int64_t ldo, int H, int N, float scale_log2e,
+                                                       float* __restrict__ lse2) {
   typedef typename T16<T>::v8 v8;
   __shared__ __attribute__((aligned(16))) T lds[2 * 2 * KT * HD];  // [buf][K | Vt][64][64] = 32 KiB
 
@@ -196,6 +197,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* __restrict__ 
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.0f / l_tot;
   const int qi = q_base + fr;
+  // log2-domain log-sum-exp of the scaled scores, per query: what the backward needs to rebuild P = exp2(s*c - lse2)
+  if (lse2 && qi < N && fh == 0) lse2[((int64_t)b * H + head) * N + qi] = m_run + __builtin_amdgcn_logf(l_tot);
   if (qi < N) {
     T* op = o + ((int64_t)b * N + qi) * ldo + head * HD + 4 * fh;
 #pragma unroll
@@ -212,8 +215,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* __restrict__ 
 
 }  // namespace
 
-extern "C" int asis_attention_fwd(void* stream, int dtype, const void* q, const void* k, int64_t ldqk, const void* vt,
-                                  int64_t ldvt, void* o, int64_t ldo, int B, int H, int N, float scale) {
+extern "C" int asis_attention_fwd_lse(void* stream, int dtype, const void* q, const void* k, int64_t ldqk, const void* vt,
+                                      int64_t ldvt, void* o, int64_t ldo, int B, int H, int N, float scale, float* lse2) {
   ASIS_REQUIRE(q && k && vt && o, "asis_attention_fwd: null pointer");
   ASIS_REQUIRE(B > 0 && H > 0 && N > 0, "asis_attention_fwd: bad shape B=%d H=%d N=%d", B, H, N);
   ASIS_REQUIRE(B <= 65535 && H <= 65535, "asis_attention_fwd: B/H too large");
@@ -229,11 +232,16 @@ extern "C" int asis_attention_fwd(void* stream, int dtype, const void* q, const 
   if (dtype == ASIS_F16)
     hipLaunchKernelGGL((attn_fwd_kernel<f16>), grid, block, 0, s, reinterpret_cast<const f16*>(q),
                        reinterpret_cast<const f16*>(k), ldqk, reinterpret_cast<const f16*>(vt), ldvt,
-                       reinterpret_cast<f16*>(o), ldo, H, N, sl);
+                       reinterpret_cast<f16*>(o), ldo, H, N, sl, lse2);
   else
     hipLaunchKernelGGL((attn_fwd_kernel<bf16>), grid, block, 0, s, reinterpret_cast<const bf16*>(q),
                        reinterpret_cast<const bf16*>(k), ldqk, reinterpret_cast<const bf16*>(vt), ldvt,
-                       reinterpret_cast<bf16*>(o), ldo, H, N, sl);
+                       reinterpret_cast<bf16*>(o), ldo, H, N, sl, lse2);
   ASIS_CHECK_LAUNCH("asis_attention_fwd");
   return ASIS_OK;
+}
+
+extern "C" int asis_attention_fwd(void* stream, int dtype, const void* q, const void* k, int64_t ldqk, const void* vt,
+                                  int64_t ldvt, void* o, int64_t ldo, int B, int H, int N, float scale) {
+  return asis_attention_fwd_lse(stream, dtype, q, k, ldqk, vt, ldvt, o, ldo, B, H, N, scale, nullptr);
 }

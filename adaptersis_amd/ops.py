@@ -206,17 +206,61 @@ def layernorm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float = 1e
 
 
 def attention_fwd(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, B: int, H: int, N: int, scale: float,
-                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """q, k: [B*N, >=H*64] views (same row stride); vt: [B, H*64, ldvt]; returns o [B*N, H*64]."""
-    _dev(q, k, vt, out)
+                  out: Optional[torch.Tensor] = None, lse: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """q, k: [B*N, >=H*64] views (same row stride); vt: [B, H*64, ldvt]; returns o [B*N, H*64].
+    ``lse``: optional fp32 [B,H,N] receiving the per-query log2-sum-exp (training forward)."""
+    _dev(q, k, vt, out, lse)
     if q.stride(0) != k.stride(0) or q.stride(1) != 1 or k.stride(1) != 1:
         raise ValueError("attention_fwd: q and k must share a row stride and be contiguous in the last dim")
     if out is None:
         out = torch.empty((B * N, H * 64), device=q.device, dtype=q.dtype)
-    check(lib().asis_attention_fwd(_stream(), _dt(q.dtype), q.data_ptr(), k.data_ptr(), q.stride(0), vt.data_ptr(),
-                                   vt.stride(1), out.data_ptr(), out.stride(0), B, H, N, float(scale)),
+    if lse is not None and (lse.dtype != torch.float32 or lse.numel() != B * H * N or not lse.is_contiguous()):
+        raise ValueError("attention_fwd: lse must be contiguous float32 [B,H,N]")
+    check(lib().asis_attention_fwd_lse(_stream(), _dt(q.dtype), q.data_ptr(), k.data_ptr(), q.stride(0), vt.data_ptr(),
+                                       vt.stride(1), out.data_ptr(), out.stride(0), B, H, N, float(scale), _p(lse)),
           "asis_attention_fwd")
     return out
+
+
+def token_ld(N: int) -> int:
+    """row stride of the token-contiguous (transposed) attention operands: N rounded up to 64"""
+    return (N + 63) // 64 * 64
+
+
+def transpose_tokens(src: torch.Tensor, B: int, N: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """16-bit [B*N, C] view (row stride free) -> [B, C, token_ld(N)], tokens contiguous, zero padded."""
+    _dev(src, out)
+    Cc = src.shape[1]
+    if src.stride(1) != 1 or src.shape[0] != B * N:
+        raise ValueError("transpose_tokens: expected a [B*N, C] row view")
+    ldt = token_ld(N)
+    if out is None:
+        out = torch.empty((B, Cc, ldt), device=src.device, dtype=src.dtype)
+    check(lib().asis_transpose_tokens(_stream(), _dt(src.dtype), src.data_ptr(), src.stride(0), out.data_ptr(), ldt, B, N,
+                                      Cc), "asis_transpose_tokens")
+    return out
+
+
+def attention_bwd(q, k, v, qt, kt, dot, o, dO, lse, B: int, H: int, N: int, scale: float,
+                  dqkv: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """-> dqkv 16-bit [B*N, 3*H*64] = [dQ | dK | dV].  q, k, v: [B*N, H*64] views with one row stride; qt, kt, dot:
+    ``transpose_tokens`` of q, k, dO; o, dO: [B*N, H*64]; lse: fp32 [B,H,N] from the forward."""
+    _dev(q, k, v, qt, kt, dot, o, dO, lse, dqkv)
+    Wd = H * 64
+    if not (q.stride(0) == k.stride(0) == v.stride(0)) or q.stride(1) != 1:
+        raise ValueError("attention_bwd: q, k, v must share a row stride")
+    if not (qt.shape == kt.shape == dot.shape) or qt.shape[-1] != token_ld(N):
+        raise ValueError("attention_bwd: qt, kt, dot must be transpose_tokens images")
+    if dqkv is None:
+        dqkv = torch.empty((B * N, 3 * Wd), device=q.device, dtype=q.dtype)
+    D = torch.empty((B, H, N), device=q.device, dtype=torch.float32)
+    es = dqkv.element_size()
+    check(lib().asis_attention_bwd(_stream(), _dt(q.dtype), q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0),
+                                   qt.data_ptr(), kt.data_ptr(), dot.data_ptr(), qt.shape[-1], o.data_ptr(), o.stride(0),
+                                   dO.data_ptr(), dO.stride(0), lse.data_ptr(), D.data_ptr(), dqkv.data_ptr(),
+                                   dqkv.data_ptr() + Wd * es, dqkv.data_ptr() + 2 * Wd * es, dqkv.stride(0), B, H, N,
+                                   float(scale)), "asis_attention_bwd")
+    return dqkv
 
 
 def im2col_patch(img: torch.Tensor, P: int, ldk: int, dtype: torch.dtype = T16_DEFAULT) -> torch.Tensor:

@@ -207,6 +207,17 @@ def make_feature_decoder_state_dict(embed_dim=1024, num_classes=2, features=(102
     return sd
 
 
+def make_setr_state_dict(in_channels=1024, out_channels=2, features=(512, 256, 128, 64), seed=0):
+    """`backbones/decoders.py:167-196` (DecoderSETR: the FeatureDecoder layout fed by ``in_channels``)."""
+    sd = OrderedDict()
+    chans = [in_channels] + list(features)
+    for i in range(4):
+        _conv(sd, f"decoder_{i + 1}.0", chans[i + 1], chans[i], 3, seed, True)
+        _bn(sd, f"decoder_{i + 1}.1", chans[i + 1], seed)
+    _conv(sd, "final_out", out_channels, chans[4], 3, seed, True)
+    return sd
+
+
 def make_decoder_mla_state_dict(mla_channels=1024, mlahead_channels=128, num_classes=2, seed=0):
     """`backbones/decoders.py:7-80`."""
     sd = OrderedDict()

@@ -118,6 +118,24 @@ int asis_layernorm(void* stream, int dtype, const float* x, int64_t ldx, const f
  * ------------------------------------------------------------------------------------------- */
 int asis_attention_fwd(void* stream, int dtype, const void* q, const void* k, int64_t ldqk, const void* vt,
                        int64_t ldvt, void* o, int64_t ldo, int B, int H, int N, float scale);
+/* same, also writing lse2[B,H,N] = log2 sum_k exp2(log2(e) * scale * q.k) per query (what asis_attention_bwd
+ * needs to rebuild the probabilities); lse2 NULL = asis_attention_fwd */
+int asis_attention_fwd_lse(void* stream, int dtype, const void* q, const void* k, int64_t ldqk, const void* vt,
+                           int64_t ldvt, void* o, int64_t ldo, int B, int H, int N, float scale, float* lse2);
+/* 16-bit [B, N, ld] (first C columns) -> [B, C, ldt], token index contiguous, columns N..ldt-1 zero
+ * (the V^T / K^T / Q^T / dO^T operand layout of the attention kernels).  C % 64 == 0, ldt % 64 == 0, ldt >= N. */
+int asis_transpose_tokens(void* stream, int dtype, const void* src, int64_t ld, void* dst, int64_t ldt, int B, int N,
+                          int C);
+/* Backward of the fused attention (the autograd transpose of attention.py:60-66):
+ *   dV = P^T dO, dS = scale * P * (dO V^T - D), D = rowsum(dO * O), dQ = dS K, dK = dS^T Q,
+ * scores recomputed from q, k and lse2.  q, k, v: 16-bit [B*N, >= H*64] row-major, row stride ld; qt, kt, dot:
+ * their / dO's asis_transpose_tokens images (row stride ldt); o, dO: forward output and its gradient; D: fp32
+ * scratch [B,H,N] (written here); dq, dk, dv: 16-bit outputs, row stride lddq (e.g. the three column blocks of one
+ * [B*N, 3*H*64] buffer, ready for the qkv weight-gradient / input-gradient GEMMs). */
+int asis_attention_bwd(void* stream, int dtype, const void* q, const void* k, const void* v, int64_t ld, const void* qt,
+                       const void* kt, const void* dot, int64_t ldt, const void* o, int64_t ldo, const void* dO,
+                       int64_t lddo, const float* lse2, float* D, void* dq, void* dk, void* dv, int64_t lddq, int B,
+                       int H, int N, float scale);
 
 /* ---------------------------------------------------------------------------------------------
  * Patch-embed im2col (patch_embed.py:75: Conv2d k=s=P) : img fp32 NCHW [B,3,Himg,Wimg] ->

@@ -63,7 +63,7 @@ def import_reference():
     from dinov2.models import vision_transformer as vits
     from backbones.encoders import FeatureEncoder
     from backbones.adapter_blocks import CAViT, CACNN, deform_inputs
-    from backbones.decoders import FeatureDecoder, DecoderMLA
+    from backbones.decoders import FeatureDecoder, DecoderMLA, DecoderSETR
     from backbones.unet_parts import UNet
     from backbones.ops.modules.ms_deform_attn import ms_deform_attn_core_pytorch
     from segloss.dice import DC
@@ -74,7 +74,7 @@ def import_reference():
     import numpy as _np
     _im.np = _np  # work-around: the reference module uses np.mean without importing numpy (iou_multi.py:1-2,65,88)
     return dict(vits=vits, FeatureEncoder=FeatureEncoder, CAViT=CAViT, CACNN=CACNN, deform_inputs=deform_inputs,
-                FeatureDecoder=FeatureDecoder, DecoderMLA=DecoderMLA, UNet=UNet,
+                FeatureDecoder=FeatureDecoder, DecoderMLA=DecoderMLA, DecoderSETR=DecoderSETR, UNet=UNet,
                 msda_core=ms_deform_attn_core_pytorch, DC=DC, SoftDiceLoss=SoftDiceLoss,
                 DC_and_CE_loss=DC_and_CE_loss, CrossentropyND=CrossentropyND, iou_loss=iou_loss,
                 TverskyLoss=TverskyLoss, ch_iou=ch_iou, isi_iou=isi_iou)
@@ -297,6 +297,37 @@ def loss_case(R, out):
     close(O.iou_loss(lg11, tg11, num_classes=C11), out["loss.iou11"], 1e-6, "iou_loss(11)")
 
 
+def setr_case(R, out):
+    """`backbones/decoders.py:167-203` DecoderSETR forward + CE/DC step gradients (oracle: the FeatureDecoder restatement,
+    whose layer structure and state_dict keys are the same)."""
+    import torch.nn.functional as F
+    B, Cin, hw, HW = 2, 64, 6, 84
+    feats = [32, 16, 16, 8]
+    sd = W.make_setr_state_dict(Cin, 3, feats)
+    m = R["DecoderSETR"](Cin, 3, features=feats)
+    m.load_state_dict(sd, strict=True)
+    m.train()
+    x = W.tensor("setr.x", (B, Cin, hw, hw), 1.0)
+    tg = W.synthetic_batch(B, HW, 3)[1]
+    oh = O.one_hot(tg, 3)
+    y = m(x)
+    o = F.interpolate(y, size=(HW, HW), mode="bilinear")
+    loss = torch.nn.CrossEntropyLoss()(o, tg) + R["DC"](3)(o, oh)
+    loss.backward()
+    osd = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sd.items()}
+    oy = O.feature_decoder(x, osd, update_bn=True)
+    oo = F.interpolate(oy, size=(HW, HW), mode="bilinear")
+    oloss = O.cross_entropy_nd(oo, tg) + O.dc_loss(oo, oh)
+    oloss.backward()
+    close(oy.detach(), y.detach(), 2e-5, "DecoderSETR logits")
+    close(oloss.detach(), loss.detach(), 1e-5, "DecoderSETR loss")
+    out["setr.logits"] = sub(y)
+    out["setr.loss"] = loss.detach().clone()
+    for k, p in m.named_parameters():
+        close(osd[k].grad, p.grad, 1e-3, f"grad {k}")
+        out[f"setr.grad.{k}"] = p.grad.clone()
+
+
 def loss2_case(R, out):
     """Every loss the scripts can select, at a resized geometry (logits 20x20 -> target 28x28, as the decoders'
     outputs are resized to the label size), with gradients wrt the low-resolution logits; plus ch_iou / isi_iou."""
@@ -516,6 +547,10 @@ def main():
         print("[decoder D=32 hw=6 B=2]"); decoder_case(R, out, 32, 6, 2, "dec_small")
         print("[MLA / UNet]"); mla_unet_case(R, out)
         save("small", out)
+    if want("setr"):
+        out = {}
+        print("[DecoderSETR step]"); setr_case(R, out)
+        save("setr", out)
     if want("unet"):
         out = {}
         print("[UNet(384) decoder step with gradients]"); unet_step_case(R, out)

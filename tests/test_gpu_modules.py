@@ -118,3 +118,26 @@ def test_dc_module_matches_oracle(dev):
     assert abs(float(out) - float(g["loss.dc"])) < 2e-6
     out2 = DC(C)(lg.to(dev), tg.unsqueeze(1).to(dev))
     assert abs(float(out2) - float(g["loss.dc"])) < 2e-6
+
+
+def test_decoder_setr_vs_reference_golden(dev):
+    """DecoderSETR (`decoders.py:167-203`) forward + CE/DC backward against the golden of the imported reference."""
+    from adaptersis_amd.backbones.decoders import DecoderSETR
+    from adaptersis_amd.segloss.dice import seg_loss
+    from adaptersis_amd import ops
+    g = load_golden("setr")
+    B, Cin, hw, HW = 2, 64, 6, 84
+    feats = [32, 16, 16, 8]
+    m = DecoderSETR(Cin, 3, features=feats).to(dev)
+    m.load_state_dict(W.make_setr_state_dict(Cin, 3, feats), strict=True)
+    m.train()
+    x = W.tensor("setr.x", (B, Cin, hw, hw), 1.0).to(dev)
+    tg = W.synthetic_batch(B, HW, 3)[1].to(dev)
+    y = m(x)
+    assert golden_err(y, g["setr.logits"]) < 1e-3
+    loss = seg_loss(y, tg, 1, ops.LOSS_DICE, 10e-20, n_ce=1)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g["setr.loss"])) < 1e-4
+    errs = {k: rel_l2(p.grad, g[f"setr.grad.{k}"]) for k, p in m.named_parameters()}
+    print("SETR grads:", {k: f"{v:.1e}" for k, v in errs.items()})
+    assert max(errs.values()) < 3e-2, errs  # ReLU-flip floor on small maps, see tests/test_gpu_unet.py

@@ -244,3 +244,23 @@ def test_unet_decoder_step():
             assert golden_err(v.grad, g[f"unet_step.grad.{k}"]) < 1e-4, k
         elif "running" in k:
             assert rel_l2(v, g[f"unet_step.buf.{k}"]) < 1e-5, k
+
+
+def test_decoder_setr_step():
+    """`decoders.py:167-203` DecoderSETR == the FeatureDecoder restatement on its own state_dict (tests/golden/setr.pt)."""
+    g = load_golden("setr")
+    B, Cin, hw, HW = 2, 64, 6, 84
+    sd = W.make_setr_state_dict(Cin, 3, [32, 16, 16, 8])
+    x = W.tensor("setr.x", (B, Cin, hw, hw), 1.0)
+    tg = W.synthetic_batch(B, HW, 3)[1]
+    oh = O.one_hot(tg, 3)
+    osd = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sd.items()}
+    oy = O.feature_decoder(x, osd)
+    oo = F.interpolate(oy, size=(HW, HW), mode="bilinear")
+    loss = O.cross_entropy_nd(oo, tg) + O.dc_loss(oo, oh)
+    loss.backward()
+    assert golden_err(oy, g["setr.logits"]) < 1e-5
+    assert abs(float(loss) - float(g["setr.loss"])) < 1e-6
+    for k, v in osd.items():
+        if v.requires_grad:
+            assert rel_l2(v.grad, g[f"setr.grad.{k}"]) < 1e-3, k
