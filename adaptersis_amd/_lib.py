@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libasis_hip.so")
 
-ASIS_F16, ASIS_BF16 = 0, 1
+ASIS_F16, ASIS_BF16, ASIS_F32 = 0, 1, 2
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 
 
@@ -77,6 +77,11 @@ SIGNATURES = {
     "asis_transpose_tokens": [_vp, _i, _vp, _i64, _vp, _i64, _i, _i, _i],
     "asis_attention_bwd": [_vp, _i, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp,
                            _i64, _i, _i, _i, _f],
+    "asis_rowblock_nblk": [_i64],
+    "asis_layernorm_bwd": [_vp, _vp, _i64, _vp, _i64, _vp, _f, _vp, _i64, _vp, _i64, _vp, _i64, _i],
+    "asis_gelu16": [_vp, _i, _vp, _vp, _vp, _i64],
+    "asis_colsum": [_vp, _i, _vp, _i64, _vp, _i64, _i],
+    "asis_ls_linear_finish": [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _i],
     "asis_attention_fwd": [_vp, _i, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _i, _f],
     "asis_im2col_patch": [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i64],
     "asis_cast_pad": [_vp, _i, _vp, _i64, _vp, _i64, _i64, _i, _f, _i],

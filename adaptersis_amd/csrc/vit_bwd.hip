@@ -1,0 +1,290 @@
+// Row / elementwise backward kernels of the DINOv2 block (dinov2/layers/block.py:89-114), all HBM-bound streaming:
+//   LayerNorm backward            nn.LayerNorm(eps=1e-6), block.py:63,75
+//   GELU (erf) forward / backward on 16-bit operands (mlp.py:35) — the training forward keeps the pre-activation
+//   column sums of a 16-bit matrix (bias gradients of qkv / fc1)
+//   LayerScale + Linear finish    out = x + gamma * (A W^T + b): from G = dout^T A (unscaled wgrad GEMM) and
+//                                 cs = colsum(dout):  dW = gamma G,  db = gamma cs,  dgamma = rowsum(W * G) + b cs
+// One wave64 per row for the row kernels, 16-byte accesses, fp32 arithmetic.
+#include "asis_common.h"
+
+namespace {
+
+constexpr int LN_MAXC = 8;  // float4 chunks per lane -> D <= 2048
+
+inline int grid_for(int64_t total, int cap = 65535 * 4) {
+  int64_t g = (total + 255) / 256;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+// dx[row] = (res ? res[row] : 0) + rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * w
+// partial[blk][0][c] = sum_rows dy * xhat (d weight),  partial[blk][1][c] = sum_rows dy (d bias)
+// Each block owns ROWS_PER_BLOCK consecutive rows, 4 waves striding over them; statistics are recomputed from x.
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, int64_t lddy,
+                                                            const float* __restrict__ x, int64_t ldx,
+                                                            const float* __restrict__ w, float eps,
+                                                            const float* __restrict__ res, int64_t ldr,
+                                                            float* __restrict__ dx, int64_t lddx,
+                                                            float* __restrict__ partial, int64_t rows, int D,
+                                                            int rows_per_block) {
+  __shared__ float red[3][2][LN_MAXC * 64 * 4];  // waves 1..3 park their column sums here
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int nchunk = D >> 2;
+  const float4* w4 = reinterpret_cast<const float4*>(w);
+  float4 gw[LN_MAXC], gb[LN_MAXC], ww[LN_MAXC];
+#pragma unroll
+  for (int i = 0; i < LN_MAXC; ++i) {
+    gw[i] = gb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int c = lane + 64 * i;
+    ww[i] = c < nchunk ? w4[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  int64_t r1 = r0 + rows_per_block;
+  if (r1 > rows) r1 = rows;
+  const float invD = 1.0f / (float)D;
+  for (int64_t row = r0 + wid; row < r1; row += 4) {
+    const float4* xr = reinterpret_cast<const float4*>(x + row * ldx);
+    const float4* gr = reinterpret_cast<const float4*>(dy + row * lddy);
+    float4 v[LN_MAXC], g[LN_MAXC];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nchunk) {
+        v[i] = xr[c];
+        g[i] = gr[c];
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+      }
+    }
+    const float mean = wave_sum(s) * invD;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nchunk) {
+        v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+        q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+      }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) * invD + eps);
+    float a = 0.f, bq = 0.f;  // sum g, sum g*xhat
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nchunk) {
+        v[i].x *= rstd; v[i].y *= rstd; v[i].z *= rstd; v[i].w *= rstd;  // xhat
+        gw[i].x += g[i].x * v[i].x; gw[i].y += g[i].y * v[i].y; gw[i].z += g[i].z * v[i].z; gw[i].w += g[i].w * v[i].w;
+        gb[i].x += g[i].x; gb[i].y += g[i].y; gb[i].z += g[i].z; gb[i].w += g[i].w;
+        g[i].x *= ww[i].x; g[i].y *= ww[i].y; g[i].z *= ww[i].z; g[i].w *= ww[i].w;
+        a += (g[i].x + g[i].y) + (g[i].z + g[i].w);
+        bq += (g[i].x * v[i].x + g[i].y * v[i].y) + (g[i].z * v[i].z + g[i].w * v[i].w);
+      }
+    }
+    a = wave_sum(a) * invD;
+    bq = wave_sum(bq) * invD;
+    float4* o = reinterpret_cast<float4*>(dx + row * lddx);
+    const float4* rr = res ? reinterpret_cast<const float4*>(res + row * ldr) : nullptr;
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nchunk) {
+        float4 t;
+        t.x = rstd * (g[i].x - a - v[i].x * bq);
+        t.y = rstd * (g[i].y - a - v[i].y * bq);
+        t.z = rstd * (g[i].z - a - v[i].z * bq);
+        t.w = rstd * (g[i].w - a - v[i].w * bq);
+        if (rr) {
+          const float4 e = rr[c];
+          t.x += e.x; t.y += e.y; t.z += e.z; t.w += e.w;
+        }
+        o[c] = t;
+      }
+    }
+  }
+  // column sums over the block's rows: waves 1..3 -> LDS -> wave 0 adds and writes
+  if (wid > 0) {
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+      reinterpret_cast<float4*>(red[wid - 1][0])[i * 64 + lane] = gw[i];
+      reinterpret_cast<float4*>(red[wid - 1][1])[i * 64 + lane] = gb[i];
+    }
+  }
+  __syncthreads();
+  if (wid == 0) {
+    float4* pw = reinterpret_cast<float4*>(partial + ((int64_t)blockIdx.x * 2 + 0) * D);
+    float4* pb = reinterpret_cast<float4*>(partial + ((int64_t)blockIdx.x * 2 + 1) * D);
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nchunk) {
+        float4 sw = gw[i], sb = gb[i];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const float4 t = reinterpret_cast<const float4*>(red[k][0])[i * 64 + lane];
+          const float4 u = reinterpret_cast<const float4*>(red[k][1])[i * 64 + lane];
+          sw.x += t.x; sw.y += t.y; sw.z += t.z; sw.w += t.w;
+          sb.x += u.x; sb.y += u.y; sb.z += u.z; sb.w += u.w;
+        }
+        pw[c] = sw;
+        pb[c] = sb;
+      }
+    }
+  }
+}
+
+// exact (libm erff) derivative is used in the backward: one pass, not in a GEMM epilogue
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void gelu16_kernel(const T* __restrict__ pre, const T* __restrict__ dpost, T* __restrict__ out,
+                                                     int64_t n8) {
+  typedef typename T16<T>::v8 v8;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+    const v8 p = reinterpret_cast<const v8*>(pre)[i];
+    v8 o;
+    if (BWD) {
+      const v8 g = reinterpret_cast<const v8*>(dpost)[i];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] = (T)((float)g[k] * gelu_erf_grad((float)p[k]));
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] = (T)gelu_erf((float)p[k]);
+    }
+    reinterpret_cast<v8*>(out)[i] = o;
+  }
+}
+
+// partial[blk][c] = sum over the block's rows of x[r, c] (16-bit input, fp32 sums); threads run along columns (8 per thread)
+template <typename T>
+__global__ __launch_bounds__(256) void colsum16_kernel(const T* __restrict__ x, int64_t ld, float* __restrict__ partial,
+                                                       int64_t rows, int C, int rows_per_block) {
+  typedef typename T16<T>::v8 v8;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  int64_t r1 = r0 + rows_per_block;
+  if (r1 > rows) r1 = rows;
+  for (int c8 = threadIdx.x; c8 < (C >> 3); c8 += blockDim.x) {
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int64_t r = r0; r < r1; ++r) {
+      const v8 v = *reinterpret_cast<const v8*>(x + r * ld + c8 * 8);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s[k] += (float)v[k];
+    }
+    float4* o = reinterpret_cast<float4*>(partial + (int64_t)blockIdx.x * C + c8 * 8);
+    o[0] = make_float4(s[0], s[1], s[2], s[3]);
+    o[1] = make_float4(s[4], s[5], s[6], s[7]);
+  }
+}
+
+// fp32 variant (column sums of the residual-stream gradient)
+__global__ __launch_bounds__(256) void colsum32_kernel(const float* __restrict__ x, int64_t ld, float* __restrict__ partial,
+                                                       int64_t rows, int C, int rows_per_block) {
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  int64_t r1 = r0 + rows_per_block;
+  if (r1 > rows) r1 = rows;
+  for (int c4 = threadIdx.x; c4 < (C >> 2); c4 += blockDim.x) {
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t r = r0; r < r1; ++r) {
+      const float4 v = *reinterpret_cast<const float4*>(x + r * ld + c4 * 4);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    *reinterpret_cast<float4*>(partial + (int64_t)blockIdx.x * C + c4 * 4) = s;
+  }
+}
+
+// one wave per output feature n: dW[n,:] = gs * gamma[n] * G[n,:];  dgamma[n] = gs * (sum_k W[n,k] G[n,k] + b[n] cs[n]);
+// db[n] = gs * gamma[n] * cs[n]     (gs = 1 / loss scale; gamma NULL = plain Linear: dW = gs G, db = gs cs)
+__global__ __launch_bounds__(256) void ls_linear_finish_kernel(const float* __restrict__ G, const float* __restrict__ Wt,
+                                                               const float* __restrict__ bias, const float* __restrict__ gamma,
+                                                               const float* __restrict__ cs, float gs, float* __restrict__ dW,
+                                                               float* __restrict__ db, float* __restrict__ dgamma, int N,
+                                                               int K) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const float ga = gamma ? gamma[n] : 1.f;
+  const float4* g4 = reinterpret_cast<const float4*>(G + (int64_t)n * K);
+  const float4* w4 = reinterpret_cast<const float4*>(Wt + (int64_t)n * K);
+  float4* o4 = reinterpret_cast<float4*>(dW + (int64_t)n * K);
+  float dot = 0.f;
+  const float sc = gs * ga;
+  for (int c = lane; c < (K >> 2); c += 64) {
+    const float4 g = g4[c];
+    if (gamma) {
+      const float4 w = w4[c];
+      dot += (g.x * w.x + g.y * w.y) + (g.z * w.z + g.w * w.w);
+    }
+    o4[c] = make_float4(g.x * sc, g.y * sc, g.z * sc, g.w * sc);
+  }
+  if (gamma) dot = wave_sum(dot);
+  if (lane == 0) {
+    const float c = cs ? cs[n] : 0.f;
+    if (db) db[n] = sc * c;
+    if (gamma && dgamma) dgamma[n] = gs * (dot + (bias ? bias[n] : 0.f) * c);
+  }
+}
+
+}  // namespace
+
+#define DT_OK(dtype, name) ASIS_REQUIRE(dtype == ASIS_F16 || dtype == ASIS_BF16, name ": bad dtype %d", dtype)
+
+extern "C" int asis_rowblock_nblk(int64_t rows) {
+  int64_t n = (rows + 31) / 32;
+  if (n > 2048) n = 2048;
+  if (n < 1) n = 1;
+  return (int)n;
+}
+
+extern "C" int asis_layernorm_bwd(void* stream, const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* w,
+                                  float eps, const float* res, int64_t ldr, float* dx, int64_t lddx, float* partial,
+                                  int64_t rows, int D) {
+  ASIS_REQUIRE(dy && x && w && dx && partial, "asis_layernorm_bwd: null pointer");
+  ASIS_REQUIRE(D > 0 && D % 4 == 0 && D <= LN_MAXC * 256, "asis_layernorm_bwd: D=%d must be a multiple of 4, <= %d", D, LN_MAXC * 256);
+  ASIS_REQUIRE(lddy % 4 == 0 && ldx % 4 == 0 && lddx % 4 == 0 && (!res || ldr % 4 == 0), "asis_layernorm_bwd: row strides must be multiples of 4");
+  ASIS_REQUIRE(rows > 0, "asis_layernorm_bwd: no rows");
+  const int nblk = asis_rowblock_nblk(rows);
+  const int rpb = (int)((rows + nblk - 1) / nblk);
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nblk), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dy, lddy, x, ldx, w,
+                     eps, res, ldr, dx, lddx, partial, rows, D, rpb);
+  ASIS_CHECK_LAUNCH("asis_layernorm_bwd");
+  return ASIS_OK;
+}
+
+extern "C" int asis_gelu16(void* stream, int dtype, const void* pre, const void* dpost, void* out, int64_t n) {
+  ASIS_REQUIRE(pre && out && n > 0 && n % 8 == 0, "asis_gelu16: bad arguments (n %% 8 == 0)");
+  DT_OK(dtype, "asis_gelu16");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int64_t n8 = n / 8;
+  const int g = grid_for(n8);
+  if (dtype == ASIS_F16) {
+    if (dpost) hipLaunchKernelGGL((gelu16_kernel<f16, true>), dim3(g), dim3(256), 0, s, (const f16*)pre, (const f16*)dpost, (f16*)out, n8);
+    else hipLaunchKernelGGL((gelu16_kernel<f16, false>), dim3(g), dim3(256), 0, s, (const f16*)pre, (const f16*)nullptr, (f16*)out, n8);
+  } else {
+    if (dpost) hipLaunchKernelGGL((gelu16_kernel<bf16, true>), dim3(g), dim3(256), 0, s, (const bf16*)pre, (const bf16*)dpost, (bf16*)out, n8);
+    else hipLaunchKernelGGL((gelu16_kernel<bf16, false>), dim3(g), dim3(256), 0, s, (const bf16*)pre, (const bf16*)nullptr, (bf16*)out, n8);
+  }
+  ASIS_CHECK_LAUNCH("asis_gelu16");
+  return ASIS_OK;
+}
+
+extern "C" int asis_colsum(void* stream, int dtype, const void* x, int64_t ld, float* partial, int64_t rows, int C) {
+  ASIS_REQUIRE(x && partial && rows > 0, "asis_colsum: bad arguments");
+  ASIS_REQUIRE(dtype == ASIS_F16 || dtype == ASIS_BF16 || dtype == ASIS_F32, "asis_colsum: bad dtype %d", dtype);
+  ASIS_REQUIRE(C > 0 && C % 8 == 0 && ld % 8 == 0 && ld >= C, "asis_colsum: C=%d and ld must be multiples of 8", C);
+  const int nblk = asis_rowblock_nblk(rows);
+  const int rpb = (int)((rows + nblk - 1) / nblk);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == ASIS_F16) hipLaunchKernelGGL((colsum16_kernel<f16>), dim3(nblk), dim3(256), 0, s, (const f16*)x, ld, partial, rows, C, rpb);
+  else if (dtype == ASIS_BF16) hipLaunchKernelGGL((colsum16_kernel<bf16>), dim3(nblk), dim3(256), 0, s, (const bf16*)x, ld, partial, rows, C, rpb);
+  else hipLaunchKernelGGL(colsum32_kernel, dim3(nblk), dim3(256), 0, s, (const float*)x, ld, partial, rows, C, rpb);
+  ASIS_CHECK_LAUNCH("asis_colsum");
+  return ASIS_OK;
+}
+
+extern "C" int asis_ls_linear_finish(void* stream, const float* G, const float* W, const float* bias, const float* gamma,
+                                     const float* cs, float grad_scale, float* dW, float* db, float* dgamma, int N, int K) {
+  ASIS_REQUIRE(G && dW && N > 0 && K > 0 && K % 4 == 0, "asis_ls_linear_finish: bad arguments (K %% 4 == 0)");
+  ASIS_REQUIRE(!gamma || W, "asis_ls_linear_finish: gamma needs the weight");
+  hipLaunchKernelGGL(ls_linear_finish_kernel, dim3((N + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), G, W, bias,
+                     gamma, cs, grad_scale, dW, db, dgamma, N, K);
+  ASIS_CHECK_LAUNCH("asis_ls_linear_finish");
+  return ASIS_OK;
+}

@@ -211,6 +211,112 @@ class Block(_Packed):
         return x3.view(B, N, D)
 
 
+    # ---- training path (block.py:89-114 under autograd; BASELINE config 4 / north_star "forward/backward") ----------
+    def _pack2(self, key: str, w: torch.Tensor, gamma: Optional[torch.Tensor], fn):
+        """cache of a 16-bit operand derived from a weight and (optionally) a LayerScale vector"""
+        tag = tuple((t.data_ptr(), t._version, getattr(t, "_asis_gen", 0)) for t in (w, gamma) if t is not None) + \
+            (config.operand_dtype,)
+        hit = self._cache.get(key)
+        if hit is None or hit[0] != tag:
+            with torch.no_grad():
+                self._cache[key] = (tag, fn())
+        return self._cache[key][1]
+
+    def _wT16(self, key: str, w: torch.Tensor, gamma: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """B operand of an input-gradient GEMM: (diag(gamma) W)^T as 16-bit [in_features, out_features]"""
+        def make():
+            wf = w.detach().float()
+            if gamma is not None:
+                wf = wf * gamma.detach().float()[:, None]
+            return ops.cast_pad(wf.t().contiguous(), dtype=config.operand_dtype)
+        return self._pack2(key, w, gamma, make)
+
+    def forward_train(self, x: torch.Tensor):
+        """x fp32 (B, N, D) -> (out fp32 (B, N, D), saved activations for ``backward``).  Same arithmetic as
+        ``forward`` except that fc1 keeps its 16-bit pre-activation (GELU runs as its own pass) and q, k, v come from
+        one [3D] GEMM (V^T by a token transpose)."""
+        B, N, D = x.shape
+        dt = config.operand_dtype
+        x2 = x.reshape(B * N, D)
+        if x2.dtype != torch.float32 or not x2.is_contiguous():
+            x2 = x2.float().contiguous()
+        m = self.mlp
+        if not isinstance(m, Mlp):
+            raise NotImplementedError("the training path is built for the Mlp FFN (ViT-S/B/L); SwiGLU (ViT-g) is forward-only")
+        g1 = self._f32("g1", self.ls1.gamma) if isinstance(self.ls1, LayerScale) else None
+        g2 = self._f32("g2", self.ls2.gamma) if isinstance(self.ls2, LayerScale) else None
+        a = self.attn
+        xn = ops.layernorm(x2, self._f32("n1w", self.norm1.weight), self._f32("n1b", self.norm1.bias), self.norm1.eps, dt)
+        qkv = ops.gemm(xn, a._w16("qkv", a.qkv.weight), bias_n=a._f32("qkv_b", a.qkv.bias))
+        vt = ops.transpose_tokens(qkv[:, 2 * D:], B, N)
+        lse = torch.empty((B, a.num_heads, N), device=x2.device, dtype=torch.float32)
+        o = ops.attention_fwd(qkv[:, :D], qkv[:, D:2 * D], vt, B, a.num_heads, N, a.scale, lse=lse)
+        x1 = ops.gemm(o, a._w16("proj", a.proj.weight), out_f32=True, bias_n=a._f32("proj_b", a.proj.bias), scale_n=g1,
+                      res=x2)
+        xn2 = ops.layernorm(x1, self._f32("n2w", self.norm2.weight), self._f32("n2b", self.norm2.bias), self.norm2.eps, dt)
+        hpre = ops.gemm(xn2, m._w16("fc1", m.fc1.weight), bias_n=m._f32("fc1_b", m.fc1.bias))
+        hpost = ops.gelu16(hpre)
+        x3 = ops.gemm(hpost, m._w16("fc2", m.fc2.weight), out_f32=True, bias_n=m._f32("fc2_b", m.fc2.bias), scale_n=g2,
+                      res=x1)
+        return x3.view(B, N, D), (x2, xn, qkv, o, lse, x1, xn2, hpre, hpost, B, N)
+
+    def _linear_bwd(self, prefix: str, lin: nn.Linear, gamma: Optional[nn.Parameter], gname: Optional[str], dy16, dy_cs,
+                    a16, inv_scale: float, grads: Optional[dict]):
+        """parameter gradients of ``gamma * (A W^T + b)`` (gamma None: plain Linear) into ``grads`` (fp32, unscaled)."""
+        if grads is None:
+            return
+        N, K = lin.weight.shape
+        R = a16.shape[0]
+        G = ops.wgrad(dy16.view(1, R, 1, N), a16.view(1, R, 1, K), N, 1, 1, 1, 0, 1.0).view(N, K)
+        cs = ops.reduce_rows(dy_cs)
+        ops.ls_linear_finish(G, lin.weight.detach() if gamma is not None else None,
+                             lin.bias.detach() if lin.bias is not None else None,
+                             gamma.detach() if gamma is not None else None, cs, inv_scale, grads[prefix + ".weight"],
+                             grads.get(prefix + ".bias") if lin.bias is not None else None,
+                             grads[gname] if gamma is not None else None)
+
+    def backward(self, saved, dres: torch.Tensor, inv_scale: float, grads: Optional[dict] = None, prefix: str = "") -> torch.Tensor:
+        """dres fp32 [B*N, D] = loss_scale * dL/d(block output) -> loss_scale * dL/d(block input).  With ``grads``
+        (name -> fp32 tensor, names as in ``state_dict`` under ``prefix``) the parameter gradients are written too;
+        without it only the input gradient is produced (frozen backbone, adapters training)."""
+        x2, xn, qkv, o, lse, x1, xn2, hpre, hpost, B, N = saved
+        dt = config.operand_dtype
+        D = x2.shape[1]
+        a, m = self.attn, self.mlp
+        ls1 = self.ls1.gamma if isinstance(self.ls1, LayerScale) else None
+        ls2 = self.ls2.gamma if isinstance(self.ls2, LayerScale) else None
+        pre = prefix + "." if prefix else ""
+        # ---- MLP branch: out = x1 + ls2 * fc2(gelu(fc1(LN2(x1)))) ----
+        d16 = ops.cast_pad(dres, D, dt)
+        self._linear_bwd(pre + "mlp.fc2", m.fc2, ls2, pre + "ls2.gamma", d16, ops.colsum(dres) if grads is not None else None,
+                         hpost, inv_scale, grads)
+        dh = ops.gemm(d16, self._wT16("fc2T", m.fc2.weight, ls2))                  # 16-bit [R, 4D]
+        dh = ops.gelu16(hpre, dh)
+        self._linear_bwd(pre + "mlp.fc1", m.fc1, None, None, dh, ops.colsum(dh) if grads is not None else None, xn2,
+                         inv_scale, grads)
+        dln = ops.gemm(dh, self._wT16("fc1T", m.fc1.weight), out_f32=True)         # fp32 [R, D]
+        dx1, part = ops.layernorm_bwd(dln, x1, self._f32("n2w", self.norm2.weight), self.norm2.eps, res=dres)
+        if grads is not None:
+            red = ops.reduce_rows(part.view(part.shape[0], 2 * D), inv_scale)
+            grads[pre + "norm2.weight"].copy_(red[:D]); grads[pre + "norm2.bias"].copy_(red[D:])
+        # ---- attention branch: x1 = x + ls1 * proj(attn(LN1(x))) ----
+        d16 = ops.cast_pad(dx1, D, dt)
+        self._linear_bwd(pre + "attn.proj", a.proj, ls1, pre + "ls1.gamma", d16, ops.colsum(dx1) if grads is not None else None,
+                         o, inv_scale, grads)
+        dO = ops.gemm(d16, self._wT16("projT", a.proj.weight, ls1))                # 16-bit [R, D]
+        q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+        dqkv = ops.attention_bwd(q, k, v, ops.transpose_tokens(q, B, N), ops.transpose_tokens(k, B, N),
+                                 ops.transpose_tokens(dO, B, N), o, dO, lse, B, a.num_heads, N, a.scale)
+        self._linear_bwd(pre + "attn.qkv", a.qkv, None, None, dqkv, ops.colsum(dqkv) if grads is not None else None, xn,
+                         inv_scale, grads)
+        dln = ops.gemm(dqkv, self._wT16("qkvT", a.qkv.weight), out_f32=True)
+        dx, part = ops.layernorm_bwd(dln, x2, self._f32("n1w", self.norm1.weight), self.norm1.eps, res=dx1)
+        if grads is not None:
+            red = ops.reduce_rows(part.view(part.shape[0], 2 * D), inv_scale)
+            grads[pre + "norm1.weight"].copy_(red[:D]); grads[pre + "norm1.bias"].copy_(red[D:])
+        return dx
+
+
 class NestedTensorBlock(Block):
     """`block.py:165-254`: list (nested-tensor) inputs need xformers in the reference; tensors only here."""
 

@@ -263,6 +263,56 @@ def attention_bwd(q, k, v, qt, kt, dot, o, dO, lse, B: int, H: int, N: int, scal
     return dqkv
 
 
+def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, w: torch.Tensor, eps: float = 1e-6,
+                  res: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
+    """fp32 [R, D] row views -> (dx = res + LN^T(dy), partial fp32 [nblk, 2, D] = (d weight, d bias) sums)."""
+    _dev(dy, x, w, res, out)
+    R, D = x.shape
+    for t in (dy, x, res, out):
+        if t is not None and (t.dtype != torch.float32 or t.stride(-1) != 1 or t.shape != x.shape):
+            raise ValueError("layernorm_bwd: float32 [R, D] row views of one shape expected")
+    if out is None:
+        out = torch.empty((R, D), device=x.device, dtype=torch.float32)
+    nblk = lib().asis_rowblock_nblk(R)
+    partial = torch.empty((nblk, 2, D), device=x.device, dtype=torch.float32)
+    check(lib().asis_layernorm_bwd(_stream(), dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), _f32c(w).data_ptr(),
+                                   float(eps), _p(res), res.stride(0) if res is not None else 0, out.data_ptr(),
+                                   out.stride(0), partial.data_ptr(), R, D), "asis_layernorm_bwd")
+    return out, partial
+
+
+def gelu16(pre: torch.Tensor, dpost: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """16-bit contiguous: gelu(pre), or with dpost the backward dpost * gelu'(pre)."""
+    _dev(pre, dpost)
+    if not pre.is_contiguous() or (dpost is not None and (not dpost.is_contiguous() or dpost.shape != pre.shape)):
+        raise ValueError("gelu16: contiguous operands of one shape expected")
+    out = torch.empty_like(pre)
+    check(lib().asis_gelu16(_stream(), _dt(pre.dtype), pre.data_ptr(), _p(dpost), out.data_ptr(), pre.numel()), "asis_gelu16")
+    return out
+
+
+def colsum(x: torch.Tensor) -> torch.Tensor:
+    """[R, C] row view (16-bit or float32) -> partial fp32 [nblk, C] column sums (finish with reduce_rows)."""
+    _dev(x)
+    R, Cc = x.shape
+    if x.stride(1) != 1:
+        raise ValueError("colsum: rows must be contiguous")
+    dt = _lib.ASIS_F32 if x.dtype == torch.float32 else _dt(x.dtype)
+    partial = torch.empty((lib().asis_rowblock_nblk(R), Cc), device=x.device, dtype=torch.float32)
+    check(lib().asis_colsum(_stream(), dt, x.data_ptr(), x.stride(0), partial.data_ptr(), R, Cc), "asis_colsum")
+    return partial
+
+
+def ls_linear_finish(G: torch.Tensor, W: Optional[torch.Tensor], bias, gamma, cs, grad_scale: float, dW: torch.Tensor,
+                     db: Optional[torch.Tensor], dgamma: Optional[torch.Tensor]) -> None:
+    """See include/asis_hip.h: (G, cs) -> dW, db, dgamma of ``x + gamma * (A W^T + b)`` (gamma None: plain Linear)."""
+    _dev(G, W, bias, gamma, cs, dW, db, dgamma)
+    N, K = G.shape
+    check(lib().asis_ls_linear_finish(_stream(), _f32c(G).data_ptr(), _p(_f32c(W)), _p(_f32c(bias)), _p(_f32c(gamma)),
+                                      _p(_f32c(cs)), float(grad_scale), _f32c(dW).data_ptr(), _p(db), _p(dgamma), N, K),
+          "asis_ls_linear_finish")
+
+
 def im2col_patch(img: torch.Tensor, P: int, ldk: int, dtype: torch.dtype = T16_DEFAULT) -> torch.Tensor:
     _dev(img)
     if img.dtype != torch.float32 or not img.is_contiguous() or img.dim() != 4 or img.shape[1] != 3:

@@ -159,6 +159,26 @@ int asis_add_cls_pos(void* stream, const float* x, const float* cls, const float
                      int D);
 
 /* ---------------------------------------------------------------------------------------------
+ * Row / elementwise backward kernels of the DINOv2 block (dinov2/layers/block.py:89-114).
+ * asis_rowblock_nblk(rows): rows of partial sums the row kernels below write.
+ * LayerNorm backward (nn.LayerNorm, eps inside sqrt, biased variance — statistics recomputed from x):
+ *   dx[r] = (res ? res[r] : 0) + rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * w      (fp32, D <= 2048, D % 4 == 0)
+ *   partial[nblk][2][D]: [0] = sum_r dy * xhat (d weight), [1] = sum_r dy (d bias); sum with asis_reduce_rows.
+ * asis_gelu16: erf-GELU on 16-bit operands (mlp.py:35): dpost NULL -> out = gelu(pre); else out = dpost * gelu'(pre).
+ * asis_colsum: partial[nblk][C] column sums of a 16-bit or fp32 (dtype ASIS_F32) [rows, C] matrix (bias gradients).
+ * asis_ls_linear_finish: for out = x + gamma * (A W^T + b) (LayerScale o Linear, block.py:112-113) given
+ *   G = dout^T A (asis_wgrad of the UNSCALED dout, fp32 [N,K]) and cs = colsum(dout):
+ *   dW = gs*gamma*G, db = gs*gamma*cs, dgamma = gs*(rowsum(W*G) + b*cs); gamma NULL: dW = gs*G, db = gs*cs.
+ * ------------------------------------------------------------------------------------------- */
+int asis_rowblock_nblk(int64_t rows);
+int asis_layernorm_bwd(void* stream, const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* w, float eps,
+                       const float* res, int64_t ldr, float* dx, int64_t lddx, float* partial, int64_t rows, int D);
+int asis_gelu16(void* stream, int dtype, const void* pre, const void* dpost, void* out, int64_t n);
+int asis_colsum(void* stream, int dtype, const void* x, int64_t ld, float* partial, int64_t rows, int C);
+int asis_ls_linear_finish(void* stream, const float* G, const float* W, const float* bias, const float* gamma,
+                          const float* cs, float grad_scale, float* dW, float* db, float* dgamma, int N, int K);
+
+/* ---------------------------------------------------------------------------------------------
  * Multi-scale deformable attention core (backbones/ops/modules/ms_deform_attn.py:33-54 and the
  * location / softmax arithmetic of MSDeformAttn.forward :155-166), forward.
  * value: 16-bit [B, Lin, M*Dh] (output of value_proj; head m at columns m*Dh..)

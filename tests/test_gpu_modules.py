@@ -138,6 +138,8 @@ def test_decoder_setr_vs_reference_golden(dev):
     loss = seg_loss(y, tg, 1, ops.LOSS_DICE, 10e-20, n_ce=1)
     loss.backward()
     assert abs(float(loss.detach()) - float(g["setr.loss"])) < 1e-4
-    errs = {k: rel_l2(p.grad, g[f"setr.grad.{k}"]) for k, p in m.named_parameters()}
+    # a conv bias in front of a train-mode BatchNorm has an exactly-zero true gradient (rounding noise only): skipped
+    errs = {k: rel_l2(p.grad, g[f"setr.grad.{k}"]) for k, p in m.named_parameters()
+            if float(g[f"setr.grad.{k}"].norm()) > 1e-6}
     print("SETR grads:", {k: f"{v:.1e}" for k, v in errs.items()})
     assert max(errs.values()) < 3e-2, errs  # ReLU-flip floor on small maps, see tests/test_gpu_unet.py

@@ -51,3 +51,92 @@ def test_transpose_tokens(dev):
     assert t.shape == (B, C, 128)
     assert torch.equal(t[:, :, :N], x[:, 64:].view(B, N, C).transpose(1, 2))
     assert float(t[:, :, N:].abs().sum()) == 0
+
+
+def _block_case(dev, arch, B, N, dt):
+    from adaptersis_amd import config
+    from adaptersis_amd.dinov2.models import vision_transformer as vits
+    D, depth, heads, ffn = W.VIT_CONFIGS[arch]
+    sd = W.make_vit_state_dict(arch, layerscale="kernel")
+    model = vits.__dict__[arch](patch_size=14, img_size=518, init_values=1e-5, ffn_layer=ffn, block_chunks=0)
+    model.load_state_dict(sd)
+    blk = model.blocks[1].to(dev)
+    x = W.tensor(f"blkb.x{B}{N}", (B, N, D), 1.0)
+    dy = W.tensor(f"blkb.dy{B}{N}", (B, N, D), 1.0)
+    # oracle autograd
+    osd = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k.startswith("blocks.1.")}
+    xr = x.clone().requires_grad_(True)
+    (O.block(xr, osd, "blocks.1", heads) * dy).sum().backward()
+    old = config.operand_dtype
+    config.set_operand_dtype(dt)
+    try:
+        y, saved = blk.forward_train(x.to(dev))
+        y_eval = blk(x.to(dev))
+        S = 1024.0
+        grads = {"blocks.1." + k: torch.empty_like(p, dtype=torch.float32) for k, p in blk.named_parameters()}
+        dx = blk.backward(saved, (dy * S).to(dev).view(B * N, D).contiguous(), 1.0 / S, grads, "blocks.1")
+    finally:
+        config.set_operand_dtype(old)
+    with torch.no_grad():
+        y_ref = O.block(x, {k: v.detach() for k, v in osd.items()}, "blocks.1", heads)
+    return y, y_eval, y_ref, dx / S, xr.grad, grads, {k: v.grad for k, v in osd.items()}
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_block_forward_train_and_backward(dev, dt):
+    """One DINOv2 block (LayerNorm, qkv, fused attention, proj + LayerScale, MLP + LayerScale) forward in training form
+    and its full backward (input gradient + all 14 parameter gradients) against autograd of the oracle block."""
+    arch, B, N = "vit_tiny_test", 2, 70
+    y, y_eval, y_ref, dx, dx_ref, grads, gref = _block_case(dev, arch, B, N, dt)
+    f16 = dt == torch.float16
+    assert rel_l2(y, y_ref) < (5e-4 if f16 else 4e-3)
+    assert rel_l2(y, y_eval) < (5e-4 if f16 else 4e-3)     # training form vs the eval kernels (fused GELU, V^T GEMM)
+    e_dx = rel_l2(dx.view_as(dx_ref), dx_ref)
+    errs = {k: rel_l2(grads[k], gref[k]) for k in grads}
+    print(dt, "dx", "%.2e" % e_dx, {k.replace("blocks.1.", ""): "%.1e" % v for k, v in errs.items()})
+    tol = 3e-3 if f16 else 2.5e-2
+    assert e_dx < tol
+    assert max(errs.values()) < tol, errs
+
+
+def test_block_backward_input_gradient_only(dev):
+    """grads=None (frozen backbone: adapters upstream need only dL/dx): same dx, no parameter work."""
+    y, y_eval, y_ref, dx, dx_ref, grads, gref = _block_case(dev, "vit_tiny_test", 1, 33, torch.float16)
+    assert rel_l2(dx.view_as(dx_ref), dx_ref) < 3e-3
+
+
+def test_layernorm_backward(dev):
+    R, D = 300, 384
+    x = W.tensor("lnb.x", (R, D), 1.5, 0.3)
+    dy = W.tensor("lnb.dy", (R, D), 1.0)
+    res = W.tensor("lnb.res", (R, D), 1.0)
+    w = 1.0 + W.tensor("lnb.w", (D,), 0.3)
+    b = W.tensor("lnb.b", (D,), 0.3)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    (torch.nn.functional.layer_norm(xr, (D,), wr, br, 1e-6) * dy).sum().backward()
+    dx, part = ops.layernorm_bwd(dy.to(dev), x.to(dev), w.to(dev), 1e-6, res=res.to(dev))
+    red = ops.reduce_rows(part.view(part.shape[0], 2 * D))
+    assert rel_l2(dx, xr.grad + res) < 1e-5
+    assert rel_l2(red[:D], wr.grad) < 1e-5 and rel_l2(red[D:], br.grad) < 1e-5
+
+
+def test_gelu16_colsum_finish(dev):
+    R, C = 257, 136
+    pre = W.tensor("g16.pre", (R, C), 2.0).to(torch.float16)
+    dp = W.tensor("g16.dp", (R, C), 1.0).to(torch.float16)
+    pr = pre.float().requires_grad_(True)
+    yr = torch.nn.functional.gelu(pr)
+    (yr * dp.float()).sum().backward()
+    assert rel_l2(ops.gelu16(pre.to(dev)), yr) < 4e-4
+    assert rel_l2(ops.gelu16(pre.to(dev), dp.to(dev)), pr.grad) < 4e-4
+    assert rel_l2(ops.reduce_rows(ops.colsum(dp.to(dev))), dp.float().sum(0)) < 1e-6
+    xf = W.tensor("g16.f", (R, C), 1.0)
+    assert rel_l2(ops.reduce_rows(ops.colsum(xf.to(dev))), xf.sum(0)) < 1e-6
+    # LayerScale o Linear finish
+    N, K = 24, 40
+    G, Wt = W.tensor("fin.G", (N, K), 1.0), W.tensor("fin.W", (N, K), 1.0)
+    bias, gam, cs = W.tensor("fin.b", (N,), 1.0), W.tensor("fin.g", (N,), 1.0), W.tensor("fin.cs", (N,), 1.0)
+    dW, db, dg = (torch.empty(N, K, device=dev), torch.empty(N, device=dev), torch.empty(N, device=dev))
+    ops.ls_linear_finish(G.to(dev), Wt.to(dev), bias.to(dev), gam.to(dev), cs.to(dev), 0.5, dW, db, dg)
+    assert rel_l2(dW, 0.5 * gam[:, None] * G) < 1e-6 and rel_l2(db, 0.5 * gam * cs) < 1e-6
+    assert rel_l2(dg, 0.5 * ((Wt * G).sum(1) + bias * cs)) < 1e-5
