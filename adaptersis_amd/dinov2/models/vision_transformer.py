@@ -15,7 +15,8 @@ from typing import Sequence, Tuple, Union
 import torch
 import torch.nn as nn
 
-from ... import ops
+from ... import config, ops
+from ..layers.blocks import _pack
 from ..layers import MemEffAttention, Mlp, NestedTensorBlock as Block, PatchEmbed, SwiGLUFFNFused
 
 
@@ -108,6 +109,90 @@ class DinoVisionTransformer(nn.Module):
             x = blk(x)
         x_norm = self._final_norm(x)
         return {"x_norm_clstoken": x_norm[:, 0], "x_norm_patchtokens": x_norm[:, 1:], "x_prenorm": x, "masks": masks}
+
+    # -- training path: forward_features under autograd (eval_dinov2_setr_cross_ete.py:145-148,318-321) -----------
+    def forward_train(self, x: torch.Tensor):
+        """images (B,3,H,W) -> (x_norm_patchtokens fp32 (B,N,D) view, saved activations for ``backward``)."""
+        B, nc, w, h = x.shape
+        pe = self.patch_embed
+        P = pe.patch_size[0]
+        a16 = ops.im2col_patch(x.contiguous().float(), P, (3 * P * P + 7) // 8 * 8, config.operand_dtype)
+        w16 = _pack(pe._cache, "w", pe.proj.weight,
+                    lambda p: ops.cast_pad(p.reshape(p.shape[0], -1).contiguous().float(), a16.shape[1], config.operand_dtype))
+        t = ops.gemm(a16, w16, out_f32=True, bias_n=pe._f32("b", pe.proj.bias)).view(B, -1, self.embed_dim)
+        pos = self._pos_for(t.shape[1], w, h)
+        xx = ops.add_cls_pos(t, self.cls_token.detach().reshape(-1).float().contiguous(),
+                             pos.detach().reshape(-1, self.embed_dim).float().contiguous())
+        saved = []
+        for blk in self.blocks:
+            xx, s = blk.forward_train(xx)
+            saved.append(s)
+        x_norm = self._final_norm(xx)
+        return x_norm[:, 1:], (a16, xx, saved, (B, t.shape[1], w, h))
+
+    def _pos_resize_matrix(self, w: int, h: int, dev):
+        """The bicubic pos-embed resize of ``_pos_for`` as a dense matrix Mt [N_orig, N_new] (it is a fixed linear map
+        per image size): d pos_embed[1:] = Mt @ d pos_interp[1:].  Built once per size with the same F.interpolate
+        call, split into 16-bit hi/lo halves for the split-precision GEMM."""
+        key = (w, h, dev, config.operand_dtype)
+        cache = self.__dict__.setdefault("_posm_cache", {})
+        hit = cache.get(key)
+        if hit is None:
+            N = self.pos_embed.shape[1] - 1
+            s = int(math.sqrt(N))
+            w0, h0 = w // self.patch_size + self.interpolate_offset, h // self.patch_size + self.interpolate_offset
+            with torch.no_grad():
+                eye = torch.eye(N).reshape(N, 1, s, s)
+                Mt = nn.functional.interpolate(eye, scale_factor=(w0 / math.sqrt(N), h0 / math.sqrt(N)), mode="bicubic")
+                Mt = Mt.reshape(N, -1).contiguous().to(dev)
+            ld = (Mt.shape[1] + 7) // 8 * 8
+            hit = (ops.cast_pad(Mt, ld, config.operand_dtype), ops.cast_pad(Mt, ld, config.operand_dtype, part=1))
+            cache[key] = hit
+        return hit
+
+    def backward(self, saved, dtok: torch.Tensor, inv_scale: float, grads: dict, block_done=None) -> None:
+        """dtok fp32 (B,N,D) = loss_scale * dL/d x_norm_patchtokens -> ``grads[name]`` (fp32, unscaled) for every
+        parameter of the model (``mask_token`` is unused on this path: zero).  ``block_done(i)`` is called when block
+        i's gradients are enqueued (i = depth .. 0, depth = final norm) so a reducer can start that bucket."""
+        a16, x_last, bsaved, (B, N, w, h) = saved
+        D = self.embed_dim
+        dev = dtok.device
+        dt = config.operand_dtype
+        dxn = torch.zeros((B, N + 1, D), device=dev, dtype=torch.float32)
+        ops.copy_channels(dtok.reshape(B, N * D), dxn.view(B, (N + 1) * D)[:, D:])
+        dx, part = ops.layernorm_bwd(dxn.view(-1, D), x_last.reshape(-1, D), self.norm.weight.detach().float().contiguous(),
+                                     self.norm.eps)
+        red = ops.reduce_rows(part.view(part.shape[0], 2 * D), inv_scale)
+        grads["norm.weight"].copy_(red[:D]); grads["norm.bias"].copy_(red[D:])
+        if block_done is not None:
+            block_done(len(self.blocks))
+        for i in range(len(self.blocks) - 1, -1, -1):
+            dx = self.blocks[i].backward(bsaved[i], dx, inv_scale, grads, f"blocks.{i}")
+            bsaved[i] = None
+            if block_done is not None:
+                block_done(i)
+        # ---- prepare_tokens: x = cat(cls, patch_embed(img)) + pos ----
+        psum = ops.reduce_rows(ops.colsum(dx.view(B, (N + 1) * D)), inv_scale).view(N + 1, D)   # sum over the batch
+        grads["cls_token"].view(-1).copy_(psum[0])
+        gp = grads["pos_embed"].view(-1, D)
+        gp[0].copy_(psum[0])
+        if gp.shape[0] - 1 == N and w == h:
+            gp[1:].copy_(psum[1:])
+        else:
+            m_hi, m_lo = self._pos_resize_matrix(w, h, dev)
+            pt = psum[1:].t().contiguous()                                                      # [D, N]
+            ld = m_hi.shape[1]
+            ops.gemm_split(m_hi, m_lo, ops.cast_pad(pt, ld, dt), ops.cast_pad(pt, ld, dt, part=1), out=gp[1:])
+        grads["mask_token"].zero_()
+        dtk = torch.empty((B * N, D), device=dev, dtype=torch.float32)
+        ops.copy_channels(dx.view(B, (N + 1) * D)[:, D:], dtk.view(B, N * D))
+        d16 = ops.cast_pad(dtk, D, dt)
+        K = grads["patch_embed.proj.weight"][0].numel()
+        gw = ops.wgrad(d16.view(1, B * N, 1, D), a16.view(1, B * N, 1, a16.shape[1]), D, 1, 1, 1, 0, inv_scale)
+        grads["patch_embed.proj.weight"].view(D, K).copy_(gw.view(D, -1)[:, :K])
+        ops.reduce_rows(ops.colsum(dtk), inv_scale, grads["patch_embed.proj.bias"])
+        if block_done is not None:
+            block_done(-1)
 
     # -- vision_transformer.py:237-247 ---------------------------------------------------------
     def _get_intermediate_layers_not_chunked(self, x, n=1):

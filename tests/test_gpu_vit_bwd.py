@@ -140,3 +140,35 @@ def test_gelu16_colsum_finish(dev):
     ops.ls_linear_finish(G.to(dev), Wt.to(dev), bias.to(dev), gam.to(dev), cs.to(dev), 0.5, dW, db, dg)
     assert rel_l2(dW, 0.5 * gam[:, None] * G) < 1e-6 and rel_l2(db, 0.5 * gam * cs) < 1e-6
     assert rel_l2(dg, 0.5 * ((Wt * G).sum(1) + bias * cs)) < 1e-5
+
+
+@pytest.mark.parametrize("size", [224, 518])
+def test_vit_forward_train_and_backward(dev, size):
+    """Whole DinoVisionTransformer: forward_features in training form and the backward of every parameter
+    (patch embed, cls token, bicubic-resized pos embed (224) / identity (518), blocks, final norm) against autograd of
+    the oracle ``forward_features`` — the `eval/eval_dinov2_setr_cross_ete.py:318-321` backbone call."""
+    from adaptersis_amd.dinov2.models import vision_transformer as vits
+    arch, B = "vit_tiny_test", 2
+    D, depth, heads, ffn = W.VIT_CONFIGS[arch]
+    sd = W.make_vit_state_dict(arch, layerscale="kernel")
+    model = vits.__dict__[arch](patch_size=14, img_size=518, init_values=1e-5, ffn_layer=ffn, block_chunks=0)
+    model.load_state_dict(sd)
+    model = model.to(dev)
+    img = W.synthetic_batch(B, size)[0]
+    N = (size // 14) ** 2
+    dy = W.tensor(f"vitb.dy{size}", (B, N, D), 1.0)
+    osd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    out_ref = O.forward_features(img, osd, heads)["x_norm_patchtokens"]
+    (out_ref * dy).sum().backward()
+    tok, saved = model.forward_train(img.to(dev))
+    assert rel_l2(tok, out_ref) < 1e-3
+    S = 256.0
+    grads = {k: torch.empty_like(p, dtype=torch.float32) for k, p in model.named_parameters()}
+    order = []
+    model.backward(saved, (dy * S).to(dev), 1.0 / S, grads, block_done=order.append)
+    assert order == [depth] + list(range(depth - 1, -2, -1))
+    errs = {k: rel_l2(grads[k], osd[k].grad) for k in grads if osd[k].grad is not None and float(osd[k].grad.norm()) > 0}
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:6]
+    print(size, "worst ViT grads:", [(k, "%.1e" % v) for k, v in worst])
+    assert max(errs.values()) < 5e-3, worst
+    assert float(grads["mask_token"].abs().sum()) == 0
