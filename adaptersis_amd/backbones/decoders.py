@@ -190,10 +190,12 @@ class FeatureDecoder(_Packed):
         saved.append(a[0] if save else None)
         return logits, saved
 
-    def _backward_core(self, saved, d16, bias_partial, inv_scale, grads, dlogits_f32=None, stage_done=None, d_lo=None):
+    def _backward_core(self, saved, d16, bias_partial, inv_scale, grads, dlogits_f32=None, stage_done=None, d_lo=None,
+                       need_input_grad: bool = False):
         """d16: 16-bit [B,h,w,CP] = loss_scale * dL/dlogits (pad channels zero).  ``stage_done()`` is
         called after the final conv and after each decoder stage (4,3,2,1) once its gradients are
-        enqueued — the engine launches that stage's gradient all-reduce from it."""
+        enqueued — the engine launches that stage's gradient all-reduce from it.  ``need_input_grad``: also return
+        loss_scale * dL/d(input) as fp32 NHWC (end-to-end training of the backbone)."""
         dt = config.operand_dtype
         C = self.num_classes
         x5 = saved[4]
@@ -212,9 +214,10 @@ class FeatureDecoder(_Packed):
         for i in range(4, 0, -1):
             seq = getattr(self, f"decoder_{i}")
             dU = conv_bn_relu_up_backward(self, f"d{i}", saved[i - 1], dU, seq[0], seq[1], inv_scale, grads,
-                                          f"decoder_{i}", need_dx=(i > 1), sync_bn=self.sync_bn)
+                                          f"decoder_{i}", need_dx=(i > 1 or need_input_grad), sync_bn=self.sync_bn)
             if stage_done is not None:
                 stage_done()
+        return dU
 
     # ---- reference-shaped entry point ----------------------------------------------------------------
     def forward(self, x):

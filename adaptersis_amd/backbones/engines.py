@@ -288,3 +288,97 @@ class SegEngine(nn.Module):
         m = ops.ce_acc(logits, target, ce_weight)
         loss1, _, _ = ops.dice_fwd(logits, target, 1, 10e-20, 1.0)
         return m, loss1
+
+
+class EndToEndEngine(nn.Module):
+    """BASELINE config 4 — the unfrozen end-to-end variant (`eval/eval_dinov2_setr_cross_ete.py:145-148,307-361`):
+
+        x_norm_patchtokens = model(inp, is_training=True)          whole ViT under autograd / DDP
+        logits = seg_decoder(tokens as (B, D, h, w)) ; resize to the label size ; loss = CE + DC(2)
+        backward through the decoder AND all ViT blocks ; DDP all-reduces every gradient
+        optimizer.step() on the decoder only (`:224-229` — the backbone gradients are computed and exchanged, then
+        discarded; reproduced as written, DESIGN.md "config 4").
+
+    The ViT runs ``forward_train`` / ``backward`` (fused attention forward+backward, LayerNorm / GELU / LayerScale
+    backward kernels, weight-gradient GEMMs); its gradients live in a gradient-only flat bucket that is all-reduced
+    in ``blocks_per_bucket``-block chunks on the side stream while earlier blocks are still in their backward.
+    """
+
+    def __init__(self, model, seg_decoder, *, lr: float = 0.01, momentum: float = 0.9, weight_decay: float = 0.0,
+                 loss: str = "ce_dc", process_group=None, blocks_per_bucket: int = 4):
+        super().__init__()
+        if loss not in SegEngine.LOSSES:
+            raise ValueError(f"loss must be one of {sorted(SegEngine.LOSSES)}")
+        self.model, self.seg_decoder, self.loss_kind, self.process_group = model, seg_decoder, loss, process_group
+        self.patch = model.patch_size
+        for p in model.parameters():
+            p.requires_grad_(True)
+        order = list(seg_decoder.GRAD_ORDER)
+        named = dict(seg_decoder.named_parameters())
+        ordered = [(n, named[n]) for pre in order for n in named if n.startswith(pre + ".")]
+        assert len(ordered) == len(named)
+        self.bucket = FlatBucket(ordered)
+        self.stage_ranges = [self.bucket.range_of([n for n in named if n.startswith(pre + ".")]) for pre in order]
+        self.optimizer = SGD([self.bucket], lr=lr, momentum=momentum, weight_decay=weight_decay)
+        self.reducer = StageReducer(self.bucket.grad, self.stage_ranges, process_group)
+        # backbone: gradient-ready order = final norm, blocks last..first, then the token embedding parameters
+        vnamed = dict(model.named_parameters())
+        depth = len(model.blocks)
+        groups = [[n for n in vnamed if n.startswith("norm.")]]
+        groups += [[n for n in vnamed if n.startswith(f"blocks.{i}.")] for i in range(depth - 1, -1, -1)]
+        groups.append([n for n in vnamed if not n.startswith("norm.") and not n.startswith("blocks.")])
+        assert sum(len(g) for g in groups) == len(vnamed)
+        self.vit_bucket = FlatBucket([(n, vnamed[n]) for g in groups for n in g], momentum=False)
+        # reduce after the final norm + every `blocks_per_bucket` blocks, the last chunk takes the embeddings along
+        self._fire_at, ranges, start = [], [], 0
+        for j in range(1, depth + 1):                       # j = number of blocks finished
+            last = j == depth
+            if j % blocks_per_bucket == 0 and not last:
+                names = [n for g in groups[start:j + 1] for n in g]
+                ranges.append(self.vit_bucket.range_of(names)); self._fire_at.append(depth - j); start = j + 1
+        ranges.append(self.vit_bucket.range_of([n for g in groups[start:] for n in g])); self._fire_at.append(-1)
+        self.vit_reducer = StageReducer(self.vit_bucket.grad, ranges, process_group)
+
+    def _block_done(self, i: int) -> None:
+        if i in self._fire_at:
+            self.vit_reducer.stage_done()
+
+    @torch.no_grad()
+    def train_step(self, inp: torch.Tensor, target: torch.Tensor, taps: Optional[dict] = None) -> torch.Tensor:
+        m, dec = self.model, self.seg_decoder
+        S = config.loss_scale
+        dt = config.operand_dtype
+        B, _, H, W = inp.shape
+        h, w = H // self.patch, W // self.patch
+        N, D = h * w, m.embed_dim
+        tok, vsaved = m.forward_train(inp)
+        t2 = torch.empty((B * N, D), device=inp.device, dtype=torch.float32)
+        ops.copy_channels(vsaved_tokens_view(tok, B, N, D), t2.view(B, N * D))
+        hi = ops.cast_pad(t2, D, dt).view(B, h, w, D)
+        lo = ops.cast_pad(t2, D, dt, part=1).view(B, h, w, D) if config.split_conv else None
+        logits, saved = dec._forward_core(hi, lo, save=True, training=True)
+        target = target.long().contiguous()
+        n_region, lmode, eps, n_ce = SegEngine.LOSSES[self.loss_kind]
+        loss, coef, _ = ops.seg_loss_fwd(logits, target, n_region, lmode, eps, n_ce, None, S)
+        dz = ops.seg_loss_bwd(logits, target, coef, n_region, lmode, n_ce, None)
+        _, hh, ww, C = logits.shape
+        r = ops.resize_bilinear_bwd(dz, hh, ww, dt, config.split_conv)
+        d16, d_lo, bpart = r if config.split_conv else (r[0], None, r[1])
+        inv = 1.0 / (S * world_size(self.process_group))
+        self.reducer.begin()
+        self.vit_reducer.begin()
+        dX = dec._backward_core(saved, d16, bpart, inv, self.bucket.views, stage_done=self.reducer.stage_done, d_lo=d_lo,
+                                need_input_grad=True)
+        m.backward(vsaved, dX.view(B, N, D), inv, self.vit_bucket.views, block_done=self._block_done)
+        self.reducer.finish()
+        self.vit_reducer.finish()
+        self.optimizer.step(1.0)
+        if taps is not None:
+            taps.update(logits=logits, loss=loss, tokens=t2.view(B, N, D))
+        return loss.view(())
+
+
+def vsaved_tokens_view(tok: torch.Tensor, B: int, N: int, D: int) -> torch.Tensor:
+    """x_norm_patchtokens is the [:, 1:] view of the (B, N+1, D) normalised tokens: as [B, N*D] rows with the batch
+    stride of the full tensor (what asis_copy_channels compacts)."""
+    return tok.as_strided((B, N * D), (tok.stride(0), 1))

@@ -21,7 +21,7 @@ from . import ops
 
 
 class FlatBucket:
-    def __init__(self, named_params: Sequence[Tuple[str, nn.Parameter]]):
+    def __init__(self, named_params: Sequence[Tuple[str, nn.Parameter]], momentum: bool = True):
         named_params = [(n, p) for n, p in named_params if p.requires_grad]
         if not named_params:
             raise ValueError("FlatBucket: no trainable parameters")
@@ -38,7 +38,8 @@ class FlatBucket:
         self.offsets = offs
         self.flat = torch.zeros(o, device=dev, dtype=torch.float32)
         self.grad = torch.zeros(o, device=dev, dtype=torch.float32)
-        self.momentum = torch.zeros(o, device=dev, dtype=torch.float32)
+        # gradient-only buckets (parameters that are all-reduced but never optimised) carry no momentum buffer
+        self.momentum = torch.zeros(o, device=dev, dtype=torch.float32) if momentum else None
         with torch.no_grad():
             for p, off in zip(self.params, offs):
                 v = self.flat[off:off + p.numel()].view(p.shape)

@@ -172,3 +172,55 @@ def test_vit_forward_train_and_backward(dev, size):
     print(size, "worst ViT grads:", [(k, "%.1e" % v) for k, v in worst])
     assert max(errs.values()) < 5e-3, worst
     assert float(grads["mask_token"].abs().sum()) == 0
+
+
+def test_end_to_end_engine_step_vs_oracle(dev):
+    """BASELINE config 4 flow at toy width (`eval/eval_dinov2_setr_cross_ete.py:307-361`): ViT forward under autograd ->
+    DecoderSETR -> resize -> CE + DC(2) -> backward through decoder and all ViT blocks -> SGD on the decoder only.
+    Loss, logits, decoder gradients and every backbone gradient against autograd of the oracle."""
+    import torch.nn.functional as F
+    from adaptersis_amd.backbones.decoders import DecoderSETR
+    from adaptersis_amd.backbones.engines import EndToEndEngine
+    from adaptersis_amd.dinov2.models import vision_transformer as vits
+    arch, B, size = "vit_tiny_test", 2, 224
+    D, depth, heads, ffn = W.VIT_CONFIGS[arch]
+    feats = [32, 16, 16, 8]
+    vsd = W.make_vit_state_dict(arch, layerscale="kernel")
+    dsd = W.make_setr_state_dict(D, 2, feats)
+    model = vits.__dict__[arch](patch_size=14, img_size=518, init_values=1e-5, ffn_layer=ffn, block_chunks=0)
+    model.load_state_dict(vsd)
+    dec = DecoderSETR(D, 2, features=feats)
+    dec.load_state_dict(dsd)
+    eng = EndToEndEngine(model.to(dev), dec.to(dev), lr=0.05, blocks_per_bucket=2)
+    img, tgt = W.synthetic_batch(B, size)
+    # oracle
+    ov = {k: v.clone().requires_grad_(True) for k, v in vsd.items()}
+    od = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in dsd.items()}
+    tok = O.forward_features(img, ov, heads)["x_norm_patchtokens"]
+    fmap = tok.transpose(1, 2).reshape(B, D, size // 14, size // 14)
+    oy = O.feature_decoder(fmap, od, update_bn=True)
+    oo = F.interpolate(oy, size=(size, size), mode="bilinear")
+    oloss = O.cross_entropy_nd(oo, tgt) + O.dc_loss(oo, O.one_hot(tgt, 2))
+    oloss.backward()
+    before = {k: p.detach().clone() for k, p in eng.model.named_parameters()}
+    taps = {}
+    loss = eng.train_step(img.to(dev), tgt.to(dev), taps)
+    assert rel_l2(taps["tokens"], tok) < 1e-3
+    assert rel_l2(taps["logits"].permute(0, 3, 1, 2), oy) < 1.5e-3
+    assert abs(float(loss) - float(oloss)) < 1e-4
+    derr = {k: rel_l2(v, od[k].grad) for k, v in eng.bucket.views.items() if float(od[k].grad.norm()) > 1e-7}
+    verr = {k: rel_l2(v, ov[k].grad) for k, v in eng.vit_bucket.views.items()
+            if ov[k].grad is not None and float(ov[k].grad.norm()) > 0}
+    print("e2e: decoder grads max %.2e, backbone grads max %.2e (%s)" % (max(derr.values()), max(verr.values()),
+                                                                           max(verr, key=verr.get)))
+    # step-level gradients: forward differences flip ReLU branches on the 16x16 .. 256x256 decoder maps (tests/test_gpu_unet.py)
+    assert max(derr.values()) < 1e-1, derr
+    assert max(verr.values()) < 1e-1, verr
+    # the optimiser touches the decoder only (`:224-229`)
+    for k, p in eng.model.named_parameters():
+        assert torch.equal(p.detach(), before[k]), k
+    names = [k for k, v in od.items() if v.requires_grad]
+    with torch.no_grad():
+        O.sgd_momentum_step({k: od[k] for k in names}, {k: od[k].grad for k in names}, {}, 0.05, 0.9, 0.0)
+    live = dict(eng.seg_decoder.named_parameters())
+    assert max(rel_l2(live[k], od[k]) for k in names) < 1e-3
