@@ -208,7 +208,8 @@ def test_end_to_end_engine_step_vs_oracle(dev):
     assert rel_l2(taps["tokens"], tok) < 1e-3
     assert rel_l2(taps["logits"].permute(0, 3, 1, 2), oy) < 1.5e-3
     assert abs(float(loss) - float(oloss)) < 1e-4
-    derr = {k: rel_l2(v, od[k].grad) for k, v in eng.bucket.views.items() if float(od[k].grad.norm()) > 1e-7}
+    # conv biases in front of a train-mode BatchNorm have an exactly-zero true gradient (rounding noise only): skipped
+    derr = {k: rel_l2(v, od[k].grad) for k, v in eng.bucket.views.items() if not k.endswith(".0.bias")}
     verr = {k: rel_l2(v, ov[k].grad) for k, v in eng.vit_bucket.views.items()
             if ov[k].grad is not None and float(ov[k].grad.norm()) > 0}
     print("e2e: decoder grads max %.2e, backbone grads max %.2e (%s)" % (max(derr.values()), max(verr.values()),
