@@ -52,6 +52,35 @@ def build_engine(arch: str, dev, lr: float):
     return SegEngine(model.to(dev).eval(), enc.to(dev), cv.to(dev), cn.to(dev), dec.to(dev), lr=lr)
 
 
+def build_engine_cfg(cfg: int, arch: str, dev, lr: float):
+    """BASELINE configs other than the headline one: 2 = ViT-B + adapters + UNet head (CE + DC), 4 = unfrozen
+    end-to-end ViT + DecoderSETR (full backward, backbone gradients all-reduced, decoder-only optimiser)."""
+    from adaptersis_amd.backbones.adapter_blocks import CACNN, CAViT
+    from adaptersis_amd.backbones.decoders import DecoderSETR
+    from adaptersis_amd.backbones.encoders import FeatureEncoder
+    from adaptersis_amd.backbones.engines import EndToEndEngine, SegEngine
+    from adaptersis_amd.backbones.unet_parts import UNet
+    from adaptersis_amd.dinov2.models import vision_transformer as vits
+    from adaptersis_amd.utils import weights as W
+
+    D, depth, heads, ffn = W.VIT_CONFIGS[arch]
+    model = vits.__dict__[arch](patch_size=14, img_size=518, init_values=1e-5, ffn_layer=ffn, block_chunks=0)
+    model.load_state_dict(W.make_vit_state_dict(arch, layerscale="kernel"))
+    if cfg == 4:
+        dec = DecoderSETR(D, 2)
+        dec.load_state_dict(W.make_setr_state_dict(D, 2))
+        return EndToEndEngine(model.to(dev), dec.to(dev), lr=lr)
+    enc = FeatureEncoder(embed_dim=D)
+    enc.load_state_dict(W.make_encoder_state_dict(D))
+    cv = CAViT(dim=D, n_levels=3, num_heads=8, init_values=0.0, n_points=4)
+    cv.load_state_dict(W.make_cavit_state_dict(D, mode="kernel"))
+    cn = CACNN(dim=D, n_levels=1, num_heads=8, n_points=4, with_cffn=True, cffn_ratio=0.25)
+    cn.load_state_dict(W.make_cacnn_state_dict(D, mode="kernel"))
+    dec = UNet(D, 2)
+    dec.load_state_dict(W.make_unet_state_dict(D, 2))
+    return SegEngine(model.to(dev).eval(), enc.to(dev), cv.to(dev), cn.to(dev), dec.to(dev), lr=lr, loss="ce_dc")
+
+
 def synthetic(batch: int, size: int, rank: int, dev):
     """images U[0,1) (no mean/std normalisation), binary masks ~30 % foreground, one
     all-background image per batch (Dice epsilon path); generator seeded 0 + rank."""
@@ -137,7 +166,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=12, help="images per GPU (README.md:45-61 of the reference)")
-    ap.add_argument("--arch", default="vit_large")
+    ap.add_argument("--arch", default=None)
+    ap.add_argument("--config", type=int, default=3, choices=[2, 3, 4],
+                    help="BASELINE.json config: 3 = the headline metric (default); 2 = ViT-B + UNet head; 4 = unfrozen end-to-end")
     ap.add_argument("--size", type=int, default=588)
     ap.add_argument("--operand", default=None, choices=[None, "f16", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -162,7 +193,8 @@ def main():
         config.set_operand_dtype(torch.float16 if a.operand == "f16" else torch.bfloat16)
         config.loss_scale = 65536.0 if a.operand == "f16" else 1.0
 
-    eng = build_engine(a.arch, dev, lr=0.01)
+    a.arch = a.arch or ("vit_base" if a.config == 2 else "vit_large")
+    eng = build_engine(a.arch, dev, lr=0.01) if a.config == 3 else build_engine_cfg(a.config, a.arch, dev, lr=0.01)
     img, tgt = synthetic(a.batch, a.size, rank, dev)
 
     def barrier():
@@ -209,20 +241,27 @@ def main():
     if rank == 0:
         global_batch = a.batch * world
         out = {
-            "metric": "training images/sec, ViT-L/14 588^2 adapter fine-tune",
+            "metric": "training images/sec, ViT-L/14 588^2 adapter fine-tune" if a.config == 3 else
+                      f"training images/sec, BASELINE config {a.config}",
             "value": round(global_batch * a.steps / elapsed, 3), "unit": "img/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
             "dtype": "f16" if config.operand_dtype == torch.float16 else "bf16", "data": "synthetic",
-            "config": {"workload": f"{a.arch}/14 frozen + CAViT/CACNN adapters (n_last_blocks=4) + FeatureDecoder, "
-                                   f"{a.size}x{a.size}, batch {a.batch}/GPU, reference_exact train.py step "
-                                   "(fwd + decoder bwd + all-reduce + SGD), random-init weights",
+            "config": {"workload": {
+                3: f"{a.arch}/14 frozen + CAViT/CACNN adapters (n_last_blocks=4) + FeatureDecoder, "
+                   f"{a.size}x{a.size}, batch {a.batch}/GPU, reference_exact train.py step "
+                   "(fwd + decoder bwd + all-reduce + SGD), random-init weights",
+                2: f"BASELINE config 2: {a.arch}/14 frozen + CAViT/CACNN adapters + UNet head, CE + DC loss, "
+                   f"{a.size}x{a.size}, batch {a.batch}/GPU (fwd + UNet bwd + all-reduce + SGD), random-init weights",
+                4: f"BASELINE config 4: {a.arch}/14 unfrozen end-to-end + DecoderSETR, CE + DC loss, {a.size}x{a.size}, "
+                   f"batch {a.batch}/GPU (fwd + full bwd incl. all ViT blocks + full-gradient all-reduce + decoder SGD), "
+                   "random-init weights"}[a.config],
                        "global_batch": global_batch, "image_size": a.size, "parallelism": f"dp{world}",
                        "split_precision_convs": bool(config.split_conv), "loss": loss_v},
         }
         if roof:
             out["roofline"] = roof
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and a.config == 3:
             out["cpu_baseline"] = cpu_baseline(a.arch, a.size)
         print(json.dumps(out), flush=True)
     if world > 1:
