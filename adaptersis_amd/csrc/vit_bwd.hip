@@ -21,6 +21,7 @@ inline int grid_for(int64_t total, int cap = 65535 * 4) {
 // dx[row] = (res ? res[row] : 0) + rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * w
 // partial[blk][0][c] = sum_rows dy * xhat (d weight),  partial[blk][1][c] = sum_rows dy (d bias)
 // Each block owns ROWS_PER_BLOCK consecutive rows, 4 waves striding over them; statistics are recomputed from x.
+template <int MAXC>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, int64_t lddy,
                                                             const float* __restrict__ x, int64_t ldx,
                                                             const float* __restrict__ w, float eps,
@@ -28,13 +29,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             float* __restrict__ dx, int64_t lddx,
                                                             float* __restrict__ partial, int64_t rows, int D,
                                                             int rows_per_block) {
-  __shared__ float red[3][2][LN_MAXC * 64 * 4];  // waves 1..3 park their column sums here
+  __shared__ float red[3][2][MAXC * 64 * 4];  // waves 1..3 park their column sums here
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int nchunk = D >> 2;
   const float4* w4 = reinterpret_cast<const float4*>(w);
-  float4 gw[LN_MAXC], gb[LN_MAXC], ww[LN_MAXC];
+  float4 gw[MAXC], gb[MAXC], ww[MAXC];
 #pragma unroll
-  for (int i = 0; i < LN_MAXC; ++i) {
+  for (int i = 0; i < MAXC; ++i) {
     gw[i] = gb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     const int c = lane + 64 * i;
     ww[i] = c < nchunk ? w4[c] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -46,10 +47,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
   for (int64_t row = r0 + wid; row < r1; row += 4) {
     const float4* xr = reinterpret_cast<const float4*>(x + row * ldx);
     const float4* gr = reinterpret_cast<const float4*>(dy + row * lddy);
-    float4 v[LN_MAXC], g[LN_MAXC];
+    float4 v[MAXC], g[MAXC];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXC; ++i) {
+    for (int i = 0; i < MAXC; ++i) {
       const int c = lane + 64 * i;
       if (c < nchunk) {
         v[i] = xr[c];
@@ -60,7 +61,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     const float mean = wave_sum(s) * invD;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXC; ++i) {
+    for (int i = 0; i < MAXC; ++i) {
       const int c = lane + 64 * i;
       if (c < nchunk) {
         v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     const float rstd = 1.0f / sqrtf(wave_sum(q) * invD + eps);
     float a = 0.f, bq = 0.f;  // sum g, sum g*xhat
 #pragma unroll
-    for (int i = 0; i < LN_MAXC; ++i) {
+    for (int i = 0; i < MAXC; ++i) {
       const int c = lane + 64 * i;
       if (c < nchunk) {
         v[i].x *= rstd; v[i].y *= rstd; v[i].z *= rstd; v[i].w *= rstd;  // xhat
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     float4* o = reinterpret_cast<float4*>(dx + row * lddx);
     const float4* rr = res ? reinterpret_cast<const float4*>(res + row * ldr) : nullptr;
 #pragma unroll
-    for (int i = 0; i < LN_MAXC; ++i) {
+    for (int i = 0; i < MAXC; ++i) {
       const int c = lane + 64 * i;
       if (c < nchunk) {
         float4 t;
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
   // column sums over the block's rows: waves 1..3 -> LDS -> wave 0 adds and writes
   if (wid > 0) {
 #pragma unroll
-    for (int i = 0; i < LN_MAXC; ++i) {
+    for (int i = 0; i < MAXC; ++i) {
       reinterpret_cast<float4*>(red[wid - 1][0])[i * 64 + lane] = gw[i];
       reinterpret_cast<float4*>(red[wid - 1][1])[i * 64 + lane] = gb[i];
     }
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     float4* pw = reinterpret_cast<float4*>(partial + ((int64_t)blockIdx.x * 2 + 0) * D);
     float4* pb = reinterpret_cast<float4*>(partial + ((int64_t)blockIdx.x * 2 + 1) * D);
 #pragma unroll
-    for (int i = 0; i < LN_MAXC; ++i) {
+    for (int i = 0; i < MAXC; ++i) {
       const int c = lane + 64 * i;
       if (c < nchunk) {
         float4 sw = gw[i], sb = gb[i];
@@ -190,6 +191,60 @@ __global__ __launch_bounds__(256) void colsum32_kernel(const float* __restrict__
   }
 }
 
+// out16[r, :] = (T)(scale * x[r, :]) and partial[blk][c] = sum over the block's rows of x[r, c]: the 16-bit GEMM operand of
+// a residual-stream gradient and its column sums (LayerScale / bias gradients) in one read of the fp32 rows
+template <typename T, int MAXC>
+__global__ __launch_bounds__(256) void cast_colsum_kernel(const float* __restrict__ x, int64_t ldx, T* __restrict__ out,
+                                                          int64_t ldo, float scale, float* __restrict__ partial,
+                                                          int64_t rows, int D, int rows_per_block) {
+  __shared__ float red[3][MAXC * 64 * 4];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int nchunk = D >> 2;
+  float4 acc[MAXC];
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  int64_t r1 = r0 + rows_per_block;
+  if (r1 > rows) r1 = rows;
+  for (int64_t row = r0 + wid; row < r1; row += 4) {
+    const float4* xr = reinterpret_cast<const float4*>(x + row * ldx);
+    uint2* o = reinterpret_cast<uint2*>(out + row * ldo);
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nchunk) {
+        const float4 v = xr[c];
+        acc[i].x += v.x; acc[i].y += v.y; acc[i].z += v.z; acc[i].w += v.w;
+        uint2 p;
+        p.x = pack2<T>(v.x * scale, v.y * scale);
+        p.y = pack2<T>(v.z * scale, v.w * scale);
+        o[c] = p;
+      }
+    }
+  }
+  if (wid > 0) {
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) reinterpret_cast<float4*>(red[wid - 1])[i * 64 + lane] = acc[i];
+  }
+  __syncthreads();
+  if (wid == 0) {
+    float4* pw = reinterpret_cast<float4*>(partial + (int64_t)blockIdx.x * D);
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nchunk) {
+        float4 s = acc[i];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const float4 t = reinterpret_cast<const float4*>(red[k])[i * 64 + lane];
+          s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+        }
+        pw[c] = s;
+      }
+    }
+  }
+}
+
 // one wave per output feature n: dW[n,:] = gs * gamma[n] * G[n,:];  dgamma[n] = gs * (sum_k W[n,k] G[n,k] + b[n] cs[n]);
 // db[n] = gs * gamma[n] * cs[n]     (gs = 1 / loss scale; gamma NULL = plain Linear: dW = gs G, db = gs cs)
 __global__ __launch_bounds__(256) void ls_linear_finish_kernel(const float* __restrict__ G, const float* __restrict__ Wt,
@@ -242,8 +297,13 @@ extern "C" int asis_layernorm_bwd(void* stream, const float* dy, int64_t lddy, c
   ASIS_REQUIRE(rows > 0, "asis_layernorm_bwd: no rows");
   const int nblk = asis_rowblock_nblk(rows);
   const int rpb = (int)((rows + nblk - 1) / nblk);
-  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nblk), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dy, lddy, x, ldx, w,
-                     eps, res, ldr, dx, lddx, partial, rows, D, rpb);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (D <= 1024)
+    hipLaunchKernelGGL((layernorm_bwd_kernel<4>), dim3(nblk), dim3(256), 0, s, dy, lddy, x, ldx, w, eps, res, ldr, dx, lddx,
+                       partial, rows, D, rpb);
+  else
+    hipLaunchKernelGGL((layernorm_bwd_kernel<LN_MAXC>), dim3(nblk), dim3(256), 0, s, dy, lddy, x, ldx, w, eps, res, ldr, dx,
+                       lddx, partial, rows, D, rpb);
   ASIS_CHECK_LAUNCH("asis_layernorm_bwd");
   return ASIS_OK;
 }
@@ -276,6 +336,26 @@ extern "C" int asis_colsum(void* stream, int dtype, const void* x, int64_t ld, f
   else if (dtype == ASIS_BF16) hipLaunchKernelGGL((colsum16_kernel<bf16>), dim3(nblk), dim3(256), 0, s, (const bf16*)x, ld, partial, rows, C, rpb);
   else hipLaunchKernelGGL(colsum32_kernel, dim3(nblk), dim3(256), 0, s, (const float*)x, ld, partial, rows, C, rpb);
   ASIS_CHECK_LAUNCH("asis_colsum");
+  return ASIS_OK;
+}
+
+extern "C" int asis_cast_colsum(void* stream, int dtype, const float* x, int64_t ldx, void* out, int64_t ldo, float scale,
+                                float* partial, int64_t rows, int D) {
+  ASIS_REQUIRE(x && out && partial && rows > 0, "asis_cast_colsum: bad arguments");
+  DT_OK(dtype, "asis_cast_colsum");
+  ASIS_REQUIRE(D > 0 && D % 4 == 0 && D <= LN_MAXC * 256 && ldx % 4 == 0 && ldo % 4 == 0 && ldo >= D,
+               "asis_cast_colsum: D=%d must be a multiple of 4, <= %d; row strides multiples of 4", D, LN_MAXC * 256);
+  const int nblk = asis_rowblock_nblk(rows);
+  const int rpb = (int)((rows + nblk - 1) / nblk);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == ASIS_F16) {
+    if (D <= 1024) hipLaunchKernelGGL((cast_colsum_kernel<f16, 4>), dim3(nblk), dim3(256), 0, s, x, ldx, (f16*)out, ldo, scale, partial, rows, D, rpb);
+    else hipLaunchKernelGGL((cast_colsum_kernel<f16, LN_MAXC>), dim3(nblk), dim3(256), 0, s, x, ldx, (f16*)out, ldo, scale, partial, rows, D, rpb);
+  } else {
+    if (D <= 1024) hipLaunchKernelGGL((cast_colsum_kernel<bf16, 4>), dim3(nblk), dim3(256), 0, s, x, ldx, (bf16*)out, ldo, scale, partial, rows, D, rpb);
+    else hipLaunchKernelGGL((cast_colsum_kernel<bf16, LN_MAXC>), dim3(nblk), dim3(256), 0, s, x, ldx, (bf16*)out, ldo, scale, partial, rows, D, rpb);
+  }
+  ASIS_CHECK_LAUNCH("asis_cast_colsum");
   return ASIS_OK;
 }
 

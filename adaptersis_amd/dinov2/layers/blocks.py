@@ -287,9 +287,8 @@ class Block(_Packed):
         ls2 = self.ls2.gamma if isinstance(self.ls2, LayerScale) else None
         pre = prefix + "." if prefix else ""
         # ---- MLP branch: out = x1 + ls2 * fc2(gelu(fc1(LN2(x1)))) ----
-        d16 = ops.cast_pad(dres, D, dt)
-        self._linear_bwd(pre + "mlp.fc2", m.fc2, ls2, pre + "ls2.gamma", d16, ops.colsum(dres) if grads is not None else None,
-                         hpost, inv_scale, grads)
+        d16, cs = ops.cast_colsum(dres, dt) if grads is not None else (ops.cast_pad(dres, D, dt), None)
+        self._linear_bwd(pre + "mlp.fc2", m.fc2, ls2, pre + "ls2.gamma", d16, cs, hpost, inv_scale, grads)
         dh = ops.gemm(d16, self._wT16("fc2T", m.fc2.weight, ls2))                  # 16-bit [R, 4D]
         dh = ops.gelu16(hpre, dh)
         self._linear_bwd(pre + "mlp.fc1", m.fc1, None, None, dh, ops.colsum(dh) if grads is not None else None, xn2,
@@ -300,9 +299,8 @@ class Block(_Packed):
             red = ops.reduce_rows(part.view(part.shape[0], 2 * D), inv_scale)
             grads[pre + "norm2.weight"].copy_(red[:D]); grads[pre + "norm2.bias"].copy_(red[D:])
         # ---- attention branch: x1 = x + ls1 * proj(attn(LN1(x))) ----
-        d16 = ops.cast_pad(dx1, D, dt)
-        self._linear_bwd(pre + "attn.proj", a.proj, ls1, pre + "ls1.gamma", d16, ops.colsum(dx1) if grads is not None else None,
-                         o, inv_scale, grads)
+        d16, cs = ops.cast_colsum(dx1, dt) if grads is not None else (ops.cast_pad(dx1, D, dt), None)
+        self._linear_bwd(pre + "attn.proj", a.proj, ls1, pre + "ls1.gamma", d16, cs, o, inv_scale, grads)
         dO = ops.gemm(d16, self._wT16("projT", a.proj.weight, ls1))                # 16-bit [R, D]
         q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
         dqkv = ops.attention_bwd(q, k, v, ops.transpose_tokens(q, B, N), ops.transpose_tokens(k, B, N),

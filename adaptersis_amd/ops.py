@@ -303,6 +303,19 @@ def colsum(x: torch.Tensor) -> torch.Tensor:
     return partial
 
 
+def cast_colsum(x: torch.Tensor, dtype: torch.dtype, scale: float = 1.0):
+    """fp32 [R, D] row view -> (16-bit [R, D], partial fp32 [nblk, D] column sums of x) in one pass."""
+    _dev(x)
+    R, D = x.shape
+    if x.dtype != torch.float32 or x.stride(1) != 1:
+        raise ValueError("cast_colsum: float32 rows expected")
+    out = torch.empty((R, D), device=x.device, dtype=dtype)
+    partial = torch.empty((lib().asis_rowblock_nblk(R), D), device=x.device, dtype=torch.float32)
+    check(lib().asis_cast_colsum(_stream(), _dt(dtype), x.data_ptr(), x.stride(0), out.data_ptr(), D, float(scale),
+                                 partial.data_ptr(), R, D), "asis_cast_colsum")
+    return out, partial
+
+
 def ls_linear_finish(G: torch.Tensor, W: Optional[torch.Tensor], bias, gamma, cs, grad_scale: float, dW: torch.Tensor,
                      db: Optional[torch.Tensor], dgamma: Optional[torch.Tensor]) -> None:
     """See include/asis_hip.h: (G, cs) -> dW, db, dgamma of ``x + gamma * (A W^T + b)`` (gamma None: plain Linear)."""

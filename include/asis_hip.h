@@ -175,6 +175,10 @@ int asis_layernorm_bwd(void* stream, const float* dy, int64_t lddy, const float*
                        const float* res, int64_t ldr, float* dx, int64_t lddx, float* partial, int64_t rows, int D);
 int asis_gelu16(void* stream, int dtype, const void* pre, const void* dpost, void* out, int64_t n);
 int asis_colsum(void* stream, int dtype, const void* x, int64_t ld, float* partial, int64_t rows, int C);
+/* fused: out (16-bit, row stride ldo) = scale * x (fp32 [rows, D], D <= 2048) and partial[asis_rowblock_nblk(rows)][D] =
+ * column sums of x — the GEMM operand of a residual-stream gradient plus its bias / LayerScale sums in one pass */
+int asis_cast_colsum(void* stream, int dtype, const float* x, int64_t ldx, void* out, int64_t ldo, float scale,
+                     float* partial, int64_t rows, int D);
 int asis_ls_linear_finish(void* stream, const float* G, const float* W, const float* bias, const float* gamma,
                           const float* cs, float grad_scale, float* dW, float* db, float* dgamma, int N, int K);
 
