@@ -158,25 +158,30 @@ class SegEngine(nn.Module):
         pos = m._pos_for(N, H, W)
         xa = ops.add_cls_pos(tokens, m.cls_token.detach().reshape(-1).float().contiguous(),
                              pos.detach().reshape(-1, D).float().contiguous())
+        # ---- both passes stacked along the rows: every block evaluation of pass A (cls + pos-embed tokens, all
+        # blocks, `train.py:287`) has a pass-B partner on the same frozen weights (raw patch tokens through
+        # blocks[0:-3], `train.py:300-302`, then one more block per adapter stage), so each launch carries 2x the rows
+        Ra, Rb = B * (N + 1), B * N
+        segs = [(B, N + 1), (B, N)]
+        xcat = torch.cat([xa.view(Ra, D), tokens.reshape(Rb, D)], 0)
         feats = []
-        for i, blk in enumerate(m.blocks):
-            xa = blk(xa)
+        for i, blk in enumerate(m.blocks[: nb - (nl - 1)]):
+            xcat = blk.forward_rows(xcat, segs)
             if i >= nb - nl:
-                feats.append(m._final_norm(xa)[:, 1:])    # [B, N, D] view, batch stride (N+1)*D
-        # ---- pass B (train.py:300-302): raw patch tokens through blocks[0:-3] ----
-        x = tokens
-        for blk in m.blocks[: nb - (nl - 1)]:
-            x = blk(x)
+                feats.append(m._final_norm(xcat[:Ra].view(B, N + 1, D))[:, 1:])   # [B, N, D] view, batch stride (N+1)*D
         if taps is not None:
-            taps.update(c=c, feats=feats, x_b0=x, shapes=shapes)
+            taps.update(c=c, x_b0=xcat[Ra:].view(B, N, D).clone(), shapes=shapes)
         c2d = c.view(B * Lc, D)
         for s in range(nl):
             if s > 0:
-                x = m.blocks[nb - (nl - 1) + s - 1](x)
-            x2 = x.view(B * N, D)
-            x2 = self._cavit(x2, c2d, g, B, N, Lc)
+                xcat = m.blocks[nb - (nl - 1) + s - 1].forward_rows(xcat, segs)
+                feats.append(m._final_norm(xcat[:Ra].view(B, N + 1, D))[:, 1:])
+            x2 = self._cavit(xcat[Ra:], c2d, g, B, N, Lc)
             c2d = self._cacnn(c2d, x2, g, B, Lc, N, shapes)
-            x = ops.add_f32(x2.view(B, N, D), feats[s])
+            # the stage output overwrites pass B's rows of the stacked buffer: the next block reads it in place
+            x = ops.add_f32(x2.view(B, N, D), feats[s], out=xcat[Ra:].view(B, N, D))
+        if taps is not None:
+            taps.update(feats=feats)
         if self.stream_only:
             xs = x.reshape(B * N, D)
             hi = ops.cast_pad(xs, D, config.operand_dtype).view(B, h, w, D)
@@ -209,22 +214,29 @@ class SegEngine(nn.Module):
         Lc = c.shape[1]
         g = self._geometry(H, W, shapes, inp.device)
         tokens = m.patch_embed(inp)
-        x = tokens
+        # pass A (`train_mla.py:361-366`, only its last layer is used) rides along with pass B on the same weights:
+        # both token batches stacked along the rows for blocks[0:-1] (see ``features``)
+        xa = ops.add_cls_pos(tokens, m.cls_token.detach().reshape(-1).float().contiguous(),
+                             m._pos_for(N, H, W).detach().reshape(-1, D).float().contiguous())
+        Ra = B * (N + 1)
+        segs = [(B, N + 1), (B, N)]
+        xcat = torch.cat([xa.view(Ra, D), tokens.reshape(B * N, D)], 0)
         for blk in m.blocks[: nb - 3]:
-            x = blk(x)
+            xcat = blk.forward_rows(xcat, segs)
         c2d = c.view(B * Lc, D)
-        x2 = self._cavit(x.view(B * N, D), c2d, g, B, N, Lc)
+        x2 = self._cavit(xcat[Ra:], c2d, g, B, N, Lc)
         outs = [x2]
-        for blk in (m.blocks[nb - 3], m.blocks[nb - 2], m.blocks[nb - 2]):  # the reference's repeated [-2:-1]
-            x2 = blk(x2.view(B, N, D)).view(B * N, D)
+        for j, bi in enumerate((nb - 3, nb - 2, nb - 2)):  # the reference's repeated [-2:-1]
+            if j < 2:
+                xcat[Ra:].copy_(x2)
+                xcat = m.blocks[bi].forward_rows(xcat, segs)
+                x2 = xcat[Ra:]
+            else:
+                x2 = m.blocks[bi](x2.view(B, N, D)).view(B * N, D)
             c2d = self._cacnn(c2d, x2, g, B, Lc, N, shapes)
             x2 = self._cavit(x2, c2d, g, B, N, Lc)
             outs.append(x2)
-        # pass A afterwards, only its last layer is used (train_mla.py:361-366)
-        xa = ops.add_cls_pos(tokens, m.cls_token.detach().reshape(-1).float().contiguous(),
-                             m._pos_for(N, H, W).detach().reshape(-1, D).float().contiguous())
-        for blk in m.blocks:
-            xa = blk(xa)
+        xa = m.blocks[nb - 1](xcat[:Ra].view(B, N + 1, D))
         vit_last = m._final_norm(xa)[:, 1:]
         last = ops.add_f32(outs[3].view(B, N, D), vit_last)
         maps = [last.view(B * N, D), outs[2], outs[1], outs[0]]

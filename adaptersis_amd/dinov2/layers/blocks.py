@@ -115,15 +115,28 @@ class Attention(_Packed):
 
     def attend(self, xn: torch.Tensor, B: int, N: int) -> torch.Tensor:
         """xn: 16-bit [B*N, D] (already normalised) -> 16-bit attention output [B*N, D] (before proj)."""
+        return self.attend_rows(xn, [(B, N)])
+
+    def attend_rows(self, xn: torch.Tensor, segs) -> torch.Tensor:
+        """Several token batches stacked along the rows (``segs`` = [(B, N), ...], e.g. the cls+pos pass and the raw
+        patch-token pass of `train.py:287,300-302`): one q|k GEMM over all rows, attention per batch."""
         D = xn.shape[1]
         w = self._w16("qkv", self.qkv.weight)  # [3D, D] rows q | k | v
         bias = self._f32("qkv_b", self.qkv.bias)
         qk = ops.gemm(xn, w[: 2 * D], bias_n=None if bias is None else bias[: 2 * D])
-        ldvt = (N + 63) // 64 * 64
-        vt = torch.empty((B, D, ldvt), device=xn.device, dtype=xn.dtype)
-        ops.gemm(w[2 * D:], xn.view(B, N, D), out=vt.as_strided((B, D, N), (D * ldvt, ldvt, 1)),
-                 bias_m=None if bias is None else bias[2 * D:])
-        return ops.attention_fwd(qk[:, :D], qk[:, D:], vt, B, self.num_heads, N, self.scale)
+        o = torch.empty((xn.shape[0], D), device=xn.device, dtype=xn.dtype)
+        r0 = 0
+        for B, N in segs:
+            r1 = r0 + B * N
+            ldvt = (N + 63) // 64 * 64
+            vt = torch.empty((B, D, ldvt), device=xn.device, dtype=xn.dtype)
+            ops.gemm(w[2 * D:], xn[r0:r1].view(B, N, D), out=vt.as_strided((B, D, N), (D * ldvt, ldvt, 1)),
+                     bias_m=None if bias is None else bias[2 * D:])
+            ops.attention_fwd(qk[r0:r1, :D], qk[r0:r1, D:], vt, B, self.num_heads, N, self.scale, out=o[r0:r1])
+            r0 = r1
+        if r0 != xn.shape[0]:
+            raise ValueError("attend_rows: segments do not cover the rows")
+        return o
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         raise RuntimeError("Attention is driven by Block.forward (LayerNorm / LayerScale / residual are fused around it)")
@@ -185,15 +198,24 @@ class Block(_Packed):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """x fp32 (B, N, D) -> fp32 (B, N, D); out of place like the reference."""
         B, N, D = x.shape
-        dt = config.operand_dtype
         x2 = x.reshape(B * N, D)
         if x2.dtype != torch.float32 or not x2.is_contiguous():
             x2 = x2.float().contiguous()
+        return self.forward_rows(x2, [(B, N)]).view(B, N, D)
+
+    def forward_rows(self, x2: torch.Tensor, segs) -> torch.Tensor:
+        """The block on several token batches stacked along the rows of one fp32 [R, D] matrix (``segs`` = [(B, N), ..]).
+        Everything but the attention itself is row-wise, so the two ViT passes of the training step (cls + pos-embed
+        tokens and raw patch tokens, same frozen weights: `train.py:287,300-302`) share every GEMM launch: twice the
+        rows per launch fill the 512 tile slots of the chip in 2.6 instead of 2 x 1.3 (-> 2 x 2) rounds on the
+        N = 1024 GEMMs, and the weights are read once."""
+        D = x2.shape[1]
+        dt = config.operand_dtype
         g1 = self._f32("g1", self.ls1.gamma) if isinstance(self.ls1, LayerScale) else None
         g2 = self._f32("g2", self.ls2.gamma) if isinstance(self.ls2, LayerScale) else None
         xn = ops.layernorm(x2, self._f32("n1w", self.norm1.weight), self._f32("n1b", self.norm1.bias),
                            self.norm1.eps, dt)
-        o = self.attn.attend(xn, B, N)
+        o = self.attn.attend_rows(xn, segs)
         x1 = ops.gemm(o, self.attn._w16("proj", self.attn.proj.weight), out_f32=True,
                       bias_n=self.attn._f32("proj_b", self.attn.proj.bias), scale_n=g1, res=x2)
         xn2 = ops.layernorm(x1, self._f32("n2w", self.norm2.weight), self._f32("n2b", self.norm2.bias),
@@ -208,8 +230,7 @@ class Block(_Packed):
             h = ops.swiglu(h12, dt)
             x3 = ops.gemm(h, m._w16("w3", m.w3.weight), out_f32=True, bias_n=m._f32("w3_b", m.w3.bias),
                           scale_n=g2, res=x1)
-        return x3.view(B, N, D)
-
+        return x3
 
     # ---- training path (block.py:89-114 under autograd; BASELINE config 4 / north_star "forward/backward") ----------
     def _pack2(self, key: str, w: torch.Tensor, gamma: Optional[torch.Tensor], fn):
