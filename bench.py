@@ -220,7 +220,7 @@ def main():
     elapsed = float(el)
     loss_v = float(loss)
 
-    # ---- roofline of the dominant kernel: the dense MFMA GEMM (asis gemm_kernel<T,false>) ----------------
+    # ---- roofline of the dominant kernel: the dense MFMA GEMM (csrc/gemm_big.h) ---------------------------
     roof = None
     if prof:
         dense = [(f, s.elapsed_time(e)) for (kind, f, s, e, _) in prof if kind == "gemm"]
@@ -230,7 +230,7 @@ def main():
         avg_ms = sum(t for _, t in dense) / n
         conv = [(f, s.elapsed_time(e)) for (kind, f, s, e, _) in prof if kind == "conv"]
         achieved = flops / (avg_ms * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": "gemm_kernel<f16,false> (all dense GEMM launches of the step)",
+        roof = {"bound": "mfma", "kernel": "gemm_big_kernel<T,4,2,2,2,3,0,false,false,32,4> = 256x128x32 LDS-DMA MFMA GEMM (all dense GEMM launches of the step)",
                 "achieved": round(achieved, 1), "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / MFMA_F16_DENSE_PEAK_TFLOPS, 4), "traffic": pmc_traffic("gemm_big_kernel", "Lb0ELb0ELi32ELi4E"),
                 "launches_per_step": n // a.steps, "avg_launch_ms": round(avg_ms, 4),
