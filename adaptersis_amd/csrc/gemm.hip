@@ -231,6 +231,13 @@ int launch(hipStream_t s, const asis_gemm_desc& d) {
     }
     return 0;
   }
+  static const int ph8 = [] { const char* e = getenv("ASIS_GEMM_8P"); return e ? atoi(e) : 0; }();
+  if (ph8 && big_mode && !d.conv && !d.stats && d.K % 64 == 0 && d.M >= 256 && d.N >= 256) {
+    // 256x256x64 tile, 8-phase main loop (one workgroup per CU: 128 KB of LDS)
+    dim3 grid(((d.M + 255) / 256) * ((d.N + 255) / 256), d.batch), block(512);
+    hipLaunchKernelGGL((gemm_big_kernel<T, 2, 4, 4, 2, 2, 0, false, false, 64, 1, true>), grid, block, 0, s, d, group_m);
+    return 0;
+  }
   if (big_mode && !d.conv && !d.stats && d.K % 32 == 0 && d.M >= 256 && d.N >= 128) {
     // 256x128x32 tile, 3 LDS stages (72 KB) and <= 128 VGPRs: TWO workgroups per CU, so one workgroup's epilogue
     // (HBM-write bound) overlaps the other's K loop: +12-15 % over the 1-workgroup 256x256x64 / 256x128x64 forms

@@ -17,8 +17,10 @@ namespace {
 __device__ __attribute__((aligned(16))) uint4 g_zero_page[1];
 
 template <typename T, int WM, int WN, int TM, int TN, int NS, int DBG = 0, bool CONV = false, bool SPLIT = false, int BKT = 64,
-          int OCC = 2>
+          int OCC = 2, bool PH8 = false>
 __global__ __launch_bounds__(512, OCC) void gemm_big_kernel(const asis_gemm_desc d, const int GROUP_M) {
+  static_assert(!PH8 || (WM == 2 && WN == 4 && TM == 4 && TN == 2 && NS == 2 && BKT == 64 && !CONV && !SPLIT),
+                "the 8-phase main loop is written for the 256x256x64 tile, 2x4 waves of 128x64");
   typedef typename T16<T>::v8 v8;
   constexpr int BM2 = WM * TM * 32, BN2 = WN * TN * 32;
   constexpr int BKB = BKT;                           // K tile (64 or 32)
@@ -55,9 +57,20 @@ __global__ __launch_bounds__(512, OCC) void gemm_big_kernel(const asis_gemm_desc
   const T* bsrc[GB];
   int a_ih0[GA], a_iw0[GA];  // CONV: top-left input pixel of this lane's output pixel
   const int lr = lane / CPR, lc = lane % CPR;
+  // first tile row / column of the 8-row group that this wave's j-th LDS-DMA instruction stages.  Default: the wave's
+  // own stripe.  PH8: instructions 0,1 stage the row halves 0 of both wave rows ({0..63, 128..191}), 2,3 the halves 1;
+  // for B the column halves 0 / 1 of the four wave columns — the order in which the phases consume them.
+  auto grp_a = [&](int j) -> int {
+    if (PH8) { const int g = wid * 2 + (j & 1); return (g < 8 ? 0 : 128) + (j >> 1) * 64 + (g & 7) * 8; }
+    return (wid * GA + j) * RPI;
+  };
+  auto grp_b = [&](int j) -> int {
+    if (PH8) { const int g = wid * 2 + (j & 1); return (g >> 2) * 64 + (j >> 1) * 32 + (g & 3) * 8; }
+    return (wid * GB + j) * RPI;
+  };
 #pragma unroll
   for (int j = 0; j < GA; ++j) {
-    const int row = (wid * GA + j) * RPI + lr;
+    const int row = grp_a(j) + lr;
     int gr = m0 + row;
     gr = gr < d.M ? gr : d.M - 1;
     if (CONV) {  // implicit im2col: A is NHWC [B,H,W,Cin]; a K tile (64) lies inside one tap (Cin % 64 == 0)
@@ -75,7 +88,7 @@ __global__ __launch_bounds__(512, OCC) void gemm_big_kernel(const asis_gemm_desc
   }
 #pragma unroll
   for (int j = 0; j < GB; ++j) {
-    const int row = (wid * GB + j) * RPI + lr;
+    const int row = grp_b(j) + lr;
     int gr = n0 + row;
     gr = gr < d.N ? gr : d.N - 1;
     bsrc[j] = B + (int64_t)gr * d.ldb + ((lc ^ ((row >> SWS) & (CPR - 1))) << 3);
@@ -107,16 +120,16 @@ __global__ __launch_bounds__(512, OCC) void gemm_big_kernel(const asis_gemm_desc
         const T* src = ((unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W)
                            ? asrc[j] + aoff + ((int64_t)ih * d.W + iw) * d.Cin + ci0
                            : reinterpret_cast<const T*>(g_zero_page);
-        __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(st + ((wid * GA + j) * RPI) * BKB), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(st + grp_a(j) * BKB), 16, 0, 0);
       }
     } else {
 #pragma unroll
       for (int j = 0; j < GA; ++j)
-        __builtin_amdgcn_global_load_lds((glb_ptr)(asrc[j] + aoff + k0), (lds_ptr)(st + ((wid * GA + j) * RPI) * BKB), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_ptr)(asrc[j] + aoff + k0), (lds_ptr)(st + grp_a(j) * BKB), 16, 0, 0);
     }
 #pragma unroll
     for (int j = 0; j < GB; ++j)
-      __builtin_amdgcn_global_load_lds((glb_ptr)(bsrc[j] + boff + k0), (lds_ptr)(st + BM2 * BKB + ((wid * GB + j) * RPI) * BKB), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_ptr)(bsrc[j] + boff + k0), (lds_ptr)(st + BM2 * BKB + grp_b(j) * BKB), 16, 0, 0);
   };
 
   f32x16 acc[TM][TN];
@@ -128,11 +141,94 @@ __global__ __launch_bounds__(512, OCC) void gemm_big_kernel(const asis_gemm_desc
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int nt = SPLIT ? 3 * nt1 : nt1;
+  const int fr = lane & 31, fh = lane >> 5;
+  if constexpr (PH8) {
+    // ---- 8-phase main loop (cdna_hip_programming.md "The 256^2 8-phase template", re-derived for 32x32x16 MFMAs and
+    // this kernel's C^T accumulators).  A K tile is consumed in four phases, one 64x32 quadrant of the wave's 128x64
+    // tile each: (rows 0, cols 0) (rows 0, cols 1) (rows 1, cols 1) (rows 1, cols 0).  A phase is
+    //     [LDS reads of the fragments this phase adds | 2 LDS-DMA instructions of the NEXT K tile | counted vmcnt]
+    //     s_barrier  [8 MFMAs]  s_barrier
+    // and the two wave rows run one barrier interval apart, so on every SIMD one wave issues MFMAs while the other
+    // does its LDS reads and staging.  Staging order of tile t+1 during tile t: A half 0 (phase 0), B half 0 (1),
+    // B half 1 (2), A half 1 (3); a half is read two or more phases after the vmcnt + barrier that retire it:
+    //     phase 0 waits for B1 of tile t (<= 4 newer instructions outstanding), phase 1 for A1 of tile t,
+    //     phase 3 for A0 and B0 of tile t+1; the buffer of tile t-1 is free from its phase 3 on (no LDS reads there).
+    auto dma_a = [&](int t, int j) {
+      __builtin_amdgcn_global_load_lds((glb_ptr)(asrc[j] + t * BKB), (lds_ptr)(lds + (t & 1) * STAGE + grp_a(j) * BKB), 16, 0, 0);
+    };
+    auto dma_b = [&](int t, int j) {
+      __builtin_amdgcn_global_load_lds((glb_ptr)(bsrc[j] + t * BKB), (lds_ptr)(lds + (t & 1) * STAGE + BM2 * BKB + grp_b(j) * BKB), 16, 0, 0);
+    };
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      dma_a(0, j);
+      dma_b(0, j);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wm == 1) __builtin_amdgcn_s_barrier();  // stagger the second wave row by one barrier interval
+    v8 af[2][4], b0f[4], b1f[4];
+    auto rd_a = [&](const T* As, int rh) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int row = (wm * TM + rh * 2 + i) * 32 + fr;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+          af[i][ks] = __builtin_bit_cast(v8, *reinterpret_cast<const uint4*>(As + row * BKB + (((2 * ks + fh) ^ ((row >> 1) & 7)) << 3)));
+      }
+    };
+    auto rd_b = [&](const T* Bs, int ch, v8* bf) {
+      const int col = (wn * TN + ch) * 32 + fr;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        bf[ks] = __builtin_bit_cast(v8, *reinterpret_cast<const uint4*>(Bs + col * BKB + (((2 * ks + fh) ^ ((col >> 1) & 7)) << 3)));
+    };
+    auto mma = [&](int rh, int ch, const v8* bf) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[rh * 2 + i][ch] = T16<T>::mfma32(bf[ks], af[i][ks], acc[rh * 2 + i][ch]);
+      __builtin_amdgcn_s_setprio(0);
+    };
+    for (int t = 0; t < nt; ++t) {
+      const T* As = lds + (t & 1) * STAGE;
+      const T* Bs = As + BM2 * BKB;
+      const bool more = t + 1 < nt;
+      // phase 0
+      rd_a(As, 0);
+      rd_b(Bs, 0, b0f);
+      if (more) { dma_a(t + 1, 0); dma_a(t + 1, 1); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+      else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      mma(0, 0, b0f);
+      __builtin_amdgcn_s_barrier();
+      // phase 1
+      rd_b(Bs, 1, b1f);
+      if (more) { dma_b(t + 1, 0); dma_b(t + 1, 1); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      mma(0, 1, b1f);
+      __builtin_amdgcn_s_barrier();
+      // phase 2
+      rd_a(As, 1);
+      if (more) { dma_b(t + 1, 2); dma_b(t + 1, 3); }
+      __builtin_amdgcn_s_barrier();
+      mma(1, 1, b1f);
+      __builtin_amdgcn_s_barrier();
+      // phase 3
+      if (more) { dma_a(t + 1, 2); dma_a(t + 1, 3); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+      __builtin_amdgcn_s_barrier();
+      mma(1, 0, b0f);
+      __builtin_amdgcn_s_barrier();
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();  // balance the stagger
+  } else {
 #pragma unroll
   for (int s = 0; s < NS - 1; ++s)
     if (s < nt) issue(s);
 
-  const int fr = lane & 31, fh = lane >> 5;
   for (int t = 0; t < nt; ++t) {
     // tile t has landed once at most (NS-2) newer tiles of this wave are still outstanding
     if (nt - t - 1 >= NS - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * G) : "memory");
@@ -170,6 +266,7 @@ __global__ __launch_bounds__(512, OCC) void gemm_big_kernel(const asis_gemm_desc
       }
     }
   }
+  }  // !PH8
 
   // ---- epilogue (same semantics as gemm_kernel) ----
   if (DBG & 4) {  // lab only: keep the accumulators live, store one value per lane
