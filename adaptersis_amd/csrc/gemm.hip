@@ -231,11 +231,13 @@ int launch(hipStream_t s, const asis_gemm_desc& d) {
     }
     return 0;
   }
+  static const int noepi = [] { const char* e = getenv("ASIS_GEMM_NOEPI"); return e ? atoi(e) : 0; }();  // lab: main loop only
   static const int ph8 = [] { const char* e = getenv("ASIS_GEMM_8P"); return e ? atoi(e) : 0; }();
   if (ph8 && big_mode && !d.conv && !d.stats && d.K % 64 == 0 && d.M >= 256 && d.N >= 256) {
     // 256x256x64 tile, 8-phase main loop (one workgroup per CU: 128 KB of LDS)
     dim3 grid(((d.M + 255) / 256) * ((d.N + 255) / 256), d.batch), block(512);
-    hipLaunchKernelGGL((gemm_big_kernel<T, 2, 4, 4, 2, 2, 0, false, false, 64, 1, true>), grid, block, 0, s, d, group_m);
+    if (noepi) hipLaunchKernelGGL((gemm_big_kernel<T, 2, 4, 4, 2, 2, 4, false, false, 64, 1, true>), grid, block, 0, s, d, group_m);
+    else hipLaunchKernelGGL((gemm_big_kernel<T, 2, 4, 4, 2, 2, 0, false, false, 64, 1, true>), grid, block, 0, s, d, group_m);
     return 0;
   }
   if (big_mode && !d.conv && !d.stats && d.K % 32 == 0 && d.M >= 256 && d.N >= 128) {
@@ -246,6 +248,7 @@ int launch(hipStream_t s, const asis_gemm_desc& d) {
     dim3 grid(((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn), d.batch), block(512);
     if (big_mode == 2 && bn == 256) hipLaunchKernelGGL((gemm_big_kernel<T, 2, 4, 4, 2, 2>), grid, block, 0, s, d, group_m);
     else if (big_mode >= 2 || d.K % 64 != 0 && false) hipLaunchKernelGGL((gemm_big_kernel<T, 4, 2, 2, 2, 3>), grid, block, 0, s, d, group_m);
+    else if (noepi) hipLaunchKernelGGL((gemm_big_kernel<T, 4, 2, 2, 2, 3, 4, false, false, 32, 4>), grid, block, 0, s, d, group_m);
     else hipLaunchKernelGGL((gemm_big_kernel<T, 4, 2, 2, 2, 3, 0, false, false, 32, 4>), grid, block, 0, s, d, group_m);
     return 0;
   }
