@@ -102,12 +102,21 @@ __device__ __forceinline__ float wave_max(float v) {
 // v_exp + one v_rcp + 6 FMAs instead of libm erff's ~40 VALU ops, which cost the fc1 epilogue 25 % of the GEMM.
 __device__ __forceinline__ float erf_fast(float x) {
   const float ax = fabsf(x);
-  const float t = __frcp_rn(1.0f + 0.3275911f * ax);
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, ax, 1.0f));  // v_rcp_f32 (1 ulp), not the IEEE division sequence
   const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
-  const float y = 1.0f - poly * __expf(-ax * ax);
+  const float y = 1.0f - poly * __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);
   return copysignf(y, x);
 }
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f)); }
+// gelu(x) = x Phi(x) with Phi from the same A&S erf: for z = x/sqrt(2), q = poly(t) exp(-z^2) / 2 is the smaller tail, so
+// gelu = x - x q (x >= 0) or x q (x < 0): no 1 + erf cancellation, 13 VALU ops of which two quarter-rate (rcp, exp2)
+__device__ __forceinline__ float gelu_erf(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f * 0.70710678118654752440f, ax, 1.0f));
+  const float poly = ((((0.5f * 1.061405429f * t - 0.5f * 1.453152027f) * t + 0.5f * 1.421413741f) * t - 0.5f * 0.284496736f) * t +
+                      0.5f * 0.254829592f) * t;
+  const float r = x * (poly * __builtin_amdgcn_exp2f(-0.5f * 1.4426950408889634f * (x * x)));
+  return x >= 0.f ? x - r : r;
+}
 // d/dx gelu
 __device__ __forceinline__ float gelu_erf_grad(float x) {
   const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
