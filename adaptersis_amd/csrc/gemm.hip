@@ -232,7 +232,7 @@ int launch(hipStream_t s, const asis_gemm_desc& d) {
     return 0;
   }
   static const int noepi = [] { const char* e = getenv("ASIS_GEMM_NOEPI"); return e ? atoi(e) : 0; }();  // lab: main loop only
-  static const int ph8 = [] { const char* e = getenv("ASIS_GEMM_8P"); return e ? atoi(e) : 1; }();
+  static const int ph8 = [] { const char* e = getenv("ASIS_GEMM_8P"); return e ? atoi(e) : 0; }();
   if (ph8 && big_mode && !d.conv && !d.stats && d.K % 64 == 0 && d.M >= 256 && d.N >= 256) {
     // 256x256x64 tile, 8-phase main loop (one workgroup per CU: 128 KB of LDS)
     dim3 grid(((d.M + 255) / 256) * ((d.N + 255) / 256), d.batch), block(512);
