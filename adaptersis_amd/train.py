@@ -23,7 +23,7 @@ import torch
 from torch import nn
 
 from .backbones.adapter_blocks import CACNN, CAViT
-from .backbones.decoders import FeatureDecoder
+from .backbones.decoders import DecoderMLA, FeatureDecoder
 from .backbones.encoders import FeatureEncoder
 from .backbones.engines import SegEngine
 from .dinov2.models import vision_transformer as vits
@@ -53,14 +53,17 @@ class _SegData(torch.utils.data.Dataset):
         return self.img[i], self.msk[i], i
 
 
-def _engine_for(model, backbone_encoder, cross_vit, cross_cnn, seg_decoder, lr=0.01):
+def _engine_for(model, backbone_encoder, cross_vit, cross_cnn, seg_decoder, lr=0.01, momentum=0.99, weight_decay=3e-5):
     key = id(seg_decoder)
     if key not in _ENGINES:
-        _ENGINES[key] = SegEngine(model, backbone_encoder, cross_vit, cross_cnn, seg_decoder, lr=lr)
+        _ENGINES[key] = SegEngine(model, backbone_encoder, cross_vit, cross_cnn, seg_decoder, lr=lr, momentum=momentum,
+                                  weight_decay=weight_decay)
     return _ENGINES[key]
 
 
-def train_seg(args):
+def train_seg(args, head: str = "feature"):
+    """``head``: "feature" = `train.py` (FeatureDecoder, SGD lr / 0.99 / 3e-5, `train.py:178-191`); "mla" = `train_mla.py`
+    (DecoderMLA, SGD lr * batch * world / 16, momentum 0.9, no weight decay, `train_mla.py:178-184`)."""
     utils.init_distributed_mode(args)
     print("\n".join("%s: %s" % (k, str(v)) for k, v in sorted(dict(vars(args)).items())))
     dev = torch.device("cuda", args.gpu)
@@ -82,9 +85,14 @@ def train_seg(args):
     backbone_encoder = FeatureEncoder(embed_dim=D).to(dev)
     cross_vit = CAViT(dim=D, n_levels=3, num_heads=8, init_values=0.0, n_points=4).to(dev)
     cross_cnn = CACNN(dim=D, n_levels=1, num_heads=8, n_points=4, with_cffn=True, cffn_ratio=0.25).to(dev)
-    seg_decoder = FeatureDecoder(embed_dim=D, num_classes=2, features=[D, 512, 256, 128, 64]).to(dev)
-    engine = _engine_for(model, backbone_encoder, cross_vit, cross_cnn, seg_decoder, lr=args.lr)
-    optimizer = engine.optimizer  # SGD(lr, momentum 0.99, wd 3e-5): train.py:178-191
+    if head == "mla":
+        seg_decoder = DecoderMLA(img_size=args.imsize, mla_channels=D, num_classes=2).to(dev)
+        lr = args.lr * (args.batch_size_per_gpu * utils.get_world_size()) / 16.0  # linear scaling rule
+        engine = _engine_for(model, backbone_encoder, cross_vit, cross_cnn, seg_decoder, lr=lr, momentum=0.9, weight_decay=0.0)
+    else:
+        seg_decoder = FeatureDecoder(embed_dim=D, num_classes=2, features=[D, 512, 256, 128, 64]).to(dev)
+        engine = _engine_for(model, backbone_encoder, cross_vit, cross_cnn, seg_decoder, lr=args.lr)
+    optimizer = engine.optimizer
 
     dataset_val = _SegData(args.data_path, "validation", args.imsize)
     val_loader = torch.utils.data.DataLoader(dataset_val, batch_size=args.batch_size_per_gpu, num_workers=0, pin_memory=True)

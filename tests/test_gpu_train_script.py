@@ -48,3 +48,23 @@ def test_train_seg_end_to_end(dev, tmp_path):
     args.evaluate = True
     ev = T.train_seg(args)  # resumes from the checkpoint and only validates
     assert abs(ev["acc1"] - lines[1]["test_acc1"]) < 1e-6
+
+
+def test_train_mla_script(dev, tmp_path):
+    """`train_mla.py` drop-in: MLA head, linear-scaled lr, momentum 0.9 / no weight decay, `--local_rank` spelling."""
+    from adaptersis_amd import train_mla as TM
+    from adaptersis_amd.backbones.decoders import DecoderMLA
+    args = TM.get_args_parser().parse_args(["--arch", "vit_tiny_test", "--imsize", "224", "--batch_size_per_gpu", "4",
+                                            "--epochs", "2", "--lr", "0.08", "--data_path", "synthetic", "--local_rank", "0",
+                                            "--output_dir", str(tmp_path)])
+    T._ENGINES.clear()
+    TM.train_seg(args)
+    (eng,) = T._ENGINES.values()
+    assert isinstance(eng.seg_decoder, DecoderMLA) and eng.is_mla
+    g = eng.optimizer.param_groups[0]
+    assert g["momentum"] == 0.9 and g["weight_decay"] == 0.0 and abs(g["initial_lr"] - 0.08 * 4 / 16.0) < 1e-12
+    lines = [json.loads(l) for l in open(os.path.join(tmp_path, "log.txt"))]
+    assert len(lines) == 2 and lines[1]["train_loss"] < lines[0]["train_loss"]
+    ck = torch.load(os.path.join(tmp_path, "checkpoint.pth.tar"), map_location="cpu")
+    assert any(k.startswith("module.mlahead.") for k in ck["state_dict"])
+    T._ENGINES.clear()
