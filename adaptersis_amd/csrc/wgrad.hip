@@ -18,7 +18,8 @@ namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64, NTHREADS = 256;
 
-template <typename T>
+// DENSE: 1x1 / stride 1 / no padding (nn.Linear and 1x1 conv weight gradients): x row p is pixel p, no index arithmetic
+template <typename T, bool DENSE>
 __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const asis_wgrad_desc d) {
   typedef typename T16<T>::v8 v8;
   typedef s16x4 __attribute__((address_space(3))) * lds_tr_ptr;
@@ -56,7 +57,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const asis_wgrad_des
       uint4 va = make_uint4(0, 0, 0, 0), vb = va;
       if (p < k_end) {
         if (a_col_ok) va = *reinterpret_cast<const uint4*>(A + p * d.ld_dy + am);
-        if (b_col_ok) {
+        if (DENSE) {
+          if (b_col_ok) vb = *reinterpret_cast<const uint4*>(X + p * d.Cin + bn);
+        } else if (b_col_ok) {
           const int b = (int)(p / ohw);
           const int rem = (int)(p - (int64_t)b * ohw);
           const int oh = rem / d.OW, ow = rem - oh * d.OW;
@@ -189,8 +192,14 @@ extern "C" int asis_wgrad(void* stream, const asis_wgrad_desc* dp) {
   ASIS_REQUIRE((int64_t)d.k_per_split * d.splits >= d.P, "asis_wgrad: internal split error");
   dim3 grid((unsigned)(asis_cdiv(d.Cout, BM) * asis_cdiv(Ntot, BN)), d.splits), block(NTHREADS);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (d.dtype == ASIS_F16) hipLaunchKernelGGL((wgrad_kernel<f16>), grid, block, 0, s, d);
-  else hipLaunchKernelGGL((wgrad_kernel<bf16>), grid, block, 0, s, d);
+  const bool dense = d.KH == 1 && d.KW == 1 && d.stride == 1 && d.pad == 0;
+  if (d.dtype == ASIS_F16) {
+    if (dense) hipLaunchKernelGGL((wgrad_kernel<f16, true>), grid, block, 0, s, d);
+    else hipLaunchKernelGGL((wgrad_kernel<f16, false>), grid, block, 0, s, d);
+  } else {
+    if (dense) hipLaunchKernelGGL((wgrad_kernel<bf16, true>), grid, block, 0, s, d);
+    else hipLaunchKernelGGL((wgrad_kernel<bf16, false>), grid, block, 0, s, d);
+  }
   ASIS_CHECK_LAUNCH("asis_wgrad");
   return ASIS_OK;
 }
