@@ -48,6 +48,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const asis_wgrad_des
   const int ci = bn - tap * d.Cin;
   const int kh = tap / d.KW, kw = tap - kh * d.KW;
   const int ohw = d.OH * d.OW;
+  const bool small_p = d.P < (1 << 24);
+  const float inv_ohw = 1.0f / (float)ohw, inv_ow = 1.0f / (float)d.OW;
 
   uint4 ra[4], rb[4];
   auto load_tile = [&](int64_t k0) {
@@ -60,9 +62,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const asis_wgrad_des
         if (DENSE) {
           if (b_col_ok) vb = *reinterpret_cast<const uint4*>(X + p * d.Cin + bn);
         } else if (b_col_ok) {
-          const int b = (int)(p / ohw);
-          const int rem = (int)(p - (int64_t)b * ohw);
-          const int oh = rem / d.OW, ow = rem - oh * d.OW;
+          int b, rem, oh, ow;
+          if (small_p) {  // P < 2^24: quotients from an fp32 reciprocal estimate + one correction step (exact), ~8 VALU
+            b = (int)((float)(int)p * inv_ohw);   // instead of two ~30-instruction integer divisions per staged row
+            rem = (int)p - b * ohw;
+            if (rem < 0) { --b; rem += ohw; } else if (rem >= ohw) { ++b; rem -= ohw; }
+            oh = (int)((float)rem * inv_ow);
+            ow = rem - oh * d.OW;
+            if (ow < 0) { --oh; ow += d.OW; } else if (ow >= d.OW) { ++oh; ow -= d.OW; }
+          } else {
+            b = (int)(p / ohw);
+            rem = (int)(p - (int64_t)b * ohw);
+            oh = rem / d.OW;
+            ow = rem - oh * d.OW;
+          }
           const int ih = oh * d.stride + kh - d.pad, iw = ow * d.stride + kw - d.pad;
           if ((unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W)
             vb = *reinterpret_cast<const uint4*>(X + (((int64_t)b * d.H + ih) * d.W + iw) * d.Cin + ci);
