@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void colsum16_kernel(const T* __restrict__ x, 
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
   int64_t r1 = r0 + rows_per_block;
   if (r1 > rows) r1 = rows;
-  for (int c8 = threadIdx.x; c8 < (C >> 3); c8 += blockDim.x) {
+  for (int c8 = blockIdx.y * blockDim.x + threadIdx.x; c8 < (C >> 3); c8 += gridDim.y * blockDim.x) {
     float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int64_t r = r0; r < r1; ++r) {
       const v8 v = *reinterpret_cast<const v8*>(x + r * ld + c8 * 8);
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void colsum32_kernel(const float* __restrict__
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
   int64_t r1 = r0 + rows_per_block;
   if (r1 > rows) r1 = rows;
-  for (int c4 = threadIdx.x; c4 < (C >> 2); c4 += blockDim.x) {
+  for (int c4 = blockIdx.y * blockDim.x + threadIdx.x; c4 < (C >> 2); c4 += gridDim.y * blockDim.x) {
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int64_t r = r0; r < r1; ++r) {
       const float4 v = *reinterpret_cast<const float4*>(x + r * ld + c4 * 4);
@@ -332,9 +332,15 @@ extern "C" int asis_colsum(void* stream, int dtype, const void* x, int64_t ld, f
   const int nblk = asis_rowblock_nblk(rows);
   const int rpb = (int)((rows + nblk - 1) / nblk);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == ASIS_F16) hipLaunchKernelGGL((colsum16_kernel<f16>), dim3(nblk), dim3(256), 0, s, (const f16*)x, ld, partial, rows, C, rpb);
-  else if (dtype == ASIS_BF16) hipLaunchKernelGGL((colsum16_kernel<bf16>), dim3(nblk), dim3(256), 0, s, (const bf16*)x, ld, partial, rows, C, rpb);
-  else hipLaunchKernelGGL(colsum32_kernel, dim3(nblk), dim3(256), 0, s, (const float*)x, ld, partial, rows, C, rpb);
+  // gridDim.y walks the columns (256 threads x 8 / 4 columns each), so few-rows x very-wide inputs (the batch sum of a
+  // [B, tokens*D] gradient) still fill the chip
+  const int per = dtype == ASIS_F32 ? 4 : 8;
+  int gy = (C / per + 255) / 256;
+  if (gy > 4096) gy = 4096;
+  if (gy < 1) gy = 1;
+  if (dtype == ASIS_F16) hipLaunchKernelGGL((colsum16_kernel<f16>), dim3(nblk, gy), dim3(256), 0, s, (const f16*)x, ld, partial, rows, C, rpb);
+  else if (dtype == ASIS_BF16) hipLaunchKernelGGL((colsum16_kernel<bf16>), dim3(nblk, gy), dim3(256), 0, s, (const bf16*)x, ld, partial, rows, C, rpb);
+  else hipLaunchKernelGGL(colsum32_kernel, dim3(nblk, gy), dim3(256), 0, s, (const float*)x, ld, partial, rows, C, rpb);
   ASIS_CHECK_LAUNCH("asis_colsum");
   return ASIS_OK;
 }
