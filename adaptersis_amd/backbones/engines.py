@@ -288,7 +288,8 @@ class SegEngine(nn.Module):
         return logits
 
     @torch.no_grad()
-    def validate_step(self, inp: torch.Tensor, target: torch.Tensor, ce_weight: Optional[torch.Tensor] = None):
+    def validate_step(self, inp: torch.Tensor, target: torch.Tensor, ce_weight: Optional[torch.Tensor] = None,
+                      with_counts: bool = False):
         """`train.py:465-642` for one batch: -> device tensor [4] = (weighted CE, dice, pixel accuracy, n_images).
         The decoder runs in eval mode (running BatchNorm statistics, `train.py:451`); the encoder's SyncBatchNorm
         stays in train mode exactly like the reference."""
@@ -297,9 +298,12 @@ class SegEngine(nn.Module):
         logits = self.eval_logits(inp)
         self.seg_decoder.train(was)
         target = target.long().contiguous()
-        m = ops.ce_acc(logits, target, ce_weight)
+        if with_counts:  # + per-class pixel counts [C,3] for ch_iou / isi_iou (train_multi_class.py:582-589)
+            m, counts = ops.ce_acc(logits, target, ce_weight, counts=True)
+        else:
+            m = ops.ce_acc(logits, target, ce_weight)
         loss1, _, _ = ops.dice_fwd(logits, target, 1, 10e-20, 1.0)
-        return m, loss1
+        return (m, loss1, counts) if with_counts else (m, loss1)
 
 
 class EndToEndEngine(nn.Module):
