@@ -188,7 +188,11 @@ def main():
 
     from adaptersis_amd import config, ops
     from adaptersis_amd.build import build_library
-    build_library()
+    # one builder per node (normally a no-op: the prebuilt in-tree .so is up to date); the other ranks wait for it
+    if local == 0:
+        build_library()
+    if world > 1:
+        dist.barrier()
     if a.operand:
         config.set_operand_dtype(torch.float16 if a.operand == "f16" else torch.bfloat16)
         config.loss_scale = 65536.0 if a.operand == "f16" else 1.0
