@@ -65,7 +65,24 @@ def build_engine_cfg(cfg: int, arch: str, dev, lr: float):
 
     D, depth, heads, ffn = W.VIT_CONFIGS[arch]
     model = vits.__dict__[arch](patch_size=14, img_size=518, init_values=1e-5, ffn_layer=ffn, block_chunks=0)
-    model.load_state_dict(W.make_vit_state_dict(arch, layerscale="kernel"))
+    if arch == "vit_giant2":
+        # 1.1 B parameters: the name-keyed CPU Philox generator of the parity tests takes minutes; the bench only needs
+        # well-scaled random weights, drawn on the device (same distributions: U(-a, a) with a = sqrt(3 / fan_in) etc.)
+        model = model.to(dev)
+        g = torch.Generator(device=dev).manual_seed(0)
+        with torch.no_grad():
+            for n, p in model.named_parameters():
+                if p.dim() >= 2 and "pos_embed" not in n and "cls_token" not in n and "mask_token" not in n:
+                    fan_in = p[0].numel()
+                    p.copy_((torch.rand(p.shape, device=dev, generator=g) * 2 - 1) * (3.0 / fan_in) ** 0.5)
+                elif n.endswith("gamma"):
+                    p.copy_(0.05 + 0.45 * torch.rand(p.shape, device=dev, generator=g))
+                elif "norm" in n and n.endswith("weight"):
+                    p.copy_(1.0 + 0.2 * (torch.rand(p.shape, device=dev, generator=g) - 0.5))
+                else:
+                    p.copy_(0.2 * (torch.rand(p.shape, device=dev, generator=g) - 0.5))
+    else:
+        model.load_state_dict(W.make_vit_state_dict(arch, layerscale="kernel"))
     if cfg == 4:
         dec = DecoderSETR(D, 2)
         dec.load_state_dict(W.make_setr_state_dict(D, 2))
@@ -76,18 +93,29 @@ def build_engine_cfg(cfg: int, arch: str, dev, lr: float):
     cv.load_state_dict(W.make_cavit_state_dict(D, mode="kernel"))
     cn = CACNN(dim=D, n_levels=1, num_heads=8, n_points=4, with_cffn=True, cffn_ratio=0.25)
     cn.load_state_dict(W.make_cacnn_state_dict(D, mode="kernel"))
+    if cfg == 5:
+        from adaptersis_amd.backbones.decoders import DecoderMLA
+        dec = DecoderMLA(img_size=588, mla_channels=D, num_classes=11)
+        dec.load_state_dict(W.make_decoder_mla_state_dict(D, 128, 11))
+        return SegEngine(model.to(dev).eval(), enc.to(dev), cv.to(dev), cn.to(dev), dec.to(dev), lr=lr, momentum=0.9,
+                         weight_decay=0.0, num_classes=11, loss="iou")
     dec = UNet(D, 2)
     dec.load_state_dict(W.make_unet_state_dict(D, 2))
     return SegEngine(model.to(dev).eval(), enc.to(dev), cv.to(dev), cn.to(dev), dec.to(dev), lr=lr, loss="ce_dc")
 
 
-def synthetic(batch: int, size: int, rank: int, dev):
+def synthetic(batch: int, size: int, rank: int, dev, num_classes: int = 2):
     """images U[0,1) (no mean/std normalisation), binary masks ~30 % foreground, one
-    all-background image per batch (Dice epsilon path); generator seeded 0 + rank."""
+    all-background image per batch (Dice epsilon path); multi-class: piecewise-constant 14x14 blocks; seed 0 + rank."""
     g = torch.Generator(device="cpu").manual_seed(rank)
     img = torch.rand(batch, 3, size, size, generator=g)
-    tgt = (torch.rand(batch, size, size, generator=g) > 0.7).long()
-    tgt[-1].zero_()
+    if num_classes == 2:
+        tgt = (torch.rand(batch, size, size, generator=g) > 0.7).long()
+        tgt[-1].zero_()
+    else:
+        gsz = (size + 13) // 14
+        blocks = torch.randint(0, num_classes, (batch, gsz, gsz), generator=g)
+        tgt = blocks.repeat_interleave(14, 1).repeat_interleave(14, 2)[:, :size, :size].contiguous()
     return img.to(dev), tgt.to(dev)
 
 
@@ -167,8 +195,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=12, help="images per GPU (README.md:45-61 of the reference)")
     ap.add_argument("--arch", default=None)
-    ap.add_argument("--config", type=int, default=3, choices=[2, 3, 4],
-                    help="BASELINE.json config: 3 = the headline metric (default); 2 = ViT-B + UNet head; 4 = unfrozen end-to-end")
+    ap.add_argument("--config", type=int, default=3, choices=[2, 3, 4, 5],
+                    help="BASELINE.json config: 3 = the headline metric (default); 2 = ViT-B + UNet head; 4 = unfrozen end-to-end; 5 = ViT-g + MLA head, 11 classes")
     ap.add_argument("--size", type=int, default=588)
     ap.add_argument("--operand", default=None, choices=[None, "f16", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -197,9 +225,9 @@ def main():
         config.set_operand_dtype(torch.float16 if a.operand == "f16" else torch.bfloat16)
         config.loss_scale = 65536.0 if a.operand == "f16" else 1.0
 
-    a.arch = a.arch or ("vit_base" if a.config == 2 else "vit_large")
+    a.arch = a.arch or {2: "vit_base", 5: "vit_giant2"}.get(a.config, "vit_large")
     eng = build_engine(a.arch, dev, lr=0.01) if a.config == 3 else build_engine_cfg(a.config, a.arch, dev, lr=0.01)
-    img, tgt = synthetic(a.batch, a.size, rank, dev)
+    img, tgt = synthetic(a.batch, a.size, rank, dev, 11 if a.config == 5 else 2)
 
     def barrier():
         if world > 1:
@@ -257,6 +285,8 @@ def main():
                    "(fwd + decoder bwd + all-reduce + SGD), random-init weights",
                 2: f"BASELINE config 2: {a.arch}/14 frozen + CAViT/CACNN adapters + UNet head, CE + DC loss, "
                    f"{a.size}x{a.size}, batch {a.batch}/GPU (fwd + UNet bwd + all-reduce + SGD), random-init weights",
+                5: f"BASELINE config 5: {a.arch}/14 (SwiGLU) frozen + CAViT/CACNN adapters + DecoderMLA head, 11 classes, soft-IoU "
+                   f"loss (train_mla.py / train_multi_class.py flow), {a.size}x{a.size}, batch {a.batch}/GPU, random-init weights",
                 4: f"BASELINE config 4: {a.arch}/14 unfrozen end-to-end + DecoderSETR, CE + DC loss, {a.size}x{a.size}, "
                    f"batch {a.batch}/GPU (fwd + full bwd incl. all ViT blocks + full-gradient all-reduce + decoder SGD), "
                    "random-init weights"}[a.config],
