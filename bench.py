@@ -261,6 +261,13 @@ def main():
         flops = sum(f for f, _ in dense) / n
         avg_ms = sum(t for _, t in dense) / n
         conv = [(f, s.elapsed_time(e)) for (kind, f, s, e, _) in prof if kind == "conv"]
+        if os.environ.get("ASIS_BENCH_SHAPES") and rank == 0:  # per-shape table (flops identify the shape) on stderr
+            by = {}
+            for (kind, f, s, e, nb) in prof:
+                by.setdefault((kind, f, nb), []).append(s.elapsed_time(e))
+            for (kind, f, nb), ts in sorted(by.items(), key=lambda kv: -sum(kv[1])):
+                print(f"  {kind:5s} {f / 1e9:9.1f} GF {nb / 1e6:8.1f} MB  x{len(ts) // a.steps:3d}/step  avg {sum(ts) / len(ts) * 1e3:8.1f} us  "
+                      f"{f / (sum(ts) / len(ts)) / 1e9:7.1f} TF/s  total {sum(ts) / a.steps:7.2f} ms/step", file=sys.stderr)
         achieved = flops / (avg_ms * 1e-3) / 1e12
         roof = {"bound": "mfma", "kernel": "gemm_big_kernel<T,4,2,2,2,3,0,false,false,32,4> = 256x128x32 LDS-DMA MFMA GEMM (all dense GEMM launches of the step)",
                 "achieved": round(achieved, 1), "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
