@@ -130,8 +130,13 @@ class Attention(_Packed):
             r1 = r0 + B * N
             ldvt = (N + 63) // 64 * 64
             vt = torch.empty((B, D, ldvt), device=xn.device, dtype=xn.dtype)
-            ops.gemm(w[2 * D:], xn[r0:r1].view(B, N, D), out=vt.as_strided((B, D, N), (D * ldvt, ldvt, 1)),
-                     bias_m=None if bias is None else bias[2 * D:])
+            # N rounded up to 4 keeps the vector epilogue (N = 1765 fell to the scalar one: 101 vs 69 us); the extra
+            # columns land in V^T's pad region, which the attention kernel zeroes in registers, and their operand rows
+            # are the first tokens of the next image (the last image reads the spare rows behind ``xn``)
+            spare = xn.untyped_storage().nbytes() // xn.element_size() - (xn.storage_offset() + xn.shape[0] * D)
+            N4 = (N + 3) // 4 * 4 if spare >= 4 * D else N
+            ops.gemm(w[2 * D:], xn[r0:r1].as_strided((B, N4, D), (N * D, D, 1)),
+                     out=vt.as_strided((B, D, N4), (D * ldvt, ldvt, 1)), bias_m=None if bias is None else bias[2 * D:])
             ops.attention_fwd(qk[r0:r1, :D], qk[r0:r1, D:], vt, B, self.num_heads, N, self.scale, out=o[r0:r1])
             r0 = r1
         if r0 != xn.shape[0]:
@@ -213,8 +218,8 @@ class Block(_Packed):
         dt = config.operand_dtype
         g1 = self._f32("g1", self.ls1.gamma) if isinstance(self.ls1, LayerScale) else None
         g2 = self._f32("g2", self.ls2.gamma) if isinstance(self.ls2, LayerScale) else None
-        xn = ops.layernorm(x2, self._f32("n1w", self.norm1.weight), self._f32("n1b", self.norm1.bias),
-                           self.norm1.eps, dt)
+        xn = torch.empty((x2.shape[0] + 4, D), device=x2.device, dtype=dt)[: x2.shape[0]]   # 4 spare rows: see attend_rows
+        ops.layernorm(x2, self._f32("n1w", self.norm1.weight), self._f32("n1b", self.norm1.bias), self.norm1.eps, dt, out=xn)
         o = self.attn.attend_rows(xn, segs)
         x1 = ops.gemm(o, self.attn._w16("proj", self.attn.proj.weight), out_f32=True,
                       bias_n=self.attn._f32("proj_b", self.attn.proj.bias), scale_n=g1, res=x2)
