@@ -269,7 +269,7 @@ def main():
                 print(f"  {kind:5s} {f / 1e9:9.1f} GF {nb / 1e6:8.1f} MB  x{len(ts) // a.steps:3d}/step  avg {sum(ts) / len(ts) * 1e3:8.1f} us  "
                       f"{f / (sum(ts) / len(ts)) / 1e9:7.1f} TF/s  total {sum(ts) / a.steps:7.2f} ms/step", file=sys.stderr)
         achieved = flops / (avg_ms * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": "gemm_big_kernel<T,4,2,2,2,3,0,false,false,32,4> = 256x128x32 LDS-DMA MFMA GEMM (all dense GEMM launches of the step)",
+        roof = {"bound": "mfma", "kernel": "gemm_big_kernel (csrc/gemm_big.h): 256x128x32 LDS-DMA MFMA GEMM, 8-phase 256x256x64 form for K >= 2048 (all dense GEMM launches of the step)",
                 "achieved": round(achieved, 1), "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / MFMA_F16_DENSE_PEAK_TFLOPS, 4), "traffic": pmc_traffic("gemm_big_kernel", "Lb0ELb0ELi32ELi4E"),
                 "launches_per_step": n // a.steps, "avg_launch_ms": round(avg_ms, 4),
