@@ -77,6 +77,9 @@ SIGNATURES = {
     "asis_transpose_tokens": [_vp, _i, _vp, _i64, _vp, _i64, _i, _i, _i],
     "asis_attention_bwd": [_vp, _i, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp,
                            _i64, _i, _i, _i, _f],
+    "asis_msda_bwd": [_vp, _i, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i],
+    "asis_dwconv_bwd_nblk": [_i64],
+    "asis_dwconv_gelu_bwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i],
     "asis_rowblock_nblk": [_i64],
     "asis_layernorm_bwd": [_vp, _vp, _i64, _vp, _i64, _vp, _f, _vp, _i64, _vp, _i64, _vp, _i64, _i],
     "asis_gelu16": [_vp, _i, _vp, _vp, _vp, _i64],

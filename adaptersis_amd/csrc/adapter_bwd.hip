@@ -1,0 +1,315 @@
+// Backward kernels of the adapter modules (`train_adapters` mode: the gradients the reference's optimiser lists but
+// its graph cut never produces — SURVEY.md fact 1 — and that its MSDeformAttnFunction cannot compute — fact 2):
+//
+//   msda_bwd        transpose of msda_fwd (msda.hip; ms_deform_attn.py:33-54,155-166 under autograd):
+//                     out[q,m,:] = sum_j A_j S_j,  A = softmax_j(logit),  S_j = bilinear(value_l(j)[.., m, :], pix_j),
+//                     pix_j = ref*(W,H) + off_j - 0.5
+//                   d value  += A_j * bw_t * d out        (scatter over the 4 taps: fp32 global atomics — the one
+//                                                          place in this library whose summation order is not fixed)
+//                   d off_j   = A_j * <d out, dS_j/d pix>  (zero-padded taps contribute nothing)
+//                   d logit_j = A_j * (<d out, S_j> - sum_k A_k <d out, S_k>)
+//   dwconv_gelu_bwd transpose of dwconv_gelu (adapter_blocks.py:67-80,95-97): g = d y * gelu'(dwconv(x) + b) with the
+//                   pre-activation recomputed, per-block partial sums of d bias and d w[9]; dwconv_t then correlates g
+//                   with the taps (depthwise transposed conv) into the 16-bit operand of fc1's backward.
+#include "asis_common.h"
+
+namespace {
+
+constexpr int MAX_LP = 16;
+constexpr int MAX_M = 32;
+
+template <typename T>
+__global__ __launch_bounds__(256) void msda_bwd_kernel(const T* __restrict__ value, const float* __restrict__ offaw,
+                                                       int64_t ld_offaw, const float* __restrict__ ref,
+                                                       const int* __restrict__ shapes, const int* __restrict__ starts,
+                                                       const float* __restrict__ dout, float* __restrict__ dvalue,
+                                                       float* __restrict__ doffaw, int B, int Lq, int Lin, int M, int L,
+                                                       int P, int Dh) {
+  __shared__ float red[MAX_M * MAX_LP * 3];  // [m][j][{<dout,S>, <dout,dS/dx>, <dout,dS/dy>}]
+  const int D = M * Dh;
+  const int cpq = D >> 3, cph = Dh >> 3;
+  const int LP = L * P;
+  const int c = threadIdx.x;
+  const bool live = c < cpq;
+  const int m = live ? c / cph : 0;
+  for (int64_t bq = blockIdx.x; bq < (int64_t)B * Lq; bq += gridDim.x) {
+    const int q = (int)(bq % Lq);
+    const int b = (int)(bq / Lq);
+    const float* orow = offaw + bq * ld_offaw;
+    for (int i = threadIdx.x; i < M * LP * 3; i += blockDim.x) red[i] = 0.f;
+    __syncthreads();
+    if (live) {
+      const float* lg = orow + (int64_t)M * LP * 2 + m * LP;
+      float w[MAX_LP];
+      float mx = -1e30f;
+#pragma unroll
+      for (int j = 0; j < MAX_LP; ++j)
+        if (j < LP) {
+          w[j] = lg[j];
+          mx = fmaxf(mx, w[j]);
+        }
+      float den = 0.f;
+#pragma unroll
+      for (int j = 0; j < MAX_LP; ++j)
+        if (j < LP) {
+          w[j] = __expf(w[j] - mx);
+          den += w[j];
+        }
+      const float inv = 1.0f / den;
+      const float rx = ref[2 * q], ry = ref[2 * q + 1];
+      float g[8];
+      {
+        const float4 g0 = *reinterpret_cast<const float4*>(dout + bq * D + c * 8);
+        const float4 g1 = *reinterpret_cast<const float4*>(dout + bq * D + c * 8 + 4);
+        g[0] = g0.x; g[1] = g0.y; g[2] = g0.z; g[3] = g0.w; g[4] = g1.x; g[5] = g1.y; g[6] = g1.z; g[7] = g1.w;
+      }
+      const T* vb = value + (int64_t)b * Lin * D + c * 8;
+      float* dvb = dvalue + (int64_t)b * Lin * D + c * 8;
+      for (int l = 0; l < L; ++l) {
+        const int Hl = shapes[2 * l], Wl = shapes[2 * l + 1];
+        const T* vl = vb + (int64_t)starts[l] * D;
+        float* dvl = dvb + (int64_t)starts[l] * D;
+        for (int p = 0; p < P; ++p) {
+          const int j = l * P + p;
+          const float ox = orow[(m * LP + j) * 2], oy = orow[(m * LP + j) * 2 + 1];
+          const float lx = rx + ox / (float)Wl, ly = ry + oy / (float)Hl;   // as msda_fwd (same taps chosen)
+          const float px = lx * (float)Wl - 0.5f, py = ly * (float)Hl - 0.5f;
+          const float fx0 = floorf(px), fy0 = floorf(py);
+          const float ax = px - fx0, ay = py - fy0;
+          const int x0 = (int)fminf(fmaxf(fx0, -2.f), (float)Wl + 1.f);
+          const int y0 = (int)fminf(fmaxf(fy0, -2.f), (float)Hl + 1.f);
+          const float aw = w[j] * inv;
+          float s_dot = 0.f, sx = 0.f, sy = 0.f;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int xx = x0 + (t & 1), yy = y0 + (t >> 1);
+            if ((unsigned)xx < (unsigned)Wl && (unsigned)yy < (unsigned)Hl) {
+              const float bx = (t & 1) ? ax : 1.f - ax, by = (t >> 1) ? ay : 1.f - ay;
+              const float dbx = (t & 1) ? 1.f : -1.f, dby = (t >> 1) ? 1.f : -1.f;
+              const int64_t o = ((int64_t)yy * Wl + xx) * D;
+              const uint4 raw = *reinterpret_cast<const uint4*>(vl + o);
+              const uint32_t* pw = reinterpret_cast<const uint32_t*>(&raw);
+              float dotv = 0.f;
+              const float wv = aw * bx * by;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                float f0, f1;
+                unpack2<T>(pw[e], f0, f1);
+                dotv += g[2 * e] * f0 + g[2 * e + 1] * f1;
+                atomicAdd(dvl + o + 2 * e, wv * g[2 * e]);
+                atomicAdd(dvl + o + 2 * e + 1, wv * g[2 * e + 1]);
+              }
+              s_dot += bx * by * dotv;
+              sx += dbx * by * dotv;
+              sy += bx * dby * dotv;
+            }
+          }
+          float* r = red + (m * LP + j) * 3;
+          atomicAdd(r + 0, s_dot);
+          atomicAdd(r + 1, sx);
+          atomicAdd(r + 2, sy);
+        }
+      }
+    }
+    __syncthreads();
+    // one thread per head: softmax backward over (l, p) and the offset gradients
+    if ((int)threadIdx.x < M) {
+      const int mm = threadIdx.x;
+      const float* lg = orow + (int64_t)M * LP * 2 + mm * LP;
+      float w[MAX_LP];
+      float mx = -1e30f;
+      for (int j = 0; j < LP; ++j) {
+        w[j] = lg[j];
+        mx = fmaxf(mx, w[j]);
+      }
+      float den = 0.f;
+      for (int j = 0; j < LP; ++j) {
+        w[j] = __expf(w[j] - mx);
+        den += w[j];
+      }
+      const float inv = 1.0f / den;
+      float dot = 0.f;
+      for (int j = 0; j < LP; ++j) dot += w[j] * inv * red[(mm * LP + j) * 3];
+      float* drow = doffaw + bq * ld_offaw;
+      for (int j = 0; j < LP; ++j) {
+        const float aw = w[j] * inv;
+        drow[(mm * LP + j) * 2 + 0] = aw * red[(mm * LP + j) * 3 + 1];
+        drow[(mm * LP + j) * 2 + 1] = aw * red[(mm * LP + j) * 3 + 2];
+        drow[M * LP * 2 + mm * LP + j] = aw * (red[(mm * LP + j) * 3] - dot);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ---- DWConv 3x3 + GELU backward ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void locate(int tok, const int* shapes, const int* starts, int L, int& l, int& y, int& x, int& H,
+                                       int& W, int& s0) {
+  l = 0;
+  for (int k = 1; k < L; ++k)
+    if (tok >= starts[k]) l = k;
+  H = shapes[2 * l];
+  W = shapes[2 * l + 1];
+  s0 = starts[l];
+  const int r = tok - s0;
+  y = r / W;
+  x = r - y * W;
+}
+
+// g[b,tok,c] = dy * gelu'(dwconv(x)[tok] + bias);  partial[blk][10][C]: rows 0..8 = d w9[tap] = sum g * x[tok+tap], row 9 = d bias.
+// Block = 256 threads = (C/4 channel chunks) x (rows): a thread keeps its channel chunk (C/4 must divide 256).
+__global__ __launch_bounds__(256) void dwconv_gelu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w9,
+                                                              const float* __restrict__ bias, const int* __restrict__ shapes,
+                                                              const int* __restrict__ starts, int L,
+                                                              const float* __restrict__ dy, float* __restrict__ g,
+                                                              float* __restrict__ partial, int B, int Ntok, int C,
+                                                              int rows_per_block) {
+  __shared__ float red[256 * 4];
+  const int cpt = C >> 2;
+  const int rw = 256 / cpt;
+  const int cx = threadIdx.x % cpt, ry = threadIdx.x / cpt;
+  const int64_t rows = (int64_t)B * Ntok;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  int64_t r1 = r0 + rows_per_block;
+  if (r1 > rows) r1 = rows;
+  float4 wt[9], acc[10];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) wt[t] = reinterpret_cast<const float4*>(w9 + (int64_t)t * C)[cx];
+  const float4 bs = reinterpret_cast<const float4*>(bias)[cx];
+#pragma unroll
+  for (int t = 0; t < 10; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int64_t row = r0 + ry; row < r1; row += rw) {
+    const int b = (int)(row / Ntok), tok = (int)(row - (int64_t)b * Ntok);
+    int l, y, xx, H, W, s0;
+    locate(tok, shapes, starts, L, l, y, xx, H, W, s0);
+    const float* xb = x + ((int64_t)b * Ntok + s0) * C;
+    float4 pre = bs, xv[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int yy = y + t / 3 - 1, x2 = xx + t % 3 - 1;
+      xv[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if ((unsigned)yy < (unsigned)H && (unsigned)x2 < (unsigned)W) {
+        xv[t] = reinterpret_cast<const float4*>(xb + ((int64_t)yy * W + x2) * C)[cx];
+        pre.x += wt[t].x * xv[t].x; pre.y += wt[t].y * xv[t].y; pre.z += wt[t].z * xv[t].z; pre.w += wt[t].w * xv[t].w;
+      }
+    }
+    const float4 d = reinterpret_cast<const float4*>(dy + row * C)[cx];
+    float4 gg;
+    gg.x = d.x * gelu_erf_grad(pre.x); gg.y = d.y * gelu_erf_grad(pre.y);
+    gg.z = d.z * gelu_erf_grad(pre.z); gg.w = d.w * gelu_erf_grad(pre.w);
+    reinterpret_cast<float4*>(g + row * C)[cx] = gg;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      acc[t].x += gg.x * xv[t].x; acc[t].y += gg.y * xv[t].y; acc[t].z += gg.z * xv[t].z; acc[t].w += gg.w * xv[t].w;
+    }
+    acc[9].x += gg.x; acc[9].y += gg.y; acc[9].z += gg.z; acc[9].w += gg.w;
+  }
+  // fold the rw row lanes of each channel chunk, one accumulator at a time
+  for (int t = 0; t < 10; ++t) {
+    reinterpret_cast<float4*>(red)[threadIdx.x] = acc[t];
+    __syncthreads();
+    if (ry == 0) {
+      float4 s = acc[t];
+      for (int k = 1; k < rw; ++k) {
+        const float4 o = reinterpret_cast<const float4*>(red)[k * cpt + cx];
+        s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+      }
+      reinterpret_cast<float4*>(partial + ((int64_t)blockIdx.x * 10 + t) * C)[cx] = s;
+    }
+    __syncthreads();
+  }
+}
+
+// dx[tok] = sum_taps w9[tap] * g[tok - tap offset]  (depthwise transposed conv = correlation with the mirrored taps) -> 16-bit
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv_t_kernel(const float* __restrict__ g, const float* __restrict__ w9,
+                                                       const int* __restrict__ shapes, const int* __restrict__ starts, int L,
+                                                       T* __restrict__ out, int B, int Ntok, int C) {
+  const int cpt = C >> 2;
+  const int64_t total = (int64_t)B * Ntok * cpt;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cpt);
+    const int64_t row = i / cpt;
+    const int b = (int)(row / Ntok), tok = (int)(row - (int64_t)b * Ntok);
+    int l, y, xx, H, W, s0;
+    locate(tok, shapes, starts, L, l, y, xx, H, W, s0);
+    const float* gb = g + ((int64_t)b * Ntok + s0) * C;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      // forward: pre[y'] += w[t] * x[y' + dt]; so x[y] receives w[t] * g[y - dt]
+      const int yy = y - (t / 3 - 1), x2 = xx - (t % 3 - 1);
+      if ((unsigned)yy < (unsigned)H && (unsigned)x2 < (unsigned)W) {
+        const float4 gv = reinterpret_cast<const float4*>(gb + ((int64_t)yy * W + x2) * C)[c];
+        const float4 wv = reinterpret_cast<const float4*>(w9 + (int64_t)t * C)[c];
+        a.x += wv.x * gv.x; a.y += wv.y * gv.y; a.z += wv.z * gv.z; a.w += wv.w * gv.w;
+      }
+    }
+    uint2 o;
+    o.x = pack2<T>(a.x, a.y);
+    o.y = pack2<T>(a.z, a.w);
+    reinterpret_cast<uint2*>(out)[i] = o;
+  }
+}
+
+}  // namespace
+
+#define DT_OK(dtype, name) ASIS_REQUIRE(dtype == ASIS_F16 || dtype == ASIS_BF16, name ": bad dtype %d", dtype)
+
+extern "C" int asis_msda_bwd(void* stream, int dtype, const void* value, const float* offaw, int64_t ld_offaw,
+                             const float* ref, const int32_t* shapes, const int32_t* starts, const float* dout, float* dvalue,
+                             float* doffaw, int B, int Lq, int Lin, int M, int L, int P, int Dh) {
+  ASIS_REQUIRE(value && offaw && ref && shapes && starts && dout && dvalue && doffaw, "asis_msda_bwd: null pointer");
+  DT_OK(dtype, "asis_msda_bwd");
+  ASIS_REQUIRE(Dh % 8 == 0 && M >= 1 && M <= MAX_M && L * P >= 1 && L * P <= MAX_LP && M * Dh / 8 <= 256,
+               "asis_msda_bwd: need Dh %% 8 == 0, M <= %d, L*P <= %d, M*Dh <= 2048", MAX_M, MAX_LP);
+  ASIS_REQUIRE(ld_offaw >= (int64_t)M * L * P * 3, "asis_msda_bwd: ld_offaw too small");
+  ASIS_REQUIRE(asis_aligned16(value) && asis_aligned16(dout), "asis_msda_bwd: value / dout must be 16-byte aligned");
+  const int cpq = M * Dh / 8;
+  int threads = (cpq + 63) / 64 * 64;
+  if (threads < 64) threads = 64;
+  int64_t grid = (int64_t)B * Lq;
+  if (grid > 65535 * 8) grid = 65535 * 8;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == ASIS_F16)
+    hipLaunchKernelGGL((msda_bwd_kernel<f16>), dim3((unsigned)grid), dim3(threads), 0, s, reinterpret_cast<const f16*>(value), offaw,
+                       ld_offaw, ref, shapes, starts, dout, dvalue, doffaw, B, Lq, Lin, M, L, P, Dh);
+  else
+    hipLaunchKernelGGL((msda_bwd_kernel<bf16>), dim3((unsigned)grid), dim3(threads), 0, s, reinterpret_cast<const bf16*>(value), offaw,
+                       ld_offaw, ref, shapes, starts, dout, dvalue, doffaw, B, Lq, Lin, M, L, P, Dh);
+  ASIS_CHECK_LAUNCH("asis_msda_bwd");
+  return ASIS_OK;
+}
+
+extern "C" int asis_dwconv_bwd_nblk(int64_t rows) {
+  int64_t n = (rows + 63) / 64;
+  if (n > 1024) n = 1024;
+  if (n < 1) n = 1;
+  return (int)n;
+}
+
+extern "C" int asis_dwconv_gelu_bwd(void* stream, int dtype, const float* x, const float* w9, const float* bias,
+                                    const int32_t* shapes, const int32_t* starts, int L, const float* dy, float* g,
+                                    float* partial, void* dx, int B, int Ntok, int C) {
+  ASIS_REQUIRE(x && w9 && bias && shapes && starts && dy && g && partial && dx, "asis_dwconv_gelu_bwd: null pointer");
+  DT_OK(dtype, "asis_dwconv_gelu_bwd");
+  ASIS_REQUIRE(C % 4 == 0 && C >= 4 && C / 4 <= 256 && 256 % (C / 4) == 0,
+               "asis_dwconv_gelu_bwd: C=%d must be 4*2^k <= 1024", C);
+  ASIS_REQUIRE(L >= 1 && B > 0 && Ntok > 0, "asis_dwconv_gelu_bwd: bad shape");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int64_t rows = (int64_t)B * Ntok;
+  const int nblk = asis_dwconv_bwd_nblk(rows);
+  const int rpb = (int)((rows + nblk - 1) / nblk);
+  hipLaunchKernelGGL(dwconv_gelu_bwd_kernel, dim3(nblk), dim3(256), 0, s, x, w9, bias, shapes, starts, L, dy, g, partial, B, Ntok,
+                     C, rpb);
+  int64_t gsz = (rows * (C / 4) + 255) / 256;
+  if (gsz > 65535 * 4) gsz = 65535 * 4;
+  if (dtype == ASIS_F16)
+    hipLaunchKernelGGL((dwconv_t_kernel<f16>), dim3((unsigned)gsz), dim3(256), 0, s, g, w9, shapes, starts, L, reinterpret_cast<f16*>(dx),
+                       B, Ntok, C);
+  else
+    hipLaunchKernelGGL((dwconv_t_kernel<bf16>), dim3((unsigned)gsz), dim3(256), 0, s, g, w9, shapes, starts, L,
+                       reinterpret_cast<bf16*>(dx), B, Ntok, C);
+  ASIS_CHECK_LAUNCH("asis_dwconv_gelu_bwd");
+  return ASIS_OK;
+}

@@ -397,6 +397,34 @@ def dwconv_gelu(x: torch.Tensor, w9: torch.Tensor, bias: torch.Tensor, shapes_i3
 # --------------------------------------------------------------------------------------------
 # CNN encoder / decoder companions
 # --------------------------------------------------------------------------------------------
+def msda_bwd(value: torch.Tensor, offaw: torch.Tensor, ref: torch.Tensor, shapes_i32: torch.Tensor, starts_i32: torch.Tensor,
+             dout: torch.Tensor, B: int, Lq: int, M: int, L: int, P: int):
+    """value 16-bit [B, Lin, D]; offaw fp32 [B*Lq, M*L*P*3]; dout fp32 [B*Lq, D] ->
+    (dvalue fp32 [B, Lin, D], doffaw fp32 like offaw)."""
+    _dev(value, offaw, ref, shapes_i32, starts_i32, dout)
+    _, Lin, D = value.shape
+    dvalue = torch.zeros((B, Lin, D), device=value.device, dtype=torch.float32)
+    doffaw = torch.empty_like(offaw)
+    check(lib().asis_msda_bwd(_stream(), _dt(value.dtype), value.data_ptr(), _f32c(offaw).data_ptr(), offaw.stride(0),
+                              _f32c(ref).data_ptr(), shapes_i32.data_ptr(), starts_i32.data_ptr(), _f32c(dout).data_ptr(),
+                              dvalue.data_ptr(), doffaw.data_ptr(), B, Lq, Lin, M, L, P, D // M), "asis_msda_bwd")
+    return dvalue, doffaw
+
+
+def dwconv_gelu_bwd(x: torch.Tensor, w9: torch.Tensor, bias: torch.Tensor, shapes_i32: torch.Tensor, starts_i32: torch.Tensor,
+                    dy: torch.Tensor, dtype: torch.dtype):
+    """x, dy fp32 [B, Ntok, C] -> (dx 16-bit [B, Ntok, C], partial fp32 [nblk, 10, C] = d w9 (9 rows) and d bias)."""
+    _dev(x, w9, bias, shapes_i32, starts_i32, dy)
+    B, Ntok, Cc = x.shape
+    g = torch.empty_like(x)
+    partial = torch.empty((lib().asis_dwconv_bwd_nblk(B * Ntok), 10, Cc), device=x.device, dtype=torch.float32)
+    dx = torch.empty((B, Ntok, Cc), device=x.device, dtype=dtype)
+    check(lib().asis_dwconv_gelu_bwd(_stream(), _dt(dtype), _f32c(x).data_ptr(), _f32c(w9).data_ptr(), _f32c(bias).data_ptr(),
+                                     shapes_i32.data_ptr(), starts_i32.data_ptr(), shapes_i32.shape[0], _f32c(dy).data_ptr(),
+                                     g.data_ptr(), partial.data_ptr(), dx.data_ptr(), B, Ntok, Cc), "asis_dwconv_gelu_bwd")
+    return dx, partial
+
+
 def conv3x3_c3(img: torch.Tensor, w: torch.Tensor, stride: int, pad: int) -> torch.Tensor:
     _dev(img, w)
     B, _, H, W = img.shape

@@ -203,6 +203,24 @@ int asis_dwconv_gelu(void* stream, int dtype, const float* x, const float* w9, c
                      const int32_t* shapes, const int32_t* starts, int L, void* out, int B, int Ntok, int C);
 
 /* ---------------------------------------------------------------------------------------------
+ * Adapter backward (`train_adapters` mode; the autograd transposes of asis_msda_fwd and asis_dwconv_gelu).
+ * asis_msda_bwd: dout fp32 [B*Lq, M*Dh] = d(sampled output) -> dvalue fp32 [B, Lin, M*Dh] (ACCUMULATED with fp32
+ *   atomics into a caller-zeroed buffer: the only non-deterministic summation order of the library) and doffaw fp32
+ *   [B*Lq, ld_offaw] in the layout of offaw (d offsets, then d logits with the softmax over L*P already applied).
+ *   M <= 32, L*P <= 16, M*Dh <= 2048.
+ * asis_dwconv_gelu_bwd: x (input of the depthwise conv, fp32 [B, Ntok, C]), dy fp32 = d(GELU output) ->
+ *   g fp32 scratch [B, Ntok, C] (= d pre-activation), partial[asis_dwconv_bwd_nblk(B*Ntok)][10][C] (rows 0..8: d w9[tap],
+ *   row 9: d bias; sum with asis_reduce_rows) and dx 16-bit [B, Ntok, C] = d x.  C = 4*2^k <= 1024.
+ * ------------------------------------------------------------------------------------------- */
+int asis_msda_bwd(void* stream, int dtype, const void* value, const float* offaw, int64_t ld_offaw, const float* ref,
+                  const int32_t* shapes, const int32_t* starts, const float* dout, float* dvalue, float* doffaw, int B,
+                  int Lq, int Lin, int M, int L, int P, int Dh);
+int asis_dwconv_bwd_nblk(int64_t rows);
+int asis_dwconv_gelu_bwd(void* stream, int dtype, const float* x, const float* w9, const float* bias, const int32_t* shapes,
+                         const int32_t* starts, int L, const float* dy, float* g, float* partial, void* dx, int B, int Ntok,
+                         int C);
+
+/* ---------------------------------------------------------------------------------------------
  * CNN encoder / decoder companions (backbones/encoders.py:9-47, backbones/decoders.py:109-135).
  * BatchNorm is in TRAIN mode everywhere on this path (batch statistics):
  *   conv (asis_gemm conv=1, fp32 out, per-tile stats) -> asis_reduce_partials -> [all-reduce of
