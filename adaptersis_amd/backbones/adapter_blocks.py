@@ -99,6 +99,50 @@ class ConvFFN(_Packed):
         return ops.gemm(g.view(B * Ntok, hid), self._w16("fc2", self.fc2.weight), out_f32=True,
                         bias_n=self._f32("fc2_b", self.fc2.bias), res=res)
 
+    def _grid_tensors(self, grids, dev):
+        key = ("grids", tuple(grids), dev)
+        if self._cache.get("gkey") != key:
+            sizes = [a * b for a, b in grids]
+            starts = [0]
+            for s in sizes[:-1]:
+                starts.append(starts[-1] + s)
+            self._cache["gshapes"] = torch.tensor(grids, dtype=torch.int32, device=dev)
+            self._cache["gstarts"] = torch.tensor(starts, dtype=torch.int32, device=dev)
+            self._cache["gkey"] = key
+        return self._cache["gshapes"], self._cache["gstarts"]
+
+    def forward16_train(self, n16, res, B, Ntok, grids):
+        """``forward16`` keeping (n16, fc1 output, GELU output) for ``backward16``."""
+        dt = config.operand_dtype
+        hid = self.fc1.out_features
+        h = ops.gemm(n16, self._w16("fc1", self.fc1.weight), out_f32=True, bias_n=self._f32("fc1_b", self.fc1.bias))
+        gsh, gst = self._grid_tensors(grids, n16.device)
+        w9 = self._f32_fn("dw9", self.dwconv.dwconv.weight, lambda p: p.reshape(hid, 9).t().contiguous().float())
+        g = ops.dwconv_gelu(h.view(B, Ntok, hid), w9, self._f32("dwb", self.dwconv.dwconv.bias), gsh, gst, dt)
+        out = ops.gemm(g.view(B * Ntok, hid), self._w16("fc2", self.fc2.weight), out_f32=True,
+                       bias_n=self._f32("fc2_b", self.fc2.bias), res=res)
+        return out, (n16, h, g, B, Ntok, tuple(grids))
+
+    def backward16(self, saved, dout, inv_scale, grads, prefix):
+        """dout fp32 [B*Ntok, D] (scaled) -> d n16-input fp32 [B*Ntok, D]; grads of fc1, dwconv, fc2 (overwritten)."""
+        n16, h, g, B, Ntok, grids = saved
+        dt = config.operand_dtype
+        hid = self.fc1.out_features
+        pre = prefix + "."
+        d16, cs = ops.cast_colsum(dout, dt)
+        self._linear_bwd(pre + "fc2", self.fc2, None, None, d16, cs, g.view(B * Ntok, hid), inv_scale, grads)
+        dg = ops.gemm(d16, self._wT16("fc2T", self.fc2.weight), out_f32=True)
+        gsh, gst = self._grid_tensors(grids, dout.device)
+        w9 = self._f32_fn("dw9", self.dwconv.dwconv.weight, lambda p: p.reshape(hid, 9).t().contiguous().float())
+        dh16, part = ops.dwconv_gelu_bwd(h.view(B, Ntok, hid), w9, self._f32("dwb", self.dwconv.dwconv.bias), gsh, gst,
+                                         dg.view(B, Ntok, hid), dt)
+        red = ops.reduce_rows(part.view(part.shape[0], 10 * hid), inv_scale).view(10, hid)
+        grads[pre + "dwconv.dwconv.weight"].view(hid, 9).copy_(red[:9].t())
+        grads[pre + "dwconv.dwconv.bias"].copy_(red[9])
+        dh2 = dh16.view(B * Ntok, hid)
+        self._linear_bwd(pre + "fc1", self.fc1, None, None, dh2, ops.colsum(dh2), n16, inv_scale, grads)
+        return ops.gemm(dh2, self._wT16("fc1T", self.fc1.weight), out_f32=True)
+
     def _f32_fn(self, key, param, fn):
         from ..dinov2.layers.blocks import _pack
         return _pack(self._cache, key, param, fn)
@@ -109,6 +153,15 @@ class _AdapterBase(_Packed):
         ln = getattr(self, name)
         return ops.layernorm(x2d, self._f32(name + "_w", ln.weight), self._f32(name + "_b", ln.bias), ln.eps,
                              config.operand_dtype)
+
+    def _ln_bwd(self, name, dy, x2d, inv_scale, grads, prefix, res=None):
+        """LayerNorm backward: dx (+ res) and the weight / bias gradients into ``grads``."""
+        ln = getattr(self, name)
+        D = x2d.shape[1]
+        dx, part = ops.layernorm_bwd(dy, x2d, self._f32(name + "_w", ln.weight), ln.eps, res=res)
+        red = ops.reduce_rows(part.view(part.shape[0], 2 * D), inv_scale)
+        grads[f"{prefix}{name}.weight"].copy_(red[:D]); grads[f"{prefix}{name}.bias"].copy_(red[D:])
+        return dx
 
     @staticmethod
     def _flat(x):
@@ -153,6 +206,32 @@ class CACNN(_AdapterBase):
         return out.view(B, Lq, D)
 
 
+    # ---- `train_adapters` mode --------------------------------------------------------------------------------------
+    def forward16_train(self, c2, x2, g, B, Lq, Lin, grids):
+        """c2 fp32 [B*Lq, D] (pyramid tokens = query), x2 fp32 [B*Lin, D] (ViT tokens = feat), g = engine geometry dict
+        (ref2 / shapes2 / starts2) -> (out fp32 [B*Lq, D], saved)."""
+        qn, fn = self._ln16("query_norm", c2), self._ln16("feat_norm", x2)
+        out1, s_attn = self.attn.forward16_train(qn, fn, g["ref2"], g["shapes2"], g["starts2"], B, Lq, Lin, res=c2)
+        s_ffn = None
+        out = out1
+        if self.with_cffn:
+            out, s_ffn = self.ffn.forward16_train(self._ln16("ffn_norm", out1), out1, B, Lq, grids)
+        return out, (c2, x2, out1, s_attn, s_ffn)
+
+    def backward16(self, saved, dout, inv_scale, grads, prefix=""):
+        """dout fp32 [B*Lq, D] -> (d c2, d x2) fp32; all parameter gradients of the module into ``grads``."""
+        c2, x2, out1, s_attn, s_ffn = saved
+        pre = prefix + "." if prefix else ""
+        d1 = dout
+        if self.with_cffn:
+            dn = self.ffn.backward16(s_ffn, dout, inv_scale, grads, pre + "ffn")
+            d1 = self._ln_bwd("ffn_norm", dn, out1, inv_scale, grads, pre, res=dout)
+        dq, dfeat = self.attn.backward16(s_attn, d1, inv_scale, grads, pre + "attn")
+        dc = self._ln_bwd("query_norm", dq, c2, inv_scale, grads, pre, res=d1)
+        dx = self._ln_bwd("feat_norm", dfeat, x2, inv_scale, grads, pre)
+        return dc, dx
+
+
 class CAViT(_AdapterBase):
     def __init__(self, dim, num_heads=6, n_points=4, n_levels=1, deform_ratio=1.0,
                  norm_layer=partial(nn.LayerNorm, eps=1e-6), init_values=0.0, with_cp=False):
@@ -172,3 +251,21 @@ class CAViT(_AdapterBase):
         out = self.attn.forward16(self._ln16("query_norm", q2), self._ln16("feat_norm", f2), ref, shapes_i32,
                                   starts_i32, B, Lq, Lin, res=q2, scale_n=self._f32("gamma", self.gamma))
         return out.view(B, Lq, D)
+
+    # ---- `train_adapters` mode --------------------------------------------------------------------------------------
+    def forward16_train(self, x2, c2, g, B, Lq, Lin):
+        """x2 fp32 [B*Lq, D] (ViT tokens = query), c2 fp32 [B*Lin, D] (pyramid tokens = feat) -> (out, saved)."""
+        qn, fn = self._ln16("query_norm", x2), self._ln16("feat_norm", c2)
+        out, s_attn = self.attn.forward16_train(qn, fn, g["ref1"], g["shapes1"], g["starts1"], B, Lq, Lin, res=x2,
+                                                scale_n=self._f32("gamma", self.gamma))
+        return out, (x2, c2, s_attn)
+
+    def backward16(self, saved, dout, inv_scale, grads, prefix=""):
+        """dout fp32 [B*Lq, D] -> (d x2, d c2) fp32; parameter gradients (incl. ``gamma``) into ``grads``."""
+        x2, c2, s_attn = saved
+        pre = prefix + "." if prefix else ""
+        dq, dfeat = self.attn.backward16(s_attn, dout, inv_scale, grads, pre + "attn", gamma=self.gamma,
+                                         gamma_name=pre + "gamma")
+        dx = self._ln_bwd("query_norm", dq, x2, inv_scale, grads, pre, res=dout)
+        dc = self._ln_bwd("feat_norm", dfeat, c2, inv_scale, grads, pre)
+        return dx, dc

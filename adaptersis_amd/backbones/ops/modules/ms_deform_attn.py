@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import math
 import warnings
+from typing import Optional
 
 import torch
 from torch import nn
@@ -88,6 +89,61 @@ class MSDeformAttn(_Packed):
         samp = ops.msda_fwd(value.view(B, Lin, self.d_model), offaw, ref, shapes_i32, starts_i32, B, Lq, M, L, P)
         return ops.gemm(samp, self._w16("wo", self.output_proj.weight), out_f32=True,
                         bias_n=self._f32("bo", self.output_proj.bias), scale_n=scale_n, res=res)
+
+    # ---- training path (`train_adapters` mode): forward that keeps what the backward needs ------------------------
+    def forward16_train(self, q16, feat16, ref, shapes_i32, starts_i32, B, Lq, Lin, *, res=None, scale_n=None):
+        """Same arithmetic as ``forward16`` -> (out fp32 [B*Lq, D], saved)."""
+        M, L, P = self.n_heads, self.n_levels, self.n_points
+        srcs = (self.sampling_offsets.weight, self.attention_weights.weight, self.sampling_offsets.bias,
+                self.attention_weights.bias)
+        tag = tuple((t.data_ptr(), t._version, getattr(t, "_asis_gen", 0)) for t in srcs) + (config.operand_dtype,)
+        if self._cache.get("oa_tag") != tag:
+            with torch.no_grad():
+                w = torch.cat([srcs[0].detach(), srcs[1].detach()], 0).float().contiguous()
+                self._cache["w_oa"] = ops.cast_pad(w, dtype=config.operand_dtype)
+                self._cache["b_oa"] = torch.cat([srcs[2].detach(), srcs[3].detach()]).float().contiguous()
+            self._cache["oa_tag"] = tag
+        value = ops.gemm(feat16, self._w16("wv", self.value_proj.weight), bias_n=self._f32("bv", self.value_proj.bias))
+        offaw = ops.gemm(q16, self._cache["w_oa"], out_f32=True, bias_n=self._cache["b_oa"])
+        samp = ops.msda_fwd(value.view(B, Lin, self.d_model), offaw, ref, shapes_i32, starts_i32, B, Lq, M, L, P)
+        out = ops.gemm(samp, self._w16("wo", self.output_proj.weight), out_f32=True,
+                       bias_n=self._f32("bo", self.output_proj.bias), scale_n=scale_n, res=res)
+        return out, (q16, feat16, value, offaw, samp, ref, shapes_i32, starts_i32, B, Lq, Lin)
+
+    def backward16(self, saved, dout: torch.Tensor, inv_scale: float, grads: dict, prefix: str,
+                   gamma: Optional[torch.nn.Parameter] = None, gamma_name: Optional[str] = None):
+        """dout fp32 [B*Lq, D] = loss_scale * dL/d(out) -> (d q16-input fp32 [B*Lq, D], d feat16-input fp32 [B*Lin, D]);
+        parameter gradients (value_proj, sampling_offsets, attention_weights, output_proj, and the caller's ``gamma``
+        when the output projection carries a per-channel scale) are written into ``grads`` (overwritten)."""
+        q16, feat16, value, offaw, samp, ref, shapes_i32, starts_i32, B, Lq, Lin = saved
+        dt = config.operand_dtype
+        D = self.d_model
+        M, L, P = self.n_heads, self.n_levels, self.n_points
+        n_off, n_aw = M * L * P * 2, M * L * P
+        pre = prefix + "."
+        # output_proj (with the caller's LayerScale-like gamma folded in)
+        d16, cs = ops.cast_colsum(dout, dt)
+        self._linear_bwd(pre + "output_proj", self.output_proj, gamma, gamma_name, d16, cs, samp, inv_scale, grads)
+        dsamp = ops.gemm(d16, self._wT16("woT", self.output_proj.weight, gamma), out_f32=True)
+        # sampling core
+        dvalue, doffaw = ops.msda_bwd(value.view(B, Lin, D), offaw, ref, shapes_i32, starts_i32, dsamp, B, Lq, M, L, P)
+        # offsets | attention logits = q16 W_oa^T + b_oa
+        doa16, cs_oa = ops.cast_colsum(doffaw, dt)
+        R = q16.shape[0]
+        G = ops.wgrad(doa16.view(1, R, 1, n_off + n_aw), q16.view(1, R, 1, D), n_off + n_aw, 1, 1, 1, 0, inv_scale)
+        G = G.view(n_off + n_aw, D)
+        grads[pre + "sampling_offsets.weight"].copy_(G[:n_off]); grads[pre + "attention_weights.weight"].copy_(G[n_off:])
+        cso = ops.reduce_rows(cs_oa, inv_scale)
+        grads[pre + "sampling_offsets.bias"].copy_(cso[:n_off]); grads[pre + "attention_weights.bias"].copy_(cso[n_off:])
+        w_oaT = self._pack2("w_oaT", self.sampling_offsets.weight, self.attention_weights.weight, lambda: ops.cast_pad(
+            torch.cat([self.sampling_offsets.weight.detach(), self.attention_weights.weight.detach()], 0).float().t().contiguous(),
+            dtype=dt))
+        dq = ops.gemm(doa16, w_oaT, out_f32=True)
+        # value_proj
+        dv16, cs_v = ops.cast_colsum(dvalue.view(B * Lin, D), dt)
+        self._linear_bwd(pre + "value_proj", self.value_proj, None, None, dv16, cs_v, feat16, inv_scale, grads)
+        dfeat = ops.gemm(dv16, self._wT16("wvT", self.value_proj.weight), out_f32=True)
+        return dq, dfeat
 
     # ---- reference-shaped entry point ---------------------------------------------------------------
     def forward(self, query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index,

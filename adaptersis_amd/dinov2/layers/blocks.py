@@ -45,6 +45,42 @@ class _Packed(nn.Module):
             return None
         return _pack(self._cache, key, param, lambda p: p.float().contiguous())
 
+    # ---- backward helpers shared by the ViT blocks and the adapter modules --------------------------------------
+    def _pack2(self, key: str, w: torch.Tensor, gamma: Optional[torch.Tensor], fn):
+        """cache of a 16-bit operand derived from a weight and (optionally) a LayerScale vector"""
+        tag = tuple((t.data_ptr(), t._version, getattr(t, "_asis_gen", 0)) for t in (w, gamma) if t is not None) + \
+            (config.operand_dtype,)
+        hit = self._cache.get(key)
+        if hit is None or hit[0] != tag:
+            with torch.no_grad():
+                self._cache[key] = (tag, fn())
+        return self._cache[key][1]
+
+    def _wT16(self, key: str, w: torch.Tensor, gamma: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """B operand of an input-gradient GEMM: (diag(gamma) W)^T as 16-bit [in_features, out_features]"""
+        def make():
+            wf = w.detach().float()
+            if gamma is not None:
+                wf = wf * gamma.detach().float()[:, None]
+            return ops.cast_pad(wf.t().contiguous(), dtype=config.operand_dtype)
+        return self._pack2(key, w, gamma, make)
+
+    def _linear_bwd(self, prefix: str, lin: nn.Linear, gamma: Optional[nn.Parameter], gname: Optional[str], dy16, dy_cs,
+                    a16, inv_scale: float, grads: Optional[dict]):
+        """parameter gradients of ``gamma * (A W^T + b)`` (gamma None: plain Linear) into ``grads`` (fp32, unscaled)."""
+        if grads is None:
+            return
+        N, K = lin.weight.shape
+        R = a16.shape[0]
+        G = ops.wgrad(dy16.view(1, R, 1, N), a16.view(1, R, 1, K), N, 1, 1, 1, 0, 1.0).view(N, K)
+        cs = ops.reduce_rows(dy_cs)
+        ops.ls_linear_finish(G, lin.weight.detach() if gamma is not None else None,
+                             lin.bias.detach() if lin.bias is not None else None,
+                             gamma.detach() if gamma is not None else None, cs, inv_scale, grads[prefix + ".weight"],
+                             grads.get(prefix + ".bias") if lin.bias is not None else None,
+                             grads[gname] if gamma is not None else None)
+
+
 
 def make_2tuple(x):
     if isinstance(x, tuple):
@@ -238,25 +274,6 @@ class Block(_Packed):
         return x3
 
     # ---- training path (block.py:89-114 under autograd; BASELINE config 4 / north_star "forward/backward") ----------
-    def _pack2(self, key: str, w: torch.Tensor, gamma: Optional[torch.Tensor], fn):
-        """cache of a 16-bit operand derived from a weight and (optionally) a LayerScale vector"""
-        tag = tuple((t.data_ptr(), t._version, getattr(t, "_asis_gen", 0)) for t in (w, gamma) if t is not None) + \
-            (config.operand_dtype,)
-        hit = self._cache.get(key)
-        if hit is None or hit[0] != tag:
-            with torch.no_grad():
-                self._cache[key] = (tag, fn())
-        return self._cache[key][1]
-
-    def _wT16(self, key: str, w: torch.Tensor, gamma: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """B operand of an input-gradient GEMM: (diag(gamma) W)^T as 16-bit [in_features, out_features]"""
-        def make():
-            wf = w.detach().float()
-            if gamma is not None:
-                wf = wf * gamma.detach().float()[:, None]
-            return ops.cast_pad(wf.t().contiguous(), dtype=config.operand_dtype)
-        return self._pack2(key, w, gamma, make)
-
     def forward_train(self, x: torch.Tensor):
         """x fp32 (B, N, D) -> (out fp32 (B, N, D), saved activations for ``backward``).  Same arithmetic as
         ``forward`` except that fc1 keeps its 16-bit pre-activation (GELU runs as its own pass) and q, k, v come from
@@ -285,21 +302,6 @@ class Block(_Packed):
         x3 = ops.gemm(hpost, m._w16("fc2", m.fc2.weight), out_f32=True, bias_n=m._f32("fc2_b", m.fc2.bias), scale_n=g2,
                       res=x1)
         return x3.view(B, N, D), (x2, xn, qkv, o, lse, x1, xn2, hpre, hpost, B, N)
-
-    def _linear_bwd(self, prefix: str, lin: nn.Linear, gamma: Optional[nn.Parameter], gname: Optional[str], dy16, dy_cs,
-                    a16, inv_scale: float, grads: Optional[dict]):
-        """parameter gradients of ``gamma * (A W^T + b)`` (gamma None: plain Linear) into ``grads`` (fp32, unscaled)."""
-        if grads is None:
-            return
-        N, K = lin.weight.shape
-        R = a16.shape[0]
-        G = ops.wgrad(dy16.view(1, R, 1, N), a16.view(1, R, 1, K), N, 1, 1, 1, 0, 1.0).view(N, K)
-        cs = ops.reduce_rows(dy_cs)
-        ops.ls_linear_finish(G, lin.weight.detach() if gamma is not None else None,
-                             lin.bias.detach() if lin.bias is not None else None,
-                             gamma.detach() if gamma is not None else None, cs, inv_scale, grads[prefix + ".weight"],
-                             grads.get(prefix + ".bias") if lin.bias is not None else None,
-                             grads[gname] if gamma is not None else None)
 
     def backward(self, saved, dres: torch.Tensor, inv_scale: float, grads: Optional[dict] = None, prefix: str = "") -> torch.Tensor:
         """dres fp32 [B*N, D] = loss_scale * dL/d(block output) -> loss_scale * dL/d(block input).  With ``grads``

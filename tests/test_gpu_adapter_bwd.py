@@ -73,3 +73,59 @@ def test_dwconv_gelu_backward(dev):
     assert rel_l2(dx, xr.grad) < 1e-3
     assert rel_l2(red[:9].t().reshape(C, 1, 3, 3), wr.grad) < 1e-5
     assert rel_l2(red[9], br.grad) < 1e-5
+
+
+def _geometry(H, Wd, shapes, dev):
+    from adaptersis_amd.backbones.adapter_blocks import deform_inputs
+    d1, d2 = deform_inputs(torch.zeros(1, 3, H, Wd), 14, shapes)
+    g = {"ref1": d1[0][0, :, 0, :].contiguous().to(dev), "shapes1": d1[1].to(torch.int32).to(dev),
+         "starts1": d1[2].to(torch.int32).to(dev), "ref2": d2[0][0, :, 0, :].contiguous().to(dev),
+         "shapes2": d2[1].to(torch.int32).to(dev), "starts2": d2[2].to(torch.int32).to(dev)}
+    return g, d1, d2
+
+
+def test_cavit_cacnn_module_backward(dev):
+    """CAViT and CACNN (LayerNorms, MSDeformAttn with all four projections, ConvFFN with the depthwise conv, gamma)
+    forward in training form + backward of every parameter and both inputs vs autograd of the oracle modules."""
+    from adaptersis_amd.backbones.adapter_blocks import CACNN, CAViT
+    D, B, size = 128, 2, 224
+    shapes = [(28, 28), (14, 14), (7, 7)]
+    N, Lc = (size // 14) ** 2, sum(a * b for a, b in shapes)
+    g, d1, d2 = _geometry(size, size, shapes, dev)
+    csd, nsd = W.make_cavit_state_dict(D, mode="kernel"), W.make_cacnn_state_dict(D, mode="kernel")
+    cv = CAViT(dim=D, n_levels=3, num_heads=8, init_values=0.0, n_points=4)
+    cv.load_state_dict(csd)
+    cn = CACNN(dim=D, n_levels=1, num_heads=8, n_points=4, with_cffn=True, cffn_ratio=0.25)
+    cn.load_state_dict(nsd)
+    cv, cn = cv.to(dev), cn.to(dev)
+    x = W.tensor("adb.x", (B, N, D), 1.0)
+    c = W.tensor("adb.c", (B, Lc, D), 1.0)
+    dy1 = W.tensor("adb.dy1", (B, N, D), 1.0)
+    dy2 = W.tensor("adb.dy2", (B, Lc, D), 1.0)
+    S = 64.0
+    # ---- CAViT
+    ocs = {k: v.clone().requires_grad_(True) for k, v in csd.items()}
+    xr, cr = x.clone().requires_grad_(True), c.clone().requires_grad_(True)
+    y_ref = O.cavit(xr, d1[0], cr, d1[1], ocs)
+    (y_ref * dy1).sum().backward()
+    y, saved = cv.forward16_train(x.view(B * N, D).to(dev), c.view(B * Lc, D).to(dev), g, B, N, Lc)
+    assert rel_l2(y.view(B, N, D), y_ref) < 1e-3
+    grads = {k: torch.zeros_like(p, dtype=torch.float32) for k, p in cv.named_parameters()}
+    dx, dc = cv.backward16(saved, (dy1 * S).view(B * N, D).contiguous().to(dev), 1.0 / S, grads)
+    errs = {k: rel_l2(grads[k], ocs[k].grad) for k in grads}
+    errs["dx"], errs["dc"] = rel_l2(dx.view(B, N, D) / S, xr.grad), rel_l2(dc.view(B, Lc, D) / S, cr.grad)
+    print("CAViT:", {k: "%.1e" % v for k, v in errs.items()})
+    assert max(errs.values()) < 5e-3, errs
+    # ---- CACNN
+    ons = {k: v.clone().requires_grad_(True) for k, v in nsd.items()}
+    xr, cr = x.clone().requires_grad_(True), c.clone().requires_grad_(True)
+    z_ref = O.cacnn(cr, d2[0], xr, d2[1], shapes, ons)
+    (z_ref * dy2).sum().backward()
+    z, saved = cn.forward16_train(c.view(B * Lc, D).to(dev), x.view(B * N, D).to(dev), g, B, Lc, N, shapes)
+    assert rel_l2(z.view(B, Lc, D), z_ref) < 1e-3
+    grads = {k: torch.zeros_like(p, dtype=torch.float32) for k, p in cn.named_parameters()}
+    dc, dx = cn.backward16(saved, (dy2 * S).view(B * Lc, D).contiguous().to(dev), 1.0 / S, grads)
+    errs = {k: rel_l2(grads[k], ons[k].grad) for k in grads}
+    errs["dx"], errs["dc"] = rel_l2(dx.view(B, N, D) / S, xr.grad), rel_l2(dc.view(B, Lc, D) / S, cr.grad)
+    print("CACNN:", {k: "%.1e" % v for k, v in errs.items()})
+    assert max(errs.values()) < 5e-3, errs
