@@ -87,8 +87,8 @@ class SegEngine(nn.Module):
         (block -> CACNN -> CAViT order, the four adapter-stream maps feed the MLA head, `blocks[-2]` is evaluated
         twice and `blocks[-1]` never: `train_mla.py:318,340`).  ``loss``: a key of ``SegEngine.LOSSES``."""
         super().__init__()
-        if mode != "reference_exact":
-            raise NotImplementedError("only mode='reference_exact' is built in this round (SURVEY.md §8 row C3)")
+        if mode not in ("reference_exact", "train_adapters"):
+            raise ValueError("mode must be 'reference_exact' or 'train_adapters'")
         if loss not in self.LOSSES:
             raise ValueError(f"loss must be one of {sorted(self.LOSSES)}")
         self.loss_kind = loss
@@ -101,8 +101,10 @@ class SegEngine(nn.Module):
         self.patch = model.patch_size
         self.heads = model.num_heads
         self.process_group = process_group
-        for p in list(model.parameters()) + list(backbone_encoder.parameters()) + list(cross_vit.parameters()) + \
-                list(cross_cnn.parameters()):
+        frozen = list(model.parameters()) + list(backbone_encoder.parameters())
+        if mode == "reference_exact":
+            frozen += list(cross_vit.parameters()) + list(cross_cnn.parameters())
+        for p in frozen:
             p.requires_grad_(False)  # no gradient reaches them in the reference step
         # gradient-ready order of the decoder backward: final conv first, decoder_1 last
         order = list(seg_decoder.GRAD_ORDER)
@@ -111,7 +113,22 @@ class SegEngine(nn.Module):
         assert len(ordered) == len(named)
         self.bucket = FlatBucket(ordered)
         self.stage_ranges = [self.bucket.range_of([n for n in named if n.startswith(pre + ".")]) for pre in order]
-        self.optimizer = SGD([self.bucket], lr=lr, momentum=momentum, weight_decay=weight_decay)
+        buckets = [self.bucket]
+        self.adapter_bucket = None
+        if mode == "train_adapters":
+            # the trainable set the reference's optimiser lists for the adapters (`train.py:178-186`) and that its
+            # no_grad block (`:389-406`) and forward-only MSDeformAttnFunction keep from ever training (SURVEY facts
+            # 1-2): CAViT + CACNN parameters, one flat bucket, all-reduced once the adapter backward is enqueued
+            if type(seg_decoder).__name__ not in ("FeatureDecoder", "DecoderSETR"):
+                raise NotImplementedError("train_adapters is built for the train.py flow (FeatureDecoder head)")
+            for p in list(cross_vit.parameters()) + list(cross_cnn.parameters()):
+                p.requires_grad_(True)
+            named_a = [("cross_vit." + n, p) for n, p in cross_vit.named_parameters()] + \
+                      [("cross_cnn." + n, p) for n, p in cross_cnn.named_parameters()]
+            self.adapter_bucket = FlatBucket(named_a)
+            self.adapter_reducer = StageReducer(self.adapter_bucket.grad, [(0, self.adapter_bucket.numel)], process_group)
+            buckets.append(self.adapter_bucket)
+        self.optimizer = SGD(buckets, lr=lr, momentum=momentum, weight_decay=weight_decay)
         self.reducer = StageReducer(self.bucket.grad, self.stage_ranges, process_group)
         self._geom = {}
 
@@ -139,8 +156,10 @@ class SegEngine(nn.Module):
         return cn.ffn.forward16(cn._ln16("ffn_norm", out), out, B, Lq, grids) if cn.with_cffn else out
 
     @torch.no_grad()
-    def features(self, inp: torch.Tensor, taps: Optional[dict] = None):
-        """`train.py:275-406`: image batch -> decoder input, NHWC 16-bit [B, h, w, 3D] as (hi, lo|None)."""
+    def features(self, inp: torch.Tensor, taps: Optional[dict] = None, adapter_saves: Optional[list] = None):
+        """`train.py:275-406`: image batch -> decoder input, NHWC 16-bit [B, h, w, 3D] as (hi, lo|None).
+        ``adapter_saves`` (train_adapters mode): list that receives, per stage, the saved activations of the frozen
+        block on pass B and of CAViT / CACNN."""
         m = self.model
         B, _, H, W = inp.shape
         inp = inp.float().contiguous()
@@ -172,12 +191,25 @@ class SegEngine(nn.Module):
         if taps is not None:
             taps.update(c=c, x_b0=xcat[Ra:].view(B, N, D).clone(), shapes=shapes)
         c2d = c.view(B * Lc, D)
+        train = self.mode == "train_adapters" and adapter_saves is not None
         for s in range(nl):
+            bsaved = None
             if s > 0:
-                xcat = m.blocks[nb - (nl - 1) + s - 1].forward_rows(xcat, segs)
+                blk = m.blocks[nb - (nl - 1) + s - 1]
+                if train:  # pass B through the frozen block with saved activations (input gradient needed), pass A plain
+                    xa_s = blk.forward_rows(xcat[:Ra], [(B, N + 1)])
+                    xb_s, bsaved = blk.forward_train(xcat[Ra:].view(B, N, D))
+                    xcat = torch.cat([xa_s, xb_s.reshape(Rb, D)], 0)
+                else:
+                    xcat = blk.forward_rows(xcat, segs)
                 feats.append(m._final_norm(xcat[:Ra].view(B, N + 1, D))[:, 1:])
-            x2 = self._cavit(xcat[Ra:], c2d, g, B, N, Lc)
-            c2d = self._cacnn(c2d, x2, g, B, Lc, N, shapes)
+            if train:
+                x2, s_cv = self.cross_vit.forward16_train(xcat[Ra:], c2d, g, B, N, Lc)
+                c2d, s_cn = self.cross_cnn.forward16_train(c2d, x2, g, B, Lc, N, shapes)
+                adapter_saves.append((bsaved, s_cv, s_cn))
+            else:
+                x2 = self._cavit(xcat[Ra:], c2d, g, B, N, Lc)
+                c2d = self._cacnn(c2d, x2, g, B, Lc, N, shapes)
             # the stage output overwrites pass B's rows of the stacked buffer: the next block reads it in place
             x = ops.add_f32(x2.view(B, N, D), feats[s], out=xcat[Ra:].view(B, N, D))
         if taps is not None:
@@ -259,7 +291,8 @@ class SegEngine(nn.Module):
         if self.is_mla:
             logits, saved = dec._forward_core(self.features_mla(inp, taps), save=True, training=True)
         else:
-            cat = self.features(inp, taps)
+            asaves = [] if self.mode == "train_adapters" else None
+            cat = self.features(inp, taps, asaves)
             logits, saved = dec._forward_core(cat[0], cat[1], save=True, training=True)
         target = target.long().contiguous()
         n_region, lmode, eps, n_ce = self.LOSSES[self.loss_kind]
@@ -271,12 +304,54 @@ class SegEngine(nn.Module):
         world = world_size(self.process_group)
         inv = 1.0 / (S * world)  # gradient mean over ranks folded into the un-scaling (DDP semantics)
         self.reducer.begin()
-        dec._backward_core(saved, d16, bpart, inv, self.bucket.views, stage_done=self.reducer.stage_done, d_lo=d_lo)
+        if self.mode == "train_adapters":
+            dcat = dec._backward_core(saved, d16, bpart, inv, self.bucket.views, stage_done=self.reducer.stage_done, d_lo=d_lo,
+                                      need_input_grad=True)
+            self.adapter_reducer.begin()
+            self._adapter_backward(asaves, dcat, inv)
+            self.adapter_reducer.stage_done()
+            self.adapter_reducer.finish()
+        else:
+            dec._backward_core(saved, d16, bpart, inv, self.bucket.views, stage_done=self.reducer.stage_done, d_lo=d_lo)
         self.reducer.finish()
         self.optimizer.step(1.0)
         if taps is not None:
             taps.update(logits=logits, loss=loss)
         return loss.view(())
+
+    def _adapter_backward(self, asaves, dcat: torch.Tensor, inv: float) -> None:
+        """Backward of the four adapter stages (`train.py:304-387` under autograd, minus its no_grad):
+        d cat[..., :D] is the gradient of the adapter stream; the c4 and pass-A slices of the decoder input come from
+        the frozen encoder / backbone.  Per stage, in reverse: x = x2 + feat (identity), CACNN (only when its output
+        fed a later stage: the last one is dead code in the reference flow), CAViT, and the input gradient of the
+        frozen ViT block in front of the stage.  CAViT / CACNN are the same modules in all four stages, so every
+        stage writes its own gradient slab and the slabs are summed in a fixed order."""
+        m, cv, cn = self.model, self.cross_vit, self.cross_cnn
+        B, h, w, D3 = dcat.shape
+        D = D3 // 3
+        N = h * w
+        nl = self.n_last_blocks
+        nb = len(m.blocks)
+        ab = self.adapter_bucket
+        slabs = torch.zeros((nl, ab.numel), device=dcat.device, dtype=torch.float32)
+        dx = torch.empty((B * N, D), device=dcat.device, dtype=torch.float32)
+        ops.copy_channels(dcat.view(B * N, D3)[:, :D], dx)
+        dc_next = None
+        for s in range(nl - 1, -1, -1):
+            bsaved, s_cv, s_cn = asaves[s]
+            gs = {n: slabs[s, o:o + p.numel()].view(p.shape) for n, p, o in zip(ab.names, ab.params, ab.offsets)}
+            dc_in = None
+            if dc_next is not None:
+                dc_in, dx_extra = cn.backward16(s_cn, dc_next, inv, gs, "cross_cnn")
+                ops.add_f32(dx.view(B, N, D), dx_extra.view(B, N, D), out=dx.view(B, N, D))
+            dx_in, dc_cv = cv.backward16(s_cv, dx, inv, gs, "cross_vit")
+            if dc_in is not None:
+                Lc = dc_cv.shape[0] // B
+                ops.add_f32(dc_cv.view(B, Lc, D), dc_in.view(B, Lc, D), out=dc_cv.view(B, Lc, D))
+            dc_next = dc_cv
+            if s > 0:
+                dx = m.blocks[nb - (nl - 1) + s - 1].backward(bsaved, dx_in, inv, None)
+        ops.reduce_rows(slabs, 1.0, ab.grad)
 
     @torch.no_grad()
     def eval_logits(self, inp: torch.Tensor) -> torch.Tensor:

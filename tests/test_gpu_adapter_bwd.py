@@ -140,3 +140,59 @@ def test_cavit_cacnn_module_backward(dev):
     errs["dx"], errs["dc"] = rel_l2(dx.view(B, N, D) / S, xr.grad), rel_l2(dc.view(B, Lc, D) / S, cr.grad)
     print("CACNN:", {k: "%.1e" % v for k, v in errs.items()})
     _check(errs)
+
+
+def test_engine_train_adapters_step_vs_oracle(dev):
+    """`train_adapters` mode: the step of `train.py:268-436` with the autograd graph left intact (no `no_grad` around
+    the adapter stream): gradients of every CAViT / CACNN parameter and of the decoder against autograd of the oracle,
+    then one SGD step over both buckets."""
+    from adaptersis_amd.backbones.adapter_blocks import CACNN, CAViT
+    from adaptersis_amd.backbones.decoders import FeatureDecoder
+    from adaptersis_amd.backbones.encoders import FeatureEncoder
+    from adaptersis_amd.backbones.engines import SegEngine
+    from adaptersis_amd.dinov2.models import vision_transformer as vits
+    arch, size, B = "vit_tiny_test", 224, 2
+    D, depth, heads, ffn = W.VIT_CONFIGS[arch]
+    feats = (128, 32, 16, 16, 8)
+    sds = dict(vit=W.make_vit_state_dict(arch, layerscale="kernel"), enc=W.make_encoder_state_dict(D),
+               cv=W.make_cavit_state_dict(D, mode="kernel"), cn=W.make_cacnn_state_dict(D, mode="kernel"),
+               dec=W.make_feature_decoder_state_dict(D, 2, features=feats))
+    model = vits.__dict__[arch](patch_size=14, img_size=518, init_values=1e-5, ffn_layer=ffn, block_chunks=0)
+    model.load_state_dict(sds["vit"])
+    enc = FeatureEncoder(embed_dim=D); enc.load_state_dict(sds["enc"])
+    cv = CAViT(dim=D, n_levels=3, num_heads=8, init_values=0.0, n_points=4); cv.load_state_dict(sds["cv"])
+    cn = CACNN(dim=D, n_levels=1, num_heads=8, n_points=4, with_cffn=True, cffn_ratio=0.25); cn.load_state_dict(sds["cn"])
+    dec = FeatureDecoder(embed_dim=D, num_classes=2, features=list(feats)); dec.load_state_dict(sds["dec"])
+    eng = SegEngine(model.to(dev).eval(), enc.to(dev), cv.to(dev), cn.to(dev), dec.to(dev), lr=0.05, mode="train_adapters")
+    img, tgt = W.synthetic_batch(B, size)
+    # oracle with the graph intact
+    ocv = {k: v.clone().requires_grad_(True) for k, v in sds["cv"].items()}
+    ocn = {k: v.clone().requires_grad_(True) for k, v in sds["cn"].items()}
+    odec = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k and "num_batches" not in k)
+            for k, v in sds["dec"].items()}
+    oenc = {k: v.clone() for k, v in sds["enc"].items()}
+    ocat = O.adapter_forward(img, sds["vit"], oenc, ocv, ocn, heads, update_bn=True)
+    oloss = O.train_step_loss(ocat, tgt, odec, 2, update_bn=True)
+    oloss.backward()
+    taps = {}
+    loss = eng.train_step(img.to(dev), tgt.to(dev), taps)
+    assert abs(float(loss) - float(oloss)) < 1e-4
+    aerr = {}
+    for k, v in eng.adapter_bucket.views.items():
+        mod, name = k.split(".", 1)
+        ref = (ocv if mod == "cross_vit" else ocn)[name].grad
+        if ref is not None and float(ref.norm()) > 0:
+            aerr[k] = rel_l2(v, ref)
+    worst = sorted(aerr.items(), key=lambda kv: -kv[1])[:5]
+    print("train_adapters: adapter grads worst:", [(k, "%.1e" % v) for k, v in worst], "n =", len(aerr))
+    # step-level bound (forward differences move ReLU branches in the decoder and sampling cells in the adapters)
+    assert max(aerr.values()) < 2.5e-1, worst
+    assert sorted(aerr.values())[len(aerr) // 2] < 5e-2
+    derr = {k: rel_l2(v, odec[k].grad) for k, v in eng.bucket.views.items() if not k.endswith(".0.bias")}
+    assert max(derr.values()) < 1e-1, derr
+    # the last stage's CACNN output is unused downstream: its own last-call contribution is zero, earlier calls are not
+    assert float(eng.adapter_bucket.views["cross_cnn.ffn.fc2.weight"].abs().sum()) > 0
+    # both buckets are optimised
+    assert len(eng.optimizer.param_groups) == 2
+    p_after = dict(eng.cross_vit.named_parameters())["attn.value_proj.weight"].detach().cpu()
+    assert not torch.equal(p_after, sds["cv"]["attn.value_proj.weight"])
