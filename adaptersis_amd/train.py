@@ -53,11 +53,12 @@ class _SegData(torch.utils.data.Dataset):
         return self.img[i], self.msk[i], i
 
 
-def _engine_for(model, backbone_encoder, cross_vit, cross_cnn, seg_decoder, lr=0.01, momentum=0.99, weight_decay=3e-5):
+def _engine_for(model, backbone_encoder, cross_vit, cross_cnn, seg_decoder, lr=0.01, momentum=0.99, weight_decay=3e-5,
+                mode="reference_exact"):
     key = id(seg_decoder)
     if key not in _ENGINES:
         _ENGINES[key] = SegEngine(model, backbone_encoder, cross_vit, cross_cnn, seg_decoder, lr=lr, momentum=momentum,
-                                  weight_decay=weight_decay)
+                                  weight_decay=weight_decay, mode=mode)
     return _ENGINES[key]
 
 
@@ -91,7 +92,8 @@ def train_seg(args, head: str = "feature"):
         engine = _engine_for(model, backbone_encoder, cross_vit, cross_cnn, seg_decoder, lr=lr, momentum=0.9, weight_decay=0.0)
     else:
         seg_decoder = FeatureDecoder(embed_dim=D, num_classes=2, features=[D, 512, 256, 128, 64]).to(dev)
-        engine = _engine_for(model, backbone_encoder, cross_vit, cross_cnn, seg_decoder, lr=args.lr)
+        engine = _engine_for(model, backbone_encoder, cross_vit, cross_cnn, seg_decoder, lr=args.lr,
+                             mode="train_adapters" if getattr(args, "train_adapters", False) else "reference_exact")
     optimizer = engine.optimizer
 
     dataset_val = _SegData(args.data_path, "validation", args.imsize)
@@ -217,6 +219,9 @@ def get_args_parser():
     p.add_argument("--evaluate", dest="evaluate", action="store_true")
     p.add_argument("--config_file", type=str)
     p.add_argument("--pretrained_weights", type=str)
+    # extension (not in the reference CLI): train CAViT / CACNN too — what `train.py:178-186` lists in its optimiser but
+    # its no_grad block keeps from training
+    p.add_argument("--train_adapters", action="store_true")
     return p
 
 

@@ -30,7 +30,7 @@ import torch.distributed as dist  # noqa: E402
 MFMA_F16_DENSE_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16/f16 (no sparsity)
 
 
-def build_engine(arch: str, dev, lr: float):
+def build_engine(arch: str, dev, lr: float, mode: str = "reference_exact"):
     from adaptersis_amd.backbones.adapter_blocks import CACNN, CAViT
     from adaptersis_amd.backbones.decoders import FeatureDecoder
     from adaptersis_amd.backbones.encoders import FeatureEncoder
@@ -49,7 +49,7 @@ def build_engine(arch: str, dev, lr: float):
     cn.load_state_dict(W.make_cacnn_state_dict(D, mode="kernel"))
     dec = FeatureDecoder(embed_dim=D, num_classes=2, features=[D, 512, 256, 128, 64])
     dec.load_state_dict(W.make_feature_decoder_state_dict(D, 2, features=(D, 512, 256, 128, 64)))
-    return SegEngine(model.to(dev).eval(), enc.to(dev), cv.to(dev), cn.to(dev), dec.to(dev), lr=lr)
+    return SegEngine(model.to(dev).eval(), enc.to(dev), cv.to(dev), cn.to(dev), dec.to(dev), lr=lr, mode=mode)
 
 
 def build_engine_cfg(cfg: int, arch: str, dev, lr: float):
@@ -199,6 +199,8 @@ def main():
                     help="BASELINE.json config: 3 = the headline metric (default); 2 = ViT-B + UNet head; 4 = unfrozen end-to-end; 5 = ViT-g + MLA head, 11 classes")
     ap.add_argument("--size", type=int, default=588)
     ap.add_argument("--operand", default=None, choices=[None, "f16", "bf16"])
+    ap.add_argument("--train-adapters", action="store_true",
+                    help="config 3 with the adapter backward (CAViT + CACNN gradients, all-reduced and optimised with the decoder)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     a = ap.parse_args()
@@ -226,7 +228,10 @@ def main():
         config.loss_scale = 65536.0 if a.operand == "f16" else 1.0
 
     a.arch = a.arch or {2: "vit_base", 5: "vit_giant2"}.get(a.config, "vit_large")
-    eng = build_engine(a.arch, dev, lr=0.01) if a.config == 3 else build_engine_cfg(a.config, a.arch, dev, lr=0.01)
+    if a.config == 3:
+        eng = build_engine(a.arch, dev, lr=0.01, mode="train_adapters" if a.train_adapters else "reference_exact")
+    else:
+        eng = build_engine_cfg(a.config, a.arch, dev, lr=0.01)
     img, tgt = synthetic(a.batch, a.size, rank, dev, 11 if a.config == 5 else 2)
 
     def barrier():
@@ -289,7 +294,8 @@ def main():
             "config": {"workload": {
                 3: f"{a.arch}/14 frozen + CAViT/CACNN adapters (n_last_blocks=4) + FeatureDecoder, "
                    f"{a.size}x{a.size}, batch {a.batch}/GPU, reference_exact train.py step "
-                   "(fwd + decoder bwd + all-reduce + SGD), random-init weights",
+                   "(fwd + decoder bwd + all-reduce + SGD), random-init weights" +
+                   (" + train_adapters (CAViT/CACNN backward through the 4 stages and 3 frozen blocks)" if a.train_adapters else ""),
                 2: f"BASELINE config 2: {a.arch}/14 frozen + CAViT/CACNN adapters + UNet head, CE + DC loss, "
                    f"{a.size}x{a.size}, batch {a.batch}/GPU (fwd + UNet bwd + all-reduce + SGD), random-init weights",
                 5: f"BASELINE config 5: {a.arch}/14 (SwiGLU) frozen + CAViT/CACNN adapters + DecoderMLA head, 11 classes, soft-IoU "
