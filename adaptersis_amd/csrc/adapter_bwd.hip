@@ -18,7 +18,7 @@ namespace {
 constexpr int MAX_LP = 16;
 constexpr int MAX_M = 32;
 
-template <typename T>
+template <typename T, bool DVALUE>
 __global__ __launch_bounds__(256) void msda_bwd_kernel(const T* __restrict__ value, const float* __restrict__ offaw,
                                                        int64_t ld_offaw, const float* __restrict__ ref,
                                                        const int* __restrict__ shapes, const int* __restrict__ starts,
@@ -96,8 +96,10 @@ __global__ __launch_bounds__(256) void msda_bwd_kernel(const T* __restrict__ val
                 float f0, f1;
                 unpack2<T>(pw[e], f0, f1);
                 dotv += g[2 * e] * f0 + g[2 * e + 1] * f1;
-                atomicAdd(dvl + o + 2 * e, wv * g[2 * e]);
-                atomicAdd(dvl + o + 2 * e + 1, wv * g[2 * e + 1]);
+                if (DVALUE) {
+                  atomicAdd(dvl + o + 2 * e, wv * g[2 * e]);
+                  atomicAdd(dvl + o + 2 * e + 1, wv * g[2 * e + 1]);
+                }
               }
               s_dot += bx * by * dotv;
               sx += dbx * by * dotv;
@@ -139,6 +141,83 @@ __global__ __launch_bounds__(256) void msda_bwd_kernel(const T* __restrict__ val
       }
     }
     __syncthreads();
+  }
+}
+
+// d value without global atomics: one workgroup owns the gradient of CH consecutive channels of ALL Lin value pixels of
+// one image in LDS (Lin * CH * 4 bytes), every thread walks queries, recomputes their sampling taps and scatters
+// A_j * bw_t * d out into the tile with LDS atomics; the tile is then stored once.  ~27 ms -> well under 1 ms per call
+// against one fp32 global atomic per (tap, channel).  Summation order inside the tile still varies from run to run.
+template <int CH>
+__global__ __launch_bounds__(256) void msda_bwd_dvalue_kernel(const float* __restrict__ offaw, int64_t ld_offaw,
+                                                              const float* __restrict__ ref, const int* __restrict__ shapes,
+                                                              const int* __restrict__ starts, const float* __restrict__ dout,
+                                                              float* __restrict__ dvalue, int B, int Lq, int Lin, int M,
+                                                              int L, int P, int Dh) {
+  extern __shared__ float tile[];  // [Lin][CH]
+  const int D = M * Dh;
+  const int LP = L * P;
+  const int chunks = D / CH;
+  const int b = blockIdx.x / chunks, cc = blockIdx.x - b * chunks;
+  const int ch0 = cc * CH;
+  const int m = ch0 / Dh;
+  for (int i = threadIdx.x; i < Lin * CH; i += blockDim.x) tile[i] = 0.f;
+  __syncthreads();
+  for (int q = threadIdx.x; q < Lq; q += blockDim.x) {
+    const int64_t bq = (int64_t)b * Lq + q;
+    const float* orow = offaw + bq * ld_offaw;
+    const float* lg = orow + (int64_t)M * LP * 2 + m * LP;
+    float w[MAX_LP];
+    float mx = -1e30f;
+#pragma unroll
+    for (int j = 0; j < MAX_LP; ++j)
+      if (j < LP) {
+        w[j] = lg[j];
+        mx = fmaxf(mx, w[j]);
+      }
+    float den = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAX_LP; ++j)
+      if (j < LP) {
+        w[j] = __expf(w[j] - mx);
+        den += w[j];
+      }
+    const float inv = 1.0f / den;
+    const float rx = ref[2 * q], ry = ref[2 * q + 1];
+    float g[CH];
+#pragma unroll
+    for (int e = 0; e < CH; ++e) g[e] = dout[bq * D + ch0 + e];
+    for (int l = 0; l < L; ++l) {
+      const int Hl = shapes[2 * l], Wl = shapes[2 * l + 1];
+      float* tl = tile + (int64_t)starts[l] * CH;
+      for (int p = 0; p < P; ++p) {
+        const int j = l * P + p;
+        const float ox = orow[(m * LP + j) * 2], oy = orow[(m * LP + j) * 2 + 1];
+        const float lx = rx + ox / (float)Wl, ly = ry + oy / (float)Hl;
+        const float px = lx * (float)Wl - 0.5f, py = ly * (float)Hl - 0.5f;
+        const float fx0 = floorf(px), fy0 = floorf(py);
+        const float ax = px - fx0, ay = py - fy0;
+        const int x0 = (int)fminf(fmaxf(fx0, -2.f), (float)Wl + 1.f);
+        const int y0 = (int)fminf(fmaxf(fy0, -2.f), (float)Hl + 1.f);
+        const float aw = w[j] * inv;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int xx = x0 + (t & 1), yy = y0 + (t >> 1);
+          if ((unsigned)xx < (unsigned)Wl && (unsigned)yy < (unsigned)Hl) {
+            const float wv = aw * ((t & 1) ? ax : 1.f - ax) * ((t >> 1) ? ay : 1.f - ay);
+            float* dst = tl + (yy * Wl + xx) * CH;
+#pragma unroll
+            for (int e = 0; e < CH; ++e) atomicAdd(dst + e, wv * g[e]);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  float* out = dvalue + (int64_t)b * Lin * D + ch0;
+  for (int i = threadIdx.x; i < Lin * CH; i += blockDim.x) {
+    const int pix = i / CH, e = i - pix * CH;
+    out[(int64_t)pix * D + e] = tile[i];
   }
 }
 
@@ -271,12 +350,35 @@ extern "C" int asis_msda_bwd(void* stream, int dtype, const void* value, const f
   int64_t grid = (int64_t)B * Lq;
   if (grid > 65535 * 8) grid = 65535 * 8;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == ASIS_F16)
-    hipLaunchKernelGGL((msda_bwd_kernel<f16>), dim3((unsigned)grid), dim3(threads), 0, s, reinterpret_cast<const f16*>(value), offaw,
-                       ld_offaw, ref, shapes, starts, dout, dvalue, doffaw, B, Lq, Lin, M, L, P, Dh);
-  else
-    hipLaunchKernelGGL((msda_bwd_kernel<bf16>), dim3((unsigned)grid), dim3(threads), 0, s, reinterpret_cast<const bf16*>(value), offaw,
-                       ld_offaw, ref, shapes, starts, dout, dvalue, doffaw, B, Lq, Lin, M, L, P, Dh);
+  // d value: LDS-tiled when CH channels of all Lin pixels fit in 128 KiB, else the global-atomics form
+  int CH = 0;
+  for (int c : {8, 4, 2})
+    if (Dh % c == 0 && (int64_t)Lin * c * 4 <= 128 * 1024) { CH = c; break; }
+  const bool tiled = CH != 0 && (int64_t)B * (M * Dh / (CH ? CH : 1)) <= 0x7fffffff;
+  if (dtype == ASIS_F16) {
+    if (tiled) hipLaunchKernelGGL((msda_bwd_kernel<f16, false>), dim3((unsigned)grid), dim3(threads), 0, s, reinterpret_cast<const f16*>(value), offaw, ld_offaw, ref, shapes, starts, dout, dvalue, doffaw, B, Lq, Lin, M, L, P, Dh);
+    else hipLaunchKernelGGL((msda_bwd_kernel<f16, true>), dim3((unsigned)grid), dim3(threads), 0, s, reinterpret_cast<const f16*>(value), offaw, ld_offaw, ref, shapes, starts, dout, dvalue, doffaw, B, Lq, Lin, M, L, P, Dh);
+  } else {
+    if (tiled) hipLaunchKernelGGL((msda_bwd_kernel<bf16, false>), dim3((unsigned)grid), dim3(threads), 0, s, reinterpret_cast<const bf16*>(value), offaw, ld_offaw, ref, shapes, starts, dout, dvalue, doffaw, B, Lq, Lin, M, L, P, Dh);
+    else hipLaunchKernelGGL((msda_bwd_kernel<bf16, true>), dim3((unsigned)grid), dim3(threads), 0, s, reinterpret_cast<const bf16*>(value), offaw, ld_offaw, ref, shapes, starts, dout, dvalue, doffaw, B, Lq, Lin, M, L, P, Dh);
+  }
+  if (tiled) {
+    const unsigned nb = (unsigned)(B * (M * Dh / CH));
+    const size_t lds = (size_t)Lin * CH * 4;
+    if (CH == 8) {
+      static bool set8 = false;
+      if (!set8) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&msda_bwd_dvalue_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set8 = true; }
+      hipLaunchKernelGGL((msda_bwd_dvalue_kernel<8>), dim3(nb), dim3(256), lds, s, offaw, ld_offaw, ref, shapes, starts, dout, dvalue, B, Lq, Lin, M, L, P, Dh);
+    } else if (CH == 4) {
+      static bool set4 = false;
+      if (!set4) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&msda_bwd_dvalue_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set4 = true; }
+      hipLaunchKernelGGL((msda_bwd_dvalue_kernel<4>), dim3(nb), dim3(256), lds, s, offaw, ld_offaw, ref, shapes, starts, dout, dvalue, B, Lq, Lin, M, L, P, Dh);
+    } else {
+      static bool set2 = false;
+      if (!set2) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&msda_bwd_dvalue_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set2 = true; }
+      hipLaunchKernelGGL((msda_bwd_dvalue_kernel<2>), dim3(nb), dim3(256), lds, s, offaw, ld_offaw, ref, shapes, starts, dout, dvalue, B, Lq, Lin, M, L, P, Dh);
+    }
+  }
   ASIS_CHECK_LAUNCH("asis_msda_bwd");
   return ASIS_OK;
 }
