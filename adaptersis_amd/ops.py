@@ -397,17 +397,43 @@ def dwconv_gelu(x: torch.Tensor, w9: torch.Tensor, bias: torch.Tensor, shapes_i3
 # --------------------------------------------------------------------------------------------
 # CNN encoder / decoder companions
 # --------------------------------------------------------------------------------------------
+_ST_CACHE = {}
+
+
 def msda_bwd(value: torch.Tensor, offaw: torch.Tensor, ref: torch.Tensor, shapes_i32: torch.Tensor, starts_i32: torch.Tensor,
-             dout: torch.Tensor, B: int, Lq: int, M: int, L: int, P: int):
+             dout: torch.Tensor, B: int, Lq: int, M: int, L: int, P: int, dense: bool = True):
     """value 16-bit [B, Lin, D]; offaw fp32 [B*Lq, M*L*P*3]; dout fp32 [B*Lq, D] ->
-    (dvalue fp32 [B, Lin, D], doffaw fp32 like offaw)."""
+    (dvalue fp32 [B, Lin, D], doffaw fp32 like offaw).
+    ``dense`` (default): d value through the dense sampling matrix and batched MFMA GEMMs (deterministic);
+    otherwise the scatter kernels (LDS tile / global atomics)."""
     _dev(value, offaw, ref, shapes_i32, starts_i32, dout)
     _, Lin, D = value.shape
-    dvalue = torch.zeros((B, Lin, D), device=value.device, dtype=torch.float32)
+    Dh = D // M
     doffaw = torch.empty_like(offaw)
+    use_dense = dense and Dh % 8 == 0 and Lin >= 1
+    dvalue = torch.empty((B, Lin, D), device=value.device, dtype=torch.float32) if use_dense else \
+        torch.zeros((B, Lin, D), device=value.device, dtype=torch.float32)
     check(lib().asis_msda_bwd(_stream(), _dt(value.dtype), value.data_ptr(), _f32c(offaw).data_ptr(), offaw.stride(0),
                               _f32c(ref).data_ptr(), shapes_i32.data_ptr(), starts_i32.data_ptr(), _f32c(dout).data_ptr(),
-                              dvalue.data_ptr(), doffaw.data_ptr(), B, Lq, Lin, M, L, P, D // M), "asis_msda_bwd")
+                              None if use_dense else dvalue.data_ptr(), doffaw.data_ptr(), B, Lq, Lin, M, L, P, Dh),
+          "asis_msda_bwd")
+    if use_dense:
+        dt = value.dtype
+        ldt = token_ld(Lq)
+        key = (B, M, Lin, ldt, dt, value.device)
+        ST = _ST_CACHE.get(key)
+        if ST is None:
+            _ST_CACHE.clear()          # one resident sampling matrix (2.4 GB at B = 12, 588^2): the call shapes alternate
+            ST = torch.empty((B * M, Lin, ldt), device=value.device, dtype=dt)
+            _ST_CACHE[key] = ST
+        ST.zero_()
+        check(lib().asis_msda_sampling_matrix(_stream(), _dt(dt), offaw.data_ptr(), offaw.stride(0), ref.data_ptr(),
+                                              shapes_i32.data_ptr(), starts_i32.data_ptr(), ST.data_ptr(), ldt, B, Lq, Lin, M, L,
+                                              P), "asis_msda_sampling_matrix")
+        doutT = transpose_tokens(cast_pad(dout, D, dt), B, Lq)                     # [B, D, ldt]
+        st4 = ST.view(B, M, Lin, ldt)
+        for m in range(M):   # out[b, pix, m*Dh + d] = sum_q ST[b, m, pix, q] * doutT[b, m*Dh + d, q]
+            gemm(st4[:, m], doutT[:, m * Dh:(m + 1) * Dh], out=dvalue[:, :, m * Dh:(m + 1) * Dh], out_f32=True)
     return dvalue, doffaw
 
 

@@ -204,8 +204,9 @@ int asis_dwconv_gelu(void* stream, int dtype, const float* x, const float* w9, c
 
 /* ---------------------------------------------------------------------------------------------
  * Adapter backward (`train_adapters` mode; the autograd transposes of asis_msda_fwd and asis_dwconv_gelu).
- * asis_msda_bwd: dout fp32 [B*Lq, M*Dh] = d(sampled output) -> dvalue fp32 [B, Lin, M*Dh] (ACCUMULATED with fp32
- *   atomics into a caller-zeroed buffer: the only non-deterministic summation order of the library) and doffaw fp32
+ * asis_msda_bwd: dout fp32 [B*Lq, M*Dh] = d(sampled output) -> dvalue fp32 [B, Lin, M*Dh] (scatter form: an LDS tile
+ *   per channel chunk, or fp32 global atomics into a caller-zeroed buffer when it does not fit; summation order not
+ *   fixed — the GEMM form below is the deterministic, faster default of the Python layer) and doffaw fp32
  *   [B*Lq, ld_offaw] in the layout of offaw (d offsets, then d logits with the softmax over L*P already applied).
  *   M <= 32, L*P <= 16, M*Dh <= 2048.
  * asis_dwconv_gelu_bwd: x (input of the depthwise conv, fp32 [B, Ntok, C]), dy fp32 = d(GELU output) ->
@@ -215,6 +216,13 @@ int asis_dwconv_gelu(void* stream, int dtype, const float* x, const float* w9, c
 int asis_msda_bwd(void* stream, int dtype, const void* value, const float* offaw, int64_t ld_offaw, const float* ref,
                   const int32_t* shapes, const int32_t* starts, const float* dout, float* dvalue, float* doffaw, int B,
                   int Lq, int Lin, int M, int L, int P, int Dh);
+/* d value as a GEMM: ST[b, m, pix, q] (16-bit, q contiguous with row stride ldt >= Lq, zeroed by the caller) = the
+ * attention-weighted bilinear sampling weight of query q on pixel pix for head m; then
+ *   d value[b, :, m*Dh:(m+1)*Dh] = ST[b, m] (Lin x Lq) . d out[b, :, m*Dh:(m+1)*Dh] (Lq x Dh)      (asis_gemm, batch B per head).
+ * asis_msda_bwd with dvalue == NULL then only produces doffaw. */
+int asis_msda_sampling_matrix(void* stream, int dtype, const float* offaw, int64_t ld_offaw, const float* ref,
+                              const int32_t* shapes, const int32_t* starts, void* ST, int64_t ldt, int B, int Lq, int Lin,
+                              int M, int L, int P);
 int asis_dwconv_bwd_nblk(int64_t rows);
 int asis_dwconv_gelu_bwd(void* stream, int dtype, const float* x, const float* w9, const float* bias, const int32_t* shapes,
                          const int32_t* starts, int L, const float* dy, float* g, float* partial, void* dx, int B, int Ntok,
