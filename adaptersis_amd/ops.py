@@ -410,7 +410,7 @@ def msda_bwd(value: torch.Tensor, offaw: torch.Tensor, ref: torch.Tensor, shapes
     _, Lin, D = value.shape
     Dh = D // M
     doffaw = torch.empty_like(offaw)
-    use_dense = dense and Dh % 8 == 0 and Lin >= 1
+    use_dense = dense and Dh % 8 == 0 and D % 64 == 0   # token transpose works on 64-column tiles
     dvalue = torch.empty((B, Lin, D), device=value.device, dtype=torch.float32) if use_dense else \
         torch.zeros((B, Lin, D), device=value.device, dtype=torch.float32)
     check(lib().asis_msda_bwd(_stream(), _dt(value.dtype), value.data_ptr(), _f32c(offaw).data_ptr(), offaw.stride(0),

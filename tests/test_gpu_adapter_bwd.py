@@ -49,7 +49,7 @@ def test_msda_backward(dev, case):
         e = (rel_l2(dvalue.view(B, Lin, M, Dh), v_r.grad), rel_l2(doffaw[:, :n_off].reshape(off.shape), off_r.grad),
              rel_l2(doffaw[:, n_off:].reshape(logit.shape), lg_r.grad))
         print(case, "dense" if dense else "scatter", "dvalue doff dlogit:", ["%.1e" % v for v in e])
-        assert e[0] < (1e-3 if dense else 1e-4) and max(e[1:]) < 1e-4, e
+        assert e[0] < (1e-3 if dense and D % 64 == 0 else 1e-4) and max(e[1:]) < 1e-4, e
 
 
 def test_dwconv_gelu_backward(dev):
