@@ -154,6 +154,40 @@ __global__ __launch_bounds__(256) void gelu16_kernel(const T* __restrict__ pre, 
   }
 }
 
+// SwiGLU gate backward (swiglu_ffn.py:30-34): h = silu(x1) * x2 with x12 = [x1 | x2] fp32 [R, 2 Hd], dh 16-bit [R, Hd]
+//   d x1 = dh * x2 * sig(x1) * (1 + x1 (1 - sig(x1))),  d x2 = dh * silu(x1)      -> 16-bit [R, 2 Hd]
+template <typename T>
+__global__ __launch_bounds__(256) void swiglu_bwd_kernel(const float* __restrict__ x12, const T* __restrict__ dh,
+                                                         T* __restrict__ dx12, int64_t R, int Hd) {
+  const int cpr = Hd >> 2;
+  const int64_t total = R * cpr;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / cpr;
+    const int c = (int)(i - r * cpr);
+    const float4 a = reinterpret_cast<const float4*>(x12 + r * 2 * Hd)[c];
+    const float4 b = reinterpret_cast<const float4*>(x12 + r * 2 * Hd + Hd)[c];
+    const uint2 gw = reinterpret_cast<const uint2*>(dh + r * Hd)[c];
+    float g[4];
+    unpack2<T>(gw.x, g[0], g[1]);
+    unpack2<T>(gw.y, g[2], g[3]);
+    const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+    float d1[4], d2[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float sg = 1.f / (1.f + __expf(-av[k]));
+      d1[k] = g[k] * bv[k] * sg * (1.f + av[k] * (1.f - sg));
+      d2[k] = g[k] * av[k] * sg;
+    }
+    uint2 o;
+    o.x = pack2<T>(d1[0], d1[1]);
+    o.y = pack2<T>(d1[2], d1[3]);
+    reinterpret_cast<uint2*>(dx12 + r * 2 * Hd)[c] = o;
+    o.x = pack2<T>(d2[0], d2[1]);
+    o.y = pack2<T>(d2[2], d2[3]);
+    reinterpret_cast<uint2*>(dx12 + r * 2 * Hd + Hd)[c] = o;
+  }
+}
+
 // partial[blk][c] = sum over the block's rows of x[r, c] (16-bit input, fp32 sums); threads run along columns (8 per thread)
 template <typename T>
 __global__ __launch_bounds__(256) void colsum16_kernel(const T* __restrict__ x, int64_t ld, float* __restrict__ partial,
@@ -322,6 +356,17 @@ extern "C" int asis_gelu16(void* stream, int dtype, const void* pre, const void*
     else hipLaunchKernelGGL((gelu16_kernel<bf16, false>), dim3(g), dim3(256), 0, s, (const bf16*)pre, (const bf16*)nullptr, (bf16*)out, n8);
   }
   ASIS_CHECK_LAUNCH("asis_gelu16");
+  return ASIS_OK;
+}
+
+extern "C" int asis_swiglu_bwd(void* stream, int dtype, const float* x12, const void* dh, void* dx12, int64_t R, int Hd) {
+  ASIS_REQUIRE(x12 && dh && dx12 && R > 0 && Hd > 0 && Hd % 4 == 0, "asis_swiglu_bwd: bad arguments (Hd %% 4 == 0)");
+  DT_OK(dtype, "asis_swiglu_bwd");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int g = grid_for(R * (Hd / 4));
+  if (dtype == ASIS_F16) hipLaunchKernelGGL((swiglu_bwd_kernel<f16>), dim3(g), dim3(256), 0, s, x12, (const f16*)dh, (f16*)dx12, R, Hd);
+  else hipLaunchKernelGGL((swiglu_bwd_kernel<bf16>), dim3(g), dim3(256), 0, s, x12, (const bf16*)dh, (bf16*)dx12, R, Hd);
+  ASIS_CHECK_LAUNCH("asis_swiglu_bwd");
   return ASIS_OK;
 }
 

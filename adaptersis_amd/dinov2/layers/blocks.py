@@ -284,8 +284,6 @@ class Block(_Packed):
         if x2.dtype != torch.float32 or not x2.is_contiguous():
             x2 = x2.float().contiguous()
         m = self.mlp
-        if not isinstance(m, Mlp):
-            raise NotImplementedError("the training path is built for the Mlp FFN (ViT-S/B/L); SwiGLU (ViT-g) is forward-only")
         g1 = self._f32("g1", self.ls1.gamma) if isinstance(self.ls1, LayerScale) else None
         g2 = self._f32("g2", self.ls2.gamma) if isinstance(self.ls2, LayerScale) else None
         a = self.attn
@@ -297,10 +295,16 @@ class Block(_Packed):
         x1 = ops.gemm(o, a._w16("proj", a.proj.weight), out_f32=True, bias_n=a._f32("proj_b", a.proj.bias), scale_n=g1,
                       res=x2)
         xn2 = ops.layernorm(x1, self._f32("n2w", self.norm2.weight), self._f32("n2b", self.norm2.bias), self.norm2.eps, dt)
-        hpre = ops.gemm(xn2, m._w16("fc1", m.fc1.weight), bias_n=m._f32("fc1_b", m.fc1.bias))
-        hpost = ops.gelu16(hpre)
-        x3 = ops.gemm(hpost, m._w16("fc2", m.fc2.weight), out_f32=True, bias_n=m._f32("fc2_b", m.fc2.bias), scale_n=g2,
-                      res=x1)
+        if isinstance(m, Mlp):
+            hpre = ops.gemm(xn2, m._w16("fc1", m.fc1.weight), bias_n=m._f32("fc1_b", m.fc1.bias))
+            hpost = ops.gelu16(hpre)
+            x3 = ops.gemm(hpost, m._w16("fc2", m.fc2.weight), out_f32=True, bias_n=m._f32("fc2_b", m.fc2.bias), scale_n=g2,
+                          res=x1)
+        else:  # SwiGLU (ViT-g): hpre = the fp32 [x1 | x2] of w12, hpost = silu(x1) * x2
+            hpre = ops.gemm(xn2, m._w16("w12", m.w12.weight), out_f32=True, bias_n=m._f32("w12_b", m.w12.bias))
+            hpost = ops.swiglu(hpre, dt)
+            x3 = ops.gemm(hpost, m._w16("w3", m.w3.weight), out_f32=True, bias_n=m._f32("w3_b", m.w3.bias), scale_n=g2,
+                          res=x1)
         return x3.view(B, N, D), (x2, xn, qkv, o, lse, x1, xn2, hpre, hpost, B, N)
 
     def backward(self, saved, dres: torch.Tensor, inv_scale: float, grads: Optional[dict] = None, prefix: str = "") -> torch.Tensor:
@@ -316,12 +320,16 @@ class Block(_Packed):
         pre = prefix + "." if prefix else ""
         # ---- MLP branch: out = x1 + ls2 * fc2(gelu(fc1(LN2(x1)))) ----
         d16, cs = ops.cast_colsum(dres, dt) if grads is not None else (ops.cast_pad(dres, D, dt), None)
-        self._linear_bwd(pre + "mlp.fc2", m.fc2, ls2, pre + "ls2.gamma", d16, cs, hpost, inv_scale, grads)
-        dh = ops.gemm(d16, self._wT16("fc2T", m.fc2.weight, ls2))                  # 16-bit [R, 4D]
-        dh = ops.gelu16(hpre, dh)
-        self._linear_bwd(pre + "mlp.fc1", m.fc1, None, None, dh, ops.colsum(dh) if grads is not None else None, xn2,
+        if isinstance(m, Mlp):
+            lin_out, lin_in, n_out, n_in, act_bwd = m.fc2, m.fc1, "mlp.fc2", "mlp.fc1", ops.gelu16
+        else:
+            lin_out, lin_in, n_out, n_in, act_bwd = m.w3, m.w12, "mlp.w3", "mlp.w12", ops.swiglu_bwd
+        self._linear_bwd(pre + n_out, lin_out, ls2, pre + "ls2.gamma", d16, cs, hpost, inv_scale, grads)
+        dh = ops.gemm(d16, self._wT16("fc2T", lin_out.weight, ls2))                # 16-bit [R, hidden]
+        dh = act_bwd(hpre, dh)                                                     # GELU' / SwiGLU gate backward
+        self._linear_bwd(pre + n_in, lin_in, None, None, dh, ops.colsum(dh) if grads is not None else None, xn2,
                          inv_scale, grads)
-        dln = ops.gemm(dh, self._wT16("fc1T", m.fc1.weight), out_f32=True)         # fp32 [R, D]
+        dln = ops.gemm(dh, self._wT16("fc1T", lin_in.weight), out_f32=True)        # fp32 [R, D]
         dx1, part = ops.layernorm_bwd(dln, x1, self._f32("n2w", self.norm2.weight), self.norm2.eps, res=dres)
         if grads is not None:
             red = ops.reduce_rows(part.view(part.shape[0], 2 * D), inv_scale)

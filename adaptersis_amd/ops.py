@@ -291,6 +291,18 @@ def gelu16(pre: torch.Tensor, dpost: Optional[torch.Tensor] = None) -> torch.Ten
     return out
 
 
+def swiglu_bwd(x12: torch.Tensor, dh: torch.Tensor) -> torch.Tensor:
+    """x12 fp32 [R, 2*Hd], dh 16-bit [R, Hd] -> 16-bit [R, 2*Hd] = [d x1 | d x2]."""
+    _dev(x12, dh)
+    R, H2 = x12.shape
+    if dh.shape != (R, H2 // 2) or not dh.is_contiguous():
+        raise ValueError("swiglu_bwd: shape mismatch")
+    out = torch.empty((R, H2), device=x12.device, dtype=dh.dtype)
+    check(lib().asis_swiglu_bwd(_stream(), _dt(dh.dtype), _f32c(x12).data_ptr(), dh.data_ptr(), out.data_ptr(), R, H2 // 2),
+          "asis_swiglu_bwd")
+    return out
+
+
 def colsum(x: torch.Tensor) -> torch.Tensor:
     """[R, C] row view (16-bit or float32) -> partial fp32 [nblk, C] column sums (finish with reduce_rows)."""
     _dev(x)

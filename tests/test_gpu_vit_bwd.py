@@ -99,6 +99,15 @@ def test_block_forward_train_and_backward(dev, dt):
     assert max(errs.values()) < tol, errs
 
 
+def test_swiglu_block_forward_train_and_backward(dev):
+    """ViT-g style block (SwiGLUFFNFused: w12 -> silu(x1) * x2 -> w3) in training form + full backward vs the oracle."""
+    y, y_eval, y_ref, dx, dx_ref, grads, gref = _block_case(dev, "vit_tiny_swiglu", 2, 45, torch.float16)
+    assert rel_l2(y, y_ref) < 5e-4 and rel_l2(y, y_eval) < 5e-4
+    errs = {k: rel_l2(grads[k], gref[k]) for k in grads}
+    print("swiglu block: dx %.2e" % rel_l2(dx.view_as(dx_ref), dx_ref), {k.replace("blocks.1.", ""): "%.1e" % v for k, v in errs.items()})
+    assert rel_l2(dx.view_as(dx_ref), dx_ref) < 3e-3 and max(errs.values()) < 3e-3, errs
+
+
 def test_block_backward_input_gradient_only(dev):
     """grads=None (frozen backbone: adapters upstream need only dL/dx): same dx, no parameter work."""
     y, y_eval, y_ref, dx, dx_ref, grads, gref = _block_case(dev, "vit_tiny_test", 1, 33, torch.float16)
