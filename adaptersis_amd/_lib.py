@@ -130,6 +130,8 @@ SIGNATURES = {
     "asis_reduce_rows": [_vp, _vp, _i, _i, _f, _vp],
     "asis_ew_blocks": [_i64],
     "asis_bn_bwd_nblk": [_i64, _i],
+    "asis_maxpool_bn_relu_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i],
+    "asis_dilate2": [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i],
     "asis_upsample_bn_relu_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i],
     "asis_bn_bwd_apply": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _vp, _vp, _vp, _i64, _i],
     "asis_wgrad_splits": [_i64, _i, _i],

@@ -29,7 +29,7 @@ from . import _bn
 
 class _Stage:
     """Saved tensors of one conv -> BN -> ReLU -> upsample stage."""
-    __slots__ = ("x16", "raw", "scale", "shift", "mean", "invstd", "count", "factor")
+    __slots__ = ("x16", "raw", "scale", "shift", "mean", "invstd", "count", "factor", "stride", "pad", "pool")
 
 
 def _conv_weights(owner: _Packed, key: str, conv: nn.Conv2d, split: bool):
@@ -41,28 +41,35 @@ def _conv_weights(owner: _Packed, key: str, conv: nn.Conv2d, split: bool):
 
 
 def conv_bn_relu_up_forward(owner: _Packed, key: str, x16, x_lo, conv: nn.Conv2d, bn: nn.BatchNorm2d, factor: int,
-                            sync_bn: bool, save: bool, training: bool = True):
+                            sync_bn: bool, save: bool, training: bool = True, stride: int = 1, pad: int = 1,
+                            pool: bool = False):
     """(x16, x_lo|None) NHWC -> ((up_hi, up_lo|None), saved stage).  training=False: BatchNorm uses its running
-    statistics (``seg_decoder.eval()`` in validate_network, train.py:451) and nothing is saved."""
+    statistics (``seg_decoder.eval()`` in validate_network, train.py:451) and nothing is saved.  ``stride`` / ``pad``:
+    the 3x3 conv's geometry (the CNN encoder's stride-2 stages); ``pool``: MaxPool2d(3, 2, 1) after the ReLU (stem)."""
     dt = config.operand_dtype
     split = x_lo is not None
     B, H, W, _ = x16.shape
+    OH, OW = (H + 2 * pad - 3) // stride + 1, (W + 2 * pad - 3) // stride + 1
     w_hi, w_lo = _conv_weights(owner, key, conv, split)
-    stats = torch.empty((ops.gemm_tiles_m(B * H * W), 2, conv.out_channels), device=x16.device,
+    stats = torch.empty((ops.gemm_tiles_m(B * OH * OW), 2, conv.out_channels), device=x16.device,
                         dtype=torch.float32) if training else None
     bias = owner._f32(key + ".b", conv.bias)
     if split:
-        raw = ops.conv_gemm_split(x16, x_lo, w_hi, w_lo, 3, 3, 1, 1, bias_n=bias, stats=stats)
+        raw = ops.conv_gemm_split(x16, x_lo, w_hi, w_lo, 3, 3, stride, pad, bias_n=bias, stats=stats)
     else:
-        raw = ops.conv_gemm(x16, w_hi, 3, 3, 1, 1, bias_n=bias, stats=stats)
+        raw = ops.conv_gemm(x16, w_hi, 3, 3, stride, pad, bias_n=bias, stats=stats)
     if training:
-        scale, shift, mean, invstd, count = _bn.finalize(stats, B * H * W, bn, sync_bn)
+        scale, shift, mean, invstd, count = _bn.finalize(stats, B * OH * OW, bn, sync_bn)
     else:
         scale, shift = ops.bn_eval_affine(bn)
         mean = invstd = count = None
         save = False
-    up = ops.bn_relu_upsample(raw, scale, shift, factor, dt, split) if factor > 1 else \
-        ops.bn_act(raw, scale, shift, True, dt, split)
+    if pool:
+        up = ops.bn_relu_maxpool(raw, scale, shift, dt, split)
+    elif factor > 1:
+        up = ops.bn_relu_upsample(raw, scale, shift, factor, dt, split)
+    else:
+        up = ops.bn_act(raw, scale, shift, True, dt, split)
     if not split:
         up = (up, None)
     st = None
@@ -70,6 +77,7 @@ def conv_bn_relu_up_forward(owner: _Packed, key: str, x16, x_lo, conv: nn.Conv2d
         st = _Stage()
         st.x16, st.raw, st.scale, st.shift, st.mean, st.invstd, st.count, st.factor = \
             x16, raw, scale, shift, mean, invstd, count, factor
+        st.stride, st.pad, st.pool = stride, pad, pool
     return up, st
 
 
@@ -83,7 +91,11 @@ def conv_bn_relu_up_backward(owner: _Packed, key: str, st: _Stage, dU, conv: nn.
     import torch.distributed as dist
     dt = config.operand_dtype
     C = conv.out_channels
-    g, partial = ops.upsample_bn_relu_bwd(dU, st.raw, st.scale, st.shift, st.mean, st.invstd, st.factor)
+    stride, pad = getattr(st, "stride", 1) or 1, getattr(st, "pad", 1)
+    if getattr(st, "pool", False):
+        g, partial = ops.maxpool_bn_relu_bwd(dU, st.raw, st.scale, st.shift, st.mean, st.invstd)
+    else:
+        g, partial = ops.upsample_bn_relu_bwd(dU, st.raw, st.scale, st.shift, st.mean, st.invstd, st.factor)
     red = ops.reduce_rows(partial.view(partial.shape[0], 2 * C))  # [2C]: sum g | sum g*xhat (scaled)
     if sync_bn and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(red)  # SyncBatchNorm backward: 2C floats
@@ -96,22 +108,29 @@ def conv_bn_relu_up_backward(owner: _Packed, key: str, st: _Stage, dU, conv: nn.
     ops.reduce_rows(dgamma_s.view(1, C), inv_scale, grads[bn_name + ".weight"])
     if conv.bias is not None:
         ops.reduce_rows(bpart, inv_scale, grads[conv_name + ".bias"])
-    ops.wgrad(dx16, st.x16, C, 3, 3, 1, 1, inv_scale, out=grads[conv_name + ".weight"])
+    ops.wgrad(dx16, st.x16, C, 3, 3, stride, pad, inv_scale, out=grads[conv_name + ".weight"])
     if not need_dx:
         return None
-    return _dgrad(owner, key, conv, dx16, dx_lo)
+    if stride == 1:
+        return _dgrad(owner, key, conv, dx16, dx_lo)
+    # stride 2: conv_transpose2d = stride-1 correlation of the zero-inserted gradient with the mirrored weights, padded by
+    # K - 1 - pad; the dilated map is sized so that the result has the input's H x W (output_padding included)
+    H, W = st.x16.shape[1:3]
+    pp = 2 - pad
+    d_hi, d_lo = ops.dilate2(dx16, dx_lo, H + 2 - 2 * pp, W + 2 - 2 * pp)
+    return _dgrad(owner, key, conv, d_hi, d_lo, pad=pp)
 
 
-def _dgrad(owner: _Packed, key: str, conv: nn.Conv2d, d16, d_lo):
+def _dgrad(owner: _Packed, key: str, conv: nn.Conv2d, d16, d_lo, pad: int = 1):
     """dX = conv_transpose(dY): implicit GEMM on dY with flipped weights; split precision when d_lo is given
     (the next stage's BatchNorm backward subtracts means: 16-bit rounding noise would be amplified)."""
     dt = config.operand_dtype
     wd = _pack(owner._cache, key + ".wd", conv.weight, lambda p: ops.pack_conv_weight(p.float().contiguous(), 1, dt))
     if d_lo is None:
-        return ops.conv_gemm(d16, wd, 3, 3, 1, 1)
+        return ops.conv_gemm(d16, wd, 3, 3, 1, pad)
     wd_lo = _pack(owner._cache, key + ".wdlo", conv.weight,
                   lambda p: ops.pack_conv_weight(p.float().contiguous(), 1, dt, 1))
-    return ops.conv_gemm_split(d16, d_lo, wd, wd_lo, 3, 3, 1, 1)
+    return ops.conv_gemm_split(d16, d_lo, wd, wd_lo, 3, 3, 1, pad)
 
 
 class _DecoderFn(torch.autograd.Function):

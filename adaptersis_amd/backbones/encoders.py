@@ -121,6 +121,93 @@ class FeatureEncoder(_Packed):
             c1 = c1.view(B, h1, w1, D)
         return c1, c, shapes
 
+    # ---- training path (`train_adapters` mode with the encoder in the trainable set) ----------------------------------
+    def forward_tokens_train(self, x, sync_bn=True):
+        """``forward_tokens`` (c1 is never used by the step) keeping what ``backward_tokens`` needs.
+        -> (c tokens fp32 [B, n2+n3+n4, D], shapes, saved)."""
+        from .decoders import conv_bn_relu_up_forward as stage
+        dt = config.operand_dtype
+        sp = config.split_conv
+        x = x.float().contiguous()
+        B, _, H, W = x.shape
+        D = self.embed_dim
+        st = self.stem
+        raw0 = ops.conv3x3_c3(x, self._f32("stem0", st[0].weight), 2, 1)
+        scale, shift, mean, invstd, count = _bn.finalize(ops.colstats(raw0), raw0.numel() // raw0.shape[-1], st[1], sync_bn)
+        a = self._pair(ops.bn_act(raw0, scale, shift, True, dt, sp), sp)
+        # the image as an 8-channel 16-bit NHWC operand of the stem's weight-gradient GEMM (channels 3..7 zero)
+        x8 = ops.cast_pad(x.permute(0, 2, 3, 1).reshape(B * H * W, 3), 8, dt).view(B, H, W, 8)
+        saved = {"stem0": (x8, raw0, scale, shift, mean, invstd, count)}
+        a, saved["stem3"] = stage(self, "stem3", a[0], a[1], st[3], st[4], 1, sync_bn, True)
+        s1, saved["stem6"] = stage(self, "stem6", a[0], a[1], st[6], st[7], 1, sync_bn, True, pool=True)
+        s2, saved["conv2"] = stage(self, "conv2", s1[0], s1[1], self.conv2[0], self.conv2[1], 1, sync_bn, True, stride=2, pad=0)
+        s3, saved["conv3"] = stage(self, "conv3", s2[0], s2[1], self.conv3[0], self.conv3[1], 1, sync_bn, True, stride=2, pad=0)
+        s4, saved["conv4"] = stage(self, "conv4", s3[0], s3[1], self.conv4[0], self.conv4[1], 1, sync_bn, True, stride=2, pad=1)
+        shapes = [tuple(t[0].shape[1:3]) for t in (s2, s3, s4)]
+        sizes = [h * w for h, w in shapes]
+        c = torch.empty((B, sum(sizes), D), device=x.device, dtype=torch.float32)
+        off = 0
+        for i, (s, fc) in enumerate(((s2, self.fc2), (s3, self.fc3), (s4, self.fc4))):
+            self._fc(i + 2, fc, s, c[:, off:off + sizes[i]])
+            off += sizes[i]
+        saved["maps"] = (s2[0], s3[0], s4[0])
+        saved["sizes"] = sizes
+        return c, shapes, saved
+
+    def backward_tokens(self, saved, dc: torch.Tensor, inv_scale: float, grads: dict, prefix: str = "", sync_bn: bool = True):
+        """dc fp32 [B, n2+n3+n4, D] = loss_scale * dL/dc -> every parameter gradient of the encoder into ``grads``
+        (``fc1`` feeds only the unused c1: zero).  Stride-2 stages: weight gradient with the strided window geometry,
+        input gradient as a stride-1 conv of the zero-inserted gradient; the stem's MaxPool through its argmax."""
+        from .decoders import conv_bn_relu_up_backward as stage_bwd
+        dt = config.operand_dtype
+        pre = prefix + "." if prefix else ""
+        B = dc.shape[0]
+        D = self.embed_dim
+        sizes = saved["sizes"]
+        # ---- fc2..fc4: tokens = map . W^T + b
+        dmaps = []
+        off = 0
+        for i, (m16, fc) in enumerate(zip(saved["maps"], (self.fc2, self.fc3, self.fc4))):
+            _, h, w, Cs = m16.shape
+            d2 = torch.empty((B * sizes[i], D), device=dc.device, dtype=torch.float32)
+            ops.copy_channels(dc.as_strided((B, sizes[i] * D), (dc.stride(0), 1), dc.storage_offset() + off * D),
+                              d2.view(B, sizes[i] * D))
+            d16, cs = ops.cast_colsum(d2, dt)
+            name = f"{pre}fc{i + 2}"
+            gw = ops.wgrad(d16.view(1, B * sizes[i], 1, D), m16.view(1, B * sizes[i], 1, Cs), D, 1, 1, 1, 0, inv_scale)
+            grads[name + ".weight"].view(D, Cs).copy_(gw.view(D, Cs))
+            ops.reduce_rows(cs, inv_scale, grads[name + ".bias"])
+            wT = self._wT16(f"fc{i + 2}T", fc.weight.view(D, Cs))
+            dmaps.append(ops.gemm(d16, wT, out_f32=True).view(B, h, w, Cs))
+            off += sizes[i]
+        grads[pre + "fc1.weight"].zero_(); grads[pre + "fc1.bias"].zero_()
+        # ---- conv4 <- conv3 <- conv2 <- stem (each map also feeds its fc projection)
+        d3 = stage_bwd(self, "conv4", saved["conv4"], dmaps[2], self.conv4[0], self.conv4[1], inv_scale, grads, pre + "conv4",
+                       True, sync_bn)
+        ops.add_f32(d3.view(B, -1, d3.shape[-1]), dmaps[1].view(B, -1, d3.shape[-1]), out=d3.view(B, -1, d3.shape[-1]))
+        d2_ = stage_bwd(self, "conv3", saved["conv3"], d3, self.conv3[0], self.conv3[1], inv_scale, grads, pre + "conv3", True,
+                        sync_bn)
+        ops.add_f32(d2_.view(B, -1, d2_.shape[-1]), dmaps[0].view(B, -1, d2_.shape[-1]), out=d2_.view(B, -1, d2_.shape[-1]))
+        d1 = stage_bwd(self, "conv2", saved["conv2"], d2_, self.conv2[0], self.conv2[1], inv_scale, grads, pre + "conv2", True,
+                       sync_bn)
+        da = stage_bwd(self, "stem6", saved["stem6"], d1, self.stem[6], self.stem[7], inv_scale, grads, pre + "stem", True,
+                       sync_bn, conv_name=pre + "stem.6", bn_name=pre + "stem.7")
+        d0 = stage_bwd(self, "stem3", saved["stem3"], da, self.stem[3], self.stem[4], inv_scale, grads, pre + "stem", True,
+                       sync_bn, conv_name=pre + "stem.3", bn_name=pre + "stem.4")
+        # ---- stem conv 0 (3 -> inplanes, stride 2): BatchNorm / ReLU backward, weight gradient on the 8-channel image
+        import torch.distributed as dist
+        x8, raw0, scale, shift, mean, invstd, count = saved["stem0"]
+        C0 = raw0.shape[-1]
+        g, partial = ops.upsample_bn_relu_bwd(d0, raw0, scale, shift, mean, invstd, 1)
+        red = ops.reduce_rows(partial.view(partial.shape[0], 2 * C0))
+        if sync_bn and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(red)
+        dx16, _ = ops.bn_bwd_apply(g, raw0, mean, invstd, self._f32("stem1.g", self.stem[1].weight), red[C0:], red[:C0], count, dt)
+        ops.reduce_rows(red[:C0].view(1, C0), inv_scale, grads[pre + "stem.1.bias"])
+        ops.reduce_rows(red[C0:].view(1, C0), inv_scale, grads[pre + "stem.1.weight"])
+        gw = ops.wgrad(dx16, x8, C0, 3, 3, 2, 1, inv_scale)                 # [C0, 8, 3, 3]
+        grads[pre + "stem.0.weight"].copy_(gw[:, :3])
+
     def forward(self, x):
         """`encoders.py:49-74`: returns (c1 map (B,D,H/4,W/4), c2, c3, c4 token tensors)."""
         c1, c, shapes = self.forward_tokens(x, need_c1=self.compute_c1)

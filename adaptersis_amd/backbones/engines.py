@@ -82,7 +82,8 @@ class SegEngine(nn.Module):
 
     def __init__(self, model, backbone_encoder, cross_vit: CAViT, cross_cnn: CACNN, seg_decoder, *,
                  n_last_blocks: int = 4, num_classes: int = 2, lr: float = 0.01, momentum: float = 0.99,
-                 weight_decay: float = 3e-5, mode: str = "reference_exact", process_group=None, loss: str = "dice"):
+                 weight_decay: float = 3e-5, mode: str = "reference_exact", process_group=None, loss: str = "dice",
+                 train_encoder: bool = False):
         """``seg_decoder``: ``FeatureDecoder`` -> the `train.py` flow; ``DecoderMLA`` -> the `train_mla.py` flow
         (block -> CACNN -> CAViT order, the four adapter-stream maps feed the MLA head, `blocks[-2]` is evaluated
         twice and `blocks[-1]` never: `train_mla.py:318,340`).  ``loss``: a key of ``SegEngine.LOSSES``."""
@@ -101,7 +102,10 @@ class SegEngine(nn.Module):
         self.patch = model.patch_size
         self.heads = model.num_heads
         self.process_group = process_group
-        frozen = list(model.parameters()) + list(backbone_encoder.parameters())
+        if train_encoder and mode != "train_adapters":
+            raise ValueError("train_encoder needs mode='train_adapters'")
+        self.train_encoder = train_encoder
+        frozen = list(model.parameters()) + ([] if train_encoder else list(backbone_encoder.parameters()))
         if mode == "reference_exact":
             frozen += list(cross_vit.parameters()) + list(cross_cnn.parameters())
         for p in frozen:
@@ -128,6 +132,13 @@ class SegEngine(nn.Module):
             self.adapter_bucket = FlatBucket(named_a)
             self.adapter_reducer = StageReducer(self.adapter_bucket.grad, [(0, self.adapter_bucket.numel)], process_group)
             buckets.append(self.adapter_bucket)
+            self.encoder_bucket = None
+            if train_encoder:  # the last member of the reference's optimiser list (`train.py:183`): the spatial-prior CNN
+                for p in backbone_encoder.parameters():
+                    p.requires_grad_(True)
+                self.encoder_bucket = FlatBucket([("backbone_encoder." + n, p) for n, p in backbone_encoder.named_parameters()])
+                self.encoder_reducer = StageReducer(self.encoder_bucket.grad, [(0, self.encoder_bucket.numel)], process_group)
+                buckets.append(self.encoder_bucket)
         self.optimizer = SGD(buckets, lr=lr, momentum=momentum, weight_decay=weight_decay)
         self.reducer = StageReducer(self.bucket.grad, self.stage_ranges, process_group)
         self._geom = {}
@@ -168,7 +179,11 @@ class SegEngine(nn.Module):
         N = h * w
         nb = len(m.blocks)
         nl = self.n_last_blocks
-        _, c, shapes = self.backbone_encoder.forward_tokens(inp, need_c1=False)
+        if self.train_encoder and adapter_saves is not None:
+            c, shapes, esaved = self.backbone_encoder.forward_tokens_train(inp)
+            self._esaved = (esaved, shapes)
+        else:
+            _, c, shapes = self.backbone_encoder.forward_tokens(inp, need_c1=False)
         c_orig = c
         Lc = c.shape[1]
         g = self._geometry(H, W, shapes, inp.device)
@@ -308,8 +323,13 @@ class SegEngine(nn.Module):
             dcat = dec._backward_core(saved, d16, bpart, inv, self.bucket.views, stage_done=self.reducer.stage_done, d_lo=d_lo,
                                       need_input_grad=True)
             self.adapter_reducer.begin()
-            self._adapter_backward(asaves, dcat, inv)
+            dc0 = self._adapter_backward(asaves, dcat, inv)
             self.adapter_reducer.stage_done()
+            if self.train_encoder:
+                self.encoder_reducer.begin()
+                self._encoder_backward(dc0, dcat, inv)
+                self.encoder_reducer.stage_done()
+                self.encoder_reducer.finish()
             self.adapter_reducer.finish()
         else:
             dec._backward_core(saved, d16, bpart, inv, self.bucket.views, stage_done=self.reducer.stage_done, d_lo=d_lo)
@@ -352,6 +372,24 @@ class SegEngine(nn.Module):
             if s > 0:
                 dx = m.blocks[nb - (nl - 1) + s - 1].backward(bsaved, dx_in, inv, None)
         ops.reduce_rows(slabs, 1.0, ab.grad)
+        return dc_next  # gradient of the encoder's pyramid tokens c (stage-0 input), fp32 [B*Lc, D]
+
+    def _encoder_backward(self, dc0: torch.Tensor, dcat: torch.Tensor, inv: float) -> None:
+        """d c = what the adapter stages send back + the c4 slice of the decoder input (`train.py:395-400`: c4 is
+        zero-padded, centred, into channels [D, 2D) of the concat) -> FeatureEncoder.backward_tokens."""
+        esaved, shapes = self._esaved
+        self._esaved = None
+        B, h, w, D3 = dcat.shape
+        D = D3 // 3
+        h4, w4 = shapes[2]
+        n4 = h4 * w4
+        Lc = dc0.shape[0] // B
+        top, left = (h - h4) // 2, (w - w4) // 2
+        d4 = dcat[:, top:top + h4, left:left + w4, D:2 * D].reshape(B, n4, D).contiguous()
+        dc = dc0.view(B, Lc, D)
+        ops.add_f32(dc[:, Lc - n4:], d4, out=dc[:, Lc - n4:])
+        gviews = {n[len("backbone_encoder."):]: v for n, v in self.encoder_bucket.views.items()}
+        self.backbone_encoder.backward_tokens(esaved, dc, inv, gviews)
 
     @torch.no_grad()
     def eval_logits(self, inp: torch.Tensor) -> torch.Tensor:

@@ -108,6 +108,106 @@ __global__ __launch_bounds__(256) void upsample_bn_relu_bwd_kernel(const float* 
   }
 }
 
+// Transpose of BN + ReLU + MaxPool2d(3, stride 2, pad 1) (encoders.py:17-18, the stem's tail), gather form:
+// g[b,ih,iw,c] = relu'(bn(x)) * sum over the <= 4 pooling windows that contain (ih,iw) and whose FIRST maximum (scan
+// order, as ATen) is this pixel of dy[b,oh,ow,c]; + the BatchNorm partial sums like upsample_bn_relu_bwd_kernel.
+__global__ __launch_bounds__(256) void maxpool_bn_relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                  const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                  const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                  float* __restrict__ g, float* __restrict__ partial, int B,
+                                                                  int H, int W, int OH, int OW, int C, int CW, int RW) {
+  __shared__ float red[2][256 * 4];
+  const int cpt = C >> 2;
+  const int64_t rows = (int64_t)B * H * W;
+  const int cx = threadIdx.x % CW, ry = threadIdx.x / CW;
+  const int c = blockIdx.y * CW + cx;
+  const bool live = c < cpt;
+  const int cc = live ? c : 0;
+  const float4 sc = reinterpret_cast<const float4*>(scale)[cc], sh = reinterpret_cast<const float4*>(shift)[cc];
+  const float4 mu = reinterpret_cast<const float4*>(mean)[cc], is = reinterpret_cast<const float4*>(invstd)[cc];
+  float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+  auto act = [&](const float4 v) {
+    return make_float4(fmaxf(v.x * sc.x + sh.x, 0.f), fmaxf(v.y * sc.y + sh.y, 0.f), fmaxf(v.z * sc.z + sh.z, 0.f),
+                       fmaxf(v.w * sc.w + sh.w, 0.f));
+  };
+  for (int64_t pix = (int64_t)blockIdx.x * RW + ry; live && pix < rows; pix += (int64_t)gridDim.x * RW) {
+    const int iw = (int)(pix % W);
+    const int ih = (int)((pix / W) % H);
+    const int b = (int)(pix / ((int64_t)W * H));
+    const float* xb = x + (int64_t)b * H * W * C;
+    const float4 xv = reinterpret_cast<const float4*>(xb + ((int64_t)ih * W + iw) * C)[c];
+    const float4 me = act(xv);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int oh = (ih - 1 + 1) >> 1; oh <= (ih + 1) >> 1; ++oh) {   // windows with 2*oh - 1 <= ih <= 2*oh + 1
+      if (oh < 0 || oh >= OH || 2 * oh - 1 > ih || ih > 2 * oh + 1) continue;
+      for (int ow = (iw - 1 + 1) >> 1; ow <= (iw + 1) >> 1; ++ow) {
+        if (ow < 0 || ow >= OW || 2 * ow - 1 > iw || iw > 2 * ow + 1) continue;
+        // is (ih, iw) the first maximum of window (oh, ow)?  per channel: no earlier element >=, no later element >
+        bool w0 = true, w1 = true, w2 = true, w3 = true;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            const int yy = 2 * oh - 1 + kh, xx = 2 * ow - 1 + kw;
+            if ((unsigned)yy >= (unsigned)H || (unsigned)xx >= (unsigned)W || (yy == ih && xx == iw)) continue;
+            const float4 o = act(reinterpret_cast<const float4*>(xb + ((int64_t)yy * W + xx) * C)[c]);
+            const bool earlier = yy < ih || (yy == ih && xx < iw);
+            if (earlier) { w0 &= o.x < me.x; w1 &= o.y < me.y; w2 &= o.z < me.z; w3 &= o.w < me.w; }
+            else { w0 &= o.x <= me.x; w1 &= o.y <= me.y; w2 &= o.z <= me.z; w3 &= o.w <= me.w; }
+          }
+        const float4 d = reinterpret_cast<const float4*>(dy + (((int64_t)b * OH + oh) * OW + ow) * C)[c];
+        if (w0) acc.x += d.x;
+        if (w1) acc.y += d.y;
+        if (w2) acc.z += d.z;
+        if (w3) acc.w += d.w;
+      }
+    }
+    float4 gg;
+    gg.x = me.x > 0.f ? acc.x : 0.f; gg.y = me.y > 0.f ? acc.y : 0.f;
+    gg.z = me.z > 0.f ? acc.z : 0.f; gg.w = me.w > 0.f ? acc.w : 0.f;
+    reinterpret_cast<float4*>(g + pix * C)[c] = gg;
+    s1.x += gg.x; s1.y += gg.y; s1.z += gg.z; s1.w += gg.w;
+    s2.x += gg.x * (xv.x - mu.x) * is.x; s2.y += gg.y * (xv.y - mu.y) * is.y;
+    s2.z += gg.z * (xv.z - mu.z) * is.z; s2.w += gg.w * (xv.w - mu.w) * is.w;
+  }
+  reinterpret_cast<float4*>(red[0])[threadIdx.x] = s1;
+  reinterpret_cast<float4*>(red[1])[threadIdx.x] = s2;
+  __syncthreads();
+  if (ry == 0 && live) {
+    for (int t = cx + CW; t < CW * RW; t += CW) {
+      const float4 a = reinterpret_cast<const float4*>(red[0])[t], bq = reinterpret_cast<const float4*>(red[1])[t];
+      s1.x += a.x; s1.y += a.y; s1.z += a.z; s1.w += a.w;
+      s2.x += bq.x; s2.y += bq.y; s2.z += bq.z; s2.w += bq.w;
+    }
+    reinterpret_cast<float4*>(partial + ((int64_t)blockIdx.x * 2 + 0) * C)[c] = s1;
+    reinterpret_cast<float4*>(partial + ((int64_t)blockIdx.x * 2 + 1) * C)[c] = s2;
+  }
+}
+
+// zero-insertion of a stride-2 gradient: out[b, 2i, 2j, :] = in[b, i, j, :], everything else 0 (out is Hd x Wd); a
+// stride-1 conv of it with the mirrored weights is the stride-2 conv's input gradient (conv_transpose2d)
+template <typename T>
+__global__ __launch_bounds__(256) void dilate2_kernel(const T* __restrict__ in, const T* __restrict__ in_lo, T* __restrict__ out,
+                                                      T* __restrict__ out_lo, int B, int OH, int OW, int Hd, int Wd, int C) {
+  const int cpt = C >> 3;
+  const int64_t total = (int64_t)B * Hd * Wd * cpt;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cpt);
+    const int64_t pix = i / cpt;
+    const int xx = (int)(pix % Wd);
+    const int yy = (int)((pix / Wd) % Hd);
+    const int b = (int)(pix / ((int64_t)Wd * Hd));
+    uint4 v = make_uint4(0, 0, 0, 0), l = v;
+    if (!(yy & 1) && !(xx & 1) && (yy >> 1) < OH && (xx >> 1) < OW) {
+      const int64_t src = ((((int64_t)b * OH + (yy >> 1)) * OW + (xx >> 1)) * C) / 8 + c;
+      v = reinterpret_cast<const uint4*>(in)[src];
+      if (in_lo) l = reinterpret_cast<const uint4*>(in_lo)[src];
+    }
+    reinterpret_cast<uint4*>(out)[i] = v;
+    if (out_lo) reinterpret_cast<uint4*>(out_lo)[i] = l;
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ x,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -214,6 +314,38 @@ extern "C" int asis_upsample_bn_relu_bwd(void* stream, const float* dU, const fl
   hipLaunchKernelGGL(upsample_bn_relu_bwd_kernel, dim3(nblk, tiles), dim3(CW * RW), 0, reinterpret_cast<hipStream_t>(stream),
                      dU, x, scale, shift, mean, invstd, g, partial, B, H, W, H * factor, W * factor, C, CW, RW);
   ASIS_CHECK_LAUNCH("asis_upsample_bn_relu_bwd");
+  return ASIS_OK;
+}
+
+extern "C" int asis_maxpool_bn_relu_bwd(void* stream, const float* dy, const float* x, const float* scale, const float* shift,
+                                        const float* mean, const float* invstd, float* g, float* partial, int B, int H, int W,
+                                        int C) {
+  ASIS_REQUIRE(dy && x && scale && shift && mean && invstd && g && partial, "asis_maxpool_bn_relu_bwd: null pointer");
+  ASIS_REQUIRE(C % 4 == 0 && C >= 4, "asis_maxpool_bn_relu_bwd: C=%d must be a positive multiple of 4", C);
+  const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+  int CW, RW, tiles;
+  bn_bwd_shape(C, &CW, &RW, &tiles);
+  const int nblk = asis_bn_bwd_nblk((int64_t)B * H * W, C);
+  hipLaunchKernelGGL(maxpool_bn_relu_bwd_kernel, dim3(nblk, tiles), dim3(CW * RW), 0, reinterpret_cast<hipStream_t>(stream), dy, x,
+                     scale, shift, mean, invstd, g, partial, B, H, W, OH, OW, C, CW, RW);
+  ASIS_CHECK_LAUNCH("asis_maxpool_bn_relu_bwd");
+  return ASIS_OK;
+}
+
+extern "C" int asis_dilate2(void* stream, int dtype, const void* in, const void* in_lo, void* out, void* out_lo, int B, int OH,
+                            int OW, int Hd, int Wd, int C) {
+  ASIS_REQUIRE(in && out && (in_lo == nullptr) == (out_lo == nullptr), "asis_dilate2: null pointer / lo halves go together");
+  ASIS_REQUIRE(dtype == ASIS_F16 || dtype == ASIS_BF16, "asis_dilate2: bad dtype %d", dtype);
+  ASIS_REQUIRE(C % 8 == 0 && C > 0 && Hd >= 2 * OH - 1 && Wd >= 2 * OW - 1, "asis_dilate2: C %% 8 == 0 and Hd >= 2*OH-1 needed");
+  const int64_t total = (int64_t)B * Hd * Wd * (C / 8);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == ASIS_F16)
+    hipLaunchKernelGGL((dilate2_kernel<f16>), dim3(grid_for(total)), dim3(256), 0, s, (const f16*)in, (const f16*)in_lo, (f16*)out,
+                       (f16*)out_lo, B, OH, OW, Hd, Wd, C);
+  else
+    hipLaunchKernelGGL((dilate2_kernel<bf16>), dim3(grid_for(total)), dim3(256), 0, s, (const bf16*)in, (const bf16*)in_lo,
+                       (bf16*)out, (bf16*)out_lo, B, OH, OW, Hd, Wd, C);
+  ASIS_CHECK_LAUNCH("asis_dilate2");
   return ASIS_OK;
 }
 

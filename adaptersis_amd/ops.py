@@ -824,6 +824,29 @@ def upsample_bn_relu_bwd(dU: torch.Tensor, x: torch.Tensor, scale, shift, mean, 
     return g, partial
 
 
+def maxpool_bn_relu_bwd(dy: torch.Tensor, x: torch.Tensor, scale, shift, mean, invstd):
+    """dy fp32 [B,OH,OW,C] (gradient of BN+ReLU+MaxPool(3,2,1) output), x raw [B,H,W,C] -> (g, partial [nblk,2,C])."""
+    _dev(dy, x)
+    B, H, W, Cc = x.shape
+    g = torch.empty_like(x)
+    partial = torch.empty((lib().asis_bn_bwd_nblk(B * H * W, Cc), 2, Cc), device=x.device, dtype=torch.float32)
+    check(lib().asis_maxpool_bn_relu_bwd(_stream(), _f32c(dy).data_ptr(), _f32c(x).data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                         mean.data_ptr(), invstd.data_ptr(), g.data_ptr(), partial.data_ptr(), B, H, W, Cc),
+          "asis_maxpool_bn_relu_bwd")
+    return g, partial
+
+
+def dilate2(x: torch.Tensor, x_lo: Optional[torch.Tensor], Hd: int, Wd: int):
+    """16-bit NHWC [B,OH,OW,C] (+lo) -> [B,Hd,Wd,C] with the input at even positions, zeros elsewhere."""
+    _dev(x, x_lo)
+    B, OH, OW, Cc = x.shape
+    out = torch.empty((B, Hd, Wd, Cc), device=x.device, dtype=x.dtype)
+    out_lo = torch.empty_like(out) if x_lo is not None else None
+    check(lib().asis_dilate2(_stream(), _dt(x.dtype), x.data_ptr(), _p(x_lo), out.data_ptr(), _p(out_lo), B, OH, OW, Hd, Wd, Cc),
+          "asis_dilate2")
+    return out, out_lo
+
+
 def bn_bwd_apply(g: torch.Tensor, x: torch.Tensor, mean, invstd, gamma, dgamma, dbeta, count: float,
                  dtype: torch.dtype, split: bool = False):
     """-> (dx 16-bit same shape as x, [dx_lo when split,] partial [nblk, C] column sums of dx)."""

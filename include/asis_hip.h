@@ -384,6 +384,13 @@ int asis_bn_bwd_nblk(int64_t rows, int C);
 int asis_upsample_bn_relu_bwd(void* stream, const float* dU, const float* x, const float* scale, const float* shift,
                               const float* mean, const float* invstd, float* g, float* partial, int B, int H, int W,
                               int C, int factor);
+/* the same for the stem's BN + ReLU + MaxPool2d(3, 2, 1) (encoders.py:17-18): dy fp32 [B,OH,OW,C], x = raw conv output
+ * [B,H,W,C] -> g [B,H,W,C] (gradient at the first maximum of every window, as ATen) + the same partial sums */
+int asis_maxpool_bn_relu_bwd(void* stream, const float* dy, const float* x, const float* scale, const float* shift,
+                             const float* mean, const float* invstd, float* g, float* partial, int B, int H, int W, int C);
+/* zero-insertion for the input gradient of a stride-2 conv: out[b,2i,2j,:] = in[b,i,j,:], rest 0; 16-bit NHWC (+lo) */
+int asis_dilate2(void* stream, int dtype, const void* in, const void* in_lo, void* out, void* out_lo, int B, int OH, int OW,
+                 int Hd, int Wd, int C);
 /* dx(16-bit) = gamma*invstd*(g - dbeta/n - xhat*dgamma/n); partial[asis_bn_bwd_nblk(R, C)][C] = sum dx.
  * out_lo (optional) = rounding residual of dx: the dgrad GEMM chain runs split-precision because the
  * mean subtraction of the next BatchNorm backward amplifies 16-bit rounding noise (Numerics). */

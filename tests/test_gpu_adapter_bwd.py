@@ -197,3 +197,33 @@ def test_engine_train_adapters_step_vs_oracle(dev):
     assert len(eng.optimizer.param_groups) == 2
     p_after = dict(eng.cross_vit.named_parameters())["attn.value_proj.weight"].detach().cpu()
     assert not torch.equal(p_after, sds["cv"]["attn.value_proj.weight"])
+
+
+def test_encoder_backward(dev):
+    """FeatureEncoder (stem with MaxPool, three stride-2 conv stages, SyncBN in train mode, 1x1 projections) in training
+    form + backward of every parameter against autograd of the oracle encoder."""
+    from adaptersis_amd.backbones.encoders import FeatureEncoder
+    D, B, size = 128, 2, 224
+    sd = W.make_encoder_state_dict(D)
+    enc = FeatureEncoder(embed_dim=D)
+    enc.load_state_dict(sd)
+    enc = enc.to(dev)
+    img = W.synthetic_batch(B, size)[0]
+    osd = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sd.items()}
+    c1, c2, c3, c4, shapes = O.feature_encoder(img, osd)
+    c_ref = torch.cat([c2, c3, c4], 1)
+    dc = W.tensor("encb.dc", tuple(c_ref.shape), 1.0)
+    (c_ref * dc).sum().backward()
+    c, shp, saved = enc.forward_tokens_train(img.to(dev), sync_bn=False)
+    assert [tuple(s) for s in shp] == [tuple(s) for s in shapes]
+    assert rel_l2(c, c_ref) < 1e-4
+    S = 16.0
+    grads = {k: torch.full_like(p, float("nan"), dtype=torch.float32) for k, p in enc.named_parameters()}
+    enc.backward_tokens(saved, (dc * S).to(dev), 1.0 / S, grads, sync_bn=False)
+    errs = {k: rel_l2(grads[k], osd[k].grad) for k in grads if osd[k].grad is not None and float(osd[k].grad.norm()) > 0}
+    print("encoder grads:", {k: "%.1e" % v for k, v in errs.items()})
+    assert float(grads["fc1.weight"].abs().sum()) == 0      # c1 is unused by the step
+    assert set(errs) >= {"stem.0.weight", "stem.7.weight", "conv2.0.weight", "conv3.0.weight", "conv4.0.weight", "fc4.bias"}
+    # ReLU / MaxPool branch flips on the small maps set the floor for everything upstream (tests/test_gpu_unet.py)
+    assert max(errs.values()) < 5e-2, errs
+    assert sorted(errs.values())[len(errs) // 2] < 1e-2
