@@ -30,7 +30,7 @@ import torch.distributed as dist  # noqa: E402
 MFMA_F16_DENSE_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16/f16 (no sparsity)
 
 
-def build_engine(arch: str, dev, lr: float, mode: str = "reference_exact"):
+def build_engine(arch: str, dev, lr: float, mode: str = "reference_exact", train_encoder: bool = False):
     from adaptersis_amd.backbones.adapter_blocks import CACNN, CAViT
     from adaptersis_amd.backbones.decoders import FeatureDecoder
     from adaptersis_amd.backbones.encoders import FeatureEncoder
@@ -49,7 +49,8 @@ def build_engine(arch: str, dev, lr: float, mode: str = "reference_exact"):
     cn.load_state_dict(W.make_cacnn_state_dict(D, mode="kernel"))
     dec = FeatureDecoder(embed_dim=D, num_classes=2, features=[D, 512, 256, 128, 64])
     dec.load_state_dict(W.make_feature_decoder_state_dict(D, 2, features=(D, 512, 256, 128, 64)))
-    return SegEngine(model.to(dev).eval(), enc.to(dev), cv.to(dev), cn.to(dev), dec.to(dev), lr=lr, mode=mode)
+    return SegEngine(model.to(dev).eval(), enc.to(dev), cv.to(dev), cn.to(dev), dec.to(dev), lr=lr, mode=mode,
+                     train_encoder=train_encoder)
 
 
 def build_engine_cfg(cfg: int, arch: str, dev, lr: float):
@@ -201,6 +202,7 @@ def main():
     ap.add_argument("--operand", default=None, choices=[None, "f16", "bf16"])
     ap.add_argument("--train-adapters", action="store_true",
                     help="config 3 with the adapter backward (CAViT + CACNN gradients, all-reduced and optimised with the decoder)")
+    ap.add_argument("--train-encoder", action="store_true", help="with --train-adapters: also the CNN encoder (the full optimiser list of train.py:178-186)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     a = ap.parse_args()
@@ -229,7 +231,8 @@ def main():
 
     a.arch = a.arch or {2: "vit_base", 5: "vit_giant2"}.get(a.config, "vit_large")
     if a.config == 3:
-        eng = build_engine(a.arch, dev, lr=0.01, mode="train_adapters" if a.train_adapters else "reference_exact")
+        eng = build_engine(a.arch, dev, lr=0.01, mode="train_adapters" if a.train_adapters else "reference_exact",
+                           train_encoder=a.train_encoder)
     else:
         eng = build_engine_cfg(a.config, a.arch, dev, lr=0.01)
     img, tgt = synthetic(a.batch, a.size, rank, dev, 11 if a.config == 5 else 2)
@@ -295,7 +298,8 @@ def main():
                 3: f"{a.arch}/14 frozen + CAViT/CACNN adapters (n_last_blocks=4) + FeatureDecoder, "
                    f"{a.size}x{a.size}, batch {a.batch}/GPU, reference_exact train.py step "
                    "(fwd + decoder bwd + all-reduce + SGD), random-init weights" +
-                   (" + train_adapters (CAViT/CACNN backward through the 4 stages and 3 frozen blocks)" if a.train_adapters else ""),
+                   (" + train_adapters (CAViT/CACNN backward through the 4 stages and 3 frozen blocks)" if a.train_adapters else "") +
+                   (" + encoder backward" if a.train_encoder else ""),
                 2: f"BASELINE config 2: {a.arch}/14 frozen + CAViT/CACNN adapters + UNet head, CE + DC loss, "
                    f"{a.size}x{a.size}, batch {a.batch}/GPU (fwd + UNet bwd + all-reduce + SGD), random-init weights",
                 5: f"BASELINE config 5: {a.arch}/14 (SwiGLU) frozen + CAViT/CACNN adapters + DecoderMLA head, 11 classes, soft-IoU "

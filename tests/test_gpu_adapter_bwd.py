@@ -143,7 +143,8 @@ def test_cavit_cacnn_module_backward(dev):
     _check(errs)
 
 
-def test_engine_train_adapters_step_vs_oracle(dev):
+@pytest.mark.parametrize("train_encoder", [False, True])
+def test_engine_train_adapters_step_vs_oracle(dev, train_encoder):
     """`train_adapters` mode: the step of `train.py:268-436` with the autograd graph left intact (no `no_grad` around
     the adapter stream): gradients of every CAViT / CACNN parameter and of the decoder against autograd of the oracle,
     then one SGD step over both buckets."""
@@ -164,15 +165,17 @@ def test_engine_train_adapters_step_vs_oracle(dev):
     cv = CAViT(dim=D, n_levels=3, num_heads=8, init_values=0.0, n_points=4); cv.load_state_dict(sds["cv"])
     cn = CACNN(dim=D, n_levels=1, num_heads=8, n_points=4, with_cffn=True, cffn_ratio=0.25); cn.load_state_dict(sds["cn"])
     dec = FeatureDecoder(embed_dim=D, num_classes=2, features=list(feats)); dec.load_state_dict(sds["dec"])
-    eng = SegEngine(model.to(dev).eval(), enc.to(dev), cv.to(dev), cn.to(dev), dec.to(dev), lr=0.05, mode="train_adapters")
+    eng = SegEngine(model.to(dev).eval(), enc.to(dev), cv.to(dev), cn.to(dev), dec.to(dev), lr=0.05, mode="train_adapters",
+                    train_encoder=train_encoder)
     img, tgt = W.synthetic_batch(B, size)
     # oracle with the graph intact
     ocv = {k: v.clone().requires_grad_(True) for k, v in sds["cv"].items()}
     ocn = {k: v.clone().requires_grad_(True) for k, v in sds["cn"].items()}
     odec = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k and "num_batches" not in k)
             for k, v in sds["dec"].items()}
-    oenc = {k: v.clone() for k, v in sds["enc"].items()}
-    ocat = O.adapter_forward(img, sds["vit"], oenc, ocv, ocn, heads, update_bn=True)
+    oenc = {k: v.clone().requires_grad_(train_encoder and v.is_floating_point() and "running" not in k)
+            for k, v in sds["enc"].items()}
+    ocat = O.adapter_forward(img, sds["vit"], oenc, ocv, ocn, heads, update_bn=not train_encoder)
     oloss = O.train_step_loss(ocat, tgt, odec, 2, update_bn=True)
     oloss.backward()
     taps = {}
@@ -193,8 +196,14 @@ def test_engine_train_adapters_step_vs_oracle(dev):
     assert max(derr.values()) < 1e-1, derr
     # the last stage's CACNN output is unused downstream: its own last-call contribution is zero, earlier calls are not
     assert float(eng.adapter_bucket.views["cross_cnn.ffn.fc2.weight"].abs().sum()) > 0
-    # both buckets are optimised
-    assert len(eng.optimizer.param_groups) == 2
+    if train_encoder:
+        eerr = {k: rel_l2(v, oenc[k[len("backbone_encoder."):]].grad) for k, v in eng.encoder_bucket.views.items()
+                if oenc[k[len("backbone_encoder."):]].grad is not None and float(oenc[k[len("backbone_encoder."):]].grad.norm()) > 0}
+        print("train_encoder: encoder grads max %.2e median %.2e (%d tensors)" %
+              (max(eerr.values()), sorted(eerr.values())[len(eerr) // 2], len(eerr)))
+        assert max(eerr.values()) < 2.5e-1 and sorted(eerr.values())[len(eerr) // 2] < 1e-1, eerr
+    # every trainable bucket is optimised
+    assert len(eng.optimizer.param_groups) == (3 if train_encoder else 2)
     p_after = dict(eng.cross_vit.named_parameters())["attn.value_proj.weight"].detach().cpu()
     assert not torch.equal(p_after, sds["cv"]["attn.value_proj.weight"])
 
