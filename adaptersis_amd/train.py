@@ -54,11 +54,11 @@ class _SegData(torch.utils.data.Dataset):
 
 
 def _engine_for(model, backbone_encoder, cross_vit, cross_cnn, seg_decoder, lr=0.01, momentum=0.99, weight_decay=3e-5,
-                mode="reference_exact"):
+                mode="reference_exact", train_encoder=False):
     key = id(seg_decoder)
     if key not in _ENGINES:
         _ENGINES[key] = SegEngine(model, backbone_encoder, cross_vit, cross_cnn, seg_decoder, lr=lr, momentum=momentum,
-                                  weight_decay=weight_decay, mode=mode)
+                                  weight_decay=weight_decay, mode=mode, train_encoder=train_encoder)
     return _ENGINES[key]
 
 
@@ -93,7 +93,8 @@ def train_seg(args, head: str = "feature"):
     else:
         seg_decoder = FeatureDecoder(embed_dim=D, num_classes=2, features=[D, 512, 256, 128, 64]).to(dev)
         engine = _engine_for(model, backbone_encoder, cross_vit, cross_cnn, seg_decoder, lr=args.lr,
-                             mode="train_adapters" if getattr(args, "train_adapters", False) else "reference_exact")
+                             mode="train_adapters" if getattr(args, "train_adapters", False) else "reference_exact",
+                             train_encoder=getattr(args, "train_encoder", False))
     optimizer = engine.optimizer
 
     dataset_val = _SegData(args.data_path, "validation", args.imsize)
@@ -222,6 +223,7 @@ def get_args_parser():
     # extension (not in the reference CLI): train CAViT / CACNN too — what `train.py:178-186` lists in its optimiser but
     # its no_grad block keeps from training
     p.add_argument("--train_adapters", action="store_true")
+    p.add_argument("--train_encoder", action="store_true", help="with --train_adapters: also the CNN encoder")
     return p
 
 
