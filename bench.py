@@ -218,6 +218,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # "nccl" == RCCL on ROCm
 
+    # torchrun exports OMP_NUM_THREADS=1: give every rank its share of the host cores for the (CPU, Philox) weight generation
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    torch.set_num_threads(max(1, min(16, cores // max(1, world))))
+
     from adaptersis_amd import config, ops
     from adaptersis_amd.build import build_library
     # one builder per node (normally a no-op: the prebuilt in-tree .so is up to date); the other ranks wait for it
