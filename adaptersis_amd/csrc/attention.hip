@@ -33,8 +33,8 @@ __device__ __forceinline__ int perm23(int r) {  // swap bits 2 and 3
   return (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1);
 }
 
-template <typename T>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, int64_t ldqk,
+template <typename T, int OCC>
+__global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, int64_t ldqk,
                                                        const T* __restrict__ vt, int64_t ldvt, T* __restrict__ o,
                                                        int64_t ldo, int H, int N, float scale_log2e,
                                                        float* __restrict__ lse2) {
@@ -229,14 +229,17 @@ extern "C" int asis_attention_fwd_lse(void* stream, int dtype, const void* q, co
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   dim3 grid((N + QT - 1) / QT, H, B), block(256);
   const float sl = scale * 1.4426950408889634f;
-  if (dtype == ASIS_F16)
-    hipLaunchKernelGGL((attn_fwd_kernel<f16>), grid, block, 0, s, reinterpret_cast<const f16*>(q),
-                       reinterpret_cast<const f16*>(k), ldqk, reinterpret_cast<const f16*>(vt), ldvt,
-                       reinterpret_cast<f16*>(o), ldo, H, N, sl, lse2);
-  else
-    hipLaunchKernelGGL((attn_fwd_kernel<bf16>), grid, block, 0, s, reinterpret_cast<const bf16*>(q),
-                       reinterpret_cast<const bf16*>(k), ldqk, reinterpret_cast<const bf16*>(vt), ldvt,
-                       reinterpret_cast<bf16*>(o), ldo, H, N, sl, lse2);
+  // workgroups per CU the kernel is compiled for (register budget 256 / 168 / 128 VGPRs): ASIS_ATTN_OCC = 2 | 3 | 4
+  static const int occ = [] { const char* e = getenv("ASIS_ATTN_OCC"); const int v = e ? atoi(e) : 2; return v < 2 ? 2 : (v > 4 ? 4 : v); }();
+#define ASIS_ATTN_LAUNCH(TT, O)                                                                                        \
+  hipLaunchKernelGGL((attn_fwd_kernel<TT, O>), grid, block, 0, s, reinterpret_cast<const TT*>(q), reinterpret_cast<const TT*>(k), \
+                     ldqk, reinterpret_cast<const TT*>(vt), ldvt, reinterpret_cast<TT*>(o), ldo, H, N, sl, lse2)
+  if (dtype == ASIS_F16) {
+    if (occ == 2) ASIS_ATTN_LAUNCH(f16, 2); else if (occ == 3) ASIS_ATTN_LAUNCH(f16, 3); else ASIS_ATTN_LAUNCH(f16, 4);
+  } else {
+    if (occ == 2) ASIS_ATTN_LAUNCH(bf16, 2); else if (occ == 3) ASIS_ATTN_LAUNCH(bf16, 3); else ASIS_ATTN_LAUNCH(bf16, 4);
+  }
+#undef ASIS_ATTN_LAUNCH
   ASIS_CHECK_LAUNCH("asis_attention_fwd");
   return ASIS_OK;
 }
