@@ -117,6 +117,31 @@ def vit_case(R, arch, size, batch, out, tag):
     out[f"{tag}.passB.x"] = sub(xb)
 
 
+def vit_backward_case(R, out, arch="vit_large_d4", size=588, batch=1, tag="vitbwd"):
+    """`eval/eval_dinov2_setr_cross_ete.py:318-347` backbone part: the imported reference ViT (ViT-L width: D = 1024, 16
+    heads, N = 1764 + cls, reduced to 4 blocks) under autograd, ``model(img, is_training=True)["x_norm_patchtokens"]``
+    with a fixed cotangent; gradients of every parameter."""
+    D, depth, heads, _ = W.VIT_CONFIGS[arch]
+    sd = W.make_vit_state_dict(arch)
+    m = build_ref_vit(R, arch, sd)
+    m.train()   # the reference calls model.train() (:308); drop_path is 0 for the teacher: same maths as eval
+    img, _ = W.synthetic_batch(batch, size)
+    N = (size // 14) ** 2
+    dy = W.tensor(f"{tag}.dy", (batch, N, D), 1.0)
+    tok = m(img, is_training=True)["x_norm_patchtokens"]
+    (tok * dy).sum().backward()
+    osd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    otok = O.forward_features(img, osd, heads)["x_norm_patchtokens"]
+    (otok * dy).sum().backward()
+    close(otok.detach(), tok.detach(), 2e-5, f"{tag} tokens")
+    out[f"{tag}.tokens"] = sub(tok)
+    for k, p in m.named_parameters():
+        if p.grad is None:
+            continue
+        close(osd[k].grad, p.grad, 1e-4, f"{tag} grad {k}")
+        out[f"{tag}.grad.{k}"] = sub(p.grad, 6000)
+
+
 def adapter_case(R, out, D=1024, size=588, batch=1, tag="adapter588"):
     """CAViT / CACNN at the only geometry the reference supports (fact 3)."""
     csd = W.make_cavit_state_dict(D)
@@ -547,6 +572,10 @@ def main():
         print("[decoder D=32 hw=6 B=2]"); decoder_case(R, out, 32, 6, 2, "dec_small")
         print("[MLA / UNet]"); mla_unet_case(R, out)
         save("small", out)
+    if want("vitbwd"):
+        out = {}
+        print("[ViT-L-width (4 blocks) forward_features + backward of every parameter, 588 B=1]"); vit_backward_case(R, out)
+        save("vitbwd", out)
     if want("setr"):
         out = {}
         print("[DecoderSETR step]"); setr_case(R, out)

@@ -234,3 +234,28 @@ def test_end_to_end_engine_step_vs_oracle(dev):
         O.sgd_momentum_step({k: od[k] for k in names}, {k: od[k].grad for k in names}, {}, 0.05, 0.9, 0.0)
     live = dict(eng.seg_decoder.named_parameters())
     assert max(rel_l2(live[k], od[k]) for k in names) < 1e-3
+
+
+def test_vit_large_width_backward_vs_reference_golden(dev):
+    """ViT-L width (D = 1024, 16 heads, N = 1764 + cls, 588x588, 4 blocks): tokens and the gradient of every parameter
+    against the golden captured from the IMPORTED reference under autograd (tests/golden/vitbwd.pt)."""
+    from adaptersis_amd.dinov2.models import vision_transformer as vits
+    from tests.conftest import golden_err, load_golden
+    g = load_golden("vitbwd")
+    arch, size = "vit_large_d4", 588
+    D, depth, heads, ffn = W.VIT_CONFIGS[arch]
+    model = vits.__dict__[arch](patch_size=14, img_size=518, init_values=1e-5, ffn_layer=ffn, block_chunks=0)
+    model.load_state_dict(W.make_vit_state_dict(arch))
+    model = model.to(dev)
+    img = W.synthetic_batch(1, size)[0]
+    N = (size // 14) ** 2
+    dy = W.tensor("vitbwd.dy", (1, N, D), 1.0)
+    tok, saved = model.forward_train(img.to(dev))
+    assert golden_err(tok, g["vitbwd.tokens"]) < 1e-3
+    S = 1024.0
+    grads = {k: torch.empty_like(p, dtype=torch.float32) for k, p in model.named_parameters()}
+    model.backward(saved, (dy * S).to(dev), 1.0 / S, grads)
+    errs = {k: golden_err(v, g[f"vitbwd.grad.{k}"]) for k, v in grads.items() if f"vitbwd.grad.{k}" in g}
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    print("ViT-L width backward vs reference: worst", [(k, "%.1e" % v) for k, v in worst], "of", len(errs))
+    assert max(errs.values()) < 5e-3, worst

@@ -264,3 +264,20 @@ def test_decoder_setr_step():
     for k, v in osd.items():
         if v.requires_grad:
             assert rel_l2(v.grad, g[f"setr.grad.{k}"]) < 1e-3, k
+
+
+@pytest.mark.skipif(not __import__("os").environ.get("ASIS_SLOW"), reason="slow CPU case: set ASIS_SLOW=1")
+def test_vit_backward_golden():
+    """Oracle autograd of forward_features at ViT-L width == the imported reference's (tests/golden/vitbwd.pt)."""
+    g = load_golden("vitbwd")
+    arch, size = "vit_large_d4", 588
+    D, depth, heads, _ = W.VIT_CONFIGS[arch]
+    sd = {k: v.clone().requires_grad_(True) for k, v in W.make_vit_state_dict(arch).items()}
+    img = W.synthetic_batch(1, size)[0]
+    dy = W.tensor("vitbwd.dy", (1, (size // 14) ** 2, D), 1.0)
+    tok = O.forward_features(img, sd, heads)["x_norm_patchtokens"]
+    (tok * dy).sum().backward()
+    assert golden_err(tok, g["vitbwd.tokens"]) < 1e-5
+    for k, v in sd.items():
+        if f"vitbwd.grad.{k}" in g:
+            assert golden_err(v.grad, g[f"vitbwd.grad.{k}"]) < 1e-4, k
