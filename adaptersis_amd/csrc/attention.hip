@@ -155,17 +155,26 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(const T* __restrict_
         oacc[1][r] *= alpha;
       }
     }
-    float psum = 0.f;
+    // two scores at a time: the scale-and-shift and the row-sum accumulate as packed fp32 ops (v_pk_fma_f32 /
+    // v_pk_add_f32: half the VALU issue slots of the scalar forms; the exp2 itself has no packed form)
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 sc2 = {scale_log2e, scale_log2e}, nm2 = {-m_run, -m_run};
+    f32x2 ps2 = {0.f, 0.f};
     v8 pf[2][2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[kb][r], scale_log2e, -m_run));
-        psum += p;
-        pf[kb][r >> 3][r & 7] = (T)p;
+      for (int r = 0; r < 16; r += 2) {
+        const f32x2 s2 = {sacc[kb][r], sacc[kb][r + 1]};
+        const f32x2 t = __builtin_elementwise_fma(s2, sc2, nm2);
+        f32x2 p2;
+        p2.x = __builtin_amdgcn_exp2f(t.x);
+        p2.y = __builtin_amdgcn_exp2f(t.y);
+        ps2 += p2;
+        pf[kb][r >> 3][r & 7] = (T)p2.x;
+        pf[kb][r >> 3][(r & 7) + 1] = (T)p2.y;
       }
-    l_run += psum;
+    l_run += ps2.x + ps2.y;
 #pragma unroll
     for (int db = 0; db < 2; ++db) {
       const int row = db * 32 + fr;
