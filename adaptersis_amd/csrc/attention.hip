@@ -36,21 +36,24 @@ __device__ __forceinline__ int perm23(int r) {  // swap bits 2 and 3
 template <typename T, int OCC>
 __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, int64_t ldqk,
                                                        const T* __restrict__ vt, int64_t ldvt, T* __restrict__ o,
-                                                       int64_t ldo, int H, int N, float scale_log2e,
-                                                       float* __restrict__ lse2) {
+                                                       int64_t ldo, int H, int N1, float scale_log2e,
+                                                       float* __restrict__ lse2, int B1, int N2) {
   typedef typename T16<T>::v8 v8;
   __shared__ __attribute__((aligned(16))) T lds[2 * 2 * KT * HD];  // [buf][K | Vt][64][64] = 32 KiB
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int fr = lane & 31, fh = lane >> 5;
   const int head = blockIdx.y, b = blockIdx.z;
+  // two stacked token batches (images 0..B1-1 with N1 tokens, the rest with N2): row0 = first row of image b
+  const int N = b < B1 ? N1 : N2;
+  const int64_t row0 = b < B1 ? (int64_t)b * N1 : (int64_t)B1 * N1 + (int64_t)(b - B1) * N2;
   const int q_base = blockIdx.x * QT + wid * 32;
 
   // ---- Q^T fragments (B operand of S^T = K Q^T): lane (fr, fh) holds Q[q][16s + 8fh .. +7] ----
   v8 qf[4];
   {
     const int qi = q_base + fr;
-    const T* qp = q + ((int64_t)b * N + (qi < N ? qi : 0)) * ldqk + head * HD + 8 * fh;
+    const T* qp = q + (row0 + (qi < N ? qi : 0)) * ldqk + head * HD + 8 * fh;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       uint4 v = make_uint4(0, 0, 0, 0);
@@ -60,7 +63,7 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(const T* __restrict_
   }
 
   // ---- K / V^T tile loaders: 512 16-byte chunks each, 2 per thread ----
-  const T* kbase = k + (int64_t)b * N * ldqk + head * HD;
+  const T* kbase = k + row0 * ldqk + head * HD;
   const T* vbase = vt + ((int64_t)b * H + head) * HD * ldvt;
   uint4 rk[2], rv[2];
   auto load_tile = [&](int key0) {
@@ -207,9 +210,9 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(const T* __restrict_
   const float inv = 1.0f / l_tot;
   const int qi = q_base + fr;
   // log2-domain log-sum-exp of the scaled scores, per query: what the backward needs to rebuild P = exp2(s*c - lse2)
-  if (lse2 && qi < N && fh == 0) lse2[((int64_t)b * H + head) * N + qi] = m_run + __builtin_amdgcn_logf(l_tot);
+  if (lse2 && qi < N && fh == 0) lse2[((int64_t)b * H + head) * N1 + qi] = m_run + __builtin_amdgcn_logf(l_tot);  // single batch only
   if (qi < N) {
-    T* op = o + ((int64_t)b * N + qi) * ldo + head * HD + 4 * fh;
+    T* op = o + (row0 + qi) * ldo + head * HD + 4 * fh;
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -224,10 +227,14 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(const T* __restrict_
 
 }  // namespace
 
-extern "C" int asis_attention_fwd_lse(void* stream, int dtype, const void* q, const void* k, int64_t ldqk, const void* vt,
-                                      int64_t ldvt, void* o, int64_t ldo, int B, int H, int N, float scale, float* lse2) {
+extern "C" int asis_attention_fwd_seg(void* stream, int dtype, const void* q, const void* k, int64_t ldqk, const void* vt,
+                                      int64_t ldvt, void* o, int64_t ldo, int B1, int N1, int B2, int N2, int H, float scale,
+                                      float* lse2) {
+  const int B = B1 + B2;
+  const int N = N1 > N2 ? N1 : N2;
   ASIS_REQUIRE(q && k && vt && o, "asis_attention_fwd: null pointer");
-  ASIS_REQUIRE(B > 0 && H > 0 && N > 0, "asis_attention_fwd: bad shape B=%d H=%d N=%d", B, H, N);
+  ASIS_REQUIRE(B1 > 0 && B2 >= 0 && H > 0 && N1 > 0 && (B2 == 0 || N2 > 0), "asis_attention_fwd: bad shape");
+  ASIS_REQUIRE(!lse2 || B2 == 0, "asis_attention_fwd: the log-sum-exp output is for a single token batch");
   ASIS_REQUIRE(B <= 65535 && H <= 65535, "asis_attention_fwd: B/H too large");
   ASIS_REQUIRE(ldqk % 8 == 0 && ldqk >= (int64_t)H * HD, "asis_attention_fwd: ldqk=%ld must be a multiple of 8 and >= H*64", (long)ldqk);
   ASIS_REQUIRE(ldvt % 8 == 0 && ldvt >= N, "asis_attention_fwd: ldvt=%ld must be a multiple of 8 and >= N=%d", (long)ldvt, N);
@@ -242,7 +249,7 @@ extern "C" int asis_attention_fwd_lse(void* stream, int dtype, const void* q, co
   static const int occ = [] { const char* e = getenv("ASIS_ATTN_OCC"); const int v = e ? atoi(e) : 2; return v < 2 ? 2 : (v > 4 ? 4 : v); }();
 #define ASIS_ATTN_LAUNCH(TT, O)                                                                                        \
   hipLaunchKernelGGL((attn_fwd_kernel<TT, O>), grid, block, 0, s, reinterpret_cast<const TT*>(q), reinterpret_cast<const TT*>(k), \
-                     ldqk, reinterpret_cast<const TT*>(vt), ldvt, reinterpret_cast<TT*>(o), ldo, H, N, sl, lse2)
+                     ldqk, reinterpret_cast<const TT*>(vt), ldvt, reinterpret_cast<TT*>(o), ldo, H, N1, sl, lse2, B1, N2)
   if (dtype == ASIS_F16) {
     if (occ == 2) ASIS_ATTN_LAUNCH(f16, 2); else if (occ == 3) ASIS_ATTN_LAUNCH(f16, 3); else ASIS_ATTN_LAUNCH(f16, 4);
   } else {
@@ -253,7 +260,12 @@ extern "C" int asis_attention_fwd_lse(void* stream, int dtype, const void* q, co
   return ASIS_OK;
 }
 
+extern "C" int asis_attention_fwd_lse(void* stream, int dtype, const void* q, const void* k, int64_t ldqk, const void* vt,
+                                      int64_t ldvt, void* o, int64_t ldo, int B, int H, int N, float scale, float* lse2) {
+  return asis_attention_fwd_seg(stream, dtype, q, k, ldqk, vt, ldvt, o, ldo, B, N, 0, 0, H, scale, lse2);
+}
+
 extern "C" int asis_attention_fwd(void* stream, int dtype, const void* q, const void* k, int64_t ldqk, const void* vt,
                                   int64_t ldvt, void* o, int64_t ldo, int B, int H, int N, float scale) {
-  return asis_attention_fwd_lse(stream, dtype, q, k, ldqk, vt, ldvt, o, ldo, B, H, N, scale, nullptr);
+  return asis_attention_fwd_seg(stream, dtype, q, k, ldqk, vt, ldvt, o, ldo, B, N, 0, 0, H, scale, nullptr);
 }

@@ -161,11 +161,14 @@ class Attention(_Packed):
         bias = self._f32("qkv_b", self.qkv.bias)
         qk = ops.gemm(xn, w[: 2 * D], bias_n=None if bias is None else bias[: 2 * D])
         o = torch.empty((xn.shape[0], D), device=xn.device, dtype=xn.dtype)
-        r0 = 0
+        one_launch = len(segs) == 2
+        ldv_all = (max(n for _, n in segs) + 63) // 64 * 64
+        vt_all = torch.empty((sum(b for b, _ in segs), D, ldv_all), device=xn.device, dtype=xn.dtype) if one_launch else None
+        r0 = b0 = 0
         for B, N in segs:
             r1 = r0 + B * N
-            ldvt = (N + 63) // 64 * 64
-            vt = torch.empty((B, D, ldvt), device=xn.device, dtype=xn.dtype)
+            ldvt = ldv_all if one_launch else (N + 63) // 64 * 64
+            vt = vt_all[b0:b0 + B] if one_launch else torch.empty((B, D, ldvt), device=xn.device, dtype=xn.dtype)
             # N rounded up to 4 keeps the vector epilogue (N = 1765 fell to the scalar one: 101 vs 69 us); the extra
             # columns land in V^T's pad region, which the attention kernel zeroes in registers, and their operand rows
             # are the first tokens of the next image (the last image reads the spare rows behind ``xn``)
@@ -173,8 +176,12 @@ class Attention(_Packed):
             N4 = (N + 3) // 4 * 4 if spare >= 4 * D else N
             ops.gemm(w[2 * D:], xn[r0:r1].as_strided((B, N4, D), (N * D, D, 1)),
                      out=vt.as_strided((B, D, N4), (D * ldvt, ldvt, 1)), bias_m=None if bias is None else bias[2 * D:])
-            ops.attention_fwd(qk[r0:r1, :D], qk[r0:r1, D:], vt, B, self.num_heads, N, self.scale, out=o[r0:r1])
-            r0 = r1
+            if not one_launch:
+                ops.attention_fwd(qk[r0:r1, :D], qk[r0:r1, D:], vt, B, self.num_heads, N, self.scale, out=o[r0:r1])
+            r0, b0 = r1, b0 + B
+        if one_launch:  # both token batches in one launch (fewer partial rounds of workgroups)
+            (B1, N1), (B2, N2) = segs
+            ops.attention_fwd_seg(qk[:, :D], qk[:, D:], vt_all, B1, N1, B2, N2, self.num_heads, self.scale, out=o)
         if r0 != xn.shape[0]:
             raise ValueError("attend_rows: segments do not cover the rows")
         return o

@@ -222,6 +222,18 @@ def attention_fwd(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, B: int, H:
     return out
 
 
+def attention_fwd_seg(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, B1: int, N1: int, B2: int, N2: int, H: int,
+                      scale: float, out: torch.Tensor) -> torch.Tensor:
+    """Two stacked token batches in one launch: q, k [B1*N1 + B2*N2, >=H*64] row views, vt [B1+B2, H*64, ldvt]."""
+    _dev(q, k, vt, out)
+    if q.stride(0) != k.stride(0) or q.stride(1) != 1 or k.stride(1) != 1 or q.shape[0] != B1 * N1 + B2 * N2:
+        raise ValueError("attention_fwd_seg: q and k must be row views over both batches with one row stride")
+    check(lib().asis_attention_fwd_seg(_stream(), _dt(q.dtype), q.data_ptr(), k.data_ptr(), q.stride(0), vt.data_ptr(),
+                                       vt.stride(1), out.data_ptr(), out.stride(0), B1, N1, B2, N2, H, float(scale), None),
+          "asis_attention_fwd")
+    return out
+
+
 def token_ld(N: int) -> int:
     """row stride of the token-contiguous (transposed) attention operands: N rounded up to 64"""
     return (N + 63) // 64 * 64

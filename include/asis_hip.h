@@ -118,6 +118,12 @@ int asis_layernorm(void* stream, int dtype, const float* x, int64_t ldx, const f
  * ------------------------------------------------------------------------------------------- */
 int asis_attention_fwd(void* stream, int dtype, const void* q, const void* k, int64_t ldqk, const void* vt,
                        int64_t ldvt, void* o, int64_t ldo, int B, int H, int N, float scale);
+/* two token batches stacked along the rows in ONE launch (images 0..B1-1 have N1 tokens, the next B2 have N2: the
+ * cls + pos-embed pass and the raw patch-token pass of train.py:287,300-302): q, k, o rows are image-major in that
+ * order, vt is [B1+B2, H*64, ldvt].  24 x 16 x 14 workgroups fill the chip in 10.5 rounds instead of 2 x 5.25 -> 2 x 6.
+ * B2 = 0: one batch (then lse2 may be given, see below). */
+int asis_attention_fwd_seg(void* stream, int dtype, const void* q, const void* k, int64_t ldqk, const void* vt, int64_t ldvt,
+                           void* o, int64_t ldo, int B1, int N1, int B2, int N2, int H, float scale, float* lse2);
 /* same, also writing lse2[B,H,N] = log2 sum_k exp2(log2(e) * scale * q.k) per query (what asis_attention_bwd
  * needs to rebuild the probabilities); lse2 NULL = asis_attention_fwd */
 int asis_attention_fwd_lse(void* stream, int dtype, const void* q, const void* k, int64_t ldqk, const void* vt,
