@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libasis_hip.so")
 
 ASIS_F16, ASIS_BF16, ASIS_F32 = 0, 1, 2
-ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
+ACT_NONE, ACT_GELU, ACT_RELU, ACT_GELU_GRAD = 0, 1, 2, 4
 
 
 class AsisError(RuntimeError):
@@ -33,6 +33,7 @@ class GemmDesc(C.Structure):
         ("OW", C.c_int32), ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
         ("stats", C.c_void_p),
         ("A_lo", C.c_void_p), ("B_lo", C.c_void_p),
+        ("aux", C.c_void_p), ("ld_aux", C.c_int64),
     ]
 
 

@@ -117,6 +117,16 @@ __device__ __forceinline__ float gelu_erf(float x) {
   const float r = x * (poly * __builtin_amdgcn_exp2f(-0.5f * 1.4426950408889634f * (x * x)));
   return x >= 0.f ? x - r : r;
 }
+// d/dx gelu = Phi(x) + x phi(x) from the same rcp / exp2 pair as gelu_erf (epilogue-friendly: no libm erff)
+__device__ __forceinline__ float gelu_erf_grad_fast(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f * 0.70710678118654752440f, ax, 1.0f));
+  const float poly = ((((0.5f * 1.061405429f * t - 0.5f * 1.453152027f) * t + 0.5f * 1.421413741f) * t - 0.5f * 0.284496736f) * t +
+                      0.5f * 0.254829592f) * t;
+  const float e = __builtin_amdgcn_exp2f(-0.5f * 1.4426950408889634f * (x * x));
+  const float q = poly * e;
+  return (x >= 0.f ? 1.0f - q : q) + x * e * 0.39894228040143267794f;
+}
 // d/dx gelu
 __device__ __forceinline__ float gelu_erf_grad(float x) {
   const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));

@@ -215,6 +215,12 @@ int launch(hipStream_t s, const asis_gemm_desc& d) {
   static const int big_mode = [] { const char* e = getenv("ASIS_GEMM_BIG"); return e ? atoi(e) : 1; }();
   const bool vec_ok = (d.N % 4 == 0) && (d.ldc % 4 == 0);
   const bool split = d.A_lo != nullptr;
+  if (d.act == ASIS_ACT_GELU_GRAD) {  // only the vector epilogue of the large-tile kernels implements it
+    const bool ok = big_mode && !d.conv && !split && !d.stats && d.aux && d.K % 32 == 0 && d.M >= 256 && d.N >= 128 && vec_ok &&
+                    d.ld_aux % 4 == 0 && d.batch == 1 && (reinterpret_cast<uintptr_t>(d.aux) & 7) == 0 &&
+                    (reinterpret_cast<uintptr_t>(d.C) & 15) == 0 && !d.bias_m;
+    if (!ok) return ASIS_EINVAL;
+  }
   if (split) {  // one pass over the virtual 3K reduction; only on the large-tile kernel
     const bool ok = big_mode && d.K % BK == 0 && d.M >= 256 && d.N >= 32 && vec_ok && d.out_f32 && (!d.conv || d.Cin % BK == 0);
     if (!ok) return ASIS_EINVAL;
@@ -288,7 +294,7 @@ extern "C" int asis_gemm(void* stream, const asis_gemm_desc* dp) {
   ASIS_REQUIRE(asis_aligned16(d.A) && asis_aligned16(d.B), "asis_gemm: A and B must be 16-byte aligned");
   ASIS_REQUIRE(d.strideA % 8 == 0 && d.strideB % 8 == 0, "asis_gemm: batch strides must be multiples of 8");
   ASIS_REQUIRE(d.ldc >= d.N, "asis_gemm: ldc=%ld < N=%d", (long)d.ldc, d.N);
-  ASIS_REQUIRE(d.act >= 0 && d.act <= ASIS_ACT_RELU, "asis_gemm: bad act %d", d.act);
+  ASIS_REQUIRE((d.act >= 0 && d.act <= ASIS_ACT_RELU) || d.act == ASIS_ACT_GELU_GRAD, "asis_gemm: bad act %d", d.act);
   if (d.batch <= 0) d.batch = 1;
   ASIS_REQUIRE(d.batch <= 65535, "asis_gemm: batch %d too large", d.batch);
   if (d.res) ASIS_REQUIRE(d.ldr >= d.N, "asis_gemm: ldr=%ld < N", (long)d.ldr);
@@ -310,8 +316,9 @@ extern "C" int asis_gemm(void* stream, const asis_gemm_desc* dp) {
   ASIS_REQUIRE((d.A_lo == nullptr) == (d.B_lo == nullptr), "asis_gemm: A_lo and B_lo must be given together");
   if (d.A_lo) ASIS_REQUIRE(asis_aligned16(d.A_lo) && asis_aligned16(d.B_lo), "asis_gemm: split halves must be 16-byte aligned");
   const int rc = (d.dtype == ASIS_F16) ? launch<f16>(s, d) : launch<bf16>(s, d);
-  if (rc != 0) ASIS_FAIL(ASIS_EINVAL, "asis_gemm: split-precision operands need the large-tile path (K %% 64 == 0, M >= 256, N >= 32, "
-                                        "N and ldc multiples of 4, fp32 output; conv: Cin %% 64 == 0)");
+  if (rc != 0) ASIS_FAIL(ASIS_EINVAL, "asis_gemm: split-precision operands / ASIS_ACT_GELU_GRAD need the large-tile path (K %% 64 "
+                                        "== 0 (GELU_GRAD: 32), M >= 256, N >= 32 (128), N and ldc multiples of 4, fp32 output for "
+                                        "split; conv: Cin %% 64 == 0)");
   ASIS_CHECK_LAUNCH("asis_gemm");
   return ASIS_OK;
 }

@@ -321,6 +321,13 @@ __global__ __launch_bounds__(512, OCC) void gemm_big_kernel(const asis_gemm_desc
           const float bmv = d.bias_m ? d.bias_m[row] : 0.f;
           v.x += b4.x + bmv; v.y += b4.y + bmv; v.z += b4.z + bmv; v.w += b4.w + bmv;
           if (d.act == ASIS_ACT_GELU) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
+          else if (d.act == ASIS_ACT_GELU_GRAD) {  // input-gradient GEMM of fc2 fused with GELU's backward
+            const uint2 pw = *reinterpret_cast<const uint2*>(reinterpret_cast<const T*>(d.aux) + (int64_t)row * d.ld_aux + col);
+            float p0, p1, p2, p3;
+            unpack2<T>(pw.x, p0, p1);
+            unpack2<T>(pw.y, p2, p3);
+            v.x *= gelu_erf_grad_fast(p0); v.y *= gelu_erf_grad_fast(p1); v.z *= gelu_erf_grad_fast(p2); v.w *= gelu_erf_grad_fast(p3);
+          }
           else if (d.act == ASIS_ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
           v.x *= s4.x; v.y *= s4.y; v.z *= s4.z; v.w *= s4.w;
           if (res) {

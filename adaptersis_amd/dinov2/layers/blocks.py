@@ -332,8 +332,13 @@ class Block(_Packed):
         else:
             lin_out, lin_in, n_out, n_in, act_bwd = m.w3, m.w12, "mlp.w3", "mlp.w12", ops.swiglu_bwd
         self._linear_bwd(pre + n_out, lin_out, ls2, pre + "ls2.gamma", d16, cs, hpost, inv_scale, grads)
-        dh = ops.gemm(d16, self._wT16("fc2T", lin_out.weight, ls2))                # 16-bit [R, hidden]
-        dh = act_bwd(hpre, dh)                                                     # GELU' / SwiGLU gate backward
+        R = d16.shape[0]
+        if isinstance(m, Mlp) and R >= 256 and lin_out.in_features >= 128 and lin_out.in_features % 4 == 0 and D % 32 == 0:
+            # fc2's input gradient with GELU's backward in the GEMM epilogue: d pre = (d16 W) * gelu'(pre)
+            dh = ops.gemm(d16, self._wT16("fc2T", lin_out.weight, ls2), act=ops.ACT_GELU_GRAD, aux=hpre)
+        else:
+            dh = ops.gemm(d16, self._wT16("fc2T", lin_out.weight, ls2))            # 16-bit [R, hidden]
+            dh = act_bwd(hpre, dh)                                                 # GELU' / SwiGLU gate backward
         self._linear_bwd(pre + n_in, lin_in, None, None, dh, ops.colsum(dh) if grads is not None else None, xn2,
                          inv_scale, grads)
         dln = ops.gemm(dh, self._wT16("fc1T", lin_in.weight), out_f32=True)        # fp32 [R, D]

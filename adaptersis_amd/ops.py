@@ -13,7 +13,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import ACT_GELU, ACT_NONE, ACT_RELU, GemmDesc, check, lib  # noqa: F401
+from ._lib import ACT_GELU, ACT_GELU_GRAD, ACT_NONE, ACT_RELU, GemmDesc, check, lib  # noqa: F401
 
 T16_DEFAULT = torch.float16
 
@@ -70,8 +70,9 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, out: Optional[torch.Tensor] = None
          bias_n: Optional[torch.Tensor] = None, bias_m: Optional[torch.Tensor] = None,
          scale_n: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None, act: int = ACT_NONE,
          stats: Optional[torch.Tensor] = None, a_lo: Optional[torch.Tensor] = None,
-         b_lo: Optional[torch.Tensor] = None) -> torch.Tensor:
+         b_lo: Optional[torch.Tensor] = None, aux: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``out = epilogue(a @ b.T)``; a [M,K] or [batch,M,K], b [N,K] or [batch,N,K] (16-bit, K contiguous).
+    ``act=ACT_GELU_GRAD`` with ``aux`` (16-bit [M, N] pre-activation): out = (a @ b.T) * gelu'(aux).
 
     A 2-D operand next to a 3-D one is shared by every batch element.  Row strides may exceed K.
     """
@@ -109,6 +110,10 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, out: Optional[torch.Tensor] = None
         d.strideR = res.stride(0) if res.dim() == 3 else 0
     d.act, d.out_f32, d.dtype = act, int(out_f32), _dt(a.dtype)
     d.stats = _p(stats)
+    if aux is not None:
+        if aux.dtype != a.dtype or aux.shape[-2:] != (M, N) or aux.stride(-1) != 1:
+            raise ValueError("gemm: aux must be a 16-bit [M, N] matrix of the operand dtype")
+        d.aux, d.ld_aux = aux.data_ptr(), aux.stride(-2)
     flops = 2.0 * batch * M * N * K
     if a_lo is not None:
         if a_lo.stride() != a.stride() or b_lo.stride() != b.stride():

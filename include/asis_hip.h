@@ -43,6 +43,7 @@ extern "C" {
 #define ASIS_ACT_GELU 1 /* exact erf GELU: dinov2/layers/mlp.py:35 (nn.GELU default) */
 #define ASIS_ACT_RELU 2
 #define ASIS_ACT_SILU_MUL 3 /* reserved: SwiGLU dinov2/layers/swiglu_ffn.py:30-34 (separate kernel) */
+#define ASIS_ACT_GELU_GRAD 4 /* backward of GELU in an input-gradient GEMM: C = (A B^T) * gelu'(aux), aux = 16-bit pre-activation */
 
 const char* asis_last_error(void);
 int asis_version(void);
@@ -94,6 +95,10 @@ typedef struct asis_gemm_desc {
    * N >= 32 (conv: Cin % 64 == 0); otherwise ASIS_EINVAL — callers then run three accumulate passes. */
   const void* A_lo;
   const void* B_lo;
+  /* act == ASIS_ACT_GELU_GRAD: 16-bit [M, N] pre-activation (row stride ld_aux, elements), large-tile path only
+   * (M >= 256, N >= 128, K % 32 == 0, N % 4 == 0); otherwise ASIS_EINVAL and the caller runs asis_gelu16 separately */
+  const void* aux;
+  int64_t ld_aux;
 } asis_gemm_desc;
 int asis_gemm(void* stream, const asis_gemm_desc* d);
 /* number of M tiles asis_gemm uses for M rows (size of the stats buffer = tiles*2*N floats) */

@@ -259,3 +259,17 @@ def test_vit_large_width_backward_vs_reference_golden(dev):
     worst = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
     print("ViT-L width backward vs reference: worst", [(k, "%.1e" % v) for k, v in worst], "of", len(errs))
     assert max(errs.values()) < 5e-3, worst
+
+
+def test_gemm_gelu_grad_epilogue(dev):
+    """ACT_GELU_GRAD: (a @ b.T) * gelu'(aux) fused in the large-tile epilogue == GEMM followed by asis_gelu16's backward."""
+    M, N, K = 600, 256, 128
+    a = W.tensor("gg.a", (M, K), 1.0).to(torch.float16).to(dev)
+    b = W.tensor("gg.b", (N, K), 0.3).to(torch.float16).to(dev)
+    pre = W.tensor("gg.pre", (M, N), 2.0).to(torch.float16).to(dev)
+    fused = ops.gemm(a, b, act=ops.ACT_GELU_GRAD, aux=pre)
+    ref = (a.float() @ b.float().t()) * torch.autograd.functional.jacobian(
+        lambda t: torch.nn.functional.gelu(t).sum(), pre.float().cpu()).to(dev)
+    assert rel_l2(fused, ref) < 1e-3
+    with pytest.raises(ValueError):
+        ops.gemm(a[:64], b, act=ops.ACT_GELU_GRAD, aux=pre[:64])      # small-tile path does not implement it: fails loudly
