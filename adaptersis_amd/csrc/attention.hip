@@ -33,7 +33,7 @@ __device__ __forceinline__ int perm23(int r) {  // swap bits 2 and 3
   return (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1);
 }
 
-template <typename T, int OCC>
+template <typename T, int OCC, int ABL = 0>   // ABL (lab only, wrong results): 1 = no exp2, 2 = no P.V MFMAs, 3 = no S MFMAs
 __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, int64_t ldqk,
                                                        const T* __restrict__ vt, int64_t ldvt, T* __restrict__ o,
                                                        int64_t ldo, int H, int N1, float scale_log2e,
@@ -132,7 +132,8 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(const T* __restrict_
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const v8 a = __builtin_bit_cast(v8, *reinterpret_cast<const uint4*>(Ks + row * HD + (((2 * s + fh) ^ rsw) << 3)));
-        sacc[kb] = T16<T>::mfma32(a, qf[s], sacc[kb]);
+        if (ABL != 3) sacc[kb] = T16<T>::mfma32(a, qf[s], sacc[kb]);
+        else sacc[kb][s] += (float)a[0];
       }
     }
     float mx = -1e30f;
@@ -171,8 +172,8 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(const T* __restrict_
         const f32x2 s2 = {sacc[kb][r], sacc[kb][r + 1]};
         const f32x2 t = __builtin_elementwise_fma(s2, sc2, nm2);
         f32x2 p2;
-        p2.x = __builtin_amdgcn_exp2f(t.x);
-        p2.y = __builtin_amdgcn_exp2f(t.y);
+        p2.x = ABL == 1 ? t.x : __builtin_amdgcn_exp2f(t.x);
+        p2.y = ABL == 1 ? t.y : __builtin_amdgcn_exp2f(t.y);
         ps2 += p2;
         pf[kb][r >> 3][r & 7] = (T)p2.x;
         pf[kb][r >> 3][(r & 7) + 1] = (T)p2.y;
@@ -188,7 +189,8 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(const T* __restrict_
         for (int s2 = 0; s2 < 2; ++s2) {
           const v8 a = __builtin_bit_cast(
               v8, *reinterpret_cast<const uint4*>(Vs + row * HD + (((4 * kb + 2 * s2 + fh) ^ rsw) << 3)));
-          oacc[db] = T16<T>::mfma32(a, pf[kb][s2], oacc[db]);
+          if (ABL != 2) oacc[db] = T16<T>::mfma32(a, pf[kb][s2], oacc[db]);
+          else oacc[db][s2] += (float)a[0] * (float)pf[kb][s2][0];
         }
     }
   };
@@ -250,7 +252,12 @@ extern "C" int asis_attention_fwd_seg(void* stream, int dtype, const void* q, co
 #define ASIS_ATTN_LAUNCH(TT, O)                                                                                        \
   hipLaunchKernelGGL((attn_fwd_kernel<TT, O>), grid, block, 0, s, reinterpret_cast<const TT*>(q), reinterpret_cast<const TT*>(k), \
                      ldqk, reinterpret_cast<const TT*>(vt), ldvt, reinterpret_cast<TT*>(o), ldo, H, N1, sl, lse2, B1, N2)
-  if (dtype == ASIS_F16) {
+  static const int abl = [] { const char* e = getenv("ASIS_ATTN_ABLATE"); return e ? atoi(e) : 0; }();
+  if (abl && dtype == ASIS_F16) {
+    if (abl == 1) hipLaunchKernelGGL((attn_fwd_kernel<f16, 2, 1>), grid, block, 0, s, (const f16*)q, (const f16*)k, ldqk, (const f16*)vt, ldvt, (f16*)o, ldo, H, N1, sl, lse2, B1, N2);
+    else if (abl == 2) hipLaunchKernelGGL((attn_fwd_kernel<f16, 2, 2>), grid, block, 0, s, (const f16*)q, (const f16*)k, ldqk, (const f16*)vt, ldvt, (f16*)o, ldo, H, N1, sl, lse2, B1, N2);
+    else hipLaunchKernelGGL((attn_fwd_kernel<f16, 2, 3>), grid, block, 0, s, (const f16*)q, (const f16*)k, ldqk, (const f16*)vt, ldvt, (f16*)o, ldo, H, N1, sl, lse2, B1, N2);
+  } else if (dtype == ASIS_F16) {
     if (occ == 2) ASIS_ATTN_LAUNCH(f16, 2); else if (occ == 3) ASIS_ATTN_LAUNCH(f16, 3); else ASIS_ATTN_LAUNCH(f16, 4);
   } else {
     if (occ == 2) ASIS_ATTN_LAUNCH(bf16, 2); else if (occ == 3) ASIS_ATTN_LAUNCH(bf16, 3); else ASIS_ATTN_LAUNCH(bf16, 4);
