@@ -126,15 +126,25 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(const T* __restrict_
 #pragma unroll
     for (int r = 0; r < 16; ++r) sacc[0][r] = sacc[1][r] = 0.f;
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      const int row = kb * 32 + prow;
-      const int rsw = (row >> 1) & 7;
+    // the two 32-key blocks alternate so that consecutive MFMAs never accumulate into the same registers (a chain of
+    // four dependent MFMAs per block exposes their latency right in front of the softmax, which needs all of S)
+    {
+      v8 ka[2][4];
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const v8 a = __builtin_bit_cast(v8, *reinterpret_cast<const uint4*>(Ks + row * HD + (((2 * s + fh) ^ rsw) << 3)));
-        if (ABL != 3) sacc[kb] = T16<T>::mfma32(a, qf[s], sacc[kb]);
-        else sacc[kb][s] += (float)a[0];
+      for (int kb = 0; kb < 2; ++kb) {
+        const int row = kb * 32 + prow;
+        const int rsw = (row >> 1) & 7;
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+          ka[kb][s] = __builtin_bit_cast(v8, *reinterpret_cast<const uint4*>(Ks + row * HD + (((2 * s + fh) ^ rsw) << 3)));
       }
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+          if (ABL != 3) sacc[kb] = T16<T>::mfma32(ka[kb][s], qf[s], sacc[kb]);
+          else sacc[kb][s] += (float)ka[kb][s][0];
+        }
     }
     float mx = -1e30f;
 #pragma unroll
