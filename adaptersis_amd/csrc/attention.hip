@@ -125,7 +125,6 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(const T* __restrict_
     f32x16 sacc[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) sacc[0][r] = sacc[1][r] = 0.f;
-#pragma unroll
     // the two 32-key blocks alternate so that consecutive MFMAs never accumulate into the same registers (a chain of
     // four dependent MFMAs per block exposes their latency right in front of the softmax, which needs all of S)
     {
