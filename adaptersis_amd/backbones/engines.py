@@ -218,13 +218,19 @@ class SegEngine(nn.Module):
                 else:
                     xcat = blk.forward_rows(xcat, segs)
                 feats.append(m._final_norm(xcat[:Ra].view(B, N + 1, D))[:, 1:])
+            # the last stage's CACNN output (`train.py:372-386`) feeds nothing: the decoder input takes c4 from the
+            # ENCODER output (`:395`), so unless a caller asks for the taps it is dead code and skipped (same results)
+            dead = s == nl - 1 and taps is None
             if train:
                 x2, s_cv = self.cross_vit.forward16_train(xcat[Ra:], c2d, g, B, N, Lc)
-                c2d, s_cn = self.cross_cnn.forward16_train(c2d, x2, g, B, Lc, N, shapes)
+                s_cn = None
+                if not dead:
+                    c2d, s_cn = self.cross_cnn.forward16_train(c2d, x2, g, B, Lc, N, shapes)
                 adapter_saves.append((bsaved, s_cv, s_cn))
             else:
                 x2 = self._cavit(xcat[Ra:], c2d, g, B, N, Lc)
-                c2d = self._cacnn(c2d, x2, g, B, Lc, N, shapes)
+                if not dead:
+                    c2d = self._cacnn(c2d, x2, g, B, Lc, N, shapes)
             # the stage output overwrites pass B's rows of the stacked buffer: the next block reads it in place
             x = ops.add_f32(x2.view(B, N, D), feats[s], out=xcat[Ra:].view(B, N, D))
         if taps is not None:
