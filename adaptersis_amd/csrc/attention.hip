@@ -33,6 +33,12 @@ __device__ __forceinline__ int perm23(int r) {  // swap bits 2 and 3
   return (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1);
 }
 
+__device__ __forceinline__ uint64_t clk_after(float dep) {  // s_memtime once `dep` exists (lab timing, ABL == 5)
+  uint64_t t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : "v"(dep) : "memory");
+  return t;
+}
+
 template <typename T, int OCC, int ABL = 0>   // ABL (lab only, wrong results): 1 = no exp2, 2 = no P.V MFMAs, 3 = no S MFMAs
 __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, int64_t ldqk,
                                                        const T* __restrict__ vt, int64_t ldvt, T* __restrict__ o,
@@ -65,43 +71,41 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(const T* __restrict_
   // ---- K / V^T tile loaders: 512 16-byte chunks each, 2 per thread ----
   const T* kbase = k + row0 * ldqk + head * HD;
   const T* vbase = vt + ((int64_t)b * H + head) * HD * ldvt;
-  uint4 rk[2], rv[2];
+  // The loads are unconditional (addresses clamped into the tensors) and nothing touches the loaded registers before
+  // store_tile: a predicated `v = load` leaves a phi behind, whose register copies put a vmcnt(0) wait right behind
+  // the issue and expose the whole global latency on every tile.  K rows >= N repeat row N-1 (their scores are
+  // overwritten with -1e30 in the tail tile); V^T columns >= N are zeroed when the tile goes to LDS.  Four named
+  // registers, not arrays: the array form ended up in scratch memory (a store right behind each load).
+  uint4 rk0, rk1, rv0, rv1;
+  const int lrow0 = tid >> 3, lrow1 = lrow0 + 32, lch = tid & 7;
   auto load_tile = [&](int key0) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int c = tid + 256 * i;
-      const int row = c >> 3, ch = c & 7;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (key0 + row < N) v = *reinterpret_cast<const uint4*>(kbase + (int64_t)(key0 + row) * ldqk + ch * 8);
-      rk[i] = v;
-      uint4 w = make_uint4(0, 0, 0, 0);
-      const int kk = key0 + ch * 8;
-      if (kk < N) {
-        w = *reinterpret_cast<const uint4*>(vbase + (int64_t)row * ldvt + kk);
-        if (kk + 8 > N) {  // ragged tail: V^T pad columns may hold anything; force exact zeros
-          const int valid = N - kk;  // 1..7
-          uint32_t* pw = reinterpret_cast<uint32_t*>(&w);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            if (2 * e >= valid) pw[e] = 0;
-            else if (2 * e + 1 >= valid) pw[e] &= 0xFFFFu;
-          }
-        }
-      }
-      rv[i] = w;
-    }
+    const int ka = key0 + lrow0 < N ? key0 + lrow0 : N - 1;
+    const int kb = key0 + lrow1 < N ? key0 + lrow1 : N - 1;
+    const int kk = key0 + lch * 8;
+    const int kc = kk < N ? kk : 0;
+    rk0 = *reinterpret_cast<const uint4*>(kbase + (int64_t)ka * ldqk + lch * 8);
+    rk1 = *reinterpret_cast<const uint4*>(kbase + (int64_t)kb * ldqk + lch * 8);
+    rv0 = *reinterpret_cast<const uint4*>(vbase + (int64_t)lrow0 * ldvt + kc);
+    rv1 = *reinterpret_cast<const uint4*>(vbase + (int64_t)lrow1 * ldvt + kc);
   };
-  auto store_tile = [&](int buf) {
+  auto store_tile = [&](int buf, int key0) {
     T* Ks = lds + buf * (2 * KT * HD);
     T* Vs = Ks + KT * HD;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int c = tid + 256 * i;
-      const int row = c >> 3, ch = c & 7;
-      const int sw = (ch ^ ((row >> 1) & 7)) << 3;
-      *reinterpret_cast<uint4*>(Ks + row * HD + sw) = rk[i];
-      *reinterpret_cast<uint4*>(Vs + row * HD + sw) = rv[i];
+    uint4 w0 = rv0, w1 = rv1;
+    if (key0 + KT > N) {  // workgroup-uniform; V^T pad columns may hold anything: force exact zeros
+      const int valid = N - (key0 + lch * 8);  // keys of this 8-key chunk that exist (<= 0: none, >= 8: all)
+      const uint32_t m0 = valid > 1 ? 0xFFFFFFFFu : (valid > 0 ? 0xFFFFu : 0u);
+      const uint32_t m1 = valid > 3 ? 0xFFFFFFFFu : (valid > 2 ? 0xFFFFu : 0u);
+      const uint32_t m2 = valid > 5 ? 0xFFFFFFFFu : (valid > 4 ? 0xFFFFu : 0u);
+      const uint32_t m3 = valid > 7 ? 0xFFFFFFFFu : (valid > 6 ? 0xFFFFu : 0u);
+      w0.x &= m0, w0.y &= m1, w0.z &= m2, w0.w &= m3;
+      w1.x &= m0, w1.y &= m1, w1.z &= m2, w1.w &= m3;
     }
+    const int sw0 = (lch ^ ((lrow0 >> 1) & 7)) << 3, sw1 = (lch ^ ((lrow1 >> 1) & 7)) << 3;
+    *reinterpret_cast<uint4*>(Ks + lrow0 * HD + sw0) = rk0;
+    *reinterpret_cast<uint4*>(Vs + lrow0 * HD + sw0) = w0;
+    *reinterpret_cast<uint4*>(Ks + lrow1 * HD + sw1) = rk1;
+    *reinterpret_cast<uint4*>(Vs + lrow1 * HD + sw1) = w1;
   };
 
   f32x16 oacc[2];
@@ -111,7 +115,7 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(const T* __restrict_
 
   const int nt = (N + KT - 1) / KT;
   load_tile(0);
-  store_tile(0);
+  store_tile(0, 0);
   __syncthreads();
 
   const int prow = perm23(fr);
@@ -120,8 +124,10 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(const T* __restrict_
   // RESCALE_THR (log2 units): P stays <= 2^THR (exact in fp32 sums, same relative precision in fp16) and the
   // 32-register O rescale is skipped on most tiles (cdna_hip_programming.md T13).
   constexpr float RESCALE_THR = 6.0f;
+  uint64_t tk[6] = {0, 0, 0, 0, 0, 0}, tk6 = 0, tk7 = 0;
   auto tile = [&](const T* Ks, const T* Vs, int key0, auto tail_tag) {
     constexpr bool TAIL = decltype(tail_tag)::value;
+    if (ABL == 5) tk[0] = clk_after(l_run);
     f32x16 sacc[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) sacc[0][r] = sacc[1][r] = 0.f;
@@ -137,6 +143,7 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(const T* __restrict_
         for (int s = 0; s < 4; ++s)
           ka[kb][s] = __builtin_bit_cast(v8, *reinterpret_cast<const uint4*>(Ks + row * HD + (((2 * s + fh) ^ rsw) << 3)));
       }
+      if (ABL == 4) __builtin_amdgcn_s_setprio(3);
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -144,6 +151,7 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(const T* __restrict_
           if (ABL != 3) sacc[kb] = T16<T>::mfma32(ka[kb][s], qf[s], sacc[kb]);
           else sacc[kb][s] += (float)ka[kb][s][0];
         }
+      if (ABL == 4) __builtin_amdgcn_s_setprio(0);
     }
     float mx = -1e30f;
 #pragma unroll
@@ -157,6 +165,7 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(const T* __restrict_
         mx = fmaxf(mx, sacc[kb][r]);
       }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * scale_log2e;  // scale > 0: max commutes with the scaling
+    if (ABL == 5) tk[1] = clk_after(mx);
     if (__any(mx > m_run + RESCALE_THR)) {
       const float m_new = fmaxf(m_run, mx);
       const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
@@ -188,6 +197,7 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(const T* __restrict_
         pf[kb][r >> 3][(r & 7) + 1] = (T)p2.y;
       }
     l_run += ps2.x + ps2.y;
+    if (ABL == 5) tk[2] = clk_after(l_run + (float)pf[1][1][7]);
 #pragma unroll
     for (int db = 0; db < 2; ++db) {
       const int row = db * 32 + fr;
@@ -202,18 +212,32 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(const T* __restrict_
           else oacc[db][s2] += (float)a[0] * (float)pf[kb][s2][0];
         }
     }
+    if (ABL == 5) tk[3] = clk_after(oacc[1][15]);
   };
 
   for (int t = 0; t < nt; ++t) {
     const int buf = t & 1;
     const int key0 = t * KT;
+    if (ABL == 5) tk6 = clk_after(l_run);
     if (t + 1 < nt) load_tile(key0 + KT);
+    if (ABL == 5) tk7 = clk_after(l_run);
     const T* Ks = lds + buf * (2 * KT * HD);
     const T* Vs = Ks + KT * HD;
     if (key0 + KT > N) tile(Ks, Vs, key0, std::true_type{});
     else tile(Ks, Vs, key0, std::false_type{});
-    if (t + 1 < nt) store_tile(buf ^ 1);
+    if (t + 1 < nt) store_tile(buf ^ 1, key0 + KT);
+    if (ABL == 5) tk[4] = clk_after(l_run);
     __syncthreads();
+    if (ABL == 5) {
+      tk[5] = clk_after(l_run);
+      if (lse2 && lane == 0 && wid == 0 && blockIdx.x == 3 && head == 5 && (b == 0 || b == gridDim.z / 2)) {
+        uint64_t* dbg = reinterpret_cast<uint64_t*>(lse2) + ((b ? 1 : 0) * 64 + t) * 8;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) dbg[i] = tk[i];
+        dbg[6] = tk6;
+        dbg[7] = tk7;
+      }
+    }
   }
 
   // ---- normalise and store: lane (fr, fh) owns query q_base+fr, d = 32db + 8g + 4fh + (0..3) ----
@@ -221,7 +245,7 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(const T* __restrict_
   const float inv = 1.0f / l_tot;
   const int qi = q_base + fr;
   // log2-domain log-sum-exp of the scaled scores, per query: what the backward needs to rebuild P = exp2(s*c - lse2)
-  if (lse2 && qi < N && fh == 0) lse2[((int64_t)b * H + head) * N1 + qi] = m_run + __builtin_amdgcn_logf(l_tot);  // single batch only
+  if (ABL != 5 && lse2 && qi < N && fh == 0) lse2[((int64_t)b * H + head) * N1 + qi] = m_run + __builtin_amdgcn_logf(l_tot);  // single batch only
   if (qi < N) {
     T* op = o + (row0 + qi) * ldo + head * HD + 4 * fh;
 #pragma unroll
@@ -265,6 +289,8 @@ extern "C" int asis_attention_fwd_seg(void* stream, int dtype, const void* q, co
   if (abl && dtype == ASIS_F16) {
     if (abl == 1) hipLaunchKernelGGL((attn_fwd_kernel<f16, 2, 1>), grid, block, 0, s, (const f16*)q, (const f16*)k, ldqk, (const f16*)vt, ldvt, (f16*)o, ldo, H, N1, sl, lse2, B1, N2);
     else if (abl == 2) hipLaunchKernelGGL((attn_fwd_kernel<f16, 2, 2>), grid, block, 0, s, (const f16*)q, (const f16*)k, ldqk, (const f16*)vt, ldvt, (f16*)o, ldo, H, N1, sl, lse2, B1, N2);
+    else if (abl == 5) hipLaunchKernelGGL((attn_fwd_kernel<f16, 2, 5>), grid, block, 0, s, (const f16*)q, (const f16*)k, ldqk, (const f16*)vt, ldvt, (f16*)o, ldo, H, N1, sl, lse2, B1, N2);
+    else if (abl == 4) hipLaunchKernelGGL((attn_fwd_kernel<f16, 2, 4>), grid, block, 0, s, (const f16*)q, (const f16*)k, ldqk, (const f16*)vt, ldvt, (f16*)o, ldo, H, N1, sl, lse2, B1, N2);
     else hipLaunchKernelGGL((attn_fwd_kernel<f16, 2, 3>), grid, block, 0, s, (const f16*)q, (const f16*)k, ldqk, (const f16*)vt, ldvt, (f16*)o, ldo, H, N1, sl, lse2, B1, N2);
   } else if (dtype == ASIS_F16) {
     if (occ == 2) ASIS_ATTN_LAUNCH(f16, 2); else if (occ == 3) ASIS_ATTN_LAUNCH(f16, 3); else ASIS_ATTN_LAUNCH(f16, 4);

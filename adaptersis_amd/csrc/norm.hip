@@ -60,6 +60,77 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   }
 }
 
+// D == 256 * NCH exactly: no predicates, RPW rows per wave so that RPW * NCH 16-byte loads per lane are in flight
+// before the first reduction, affine parameters fetched under the reductions.
+template <typename T, bool OUT_F32, int NCH, int RPW>
+__global__ __launch_bounds__(256) void layernorm_fixed_kernel(const float* __restrict__ x, int64_t ldx,
+                                                              const float* __restrict__ w, const float* __restrict__ b,
+                                                              float eps, void* __restrict__ y, int64_t ldy,
+                                                              int64_t rows) {
+  constexpr int D = 256 * NCH;
+  const int lane = threadIdx.x & 63;
+  const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
+  if (row0 >= rows) return;
+  float4 v[RPW][NCH];
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) {
+    const int64_t row = row0 + r < rows ? row0 + r : rows - 1;
+    const float4* xr = reinterpret_cast<const float4*>(x + row * ldx);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) v[r][i] = xr[lane + 64 * i];
+  }
+  float4 ww[NCH], bb[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    ww[i] = reinterpret_cast<const float4*>(w)[lane + 64 * i];
+    bb[i] = reinterpret_cast<const float4*>(b)[lane + 64 * i];
+  }
+  float mean[RPW], rstd[RPW];
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) s += (v[r][i].x + v[r][i].y) + (v[r][i].z + v[r][i].w);
+    mean[r] = s;
+  }
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) mean[r] = wave_sum(mean[r]) / (float)D;
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) {
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const float a0 = v[r][i].x - mean[r], a1 = v[r][i].y - mean[r], a2 = v[r][i].z - mean[r],
+                  a3 = v[r][i].w - mean[r];
+      q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+    }
+    rstd[r] = q;
+  }
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) rstd[r] = 1.0f / sqrtf(wave_sum(rstd[r]) / (float)D + eps);
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) {
+    const int64_t row = row0 + r;
+    if (row >= rows) break;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + 64 * i;
+      const float o0 = (v[r][i].x - mean[r]) * rstd[r] * ww[i].x + bb[i].x;
+      const float o1 = (v[r][i].y - mean[r]) * rstd[r] * ww[i].y + bb[i].y;
+      const float o2 = (v[r][i].z - mean[r]) * rstd[r] * ww[i].z + bb[i].z;
+      const float o3 = (v[r][i].w - mean[r]) * rstd[r] * ww[i].w + bb[i].w;
+      if (OUT_F32) {
+        reinterpret_cast<float4*>(reinterpret_cast<float*>(y) + row * ldy)[c] = make_float4(o0, o1, o2, o3);
+      } else {
+        uint2 p;
+        p.x = pack2<T>(o0, o1);
+        p.y = pack2<T>(o2, o3);
+        reinterpret_cast<uint2*>(reinterpret_cast<T*>(y) + row * ldy)[c] = p;
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void add_cls_pos_kernel(const float4* __restrict__ x, const float4* __restrict__ cls,
                                                           const float4* __restrict__ pos, float4* __restrict__ out,
                                                           int B, int N, int D4) {
@@ -154,6 +225,33 @@ extern "C" int asis_layernorm(void* stream, int dtype, const float* x, int64_t l
   if (rows <= 0) return ASIS_OK;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   dim3 grid((unsigned)asis_cdiv(rows, 4)), block(256);
+  static const int ln_fast = [] {
+    const char* e = getenv("ASIS_LN_FAST");
+    return e ? atoi(e) : 2;
+  }();
+  if (ln_fast && !out_f32 && (D == 768 || D == 1024 || D == 1536) && rows >= 4096) {
+#define ASIS_LN_FIXED(T, NCH)                                                                                         \
+  do {                                                                                                                \
+    if (ln_fast == 1)                                                                                                 \
+      hipLaunchKernelGGL((layernorm_fixed_kernel<T, false, NCH, 1>), grid, block, 0, s, x, ldx, w, b, eps, y, ldy,   \
+                         rows);                                                                                       \
+    else                                                                                                              \
+      hipLaunchKernelGGL((layernorm_fixed_kernel<T, false, NCH, 2>), dim3((unsigned)asis_cdiv(rows, 8)), block, 0, s, \
+                         x, ldx, w, b, eps, y, ldy, rows);                                                            \
+  } while (0)
+    if (dtype == ASIS_F16) {
+      if (D == 768) ASIS_LN_FIXED(f16, 3);
+      else if (D == 1024) ASIS_LN_FIXED(f16, 4);
+      else ASIS_LN_FIXED(f16, 6);
+    } else {
+      if (D == 768) ASIS_LN_FIXED(bf16, 3);
+      else if (D == 1024) ASIS_LN_FIXED(bf16, 4);
+      else ASIS_LN_FIXED(bf16, 6);
+    }
+#undef ASIS_LN_FIXED
+    ASIS_CHECK_LAUNCH("asis_layernorm");
+    return ASIS_OK;
+  }
   if (out_f32)
     hipLaunchKernelGGL((layernorm_kernel<f16, true>), grid, block, 0, s, x, ldx, w, b, eps, y, ldy, rows, D);
   else if (dtype == ASIS_F16)
