@@ -114,6 +114,11 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(const T* __restrict_
   float m_run = -1e30f, l_run = 0.f;
 
   const int nt = (N + KT - 1) / KT;
+  uint64_t clk0 = 0, rt0 = 0;
+  if (ABL == 5) {
+    clk0 = clk_after(0.f);
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt0)::"memory");
+  }
   load_tile(0);
   store_tile(0, 0);
   __syncthreads();
@@ -240,12 +245,276 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(const T* __restrict_
     }
   }
 
+  if (ABL == 5 && lse2 && lane == 0 && wid == 0 && blockIdx.x == 3 && head == 5 && (b == 0 || b == gridDim.z / 2)) {
+    uint64_t rt1;
+    const uint64_t clk1 = clk_after(l_run);
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt1)::"memory");
+    uint64_t* dbg = reinterpret_cast<uint64_t*>(lse2) + 2 * 64 * 8 + (b ? 1 : 0) * 2;
+    dbg[0] = clk1 - clk0;
+    dbg[1] = rt1 - rt0;
+  }
   // ---- normalise and store: lane (fr, fh) owns query q_base+fr, d = 32db + 8g + 4fh + (0..3) ----
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.0f / l_tot;
   const int qi = q_base + fr;
   // log2-domain log-sum-exp of the scaled scores, per query: what the backward needs to rebuild P = exp2(s*c - lse2)
   if (ABL != 5 && lse2 && qi < N && fh == 0) lse2[((int64_t)b * H + head) * N1 + qi] = m_run + __builtin_amdgcn_logf(l_tot);  // single batch only
+  if (qi < N) {
+    T* op = o + (row0 + qi) * ldo + head * HD + 4 * fh;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        uint2 w;
+        w.x = pack2<T>(oacc[db][4 * g + 0] * inv, oacc[db][4 * g + 1] * inv);
+        w.y = pack2<T>(oacc[db][4 * g + 2] * inv, oacc[db][4 * g + 3] * inv);
+        *reinterpret_cast<uint2*>(op + db * 32 + g * 8) = w;
+      }
+  }
+}
+
+
+// ---- software-pipelined form --------------------------------------------------------------------------------------
+// Same fragments and maths as attn_fwd_kernel, different schedule.  One wave's tile used to be a serial chain
+// (K reads -> S MFMAs -> softmax -> V reads -> P.V MFMAs -> staging stores -> barrier) with only the other resident wave
+// of the SIMD to overlap with (measured with the ABL == 5 stamps: S 24 %, softmax 21 %, P.V 13 %, staging 19 %).
+// Here S of tile t+1 is issued before the softmax of tile t, so the matrix pipe works under the exponentials of the
+// same wave, and K / V^T go global -> LDS by LDS-DMA (no staging registers, no ds_write, nothing to wait for until the
+// end of the iteration):
+//   K ring of 3 tiles, V^T ring of 2 (40 KiB).  Iteration t: DMA K(t+2), V(t+1) | S(t+1) = K(t+1) Q^T |
+//   softmax(S(t)) | O += V(t) P(t) | vmcnt(0) + barrier.
+// Every buffer a DMA overwrites was last read before the previous barrier; everything read was waited for at it.
+// Out-of-range K rows repeat row N-1 (scores masked in the tail tile), out-of-range V^T columns are zeroed in the
+// fragment registers of the tail tile (P is exactly 0 there, but 0 * garbage must not make a NaN).
+template <typename T, int SCHED, int DBG = 0>
+__global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(const T* __restrict__ q, const T* __restrict__ k, int64_t ldqk,
+                                                              const T* __restrict__ vt, int64_t ldvt, T* __restrict__ o,
+                                                              int64_t ldo, int H, int N1, float scale_log2e,
+                                                              float* __restrict__ lse2, int B1, int N2) {
+  typedef typename T16<T>::v8 v8;
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  typedef const __attribute__((address_space(1))) void* glb_ptr;
+  __shared__ __attribute__((aligned(16))) T lds[5 * KT * HD];  // K ring [3][64][64] | V^T ring [2][64][64] = 40 KiB
+  T* const Kr = lds;
+  T* const Vr = lds + 3 * KT * HD;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 31, fh = lane >> 5;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int N = b < B1 ? N1 : N2;
+  const int64_t row0 = b < B1 ? (int64_t)b * N1 : (int64_t)B1 * N1 + (int64_t)(b - B1) * N2;
+  const int q_base = blockIdx.x * QT + wid * 32;
+
+  v8 qf[4];
+  {
+    const int qi = q_base + fr;
+    const T* qp = q + (row0 + (qi < N ? qi : N - 1)) * ldqk + head * HD + 8 * fh;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = __builtin_bit_cast(v8, *reinterpret_cast<const uint4*>(qp + 16 * s));
+  }
+
+  const T* kbase = k + row0 * ldqk + head * HD;
+  const T* vbase = vt + ((int64_t)b * H + head) * HD * ldvt;
+  // LDS-DMA: one wave-instruction lands 1 KiB = 8 rows x 8 chunks linearly; lane (lr, lc) therefore fetches the chunk
+  // that the XOR swizzle wants at slot lc of row r.  Wave `wid` stages rows 16 wid .. 16 wid + 15 of every tile.
+  const int lr = lane >> 3, lc = lane & 7;
+  const int r0 = wid * 16 + lr, r1 = r0 + 8;
+  const int nt = (N + KT - 1) / KT;
+  const int c0 = (lc ^ ((r0 >> 1) & 7)) << 3, c1 = (lc ^ ((r1 >> 1) & 7)) << 3;
+  // per-lane source pointers of tile 0; a full tile is a constant step away (rows += 64 for K, columns += 64 for
+  // V^T), only the last tile needs the clamped addresses
+  const T* const kp0 = kbase + (int64_t)r0 * ldqk + c0;
+  const T* const kp1 = kbase + (int64_t)r1 * ldqk + c1;
+  const T* const vp0 = vbase + (int64_t)r0 * ldvt + c0;
+  const T* const vp1 = vbase + (int64_t)r1 * ldvt + c1;
+  const int64_t kstep = (int64_t)KT * ldqk;
+  auto dma_k = [&](int t, int slot) {
+    T* dst = Kr + slot * (KT * HD) + wid * 16 * HD;
+    const T *a = kp0 + t * kstep, *bb = kp1 + t * kstep;
+    if (t == nt - 1) {  // uniform
+      const int key0 = t * KT;
+      const int ka = key0 + r0 < N ? key0 + r0 : N - 1;
+      const int kb = key0 + r1 < N ? key0 + r1 : N - 1;
+      a = kbase + (int64_t)ka * ldqk + c0;
+      bb = kbase + (int64_t)kb * ldqk + c1;
+    }
+    __builtin_amdgcn_global_load_lds((glb_ptr)a, (lds_ptr)dst, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((glb_ptr)bb, (lds_ptr)(dst + 8 * HD), 16, 0, 0);
+  };
+  auto dma_v = [&](int t) {
+    T* dst = Vr + (t & 1) * (KT * HD) + wid * 16 * HD;
+    const T *a = vp0 + t * KT, *bb = vp1 + t * KT;
+    if (t == nt - 1) {
+      const int key0 = t * KT;
+      if (key0 + c0 >= N) a = vbase + (int64_t)r0 * ldvt;
+      if (key0 + c1 >= N) bb = vbase + (int64_t)r1 * ldvt;
+    }
+    __builtin_amdgcn_global_load_lds((glb_ptr)a, (lds_ptr)dst, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((glb_ptr)bb, (lds_ptr)(dst + 8 * HD), 16, 0, 0);
+  };
+
+  f32x16 oacc[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) oacc[0][r] = oacc[1][r] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;
+  const int prow = perm23(fr);
+  constexpr float RESCALE_THR = 6.0f;
+
+  auto k_frags = [&](int slot, v8 (&ka)[2][4]) {
+    const T* Ks = Kr + slot * (KT * HD);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      const int row = kb * 32 + prow;
+      const int rsw = (row >> 1) & 7;
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        ka[kb][s] = __builtin_bit_cast(v8, *reinterpret_cast<const uint4*>(Ks + row * HD + (((2 * s + fh) ^ rsw) << 3)));
+    }
+  };
+  auto s_mfma = [&](const v8 (&ka)[2][4], f32x16 (&sacc)[2]) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sacc[0][r] = sacc[1][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) sacc[kb] = T16<T>::mfma32(ka[kb][s], qf[s], sacc[kb]);
+  };
+
+  // one iteration: `cur` holds S(t); `nxt` receives S(t+1)
+  auto step = [&](int t, int kslot_next, f32x16 (&cur)[2], f32x16 (&nxt)[2], auto tail_tag) {
+    constexpr bool tail = decltype(tail_tag)::value;  // the last tile: masks, no successor
+    const int key0 = t * KT;
+    const bool more = !tail;
+    uint64_t tk[8];
+    if (DBG) tk[0] = clk_after(l_run);
+    if (t + 2 < nt) dma_k(t + 2, kslot_next == 2 ? 0 : kslot_next + 1);
+    if (more) dma_v(t + 1);
+    v8 ka[2][4];
+    if (DBG) tk[1] = clk_after(l_run);
+    if (!tail) k_frags(kslot_next, ka);
+    if (tail) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = key0 + kb * 32 + perm23((r & 3) + 8 * (r >> 2) + 4 * fh);
+          if (key >= N) cur[kb][r] = -1e30f;
+        }
+    }
+    float mx = -1e30f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, cur[kb][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * scale_log2e;
+    if (DBG) tk[2] = clk_after(mx);
+    if (__any(mx > m_run + RESCALE_THR)) {
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        oacc[0][r] *= alpha;
+        oacc[1][r] *= alpha;
+      }
+    }
+    if (DBG) tk[3] = clk_after(oacc[1][15]);
+    // S(t+1) goes to the matrix pipe here, in the same basic block as the exponentials of tile t
+    if (!tail) s_mfma(ka, nxt);
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 sc2 = {scale_log2e, scale_log2e}, nm2 = {-m_run, -m_run};
+    f32x2 ps2 = {0.f, 0.f};
+    v8 pf[2][2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const f32x2 s2 = {cur[kb][r], cur[kb][r + 1]};
+        const f32x2 tt = __builtin_elementwise_fma(s2, sc2, nm2);
+        f32x2 p2;
+        p2.x = __builtin_amdgcn_exp2f(tt.x);
+        p2.y = __builtin_amdgcn_exp2f(tt.y);
+        ps2 += p2;
+        pf[kb][r >> 3][r & 7] = (T)p2.x;
+        pf[kb][r >> 3][(r & 7) + 1] = (T)p2.y;
+      }
+    l_run += ps2.x + ps2.y;
+    if (DBG) tk[4] = clk_after(l_run + (float)pf[1][1][7]);
+    const T* Vs = Vr + (t & 1) * (KT * HD);
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+      const int row = db * 32 + fr;
+      const int rsw = (row >> 1) & 7;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const int ch = 4 * kb + 2 * s2 + fh;
+          uint4 w = *reinterpret_cast<const uint4*>(Vs + row * HD + ((ch ^ rsw) << 3));
+          if (tail) {
+            const int valid = N - (key0 + ch * 8);
+            w.x &= valid > 1 ? 0xFFFFFFFFu : (valid > 0 ? 0xFFFFu : 0u);
+            w.y &= valid > 3 ? 0xFFFFFFFFu : (valid > 2 ? 0xFFFFu : 0u);
+            w.z &= valid > 5 ? 0xFFFFFFFFu : (valid > 4 ? 0xFFFFu : 0u);
+            w.w &= valid > 7 ? 0xFFFFFFFFu : (valid > 6 ? 0xFFFFu : 0u);
+          }
+          oacc[db] = T16<T>::mfma32(__builtin_bit_cast(v8, w), pf[kb][s2], oacc[db]);
+        }
+    }
+    if (SCHED == 1) {
+      // 8 S MFMAs spread over the softmax VALU work, then the P.V MFMAs with their reads
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);  // VALU
+      }
+    }
+    if (DBG) tk[5] = clk_after(oacc[1][15] + (tail ? 0.f : nxt[1][15]));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (DBG) tk[6] = clk_after(l_run);
+    __syncthreads();
+    if (DBG) {
+      tk[7] = clk_after(l_run);
+      if (lse2 && lane == 0 && wid == 0 && blockIdx.x == 3 && head == 5 && (b == 0 || b == gridDim.z / 2)) {
+        uint64_t* dbg = reinterpret_cast<uint64_t*>(lse2) + ((b ? 1 : 0) * 64 + t) * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dbg[i] = tk[i];
+      }
+    }
+  };
+
+  dma_k(0, 0);
+  dma_v(0);
+  if (nt > 1) dma_k(1, 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  f32x16 sA[2], sB[2];
+  {
+    v8 ka[2][4];
+    k_frags(0, ka);
+    s_mfma(ka, sA);
+  }
+  int slot = 1;  // ring slot of K(t+1)
+  int t = 0;
+  for (; t + 2 < nt; t += 2) {  // tiles 0 .. nt-2 are full and have a successor
+    step(t, slot, sA, sB, std::false_type{});
+    slot = slot == 2 ? 0 : slot + 1;
+    step(t + 1, slot, sB, sA, std::false_type{});
+    slot = slot == 2 ? 0 : slot + 1;
+  }
+  if (t + 1 < nt) {
+    step(t, slot, sA, sB, std::false_type{});
+    step(t + 1, 0, sB, sA, std::true_type{});
+  } else {
+    step(t, 0, sA, sB, std::true_type{});
+  }
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  const int qi = q_base + fr;
+  if (!DBG && lse2 && qi < N && fh == 0) lse2[((int64_t)b * H + head) * N1 + qi] = m_run + __builtin_amdgcn_logf(l_tot);
   if (qi < N) {
     T* op = o + (row0 + qi) * ldo + head * HD + 4 * fh;
 #pragma unroll
@@ -286,7 +555,20 @@ extern "C" int asis_attention_fwd_seg(void* stream, int dtype, const void* q, co
   hipLaunchKernelGGL((attn_fwd_kernel<TT, O>), grid, block, 0, s, reinterpret_cast<const TT*>(q), reinterpret_cast<const TT*>(k), \
                      ldqk, reinterpret_cast<const TT*>(vt), ldvt, reinterpret_cast<TT*>(o), ldo, H, N1, sl, lse2, B1, N2)
   static const int abl = [] { const char* e = getenv("ASIS_ATTN_ABLATE"); return e ? atoi(e) : 0; }();
-  if (abl && dtype == ASIS_F16) {
+  // ASIS_ATTN_PIPE: 0 = the two-buffer register-staged kernel, 1 = software-pipelined LDS-DMA kernel, 2 = the same with
+  // an explicit MFMA / VALU interleave
+  static const int pipe = [] { const char* e = getenv("ASIS_ATTN_PIPE"); return e ? atoi(e) : 1; }();
+  if (pipe && abl == 6 && dtype == ASIS_F16) {
+    hipLaunchKernelGGL((attn_fwd_pipe_kernel<f16, 0, 1>), grid, block, 0, s, (const f16*)q, (const f16*)k, ldqk, (const f16*)vt, ldvt, (f16*)o, ldo, H, N1, sl, lse2, B1, N2);
+  } else if (pipe && !abl) {
+#define ASIS_ATTN_PIPE_LAUNCH(TT, SC)                                                                                   \
+  hipLaunchKernelGGL((attn_fwd_pipe_kernel<TT, SC>), grid, block, 0, s, reinterpret_cast<const TT*>(q),                \
+                     reinterpret_cast<const TT*>(k), ldqk, reinterpret_cast<const TT*>(vt), ldvt, reinterpret_cast<TT*>(o), \
+                     ldo, H, N1, sl, lse2, B1, N2)
+    if (dtype == ASIS_F16) { if (pipe == 2) ASIS_ATTN_PIPE_LAUNCH(f16, 1); else ASIS_ATTN_PIPE_LAUNCH(f16, 0); }
+    else { if (pipe == 2) ASIS_ATTN_PIPE_LAUNCH(bf16, 1); else ASIS_ATTN_PIPE_LAUNCH(bf16, 0); }
+#undef ASIS_ATTN_PIPE_LAUNCH
+  } else if (abl && dtype == ASIS_F16) {
     if (abl == 1) hipLaunchKernelGGL((attn_fwd_kernel<f16, 2, 1>), grid, block, 0, s, (const f16*)q, (const f16*)k, ldqk, (const f16*)vt, ldvt, (f16*)o, ldo, H, N1, sl, lse2, B1, N2);
     else if (abl == 2) hipLaunchKernelGGL((attn_fwd_kernel<f16, 2, 2>), grid, block, 0, s, (const f16*)q, (const f16*)k, ldqk, (const f16*)vt, ldvt, (f16*)o, ldo, H, N1, sl, lse2, B1, N2);
     else if (abl == 5) hipLaunchKernelGGL((attn_fwd_kernel<f16, 2, 5>), grid, block, 0, s, (const f16*)q, (const f16*)k, ldqk, (const f16*)vt, ldvt, (f16*)o, ldo, H, N1, sl, lse2, B1, N2);

@@ -134,32 +134,35 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const T* __restrict
   const T* kbase = k + (int64_t)b * N * ld + head * HD;
   const T* vbase = v + (int64_t)b * N * ld + head * HD;
   const T* ktbase = kt + bh * HD * ldt;
-  uint4 rk[2], rv[2], rt[2];
+  // staging in named registers, loads unconditional from clamped rows, rows >= N zeroed when the tile goes to LDS
+  // (see attention.hip: the predicated / array forms wait on every load right behind its issue)
+  uint4 rk0, rk1, rv0, rv1, rt0, rt1;
+  const int lrow0 = tid >> 3, lrow1 = lrow0 + 32, lch = tid & 7;
   auto load_tile = [&](int key0) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int c = tid + 256 * i;
-      const int row = c >> 3, ch = c & 7;
-      uint4 a = make_uint4(0, 0, 0, 0), w = a;
-      if (key0 + row < N) {
-        a = *reinterpret_cast<const uint4*>(kbase + (int64_t)(key0 + row) * ld + ch * 8);
-        w = *reinterpret_cast<const uint4*>(vbase + (int64_t)(key0 + row) * ld + ch * 8);
-      }
-      rk[i] = a;
-      rv[i] = w;
-      rt[i] = *reinterpret_cast<const uint4*>(ktbase + (int64_t)row * ldt + key0 + ch * 8);  // zero-padded to ldt
-    }
+    const int ka = key0 + lrow0 < N ? key0 + lrow0 : N - 1;
+    const int kb = key0 + lrow1 < N ? key0 + lrow1 : N - 1;
+    rk0 = *reinterpret_cast<const uint4*>(kbase + (int64_t)ka * ld + lch * 8);
+    rv0 = *reinterpret_cast<const uint4*>(vbase + (int64_t)ka * ld + lch * 8);
+    rk1 = *reinterpret_cast<const uint4*>(kbase + (int64_t)kb * ld + lch * 8);
+    rv1 = *reinterpret_cast<const uint4*>(vbase + (int64_t)kb * ld + lch * 8);
+    rt0 = *reinterpret_cast<const uint4*>(ktbase + (int64_t)lrow0 * ldt + key0 + lch * 8);  // zero-padded to ldt
+    rt1 = *reinterpret_cast<const uint4*>(ktbase + (int64_t)lrow1 * ldt + key0 + lch * 8);
   };
-  auto store_tile = [&](int buf) {
+  auto store_tile = [&](int buf, int key0) {
     T* Ks = lds + buf * (3 * TT * HD);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int c = tid + 256 * i;
-      const int o = sw_off(c >> 3, c & 7);
-      *reinterpret_cast<uint4*>(Ks + o) = rk[i];
-      *reinterpret_cast<uint4*>(Ks + TT * HD + o) = rv[i];
-      *reinterpret_cast<uint4*>(Ks + 2 * TT * HD + o) = rt[i];
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    uint4 a0 = rk0, a1 = rk1, w0 = rv0, w1 = rv1;
+    if (key0 + TT > N) {  // workgroup-uniform
+      if (key0 + lrow0 >= N) a0 = w0 = z;
+      if (key0 + lrow1 >= N) a1 = w1 = z;
     }
+    const int o0 = sw_off(lrow0, lch), o1 = sw_off(lrow1, lch);
+    *reinterpret_cast<uint4*>(Ks + o0) = a0;
+    *reinterpret_cast<uint4*>(Ks + TT * HD + o0) = w0;
+    *reinterpret_cast<uint4*>(Ks + 2 * TT * HD + o0) = rt0;
+    *reinterpret_cast<uint4*>(Ks + o1) = a1;
+    *reinterpret_cast<uint4*>(Ks + TT * HD + o1) = w1;
+    *reinterpret_cast<uint4*>(Ks + 2 * TT * HD + o1) = rt1;
   };
 
   f32x16 acc[2];
@@ -168,7 +171,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const T* __restrict
 
   const int nt = (N + TT - 1) / TT;
   load_tile(0);
-  store_tile(0);
+  store_tile(0, 0);
   __syncthreads();
   const int prow = perm23(fr);
 
@@ -214,7 +217,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const T* __restrict
           acc[db] = T16<T>::mfma32(a, dsf[kb][s2], acc[db]);
         }
     }
-    if (t + 1 < nt) store_tile(buf ^ 1);
+    if (t + 1 < nt) store_tile(buf ^ 1, key0 + TT);
     __syncthreads();
   }
 
@@ -273,42 +276,50 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const T* __restric
   const T* gbase = dO + (int64_t)b * N * lddo + head * HD;
   const T* qtbase = qt + bh * HD * ldt;
   const T* gtbase = dot + bh * HD * ldt;
-  uint4 rq[2], rg[2], rqt[2], rgt[2];
+  uint4 rq0, rq1, rg0, rg1, rqt0, rqt1, rgt0, rgt1;
   float rstat = 0.f;
+  const int lrow0 = tid >> 3, lrow1 = lrow0 + 32, lch = tid & 7;
   auto load_tile = [&](int q0) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int c = tid + 256 * i;
-      const int row = c >> 3, ch = c & 7;
-      uint4 a = make_uint4(0, 0, 0, 0), g = a;
-      if (q0 + row < N) {
-        a = *reinterpret_cast<const uint4*>(qbase + (int64_t)(q0 + row) * ld + ch * 8);
-        g = *reinterpret_cast<const uint4*>(gbase + (int64_t)(q0 + row) * lddo + ch * 8);
-      }
-      rq[i] = a;
-      rg[i] = g;
-      rqt[i] = *reinterpret_cast<const uint4*>(qtbase + (int64_t)row * ldt + q0 + ch * 8);  // zero-padded to ldt
-      rgt[i] = *reinterpret_cast<const uint4*>(gtbase + (int64_t)row * ldt + q0 + ch * 8);
-    }
+    const int qa = q0 + lrow0 < N ? q0 + lrow0 : N - 1;
+    const int qb = q0 + lrow1 < N ? q0 + lrow1 : N - 1;
+    rq0 = *reinterpret_cast<const uint4*>(qbase + (int64_t)qa * ld + lch * 8);
+    rg0 = *reinterpret_cast<const uint4*>(gbase + (int64_t)qa * lddo + lch * 8);
+    rq1 = *reinterpret_cast<const uint4*>(qbase + (int64_t)qb * ld + lch * 8);
+    rg1 = *reinterpret_cast<const uint4*>(gbase + (int64_t)qb * lddo + lch * 8);
+    rqt0 = *reinterpret_cast<const uint4*>(qtbase + (int64_t)lrow0 * ldt + q0 + lch * 8);  // zero-padded to ldt
+    rgt0 = *reinterpret_cast<const uint4*>(gtbase + (int64_t)lrow0 * ldt + q0 + lch * 8);
+    rqt1 = *reinterpret_cast<const uint4*>(qtbase + (int64_t)lrow1 * ldt + q0 + lch * 8);
+    rgt1 = *reinterpret_cast<const uint4*>(gtbase + (int64_t)lrow1 * ldt + q0 + lch * 8);
     if (tid < 2 * TT) {  // threads 0..63: lse2, 64..127: D.  Queries >= N: lse2 = +huge -> P = 0
       const int j = tid & (TT - 1);
       const bool isD = tid >= TT;
       const int qq = q0 + j;
-      rstat = qq < N ? (isD ? Dv[bh * N + qq] : lse2[bh * N + qq]) : (isD ? 0.f : 1e30f);
+      const int qc = qq < N ? qq : N - 1;
+      const float v = isD ? Dv[bh * N + qc] : lse2[bh * N + qc];
+      rstat = v;
     }
   };
-  auto store_tile = [&](int buf) {
+  auto store_tile = [&](int buf, int q0) {
     T* Qs = lds + buf * (4 * TT * HD);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int c = tid + 256 * i;
-      const int o = sw_off(c >> 3, c & 7);
-      *reinterpret_cast<uint4*>(Qs + o) = rq[i];
-      *reinterpret_cast<uint4*>(Qs + TT * HD + o) = rg[i];
-      *reinterpret_cast<uint4*>(Qs + 2 * TT * HD + o) = rqt[i];
-      *reinterpret_cast<uint4*>(Qs + 3 * TT * HD + o) = rgt[i];
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    uint4 a0 = rq0, a1 = rq1, g0 = rg0, g1 = rg1;
+    if (q0 + TT > N) {  // workgroup-uniform
+      if (q0 + lrow0 >= N) a0 = g0 = z;
+      if (q0 + lrow1 >= N) a1 = g1 = z;
     }
-    if (tid < 2 * TT) stat[buf][tid >> 6][tid & (TT - 1)] = rstat;
+    const int o0 = sw_off(lrow0, lch), o1 = sw_off(lrow1, lch);
+    *reinterpret_cast<uint4*>(Qs + o0) = a0;
+    *reinterpret_cast<uint4*>(Qs + TT * HD + o0) = g0;
+    *reinterpret_cast<uint4*>(Qs + 2 * TT * HD + o0) = rqt0;
+    *reinterpret_cast<uint4*>(Qs + 3 * TT * HD + o0) = rgt0;
+    *reinterpret_cast<uint4*>(Qs + o1) = a1;
+    *reinterpret_cast<uint4*>(Qs + TT * HD + o1) = g1;
+    *reinterpret_cast<uint4*>(Qs + 2 * TT * HD + o1) = rqt1;
+    *reinterpret_cast<uint4*>(Qs + 3 * TT * HD + o1) = rgt1;
+    if (tid < 2 * TT) {
+      const int qq = q0 + (tid & (TT - 1));
+      stat[buf][tid >> 6][tid & (TT - 1)] = qq < N ? rstat : (tid >= TT ? 0.f : 1e30f);
+    }
   };
 
   f32x16 dvacc[2], dkacc[2];
@@ -317,7 +328,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const T* __restric
 
   const int nt = (N + TT - 1) / TT;
   load_tile(0);
-  store_tile(0);
+  store_tile(0, 0);
   __syncthreads();
   const int prow = perm23(fr);
 
@@ -370,7 +381,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const T* __restric
           dkacc[db] = T16<T>::mfma32(__builtin_bit_cast(v8, *reinterpret_cast<const uint4*>(QTs + o)), dsf[kb][s2], dkacc[db]);
         }
     }
-    if (t + 1 < nt) store_tile(buf ^ 1);
+    if (t + 1 < nt) store_tile(buf ^ 1, (t + 1) * TT);
     __syncthreads();
   }
 
