@@ -48,53 +48,106 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const asis_wgrad_des
   const int ci = bn - tap * d.Cin;
   const int kh = tap / d.KW, kw = tap - kh * d.KW;
   const int ohw = d.OH * d.OW;
-  const bool small_p = d.P < (1 << 24);
-  const float inv_ohw = 1.0f / (float)ohw, inv_ow = 1.0f / (float)d.OW;
 
-  uint4 ra[4], rb[4];
-  auto load_tile = [&](int64_t k0) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int64_t p = k0 + lk + 16 * i;
-      uint4 va = make_uint4(0, 0, 0, 0), vb = va;
-      if (p < k_end) {
-        if (a_col_ok) va = *reinterpret_cast<const uint4*>(A + p * d.ld_dy + am);
-        if (DENSE) {
-          if (b_col_ok) vb = *reinterpret_cast<const uint4*>(X + p * d.Cin + bn);
-        } else if (b_col_ok) {
-          int b, rem, oh, ow;
-          if (small_p) {  // P < 2^24: quotients from an fp32 reciprocal estimate + one correction step (exact), ~8 VALU
-            b = (int)((float)(int)p * inv_ohw);   // instead of two ~30-instruction integer divisions per staged row
-            rem = (int)p - b * ohw;
-            if (rem < 0) { --b; rem += ohw; } else if (rem >= ohw) { ++b; rem -= ohw; }
-            oh = (int)((float)rem * inv_ow);
-            ow = rem - oh * d.OW;
-            if (ow < 0) { --oh; ow += d.OW; } else if (ow >= d.OW) { ++oh; ow -= d.OW; }
-          } else {
-            b = (int)(p / ohw);
-            rem = (int)(p - (int64_t)b * ohw);
-            oh = rem / d.OW;
-            ow = rem - oh * d.OW;
-          }
-          const int ih = oh * d.stride + kh - d.pad, iw = ow * d.stride + kw - d.pad;
-          if ((unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W)
-            vb = *reinterpret_cast<const uint4*>(X + (((int64_t)b * d.H + ih) * d.W + iw) * d.Cin + ci);
-        }
-      }
-      ra[i] = va;
-      rb[i] = vb;
+  // Loader state, advanced incrementally: a K step moves every staged row BK pixels on, i.e. (sb images, soh rows,
+  // sow columns) with at most one carry per digit, so no division happens inside the loop (the divisions used to be
+  // ~300 VALU instructions per staged row against 16 MFMAs per tile).  Loads are unconditional from addresses clamped
+  // into the tensors; what must read as zero (rows past the split, padding taps, columns past the tile) is masked
+  // when the registers go to LDS, after the wait that is needed there anyway (a predicated `v = load` would put that
+  // wait right behind the issue).
+  const int sb = BK / ohw, srem = BK - sb * ohw;
+  const int soh = srem / d.OW, sow = srem - soh * d.OW;
+  const int64_t img = (int64_t)d.H * d.W * d.Cin;
+  struct Row {  // one staged pixel row; four named instances (arrays of these ended up in scratch memory)
+    const T* pa;  // dy row (+ column chunk)
+    const T* px;  // DENSE: x row (+ column chunk); conv: base of the row's image (+ ci)
+    int64_t p;
+    int oh, ow;
+  };
+  Row w0, w1, w2, w3;
+  uint32_t okm = 0;  // bit i: row i of the tile in flight is inside the split; bit 4+i: its tap is inside the image
+  auto init_row = [&](Row& r, int i) {
+    r.p = k_begin + lk + 16 * i;
+    const int64_t pc = r.p < k_end ? r.p : (k_end > k_begin ? k_end - 1 : k_begin);
+    if (r.p < k_end) okm |= 1u << i;
+    r.pa = A + pc * d.ld_dy + (a_col_ok ? am : 0);
+    if (DENSE) {
+      r.px = X + pc * d.Cin + (b_col_ok ? bn : 0);
+      r.oh = r.ow = 0;
+    } else {
+      const int64_t bimg = pc / ohw;
+      const int rem = (int)(pc - bimg * ohw);
+      r.oh = rem / d.OW;
+      r.ow = rem - r.oh * d.OW;
+      r.px = X + bimg * img + (b_col_ok ? ci : 0);
     }
+  };
+  init_row(w0, 0);
+  init_row(w1, 1);
+  init_row(w2, 2);
+  init_row(w3, 3);
+  const int64_t a_step = (int64_t)BK * d.ld_dy, x_step = (int64_t)BK * d.Cin;
+  auto adv_row = [&](Row& r, int i) {
+    r.p += BK;
+    const bool in = r.p < k_end;  // rows past the split keep their last valid addresses and are masked
+    okm = in ? okm : (okm & ~(1u << i));
+    r.pa += in ? a_step : 0;
+    if (DENSE) {
+      r.px += in ? x_step : 0;
+    } else {
+      int w2_ = r.ow + sow;
+      const int c1 = w2_ >= d.OW;
+      w2_ -= c1 ? d.OW : 0;
+      int h2 = r.oh + soh + c1;
+      const int c2 = h2 >= d.OH;
+      h2 -= c2 ? d.OH : 0;
+      r.ow = in ? w2_ : r.ow;
+      r.oh = in ? h2 : r.oh;
+      r.px += in ? (int64_t)(sb + c2) * img : 0;
+    }
+  };
+  auto x_addr = [&](const Row& r, int i) -> const T* {  // the tap's address, clamped into the image
+    if (DENSE) return r.px;
+    const int ih = r.oh * d.stride + kh - d.pad, iw = r.ow * d.stride + kw - d.pad;
+    const bool inb = (unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W;
+    okm = inb ? (okm | (16u << i)) : (okm & ~(16u << i));
+    const int ihc = ih < 0 ? 0 : (ih >= d.H ? d.H - 1 : ih), iwc = iw < 0 ? 0 : (iw >= d.W ? d.W - 1 : iw);
+    return r.px + (ihc * d.W + iwc) * d.Cin;
+  };
+  auto advance = [&]() {
+    adv_row(w0, 0);
+    adv_row(w1, 1);
+    adv_row(w2, 2);
+    adv_row(w3, 3);
+  };
+  uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+  auto load_tile = [&]() {
+    ra0 = *reinterpret_cast<const uint4*>(w0.pa);
+    rb0 = *reinterpret_cast<const uint4*>(x_addr(w0, 0));
+    ra1 = *reinterpret_cast<const uint4*>(w1.pa);
+    rb1 = *reinterpret_cast<const uint4*>(x_addr(w1, 1));
+    ra2 = *reinterpret_cast<const uint4*>(w2.pa);
+    rb2 = *reinterpret_cast<const uint4*>(x_addr(w2, 2));
+    ra3 = *reinterpret_cast<const uint4*>(w3.pa);
+    rb3 = *reinterpret_cast<const uint4*>(x_addr(w3, 3));
+  };
+  auto store_row = [&](T* As, T* Bs, int i, const uint4& va, const uint4& vb) {
+    const int k = lk + 16 * i;
+    const int sw = (lch ^ ((k & 3) << 2)) << 3;
+    const bool row_ok = (okm >> i) & 1u;
+    const bool tap_ok = DENSE || ((okm >> (4 + i)) & 1u);
+    // component-wise: `c ? va : z` on two lvalues selects an ADDRESS and sends both through scratch memory
+    const uint32_t ma = (row_ok && a_col_ok) ? 0xFFFFFFFFu : 0u, mb = (row_ok && b_col_ok && tap_ok) ? 0xFFFFFFFFu : 0u;
+    *reinterpret_cast<uint4*>(As + k * BM + sw) = make_uint4(va.x & ma, va.y & ma, va.z & ma, va.w & ma);
+    *reinterpret_cast<uint4*>(Bs + k * BN + sw) = make_uint4(vb.x & mb, vb.y & mb, vb.z & mb, vb.w & mb);
   };
   auto store_tile = [&](int buf) {
     T* As = lds + buf * (2 * BK * BM);
     T* Bs = As + BK * BM;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int k = lk + 16 * i;
-      const int sw = (lch ^ ((k & 3) << 2)) << 3;
-      *reinterpret_cast<uint4*>(As + k * BM + sw) = ra[i];
-      *reinterpret_cast<uint4*>(Bs + k * BN + sw) = rb[i];
-    }
+    store_row(As, Bs, 0, ra0, rb0);
+    store_row(As, Bs, 1, ra1, rb1);
+    store_row(As, Bs, 2, ra2, rb2);
+    store_row(As, Bs, 3, ra3, rb3);
   };
 
   f32x16 acc[2][2];
@@ -107,7 +160,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const asis_wgrad_des
 
   const int nt = (int)((k_end - k_begin + BK - 1) / BK);
   if (nt > 0) {
-    load_tile(k_begin);
+    load_tile();
     store_tile(0);
   }
   __syncthreads();
@@ -119,7 +172,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const asis_wgrad_des
   const int q = li >> 2, pc = li & 3; // this lane supplies row q, columns 4*pc..4*pc+3
   for (int t = 0; t < nt; ++t) {
     const int buf = t & 1;
-    if (t + 1 < nt) load_tile(k_begin + (int64_t)(t + 1) * BK);
+    if (t + 1 < nt) {
+      advance();
+      load_tile();
+    }
     const T* As = lds + buf * (2 * BK * BM);
     const T* Bs = As + BK * BM;
 #pragma unroll
