@@ -304,6 +304,17 @@ __global__ __launch_bounds__(512, OCC) void gemm_big_kernel(const asis_gemm_desc
     if (cok && d.bias_n) b4 = *reinterpret_cast<const float4*>(d.bias_n + col);
     if (cok && d.scale_n) s4 = *reinterpret_cast<const float4*>(d.scale_n + col);
     float4 st_s = make_float4(0.f, 0.f, 0.f, 0.f), st_q = st_s;  // BatchNorm partial sums of this lane's columns
+    // Residual / per-row bias / GELU'(pre-activation) operands of a whole 32-row slab are fetched up front, from
+    // addresses clamped into the tensors (a zero page stands in for an absent operand), so their latency runs under
+    // the LDS transpose instead of once per pass: a load inside `if (row < M && ...)` is waited for on the spot.
+    constexpr int NP = 32 / RPP;
+    const float* const zp = reinterpret_cast<const float*>(g_zero_page);
+    const bool has_aux = d.act == ASIS_ACT_GELU_GRAD;
+    const int colc = cok ? col : 0;
+    const float* const resp = res ? res + colc : zp;
+    const int64_t ldr_e = res ? d.ldr : 0;
+    const float* const bmp = d.bias_m ? d.bias_m : zp;
+    const int bm_e = d.bias_m ? 1 : 0;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -312,38 +323,59 @@ __global__ __launch_bounds__(512, OCC) void gemm_big_kernel(const asis_gemm_desc
         for (int g = 0; g < 4; ++g)
           *reinterpret_cast<float4*>(slab + fr * SW + 32 * j + 8 * g + 4 * fh) =
               make_float4(acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+      // issued after the slab writes (the accumulator registers of this slab are free again), PG passes at a time:
+      // a whole slab's worth spills in the 128-register form of the kernel
+      constexpr int PG = (OCC >= 4 && NP > 4) ? 4 : NP;
 #pragma unroll
-      for (int p = 0; p < 32 / RPP; ++p) {
-        const int lrow = p * RPP + rr;
-        const int row = m0 + (wm * TM + i) * 32 + lrow;
-        float4 v = *reinterpret_cast<const float4*>(slab + lrow * SW + ch * 4);
-        if (row < d.M && cok) {
-          const float bmv = d.bias_m ? d.bias_m[row] : 0.f;
-          v.x += b4.x + bmv; v.y += b4.y + bmv; v.z += b4.z + bmv; v.w += b4.w + bmv;
-          if (d.act == ASIS_ACT_GELU) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
-          else if (d.act == ASIS_ACT_GELU_GRAD) {  // input-gradient GEMM of fc2 fused with GELU's backward
-            const uint2 pw = *reinterpret_cast<const uint2*>(reinterpret_cast<const T*>(d.aux) + (int64_t)row * d.ld_aux + col);
-            float p0, p1, p2, p3;
-            unpack2<T>(pw.x, p0, p1);
-            unpack2<T>(pw.y, p2, p3);
-            v.x *= gelu_erf_grad_fast(p0); v.y *= gelu_erf_grad_fast(p1); v.z *= gelu_erf_grad_fast(p2); v.w *= gelu_erf_grad_fast(p3);
+      for (int p0 = 0; p0 < NP; p0 += PG) {
+        float4 r4[PG];
+        float bmv[PG];
+        uint2 pw[PG];
+#pragma unroll
+        for (int q = 0; q < PG; ++q) {
+          const int row = m0 + (wm * TM + i) * 32 + (p0 + q) * RPP + rr;
+          const int rowc = row < d.M ? row : d.M - 1;
+          r4[q] = *reinterpret_cast<const float4*>(resp + (int64_t)rowc * ldr_e);
+          bmv[q] = bmp[rowc * bm_e];
+          pw[q] = make_uint2(0u, 0u);
+        }
+        if (has_aux) {
+#pragma unroll
+          for (int q = 0; q < PG; ++q) {
+            const int row = m0 + (wm * TM + i) * 32 + (p0 + q) * RPP + rr;
+            const int rowc = row < d.M ? row : d.M - 1;
+            pw[q] = *reinterpret_cast<const uint2*>(reinterpret_cast<const T*>(d.aux) + (int64_t)rowc * d.ld_aux + colc);
           }
-          else if (d.act == ASIS_ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-          v.x *= s4.x; v.y *= s4.y; v.z *= s4.z; v.w *= s4.w;
-          if (res) {
-            const float4 r4 = *reinterpret_cast<const float4*>(res + (int64_t)row * d.ldr + col);
-            v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
+        }
+#pragma unroll
+        for (int q = 0; q < PG; ++q) {
+          const int lrow = (p0 + q) * RPP + rr;
+          const int row = m0 + (wm * TM + i) * 32 + lrow;
+          float4 v = *reinterpret_cast<const float4*>(slab + lrow * SW + ch * 4);
+          if (row < d.M && cok) {
+            const float bm1 = bmv[q];
+            v.x += b4.x + bm1; v.y += b4.y + bm1; v.z += b4.z + bm1; v.w += b4.w + bm1;
+            if (d.act == ASIS_ACT_GELU) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
+            else if (has_aux) {  // input-gradient GEMM of fc2 fused with GELU's backward
+              float g0, g1, g2, g3;
+              unpack2<T>(pw[q].x, g0, g1);
+              unpack2<T>(pw[q].y, g2, g3);
+              v.x *= gelu_erf_grad_fast(g0); v.y *= gelu_erf_grad_fast(g1); v.z *= gelu_erf_grad_fast(g2); v.w *= gelu_erf_grad_fast(g3);
+            }
+            else if (d.act == ASIS_ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            v.x *= s4.x; v.y *= s4.y; v.z *= s4.z; v.w *= s4.w;
+            v.x += r4[q].x; v.y += r4[q].y; v.z += r4[q].z; v.w += r4[q].w;
+            if (d.out_f32) {
+              *reinterpret_cast<float4*>(reinterpret_cast<float*>(d.C) + cbase + (int64_t)row * d.ldc + col) = v;
+            } else {
+              uint2 pk;
+              pk.x = pack2<T>(v.x, v.y);
+              pk.y = pack2<T>(v.z, v.w);
+              *reinterpret_cast<uint2*>(reinterpret_cast<T*>(d.C) + cbase + (int64_t)row * d.ldc + col) = pk;
+            }
+            st_s.x += v.x; st_s.y += v.y; st_s.z += v.z; st_s.w += v.w;
+            st_q.x += v.x * v.x; st_q.y += v.y * v.y; st_q.z += v.z * v.z; st_q.w += v.w * v.w;
           }
-          if (d.out_f32) {
-            *reinterpret_cast<float4*>(reinterpret_cast<float*>(d.C) + cbase + (int64_t)row * d.ldc + col) = v;
-          } else {
-            uint2 pk;
-            pk.x = pack2<T>(v.x, v.y);
-            pk.y = pack2<T>(v.z, v.w);
-            *reinterpret_cast<uint2*>(reinterpret_cast<T*>(d.C) + cbase + (int64_t)row * d.ldc + col) = pk;
-          }
-          st_s.x += v.x; st_s.y += v.y; st_s.z += v.z; st_s.w += v.w;
-          st_q.x += v.x * v.x; st_q.y += v.y * v.y; st_q.z += v.z * v.z; st_q.w += v.w * v.w;
         }
       }
     }
