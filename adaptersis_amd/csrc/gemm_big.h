@@ -35,6 +35,8 @@ __global__ __launch_bounds__(512, OCC) void gemm_big_kernel(const asis_gemm_desc
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid / WN, wn = wid - wm * WN;
+  uint64_t dbg_c0 = 0, dbg_r0 = 0;
+  if (DBG & 4) asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(dbg_c0), "=s"(dbg_r0)::"memory");
   const int tiles_n = (d.N + BN2 - 1) / BN2;
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
   // grouped raster: 8 row tiles x tiles_n column tiles per band, column-major inside the band, so the ~64 tiles an
@@ -270,6 +272,13 @@ __global__ __launch_bounds__(512, OCC) void gemm_big_kernel(const asis_gemm_desc
 
   // ---- epilogue (same semantics as gemm_kernel) ----
   if (DBG & 4) {  // lab only: keep the accumulators live, store one value per lane
+    if (blockIdx.x == gridDim.x / 2 && tid == 0) {  // shader clock under load: s_memtime ticks per 100 MHz s_memrealtime tick
+      uint64_t c1, r1;
+      asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c1), "=s"(r1)::"memory");
+      uint64_t* o = reinterpret_cast<uint64_t*>(d.C);
+      o[0] = c1 - dbg_c0;
+      o[1] = r1 - dbg_r0;
+    }
     float z = 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i)

@@ -19,18 +19,24 @@ namespace {
 constexpr int BM = 128, BN = 128, BK = 64, NTHREADS = 256;
 
 // DENSE: 1x1 / stride 1 / no padding (nn.Linear and 1x1 conv weight gradients): x row p is pixel p, no index arithmetic
-template <typename T, bool DENSE>
+// BME: rows (output channels) of the tile that are computed: 128, 64 or 32.  The LDS image keeps 128 columns; a
+// narrower tile only changes which fragments the four waves own (2x2 of 64x64 | 1x4 of 64x32 | 1x4 of 32x32), so a
+// conv with 64 (or 2) output channels does not pay MFMAs for 128.
+template <typename T, bool DENSE, int BME = 128>
 __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const asis_wgrad_desc d) {
+  constexpr int WR = BME == 128 ? 2 : 1, WC = 4 / WR;
+  constexpr int FI = BME / (32 * WR), FJ = BN / (32 * WC);
   typedef typename T16<T>::v8 v8;
   typedef s16x4 __attribute__((address_space(3))) * lds_tr_ptr;
   __shared__ __attribute__((aligned(16))) T lds[2 * 2 * BK * BM];  // [buf][A|B][64 k][128] = 64 KiB
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wr = wid >> 1, wc = wid & 1;
+  const int wr = WR == 2 ? wid >> 1 : 0, wc = WR == 2 ? (wid & 1) : wid;
+  const int m_off = wr * (BME / WR), n_off = wc * (BN / WC);
   const int Ntot = d.KH * d.KW * d.Cin;
   const int tiles_n = (Ntot + BN - 1) / BN;
   const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x - tile_m * tiles_n;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int m0 = tile_m * BME, n0 = tile_n * BN;
   const int64_t k_begin = (int64_t)blockIdx.y * d.k_per_split;
   int64_t k_end = k_begin + d.k_per_split;
   if (k_end > d.P) k_end = d.P;
@@ -41,7 +47,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const asis_wgrad_des
   // loader: thread -> k rows (tid>>4) + 16*i, 16-byte chunk (tid & 15)
   const int lk = tid >> 4, lch = tid & 15;
   const int am = m0 + lch * 8;
-  const bool a_col_ok = am < d.CoP;
+  const bool a_col_ok = am < d.CoP && lch * 8 < BME;
   const int bn = n0 + lch * 8;
   const bool b_col_ok = bn < Ntot;
   const int tap = b_col_ok ? bn / d.Cin : 0;
@@ -150,11 +156,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const asis_wgrad_des
     store_row(As, Bs, 3, ra3, rb3);
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[FI][FJ];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < FI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < FJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -180,32 +186,26 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const asis_wgrad_des
     const T* Bs = As + BK * BM;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      v8 af[2], bf[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int ca = wr * 64 + i * 32 + msub + 4 * pc;  // first column supplied by this lane
-        const int cb = wc * 64 + i * 32 + msub + 4 * pc;
-        s16x4 lo[2], hi[2];
+      v8 af[FI], bf[FJ];
+      typedef short s16x8 __attribute__((ext_vector_type(8)));
+      auto frag = [&](const T* S, int c0) -> v8 {  // 8 consecutive k of column block c0 (this lane: 4 columns at c0)
+        s16x4 h[2];
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
           const int k = ks * 16 + 8 * fh + 4 * half + q;
           const int swz = (k & 3) << 2;
-          const T* pa = As + k * BM + ((((ca >> 3) ^ swz) << 3) | (ca & 7));
-          const T* pb = Bs + k * BN + ((((cb >> 3) ^ swz) << 3) | (cb & 7));
-          const s16x4 va = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(pa));
-          const s16x4 vb = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(pb));
-          if (half == 0) { lo[0] = va; lo[1] = vb; } else { hi[0] = va; hi[1] = vb; }
+          h[half] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(S + k * BM + ((((c0 >> 3) ^ swz) << 3) | (c0 & 7))));
         }
-        typedef short s16x8 __attribute__((ext_vector_type(8)));
-        const s16x8 a8 = __builtin_shufflevector(lo[0], hi[0], 0, 1, 2, 3, 4, 5, 6, 7);
-        const s16x8 b8 = __builtin_shufflevector(lo[1], hi[1], 0, 1, 2, 3, 4, 5, 6, 7);
-        af[i] = __builtin_bit_cast(v8, a8);
-        bf[i] = __builtin_bit_cast(v8, b8);
-      }
+        return __builtin_bit_cast(v8, (s16x8)__builtin_shufflevector(h[0], h[1], 0, 1, 2, 3, 4, 5, 6, 7));
+      };
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < FI; ++i) af[i] = frag(As, m_off + i * 32 + msub + 4 * pc);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = T16<T>::mfma32(af[i], bf[j], acc[i][j]);
+      for (int j = 0; j < FJ; ++j) bf[j] = frag(Bs, n_off + j * 32 + msub + 4 * pc);
+#pragma unroll
+      for (int i = 0; i < FI; ++i)
+#pragma unroll
+        for (int j = 0; j < FJ; ++j) acc[i][j] = T16<T>::mfma32(af[i], bf[j], acc[i][j]);
     }
     if (t + 1 < nt) store_tile(buf ^ 1);
     __syncthreads();
@@ -216,15 +216,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const asis_wgrad_des
   const int taps = d.KH * d.KW;
   const int fr = lane & 31, fq = lane >> 5;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int n = n0 + wc * 64 + j * 32 + fr;
+  for (int j = 0; j < FJ; ++j) {
+    const int n = n0 + n_off + j * 32 + fr;
     if (n >= Ntot) continue;
     const int tp = n / d.Cin, cc = n - tp * d.Cin;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < FI; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fq;
+        const int m = m0 + m_off + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fq;
         if (m < d.Cout) slab[((int64_t)m * d.Cin + cc) * taps + tp] = acc[i][j][r];
       }
   }
@@ -232,8 +232,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const asis_wgrad_des
 
 }  // namespace
 
+static inline int wgrad_bme(int Cout) {
+  static const int force = [] { const char* e = getenv("ASIS_WGRAD_BME"); return e ? atoi(e) : 0; }();  // lab: 128 = always the full tile
+  if (force == 128) return BM;
+  return Cout <= 32 ? 32 : (Cout <= 64 ? 64 : BM);
+}
+
 extern "C" int asis_wgrad_splits(int64_t P, int Cout, int Ntot) {
-  const int64_t tiles = asis_cdiv(Cout, BM) * asis_cdiv(Ntot, BN);
+  const int64_t tiles = asis_cdiv(Cout, wgrad_bme(Cout)) * asis_cdiv(Ntot, BN);
   int64_t want = asis_cdiv(1024, tiles);          // ~4 workgroups per CU overall
   const int64_t max_by_k = asis_cdiv(P, 4 * BK);  // at least 4 K tiles per split
   if (want > max_by_k) want = max_by_k;
@@ -259,16 +265,22 @@ extern "C" int asis_wgrad(void* stream, const asis_wgrad_desc* dp) {
   const int Ntot = d.KH * d.KW * d.Cin;
   d.k_per_split = asis_cdiv(asis_cdiv(d.P, d.splits), BK) * BK;
   ASIS_REQUIRE((int64_t)d.k_per_split * d.splits >= d.P, "asis_wgrad: internal split error");
-  dim3 grid((unsigned)(asis_cdiv(d.Cout, BM) * asis_cdiv(Ntot, BN)), d.splits), block(NTHREADS);
+  const int bme = wgrad_bme(d.Cout);
+  dim3 grid((unsigned)(asis_cdiv(d.Cout, bme) * asis_cdiv(Ntot, BN)), d.splits), block(NTHREADS);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const bool dense = d.KH == 1 && d.KW == 1 && d.stride == 1 && d.pad == 0;
+#define ASIS_WGRAD_LAUNCH(TT, DN)                                                                         \
+  do {                                                                                                    \
+    if (bme == 32) hipLaunchKernelGGL((wgrad_kernel<TT, DN, 32>), grid, block, 0, s, d);                  \
+    else if (bme == 64) hipLaunchKernelGGL((wgrad_kernel<TT, DN, 64>), grid, block, 0, s, d);             \
+    else hipLaunchKernelGGL((wgrad_kernel<TT, DN, 128>), grid, block, 0, s, d);                           \
+  } while (0)
   if (d.dtype == ASIS_F16) {
-    if (dense) hipLaunchKernelGGL((wgrad_kernel<f16, true>), grid, block, 0, s, d);
-    else hipLaunchKernelGGL((wgrad_kernel<f16, false>), grid, block, 0, s, d);
+    if (dense) ASIS_WGRAD_LAUNCH(f16, true); else ASIS_WGRAD_LAUNCH(f16, false);
   } else {
-    if (dense) hipLaunchKernelGGL((wgrad_kernel<bf16, true>), grid, block, 0, s, d);
-    else hipLaunchKernelGGL((wgrad_kernel<bf16, false>), grid, block, 0, s, d);
+    if (dense) ASIS_WGRAD_LAUNCH(bf16, true); else ASIS_WGRAD_LAUNCH(bf16, false);
   }
+#undef ASIS_WGRAD_LAUNCH
   ASIS_CHECK_LAUNCH("asis_wgrad");
   return ASIS_OK;
 }
