@@ -99,6 +99,7 @@ SIGNATURES = {
     "asis_conv3x3_c3": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i],
     "asis_conv3x3_smallcout_fwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i],
     "asis_conv3x3_smallcout_dgrad": [_vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i],
+    "asis_conv3x3_smallcout_wgrad": [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i],
     "asis_colstats_nparts": [_i64],
     "asis_colstats": [_vp, _vp, _i64, _i, _vp],
     "asis_reduce_partials": [_vp, _vp, _i, _i, _vp],

@@ -70,21 +70,29 @@ __global__ __launch_bounds__(256) void msda_fwd_kernel(const T* __restrict__ val
         const int x0 = (int)fminf(fmaxf(fx0, -2.f), (float)Wl + 1.f);
         const int y0 = (int)fminf(fmaxf(fy0, -2.f), (float)Hl + 1.f);
         const float aw = w[j] * inv;
+        // the four corners are fetched unconditionally from coordinates clamped into the level, an out-of-range
+        // corner only loses its weight: a load under `if (in range)` is waited for on the spot, one at a time
+        uint4 raw[4];
+        float wt[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           const int xx = x0 + (t & 1), yy = y0 + (t >> 1);
-          const float wt = ((t & 1) ? ax : 1.f - ax) * ((t >> 1) ? ay : 1.f - ay) * aw;
-          if ((unsigned)xx < (unsigned)Wl && (unsigned)yy < (unsigned)Hl) {
-            const uint4 raw = *reinterpret_cast<const uint4*>(vl + ((int64_t)yy * Wl + xx) * D);
-            const uint32_t* pw = reinterpret_cast<const uint32_t*>(&raw);
+          const bool inb = (unsigned)xx < (unsigned)Wl && (unsigned)yy < (unsigned)Hl;
+          const int xc = xx < 0 ? 0 : (xx >= Wl ? Wl - 1 : xx), yc = yy < 0 ? 0 : (yy >= Hl ? Hl - 1 : yy);
+          wt[t] = inb ? ((t & 1) ? ax : 1.f - ax) * ((t >> 1) ? ay : 1.f - ay) * aw : 0.f;
+          raw[t] = *reinterpret_cast<const uint4*>(vl + ((int64_t)yc * Wl + xc) * D);
+        }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              float f0, f1;
-              unpack2<T>(pw[e], f0, f1);
-              acc[2 * e] += wt * f0;
-              acc[2 * e + 1] += wt * f1;
-            }
-          }
+        for (int t = 0; t < 4; ++t) {
+          float f0, f1;
+          unpack2<T>(raw[t].x, f0, f1);
+          acc[0] += wt[t] * f0; acc[1] += wt[t] * f1;
+          unpack2<T>(raw[t].y, f0, f1);
+          acc[2] += wt[t] * f0; acc[3] += wt[t] * f1;
+          unpack2<T>(raw[t].z, f0, f1);
+          acc[4] += wt[t] * f0; acc[5] += wt[t] * f1;
+          unpack2<T>(raw[t].w, f0, f1);
+          acc[6] += wt[t] * f0; acc[7] += wt[t] * f1;
         }
       }
     }

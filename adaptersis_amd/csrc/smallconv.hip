@@ -121,6 +121,101 @@ __global__ __launch_bounds__(256) void smallcout_dgrad_kernel(const T* __restric
   }
 }
 
+// dW[co][ci][kh][kw] = sum_p dy[p][co] * x[p + (kh-1, kw-1)][ci] for TWO output channels (co0, co0+1) per launch row
+// (gridDim.y walks the channel pairs).  Same thread map as the forward: lane = (pixel, 8-channel chunk); the 9 taps'
+// chunks are fetched unconditionally from coordinates clamped into the image (an outside tap only loses its dy),
+// 9 x 8 x 2 partial sums live in registers over the lane's whole pixel range, and are folded once at the end: lanes of
+// equal chunk by xor-shuffles, the four waves through LDS, one fp32 slab row per workgroup (asis_reduce_rows sums the
+// rows in a fixed order: deterministic).  As an MFMA wgrad this layer pays a 32-row tile for 2 rows and is bound by
+// staging the im2col operand through LDS (1.16 ms at 12 x 672^2 x 64); here x is read from L1/L2 nine times and
+// nothing else moves.
+template <typename T>
+__global__ __launch_bounds__(256) void smallcout_wgrad_kernel(const T* __restrict__ dy, int CoP, const T* __restrict__ x,
+                                                              float* __restrict__ slab, int B, int H, int W, int Cin,
+                                                              int Cout) {
+  __shared__ float red[4][8 * 144];  // [wave][chunk slot][tap*16 + e*2 + c]  (cpp <= 8 chunk slots per wave pass)
+  const int cpp = Cin >> 3;          // lanes per pixel: 1, 2, 4 or 8
+  const int co0 = blockIdx.y * 2;
+  const bool two = co0 + 1 < Cout;
+  const int64_t total = (int64_t)B * H * W * cpp;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  float acc[9][8][2];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[t][e][0] = acc[t][e][1] = 0.f;
+  const int c8 = (threadIdx.x & (cpp - 1)) * 8;  // the chunk is the same in every iteration (stride % cpp == 0)
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int64_t p = i / cpp;
+    const int xq = (int)(p % W);
+    const int yq = (int)((p / W) % H);
+    const uint4 draw = *reinterpret_cast<const uint4*>(dy + p * CoP + (co0 & ~7));
+    float d0, d1;
+    {
+      const uint32_t wsel = ((co0 & 7) >> 1) == 0 ? draw.x : (((co0 & 7) >> 1) == 1 ? draw.y : (((co0 & 7) >> 1) == 2 ? draw.z : draw.w));
+      unpack2<T>(wsel, d0, d1);  // co0 is even: the pair sits in one 32-bit word
+      if (!two) d1 = 0.f;
+    }
+    uint4 raw[9];
+    float m[9];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int yy = yq + kh - 1, xx = xq + kw - 1;
+        const bool inb = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+        const int yc = yy < 0 ? 0 : (yy >= H ? H - 1 : yy), xc = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
+        const int64_t q = p + (int64_t)(yc - yq) * W + (xc - xq);
+        raw[kh * 3 + kw] = *reinterpret_cast<const uint4*>(x + q * Cin + c8);
+        m[kh * 3 + kw] = inb ? 1.f : 0.f;
+      }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const float a0 = d0 * m[t], a1 = d1 * m[t];
+      float f0, f1;
+      unpack2<T>(raw[t].x, f0, f1);
+      acc[t][0][0] += a0 * f0; acc[t][0][1] += a1 * f0; acc[t][1][0] += a0 * f1; acc[t][1][1] += a1 * f1;
+      unpack2<T>(raw[t].y, f0, f1);
+      acc[t][2][0] += a0 * f0; acc[t][2][1] += a1 * f0; acc[t][3][0] += a0 * f1; acc[t][3][1] += a1 * f1;
+      unpack2<T>(raw[t].z, f0, f1);
+      acc[t][4][0] += a0 * f0; acc[t][4][1] += a1 * f0; acc[t][5][0] += a0 * f1; acc[t][5][1] += a1 * f1;
+      unpack2<T>(raw[t].w, f0, f1);
+      acc[t][6][0] += a0 * f0; acc[t][6][1] += a1 * f0; acc[t][7][0] += a0 * f1; acc[t][7][1] += a1 * f1;
+    }
+  }
+  // fold lanes that hold the same chunk (lane bits above log2(cpp)), then the four waves
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        float v = acc[t][e][c];
+        for (int o = cpp; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+        acc[t][e][c] = v;
+      }
+  if (lane < cpp) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        red[wid][lane * 144 + t * 16 + e * 2 + 0] = acc[t][e][0];
+        red[wid][lane * 144 + t * 16 + e * 2 + 1] = acc[t][e][1];
+      }
+  }
+  __syncthreads();
+  // slab row layout = the parameter's [Cout][Cin][3][3]
+  float* row = slab + (int64_t)blockIdx.x * Cout * Cin * 9;
+  for (int i = threadIdx.x; i < cpp * 144; i += blockDim.x) {
+    const int ch = i / 144, r = i - ch * 144;
+    const int t = r >> 4, e = (r >> 1) & 7, c = r & 1;
+    if (c == 1 && !two) continue;
+    const float v = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+    row[((int64_t)(co0 + c) * Cin + ch * 8 + e) * 9 + t] = v;
+  }
+}
+
 inline int grid_for(int64_t total, int cap = 256 * 32) {
   int64_t g = (total + 255) / 256;
   if (g > cap) g = cap;
@@ -183,5 +278,25 @@ extern "C" int asis_conv3x3_smallcout_dgrad(void* stream, int dtype, const void*
   }
 #undef DG
   ASIS_CHECK_LAUNCH("asis_conv3x3_smallcout_dgrad");
+  return ASIS_OK;
+}
+
+extern "C" int asis_conv3x3_smallcout_wgrad(void* stream, int dtype, const void* dy, int CoP, const void* x, float* slabs,
+                                            int nblk, int B, int H, int W, int Cin, int Cout) {
+  ASIS_REQUIRE(dy && x && slabs, "asis_conv3x3_smallcout_wgrad: null pointer");
+  ASIS_REQUIRE(Cout >= 1 && Cout <= CoP && CoP % 8 == 0, "asis_conv3x3_smallcout_wgrad: Cout=%d CoP=%d", Cout, CoP);
+  ASIS_REQUIRE(Cin >= 8 && Cin <= 64 && (Cin & (Cin - 1)) == 0, "asis_conv3x3_smallcout_wgrad: Cin=%d must be 8, 16, 32 or 64", Cin);
+  ASIS_REQUIRE(nblk >= 1 && nblk <= 65535, "asis_conv3x3_smallcout_wgrad: bad slab count %d", nblk);
+  ASIS_REQUIRE(asis_aligned16(dy) && asis_aligned16(x), "asis_conv3x3_smallcout_wgrad: alignment");
+  ASIS_REQUIRE(dtype == ASIS_F16 || dtype == ASIS_BF16, "asis_conv3x3_smallcout_wgrad: bad dtype %d", dtype);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  dim3 grid(nblk, (Cout + 1) / 2), block(256);
+  if (dtype == ASIS_F16)
+    hipLaunchKernelGGL((smallcout_wgrad_kernel<f16>), grid, block, 0, s, reinterpret_cast<const f16*>(dy), CoP,
+                       reinterpret_cast<const f16*>(x), slabs, B, H, W, Cin, Cout);
+  else
+    hipLaunchKernelGGL((smallcout_wgrad_kernel<bf16>), grid, block, 0, s, reinterpret_cast<const bf16*>(dy), CoP,
+                       reinterpret_cast<const bf16*>(x), slabs, B, H, W, Cin, Cout);
+  ASIS_CHECK_LAUNCH("asis_conv3x3_smallcout_wgrad");
   return ASIS_OK;
 }

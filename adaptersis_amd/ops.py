@@ -890,6 +890,17 @@ def wgrad(dy: torch.Tensor, x_nhwc: torch.Tensor, Cout: int, KH: int, KW: int, s
     _, OH, OW, CoP = dy.shape
     P = Bn * OH * OW
     Ntot = KH * KW * Cin
+    if (KH == 3 and KW == 3 and stride == 1 and pad == 1 and Cout <= 4 and Cin in (8, 16, 32, 64)
+            and os.environ.get("ASIS_WGRAD_SMALLCOUT", "1") != "0"):
+        # classifier convs: a handful of output channels -> direct fp32 kernel instead of an MFMA tile that is mostly padding
+        nblk = 1024
+        slabs = torch.empty((nblk, Cout * Ntot), device=dy.device, dtype=torch.float32)
+        check(lib().asis_conv3x3_smallcout_wgrad(_stream(), _dt(dy.dtype), dy.data_ptr(), CoP, x_nhwc.data_ptr(),
+                                                 slabs.data_ptr(), nblk, Bn, H, W, Cin, Cout), "asis_conv3x3_smallcout_wgrad")
+        if out is None:
+            out = torch.empty((Cout, Cin, KH, KW), device=dy.device, dtype=torch.float32)
+        reduce_rows(slabs, inv_scale, out.view(-1))
+        return out
     splits = lib().asis_wgrad_splits(P, Cout, Ntot)
     slabs = torch.empty((splits, Cout * Ntot), device=dy.device, dtype=torch.float32)
     d = _lib.WgradDesc()

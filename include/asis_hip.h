@@ -260,6 +260,12 @@ int asis_conv3x3_smallcout_fwd(void* stream, int dtype, const void* x_hi, const 
  * -> dx fp32 NHWC [B,H,W,Cin] */
 int asis_conv3x3_smallcout_dgrad(void* stream, int dtype, const void* dy_hi, const void* dy_lo, int CoP, const float* w,
                                  float* dx, int B, int H, int W, int Cin, int Cout);
+
+/* Weight gradient of the same 3x3 / stride 1 / pad 1 classifier conv (`backbones/decoders.py:135` under
+ * `loss.backward()`, `train.py:432`): dy 16-bit [B,H,W,CoP], x 16-bit [B,H,W,Cin] -> `nblk` fp32 slab rows of
+ * [Cout,Cin,3,3] partial sums (one per workgroup; sum them with asis_reduce_rows).  Cin in {8,16,32,64}. */
+int asis_conv3x3_smallcout_wgrad(void* stream, int dtype, const void* dy, int CoP, const void* x, float* slabs, int nblk,
+                                 int B, int H, int W, int Cin, int Cout);
 /* column sums / sums of squares of fp32 [R, C] -> partial[nparts][2][C], nparts = asis_colstats_nparts(R) */
 int asis_colstats_nparts(int64_t R);
 int asis_colstats(void* stream, const float* x, int64_t R, int C, float* partial);
