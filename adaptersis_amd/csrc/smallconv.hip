@@ -43,26 +43,35 @@ __global__ __launch_bounds__(256) void smallcout_fwd_kernel(const T* __restrict_
     float acc[CO];
 #pragma unroll
     for (int c = 0; c < CO; ++c) acc[c] = 0.f;
+    // all taps are fetched up front from coordinates clamped into the image and an outside tap is zeroed afterwards:
+    // a load under `if (inside)` is waited for on the spot, i.e. up to 18 exposed latencies per pixel
+    uint4 rh[9], rl[9];
+    float msk[9];
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw) {
+        const int t = kh * 3 + kw;
         const int yy = y + kh - 1, xx = x + kw - 1;
-        if ((unsigned)yy >= (unsigned)H || (unsigned)xx >= (unsigned)W) continue;
-        const int64_t q = p + (int64_t)(kh - 1) * W + (kw - 1);
-        float f[8], g[8];
-        load8<T>(xh + q * Cin + c8, f);
-        if (xl) {
-          load8<T>(xl + q * Cin + c8, g);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) f[e] += g[e];
-        }
-        const float* wt = wl + ((kh * 3 + kw) * Cin + c8) * CO;
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-#pragma unroll
-          for (int c = 0; c < CO; ++c) acc[c] += f[e] * wt[e * CO + c];
+        msk[t] = ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) ? 1.f : 0.f;
+        const int yc = yy < 0 ? 0 : (yy >= H ? H - 1 : yy), xc = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
+        const int64_t q = p + (int64_t)(yc - y) * W + (xc - x);
+        rh[t] = *reinterpret_cast<const uint4*>(xh + q * Cin + c8);
+        rl[t] = xl ? *reinterpret_cast<const uint4*>(xl + q * Cin + c8) : make_uint4(0u, 0u, 0u, 0u);
       }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      float f[8], g[8];
+      unpack2<T>(rh[t].x, f[0], f[1]); unpack2<T>(rh[t].y, f[2], f[3]); unpack2<T>(rh[t].z, f[4], f[5]); unpack2<T>(rh[t].w, f[6], f[7]);
+      unpack2<T>(rl[t].x, g[0], g[1]); unpack2<T>(rl[t].y, g[2], g[3]); unpack2<T>(rl[t].z, g[4], g[5]); unpack2<T>(rl[t].w, g[6], g[7]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = (f[e] + g[e]) * msk[t];
+      const float* wt = wl + (t * Cin + c8) * CO;
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+#pragma unroll
+        for (int c = 0; c < CO; ++c) acc[c] += f[e] * wt[e * CO + c];
+    }
     for (int o = 1; o < cpp; o <<= 1)
 #pragma unroll
       for (int c = 0; c < CO; ++c) acc[c] += __shfl_xor(acc[c], o, 64);
@@ -92,29 +101,35 @@ __global__ __launch_bounds__(256) void smallcout_dgrad_kernel(const T* __restric
     float acc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    uint4 rh[9], rl[9];
+    float msk[9];
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw) {
+        const int t = kh * 3 + kw;
         const int yy = y - (kh - 1), xx = x - (kw - 1);
-        if ((unsigned)yy >= (unsigned)H || (unsigned)xx >= (unsigned)W) continue;
-        const int64_t q = p - (int64_t)(kh - 1) * W - (kw - 1);
-        float d[8], g[8];
-        load8<T>(dh + q * CoP, d);  // CO <= 8 channels live in the first 16 bytes
-        if (dl) {
-          load8<T>(dl + q * CoP, g);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) d[e] += g[e];
-        }
-        const float* wt = wl + (kh * 3 + kw) * CO * Cin + c8;
-#pragma unroll
-        for (int c = 0; c < CO; ++c) {
-          const float4 w0 = *reinterpret_cast<const float4*>(wt + c * Cin);
-          const float4 w1 = *reinterpret_cast<const float4*>(wt + c * Cin + 4);
-          acc[0] += d[c] * w0.x; acc[1] += d[c] * w0.y; acc[2] += d[c] * w0.z; acc[3] += d[c] * w0.w;
-          acc[4] += d[c] * w1.x; acc[5] += d[c] * w1.y; acc[6] += d[c] * w1.z; acc[7] += d[c] * w1.w;
-        }
+        msk[t] = ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) ? 1.f : 0.f;
+        const int yc = yy < 0 ? 0 : (yy >= H ? H - 1 : yy), xc = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
+        const int64_t q = p + (int64_t)(yc - y) * W + (xc - x);
+        rh[t] = *reinterpret_cast<const uint4*>(dh + q * CoP);  // CO <= 8 channels live in the first 16 bytes
+        rl[t] = dl ? *reinterpret_cast<const uint4*>(dl + q * CoP) : make_uint4(0u, 0u, 0u, 0u);
       }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      float d[8], g[8];
+      unpack2<T>(rh[t].x, d[0], d[1]); unpack2<T>(rh[t].y, d[2], d[3]); unpack2<T>(rh[t].z, d[4], d[5]); unpack2<T>(rh[t].w, d[6], d[7]);
+      unpack2<T>(rl[t].x, g[0], g[1]); unpack2<T>(rl[t].y, g[2], g[3]); unpack2<T>(rl[t].z, g[4], g[5]); unpack2<T>(rl[t].w, g[6], g[7]);
+      const float* wt = wl + t * CO * Cin + c8;
+#pragma unroll
+      for (int c = 0; c < CO; ++c) {
+        const float dc = (d[c] + g[c]) * msk[t];
+        const float4 w0 = *reinterpret_cast<const float4*>(wt + c * Cin);
+        const float4 w1 = *reinterpret_cast<const float4*>(wt + c * Cin + 4);
+        acc[0] += dc * w0.x; acc[1] += dc * w0.y; acc[2] += dc * w0.z; acc[3] += dc * w0.w;
+        acc[4] += dc * w1.x; acc[5] += dc * w1.y; acc[6] += dc * w1.z; acc[7] += dc * w1.w;
+      }
+    }
     float4* o = reinterpret_cast<float4*>(dx + p * Cin + c8);
     o[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
     o[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
