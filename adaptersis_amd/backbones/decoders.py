@@ -21,6 +21,7 @@ from typing import Dict, List, Optional
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from .. import config, ops
 from ..dinov2.layers.blocks import _Packed, _pack
@@ -195,29 +196,24 @@ class FeatureDecoder(_Packed):
             seq = getattr(self, f"decoder_{i}")
             a, st = conv_bn_relu_up_forward(self, f"d{i}", a[0], a[1], seq[0], seq[1], 2, self.sync_bn, save, training)
             saved.append(st)
-        bias = self._f32("final.b", self.final_out.bias)
-        fo = self.final_out
-        if fo.out_channels <= 16 and fo.in_channels in (8, 16, 32, 64):  # few classes: direct fp32 kernel, no MFMA tile waste
-            logits = ops.conv3x3_smallcout_fwd(a[0], a[1], self._f32("final.wf", fo.weight), bias)
-            saved.append(a[0] if save else None)
-            return logits, saved
-        w_hi, w_lo = _conv_weights(self, "final", self.final_out, a[1] is not None)
-        if a[1] is not None:
-            logits = ops.conv_gemm_split(a[0], a[1], w_hi, w_lo, 3, 3, 1, 1, bias_n=bias)
-        else:
-            logits = ops.conv_gemm(a[0], w_hi, 3, 3, 1, 1, bias_n=bias)
+        logits = self._final_forward(a)
         saved.append(a[0] if save else None)
         return logits, saved
 
-    def _backward_core(self, saved, d16, bias_partial, inv_scale, grads, dlogits_f32=None, stage_done=None, d_lo=None,
-                       need_input_grad: bool = False):
-        """d16: 16-bit [B,h,w,CP] = loss_scale * dL/dlogits (pad channels zero).  ``stage_done()`` is
-        called after the final conv and after each decoder stage (4,3,2,1) once its gradients are
-        enqueued — the engine launches that stage's gradient all-reduce from it.  ``need_input_grad``: also return
-        loss_scale * dL/d(input) as fp32 NHWC (end-to-end training of the backbone)."""
-        dt = config.operand_dtype
+    def _final_forward(self, a):
+        """`decoders.py:135` classifier conv on the (hi, lo) NHWC operand pair."""
+        bias = self._f32("final.b", self.final_out.bias)
+        fo = self.final_out
+        if fo.out_channels <= 16 and fo.in_channels in (8, 16, 32, 64):  # few classes: direct fp32 kernel, no MFMA tile waste
+            return ops.conv3x3_smallcout_fwd(a[0], a[1], self._f32("final.wf", fo.weight), bias)
+        w_hi, w_lo = _conv_weights(self, "final", self.final_out, a[1] is not None)
+        if a[1] is not None:
+            return ops.conv_gemm_split(a[0], a[1], w_hi, w_lo, 3, 3, 1, 1, bias_n=bias)
+        return ops.conv_gemm(a[0], w_hi, 3, 3, 1, 1, bias_n=bias)
+
+    def _final_backward(self, x5, d16, d_lo, bias_partial, inv_scale, grads, dlogits_f32):
+        """Gradients of the classifier conv; returns loss_scale * dL/d(its input), fp32 NHWC."""
         C = self.num_classes
-        x5 = saved[4]
         if bias_partial is not None:
             ops.reduce_rows(bias_partial, inv_scale, grads["final_out.bias"])
         else:  # compatibility path: column sums of the fp32 dlogits [P, C]
@@ -225,9 +221,16 @@ class FeatureDecoder(_Packed):
         ops.wgrad(d16, x5, C, 3, 3, 1, 1, inv_scale, out=grads["final_out.weight"])
         fo = self.final_out
         if fo.out_channels <= 8 and fo.in_channels <= 224:
-            dU = ops.conv3x3_smallcout_dgrad(d16, d_lo, self._f32("final.wf", fo.weight))
-        else:
-            dU = _dgrad(self, "final", fo, d16, d_lo)
+            return ops.conv3x3_smallcout_dgrad(d16, d_lo, self._f32("final.wf", fo.weight))
+        return _dgrad(self, "final", fo, d16, d_lo)
+
+    def _backward_core(self, saved, d16, bias_partial, inv_scale, grads, dlogits_f32=None, stage_done=None, d_lo=None,
+                       need_input_grad: bool = False):
+        """d16: 16-bit [B,h,w,CP] = loss_scale * dL/dlogits (pad channels zero).  ``stage_done()`` is
+        called after the final conv and after each decoder stage (4,3,2,1) once its gradients are
+        enqueued — the engine launches that stage's gradient all-reduce from it.  ``need_input_grad``: also return
+        loss_scale * dL/d(input) as fp32 NHWC (end-to-end training of the backbone)."""
+        dU = self._final_backward(saved[4], d16, d_lo, bias_partial, inv_scale, grads, dlogits_f32)
         if stage_done is not None:
             stage_done()
         for i in range(4, 0, -1):
@@ -266,6 +269,121 @@ class DecoderSETR(FeatureDecoder):
                 nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True)))
         self.final_out = nn.Conv2d(chans[4], out_channels, 3, padding=1)
         self.sync_bn = False
+
+
+class _SETRFFn(torch.autograd.Function):
+    """autograd bridge of DecoderSETRF: x and the three skips in, logits out; gradients for the parameters, the skips and x."""
+
+    @staticmethod
+    def forward(ctx, module, x, c1, c2, c3, *params):
+        logits, saved = module._forward_core(module._to_nhwc16(x), [module._to_nhwc16(c) for c in (c1, c2, c3)], save=True)
+        ctx.module, ctx.saved = module, saved
+        ctx.names = [n for n, _ in module.named_parameters()]
+        return logits.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        m = ctx.module
+        dt = config.operand_dtype
+        S = config.loss_scale
+        B, C, h, w = dlogits.shape
+        d = dlogits.permute(0, 2, 3, 1).contiguous().float().view(B * h * w, C)
+        CP = (C + 7) // 8 * 8
+        d16 = ops.cast_pad(d, CP, dt, scale=S).view(B, h, w, CP)
+        d_lo = ops.cast_pad(d, CP, dt, scale=S, part=1).view(B, h, w, CP) if config.split_conv else None
+        grads = {n: torch.empty_like(p) for n, p in m.named_parameters()}
+        dx, dcs = m._backward_core(ctx.saved, d16, 1.0 / S, grads, d, d_lo, need_x=ctx.needs_input_grad[1])
+        ctx.saved = None
+        nchw = lambda t: None if t is None else (t * (1.0 / S)).permute(0, 3, 1, 2)
+        dc = [nchw(t) if need else None for t, need in zip(dcs, ctx.needs_input_grad[2:5])]
+        return (None, nchw(dx), dc[0], dc[1], dc[2]) + tuple(grads[n] for n in ctx.names)
+
+
+class DecoderSETRF(FeatureDecoder):
+    """`backbones/decoders.py:205-257`: DecoderSETR with the CNN pyramid fused in.  After stage 2 the map is
+    zero-padded (centred, `:240-243`) to c3's size and concatenated with it along the channels; c2 joins after stage 3
+    and c1 after stage 4, so decoder_3 / decoder_4 / final_out see twice the channels.  Same ``state_dict`` keys as the
+    reference; the convs, BatchNorm(train), ReLU, bilinear x2 and all their gradients are the FeatureDecoder kernels,
+    the pad + concat between them is plain tensor plumbing on the 16-bit NHWC operands."""
+
+    def __init__(self, in_channels, out_channels, features=[512, 256, 128, 64]):
+        _Packed.__init__(self)
+        f = list(features)
+        cin = [in_channels, f[0], 2 * f[1], 2 * f[2]]
+        for c in cin + f + [2 * f[3]]:
+            if c % 8:
+                raise ValueError("DecoderSETRF channel counts must be multiples of 8")
+        self.in_channels, self.out_channels, self.features = in_channels, out_channels, f
+        self.num_classes = out_channels
+        for i in range(4):
+            setattr(self, f"decoder_{i + 1}", nn.Sequential(
+                nn.Conv2d(cin[i], f[i], 3, padding=1), nn.BatchNorm2d(f[i]), nn.ReLU(inplace=True),
+                nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True)))
+        self.final_out = nn.Conv2d(2 * f[3], out_channels, 3, padding=1)
+        self.sync_bn = False
+
+    @staticmethod
+    def _fuse(a, c):
+        """(hi, lo) NHWC stage output + (hi, lo) NHWC skip -> zero-padded concat and the crop window of the first part."""
+        B, h, w, Cx = a[0].shape
+        H, Wd = c[0].shape[1:3]
+        dy, dx = H - h, Wd - w
+        if dy < 0 or dx < 0:
+            raise ValueError(f"DecoderSETRF: the skip ({H}x{Wd}) must not be smaller than the decoder map ({h}x{w})")
+        top, left = dy // 2, dx // 2
+        pad = (0, 0, left, dx - left, top, dy - top)
+        cat = lambda u, v: torch.cat([F.pad(u, pad), v], dim=3).contiguous()
+        hi = cat(a[0], c[0])
+        lo = cat(a[1], c[1]) if a[1] is not None and c[1] is not None else None
+        return (hi, lo), (top, left, h, w, Cx)
+
+    @staticmethod
+    def _unfuse(d, win):
+        top, left, h, w, Cx = win
+        return d[:, top:top + h, left:left + w, :Cx].contiguous(), d[..., Cx:]
+
+    def _forward_core(self, x, skips, save: bool, training: Optional[bool] = None):
+        training = self.training if training is None else training
+        c1, c2, c3 = skips
+        saved, wins = [], {}
+        a = x
+        for i in range(1, 5):
+            if i == 3:
+                a, wins[3] = self._fuse(a, c3)
+            elif i == 4:
+                a, wins[4] = self._fuse(a, c2)
+            seq = getattr(self, f"decoder_{i}")
+            a, st = conv_bn_relu_up_forward(self, f"d{i}", a[0], a[1], seq[0], seq[1], 2, self.sync_bn, save, training)
+            saved.append(st)
+        a, wins[5] = self._fuse(a, c1)
+        logits = self._final_forward(a)
+        saved.append(a[0] if save else None)
+        saved.append(wins)
+        return logits, saved
+
+    def _backward_core(self, saved, d16, inv_scale, grads, dlogits_f32, d_lo, need_x: bool = False):
+        """-> (loss_scale * dL/dx or None, [loss_scale * dL/dc1, dc2, dc3]) as fp32 NHWC."""
+        wins = saved[5]
+        dU = self._final_backward(saved[4], d16, d_lo, None, inv_scale, grads, dlogits_f32)
+        dU, dc1 = self._unfuse(dU, wins[5])
+        dcs = {1: dc1}
+        for i in range(4, 0, -1):
+            seq = getattr(self, f"decoder_{i}")
+            dU = conv_bn_relu_up_backward(self, f"d{i}", saved[i - 1], dU, seq[0], seq[1], inv_scale, grads,
+                                          f"decoder_{i}", need_dx=(i > 1 or need_x), sync_bn=self.sync_bn)
+            if i == 4:
+                dU, dcs[2] = self._unfuse(dU, wins[4])
+            elif i == 3:
+                dU, dcs[3] = self._unfuse(dU, wins[3])
+        return dU, [dcs[1], dcs[2], dcs[3]]
+
+    def forward(self, x, c1, c2, c3):
+        """`decoders.py:238-257`: x (B, in_channels, h, w) and the pyramid c1 (finest) .. c3 -> logits, fp32 NCHW."""
+        if self.training and torch.is_grad_enabled() and (any(p.requires_grad for p in self.parameters())
+                                                          or any(t.requires_grad for t in (x, c1, c2, c3))):
+            return _SETRFFn.apply(self, x, c1, c2, c3, *list(self.parameters()))
+        logits, _ = self._forward_core(self._to_nhwc16(x), [self._to_nhwc16(c) for c in (c1, c2, c3)], save=False)
+        return logits.permute(0, 3, 1, 2)
 
 
 class _MLAFn(torch.autograd.Function):

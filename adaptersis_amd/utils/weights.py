@@ -218,6 +218,18 @@ def make_setr_state_dict(in_channels=1024, out_channels=2, features=(512, 256, 1
     return sd
 
 
+def make_setrf_state_dict(in_channels=1024, out_channels=2, features=(512, 256, 128, 64), seed=0):
+    """`backbones/decoders.py:205-236` (DecoderSETRF: SETR stages whose 3rd / 4th / final convs take the skip concat)."""
+    sd = OrderedDict()
+    f = list(features)
+    cin = [in_channels, f[0], 2 * f[1], 2 * f[2]]
+    for i in range(4):
+        _conv(sd, f"decoder_{i + 1}.0", f[i], cin[i], 3, seed, True)
+        _bn(sd, f"decoder_{i + 1}.1", f[i], seed)
+    _conv(sd, "final_out", out_channels, 2 * f[3], 3, seed, True)
+    return sd
+
+
 def make_decoder_mla_state_dict(mla_channels=1024, mlahead_channels=128, num_classes=2, seed=0):
     """`backbones/decoders.py:7-80`."""
     sd = OrderedDict()

@@ -312,6 +312,30 @@ def feature_decoder(x, sd: SD, p: str = "", update_bn: bool = False, training: b
     return F.conv2d(x, sd[pre + "final_out.weight"], sd[pre + "final_out.bias"], padding=1)
 
 
+def decoder_setrf(x, c1, c2, c3, sd: SD, p: str = "", update_bn: bool = False):
+    """`backbones/decoders.py:205-257` DecoderSETRF: the SETR stages with the CNN pyramid fused in — after stage 2 the
+    map is zero-padded (centred, `:240-243`) to c3's size and concatenated with it, likewise c2 after stage 3 and c1
+    after stage 4, then the final conv3x3."""
+    pre = p + "." if p else ""
+
+    def stage(x, i):
+        q = f"{pre}decoder_{i}"
+        x = F.conv2d(x, sd[q + ".0.weight"], sd[q + ".0.bias"], padding=1)
+        x = F.relu(batch_norm_train(x, sd, q + ".1", update=update_bn))
+        return F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
+
+    def fuse(x, c):
+        dy, dx = c.shape[2] - x.shape[2], c.shape[3] - x.shape[3]
+        x = F.pad(x, [dx // 2, dx - dx // 2, dy // 2, dy - dy // 2])
+        return torch.cat([x, c], dim=1)
+
+    x = stage(stage(x, 1), 2)
+    x = stage(fuse(x, c3), 3)
+    x = stage(fuse(x, c2), 4)
+    x = fuse(x, c1)
+    return F.conv2d(x, sd[pre + "final_out.weight"], sd[pre + "final_out.bias"], padding=1)
+
+
 def decoder_mla(i0, i1, i2, i3, sd: SD, img_size: int = 588, p: str = "", update_bn: bool = False):
     """`backbones/decoders.py:7-89`."""
     pre = p + "." if p else ""

@@ -63,7 +63,7 @@ def import_reference():
     from dinov2.models import vision_transformer as vits
     from backbones.encoders import FeatureEncoder
     from backbones.adapter_blocks import CAViT, CACNN, deform_inputs
-    from backbones.decoders import FeatureDecoder, DecoderMLA, DecoderSETR
+    from backbones.decoders import FeatureDecoder, DecoderMLA, DecoderSETR, DecoderSETRF
     from backbones.unet_parts import UNet
     from backbones.ops.modules.ms_deform_attn import ms_deform_attn_core_pytorch
     from segloss.dice import DC
@@ -74,7 +74,7 @@ def import_reference():
     import numpy as _np
     _im.np = _np  # work-around: the reference module uses np.mean without importing numpy (iou_multi.py:1-2,65,88)
     return dict(vits=vits, FeatureEncoder=FeatureEncoder, CAViT=CAViT, CACNN=CACNN, deform_inputs=deform_inputs,
-                FeatureDecoder=FeatureDecoder, DecoderMLA=DecoderMLA, DecoderSETR=DecoderSETR, UNet=UNet,
+                FeatureDecoder=FeatureDecoder, DecoderMLA=DecoderMLA, DecoderSETR=DecoderSETR, DecoderSETRF=DecoderSETRF, UNet=UNet,
                 msda_core=ms_deform_attn_core_pytorch, DC=DC, SoftDiceLoss=SoftDiceLoss,
                 DC_and_CE_loss=DC_and_CE_loss, CrossentropyND=CrossentropyND, iou_loss=iou_loss,
                 TverskyLoss=TverskyLoss, ch_iou=ch_iou, isi_iou=isi_iou)
@@ -353,6 +353,45 @@ def setr_case(R, out):
         out[f"setr.grad.{k}"] = p.grad.clone()
 
 
+SETRF_SHAPES = dict(B=2, Cin=16, hw=6, feats=[32, 16, 16, 8], c3=(16, 26), c2=(16, 52), c1=(8, 105), HW=120)
+
+
+def setrf_case(R, out):
+    """`backbones/decoders.py:205-257` DecoderSETRF forward + CE/DC step gradients (parameters and the three skips); the
+    skip sizes exercise the centred zero-padding with even, zero and odd differences."""
+    import torch.nn.functional as F
+    S = SETRF_SHAPES
+    B, Cin, hw, feats, HW = S["B"], S["Cin"], S["hw"], S["feats"], S["HW"]
+    sd = W.make_setrf_state_dict(Cin, 3, feats)
+    m = R["DecoderSETRF"](Cin, 3, features=feats)
+    m.load_state_dict(sd, strict=True)
+    m.train()
+    x = W.tensor("setrf.x", (B, Cin, hw, hw), 1.0)
+    cs = [W.tensor(f"setrf.{n}", (B, S[n][0], S[n][1], S[n][1]), 1.0).requires_grad_() for n in ("c1", "c2", "c3")]
+    tg = W.synthetic_batch(B, HW, 3)[1]
+    oh = O.one_hot(tg, 3)
+    y = m(x, *cs)
+    o = F.interpolate(y, size=(HW, HW), mode="bilinear")
+    loss = torch.nn.CrossEntropyLoss()(o, tg) + R["DC"](3)(o, oh)
+    loss.backward()
+    osd = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sd.items()}
+    ocs = [c.detach().clone().requires_grad_() for c in cs]
+    oy = O.decoder_setrf(x, *ocs, osd, update_bn=True)
+    oo = F.interpolate(oy, size=(HW, HW), mode="bilinear")
+    oloss = O.cross_entropy_nd(oo, tg) + O.dc_loss(oo, oh)
+    oloss.backward()
+    close(oy.detach(), y.detach(), 2e-5, "DecoderSETRF logits")
+    close(oloss.detach(), loss.detach(), 1e-5, "DecoderSETRF loss")
+    out["setrf.logits"] = sub(y)
+    out["setrf.loss"] = loss.detach().clone()
+    for k, p in m.named_parameters():
+        close(osd[k].grad, p.grad, 1e-3, f"grad {k}")
+        out[f"setrf.grad.{k}"] = p.grad.clone()
+    for n, c, oc in zip(("c1", "c2", "c3"), cs, ocs):
+        close(oc.grad, c.grad, 1e-3, f"grad {n}")
+        out[f"setrf.grad.{n}"] = sub(c.grad)
+
+
 def loss2_case(R, out):
     """Every loss the scripts can select, at a resized geometry (logits 20x20 -> target 28x28, as the decoders'
     outputs are resized to the label size), with gradients wrt the low-resolution logits; plus ch_iou / isi_iou."""
@@ -576,6 +615,10 @@ def main():
         out = {}
         print("[ViT-L-width (4 blocks) forward_features + backward of every parameter, 588 B=1]"); vit_backward_case(R, out)
         save("vitbwd", out)
+    if want("setrf"):
+        out = {}
+        print("[DecoderSETRF step]"); setrf_case(R, out)
+        save("setrf", out)
     if want("setr"):
         out = {}
         print("[DecoderSETR step]"); setr_case(R, out)

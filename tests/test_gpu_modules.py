@@ -120,6 +120,35 @@ def test_dc_module_matches_oracle(dev):
     assert abs(float(out2) - float(g["loss.dc"])) < 2e-6
 
 
+def test_decoder_setrf_vs_reference_golden(dev):
+    """DecoderSETRF (`decoders.py:205-257`) forward + CE/DC backward against the golden of the imported reference:
+    logits, loss, parameter gradients and the gradients that flow back into the three skips."""
+    from adaptersis_amd.backbones.decoders import DecoderSETRF
+    from adaptersis_amd.segloss.dice import seg_loss
+    from adaptersis_amd import ops
+    g = load_golden("setrf")
+    B, Cin, hw, feats, HW = 2, 16, 6, [32, 16, 16, 8], 120
+    shapes = dict(c1=(8, 105), c2=(16, 52), c3=(16, 26))
+    m = DecoderSETRF(Cin, 3, features=feats).to(dev)
+    m.load_state_dict(W.make_setrf_state_dict(Cin, 3, feats), strict=True)
+    m.train()
+    x = W.tensor("setrf.x", (B, Cin, hw, hw), 1.0).to(dev)
+    cs = [W.tensor(f"setrf.{n}", (B, shapes[n][0], shapes[n][1], shapes[n][1]), 1.0).to(dev).requires_grad_()
+          for n in ("c1", "c2", "c3")]
+    tg = W.synthetic_batch(B, HW, 3)[1].to(dev)
+    y = m(x, *cs)
+    assert golden_err(y, g["setrf.logits"]) < 1e-3
+    loss = seg_loss(y, tg, 1, ops.LOSS_DICE, 10e-20, n_ce=1)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g["setrf.loss"])) < 1e-4
+    errs = {k: rel_l2(p.grad, g[f"setrf.grad.{k}"]) for k, p in m.named_parameters()
+            if float(g[f"setrf.grad.{k}"].norm()) > 1e-6}
+    serr = {n: golden_err(c.grad, g[f"setrf.grad.{n}"]) for n, c in zip(("c1", "c2", "c3"), cs)}
+    print("SETRF grads:", {k: f"{v:.1e}" for k, v in errs.items()}, {k: f"{v:.1e}" for k, v in serr.items()})
+    assert max(errs.values()) < 3e-2, errs  # ReLU-flip floor on small maps, see tests/test_gpu_unet.py
+    assert max(serr.values()) < 3e-2, serr
+
+
 def test_decoder_setr_vs_reference_golden(dev):
     """DecoderSETR (`decoders.py:167-203`) forward + CE/DC backward against the golden of the imported reference."""
     from adaptersis_amd.backbones.decoders import DecoderSETR

@@ -266,6 +266,31 @@ def test_decoder_setr_step():
             assert rel_l2(v.grad, g[f"setr.grad.{k}"]) < 1e-3, k
 
 
+def test_decoder_setrf_step():
+    """`decoders.py:205-257` DecoderSETRF restatement == the imported reference (tests/golden/setrf.pt): logits, loss and
+    the gradients of every parameter and of the three skips (centred zero-padding with even / zero / odd differences)."""
+    g = load_golden("setrf")
+    B, Cin, hw, feats, HW = 2, 16, 6, [32, 16, 16, 8], 120
+    shapes = dict(c1=(8, 105), c2=(16, 52), c3=(16, 26))
+    sd = W.make_setrf_state_dict(Cin, 3, feats)
+    x = W.tensor("setrf.x", (B, Cin, hw, hw), 1.0)
+    cs = [W.tensor(f"setrf.{n}", (B, shapes[n][0], shapes[n][1], shapes[n][1]), 1.0).requires_grad_() for n in ("c1", "c2", "c3")]
+    tg = W.synthetic_batch(B, HW, 3)[1]
+    oh = O.one_hot(tg, 3)
+    osd = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sd.items()}
+    oy = O.decoder_setrf(x, *cs, osd)
+    oo = F.interpolate(oy, size=(HW, HW), mode="bilinear")
+    loss = O.cross_entropy_nd(oo, tg) + O.dc_loss(oo, oh)
+    loss.backward()
+    assert golden_err(oy, g["setrf.logits"]) < 1e-5
+    assert abs(float(loss) - float(g["setrf.loss"])) < 1e-6
+    for k, v in osd.items():
+        if v.requires_grad:
+            assert rel_l2(v.grad, g[f"setrf.grad.{k}"]) < 1e-3, k
+    for n, c in zip(("c1", "c2", "c3"), cs):
+        assert golden_err(c.grad, g[f"setrf.grad.{n}"]) < 1e-3, n
+
+
 @pytest.mark.skipif(not __import__("os").environ.get("ASIS_SLOW"), reason="slow CPU case: set ASIS_SLOW=1")
 def test_vit_backward_golden():
     """Oracle autograd of forward_features at ViT-L width == the imported reference's (tests/golden/vitbwd.pt)."""
