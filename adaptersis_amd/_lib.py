@@ -34,6 +34,7 @@ class GemmDesc(C.Structure):
         ("stats", C.c_void_p),
         ("A_lo", C.c_void_p), ("B_lo", C.c_void_p),
         ("aux", C.c_void_p), ("ld_aux", C.c_int64),
+        ("ksplit", C.c_int32),
     ]
 
 

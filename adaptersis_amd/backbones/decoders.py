@@ -17,6 +17,7 @@ The same functional core serves two front-ends:
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -41,6 +42,23 @@ def _conv_weights(owner: _Packed, key: str, conv: nn.Conv2d, split: bool):
     return w_hi, w_lo
 
 
+_KSPLIT = os.environ.get("ASIS_CONV_KSPLIT", "1") != "0"
+
+
+def _conv_ksplit(P: int, Cout: int, Cin: int, split: bool) -> int:
+    """3 = run the three kernel rows of a 3x3 conv as side-by-side K parts.  The large-tile kernel keeps 512 tiles of
+    256 x 128 resident; a layer with 332 tiles (decoder_1: 21 168 pixels x 512 channels) occupies 65 % of the slots for
+    one full tile time, one with 662 runs a second, 30 %-full round.  Cut in three, the same work is 996 / 1 986 tiles of
+    a third of the length: 2 / 4 third-rounds instead of 3 / 6.  Only taken when the round count drops by >= 15 %."""
+    if not _KSPLIT or Cin % 64 or P < 256 or Cout < 32 or Cout % 4:
+        return 1
+    tiles = ((P + 255) // 256) * ((Cout + 127) // 128 if Cout > 64 else (Cout + 63) // 64)
+    slots = 512
+    now = -(-tiles // slots)
+    cut = -(-3 * tiles // slots) / 3.0 + 0.05
+    return 3 if cut < 0.85 * now else 1
+
+
 def conv_bn_relu_up_forward(owner: _Packed, key: str, x16, x_lo, conv: nn.Conv2d, bn: nn.BatchNorm2d, factor: int,
                             sync_bn: bool, save: bool, training: bool = True, stride: int = 1, pad: int = 1,
                             pool: bool = False):
@@ -52,13 +70,16 @@ def conv_bn_relu_up_forward(owner: _Packed, key: str, x16, x_lo, conv: nn.Conv2d
     B, H, W, _ = x16.shape
     OH, OW = (H + 2 * pad - 3) // stride + 1, (W + 2 * pad - 3) // stride + 1
     w_hi, w_lo = _conv_weights(owner, key, conv, split)
-    stats = torch.empty((ops.gemm_tiles_m(B * OH * OW), 2, conv.out_channels), device=x16.device,
-                        dtype=torch.float32) if training else None
     bias = owner._f32(key + ".b", conv.bias)
+    ks = _conv_ksplit(B * OH * OW, conv.out_channels, x16.shape[3], split)
+    stats = torch.empty((ops.gemm_tiles_m(B * OH * OW), 2, conv.out_channels), device=x16.device,
+                        dtype=torch.float32) if (training and ks == 1) else None
     if split:
-        raw = ops.conv_gemm_split(x16, x_lo, w_hi, w_lo, 3, 3, stride, pad, bias_n=bias, stats=stats)
+        raw = ops.conv_gemm_split(x16, x_lo, w_hi, w_lo, 3, 3, stride, pad, bias_n=bias, stats=stats, ksplit=ks)
     else:
-        raw = ops.conv_gemm(x16, w_hi, 3, 3, stride, pad, bias_n=bias, stats=stats)
+        raw = ops.conv_gemm(x16, w_hi, 3, 3, stride, pad, bias_n=bias, stats=stats, ksplit=ks)
+    if training and ks > 1:
+        stats = ops.colstats(raw)
     if training:
         scale, shift, mean, invstd, count = _bn.finalize(stats, B * OH * OW, bn, sync_bn)
     else:

@@ -221,11 +221,13 @@ int launch(hipStream_t s, const asis_gemm_desc& d) {
                     (reinterpret_cast<uintptr_t>(d.C) & 15) == 0 && !d.bias_m;
     if (!ok) return ASIS_EINVAL;
   }
+  if (d.ksplit > 1 && !(big_mode && d.conv)) return ASIS_EINVAL;
   if (split) {  // one pass over the virtual 3K reduction; only on the large-tile kernel
     const bool ok = big_mode && d.K % BK == 0 && d.M >= 256 && d.N >= 32 && vec_ok && d.out_f32 && (!d.conv || d.Cin % BK == 0);
     if (!ok) return ASIS_EINVAL;
     const int bm = 256, bn = d.N > 64 ? 128 : 64;
-    dim3 grid(((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn), d.batch), block(512);
+    if (d.ksplit > 1 && (d.batch != 1 || d.stats || d.K % (d.ksplit * BK) != 0 || !d.out_f32 || d.res)) return ASIS_EINVAL;
+    dim3 grid(((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn), d.ksplit > 1 ? d.ksplit : d.batch), block(512);
     static const int conv32 = [] { const char* e = getenv("ASIS_CONV_BK32"); return e ? atoi(e) : 0; }();
     if (d.conv) {
       if (conv32 && bn == 128) hipLaunchKernelGGL((gemm_big_kernel<T, 4, 2, 2, 2, 3, 0, true, true, 32, 4>), grid, block, 0, s, d, group_m);
@@ -265,11 +267,13 @@ int launch(hipStream_t s, const asis_gemm_desc& d) {
   // come from the vectorised epilogue
   if (big_mode && d.conv && d.Cin % BK == 0 && d.M >= 256 && d.N >= 32 && vec_ok && d.out_f32) {
     const int bm = 256, bn = d.N > 64 ? 128 : 64;
-    dim3 grid(((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn), 1), block(512);
+    if (d.ksplit > 1 && (d.stats || d.K % (d.ksplit * BK) != 0 || d.res)) return ASIS_EINVAL;
+    dim3 grid(((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn), d.ksplit > 1 ? d.ksplit : 1), block(512);
     if (bn == 128) hipLaunchKernelGGL((gemm_big_kernel<T, 4, 2, 2, 2, 3, 0, true>), grid, block, 0, s, d, group_m);
     else hipLaunchKernelGGL((gemm_big_kernel<T, 8, 1, 1, 2, 3, 0, true>), grid, block, 0, s, d, group_m);
     return 0;
   }
+  if (d.ksplit > 1) return ASIS_EINVAL;  // K parts exist on the large-tile conv forms only
   const int tiles_m = (d.M + BM - 1) / BM, tiles_n = (d.N + BN - 1) / BN;
   dim3 grid(tiles_m * tiles_n, d.batch), block(NTHREADS);
   if (d.conv)
@@ -316,7 +320,7 @@ extern "C" int asis_gemm(void* stream, const asis_gemm_desc* dp) {
   ASIS_REQUIRE((d.A_lo == nullptr) == (d.B_lo == nullptr), "asis_gemm: A_lo and B_lo must be given together");
   if (d.A_lo) ASIS_REQUIRE(asis_aligned16(d.A_lo) && asis_aligned16(d.B_lo), "asis_gemm: split halves must be 16-byte aligned");
   const int rc = (d.dtype == ASIS_F16) ? launch<f16>(s, d) : launch<bf16>(s, d);
-  if (rc != 0) ASIS_FAIL(ASIS_EINVAL, "asis_gemm: split-precision operands / ASIS_ACT_GELU_GRAD need the large-tile path (K %% 64 "
+  if (rc != 0) ASIS_FAIL(ASIS_EINVAL, "asis_gemm: split-precision operands / ASIS_ACT_GELU_GRAD / ksplit need the large-tile path (K %% 64 "
                                         "== 0 (GELU_GRAD: 32), M >= 256, N >= 32 (128), N and ldc multiples of 4, fp32 output for "
                                         "split; conv: Cin %% 64 == 0)");
   ASIS_CHECK_LAUNCH("asis_gemm");

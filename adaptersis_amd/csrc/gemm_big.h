@@ -99,7 +99,10 @@ __global__ __launch_bounds__(512, OCC) void gemm_big_kernel(const asis_gemm_desc
   // layout of the hi ones, so a part only changes the base pointers by a constant element offset.
   const int64_t a_lo_off = SPLIT ? (reinterpret_cast<const T*>(d.A_lo) - reinterpret_cast<const T*>(d.A)) : 0;
   const int64_t b_lo_off = SPLIT ? (reinterpret_cast<const T*>(d.B_lo) - reinterpret_cast<const T*>(d.B)) : 0;
-  const int nt1 = d.K / BKB;
+  // ksplit > 1: blockIdx.y is a K part, not a batch entry (the host passes zero A/B batch strides)
+  const int ksp = (!PH8 && d.ksplit > 1) ? d.ksplit : 1;
+  const int nt1 = d.K / ksp / BKB;
+  const int kt_base = ksp > 1 ? bz * nt1 : 0;
   typedef __attribute__((address_space(3))) void* lds_ptr;
   typedef const __attribute__((address_space(1))) void* glb_ptr;
   auto issue = [&](int t) {
@@ -112,7 +115,7 @@ __global__ __launch_bounds__(512, OCC) void gemm_big_kernel(const asis_gemm_desc
       aoff = part == 1 ? a_lo_off : 0;
       boff = part == 2 ? b_lo_off : 0;
     }
-    const int k0 = kt * BKB;
+    const int k0 = (kt + kt_base) * BKB;
     if (CONV) {
       const int tap = k0 / d.Cin, ci0 = k0 - tap * d.Cin;
       const int kh = tap / d.KW, kw = tap - kh * d.KW;
@@ -310,7 +313,7 @@ __global__ __launch_bounds__(512, OCC) void gemm_big_kernel(const asis_gemm_desc
     const int col = n0 + wn * TN * 32 + ch * 4;
     const bool cok = col < d.N;
     float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f), s4 = make_float4(1.f, 1.f, 1.f, 1.f);
-    if (cok && d.bias_n) b4 = *reinterpret_cast<const float4*>(d.bias_n + col);
+    if (cok && d.bias_n && kt_base == 0) b4 = *reinterpret_cast<const float4*>(d.bias_n + col);  // K parts: part 0 only
     if (cok && d.scale_n) s4 = *reinterpret_cast<const float4*>(d.scale_n + col);
     float4 st_s = make_float4(0.f, 0.f, 0.f, 0.f), st_q = st_s;  // BatchNorm partial sums of this lane's columns
     // Residual / per-row bias / GELU'(pre-activation) operands of a whole 32-row slab are fetched up front, from

@@ -131,9 +131,12 @@ def gemm_tiles_m(M: int) -> int:
 def conv_gemm(x_nhwc: torch.Tensor, w_packed: torch.Tensor, KH: int, KW: int, stride: int, pad: int, *,
               out: Optional[torch.Tensor] = None, out_f32: bool = True, bias_n: Optional[torch.Tensor] = None,
               act: int = ACT_NONE, stats: Optional[torch.Tensor] = None, accumulate: bool = False,
-              x_lo: Optional[torch.Tensor] = None, w_lo: Optional[torch.Tensor] = None) -> torch.Tensor:
+              x_lo: Optional[torch.Tensor] = None, w_lo: Optional[torch.Tensor] = None, ksplit: int = 1) -> torch.Tensor:
     """Implicit-GEMM convolution: x [B,H,W,Cin] (16-bit NHWC), w_packed [Cout, KH*KW*Cin] ->
-    out [B,OH,OW,Cout] (fp32 by default: BatchNorm statistics are taken on it)."""
+    out [B,OH,OW,Cout] (fp32 by default: BatchNorm statistics are taken on it).
+    ``ksplit`` > 1: the reduction runs as that many side-by-side parts (fp32 partial maps summed in a fixed order, then the
+    caller takes the
+    BatchNorm statistics from the sum with ``colstats``) — for layers whose tile count fills only part of the machine."""
     _dev(x_nhwc, w_packed, out, bias_n, stats)
     if not x_nhwc.is_contiguous():
         raise ValueError("conv_gemm: x must be contiguous NHWC")
@@ -141,10 +144,18 @@ def conv_gemm(x_nhwc: torch.Tensor, w_packed: torch.Tensor, KH: int, KW: int, st
     Cout, K = w_packed.shape
     OH = (H + 2 * pad - KH) // stride + 1
     OW = (W + 2 * pad - KW) // stride + 1
+    if ksplit > 1:
+        if out is not None or accumulate or not out_f32 or act != ACT_NONE or stats is not None:
+            raise ValueError("conv_gemm: ksplit needs a fresh fp32 output without activation; take the BatchNorm "
+                             "statistics from the sum with colstats()")
+        parts = torch.empty((ksplit, Bn, OH, OW, Cout), device=x_nhwc.device, dtype=torch.float32)
+        out = parts
     if out is None:
         out = torch.empty((Bn, OH, OW, Cout), device=x_nhwc.device, dtype=torch.float32 if out_f32 else x_nhwc.dtype)
     d = GemmDesc()
     d.A, d.B, d.C = x_nhwc.data_ptr(), w_packed.data_ptr(), out.data_ptr()
+    if ksplit > 1:
+        d.ksplit, d.strideC = ksplit, Bn * OH * OW * Cout
     d.lda, d.ldb, d.ldc = K, w_packed.stride(0), Cout
     d.batch, d.M, d.N, d.K = 1, Bn * OH * OW, Cout, K
     d.bias_n = _p(_f32c(bias_n))
@@ -160,13 +171,17 @@ def conv_gemm(x_nhwc: torch.Tensor, w_packed: torch.Tensor, KH: int, KW: int, st
     if x_lo is not None:
         d.A_lo, d.B_lo = x_lo.data_ptr(), w_lo.data_ptr()
     check(_launch_timed("conv", flops, lambda: lib().asis_gemm(_stream(), C.byref(d))), "asis_gemm(conv)")
+    if ksplit > 1:
+        out = torch.empty((Bn, OH, OW, Cout), device=x_nhwc.device, dtype=torch.float32)
+        reduce_rows(parts.view(ksplit, -1), 1.0, out.view(-1))
     return out
 
 
 _FUSED_SPLIT = os.environ.get("ASIS_GEMM_BIG", "1") != "0" and os.environ.get("ASIS_SPLIT_FUSED", "1") != "0"
 
 
-def conv_gemm_split(x_hi, x_lo, w_hi, w_lo, KH: int, KW: int, stride: int, pad: int, *, bias_n=None, stats=None):
+def conv_gemm_split(x_hi, x_lo, w_hi, w_lo, KH: int, KW: int, stride: int, pad: int, *, bias_n=None, stats=None,
+                    ksplit: int = 1):
     """Split-precision convolution: x ~= x_hi + x_lo, w ~= w_hi + w_lo (16-bit halves), fp32 out =
     x_hi*w_hi + x_lo*w_hi + x_hi*w_lo (+ bias), accumulated in fp32 (the dropped x_lo*w_lo term is ~2^-22
     relative): one launch over a virtual 3K reduction on the large-tile kernel, else three accumulate passes."""
@@ -174,7 +189,7 @@ def conv_gemm_split(x_hi, x_lo, w_hi, w_lo, KH: int, KW: int, stride: int, pad: 
     OH, OW = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
     Cout = w_hi.shape[0]
     if Cin % 64 == 0 and Bn * OH * OW >= 256 and Cout >= 32 and Cout % 4 == 0 and _FUSED_SPLIT:
-        return conv_gemm(x_hi, w_hi, KH, KW, stride, pad, bias_n=bias_n, stats=stats, x_lo=x_lo, w_lo=w_lo)
+        return conv_gemm(x_hi, w_hi, KH, KW, stride, pad, bias_n=bias_n, stats=stats, x_lo=x_lo, w_lo=w_lo, ksplit=ksplit)
     out = conv_gemm(x_hi, w_hi, KH, KW, stride, pad, bias_n=bias_n)
     conv_gemm(x_lo, w_hi, KH, KW, stride, pad, out=out, accumulate=True)
     conv_gemm(x_hi, w_lo, KH, KW, stride, pad, out=out, accumulate=True, stats=stats)

@@ -203,6 +203,33 @@ def test_conv_wgrad_and_dgrad(dev, dt, Cin, Cout, H, k, pad):
     assert rel_l2(dx, xr.grad.permute(0, 2, 3, 1)) < 5e-6
 
 
+@pytest.mark.parametrize("split", [False, True])
+def test_conv_ksplit_matches_single_pass(dev, split):
+    """3x3 conv run as three side-by-side K parts (`ksplit=3`: one kernel row each, partial maps summed in a fixed order)
+    == the one-pass launch and the fp32 convolution; the bias is added exactly once."""
+    Bn, Cin, Cout, H = 2, 64, 160, 23
+    x = W.tensor("ks.x", (Bn, Cin, H, H), 1.0)
+    w = W.tensor("ks.w", (Cout, Cin, 3, 3), 0.1)
+    bias = W.tensor("ks.b", (Cout,), 0.5)
+    ref = F.conv2d(x, w, bias, padding=1).permute(0, 2, 3, 1)
+    xn = x.permute(0, 2, 3, 1).contiguous().view(-1, Cin).to(dev)
+    dt = torch.float16
+    x_hi = ops.cast_pad(xn, Cin, dt).view(Bn, H, H, Cin)
+    w_hi = ops.pack_conv_weight(w.to(dev), 0, dt)
+    if split:
+        x_lo = ops.cast_pad(xn, Cin, dt, part=1).view(Bn, H, H, Cin)
+        w_lo = ops.pack_conv_weight(w.to(dev), 0, dt, 1)
+        one = ops.conv_gemm_split(x_hi, x_lo, w_hi, w_lo, 3, 3, 1, 1, bias_n=bias.to(dev))
+        three = ops.conv_gemm_split(x_hi, x_lo, w_hi, w_lo, 3, 3, 1, 1, bias_n=bias.to(dev), ksplit=3)
+        assert rel_l2(three, ref) < 2e-6
+    else:
+        one = ops.conv_gemm(x_hi, w_hi, 3, 3, 1, 1, bias_n=bias.to(dev))
+        three = ops.conv_gemm(x_hi, w_hi, 3, 3, 1, 1, bias_n=bias.to(dev), ksplit=3)
+        assert rel_l2(three, ref) < 1e-3
+    assert three.shape == one.shape
+    assert rel_l2(three, one) < 1e-6
+
+
 def test_sgd_momentum_matches_torch(dev):
     n = 1000
     p0, g1, g2 = W.tensor("sg.p", (n,), 1.0), W.tensor("sg.g1", (n,), 1.0), W.tensor("sg.g2", (n,), 1.0)
