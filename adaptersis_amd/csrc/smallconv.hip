@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void smallcout_fwd_kernel(const T* __restrict_
   const int64_t total = (int64_t)B * H * W * cpp;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   // every lane of a wave runs the same number of iterations (total and stride are multiples of 64)
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+  for (int64_t i = (int64_t)xcd_remap(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x; i < total; i += stride) {
     const int c8 = (int)(i & (cpp - 1)) * 8;
     const int64_t p = i / cpp;
     const int x = (int)(p % W);
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void smallcout_dgrad_kernel(const T* __restric
   __syncthreads();
   const int cpp = Cin >> 3;
   const int64_t total = (int64_t)B * H * W * cpp;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+  for (int64_t i = (int64_t)xcd_remap(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int c8 = (int)(i % cpp) * 8;
     const int64_t p = i / cpp;
     const int x = (int)(p % W);
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void smallcout_wgrad_kernel(const T* __restric
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[t][e][0] = acc[t][e][1] = 0.f;
   const int c8 = (threadIdx.x & (cpp - 1)) * 8;  // the chunk is the same in every iteration (stride % cpp == 0)
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+  for (int64_t i = (int64_t)xcd_remap(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x; i < total; i += stride) {
     const int64_t p = i / cpp;
     const int xq = (int)(p % W);
     const int yq = (int)((p / W) % H);
