@@ -226,7 +226,7 @@ int launch(hipStream_t s, const asis_gemm_desc& d) {
     const bool ok = big_mode && d.K % BK == 0 && d.M >= 256 && d.N >= 32 && vec_ok && d.out_f32 && (!d.conv || d.Cin % BK == 0);
     if (!ok) return ASIS_EINVAL;
     const int bm = 256, bn = d.N > 64 ? 128 : 64;
-    if (d.ksplit > 1 && (d.batch != 1 || d.stats || d.K % (d.ksplit * BK) != 0 || !d.out_f32 || d.res)) return ASIS_EINVAL;
+    if (d.ksplit > 1 && (d.batch != 1 || d.stats || (d.KH * d.KW) % d.ksplit != 0 || !d.out_f32 || d.res)) return ASIS_EINVAL;
     dim3 grid(((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn), d.ksplit > 1 ? d.ksplit : d.batch), block(512);
     static const int conv32 = [] { const char* e = getenv("ASIS_CONV_BK32"); return e ? atoi(e) : 0; }();
     if (d.conv) {
@@ -267,7 +267,7 @@ int launch(hipStream_t s, const asis_gemm_desc& d) {
   // come from the vectorised epilogue
   if (big_mode && d.conv && d.Cin % BK == 0 && d.M >= 256 && d.N >= 32 && vec_ok && d.out_f32) {
     const int bm = 256, bn = d.N > 64 ? 128 : 64;
-    if (d.ksplit > 1 && (d.stats || d.K % (d.ksplit * BK) != 0 || d.res)) return ASIS_EINVAL;
+    if (d.ksplit > 1 && (d.stats || (d.KH * d.KW) % d.ksplit != 0 || d.res)) return ASIS_EINVAL;
     dim3 grid(((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn), d.ksplit > 1 ? d.ksplit : 1), block(512);
     if (bn == 128) hipLaunchKernelGGL((gemm_big_kernel<T, 4, 2, 2, 2, 3, 0, true>), grid, block, 0, s, d, group_m);
     else hipLaunchKernelGGL((gemm_big_kernel<T, 8, 1, 1, 2, 3, 0, true>), grid, block, 0, s, d, group_m);

@@ -103,19 +103,39 @@ __global__ __launch_bounds__(512, OCC) void gemm_big_kernel(const asis_gemm_desc
   const int ksp = (!PH8 && d.ksplit > 1) ? d.ksplit : 1;
   const int nt1 = d.K / ksp / BKB;
   const int kt_base = ksp > 1 ? bz * nt1 : 0;
+  const int ntap_part = CONV ? (d.KH * d.KW) / ksp : 1;  // conv K parts are whole taps (kernel rows for a 3x3 in three)
+  const int tap_base = (CONV && ksp > 1) ? bz * ntap_part : 0;
   typedef __attribute__((address_space(3))) void* lds_ptr;
   typedef const __attribute__((address_space(1))) void* glb_ptr;
   auto issue = [&](int t) {
     T* st = lds + (t % NS) * STAGE;
     int kt = t;
     int64_t aoff = 0, boff = 0;
-    if (SPLIT) {
-      const int part = t / nt1;
-      kt = t - part * nt1;
-      aoff = part == 1 ? a_lo_off : 0;
-      boff = part == 2 ? b_lo_off : 0;
+    int k0;
+    if (CONV) {
+      // Reduction order of a convolution: channel chunk outermost, then the taps, then (SPLIT) the three hi/lo parts.
+      // A chunk of 64 channels of the ~2.3 image rows a 256-pixel tile touches is ~75 KB; all 9 taps and all parts of it
+      // are consumed back to back, so they hit in L1 / L2.  Tap-major order (the layout order of the packed weights)
+      // came back to the same pixels only after a whole sweep over Cin, by which time the 64 tiles resident on an XCD
+      // had pushed them out of its 4 MB L2: 3.2x the tensor bytes in L2 fills (profiles/r01_pmc_traffic.json).
+      int tt = t, part = 0;
+      if (SPLIT) {
+        tt = t / 3;
+        part = t - 3 * tt;
+        aoff = part == 1 ? a_lo_off : 0;
+        boff = part == 2 ? b_lo_off : 0;
+      }
+      const int c = tt / ntap_part, tl = tt - c * ntap_part;
+      k0 = (tap_base + tl) * d.Cin + c * BKB;
+    } else {
+      if (SPLIT) {
+        const int part = t / nt1;
+        kt = t - part * nt1;
+        aoff = part == 1 ? a_lo_off : 0;
+        boff = part == 2 ? b_lo_off : 0;
+      }
+      k0 = (kt + kt_base) * BKB;
     }
-    const int k0 = (kt + kt_base) * BKB;
     if (CONV) {
       const int tap = k0 / d.Cin, ci0 = k0 - tap * d.Cin;
       const int kh = tap / d.KW, kw = tap - kh * d.KW;
