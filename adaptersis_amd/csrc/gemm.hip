@@ -259,6 +259,9 @@ int launch(hipStream_t s, const asis_gemm_desc& d) {
     dim3 grid(((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn), d.batch), block(512);
     if (big_mode == 2 && bn == 256) hipLaunchKernelGGL((gemm_big_kernel<T, 2, 4, 4, 2, 2>), grid, block, 0, s, d, group_m);
     else if (big_mode >= 2 || d.K % 64 != 0 && false) hipLaunchKernelGGL((gemm_big_kernel<T, 4, 2, 2, 2, 3>), grid, block, 0, s, d, group_m);
+    else if (noepi == 8) hipLaunchKernelGGL((gemm_big_kernel<T, 4, 2, 2, 2, 3, 8, false, false, 32, 4>), grid, block, 0, s, d, group_m);
+    else if (noepi == 32) hipLaunchKernelGGL((gemm_big_kernel<T, 4, 2, 2, 2, 3, 32, false, false, 32, 4>), grid, block, 0, s, d, group_m);
+    else if (noepi == 40) hipLaunchKernelGGL((gemm_big_kernel<T, 4, 2, 2, 2, 3, 40, false, false, 32, 4>), grid, block, 0, s, d, group_m);
     else if (noepi) hipLaunchKernelGGL((gemm_big_kernel<T, 4, 2, 2, 2, 3, 4, false, false, 32, 4>), grid, block, 0, s, d, group_m);
     else hipLaunchKernelGGL((gemm_big_kernel<T, 4, 2, 2, 2, 3, 0, false, false, 32, 4>), grid, block, 0, s, d, group_m);
     return 0;

@@ -343,8 +343,8 @@ __global__ __launch_bounds__(512, OCC) void gemm_big_kernel(const asis_gemm_desc
     const float* const zp = reinterpret_cast<const float*>(g_zero_page);
     const bool has_aux = d.act == ASIS_ACT_GELU_GRAD;
     const int colc = cok ? col : 0;
-    const float* const resp = res ? res + colc : zp;
-    const int64_t ldr_e = res ? d.ldr : 0;
+    const float* const resp = (res && !(DBG & 32)) ? res + colc : zp;  // DBG & 32 (lab): no residual fetch
+    const int64_t ldr_e = (res && !(DBG & 32)) ? d.ldr : 0;
     const float* const bmp = d.bias_m ? d.bias_m : zp;
     const int bm_e = d.bias_m ? 1 : 0;
 #pragma unroll
@@ -397,7 +397,8 @@ __global__ __launch_bounds__(512, OCC) void gemm_big_kernel(const asis_gemm_desc
             else if (d.act == ASIS_ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
             v.x *= s4.x; v.y *= s4.y; v.z *= s4.z; v.w *= s4.w;
             v.x += r4[q].x; v.y += r4[q].y; v.z += r4[q].z; v.w += r4[q].w;
-            if (d.out_f32) {
+            if ((DBG & 8) && v.x != 123.456f) {  // lab: everything but the global stores
+            } else if (d.out_f32) {
               *reinterpret_cast<float4*>(reinterpret_cast<float*>(d.C) + cbase + (int64_t)row * d.ldc + col) = v;
             } else {
               uint2 pk;

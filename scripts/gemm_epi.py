@@ -39,10 +39,15 @@ if __name__ == "__main__":
         run()
     else:
         res = {}
-        for tag, env in (("full", {}), ("mainloop", {"ASIS_GEMM_NOEPI": "1"})):
+        variants = (("full", {}), ("mainloop", {"ASIS_GEMM_NOEPI": "1"}), ("nostore", {"ASIS_GEMM_NOEPI": "8"}),
+                    ("nores", {"ASIS_GEMM_NOEPI": "32"}), ("nostore_nores", {"ASIS_GEMM_NOEPI": "40"}))
+        for tag, env in variants:
             r = subprocess.run([sys.executable, __file__, "child"], env={**os.environ, **env}, capture_output=True, text=True)
             res[tag] = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
         for name, M, N, K, _ in SHAPES:
             a, b = res["full"][name], res["mainloop"][name]
+            if name != "fc2+ls+res":  # the lab variants exist for the default (K < 2048) form only
+                print(f"{name:12s}   lab (us): no global stores {res['nostore'][name]:.1f}, no residual fetch {res['nores'][name]:.1f}, "
+                      f"neither {res['nostore_nores'][name]:.1f}")
             print(f"{name:12s} M={M} N={N} K={K}: full {a:7.1f} us ({2.0 * M * N * K / a / 1e6:6.0f} TFLOP/s)  main loop {b:7.1f} us "
                   f"({2.0 * M * N * K / b / 1e6:6.0f})  epilogue share {100 * (a - b) / a:4.1f} %")
