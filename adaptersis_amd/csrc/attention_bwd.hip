@@ -106,8 +106,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const T* __restrict
   __shared__ __attribute__((aligned(16))) T lds[2 * 3 * TT * HD];  // [buf][K | V | K^T][64][64] = 48 KiB
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int fr = lane & 31, fh = lane >> 5;
-  const int head = blockIdx.y, b = blockIdx.z;
-  const int q_base = blockIdx.x * 128 + wid * 32;
+  // XCD-aware order (see attention.hip): the tiles of one (image, head) share K / V / K^T and stay on one XCD's L2
+  const int ntl = gridDim.x;
+  const int lin = xcd_remap(blockIdx.x + ntl * (blockIdx.y + gridDim.y * blockIdx.z), ntl * gridDim.y * gridDim.z);
+  const int head = (lin / ntl) % gridDim.y, b = lin / (ntl * gridDim.y);
+  const int q_base = (lin % ntl) * 128 + wid * 32;
   const int qi = q_base + fr;
   const bool qok = qi < N;
 
@@ -250,8 +253,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const T* __restric
   __shared__ __attribute__((aligned(16))) float stat[2][2][TT];     // [buf][lse2 | D][64]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int fr = lane & 31, fh = lane >> 5;
-  const int head = blockIdx.y, b = blockIdx.z;
-  const int key_base = blockIdx.x * 128 + wid * 32;
+  const int ntl = gridDim.x;  // XCD-aware order: the key tiles of one (image, head) share Q / dO and their transposes
+  const int lin = xcd_remap(blockIdx.x + ntl * (blockIdx.y + gridDim.y * blockIdx.z), ntl * gridDim.y * gridDim.z);
+  const int head = (lin / ntl) % gridDim.y, b = lin / (ntl * gridDim.y);
+  const int key_base = (lin % ntl) * 128 + wid * 32;
   const int ki = key_base + fr;
   const bool kok = ki < N;
 
