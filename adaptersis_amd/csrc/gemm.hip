@@ -257,6 +257,10 @@ int launch(hipStream_t s, const asis_gemm_desc& d) {
     // on the fc1 shape (scripts/gemm_lab.hip).  big_mode 2/3 keep the older forms selectable for A/B runs.
     const int bm = 256, bn = (big_mode == 2 && d.N >= 2048) ? 256 : 128;
     dim3 grid(((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn), d.batch), block(512);
+    if (big_mode == 4 && !noepi) {  // lab: four waves of 128x64 (0.75 KB of LDS reads per MFMA instead of 1), two workgroups per CU
+      hipLaunchKernelGGL((gemm_big_kernel<T, 2, 2, 4, 2, 3, 0, false, false, 32, 2>), grid, dim3(256), 0, s, d, group_m);
+      return 0;
+    }
     if (big_mode == 2 && bn == 256) hipLaunchKernelGGL((gemm_big_kernel<T, 2, 4, 4, 2, 2>), grid, block, 0, s, d, group_m);
     else if (big_mode >= 2 || d.K % 64 != 0 && false) hipLaunchKernelGGL((gemm_big_kernel<T, 4, 2, 2, 2, 3>), grid, block, 0, s, d, group_m);
     else if (noepi == 8) hipLaunchKernelGGL((gemm_big_kernel<T, 4, 2, 2, 2, 3, 8, false, false, 32, 4>), grid, block, 0, s, d, group_m);

@@ -18,7 +18,7 @@ __device__ __attribute__((aligned(16))) uint4 g_zero_page[1];
 
 template <typename T, int WM, int WN, int TM, int TN, int NS, int DBG = 0, bool CONV = false, bool SPLIT = false, int BKT = 64,
           int OCC = 2, bool PH8 = false>
-__global__ __launch_bounds__(512, OCC) void gemm_big_kernel(const asis_gemm_desc d, const int GROUP_M) {
+__global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_big_kernel(const asis_gemm_desc d, const int GROUP_M) {
   static_assert(!PH8 || (WM == 2 && WN == 4 && TM == 4 && TN == 2 && NS == 2 && BKT == 64 && !CONV && !SPLIT),
                 "the 8-phase main loop is written for the 256x256x64 tile, 2x4 waves of 128x64");
   typedef typename T16<T>::v8 v8;
@@ -28,7 +28,8 @@ __global__ __launch_bounds__(512, OCC) void gemm_big_kernel(const asis_gemm_desc
   constexpr int RPI = 64 / CPR;                      // rows covered by one 1-KB LDS-DMA wave-instruction
   constexpr int SWS = (CPR == 8) ? 1 : 2;            // swizzle: chunk ^= (row >> SWS) & (CPR-1)  (conflict-free b128 reads)
   constexpr int STAGE = (BM2 + BN2) * BKB;           // elements per stage
-  constexpr int GA = BM2 / RPI / 8, GB = BN2 / RPI / 8;  // LDS-DMA wave-instructions per wave and K tile
+  constexpr int NWV = WM * WN;                       // waves per workgroup (8, or 4 with 128x64 wave tiles)
+  constexpr int GA = BM2 / RPI / NWV, GB = BN2 / RPI / NWV;  // LDS-DMA wave-instructions per wave and K tile
   constexpr int G = GA + GB;
   __shared__ __attribute__((aligned(16))) T lds[NS * STAGE];
 
