@@ -99,10 +99,11 @@ typedef struct asis_gemm_desc {
    * (M >= 256, N >= 128, K % 32 == 0, N % 4 == 0); otherwise ASIS_EINVAL and the caller runs asis_gelu16 separately */
   const void* aux;
   int64_t ld_aux;
-  int32_t ksplit;                    /* > 1 (large-tile conv/dense kernel, batch == 1): the reduction is cut into `ksplit`
-                                        equal parts run side by side (gridDim.y); part p writes its fp32 partial result
-                                        at C + p * strideC, part 0 adds bias_n; `stats` must be null.  Sum the parts with
-                                        asis_reduce_rows.  For GEMMs whose tile count fills only part of the machine. */
+  int32_t ksplit;                    /* > 1 (conv = 1 on the large-tile kernel, batch == 1, KH*KW divisible by it): the taps
+                                        are cut into `ksplit` groups run side by side (gridDim.y); group p writes its fp32
+                                        partial map at C + p * strideC, group 0 adds bias_n; `stats` and `res` must be null.
+                                        Sum the parts with asis_reduce_rows, take BatchNorm statistics with asis_colstats.
+                                        For layers whose tile count fills only part of the machine (EINVAL elsewhere). */
 } asis_gemm_desc;
 int asis_gemm(void* stream, const asis_gemm_desc* d);
 /* number of M tiles asis_gemm uses for M rows (size of the stats buffer = tiles*2*N floats) */
