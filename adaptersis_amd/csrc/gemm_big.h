@@ -415,7 +415,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_big_kernel(const asis_
     }
     if (d.stats) {
       // lanes ch + LPR*rr hold the same columns: fold rr with xor-shuffles, then the WM row blocks through LDS.
-      // stats rows are per 128 rows (asis_gemm_tiles_m): this 256-row tile writes row 2*tile_m and zeroes 2*tile_m+1.
+      // stats rows are per 128 rows (asis_gemm_tiles_m): a tile writes its first row and zeroes the others it covers.
       for (int o = LPR; o < 64; o <<= 1) {
         st_s.x += __shfl_xor(st_s.x, o, 64); st_s.y += __shfl_xor(st_s.y, o, 64);
         st_s.z += __shfl_xor(st_s.z, o, 64); st_s.w += __shfl_xor(st_s.w, o, 64);
@@ -437,13 +437,16 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_big_kernel(const asis_
           q += red[(w2 * 2 + 1) * BN2 + tid];
         }
         const int c = n0 + tid;
-        const int64_t r0 = (int64_t)tile_m * 2;
+        constexpr int RB = BM2 / 128;  // stats rows (of 128 output rows each) this tile covers: the first takes the sums
+        const int64_t r0 = (int64_t)tile_m * RB;
         d.stats[(r0 * 2 + 0) * d.N + c] = s;
         d.stats[(r0 * 2 + 1) * d.N + c] = q;
-        if ((r0 + 1) * 128 < d.M) {
-          d.stats[((r0 + 1) * 2 + 0) * d.N + c] = 0.f;
-          d.stats[((r0 + 1) * 2 + 1) * d.N + c] = 0.f;
-        }
+#pragma unroll
+        for (int e = 1; e < RB; ++e)
+          if ((r0 + e) * 128 < d.M) {
+            d.stats[((r0 + e) * 2 + 0) * d.N + c] = 0.f;
+            d.stats[((r0 + e) * 2 + 1) * d.N + c] = 0.f;
+          }
       }
     }
     return;
