@@ -46,17 +46,27 @@ _KSPLIT = os.environ.get("ASIS_CONV_KSPLIT", "1") != "0"
 
 
 def _conv_ksplit(P: int, Cout: int, Cin: int, split: bool) -> int:
-    """3 = run the three kernel rows of a 3x3 conv as side-by-side K parts.  The large-tile kernel keeps 512 tiles of
-    256 x 128 resident; a layer with 332 tiles (decoder_1: 21 168 pixels x 512 channels) occupies 65 % of the slots for
-    one full tile time, one with 662 runs a second, 30 %-full round.  Cut in three, the same work is 996 / 1 986 tiles of
-    a third of the length: 2 / 4 third-rounds instead of 3 / 6.  Only taken when the round count drops by >= 15 %."""
+    """3 = run the three kernel rows of a 3x3 conv as side-by-side K parts (`asis_gemm_desc.ksplit`).  Cost model per CU
+    (256 of them, at most two resident 256 x 128 tiles each): a CU that gets c tiles needs about
+    1.7 * (c // 2) + (c % 2) single-tile times (two co-resident tiles take ~1.7x one), and the launch lasts as long as its
+    busiest CU.  decoder_1 (332 tiles: some CUs hold two) goes from 1.7 to 3.4 / 3 = 1.13 (measured 3.07 -> 2.13 ms),
+    decoder_2 (662) from 2.7 to 2.27; a layer with 252 tiles already has one tile on every CU and would only pay for the
+    partial maps (measured: slower), one with 120 leaves half the CUs idle and gains.  Taken when the model promises >= 12 %
+    after an 8 % allowance for summing the parts and taking the BatchNorm statistics in a separate pass."""
     if not _KSPLIT or Cin % 64 or P < 256 or Cout < 32 or Cout % 4:
         return 1
     tiles = ((P + 255) // 256) * ((Cout + 127) // 128 if Cout > 64 else (Cout + 63) // 64)
-    slots = 512
-    now = -(-tiles // slots)
-    cut = -(-3 * tiles // slots) / 3.0 + 0.05
-    return 3 if cut < 0.85 * now else 1
+    cus = 256
+
+    def cost(t):
+        c = -(-t // cus)
+        return 1.7 * (c // 2) + (c % 2)
+
+    now, cut = cost(tiles), cost(3 * tiles) / 3.0 * 1.08
+    r = 3 if cut < 0.88 * now else 1
+    if r == 3 and os.environ.get("ASIS_CONV_KSPLIT_DEBUG"):
+        print(f"[ksplit] P={P} Cout={Cout} Cin={Cin} tiles={tiles} now={now:.2f} cut={cut:.2f}", flush=True)
+    return r
 
 
 def conv_bn_relu_up_forward(owner: _Packed, key: str, x16, x_lo, conv: nn.Conv2d, bn: nn.BatchNorm2d, factor: int,
