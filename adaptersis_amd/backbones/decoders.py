@@ -129,15 +129,19 @@ def conv_bn_relu_up_backward(owner: _Packed, key: str, st: _Stage, dU, conv: nn.
     else:
         g, partial = ops.upsample_bn_relu_bwd(dU, st.raw, st.scale, st.shift, st.mean, st.invstd, st.factor)
     red = ops.reduce_rows(partial.view(partial.shape[0], 2 * C))  # [2C]: sum g | sum g*xhat (scaled)
+    local = red
     if sync_bn and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(red)  # SyncBatchNorm backward: 2C floats
+        # SyncBatchNorm backward: the 2C global sums feed dx only; gamma / beta gradients stay LOCAL sums (the bucket
+        # all-reduce averages them over ranks like every other parameter gradient — torch's SyncBatchNorm does the same)
+        local = red.clone()
+        dist.all_reduce(red)
     dbeta_s, dgamma_s = red[:C], red[C:]
     split = config.split_conv and need_dx
     r = ops.bn_bwd_apply(g, st.raw, st.mean, st.invstd, owner._f32(key + ".g", bn.weight), dgamma_s, dbeta_s,
                          st.count, dt, split)
     dx16, dx_lo, bpart = r if split else (r[0], None, r[1])
-    ops.reduce_rows(dbeta_s.view(1, C), inv_scale, grads[bn_name + ".bias"])      # unscale (n = 1 row)
-    ops.reduce_rows(dgamma_s.view(1, C), inv_scale, grads[bn_name + ".weight"])
+    ops.reduce_rows(local[:C].view(1, C), inv_scale, grads[bn_name + ".bias"])      # unscale (n = 1 row)
+    ops.reduce_rows(local[C:].view(1, C), inv_scale, grads[bn_name + ".weight"])
     if conv.bias is not None:
         ops.reduce_rows(bpart, inv_scale, grads[conv_name + ".bias"])
     ops.wgrad(dx16, st.x16, C, 3, 3, stride, pad, inv_scale, out=grads[conv_name + ".weight"])

@@ -200,11 +200,13 @@ class FeatureEncoder(_Packed):
         C0 = raw0.shape[-1]
         g, partial = ops.upsample_bn_relu_bwd(d0, raw0, scale, shift, mean, invstd, 1)
         red = ops.reduce_rows(partial.view(partial.shape[0], 2 * C0))
+        local = red
         if sync_bn and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            local = red.clone()  # gamma / beta gradients are local sums (averaged with the bucket), dx uses the global ones
             dist.all_reduce(red)
         dx16, _ = ops.bn_bwd_apply(g, raw0, mean, invstd, self._f32("stem1.g", self.stem[1].weight), red[C0:], red[:C0], count, dt)
-        ops.reduce_rows(red[:C0].view(1, C0), inv_scale, grads[pre + "stem.1.bias"])
-        ops.reduce_rows(red[C0:].view(1, C0), inv_scale, grads[pre + "stem.1.weight"])
+        ops.reduce_rows(local[:C0].view(1, C0), inv_scale, grads[pre + "stem.1.bias"])
+        ops.reduce_rows(local[C0:].view(1, C0), inv_scale, grads[pre + "stem.1.weight"])
         gw = ops.wgrad(dx16, x8, C0, 3, 3, 2, 1, inv_scale)                 # [C0, 8, 3, 3]
         grads[pre + "stem.0.weight"].copy_(gw[:, :3])
 

@@ -56,8 +56,20 @@ def _compile(src: str, verbose: bool) -> str:
 
 
 def build_library(force: bool = False, verbose: bool = False) -> str:
+    """Idempotent and safe to call from several ranks at once: an exclusive file lock serialises the builders (the first
+    one compiles, the others find everything up to date)."""
+    import fcntl
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
+    with open(os.path.join(OBJ, ".lock"), "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        try:
+            return _build_locked(force, verbose)
+        finally:
+            fcntl.flock(lk, fcntl.LOCK_UN)
+
+
+def _build_locked(force: bool, verbose: bool) -> str:
     dep_t = _deps_mtime()
     todo, objs = [], []
     for src in sources():

@@ -82,8 +82,21 @@ class SGD:
                 "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
 
     def load_state_dict(self, sd):
+        # validate first (a `torch.optim.SGD` entry of a reference checkpoint holds per-parameter buffers): nothing is
+        # modified when the entry does not fit, and `restart_from_checkpoint` reports + skips it
+        state = sd.get("state", {})
+        bufs = []
         for i, b in enumerate(self.buckets):
-            b.momentum.copy_(sd["state"][i]["momentum_buffer"])
+            ent = state.get(i, state.get(str(i)))
+            mb = ent.get("momentum_buffer") if isinstance(ent, dict) else None
+            if not torch.is_tensor(mb) or mb.numel() != b.numel:
+                raise ValueError(f"optimizer state does not match flat bucket {i} ({b.numel} elements): not written by "
+                                 "adaptersis_amd.optim.SGD with the same trainable set")
+            bufs.append(mb)
+        if len(sd.get("param_groups", [])) != len(self.param_groups):
+            raise ValueError("optimizer state has a different number of parameter groups")
+        for b, mb in zip(self.buckets, bufs):
+            b.momentum.copy_(mb.reshape(-1))
         self._steps = int(sd.get("steps", 1))
         for g, s in zip(self.param_groups, sd["param_groups"]):
             g.update(s)

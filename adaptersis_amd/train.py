@@ -53,6 +53,26 @@ class _SegData(torch.utils.data.Dataset):
         return self.img[i], self.msk[i], i
 
 
+def broadcast_module_states(modules, src: int = 0, group=None) -> None:
+    """What ``DistributedDataParallel.__init__`` does for the reference (`train.py:84-116`): every parameter and buffer of
+    the trainable / SyncBN modules takes rank ``src``'s value.  One flat fp32 message per module (plus one for integer
+    buffers), no-op without an initialised process group."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    with torch.no_grad():
+        for m in modules:
+            ts = [t for t in list(m.parameters()) + list(m.buffers())]
+            for dtype in sorted({t.dtype for t in ts}, key=str):
+                part = [t for t in ts if t.dtype == dtype]
+                flat = torch.cat([t.detach().reshape(-1) for t in part])
+                dist.broadcast(flat, src, group=group)
+                o = 0
+                for t in part:
+                    t.copy_(flat[o:o + t.numel()].view(t.shape))
+                    o += t.numel()
+
+
 def _engine_for(model, backbone_encoder, cross_vit, cross_cnn, seg_decoder, lr=0.01, momentum=0.99, weight_decay=3e-5,
                 mode="reference_exact", train_encoder=False):
     key = id(seg_decoder)
@@ -88,10 +108,15 @@ def train_seg(args, head: str = "feature"):
     cross_cnn = CACNN(dim=D, n_levels=1, num_heads=8, n_points=4, with_cffn=True, cffn_ratio=0.25).to(dev)
     if head == "mla":
         seg_decoder = DecoderMLA(img_size=args.imsize, mla_channels=D, num_classes=2).to(dev)
+    else:
+        seg_decoder = FeatureDecoder(embed_dim=D, num_classes=2, features=[D, 512, 256, 128, 64]).to(dev)
+    # the reference wraps these four modules in DistributedDataParallel (`train.py:84-116`), whose constructor broadcasts
+    # rank 0's parameters and buffers: without it every rank would train its own randomly initialised copy
+    broadcast_module_states([backbone_encoder, cross_vit, cross_cnn, seg_decoder])
+    if head == "mla":
         lr = args.lr * (args.batch_size_per_gpu * utils.get_world_size()) / 16.0  # linear scaling rule
         engine = _engine_for(model, backbone_encoder, cross_vit, cross_cnn, seg_decoder, lr=lr, momentum=0.9, weight_decay=0.0)
     else:
-        seg_decoder = FeatureDecoder(embed_dim=D, num_classes=2, features=[D, 512, 256, 128, 64]).to(dev)
         engine = _engine_for(model, backbone_encoder, cross_vit, cross_cnn, seg_decoder, lr=args.lr,
                              mode="train_adapters" if getattr(args, "train_adapters", False) else "reference_exact",
                              train_encoder=getattr(args, "train_encoder", False))
@@ -126,8 +151,15 @@ def train_seg(args, head: str = "feature"):
 
     scheduler = _Cosine(optimizer, args.epochs)
     to_restore = {"epoch": 0, "best_acc": 0.0}
+    # reference keys (`train.py:244-255`) + the adapters / encoder when they train (without them a resume
+    # would put the restored momentum on freshly re-randomised weights)
+    extra = {}
+    if engine.mode == "train_adapters":
+        extra = {"cross_vit": cross_vit, "cross_cnn": cross_cnn}
+        if engine.train_encoder:
+            extra["backbone_encoder"] = backbone_encoder
     utils.restart_from_checkpoint(os.path.join(args.output_dir, "checkpoint.pth.tar"), run_variables=to_restore,
-                                  state_dict=seg_decoder, optimizer=optimizer, scheduler=scheduler)
+                                  state_dict=seg_decoder, **extra, optimizer=optimizer, scheduler=scheduler)
     start_epoch, best_acc = to_restore["epoch"], to_restore["best_acc"]
     if args.evaluate:
         stats = validate_network(val_loader, model, feature_model, backbone_encoder, cross_vit, cross_cnn, seg_decoder,
@@ -152,10 +184,12 @@ def train_seg(args, head: str = "feature"):
             Path(args.output_dir).mkdir(parents=True, exist_ok=True)
             with (Path(args.output_dir) / "log.txt").open("a") as f:
                 f.write(json.dumps(log_stats) + "\n")
-            torch.save({"epoch": epoch + 1,
-                        "state_dict": {"module." + k: v for k, v in seg_decoder.state_dict().items()},  # DDP prefix kept
-                        "optimizer": optimizer.state_dict(), "scheduler": scheduler.state_dict(), "best_acc": best_acc},
-                       os.path.join(args.output_dir, "checkpoint.pth.tar"))
+            ckpt = {"epoch": epoch + 1,
+                    "state_dict": {"module." + k: v for k, v in seg_decoder.state_dict().items()},  # DDP prefix kept
+                    "optimizer": optimizer.state_dict(), "scheduler": scheduler.state_dict(), "best_acc": best_acc}
+            for k, mod in extra.items():
+                ckpt[k] = {"module." + n: v for n, v in mod.state_dict().items()}
+            torch.save(ckpt, os.path.join(args.output_dir, "checkpoint.pth.tar"))
     print("Training of the supervised linear classifier on frozen features completed.\n"
           "Top-1 test accuracy: {acc:.1f}".format(acc=best_acc))
     return log_stats

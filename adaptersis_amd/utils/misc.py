@@ -161,7 +161,7 @@ def restart_from_checkpoint(ckp_path, run_variables=None, **kwargs):
                 else:
                     msg = value.load_state_dict(sd)
                 print(f"=> loaded '{key}' from checkpoint '{ckp_path}' with msg {msg}")
-            except (TypeError, ValueError, KeyError) as e:
+            except (TypeError, ValueError, KeyError, RuntimeError) as e:
                 print(f"=> failed to load '{key}' from checkpoint: '{ckp_path}' ({e})")
         else:
             print(f"=> key '{key}' not found in checkpoint: '{ckp_path}'")

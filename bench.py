@@ -120,57 +120,59 @@ def synthetic(batch: int, size: int, rank: int, dev, num_classes: int = 2):
     return img.to(dev), tgt.to(dev)
 
 
-def cpu_baseline(arch: str, size: int):
-    """Reference CPU path (the fp32 eager oracle restatement, parity-pinned to the imported reference) timed on
-    this box's host cores on a bounded sample of the same step at batch 1, extrapolated to one image."""
+def cpu_baseline(arch: str, size: int, batch: int = 1):
+    """Reference CPU path (the fp32 eager oracle restatement, parity-pinned to the imported reference) on this box's
+    host cores: ONE WHOLE `train.py:268-436` step at batch ``batch`` is timed end to end (encoder, ViT pass A + pass B,
+    4 adapter stages, decoder forward, loss, decoder backward, SGD) — no extrapolation; ``sample`` also lists the
+    per-part times of a short probe (one block per pass, one adapter stage) for orientation."""
     from adaptersis_amd.utils import weights as W
     from oracle import ref_torch as O  # cpu_baseline leg only
 
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = min(cores, int(os.environ.get("ASIS_CPU_THREADS", 16)))  # a 1-GPU box owns a 16-core share of the host
+    if os.environ.get("ASIS_CPU_THREADS"):
+        cores = min(cores, int(os.environ["ASIS_CPU_THREADS"]))
     torch.set_num_threads(cores)
     D, depth, heads, _ = W.VIT_CONFIGS[arch]
     vsd = W.make_vit_state_dict(arch, layerscale="kernel")
     esd, csd, nsd = W.make_encoder_state_dict(D), W.make_cavit_state_dict(D), W.make_cacnn_state_dict(D)
     dsd = W.make_feature_decoder_state_dict(D, 2, features=(D, 512, 256, 128, 64))
-    img, tgt = W.synthetic_batch(1, size)
+    img, tgt = W.synthetic_batch(batch, size)
     N = (size // 14) ** 2
 
-    def t(fn, reps=1):
-        fn()
+    def t(fn):
         t0 = time.perf_counter()
-        for _ in range(reps):
-            out = fn()
-        return (time.perf_counter() - t0) / reps, out
+        out = fn()
+        return time.perf_counter() - t0, out
 
-    with torch.no_grad():
+    with torch.no_grad():  # warm the thread pool / allocator on one block (not part of the timed step)
         xa = W.tensor("cb.xa", (1, N + 1, D), 1.0)
-        xb = xa[:, 1:].contiguous()
+        O.block(xa, vsd, "blocks.0", heads)
         t_a, _ = t(lambda: O.block(xa, vsd, "blocks.0", heads))
-        t_b, _ = t(lambda: O.block(xb, vsd, "blocks.1", heads))
-        t_enc, (c1, c2, c3, c4, shapes) = t(lambda: O.feature_encoder(img, esd))
-        c = torch.cat([c2, c3, c4], 1)
-        d1, d2 = O.deform_inputs(size, size, 14, shapes)
-
-        def stage():
-            x1 = O.cavit(xb, d1[0], c, d1[1], csd)
-            return O.cacnn(c, d2[0], x1, d2[1], shapes, nsd)
-        t_ad, _ = t(stage)
-        cat = O.assemble_decoder_input(xb, c4, xb, (size // 14, size // 14), shapes[2])
     params = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in dsd.items()}
+    mom = {}
 
-    def dec_step():
-        for p in params.values():
-            p.grad = None
-        O.train_step_loss(cat, tgt, params, 2).backward()
-    t_dec, _ = t(dec_step)
-    nb = depth
-    per_img = nb * t_a + (nb - 3) * t_b + 3 * t_b + 4 * t_ad + t_enc + t_dec
+    def step():
+        with torch.no_grad():
+            cat = O.adapter_forward(img, vsd, esd, csd, nsd, heads)
+        t_fwd = time.perf_counter()
+        for p_ in params.values():
+            p_.grad = None
+        loss = O.train_step_loss(cat, tgt, params, 2)
+        loss.backward()
+        with torch.no_grad():   # torch.optim.SGD(momentum 0.99, wd 3e-5), train.py:178-191
+            tr = {k: p_ for k, p_ in params.items() if p_.grad is not None}
+            O.sgd_momentum_step(tr, {k: p_.grad for k, p_ in tr.items()}, mom, 0.01)
+        return t_fwd, float(loss)
+
+    t0 = time.perf_counter()
+    t_fwd, loss = step()
+    t_step = time.perf_counter() - t0
     return {
-        "value": round(1.0 / per_img, 5), "unit": "img/s", "cores": cores, "kind": "port",
-        "sample": (f"batch 1: one {arch} block at N={N + 1} ({t_a:.2f}s) and at N={N} ({t_b:.2f}s), one CAViT+CACNN "
-                   f"stage ({t_ad:.2f}s), encoder ({t_enc:.2f}s), decoder fwd+loss+bwd ({t_dec:.2f}s); step time = "
-                   f"{nb}*A + {nb}*B + 4*adapter + encoder + decoder = {per_img:.1f}s/img (fp32 eager torch {torch.__version__})"),
+        "value": round(batch / t_step, 5), "unit": "img/s", "cores": cores, "kind": "port",
+        "sample": (f"one whole train.py step timed end to end at batch {batch}, {arch} {size}x{size}: {t_step:.1f}s "
+                   f"(features {t_fwd - t0:.1f}s, decoder fwd+loss+bwd+SGD {t_step - (t_fwd - t0):.1f}s; one block at "
+                   f"N={N + 1} alone: {t_a:.2f}s; loss {loss:.4f}); fp32 eager torch {torch.__version__}, "
+                   f"{cores} threads = all cores this process may use"),
     }
 
 
@@ -189,6 +191,24 @@ def pmc_traffic(kernel: str, variant: str):
     return None
 
 
+def launch_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without torchrun: run N ranks as children of this (GPU-free) process through
+    ``python -m torch.distributed.run`` on 127.0.0.1, pass their stdout / stderr through (rank 0 prints the JSON line)
+    and return the launcher's exit code (non-zero when any rank failed)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this pool (RCCL needs it)
+    env.pop("RANK", None)
+    env.pop("LOCAL_RANK", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -205,11 +225,24 @@ def main():
     ap.add_argument("--train-encoder", action="store_true", help="with --train-adapters: also the CNN encoder (the full optimiser list of train.py:178-186)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--cpu-baseline-batch", type=int, default=1, help="batch of the timed CPU (oracle) step: 1 or 2")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N`: start the N ranks ourselves, BEFORE this process makes any GPU call (a process that
+        # has initialised HIP must never exec / fork GPU children); the parent only relays output and the exit code
+        return launch_ranks(a.gpus)
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(python bench.py --gpus N starts them itself)")
+
+    # the in-tree library is built (normally a no-op) BEFORE the first GPU call of this process: no compiler children
+    # under an initialised HIP runtime / a preloaded profiler.  File-locked: one rank builds, the others wait.
+    from adaptersis_amd.build import build_library
+    build_library()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (HIP device); there is no CPU fallback")
     torch.cuda.set_device(local)
@@ -223,12 +256,6 @@ def main():
     torch.set_num_threads(max(1, min(16, cores // max(1, world))))
 
     from adaptersis_amd import config, ops
-    from adaptersis_amd.build import build_library
-    # one builder per node (normally a no-op: the prebuilt in-tree .so is up to date); the other ranks wait for it
-    if local == 0:
-        build_library()
-    if world > 1:
-        dist.barrier()
     if a.operand:
         config.set_operand_dtype(torch.float16 if a.operand == "f16" else torch.bfloat16)
         config.loss_scale = 65536.0 if a.operand == "f16" else 1.0
@@ -249,20 +276,27 @@ def main():
     for _ in range(a.warmup):
         eng.train_step(img, tgt)
     barrier()
-    prof = None if a.no_kernel_timing else []
-    ops.PROFILE = prof
+    # ---- the timed region: exactly `steps` steps, no instrumentation (no per-launch events) ----------------
+    ops.PROFILE = None
     t0 = time.perf_counter()
     loss = None
     for _ in range(a.steps):
         loss = eng.train_step(img, tgt)
     barrier()
     elapsed = time.perf_counter() - t0
-    ops.PROFILE = None
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el)
     loss_v = float(loss)
+    # ---- second pass of the same steps with a HIP event pair around every GEMM launch: the roofline figures ----
+    prof = None if a.no_kernel_timing else []
+    if prof is not None:
+        ops.PROFILE = prof
+        for _ in range(a.steps):
+            eng.train_step(img, tgt)
+        barrier()
+        ops.PROFILE = None
 
     # ---- roofline of the dominant kernel: the dense MFMA GEMM (csrc/gemm_big.h) ---------------------------
     roof = None
@@ -294,7 +328,8 @@ def main():
         out = {
             "metric": "training images/sec, ViT-L/14 588^2 adapter fine-tune" if a.config == 3 else
                       f"training images/sec, BASELINE config {a.config}",
-            "value": round(global_batch * a.steps / elapsed, 3), "unit": "img/s", "n_gpus": world, "steps": a.steps,
+            "value": round(global_batch * a.steps / elapsed, 3), "unit": "img/s", "n_gpus": world,
+            "n_ranks_seen": (dist.get_world_size() if world > 1 else 1), "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
             "dtype": "f16" if config.operand_dtype == torch.float16 else "bf16", "data": "synthetic",
@@ -317,11 +352,11 @@ def main():
         if roof:
             out["roofline"] = roof
         if world == 1 and not a.no_cpu_baseline and a.config == 3:
-            out["cpu_baseline"] = cpu_baseline(a.arch, a.size)
+            out["cpu_baseline"] = cpu_baseline(a.arch, a.size, a.cpu_baseline_batch)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)
