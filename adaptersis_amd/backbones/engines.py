@@ -83,10 +83,20 @@ class SegEngine(nn.Module):
     def __init__(self, model, backbone_encoder, cross_vit: CAViT, cross_cnn: CACNN, seg_decoder, *,
                  n_last_blocks: int = 4, num_classes: int = 2, lr: float = 0.01, momentum: float = 0.99,
                  weight_decay: float = 3e-5, mode: str = "reference_exact", process_group=None, loss: str = "dice",
-                 train_encoder: bool = False):
+                 train_encoder: bool = False, train_backbone: bool = False, optimize_backbone: bool = False,
+                 blocks_per_bucket: int = 4):
         """``seg_decoder``: ``FeatureDecoder`` -> the `train.py` flow; ``DecoderMLA`` -> the `train_mla.py` flow
         (block -> CACNN -> CAViT order, the four adapter-stream maps feed the MLA head, `blocks[-2]` is evaluated
-        twice and `blocks[-1]` never: `train_mla.py:318,340`).  ``loss``: a key of ``SegEngine.LOSSES``."""
+        twice and `blocks[-1]` never: `train_mla.py:318,340`).  ``loss``: a key of ``SegEngine.LOSSES``.
+
+        ``train_backbone`` (with mode="train_adapters"; BASELINE config 4): the `train.py` adapter flow with its
+        no_grad / inference_mode regions removed (`train.py:287,300-302,389-406`), i.e. the unfreezing pattern of
+        `eval/eval_dinov2_setr_cross_ete.py:145-148,307-361` applied to this flow: BOTH ViT passes run with saved
+        activations, the backward goes through the head, the four adapter stages, the encoder (``train_encoder``) and
+        every block evaluation of both passes with weight gradients; the 304 M backbone gradients live in a flat
+        gradient bucket all-reduced in ``blocks_per_bucket``-block chunks while earlier blocks are still in their
+        backward.  Like the reference script (its optimizer lists the decoder only, `:224-229`) the backbone gradients are
+        computed and exchanged but not applied unless ``optimize_backbone`` is set."""
         super().__init__()
         if mode not in ("reference_exact", "train_adapters"):
             raise ValueError("mode must be 'reference_exact' or 'train_adapters'")
@@ -139,6 +149,15 @@ class SegEngine(nn.Module):
                 self.encoder_bucket = FlatBucket([("backbone_encoder." + n, p) for n, p in backbone_encoder.named_parameters()])
                 self.encoder_reducer = StageReducer(self.encoder_bucket.grad, [(0, self.encoder_bucket.numel)], process_group)
                 buckets.append(self.encoder_bucket)
+        self.train_backbone = bool(train_backbone)
+        self.vit_bucket = None
+        if train_backbone:
+            if mode != "train_adapters":
+                raise ValueError("train_backbone needs mode='train_adapters' (the unfrozen variant of the adapter flow)")
+            self.vit_bucket, self.vit_reducer, self._fire_at = make_vit_bucket(model, blocks_per_bucket, process_group,
+                                                                               momentum=optimize_backbone)
+            if optimize_backbone:
+                buckets.append(self.vit_bucket)
         self.optimizer = SGD(buckets, lr=lr, momentum=momentum, weight_decay=weight_decay)
         self.reducer = StageReducer(self.bucket.grad, self.stage_ranges, process_group)
         self._geom = {}
@@ -222,7 +241,9 @@ class SegEngine(nn.Module):
             # ENCODER output (`:395`), so unless a caller asks for the taps it is dead code and skipped (same results)
             dead = s == nl - 1 and taps is None
             if train:
-                x2, s_cv = self.cross_vit.forward16_train(xcat[Ra:], c2d, g, B, N, Lc)
+                # CAViT keeps its query for the LayerNorm backward; the stage output below overwrites these rows of the
+                # stacked buffer in place, so the saved copy must be its own tensor
+                x2, s_cv = self.cross_vit.forward16_train(xcat[Ra:].clone(), c2d, g, B, N, Lc)
                 s_cn = None
                 if not dead:
                     c2d, s_cn = self.cross_cnn.forward16_train(c2d, x2, g, B, Lc, N, shapes)
@@ -311,6 +332,9 @@ class SegEngine(nn.Module):
         S = config.loss_scale
         if self.is_mla:
             logits, saved = dec._forward_core(self.features_mla(inp, taps), save=True, training=True)
+        elif self.train_backbone:
+            cat, e2e = self._features_e2e(inp, taps)
+            logits, saved = dec._forward_core(cat[0], cat[1], save=True, training=True)
         else:
             asaves = [] if self.mode == "train_adapters" else None
             cat = self.features(inp, taps, asaves)
@@ -329,6 +353,20 @@ class SegEngine(nn.Module):
             dcat = dec._backward_core(saved, d16, bpart, inv, self.bucket.views, stage_done=self.reducer.stage_done, d_lo=d_lo,
                                       need_input_grad=True)
             self.adapter_reducer.begin()
+            if self.train_backbone:
+                self.vit_reducer.begin()
+                if self.train_encoder:
+                    self.encoder_reducer.begin()
+                self._e2e_backward(e2e, dcat, inv)
+                self.vit_reducer.finish()
+                if self.train_encoder:
+                    self.encoder_reducer.finish()
+                self.adapter_reducer.finish()
+                self.reducer.finish()
+                self.optimizer.step(1.0)
+                if taps is not None:
+                    taps.update(logits=logits, loss=loss)
+                return loss.view(())
             dc0 = self._adapter_backward(asaves, dcat, inv)
             self.adapter_reducer.stage_done()
             if self.train_encoder:
@@ -344,6 +382,137 @@ class SegEngine(nn.Module):
         if taps is not None:
             taps.update(logits=logits, loss=loss)
         return loss.view(())
+
+    # ---- BASELINE config 4: the adapter flow with the backbone unfrozen ------------------------------------------------
+    @torch.no_grad()
+    def _features_e2e(self, inp: torch.Tensor, taps: Optional[dict] = None):
+        """``features`` with everything kept for the backward: both ViT passes stacked along the rows run
+        ``Block.forward_train_rows`` (so each block's weight gradients are later taken over the rows of both passes in
+        one GEMM), the final norm's inputs of the last ``n_last_blocks`` outputs, CAViT / CACNN activations, the encoder's
+        when it trains.  -> ((cat_hi, cat_lo|None), saved)."""
+        m = self.model
+        B, _, H, W = inp.shape
+        inp = inp.float().contiguous()
+        D = m.embed_dim
+        h, w = H // self.patch, W // self.patch
+        N = h * w
+        nb, nl = len(m.blocks), self.n_last_blocks
+        if self.train_encoder:
+            c, shapes, esaved = self.backbone_encoder.forward_tokens_train(inp)
+            self._esaved = (esaved, shapes)
+        else:
+            _, c, shapes = self.backbone_encoder.forward_tokens(inp, need_c1=False)
+        c_orig = c
+        Lc = c.shape[1]
+        g = self._geometry(H, W, shapes, inp.device)
+        tokens, a16 = m.patch_tokens_train(inp)           # shared by both passes: its gradient is the sum of both
+        xa = ops.add_cls_pos(tokens, m.cls_token.detach().reshape(-1).float().contiguous(),
+                             m._pos_for(N, H, W).detach().reshape(-1, D).float().contiguous())
+        Ra, Rb = B * (N + 1), B * N
+        segs = [(B, N + 1), (B, N)]
+        xcat = torch.cat([xa.view(Ra, D), tokens.reshape(Rb, D)], 0)
+        bsaves, feats, fin, asaves = [], [], [], []
+        for i, blk in enumerate(m.blocks[: nb - (nl - 1)]):
+            xcat, sv = blk.forward_train_rows(xcat, segs)
+            bsaves.append(sv)
+            if i >= nb - nl:
+                feats.append(m._final_norm(xcat[:Ra].view(B, N + 1, D))[:, 1:])
+                fin.append(xcat)                           # rows [:Ra] = input of that final norm (never overwritten)
+        if taps is not None:
+            taps.update(c=c, x_b0=xcat[Ra:].view(B, N, D).clone(), shapes=shapes)
+        c2d = c.view(B * Lc, D)
+        for s in range(nl):
+            if s > 0:
+                xcat, sv = m.blocks[nb - nl + s].forward_train_rows(xcat, segs)
+                bsaves.append(sv)
+                feats.append(m._final_norm(xcat[:Ra].view(B, N + 1, D))[:, 1:])
+                fin.append(xcat)
+            dead = s == nl - 1 and taps is None            # see ``features``: the last CACNN output feeds nothing
+            x2, s_cv = self.cross_vit.forward16_train(xcat[Ra:].clone(), c2d, g, B, N, Lc)
+            s_cn = None
+            if not dead:
+                c2d, s_cn = self.cross_cnn.forward16_train(c2d, x2, g, B, Lc, N, shapes)
+            asaves.append((s_cv, s_cn))
+            x = ops.add_f32(x2.view(B, N, D), feats[s], out=xcat[Ra:].view(B, N, D))
+        if taps is not None:
+            taps.update(feats=feats)
+        n4 = shapes[2][0] * shapes[2][1]
+        cat = ops.decoder_input(x, c_orig[:, Lc - n4:], feats[-1], (h, w), shapes[2], config.operand_dtype, config.split_conv)
+        if not config.split_conv:
+            cat = (cat, None)
+        if taps is not None:
+            taps.update(x_final=x, c_final=c2d.view(B, Lc, D), cat=cat[0])
+        return cat, (a16, bsaves, fin, asaves, (B, N, H, W))
+
+    def _block_done(self, i: int) -> None:
+        if i in self._fire_at:
+            self.vit_reducer.stage_done()
+
+    def _e2e_backward(self, saved, dcat: torch.Tensor, inv: float) -> None:
+        """Backward of ``_features_e2e``.  G = gradient of the stacked token matrix [pass A rows | pass B rows] at the
+        current point of the reverse walk.  Per adapter stage (last to first): the stage output x = CAViT(x_B, c) + f_s
+        sends its gradient to the CAViT output and to f_s = final_norm(pass-A block output)[:, 1:] (LayerNorm backward
+        into the pass-A rows; the last feature also receives the pass-A slice of the decoder input); CACNN (when it fed a
+        later stage) and CAViT run their backward; then the block in front of the stage takes G for both passes at once.
+        ``model.norm``, CAViT and CACNN are used once per stage: per-stage gradient slabs summed in a fixed order."""
+        a16, bsaves, fin, asaves, (B, N, H, W) = saved
+        m, cv, cn = self.model, self.cross_vit, self.cross_cnn
+        _, h, w, D3 = dcat.shape
+        D = D3 // 3
+        nb, nl = len(m.blocks), self.n_last_blocks
+        Ra, Rb = B * (N + 1), B * N
+        dev = dcat.device
+        ab, vg = self.adapter_bucket, self.vit_bucket.views
+        slabs = torch.zeros((nl, ab.numel), device=dev, dtype=torch.float32)
+        nslab = torch.zeros((nl, 2 * D), device=dev, dtype=torch.float32)
+        nw = m.norm.weight.detach().float().contiguous()
+        dcat2 = dcat.view(B * N, D3)
+        G = torch.zeros((Ra + Rb, D), device=dev, dtype=torch.float32)
+        ops.copy_channels(dcat2[:, :D], G[Ra:])
+        dvit = torch.empty((B * N, D), device=dev, dtype=torch.float32)       # pass-A slice of the decoder input
+        ops.copy_channels(dcat2[:, 2 * D:], dvit)
+        dc_next = None
+        for s in range(nl - 1, -1, -1):
+            s_cv, s_cn = asaves[s]
+            gs = {n: slabs[s, o:o + p.numel()].view(p.shape) for n, p, o in zip(ab.names, ab.params, ab.offsets)}
+            # d f_s: the stage's residual add, + the decoder input's third slice for the last feature
+            dyA = torch.zeros((B, N + 1, D), device=dev, dtype=torch.float32)
+            ops.copy_channels(G[Ra:].view(B, N * D), dyA.view(B, (N + 1) * D)[:, D:])
+            if s == nl - 1:
+                ops.add_f32(dyA[:, 1:], dvit.view(B, N, D), out=dyA[:, 1:])
+            Gn = torch.empty((Ra + Rb, D), device=dev, dtype=torch.float32)
+            _, part = ops.layernorm_bwd(dyA.view(Ra, D), fin[s][:Ra], nw, m.norm.eps, res=G[:Ra], out=Gn[:Ra])
+            ops.reduce_rows(part.view(part.shape[0], 2 * D), inv, nslab[s])
+            dx = G[Ra:]
+            dc_in = None
+            if dc_next is not None:
+                dc_in, dx_extra = cn.backward16(s_cn, dc_next, inv, gs, "cross_cnn")
+                dx = ops.add_f32(dx.view(B, N, D), dx_extra.view(B, N, D)).view(Rb, D)
+            dx_in, dc_cv = cv.backward16(s_cv, dx, inv, gs, "cross_vit")
+            if dc_in is not None:
+                Lc = dc_cv.shape[0] // B
+                ops.add_f32(dc_cv.view(B, Lc, D), dc_in.view(B, Lc, D), out=dc_cv.view(B, Lc, D))
+            dc_next = dc_cv
+            ops.copy_channels(dx_in, Gn[Ra:])
+            if s == 0:   # every use of model.norm / CAViT / CACNN has contributed: finish their gradients, start the exchanges
+                red = ops.reduce_rows(nslab, 1.0)
+                vg["norm.weight"].copy_(red[:D]); vg["norm.bias"].copy_(red[D:])
+                self._block_done(nb)
+                ops.reduce_rows(slabs, 1.0, ab.grad)
+                self.adapter_reducer.stage_done()
+                if self.train_encoder:
+                    self._encoder_backward(dc_next, dcat, inv)
+                    self.encoder_reducer.stage_done()
+            bi = nb - nl + s
+            G = m.blocks[bi].backward(bsaves[bi], Gn, inv, vg, f"blocks.{bi}")
+            bsaves[bi] = None
+            self._block_done(bi)
+        for i in range(nb - nl - 1, -1, -1):
+            G = m.blocks[i].backward(bsaves[i], G, inv, vg, f"blocks.{i}")
+            bsaves[i] = None
+            self._block_done(i)
+        m.embed_backward(a16, G[:Ra].view(B, N + 1, D), G[Ra:], H, W, inv, vg)
+        self._block_done(-1)
 
     def _adapter_backward(self, asaves, dcat: torch.Tensor, inv: float) -> None:
         """Backward of the four adapter stages (`train.py:304-387` under autograd, minus its no_grad):
@@ -425,6 +594,29 @@ class SegEngine(nn.Module):
         return (m, loss1, counts) if with_counts else (m, loss1)
 
 
+def make_vit_bucket(model, blocks_per_bucket: int, process_group, momentum: bool = False):
+    """Flat gradient bucket of the whole backbone in gradient-ready order (final norm, blocks last..first, then the token
+    embedding parameters) + a reducer over ``blocks_per_bucket``-block chunks (the last chunk takes the embeddings along).
+    -> (bucket, reducer, fire_at) with fire_at = block indices after whose backward the next chunk is complete (-1 = after
+    the embedding backward)."""
+    vnamed = dict(model.named_parameters())
+    depth = len(model.blocks)
+    groups = [[n for n in vnamed if n.startswith("norm.")]]
+    groups += [[n for n in vnamed if n.startswith(f"blocks.{i}.")] for i in range(depth - 1, -1, -1)]
+    groups.append([n for n in vnamed if not n.startswith("norm.") and not n.startswith("blocks.")])
+    assert sum(len(g) for g in groups) == len(vnamed)
+    for p in model.parameters():
+        p.requires_grad_(True)
+    bucket = FlatBucket([(n, vnamed[n]) for g in groups for n in g], momentum=momentum)
+    fire_at, ranges, start = [], [], 0
+    for j in range(1, depth + 1):                       # j = number of blocks finished
+        if j % blocks_per_bucket == 0 and j != depth:
+            names = [n for g in groups[start:j + 1] for n in g]
+            ranges.append(bucket.range_of(names)); fire_at.append(depth - j); start = j + 1
+    ranges.append(bucket.range_of([n for g in groups[start:] for n in g])); fire_at.append(-1)
+    return bucket, StageReducer(bucket.grad, ranges, process_group), fire_at
+
+
 class EndToEndEngine(nn.Module):
     """BASELINE config 4 — the unfrozen end-to-end variant (`eval/eval_dinov2_setr_cross_ete.py:145-148,307-361`):
 
@@ -456,23 +648,9 @@ class EndToEndEngine(nn.Module):
         self.stage_ranges = [self.bucket.range_of([n for n in named if n.startswith(pre + ".")]) for pre in order]
         self.optimizer = SGD([self.bucket], lr=lr, momentum=momentum, weight_decay=weight_decay)
         self.reducer = StageReducer(self.bucket.grad, self.stage_ranges, process_group)
-        # backbone: gradient-ready order = final norm, blocks last..first, then the token embedding parameters
-        vnamed = dict(model.named_parameters())
-        depth = len(model.blocks)
-        groups = [[n for n in vnamed if n.startswith("norm.")]]
-        groups += [[n for n in vnamed if n.startswith(f"blocks.{i}.")] for i in range(depth - 1, -1, -1)]
-        groups.append([n for n in vnamed if not n.startswith("norm.") and not n.startswith("blocks.")])
-        assert sum(len(g) for g in groups) == len(vnamed)
-        self.vit_bucket = FlatBucket([(n, vnamed[n]) for g in groups for n in g], momentum=False)
-        # reduce after the final norm + every `blocks_per_bucket` blocks, the last chunk takes the embeddings along
-        self._fire_at, ranges, start = [], [], 0
-        for j in range(1, depth + 1):                       # j = number of blocks finished
-            last = j == depth
-            if j % blocks_per_bucket == 0 and not last:
-                names = [n for g in groups[start:j + 1] for n in g]
-                ranges.append(self.vit_bucket.range_of(names)); self._fire_at.append(depth - j); start = j + 1
-        ranges.append(self.vit_bucket.range_of([n for g in groups[start:] for n in g])); self._fire_at.append(-1)
-        self.vit_reducer = StageReducer(self.vit_bucket.grad, ranges, process_group)
+        # backbone: gradient-ready order = final norm, blocks last..first, then the token embedding parameters; reduced
+        # after every `blocks_per_bucket` blocks
+        self.vit_bucket, self.vit_reducer, self._fire_at = make_vit_bucket(model, blocks_per_bucket, process_group)
 
     def _block_done(self, i: int) -> None:
         if i in self._fire_at:

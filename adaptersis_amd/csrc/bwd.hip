@@ -267,6 +267,33 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
   }
 }
 
+// Overflow guard of the static loss scale (16-bit gradient tensors saturate to inf): guard[0] = 1 when any gradient element
+// is not finite.  The guarded SGD kernel then leaves p / buf untouched and counts the skipped step in guard[1].
+__global__ __launch_bounds__(256) void nonfinite_kernel(const float* __restrict__ g, int64_t n, int* __restrict__ guard) {
+  bool bad = false;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float v = g[i];
+    bad |= !(fabsf(v) <= 3.402823466e38f);   // false for inf and NaN
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(guard, 1);
+}
+
+__global__ __launch_bounds__(256) void sgd_guarded_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
+                                                          int64_t n, float lr, float momentum, float wd, float inv_scale, int first,
+                                                          int* __restrict__ guard) {
+  if (guard[0] != 0) {   // uniform over the grid: every thread reads the same word, written by the kernel before this one
+    if (blockIdx.x == 0 && threadIdx.x == 0) guard[1] += 1;
+    return;
+  }
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float pv = p[i];
+    const float gv = g[i] * inv_scale + wd * pv;
+    const float bv = first ? gv : momentum * buf[i] + gv;
+    buf[i] = bv;
+    p[i] = pv - lr * bv;
+  }
+}
+
 __global__ __launch_bounds__(256) void scale_kernel(float* __restrict__ x, int64_t n, float a) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) x[i] *= a;
 }
@@ -377,6 +404,26 @@ extern "C" int asis_sgd_momentum(void* stream, float* p, const float* g, float* 
   hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p, g, buf, n, lr,
                      momentum, weight_decay, inv_scale, first_step);
   ASIS_CHECK_LAUNCH("asis_sgd_momentum");
+  return ASIS_OK;
+}
+
+extern "C" int asis_grad_guard(void* stream, const float* g, int64_t n, int32_t* guard, int reset) {
+  ASIS_REQUIRE(g && guard && n >= 0, "asis_grad_guard: bad arguments");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (reset) ASIS_REQUIRE(hipMemsetAsync(guard, 0, sizeof(int32_t), s) == hipSuccess, "asis_grad_guard: memset failed");
+  if (n == 0) return ASIS_OK;
+  hipLaunchKernelGGL(nonfinite_kernel, dim3(grid_for(n)), dim3(256), 0, s, g, n, reinterpret_cast<int*>(guard));
+  ASIS_CHECK_LAUNCH("asis_grad_guard");
+  return ASIS_OK;
+}
+
+extern "C" int asis_sgd_momentum_guarded(void* stream, float* p, const float* g, float* buf, int64_t n, float lr, float momentum,
+                                         float weight_decay, float inv_scale, int first_step, int32_t* guard) {
+  ASIS_REQUIRE(p && g && buf && guard && n >= 0, "asis_sgd_momentum_guarded: bad arguments");
+  if (n == 0) return ASIS_OK;
+  hipLaunchKernelGGL(sgd_guarded_kernel, dim3(grid_for(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p, g, buf, n,
+                     lr, momentum, weight_decay, inv_scale, first_step, reinterpret_cast<int*>(guard));
+  ASIS_CHECK_LAUNCH("asis_sgd_momentum_guarded");
   return ASIS_OK;
 }
 

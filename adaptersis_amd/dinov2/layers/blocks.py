@@ -286,19 +286,37 @@ class Block(_Packed):
         ``forward`` except that fc1 keeps its 16-bit pre-activation (GELU runs as its own pass) and q, k, v come from
         one [3D] GEMM (V^T by a token transpose)."""
         B, N, D = x.shape
-        dt = config.operand_dtype
         x2 = x.reshape(B * N, D)
         if x2.dtype != torch.float32 or not x2.is_contiguous():
             x2 = x2.float().contiguous()
+        out, saved = self.forward_train_rows(x2, [(B, N)])
+        return out.view(B, N, D), saved
+
+    def forward_train_rows(self, x2: torch.Tensor, segs):
+        """``forward_train`` on several token batches stacked along the rows of one fp32 [R, D] matrix (``segs`` =
+        [(B, N), ...], see ``forward_rows``): every GEMM / LayerNorm / GELU launch — and in the backward every weight-gradient
+        GEMM — covers all rows, so the parameter gradients of the two ViT passes of the unfrozen adapter step (BASELINE
+        config 4) are summed by construction; only the attention runs per batch."""
+        dt = config.operand_dtype
+        D = x2.shape[1]
         m = self.mlp
         g1 = self._f32("g1", self.ls1.gamma) if isinstance(self.ls1, LayerScale) else None
         g2 = self._f32("g2", self.ls2.gamma) if isinstance(self.ls2, LayerScale) else None
         a = self.attn
         xn = ops.layernorm(x2, self._f32("n1w", self.norm1.weight), self._f32("n1b", self.norm1.bias), self.norm1.eps, dt)
         qkv = ops.gemm(xn, a._w16("qkv", a.qkv.weight), bias_n=a._f32("qkv_b", a.qkv.bias))
-        vt = ops.transpose_tokens(qkv[:, 2 * D:], B, N)
-        lse = torch.empty((B, a.num_heads, N), device=x2.device, dtype=torch.float32)
-        o = ops.attention_fwd(qkv[:, :D], qkv[:, D:2 * D], vt, B, a.num_heads, N, a.scale, lse=lse)
+        o = torch.empty((x2.shape[0], D), device=x2.device, dtype=dt)
+        lse = []
+        r0 = 0
+        for B, N in segs:
+            r1 = r0 + B * N
+            vt = ops.transpose_tokens(qkv[r0:r1, 2 * D:], B, N)
+            l = torch.empty((B, a.num_heads, N), device=x2.device, dtype=torch.float32)
+            ops.attention_fwd(qkv[r0:r1, :D], qkv[r0:r1, D:2 * D], vt, B, a.num_heads, N, a.scale, out=o[r0:r1], lse=l)
+            lse.append(l)
+            r0 = r1
+        if r0 != x2.shape[0]:
+            raise ValueError("forward_train_rows: segments do not cover the rows")
         x1 = ops.gemm(o, a._w16("proj", a.proj.weight), out_f32=True, bias_n=a._f32("proj_b", a.proj.bias), scale_n=g1,
                       res=x2)
         xn2 = ops.layernorm(x1, self._f32("n2w", self.norm2.weight), self._f32("n2b", self.norm2.bias), self.norm2.eps, dt)
@@ -312,13 +330,13 @@ class Block(_Packed):
             hpost = ops.swiglu(hpre, dt)
             x3 = ops.gemm(hpost, m._w16("w3", m.w3.weight), out_f32=True, bias_n=m._f32("w3_b", m.w3.bias), scale_n=g2,
                           res=x1)
-        return x3.view(B, N, D), (x2, xn, qkv, o, lse, x1, xn2, hpre, hpost, B, N)
+        return x3, (x2, xn, qkv, o, lse, x1, xn2, hpre, hpost, list(segs))
 
     def backward(self, saved, dres: torch.Tensor, inv_scale: float, grads: Optional[dict] = None, prefix: str = "") -> torch.Tensor:
         """dres fp32 [B*N, D] = loss_scale * dL/d(block output) -> loss_scale * dL/d(block input).  With ``grads``
         (name -> fp32 tensor, names as in ``state_dict`` under ``prefix``) the parameter gradients are written too;
         without it only the input gradient is produced (frozen backbone, adapters training)."""
-        x2, xn, qkv, o, lse, x1, xn2, hpre, hpost, B, N = saved
+        x2, xn, qkv, o, lse, x1, xn2, hpre, hpost, segs = saved
         dt = config.operand_dtype
         D = x2.shape[1]
         a, m = self.attn, self.mlp
@@ -350,9 +368,15 @@ class Block(_Packed):
         d16, cs = ops.cast_colsum(dx1, dt) if grads is not None else (ops.cast_pad(dx1, D, dt), None)
         self._linear_bwd(pre + "attn.proj", a.proj, ls1, pre + "ls1.gamma", d16, cs, o, inv_scale, grads)
         dO = ops.gemm(d16, self._wT16("projT", a.proj.weight, ls1))                # 16-bit [R, D]
-        q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
-        dqkv = ops.attention_bwd(q, k, v, ops.transpose_tokens(q, B, N), ops.transpose_tokens(k, B, N),
-                                 ops.transpose_tokens(dO, B, N), o, dO, lse, B, a.num_heads, N, a.scale)
+        dqkv = torch.empty((x2.shape[0], 3 * D), device=x2.device, dtype=dt)
+        r0 = 0
+        for (B, N), l in zip(segs, lse):   # attention backward per stacked token batch
+            r1 = r0 + B * N
+            q, k, v = qkv[r0:r1, :D], qkv[r0:r1, D:2 * D], qkv[r0:r1, 2 * D:]
+            ops.attention_bwd(q, k, v, ops.transpose_tokens(q, B, N), ops.transpose_tokens(k, B, N),
+                              ops.transpose_tokens(dO[r0:r1], B, N), o[r0:r1], dO[r0:r1], l, B, a.num_heads, N, a.scale,
+                              dqkv=dqkv[r0:r1])
+            r0 = r1
         self._linear_bwd(pre + "attn.qkv", a.qkv, None, None, dqkv, ops.colsum(dqkv) if grads is not None else None, xn,
                          inv_scale, grads)
         dln = ops.gemm(dqkv, self._wT16("qkvT", a.qkv.weight), out_f32=True)

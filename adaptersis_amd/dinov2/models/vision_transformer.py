@@ -10,7 +10,7 @@ from __future__ import annotations
 
 import math
 from functools import partial
-from typing import Sequence, Tuple, Union
+from typing import Optional, Sequence, Tuple, Union
 
 import torch
 import torch.nn as nn
@@ -110,16 +110,22 @@ class DinoVisionTransformer(nn.Module):
         x_norm = self._final_norm(x)
         return {"x_norm_clstoken": x_norm[:, 0], "x_norm_patchtokens": x_norm[:, 1:], "x_prenorm": x, "masks": masks}
 
-    # -- training path: forward_features under autograd (eval_dinov2_setr_cross_ete.py:145-148,318-321) -----------
-    def forward_train(self, x: torch.Tensor):
-        """images (B,3,H,W) -> (x_norm_patchtokens fp32 (B,N,D) view, saved activations for ``backward``)."""
-        B, nc, w, h = x.shape
+    def patch_tokens_train(self, x: torch.Tensor):
+        """PatchEmbed keeping its im2col operand: -> (tokens fp32 (B, N, D), a16 16-bit [B*N, ldk]) for the weight gradient."""
+        B = x.shape[0]
         pe = self.patch_embed
         P = pe.patch_size[0]
         a16 = ops.im2col_patch(x.contiguous().float(), P, (3 * P * P + 7) // 8 * 8, config.operand_dtype)
         w16 = _pack(pe._cache, "w", pe.proj.weight,
                     lambda p: ops.cast_pad(p.reshape(p.shape[0], -1).contiguous().float(), a16.shape[1], config.operand_dtype))
         t = ops.gemm(a16, w16, out_f32=True, bias_n=pe._f32("b", pe.proj.bias)).view(B, -1, self.embed_dim)
+        return t, a16
+
+    # -- training path: forward_features under autograd (eval_dinov2_setr_cross_ete.py:145-148,318-321) -----------
+    def forward_train(self, x: torch.Tensor):
+        """images (B,3,H,W) -> (x_norm_patchtokens fp32 (B,N,D) view, saved activations for ``backward``)."""
+        B, nc, w, h = x.shape
+        t, a16 = self.patch_tokens_train(x)
         pos = self._pos_for(t.shape[1], w, h)
         xx = ops.add_cls_pos(t, self.cls_token.detach().reshape(-1).float().contiguous(),
                              pos.detach().reshape(-1, self.embed_dim).float().contiguous())
@@ -171,6 +177,21 @@ class DinoVisionTransformer(nn.Module):
             bsaved[i] = None
             if block_done is not None:
                 block_done(i)
+        self.embed_backward(a16, dx.view(B, N + 1, D), None, w, h, inv_scale, grads)
+        if block_done is not None:
+            block_done(-1)
+
+    def embed_backward(self, a16, dxa: torch.Tensor, dtb: Optional[torch.Tensor], w: int, h: int, inv_scale: float,
+                       grads: dict) -> None:
+        """Backward of ``prepare_tokens_with_masks`` + PatchEmbed: dxa fp32 (B, N+1, D) = gradient of the cls + pos-embed
+        token matrix; dtb fp32 [B*N, D] or None = gradient that reaches the raw patch tokens directly (pass B of the
+        adapter flow, `train.py:300`, which takes ``patch_embed(inp)`` without cls / pos-embed).  Writes cls_token,
+        pos_embed, mask_token (unused: zero) and patch_embed.proj.{weight,bias} into ``grads``."""
+        B, N1, D = dxa.shape
+        N = N1 - 1
+        dev = dxa.device
+        dt = config.operand_dtype
+        dx = dxa
         # ---- prepare_tokens: x = cat(cls, patch_embed(img)) + pos ----
         psum = ops.reduce_rows(ops.colsum(dx.view(B, (N + 1) * D)), inv_scale).view(N + 1, D)   # sum over the batch
         grads["cls_token"].view(-1).copy_(psum[0])
@@ -186,13 +207,13 @@ class DinoVisionTransformer(nn.Module):
         grads["mask_token"].zero_()
         dtk = torch.empty((B * N, D), device=dev, dtype=torch.float32)
         ops.copy_channels(dx.view(B, (N + 1) * D)[:, D:], dtk.view(B, N * D))
+        if dtb is not None:
+            ops.add_f32(dtk.view(B, N, D), dtb.view(B, N, D), out=dtk.view(B, N, D))
         d16 = ops.cast_pad(dtk, D, dt)
         K = grads["patch_embed.proj.weight"][0].numel()
         gw = ops.wgrad(d16.view(1, B * N, 1, D), a16.view(1, B * N, 1, a16.shape[1]), D, 1, 1, 1, 0, inv_scale)
         grads["patch_embed.proj.weight"].view(D, K).copy_(gw.view(D, -1)[:, :K])
         ops.reduce_rows(ops.colsum(dtk), inv_scale, grads["patch_embed.proj.bias"])
-        if block_done is not None:
-            block_done(-1)
 
     # -- vision_transformer.py:237-247 ---------------------------------------------------------
     def _get_intermediate_layers_not_chunked(self, x, n=1):
@@ -244,6 +265,18 @@ def vit_tiny_swiglu(patch_size=14, **kwargs):
 def vit_large_d4(patch_size=14, **kwargs):
     """Test-only: ViT-L width with 4 blocks."""
     return DinoVisionTransformer(patch_size=patch_size, embed_dim=1024, depth=4, num_heads=16, mlp_ratio=4,
+                                 block_fn=partial(Block, attn_class=MemEffAttention), **kwargs)
+
+
+def vit_base_d4(patch_size=14, **kwargs):
+    """Test-only: ViT-B width with 4 blocks."""
+    return DinoVisionTransformer(patch_size=patch_size, embed_dim=768, depth=4, num_heads=12, mlp_ratio=4,
+                                 block_fn=partial(Block, attn_class=MemEffAttention), **kwargs)
+
+
+def vit_giant2_d4(patch_size=14, **kwargs):
+    """Test-only: ViT-g width (SwiGLU FFN when built with ffn_layer="swiglufused") with 4 blocks."""
+    return DinoVisionTransformer(patch_size=patch_size, embed_dim=1536, depth=4, num_heads=24, mlp_ratio=4,
                                  block_fn=partial(Block, attn_class=MemEffAttention), **kwargs)
 
 

@@ -931,9 +931,23 @@ def wgrad(dy: torch.Tensor, x_nhwc: torch.Tensor, Cout: int, KH: int, KW: int, s
     return out
 
 
+def grad_guard(g: torch.Tensor, guard: torch.Tensor, reset: bool) -> None:
+    """guard int32[2]: guard[0] |= any non-finite element of ``g`` (cleared first when ``reset``)."""
+    _dev(g, guard)
+    if guard.dtype != torch.int32 or guard.numel() < 2:
+        raise ValueError("guard must be an int32 tensor of 2 elements")
+    check(lib().asis_grad_guard(_stream(), _f32c(g).data_ptr(), g.numel(), guard.data_ptr(), int(reset)), "asis_grad_guard")
+
+
 def sgd_momentum(p: torch.Tensor, g: torch.Tensor, buf: torch.Tensor, lr: float, momentum: float, weight_decay: float,
-                 inv_scale: float, first_step: bool) -> None:
+                 inv_scale: float, first_step: bool, guard: Optional[torch.Tensor] = None) -> None:
     _dev(p, g, buf)
+    if guard is not None:
+        _dev(guard)
+        check(lib().asis_sgd_momentum_guarded(_stream(), _f32c(p).data_ptr(), _f32c(g).data_ptr(), _f32c(buf).data_ptr(),
+                                              p.numel(), float(lr), float(momentum), float(weight_decay), float(inv_scale),
+                                              int(first_step), guard.data_ptr()), "asis_sgd_momentum_guarded")
+        return
     check(lib().asis_sgd_momentum(_stream(), _f32c(p).data_ptr(), _f32c(g).data_ptr(), _f32c(buf).data_ptr(), p.numel(),
                                   float(lr), float(momentum), float(weight_decay), float(inv_scale), int(first_step)),
           "asis_sgd_momentum")

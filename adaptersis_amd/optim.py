@@ -64,14 +64,25 @@ class SGD:
                                           "weight_decay": weight_decay, "dampening": 0, "nesterov": False}
                                          for b in self.buckets]
         self._steps = 0
+        # overflow guard of the static loss scale (config.loss_scale, 16-bit gradient tensors): a step whose all-reduced
+        # gradients hold an inf / NaN is skipped on the device — no host sync; ``skipped_steps`` reads the counter
+        self.guard = torch.zeros(2, device=self.buckets[0].flat.device, dtype=torch.int32) \
+            if self.buckets and self.buckets[0].flat.is_cuda else None
+
+    @property
+    def skipped_steps(self) -> int:
+        return 0 if self.guard is None else int(self.guard[1].item())
 
     def zero_grad(self, set_to_none: bool = False):
         pass  # every gradient element is overwritten by the backward kernels each step
 
     def step(self, inv_scale: float = 1.0):
+        if self.guard is not None:
+            for i, b in enumerate(self.buckets):
+                ops.grad_guard(b.grad, self.guard, i == 0)
         for b, g in zip(self.buckets, self.param_groups):
             ops.sgd_momentum(b.flat, b.grad, b.momentum, g["lr"], g["momentum"], g["weight_decay"], inv_scale,
-                             self._steps == 0)
+                             self._steps == 0, self.guard)
             for p in b.params:  # changed in place behind torch's back: invalidate the packed 16-bit copies
                 p._asis_gen = getattr(p, "_asis_gen", 0) + 1
         self._steps += 1

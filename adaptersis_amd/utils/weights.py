@@ -30,6 +30,8 @@ VIT_CONFIGS = {
     "vit_tiny_test": (128, 4, 2, "mlp"),  # test-only geometry (head dim 64 like all real archs)
     "vit_tiny_swiglu": (128, 4, 2, "swiglufused"),  # test-only: the ViT-g FFN at toy width
     "vit_large_d4": (1024, 4, 16, "mlp"),  # test-only: ViT-L width (the only D the reference adapters accept), 4 blocks
+    "vit_base_d4": (768, 4, 12, "mlp"),  # test-only: ViT-B width (BASELINE config 2; MSDA head dim 96), 4 blocks
+    "vit_giant2_d4": (1536, 4, 24, "swiglufused"),  # test-only: ViT-g width (config 5; SwiGLU 8192/4096, MSDA head dim 192)
     "vit_small": (384, 12, 6, "mlp"),
     "vit_base": (768, 12, 12, "mlp"),
     "vit_large": (1024, 24, 16, "mlp"),

@@ -120,6 +120,34 @@ def synthetic(batch: int, size: int, rank: int, dev, num_classes: int = 2):
     return img.to(dev), tgt.to(dev)
 
 
+def host_cores() -> int:
+    """Cores this process may really use: the affinity mask, cut to the cgroup CPU quota (a 1-GPU box exposes all 256
+    host threads in the mask but owns a 16-core share: 256 oracle threads on 16 cores ran 12x slower than 16),
+    ``ASIS_CPU_THREADS`` overrides."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()
+            if q != "max":
+                quota = max(1, int(float(q) / float(per) + 0.5))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f2:
+                q, per = int(f.read()), int(f2.read())
+                if q > 0:
+                    quota = max(1, int(q / per + 0.5))
+        except (OSError, ValueError):
+            pass
+    if quota is None and n > 64:
+        quota = 16          # no quota visible on a many-core host: the documented share of a 1-GPU box
+    if quota is not None:
+        n = min(n, quota)
+    if os.environ.get("ASIS_CPU_THREADS"):
+        n = int(os.environ["ASIS_CPU_THREADS"])
+    return max(1, n)
+
+
 def cpu_baseline(arch: str, size: int, batch: int = 1):
     """Reference CPU path (the fp32 eager oracle restatement, parity-pinned to the imported reference) on this box's
     host cores: ONE WHOLE `train.py:268-436` step at batch ``batch`` is timed end to end (encoder, ViT pass A + pass B,
@@ -128,9 +156,7 @@ def cpu_baseline(arch: str, size: int, batch: int = 1):
     from adaptersis_amd.utils import weights as W
     from oracle import ref_torch as O  # cpu_baseline leg only
 
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    if os.environ.get("ASIS_CPU_THREADS"):
-        cores = min(cores, int(os.environ["ASIS_CPU_THREADS"]))
+    cores = host_cores()
     torch.set_num_threads(cores)
     D, depth, heads, _ = W.VIT_CONFIGS[arch]
     vsd = W.make_vit_state_dict(arch, layerscale="kernel")
@@ -172,7 +198,7 @@ def cpu_baseline(arch: str, size: int, batch: int = 1):
         "sample": (f"one whole train.py step timed end to end at batch {batch}, {arch} {size}x{size}: {t_step:.1f}s "
                    f"(features {t_fwd - t0:.1f}s, decoder fwd+loss+bwd+SGD {t_step - (t_fwd - t0):.1f}s; one block at "
                    f"N={N + 1} alone: {t_a:.2f}s; loss {loss:.4f}); fp32 eager torch {torch.__version__}, "
-                   f"{cores} threads = all cores this process may use"),
+                   f"{cores} threads = the CPU share of this box (affinity mask cut to the cgroup quota)"),
     }
 
 

@@ -443,6 +443,15 @@ int asis_wgrad(void* stream, const asis_wgrad_desc* d);
  * fp32 parameter buffer; g is multiplied by inv_scale (1/loss_scale) first. */
 int asis_sgd_momentum(void* stream, float* p, const float* g, float* buf, int64_t n, float lr, float momentum,
                       float weight_decay, float inv_scale, int first_step);
+/* Overflow guard for the static loss scale of the 16-bit gradient tensors (the reference trains in fp32 and has no
+ * counterpart; torch.cuda.amp.GradScaler.step has the same skip semantics).  guard = int32[2] in device memory:
+ *   asis_grad_guard: guard[0] |= (any element of g is inf / NaN); reset != 0 clears guard[0] first (call once per step
+ *   with reset = 1 on the first bucket, reset = 0 on the others);
+ *   asis_sgd_momentum_guarded: asis_sgd_momentum, except that a step with guard[0] != 0 changes nothing and adds 1 to
+ *   guard[1] (the count of skipped steps, read by the host whenever it likes). */
+int asis_grad_guard(void* stream, const float* g, int64_t n, int32_t* guard, int reset);
+int asis_sgd_momentum_guarded(void* stream, float* p, const float* g, float* buf, int64_t n, float lr, float momentum,
+                              float weight_decay, float inv_scale, int first_step, int32_t* guard);
 int asis_scale_f32(void* stream, float* x, int64_t n, float a);
 
 #ifdef __cplusplus

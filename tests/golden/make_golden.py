@@ -583,6 +583,239 @@ def mla_step_case(R, out, mode, tag, arch="vit_large_d4"):
         out[f"{tag}.grad.{k}"] = sub(p.grad, 3000)
 
 
+def _ref_adapter_modules(R, arch, mode):
+    """Imported reference modules of the adapter flow at the width of ``arch`` (the classes are width-generic; only the
+    scripts hard-code 1024)."""
+    D, depth, heads, _ = W.VIT_CONFIGS[arch]
+    vsd = W.make_vit_state_dict(arch, layerscale=("kernel" if mode == "kernel" else "init"))
+    esd, csd, nsd = W.make_encoder_state_dict(D), W.make_cavit_state_dict(D, mode=mode), W.make_cacnn_state_dict(D, mode=mode)
+    ln = from_partial()
+    model = build_ref_vit(R, arch, vsd)
+    enc = R["FeatureEncoder"](embed_dim=D); enc.load_state_dict(esd)
+    cv = R["CAViT"](dim=D, n_levels=3, num_heads=8, init_values=0.0, n_points=4, norm_layer=ln); cv.load_state_dict(csd)
+    cn = R["CACNN"](dim=D, n_levels=1, num_heads=8, n_points=4, norm_layer=ln, with_cffn=True, cffn_ratio=0.25); cn.load_state_dict(nsd)
+    return model, enc, cv, cn, (vsd, esd, csd, nsd)
+
+
+def _ref_adapter_stream(R, model, enc, cv, cn, inp, grad_backbone=False):
+    """`train.py:275-387` with the imported reference modules -> (x after stage 4, [x after each stage], c, c4, pass-A feats)."""
+    import contextlib
+    ng = contextlib.nullcontext if grad_backbone else torch.no_grad
+    d1, d2 = R["deform_inputs"](inp, 14)
+    c1, c2, c3, c4 = enc(inp)
+    c = torch.cat([c2, c3, c4], dim=1)
+    with ng():
+        feats = model.get_intermediate_layers(inp, 4, return_class_token=True)
+        outs = [f for f, _ in feats]
+        x = model.patch_embed(inp)
+        for blk in model.blocks[0:-3]:
+            x = blk(x)
+    stages = [None, model.blocks[-3], model.blocks[-2], model.blocks[-1]]
+    xs = []
+    for s in range(4):
+        if s:
+            with ng():
+                x = stages[s](x)
+        x = cv(query=x, reference_points=d1[0], feat=c, spatial_shapes=d1[1], level_start_index=d1[2])
+        c = cn(query=c, reference_points=d2[0], feat=x, spatial_shapes=d2[1], level_start_index=d2[2], H=36, W=36)
+        x = x + outs[s]
+        xs.append(x)
+    return x, xs, c, c4, outs
+
+
+def ref_unet_wide(R, C, n_classes):
+    """The reference's UNet hard-wires base width 384 (`backbones/unet_parts.py:106-124`); this is the SAME assembly at base
+    width C built from the reference's own part classes (Down / Up / Up_wc / OutConv), attribute names unchanged."""
+    import importlib
+    P = importlib.import_module("backbones.unet_parts")
+
+    class UNetWide(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.down3 = P.Down(C, 2 * C)
+            self.down4 = P.Down(2 * C, 4 * C)
+            self.up1 = P.Up(4 * C, 2 * C, False)
+            self.up2 = P.Up(2 * C, C, False)
+            self.up3 = P.Up_wc(C, C // 2, False)
+            self.up4 = P.Up_wc(C // 2, C // 4, False)
+            self.outc = P.OutConv(C // 4, n_classes)
+
+        def forward(self, x):
+            x3 = x
+            x4 = self.down3(x3)
+            x5 = self.down4(x4)
+            x = self.up1(x5, x4)
+            x = self.up2(x, x3)
+            x = self.up3(x)
+            x = self.up4(x)
+            return self.outc(x)
+    return UNetWide()
+
+
+def c2_case(R, out, arch="vit_base_d4", batch=2, tag="c2"):
+    """BASELINE config 2 at full WIDTH (ViT-B: D = 768, 12 heads, MSDA head dim 96; depth reduced to 4 blocks), 588x588,
+    batch 2: `train.py:275-387` adapter flow with the imported reference ViT / FeatureEncoder / CAViT / CACNN at dim 768,
+    adapter-stream map -> UNet(768) assembled from the reference's own parts -> resize -> CE + DC(2)
+    (`eval/eval_dinov2_unet.py:286-297`), gradients of every UNet parameter."""
+    import torch.nn.functional as F
+    D, depth, heads, _ = W.VIT_CONFIGS[arch]
+    model, enc, cv, cn, (vsd, esd, csd, nsd) = _ref_adapter_modules(R, arch, "kernel")
+    usd = W.make_unet_state_dict(D, 2)
+    u = ref_unet_wide(R, D, 2)
+    u.load_state_dict(usd, strict=True)
+    u.train()
+    inp, target = W.synthetic_batch(batch, 588)
+    with torch.no_grad():
+        x, xs, c, c4, outs = _ref_adapter_stream(R, model, enc, cv, cn, inp)
+        xm = x.transpose(1, 2).reshape(batch, D, 42, 42)
+    y = u(xm)
+    o = F.interpolate(y, size=(588, 588), mode="bilinear")
+    loss = torch.nn.CrossEntropyLoss()(o, target) + R["DC"](2)(o, O.one_hot(target, 2))
+    loss.backward()
+    otaps = {}
+    with torch.no_grad():
+        O.adapter_forward(inp, vsd, {k: t.clone() for k, t in esd.items()}, csd, nsd, heads, taps=otaps)
+    close(otaps["x_stage3"], x, 5e-5, f"{tag} adapter stream")
+    close(otaps["c_stage3"], c, 5e-5, f"{tag} c")
+    osd = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in usd.items()}
+    oy = O.unet(xm, osd, update_bn=True)
+    oo = F.interpolate(oy, size=(588, 588), mode="bilinear")
+    oloss = O.cross_entropy_nd(oo, target) + O.dc_loss(oo, O.one_hot(target, 2))
+    oloss.backward()
+    close(oy.detach(), y.detach(), 2e-5, f"{tag} UNet(768) logits")
+    close(oloss.detach(), loss.detach(), 1e-5, f"{tag} loss")
+    out[f"{tag}.x_final"] = sub(x)
+    out[f"{tag}.c_final"] = sub(c)
+    for i, t in enumerate(xs):
+        out[f"{tag}.x_stage{i}"] = sub(t)
+    out[f"{tag}.logits"] = sub(y)
+    out[f"{tag}.loss"] = loss.detach().clone()
+    for k, p in u.named_parameters():
+        close(osd[k].grad, p.grad, 5e-3, f"{tag} grad {k}")
+        out[f"{tag}.grad.{k}"] = sub(p.grad, 3000)
+
+
+def c5_case(R, out, arch="vit_giant2_d4", batch=2, tag="c5", ncls=11):
+    """BASELINE config 5 at full WIDTH (ViT-g: D = 1536, 24 heads, SwiGLU 8192 -> 4096, MSDA head dim 192; 4 blocks),
+    588x588, batch 2, 11 classes: `train_mla.py:266-383` flow with the imported reference modules, the reference DecoderMLA
+    with its classifier conv re-made for 11 classes (`decoders.py:59` forces 2), softmax -> the reference's
+    ``iou_loss(num_classes=11)`` (`train_multi_class.py:391-393`), gradients of every decoder parameter."""
+    D, depth, heads, _ = W.VIT_CONFIGS[arch]
+    model, enc, cv, cn, (vsd, esd, csd, nsd) = _ref_adapter_modules(R, arch, "kernel")
+    dsd = W.make_decoder_mla_state_dict(D, 128, ncls)
+    dec = R["DecoderMLA"](img_size=588, mla_channels=D, mlahead_channels=128)
+    dec.cls_3 = torch.nn.Conv2d(64, ncls, 3, padding=1)
+    dec.num_classes = ncls
+    dec.load_state_dict(dsd)
+    dec.train()
+    inp, target = W.synthetic_batch(batch, 588, ncls)
+    d1, d2 = R["deform_inputs"](inp, 14)
+    c1, c2, c3, c4 = enc(inp)
+    c = torch.cat([c2, c3, c4], dim=1)
+    with torch.no_grad():
+        x = model.patch_embed(inp)
+        for blk in model.blocks[0:-3]:
+            x = blk(x)
+        x = cv(query=x, reference_points=d1[0], feat=c, spatial_shapes=d1[1], level_start_index=d1[2])
+        outs = [x]
+        for sl in (slice(-3, -2), slice(-2, -1), slice(-2, -1)):
+            for blk in model.blocks[sl]:
+                x = blk(x)
+            c = cn(query=c, reference_points=d2[0], feat=x, spatial_shapes=d2[1], level_start_index=d2[2], H=36, W=36)
+            x = cv(query=x, reference_points=d1[0], feat=c, spatial_shapes=d1[1], level_start_index=d1[2])
+            outs.append(x)
+        feats = model.get_intermediate_layers(inp, 4, return_class_token=True)
+        last = feats[-1][0] + outs[3]
+        maps = [t.transpose(1, 2).reshape(batch, D, 42, 42) for t in (last, outs[2], outs[1], outs[0])]
+    output = dec(*maps)
+    loss = R["iou_loss"](torch.softmax(output, 1), target, num_classes=ncls)
+    loss.backward()
+    with torch.no_grad():
+        omaps = O.mla_forward(inp, vsd, {k: t.clone() for k, t in esd.items()}, csd, nsd, heads)
+    for i, (a, b) in enumerate(zip(omaps, maps)):
+        close(a, b, 5e-5, f"{tag} mla input {i}")
+        out[f"{tag}.in{i}"] = sub(b)
+    osd = {k: t.clone().requires_grad_(t.is_floating_point() and "running" not in k) for k, t in dsd.items()}
+    taps = {}
+    oloss = O.train_step_loss_mla(omaps, target, osd, ncls, "iou", taps)
+    oloss.backward()
+    close(taps["out"].detach(), output.detach(), 1e-4, f"{tag} output")
+    close(oloss.detach(), loss.detach(), 1e-5, f"{tag} loss")
+    out[f"{tag}.output"] = sub(output, 40000)
+    out[f"{tag}.loss"] = loss.detach().clone()
+    for k, p in dec.named_parameters():
+        close(osd[k].grad, p.grad, 2e-3, f"{tag} grad {k}")
+        out[f"{tag}.grad.{k}"] = sub(p.grad, 3000)
+
+
+def c4_case(R, out, arch="vit_large_d4", batch=1, tag="c4"):
+    """BASELINE config 4: the `train.py:268-436` adapter flow with the backbone UNFROZEN — its no_grad /
+    inference_mode regions (`:287,300-302,389-406`) removed, as `eval/eval_dinov2_setr_cross_ete.py:145-148,307-361` does
+    for its own flow — run with the imported reference modules under autograd at ViT-L width (4 blocks), 588x588.
+    ``MSDeformAttnFunction`` has no backward, so for this case the reference module's call is routed to
+    the reference's own differentiable ``ms_deform_attn_core_pytorch`` (same file, the function its forward calls)."""
+    import importlib
+    import torch.nn.functional as F
+    D, depth, heads, _ = W.VIT_CONFIGS[arch]
+    msda_mod = importlib.import_module("backbones.ops.modules.ms_deform_attn")
+    core = msda_mod.ms_deform_attn_core_pytorch
+
+    class _Differentiable:
+        @staticmethod
+        def apply(value, shapes, level_start_index, loc, aw, im2col_step):
+            return core(value.float(), shapes, loc.float(), aw.float())
+    orig = msda_mod.MSDeformAttnFunction
+    msda_mod.MSDeformAttnFunction = _Differentiable
+    try:
+        model, enc, cv, cn, (vsd, esd, csd, nsd) = _ref_adapter_modules(R, arch, "kernel")
+        model.train()   # eval_dinov2_setr_cross_ete.py:308; drop_path 0: same maths
+        dsd = W.make_feature_decoder_state_dict(D, 2, features=(D, 512, 256, 128, 64))
+        dec = R["FeatureDecoder"](embed_dim=D, num_classes=2, features=[D, 512, 256, 128, 64]); dec.load_state_dict(dsd)
+        dec.train()
+        inp, target = W.synthetic_batch(batch, 588)
+        x, xs, c, c4, outs = _ref_adapter_stream(R, model, enc, cv, cn, inp, grad_backbone=True)
+        a = x.transpose(1, 2).reshape(batch, D, 42, 42)
+        v = outs[-1].transpose(1, 2).reshape(batch, D, 42, 42)
+        cc = F.pad(c4.transpose(1, 2).reshape(batch, D, 18, 18), [12, 12, 12, 12])
+        cat = torch.cat((a, cc, v), dim=1)
+        logits = dec(cat)
+        o = torch.softmax(F.interpolate(logits, size=(588, 588), mode="bilinear"), 1)
+        loss = R["DC"](2)(o, O.one_hot(target, 2))
+        loss.backward()
+    finally:
+        msda_mod.MSDeformAttnFunction = orig
+
+    def leaf(sd):
+        return {k: t.clone().requires_grad_(t.is_floating_point() and "running" not in k and "num_batches" not in k)
+                for k, t in sd.items()}
+    ovit, oenc, ocv, ocn, odec = leaf(vsd), leaf(esd), leaf(csd), leaf(nsd), leaf(dsd)
+    ocat = O.adapter_forward(inp, ovit, oenc, ocv, ocn, heads)
+    taps = {}
+    oloss = O.train_step_loss(ocat, target, odec, 2, taps)
+    oloss.backward()
+    close(ocat.detach(), cat.detach(), 5e-5, f"{tag} output_last_cat")
+    close(taps["logits"].detach(), logits.detach(), 1e-4, f"{tag} logits")
+    close(oloss.detach(), loss.detach(), 1e-5, f"{tag} loss")
+    out[f"{tag}.cat"] = sub(cat)
+    out[f"{tag}.logits"] = sub(logits)
+    out[f"{tag}.loss"] = loss.detach().clone()
+    worst = 0.0
+    for pre, mod, osd in (("vit.", model, ovit), ("cross_vit.", cv, ocv), ("cross_cnn.", cn, ocn),
+                          ("backbone_encoder.", enc, oenc), ("dec.", dec, odec)):
+        n = 0
+        for k, p_ in mod.named_parameters():
+            if p_.grad is None or float(p_.grad.norm()) == 0:
+                continue
+            og = osd[k].grad
+            err = float((og.double() - p_.grad.double()).norm() / p_.grad.double().norm())
+            worst = max(worst, err)
+            assert err < 5e-3, (pre + k, err)
+            out[f"{tag}.grad.{pre}{k}"] = sub(p_.grad, 3000)
+            n += 1
+        print(f"  {pre:18s} {n} parameter gradients stored")
+    print(f"  oracle vs reference gradients: worst rel-L2 {worst:.2e}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true", help="also generate the ViT-L/14 588x588 cases")
@@ -648,6 +881,23 @@ def main():
         out = {}
         print("[train_mla step, ViT-L width x 4 blocks, 588 B=1, kernel-mode weights]"); mla_step_case(R, out, "kernel", "mla_kernel")
         save("mla", out)
+    if want("c2"):
+        out = {}
+        print("[config 2 width: ViT-B x 4 blocks + adapters(768) + UNet(768) step, 588 B=2]"); c2_case(R, out)
+        save("c2", out)
+    if want("c4"):
+        out = {}
+        print("[config 4: unfrozen backbone in the adapter flow, ViT-L width x 4 blocks, 588 B=1, every gradient]"); c4_case(R, out)
+        save("c4", out)
+    if want("c5"):
+        out = {}
+        print("[config 5 width: ViT-g (SwiGLU) x 4 blocks + adapters(1536) + DecoderMLA 11 classes + iou_loss, 588 B=2]"); c5_case(R, out)
+        save("c5", out)
+    if args.full or "step_b2" in only:
+        out = {}
+        print("[step ViT-L 588 B=2 reference_exact (init mode)]"); step_case(R, out, "vit_large", "init", "step_b2_exact", batch=2)
+        print("[step ViT-L 588 B=2 kernel-mode weights]"); step_case(R, out, "vit_large", "kernel", "step_b2_kernel", batch=2)
+        save("step_b2", out)
     if args.full or "step" in only:
         out = {}
         print("[step ViT-L 588 B=1 reference_exact (init mode)]"); step_case(R, out, "vit_large", "init", "step_exact")

@@ -97,3 +97,41 @@ def test_multi_bucket_reducers_two_ranks_gloo():
         out = mgr.dict()
         mp.spawn(_worker_multi, args=(world, _free_port(), out), nprocs=world, join=True)
         assert dict(out) == {0: True, 1: True}
+
+
+def _worker_bcast(rank, world, port, out):
+    """modules built with torch's default per-process init must leave `train_seg` identical on all ranks."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from adaptersis_amd.backbones.adapter_blocks import CACNN, CAViT
+    from adaptersis_amd.backbones.decoders import FeatureDecoder
+    from adaptersis_amd.backbones.encoders import FeatureEncoder
+    from adaptersis_amd.optim import FlatBucket
+    from adaptersis_amd.train import broadcast_module_states
+    torch.manual_seed(100 + rank)        # what separate processes get: different random initialisations
+    D = 64
+    mods = [FeatureEncoder(embed_dim=D), CAViT(dim=D, n_levels=3, num_heads=8, init_values=0.0, n_points=4),
+            CACNN(dim=D, n_levels=1, num_heads=8, n_points=4, with_cffn=True, cffn_ratio=0.25),
+            FeatureDecoder(embed_dim=D, num_classes=2, features=[D, 32, 16, 16, 8])]
+    mods[0].stem[1].num_batches_tracked.fill_(rank + 3)   # integer buffer
+    before = torch.cat([p.detach().reshape(-1) for p in mods[3].parameters()]).clone()
+    broadcast_module_states(mods)
+    bucket = FlatBucket([(f"{i}.{n}", p) for i, m in enumerate(mods) for n, p in m.named_parameters()])
+    bufs = torch.cat([b.detach().double().reshape(-1) for m in mods for b in m.buffers()])
+    gathered = [torch.empty_like(bucket.flat) for _ in range(world)]
+    dist.all_gather(gathered, bucket.flat)
+    gb = [torch.empty_like(bufs) for _ in range(world)]
+    dist.all_gather(gb, bufs)
+    same = all(torch.equal(g, gathered[0]) for g in gathered) and all(torch.equal(g, gb[0]) for g in gb)
+    changed = not torch.equal(before, torch.cat([p.detach().reshape(-1) for p in mods[3].parameters()]))
+    out[rank] = bool(same) and (changed if rank > 0 else not changed) and int(mods[0].stem[1].num_batches_tracked) == 3
+    dist.destroy_process_group()
+
+
+def test_broadcast_module_states_two_ranks_gloo():
+    world = 2
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_worker_bcast, args=(world, _free_port(), out), nprocs=world, join=True)
+        assert dict(out) == {0: True, 1: True}

@@ -1,0 +1,104 @@
+"""GPU: the BASELINE configurations at their FULL WIDTH (reduced depth), 588x588, batch 2, against goldens produced by the
+imported reference modules (tests/golden/make_golden.py: c2_case / c5_case / step_case(batch=2)):
+
+  * config 2 — ViT-B width (D = 768, 12 heads, MSDA head dim 96) + CAViT / CACNN (768) + UNet(768), CE + DC;
+  * config 5 — ViT-g width (D = 1536, 24 heads, SwiGLU 8192 -> 4096, MSDA head dim 192) + adapters + DecoderMLA,
+    11 classes, softmax -> soft-IoU;
+  * config 3 at batch 2 — the whole ViT-L/14 step with the decoder's train-mode BatchNorm statistics taken over B > 1.
+
+north_star tolerance: 1e-3 relative (rel-L2) on the logits."""
+import pytest
+import torch
+
+from adaptersis_amd import ops
+from adaptersis_amd.backbones.adapter_blocks import CACNN, CAViT
+from adaptersis_amd.backbones.decoders import DecoderMLA
+from adaptersis_amd.backbones.encoders import FeatureEncoder
+from adaptersis_amd.backbones.engines import SegEngine
+from adaptersis_amd.backbones.unet_parts import UNet
+from adaptersis_amd.dinov2.models import vision_transformer as vits
+from adaptersis_amd.utils import weights as W
+from tests.conftest import golden_err, load_golden
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+def _adapter_modules(arch, dev):
+    D, depth, heads, ffn = W.VIT_CONFIGS[arch]
+    model = vits.__dict__[arch](patch_size=14, img_size=518, init_values=1e-5, ffn_layer=ffn, block_chunks=0)
+    model.load_state_dict(W.make_vit_state_dict(arch, layerscale="kernel"))
+    enc = FeatureEncoder(embed_dim=D); enc.load_state_dict(W.make_encoder_state_dict(D))
+    cv = CAViT(dim=D, n_levels=3, num_heads=8, init_values=0.0, n_points=4); cv.load_state_dict(W.make_cavit_state_dict(D, mode="kernel"))
+    cn = CACNN(dim=D, n_levels=1, num_heads=8, n_points=4, with_cffn=True, cffn_ratio=0.25)
+    cn.load_state_dict(W.make_cacnn_state_dict(D, mode="kernel"))
+    return D, model.to(dev).eval(), enc.to(dev), cv.to(dev), cn.to(dev)
+
+
+def _grad_report(tag, views, g, prefix):
+    errs = {k: golden_err(v, g[prefix + k]) for k, v in views.items() if float(g[prefix + k]["sumsq"]) > 1e-18}
+    v = sorted(errs.values())
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:4]
+    print(f"{tag} grads: n={len(errs)} max {v[-1]:.2e} median {v[len(v) // 2]:.2e} worst {[(k, '%.1e' % e) for k, e in worst]}")
+    return v[-1], v[len(v) // 2]
+
+
+def test_config2_vitb_width_unet768_step_vs_reference_golden(dev):
+    g = load_golden("c2")
+    D, model, enc, cv, cn = _adapter_modules("vit_base_d4", dev)
+    dec = UNet(D, 2); dec.load_state_dict(W.make_unet_state_dict(D, 2))
+    eng = SegEngine(model, enc, cv, cn, dec.to(dev), lr=0.01, loss="ce_dc")
+    img, tgt = W.synthetic_batch(2, 588)
+    taps = {}
+    loss = eng.train_step(img.to(dev), tgt.to(dev), taps)
+    e_x = golden_err(taps["x_final"], g["c2.x_final"])
+    e_c = golden_err(taps["c_final"], g["c2.c_final"])
+    e_lg = golden_err(taps["logits"].permute(0, 3, 1, 2), g["c2.logits"])
+    print(f"config 2 (D=768): x_final {e_x:.2e} c_final {e_c:.2e} logits {e_lg:.2e} loss {float(loss):.6f} golden {float(g['c2.loss']):.6f}")
+    assert e_x < TOL and e_c < TOL
+    assert e_lg < TOL
+    assert abs(float(loss) - float(g["c2.loss"])) < 1e-4
+    gmax, gmed = _grad_report("config 2", eng.bucket.views, g, "c2.grad.")
+    assert gmax < 1e-1 and gmed < 3e-2     # step-level conditioning; kernels on exact inputs: test_gpu_unet.py
+
+
+def test_config5_vitg_width_mla11_step_vs_reference_golden(dev):
+    g = load_golden("c5")
+    D, model, enc, cv, cn = _adapter_modules("vit_giant2_d4", dev)
+    dec = DecoderMLA(img_size=588, mla_channels=D, mlahead_channels=128, num_classes=11)
+    dec.load_state_dict(W.make_decoder_mla_state_dict(D, 128, 11))
+    eng = SegEngine(model, enc, cv, cn, dec.to(dev), lr=0.01, momentum=0.9, weight_decay=0.0, num_classes=11, loss="iou")
+    img, tgt = W.synthetic_batch(2, 588, 11)
+    taps = {}
+    loss = eng.train_step(img.to(dev), tgt.to(dev), taps)
+    for i, t in enumerate(taps["mla_inputs"]):
+        e = golden_err(t.transpose(1, 2).reshape(2, D, 42, 42), g[f"c5.in{i}"])
+        print(f"config 5 (D=1536, SwiGLU): MLA input {i} rel-L2 {e:.2e}")
+        assert e < TOL, (i, e)
+    out = ops.resize_bilinear_fwd(taps["logits"], 588, 588).permute(0, 3, 1, 2)
+    e_out = golden_err(out, g["c5.output"])
+    print(f"config 5: output (11 classes, 588^2) rel-L2 {e_out:.2e} loss {float(loss):.6f} golden {float(g['c5.loss']):.6f}")
+    assert e_out < TOL
+    assert abs(float(loss) - float(g["c5.loss"])) < 1e-4
+    gmax, gmed = _grad_report("config 5", eng.bucket.views, g, "c5.grad.")
+    assert gmax < 1e-1 and gmed < 3e-2
+
+
+@pytest.mark.parametrize("mode,tag", [("init", "step_b2_exact"), ("kernel", "step_b2_kernel")])
+def test_vitl_588_batch2_step_vs_reference_golden(dev, mode, tag):
+    from tests.test_gpu_step import build_engine
+    g = load_golden("step_b2")
+    eng, _ = build_engine("vit_large", mode, dev)
+    img, tgt = W.synthetic_batch(2, 588)
+    taps = {}
+    loss = eng.train_step(img.to(dev), tgt.to(dev), taps)
+    e = {"cat": golden_err(taps["cat"].float().permute(0, 3, 1, 2), g[f"{tag}.cat"]),
+         "x_final": golden_err(taps["x_final"], g[f"{tag}.x_final"]),
+         "c_final": golden_err(taps["c_final"], g[f"{tag}.c_final"]),
+         "logits": golden_err(taps["logits"].permute(0, 3, 1, 2), g[f"{tag}.logits"])}
+    print(tag, {k: "%.2e" % v for k, v in e.items()}, "loss", float(loss), "golden", float(g[f"{tag}.loss"]))
+    assert e["logits"] < TOL, e
+    assert e["cat"] < 2 * TOL and e["x_final"] < 2 * TOL and e["c_final"] < 2 * TOL, e
+    assert abs(float(loss) - float(g[f"{tag}.loss"])) < 1e-4
+    gmax, gmed = _grad_report(tag, eng.bucket.views, g, f"{tag}.grad.")
+    assert gmax < 1e-1

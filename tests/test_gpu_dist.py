@@ -55,3 +55,53 @@ def test_two_rank_step_matches_gradient_average(dev):
     eng.train_step(img.to(dev), tgt.to(dev))
     full_rm = eng.backbone_encoder.stem[1].running_mean.cpu()
     assert torch.allclose(full_rm, r0["rm"], rtol=1e-5, atol=1e-7), "2-rank SyncBN == 1-rank BN over the whole batch"
+
+
+def _worker_enc(rank, world, port, out):
+    """FeatureEncoder forward + backward (SyncBatchNorm in both directions) on this rank's half of the batch."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    out[rank] = _encoder_grads(slice(rank * 2, rank * 2 + 2), 1.0 / world, reduce=True)
+    dist.destroy_process_group()
+
+
+def _encoder_grads(sl, inv, reduce):
+    from adaptersis_amd.backbones.encoders import FeatureEncoder
+    from adaptersis_amd.utils import weights as W
+    dev = torch.device("cuda:0")
+    D = 128
+    enc = FeatureEncoder(embed_dim=D)
+    enc.load_state_dict(W.make_encoder_state_dict(D))
+    enc = enc.to(dev)
+    img, _ = W.synthetic_batch(4, 224, seed=11)
+    c, shapes, saved = enc.forward_tokens_train(img[sl].to(dev))
+    dc = W.tensor("dist.dc", (4, c.shape[1], D), 1.0)[sl].to(dev).contiguous()
+    grads = {n: torch.zeros_like(p) for n, p in enc.named_parameters()}
+    enc.backward_tokens(saved, dc, inv, grads)
+    if reduce:
+        flat = torch.cat([g.reshape(-1) for g in grads.values()])
+        dist.all_reduce(flat)            # what the engine's encoder bucket reducer does (SUM of 1/world-scaled gradients)
+        o = 0
+        for g in grads.values():
+            g.copy_(flat[o:o + g.numel()].view(g.shape)); o += g.numel()
+    torch.cuda.synchronize()
+    return {n: g.cpu() for n, g in grads.items()}
+
+
+def test_two_rank_encoder_backward_matches_full_batch(dev):
+    """SyncBatchNorm gamma / beta gradients must be LOCAL sums (averaged by the bucket all-reduce), not the
+    all-reduced sums again — 2 ranks x half batch == 1 process x full batch for every encoder parameter."""
+    world = 2
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_worker_enc, args=(world, _free_port(), out), nprocs=world, join=True)
+        r0, r1 = out[0], out[1]
+    full = _encoder_grads(slice(0, 4), 1.0 / world, reduce=False)
+    for n, g in full.items():
+        assert torch.equal(r0[n], r1[n]), n
+        if float(g.norm()) == 0:
+            continue
+        err = float((r0[n].double() - g.double()).norm() / g.double().norm())
+        assert err < 2e-3, (n, err)

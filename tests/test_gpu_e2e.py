@@ -1,0 +1,178 @@
+"""GPU: BASELINE config 4 as SURVEY.md §8 defines it — the `train.py` adapter flow with the backbone UNFROZEN
+(`train.py:268-436` minus its no_grad / inference_mode regions; unfreezing pattern of
+`eval/eval_dinov2_setr_cross_ete.py:145-148,307-361`): ``SegEngine(mode="train_adapters", train_encoder=True,
+train_backbone=True)`` against autograd of the CPU oracle with the whole graph intact — every parameter of the ViT
+(both passes), CAViT, CACNN, the encoder and the decoder."""
+import pytest
+import torch
+
+from adaptersis_amd.backbones.adapter_blocks import CACNN, CAViT
+from adaptersis_amd.backbones.decoders import FeatureDecoder
+from adaptersis_amd.backbones.encoders import FeatureEncoder
+from adaptersis_amd.backbones.engines import SegEngine
+from adaptersis_amd.dinov2.models import vision_transformer as vits
+from adaptersis_amd.utils import weights as W
+from oracle import ref_torch as O
+from tests.conftest import golden_err, load_golden, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def build_e2e_engine(arch, dev, feats, lr=0.05, **kw):
+    D, depth, heads, ffn = W.VIT_CONFIGS[arch]
+    sds = dict(vit=W.make_vit_state_dict(arch, layerscale="kernel"), enc=W.make_encoder_state_dict(D),
+               cv=W.make_cavit_state_dict(D, mode="kernel"), cn=W.make_cacnn_state_dict(D, mode="kernel"),
+               dec=W.make_feature_decoder_state_dict(D, 2, features=feats))
+    model = vits.__dict__[arch](patch_size=14, img_size=518, init_values=1e-5, ffn_layer=ffn, block_chunks=0)
+    model.load_state_dict(sds["vit"])
+    enc = FeatureEncoder(embed_dim=D); enc.load_state_dict(sds["enc"])
+    cv = CAViT(dim=D, n_levels=3, num_heads=8, init_values=0.0, n_points=4); cv.load_state_dict(sds["cv"])
+    cn = CACNN(dim=D, n_levels=1, num_heads=8, n_points=4, with_cffn=True, cffn_ratio=0.25); cn.load_state_dict(sds["cn"])
+    dec = FeatureDecoder(embed_dim=D, num_classes=2, features=list(feats)); dec.load_state_dict(sds["dec"])
+    eng = SegEngine(model.to(dev), enc.to(dev), cv.to(dev), cn.to(dev), dec.to(dev), lr=lr, mode="train_adapters",
+                    train_encoder=True, train_backbone=True, **kw)
+    return eng, sds
+
+
+def _stats(errs):
+    v = sorted(errs.values())
+    return max(v), v[len(v) // 2]
+
+
+def test_unfrozen_adapter_step_vs_oracle_autograd(dev):
+    arch, size, B = "vit_tiny_test", 224, 2
+    D, depth, heads, ffn = W.VIT_CONFIGS[arch]
+    feats = (128, 32, 16, 16, 8)
+    eng, sds = build_e2e_engine(arch, dev, feats, blocks_per_bucket=2)
+    img, tgt = W.synthetic_batch(B, size)
+
+    def leaf(sd, skip=()):
+        return {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k and "num_batches" not in k and k not in skip)
+                for k, v in sd.items()}
+    ovit, oenc, ocv, ocn, odec = leaf(sds["vit"]), leaf(sds["enc"]), leaf(sds["cv"]), leaf(sds["cn"]), leaf(sds["dec"])
+    ocat = O.adapter_forward(img, ovit, oenc, ocv, ocn, heads)
+    otaps = {}
+    oloss = O.train_step_loss(ocat, tgt, odec, 2, otaps, update_bn=True)
+    oloss.backward()
+    taps = {}
+    loss = eng.train_step(img.to(dev), tgt.to(dev), taps)
+    torch.cuda.synchronize()
+    e_lg = rel_l2(taps["logits"].permute(0, 3, 1, 2), otaps["logits"])
+    print(f"unfrozen step: logits {e_lg:.2e} loss {float(loss):.6f} oracle {float(oloss):.6f}")
+    assert e_lg < 1.5e-3          # toy-width stress weights (tests/test_gpu_step.py)
+    assert abs(float(loss) - float(oloss)) < 1e-4
+
+    def group(views, ref, strip=""):
+        out = {}
+        for k, v in views.items():
+            r = ref[k[len(strip):]].grad
+            if r is not None and float(r.norm()) > 0:
+                out[k] = rel_l2(v, r)
+        return out
+    verr = group(eng.vit_bucket.views, ovit)
+    aerr = {}
+    for k, v in eng.adapter_bucket.views.items():
+        mod, name = k.split(".", 1)
+        r = (ocv if mod == "cross_vit" else ocn)[name].grad
+        if r is not None and float(r.norm()) > 0:
+            aerr[k] = rel_l2(v, r)
+    eerr = group(eng.encoder_bucket.views, oenc, "backbone_encoder.")
+    derr = {k: rel_l2(v, odec[k].grad) for k, v in eng.bucket.views.items() if not k.endswith(".0.bias")}
+    for nm, e in (("vit", verr), ("adapters", aerr), ("encoder", eerr), ("decoder", derr)):
+        worst = sorted(e.items(), key=lambda kv: -kv[1])[:4]
+        print(f"  {nm}: n={len(e)} max %.2e median %.2e  worst %s" % (*_stats(e), [(k, "%.1e" % v) for k, v in worst]))
+    # every backbone parameter that the oracle gives a gradient has one here (both passes summed), incl. the embeddings
+    assert set(verr) >= {"cls_token", "pos_embed", "patch_embed.proj.weight", "norm.weight", "blocks.0.attn.qkv.weight",
+                         f"blocks.{depth - 1}.mlp.fc2.weight", f"blocks.{depth - 1}.ls2.gamma"}
+    assert float(eng.vit_bucket.views["mask_token"].abs().sum()) == 0
+    # step-level bounds (ReLU branch flips in the decoder / sampling-cell crossings in MSDA set the floor for everything
+    # upstream: DESIGN.md §3; the kernels themselves are checked on exact inputs in test_gpu_vit_bwd / test_gpu_adapter_bwd)
+    assert _stats(verr)[0] < 2.5e-1 and _stats(verr)[1] < 5e-2, verr
+    assert _stats(aerr)[0] < 2.5e-1 and _stats(aerr)[1] < 5e-2, aerr
+    assert _stats(eerr)[0] < 2.5e-1 and _stats(eerr)[1] < 1e-1, eerr
+    assert _stats(derr)[0] < 1e-1, derr
+    # optimiser: decoder + adapters + encoder are stepped; the backbone gradients are exchanged but not applied
+    # (`eval_dinov2_setr_cross_ete.py:224-229`) unless optimize_backbone is set
+    assert len(eng.optimizer.param_groups) == 3 and eng.vit_bucket.momentum is None
+    assert torch.equal(dict(eng.model.named_parameters())["blocks.0.attn.qkv.weight"].detach().cpu(),
+                       sds["vit"]["blocks.0.attn.qkv.weight"])
+
+
+def test_unfrozen_step_optimizes_backbone_when_asked(dev):
+    eng, sds = build_e2e_engine("vit_tiny_test", dev, (128, 32, 16, 16, 8), optimize_backbone=True)
+    img, tgt = W.synthetic_batch(2, 224)
+    l0 = float(eng.train_step(img.to(dev), tgt.to(dev)))
+    assert len(eng.optimizer.param_groups) == 4
+    w = dict(eng.model.named_parameters())["blocks.0.attn.qkv.weight"].detach().cpu()
+    assert not torch.equal(w, sds["vit"]["blocks.0.attn.qkv.weight"])
+    l1 = float(eng.train_step(img.to(dev), tgt.to(dev)))     # packed 16-bit weight copies follow the update
+    assert l1 == l1 and l1 != l0
+
+
+def test_unfrozen_vitl_width_step_vs_reference_golden(dev):
+    """ViT-L width (D = 1024, 16 heads, N = 1764 + cls, 4 blocks) at 588x588: the golden is the imported reference's own
+    modules under autograd with the no_grad regions removed (tests/golden/make_golden.py:c4_case)."""
+    g = load_golden("c4")
+    eng, _ = build_e2e_engine("vit_large_d4", dev, (1024, 512, 256, 128, 64), lr=0.01)
+    img, tgt = W.synthetic_batch(1, 588)
+    taps = {}
+    loss = eng.train_step(img.to(dev), tgt.to(dev), taps)
+    e_lg = golden_err(taps["logits"].permute(0, 3, 1, 2), g["c4.logits"])
+    e_cat = golden_err(taps["cat"].float().permute(0, 3, 1, 2), g["c4.cat"])
+    print(f"c4 golden: cat {e_cat:.2e} logits {e_lg:.2e} loss {float(loss):.6f} golden {float(g['c4.loss']):.6f}")
+    assert e_lg < 1e-3 and e_cat < 1e-3
+    assert abs(float(loss) - float(g["c4.loss"])) < 1e-4
+    groups = {"vit": (eng.vit_bucket.views, "c4.grad.vit."), "adapter": (eng.adapter_bucket.views, "c4.grad."),
+              "encoder": (eng.encoder_bucket.views, "c4.grad."), "decoder": (eng.bucket.views, "c4.grad.dec.")}
+    for nm, (views, pre) in groups.items():
+        errs = {k: golden_err(v, g[pre + k]) for k, v in views.items()
+                if (pre + k) in g and float(g[pre + k]["sumsq"]) > 1e-20}
+        worst = sorted(errs.items(), key=lambda kv: -kv[1])[:4]
+        print(f"  {nm}: n={len(errs)} max %.2e median %.2e  worst %s" % (*_stats(errs), [(k, "%.1e" % v) for k, v in worst]))
+        assert len(errs) >= 10
+        assert _stats(errs)[0] < 2.5e-1 and _stats(errs)[1] < 5e-2, (nm, worst)
+
+
+def test_unfrozen_backward_on_fixed_cotangent(dev):
+    """The backward walk of the unfrozen flow ALONE: a fixed cotangent is injected at the decoder input (no decoder, no
+    loss), so neither ReLU / BatchNorm branch flips of the head nor the Dice conditioning blur the comparison — what is
+    left is 16-bit operand rounding (~1e-3) and, only on paths through d(sampling offsets), MSDA cell crossings."""
+    from adaptersis_amd import config
+    arch, size, B = "vit_tiny_test", 224, 2
+    D, depth, heads, ffn = W.VIT_CONFIGS[arch]
+    eng, sds = build_e2e_engine(arch, dev, (128, 32, 16, 16, 8), blocks_per_bucket=2)
+    img, _ = W.synthetic_batch(B, size)
+    h = size // 14
+    dcat = W.tensor("e2e.dcat", (B, h, h, 3 * D), 1.0)
+
+    def leaf(sd):
+        return {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k and "num_batches" not in k)
+                for k, v in sd.items()}
+    ovit, oenc, ocv, ocn = leaf(sds["vit"]), leaf(sds["enc"]), leaf(sds["cv"]), leaf(sds["cn"])
+    ocat = O.adapter_forward(img, ovit, oenc, ocv, ocn, heads)
+    (ocat * dcat.permute(0, 3, 1, 2)).sum().backward()
+    with torch.no_grad():
+        cat, saved = eng._features_e2e(img.to(dev))
+        assert rel_l2(cat[0].float().permute(0, 3, 1, 2) + (cat[1].float().permute(0, 3, 1, 2) if cat[1] is not None else 0),
+                      ocat) < 1e-3
+        for r in (eng.adapter_reducer, eng.encoder_reducer, eng.vit_reducer):
+            r.begin()
+        eng._e2e_backward(saved, dcat.to(dev).contiguous(), 1.0)
+    torch.cuda.synchronize()
+    verr = {k: rel_l2(v, ovit[k].grad) for k, v in eng.vit_bucket.views.items()
+            if ovit[k].grad is not None and float(ovit[k].grad.norm()) > 0}
+    aerr = {}
+    for k, v in eng.adapter_bucket.views.items():
+        mod, name = k.split(".", 1)
+        r = (ocv if mod == "cross_vit" else ocn)[name].grad
+        if r is not None and float(r.norm()) > 0:
+            aerr[k] = rel_l2(v, r)
+    eerr = {k: rel_l2(v, oenc[k[len("backbone_encoder."):]].grad) for k, v in eng.encoder_bucket.views.items()
+            if oenc[k[len("backbone_encoder."):]].grad is not None and float(oenc[k[len("backbone_encoder."):]].grad.norm()) > 0}
+    for nm, e in (("vit", verr), ("adapters", aerr), ("encoder", eerr)):
+        worst = sorted(e.items(), key=lambda kv: -kv[1])[:6]
+        print(f"  fixed cotangent {nm}: n={len(e)} max %.2e median %.2e  worst %s" % (*_stats(e), [(k, "%.1e" % v) for k, v in worst]))
+    assert len(verr) == 62 and len(aerr) == 33
+    assert _stats(verr)[1] < 5e-3 and _stats(verr)[0] < 5e-2, verr
+    assert _stats(aerr)[1] < 5e-3 and _stats(aerr)[0] < 1e-1, aerr
+    assert _stats(eerr)[1] < 2e-2 and _stats(eerr)[0] < 1e-1, eerr
