@@ -136,7 +136,7 @@ class FeatureEncoder(_Packed):
         scale, shift, mean, invstd, count = _bn.finalize(ops.colstats(raw0), raw0.numel() // raw0.shape[-1], st[1], sync_bn)
         a = self._pair(ops.bn_act(raw0, scale, shift, True, dt, sp), sp)
         # the image as an 8-channel 16-bit NHWC operand of the stem's weight-gradient GEMM (channels 3..7 zero)
-        x8 = ops.cast_pad(x.permute(0, 2, 3, 1).reshape(B * H * W, 3), 8, dt).view(B, H, W, 8)
+        x8 = ops.cast_pad(x.permute(0, 2, 3, 1).contiguous().view(B * H * W, 3), 8, dt).view(B, H, W, 8)
         saved = {"stem0": (x8, raw0, scale, shift, mean, invstd, count)}
         a, saved["stem3"] = stage(self, "stem3", a[0], a[1], st[3], st[4], 1, sync_bn, True)
         s1, saved["stem6"] = stage(self, "stem6", a[0], a[1], st[6], st[7], 1, sync_bn, True, pool=True)

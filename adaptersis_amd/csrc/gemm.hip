@@ -247,6 +247,7 @@ int launch(hipStream_t s, const asis_gemm_desc& d) {
     }
     return 0;
   }
+  static const int m16 = [] { const char* e = getenv("ASIS_GEMM_M16"); return e ? atoi(e) : 1; }();  // 16x16x32 MFMAs in the default dense form
   static const int noepi = [] { const char* e = getenv("ASIS_GEMM_NOEPI"); return e ? atoi(e) : 0; }();  // lab: main loop only
   // ASIS_GEMM_8P: 0 = never, 1 (default) = long reductions only (K >= 2048: fc2 / its input gradient, where the 8-phase
   // loop is 17-20 % faster in the step: 397 vs 476 us at 42348x1024x4096; at K = 1024 the two forms tie and the
@@ -275,6 +276,7 @@ int launch(hipStream_t s, const asis_gemm_desc& d) {
     else if (noepi == 32) hipLaunchKernelGGL((gemm_big_kernel<T, 4, 2, 2, 2, 3, 32, false, false, 32, 4>), grid, block, 0, s, d, group_m);
     else if (noepi == 40) hipLaunchKernelGGL((gemm_big_kernel<T, 4, 2, 2, 2, 3, 40, false, false, 32, 4>), grid, block, 0, s, d, group_m);
     else if (noepi) hipLaunchKernelGGL((gemm_big_kernel<T, 4, 2, 2, 2, 3, 4, false, false, 32, 4>), grid, block, 0, s, d, group_m);
+    else if (m16) hipLaunchKernelGGL((gemm_big_kernel<T, 4, 2, 2, 2, 3, 0, false, false, 32, 4, false, true>), grid, block, 0, s, d, group_m);
     else hipLaunchKernelGGL((gemm_big_kernel<T, 4, 2, 2, 2, 3, 0, false, false, 32, 4>), grid, block, 0, s, d, group_m);
     return 0;
   }

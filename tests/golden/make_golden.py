@@ -744,6 +744,10 @@ def c5_case(R, out, arch="vit_giant2_d4", batch=2, tag="c5", ncls=11):
     out[f"{tag}.output"] = sub(output, 40000)
     out[f"{tag}.loss"] = loss.detach().clone()
     for k, p in dec.named_parameters():
+        if k in ("cls.0.bias", "cls_1.0.bias", "cls_2.0.bias"):
+            # a conv bias in front of a train-mode BatchNorm: the exact gradient is 0, both sides hold cancellation noise
+            assert float(p.grad.norm()) < 1e-6 * float(dict(dec.named_parameters())[k[:-4] + "weight"].grad.norm())
+            continue
         close(osd[k].grad, p.grad, 2e-3, f"{tag} grad {k}")
         out[f"{tag}.grad.{k}"] = sub(p.grad, 3000)
 

@@ -36,7 +36,8 @@ def _adapter_modules(arch, dev):
 
 
 def _grad_report(tag, views, g, prefix):
-    errs = {k: golden_err(v, g[prefix + k]) for k, v in views.items() if float(g[prefix + k]["sumsq"]) > 1e-18}
+    errs = {k: golden_err(v, g[prefix + k]) for k, v in views.items()
+            if (prefix + k) in g and not k.endswith(".0.bias") and float(g[prefix + k]["sumsq"]) > 1e-18}
     v = sorted(errs.values())
     worst = sorted(errs.items(), key=lambda kv: -kv[1])[:4]
     print(f"{tag} grads: n={len(errs)} max {v[-1]:.2e} median {v[len(v) // 2]:.2e} worst {[(k, '%.1e' % e) for k, e in worst]}")
