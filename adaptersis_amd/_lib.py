@@ -141,6 +141,7 @@ SIGNATURES = {
     "asis_wgrad_splits": [_i64, _i, _i],
     "asis_wgrad": [_vp, C.POINTER(WgradDesc)],
     "asis_sgd_momentum": [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i],
+    "asis_augment": [_vp] * 13 + [_i, _i],
     "asis_grad_guard": [_vp, _vp, _i64, _vp, _i],
     "asis_sgd_momentum_guarded": [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i, _vp],
     "asis_scale_f32": [_vp, _vp, _i64, _f],

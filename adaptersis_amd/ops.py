@@ -951,3 +951,30 @@ def sgd_momentum(p: torch.Tensor, g: torch.Tensor, buf: torch.Tensor, lr: float,
     check(lib().asis_sgd_momentum(_stream(), _f32c(p).data_ptr(), _f32c(g).data_ptr(), _f32c(buf).data_ptr(), p.numel(),
                                   float(lr), float(momentum), float(weight_decay), float(inv_scale), int(first_step)),
           "asis_sgd_momentum")
+
+
+# --------------------------------------------------------------------------------------------
+# input pipeline
+# --------------------------------------------------------------------------------------------
+def augment(img_u8: torch.Tensor, mask_u8: torch.Tensor, tables: dict):
+    """uint8 [B,S,S,3] / uint8 [B,S,S] + the per-sample tables of ``tools.augment.TrainAugment.tables`` ->
+    (fp32 [B,3,S,S] in [0,1], int64 [B,S,S])."""
+    _dev(img_u8, mask_u8, *tables.values())
+    B, S = img_u8.shape[0], img_u8.shape[1]
+    if img_u8.dtype != torch.uint8 or mask_u8.dtype != torch.uint8 or img_u8.shape != (B, S, S, 3) or mask_u8.shape != (B, S, S) \
+            or not img_u8.is_contiguous() or not mask_u8.is_contiguous():
+        raise ValueError("augment: img uint8 [B,S,S,3] and mask uint8 [B,S,S], contiguous")
+    want = {"geo": (torch.int32, (B, 4)), "xofs": (torch.int32, (B, S)), "yofs": (torch.int32, (B, S)),
+            "xa": (torch.int16, (B, S, 2)), "ya": (torch.int16, (B, S, 2)), "mx": (torch.int32, (B, S)),
+            "my": (torch.int32, (B, S)), "lut": (torch.uint8, (B, 256))}
+    for k, (dt, shp) in want.items():
+        t = tables[k]
+        if t.dtype != dt or tuple(t.shape) != shp or not t.is_contiguous():
+            raise ValueError(f"augment: table {k} must be contiguous {dt} {shp}")
+    out = torch.empty((B, 3, S, S), device=img_u8.device, dtype=torch.float32)
+    mout = torch.empty((B, S, S), device=img_u8.device, dtype=torch.int64)
+    check(lib().asis_augment(_stream(), img_u8.data_ptr(), mask_u8.data_ptr(), tables["geo"].data_ptr(),
+                             tables["xofs"].data_ptr(), tables["yofs"].data_ptr(), tables["xa"].data_ptr(),
+                             tables["ya"].data_ptr(), tables["mx"].data_ptr(), tables["my"].data_ptr(), tables["lut"].data_ptr(),
+                             out.data_ptr(), mout.data_ptr(), B, S), "asis_augment")
+    return out, mout

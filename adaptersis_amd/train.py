@@ -94,10 +94,7 @@ def train_seg(args, head: str = "feature"):
     model = vits.__dict__[arch](patch_size=args.patch_size, img_size=518, init_values=1e-5, ffn_layer=ARCH_FFN[arch],
                                 block_chunks=0)
     if args.pretrained_weights and os.path.isfile(args.pretrained_weights):
-        sd = torch.load(args.pretrained_weights, map_location="cpu")
-        sd = sd.get(args.checkpoint_key, sd) if isinstance(sd, dict) else sd
-        sd = {k.replace("module.", "").replace("backbone.", ""): v for k, v in sd.items()}  # dinov2/utils/utils.py:20-33
-        print("Pretrained weights loaded with msg:", model.load_state_dict(sd, strict=False))
+        utils.load_pretrained_weights(model, args.pretrained_weights, args.checkpoint_key)   # dinov2/utils/utils.py:20-33
     else:
         model.load_state_dict(W.make_vit_state_dict(arch, patch_size=args.patch_size, layerscale="init"))
         print("No pretrained weights: deterministic synthetic initialisation (adaptersis_amd.utils.weights)")

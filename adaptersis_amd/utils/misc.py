@@ -169,3 +169,22 @@ def restart_from_checkpoint(ckp_path, run_variables=None, **kwargs):
         for name in run_variables:
             if name in checkpoint:
                 run_variables[name] = checkpoint[name]
+
+
+def load_pretrained_weights(model, pretrained_weights, checkpoint_key):
+    """`dinov2/utils/utils.py:20-33`: load a DINOv2 ``.pth`` into the backbone — take ``checkpoint_key`` ("teacher") when the
+    file holds it, strip the ``module.`` (DDP) and ``backbone.`` (multi-crop wrapper) prefixes, ``strict=False`` (the
+    checkpoints also carry the DINO / iBOT heads).  Local files only: there is no network on this path (an URL raises).
+    Returns torch's (missing_keys, unexpected_keys) message."""
+    from urllib.parse import urlparse
+    if urlparse(str(pretrained_weights)).scheme not in ("", "file"):
+        raise ValueError("load_pretrained_weights: URL checkpoints need a network; download the file and pass its path")
+    state_dict = torch.load(pretrained_weights, map_location="cpu")
+    if checkpoint_key is not None and isinstance(state_dict, dict) and checkpoint_key in state_dict:
+        print(f"Take key {checkpoint_key} in provided checkpoint dict")
+        state_dict = state_dict[checkpoint_key]
+    state_dict = {k.replace("module.", ""): v for k, v in state_dict.items()}
+    state_dict = {k.replace("backbone.", ""): v for k, v in state_dict.items()}
+    msg = model.load_state_dict(state_dict, strict=False)
+    print("Pretrained weights found at {} and loaded with msg: {}".format(pretrained_weights, msg))
+    return msg

@@ -53,7 +53,7 @@ def build_engine(arch: str, dev, lr: float, mode: str = "reference_exact", train
                      train_encoder=train_encoder)
 
 
-def build_engine_cfg(cfg: int, arch: str, dev, lr: float):
+def build_engine_cfg(cfg: int, arch: str, dev, lr: float, setr_only: bool = False):
     """BASELINE configs other than the headline one: 2 = ViT-B + adapters + UNet head (CE + DC), 4 = unfrozen
     end-to-end ViT + DecoderSETR (full backward, backbone gradients all-reduced, decoder-only optimiser)."""
     from adaptersis_amd.backbones.adapter_blocks import CACNN, CAViT
@@ -84,7 +84,8 @@ def build_engine_cfg(cfg: int, arch: str, dev, lr: float):
                     p.copy_(0.2 * (torch.rand(p.shape, device=dev, generator=g) - 0.5))
     else:
         model.load_state_dict(W.make_vit_state_dict(arch, layerscale="kernel"))
-    if cfg == 4:
+    if cfg == 4 and setr_only:
+        # the reference's own end-to-end script (`eval/eval_dinov2_setr_cross_ete.py`): ViT -> DecoderSETR, no adapters
         dec = DecoderSETR(D, 2)
         dec.load_state_dict(W.make_setr_state_dict(D, 2))
         return EndToEndEngine(model.to(dev), dec.to(dev), lr=lr)
@@ -94,6 +95,14 @@ def build_engine_cfg(cfg: int, arch: str, dev, lr: float):
     cv.load_state_dict(W.make_cavit_state_dict(D, mode="kernel"))
     cn = CACNN(dim=D, n_levels=1, num_heads=8, n_points=4, with_cffn=True, cffn_ratio=0.25)
     cn.load_state_dict(W.make_cacnn_state_dict(D, mode="kernel"))
+    if cfg == 4:
+        # BASELINE config 4: the train.py adapter flow with the backbone unfrozen — both ViT passes with
+        # weight gradients, adapters + encoder + decoder trained, 304 M + 31 M gradients all-reduced in buckets
+        from adaptersis_amd.backbones.decoders import FeatureDecoder
+        dec = FeatureDecoder(embed_dim=D, num_classes=2, features=[D, 512, 256, 128, 64])
+        dec.load_state_dict(W.make_feature_decoder_state_dict(D, 2, features=(D, 512, 256, 128, 64)))
+        return SegEngine(model.to(dev), enc.to(dev), cv.to(dev), cn.to(dev), dec.to(dev), lr=lr, mode="train_adapters",
+                         train_encoder=True, train_backbone=True)
     if cfg == 5:
         from adaptersis_amd.backbones.decoders import DecoderMLA
         dec = DecoderMLA(img_size=588, mla_channels=D, num_classes=11)
@@ -249,6 +258,7 @@ def main():
     ap.add_argument("--train-adapters", action="store_true",
                     help="config 3 with the adapter backward (CAViT + CACNN gradients, all-reduced and optimised with the decoder)")
     ap.add_argument("--train-encoder", action="store_true", help="with --train-adapters: also the CNN encoder (the full optimiser list of train.py:178-186)")
+    ap.add_argument("--e2e-setr", action="store_true", help="config 4 as the reference's own end-to-end script: ViT -> DecoderSETR without adapters")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--cpu-baseline-batch", type=int, default=1, help="batch of the timed CPU (oracle) step: 1 or 2")
@@ -291,7 +301,7 @@ def main():
         eng = build_engine(a.arch, dev, lr=0.01, mode="train_adapters" if a.train_adapters else "reference_exact",
                            train_encoder=a.train_encoder)
     else:
-        eng = build_engine_cfg(a.config, a.arch, dev, lr=0.01)
+        eng = build_engine_cfg(a.config, a.arch, dev, lr=0.01, setr_only=a.e2e_setr)
     img, tgt = synthetic(a.batch, a.size, rank, dev, 11 if a.config == 5 else 2)
 
     def barrier():
@@ -369,9 +379,12 @@ def main():
                    f"{a.size}x{a.size}, batch {a.batch}/GPU (fwd + UNet bwd + all-reduce + SGD), random-init weights",
                 5: f"BASELINE config 5: {a.arch}/14 (SwiGLU) frozen + CAViT/CACNN adapters + DecoderMLA head, 11 classes, soft-IoU "
                    f"loss (train_mla.py / train_multi_class.py flow), {a.size}x{a.size}, batch {a.batch}/GPU, random-init weights",
-                4: f"BASELINE config 4: {a.arch}/14 unfrozen end-to-end + DecoderSETR, CE + DC loss, {a.size}x{a.size}, "
-                   f"batch {a.batch}/GPU (fwd + full bwd incl. all ViT blocks + full-gradient all-reduce + decoder SGD), "
-                   "random-init weights"}[a.config],
+                4: (f"BASELINE config 4: {a.arch}/14 unfrozen end-to-end + DecoderSETR, CE + DC loss, {a.size}x{a.size}, "
+                    f"batch {a.batch}/GPU (fwd + full bwd incl. all ViT blocks + full-gradient all-reduce + decoder SGD), "
+                    "random-init weights") if a.e2e_setr else
+                   (f"BASELINE config 4: {a.arch}/14 UNFROZEN in the train.py adapter flow (both ViT passes with weight "
+                    f"gradients) + CAViT/CACNN + encoder + FeatureDecoder all trained, {a.size}x{a.size}, batch {a.batch}/GPU "
+                    "(fwd + full bwd + bucketed all-reduce of backbone/adapter/encoder/decoder gradients + SGD), random-init weights")}[a.config],
                        "global_batch": global_batch, "image_size": a.size, "parallelism": f"dp{world}",
                        "split_precision_convs": bool(config.split_conv), "loss": loss_v},
         }

@@ -443,6 +443,17 @@ int asis_wgrad(void* stream, const asis_wgrad_desc* d);
  * fp32 parameter buffer; g is multiplied by inv_scale (1/loss_scale) first. */
 int asis_sgd_momentum(void* stream, float* p, const float* g, float* buf, int64_t n, float lr, float momentum,
                       float weight_decay, float inv_scale, int first_step);
+/* Training-time augmentation on the device (train.py:139-163 runs albumentations on uint8 images in the DataLoader
+ * workers, tools/dataset.py:150-161 converts to float / 255): img uint8 [B,S,S,3], mask uint8 [B,S,S] ->
+ * out fp32 [B,3,S,S] in [0,1], mask_out int64 [B,S,S].  Per sample: crop + resize back to S x S (OpenCV 8-bit INTER_LINEAR
+ * fixed-point arithmetic; mask INTER_NEAREST), horizontal flip, np.rot90 by rotk, one 256-entry look-up table
+ * (brightness/contrast then gamma).  Tables are built by the host (adaptersis_amd/tools/augment.py):
+ *   geo int32 [B,4] = {flip, rotk, identity (no crop), 0}; xofs, yofs int32 [B,S] left / top source index;
+ *   xa, ya int16 [B,S,2] the two 11-bit coefficients; mx, my int32 [B,S] nearest source index; lut uint8 [B,256]. */
+int asis_augment(void* stream, const uint8_t* img, const uint8_t* mask, const int32_t* geo, const int32_t* xofs,
+                 const int32_t* yofs, const int16_t* xa, const int16_t* ya, const int32_t* mx, const int32_t* my,
+                 const uint8_t* lut, float* out, int64_t* mask_out, int B, int S);
+
 /* Overflow guard for the static loss scale of the 16-bit gradient tensors (the reference trains in fp32 and has no
  * counterpart; torch.cuda.amp.GradScaler.step has the same skip semantics).  guard = int32[2] in device memory:
  *   asis_grad_guard: guard[0] |= (any element of g is inf / NaN); reset != 0 clears guard[0] first (call once per step

@@ -74,3 +74,57 @@ def test_reference_error_conventions():
     from adaptersis_amd.dinov2.layers import Attention
     with pytest.raises(ValueError):
         Attention(dim=96, num_heads=2)  # head dim 48: every DINOv2 arch has 64
+
+
+def test_dinov2_checkpoint_loader_prefixes_and_key(tmp_path):
+    """`dinov2/utils/utils.py:20-33`: ``teacher``-keyed files, ``module.`` / ``backbone.`` prefixes, extra head keys
+    (strict=False), plain state dicts; URLs are refused (no network on this path)."""
+    import pytest
+    import torch
+    from adaptersis_amd.dinov2.models import vision_transformer as vits
+    from adaptersis_amd.utils import misc, weights as W
+    sd = W.make_vit_state_dict("vit_tiny_test", layerscale="kernel")
+    model = vits.vit_tiny_test(img_size=518, init_values=1e-5, block_chunks=0)
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    ck = {"teacher": {**{"module.backbone." + k: v for k, v in sd.items()}, "module.dino_head.mlp.0.weight": torch.zeros(3, 3)},
+          "student": {"backbone." + k: torch.zeros_like(v) for k, v in sd.items()}, "epoch": 7}
+    path = tmp_path / "dinov2_tiny.pth"
+    torch.save(ck, path)
+    msg = misc.load_pretrained_weights(model, str(path), "teacher")
+    assert list(msg.missing_keys) == [] and list(msg.unexpected_keys) == ["dino_head.mlp.0.weight"]
+    after = model.state_dict()
+    assert all(torch.equal(after[k], sd[k]) for k in sd) and any(not torch.equal(after[k], before[k]) for k in sd)
+    # a plain (un-keyed, un-prefixed) state dict loads as is; a wrong key falls back to the whole file
+    model2 = vits.vit_tiny_test(img_size=518, init_values=1e-5, block_chunks=0)
+    torch.save(sd, tmp_path / "plain.pth")
+    msg = misc.load_pretrained_weights(model2, str(tmp_path / "plain.pth"), "teacher")
+    assert not msg.missing_keys and not msg.unexpected_keys
+    assert torch.equal(model2.state_dict()["blocks.3.mlp.fc2.weight"], sd["blocks.3.mlp.fc2.weight"])
+    with pytest.raises(ValueError):
+        misc.load_pretrained_weights(model2, "https://example.invalid/dinov2_vitl14_pretrain.pth", "teacher")
+
+
+def test_restart_skips_reference_format_optimizer_entry(tmp_path, capsys):
+    """a checkpoint written by the reference holds a per-parameter ``torch.optim.SGD`` state; loading it into the
+    flat-bucket optimizer must be reported and skipped, not crash the run — and must leave the momentum untouched."""
+    import torch
+    from adaptersis_amd import optim
+    from adaptersis_amd.utils import misc
+    lin = torch.nn.Linear(4, 3)
+    ref_opt = torch.optim.SGD(lin.parameters(), lr=0.1, momentum=0.9)
+    lin(torch.ones(2, 4)).sum().backward()
+    ref_opt.step()
+    torch.save({"optimizer": ref_opt.state_dict(), "epoch": 3}, tmp_path / "checkpoint.pth.tar")
+    lin2 = torch.nn.Linear(4, 3)
+    bucket = optim.FlatBucket(list(lin2.named_parameters()))
+    opt = optim.SGD([bucket], lr=0.1, momentum=0.9)
+    bucket.momentum.fill_(0.25)
+    rv = {"epoch": 0}
+    misc.restart_from_checkpoint(str(tmp_path / "checkpoint.pth.tar"), run_variables=rv, optimizer=opt)
+    assert rv["epoch"] == 3 and float(bucket.momentum.min()) == 0.25
+    assert "failed to load 'optimizer'" in capsys.readouterr().out
+    # its own format round-trips
+    torch.save({"optimizer": opt.state_dict()}, tmp_path / "own.pth.tar")
+    bucket.momentum.zero_()
+    misc.restart_from_checkpoint(str(tmp_path / "own.pth.tar"), optimizer=opt)
+    assert float(bucket.momentum.min()) == 0.25

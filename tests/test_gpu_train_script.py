@@ -68,3 +68,58 @@ def test_train_mla_script(dev, tmp_path):
     ck = torch.load(os.path.join(tmp_path, "checkpoint.pth.tar"), map_location="cpu")
     assert any(k.startswith("module.mlahead.") for k in ck["state_dict"])
     T._ENGINES.clear()
+
+
+def test_train_adapters_checkpoint_holds_adapters_and_encoder(dev, tmp_path):
+    """SURVEY.md §5 / ADVICE r1: with --train_adapters --train_encoder the checkpoint also carries CAViT, CACNN and the encoder
+    (reference keys untouched); a resume restores them onto the freshly constructed modules together with the optimiser
+    state of all three buckets."""
+    argv = ["--arch", "vit_tiny_test", "--imsize", "224", "--batch_size_per_gpu", "4", "--epochs", "1", "--lr", "0.05",
+            "--data_path", "synthetic", "--output_dir", str(tmp_path), "--train_adapters", "--train_encoder"]
+    T._ENGINES.clear()
+    T.train_seg(T.get_args_parser().parse_args(argv))
+    (eng,) = T._ENGINES.values()
+    assert eng.optimizer.skipped_steps == 0          # overflow guard of the static loss scale never fired
+    want = {"cv": eng.cross_vit.state_dict()["attn.value_proj.weight"].cpu().clone(),
+            "cn": eng.cross_cnn.state_dict()["ffn.fc2.weight"].cpu().clone(),
+            "enc": eng.backbone_encoder.state_dict()["conv3.0.weight"].cpu().clone(),
+            "rm": eng.backbone_encoder.state_dict()["stem.1.running_mean"].cpu().clone(),
+            "mom": [b.momentum.cpu().clone() for b in eng.optimizer.buckets]}
+    ck = torch.load(os.path.join(tmp_path, "checkpoint.pth.tar"), map_location="cpu")
+    assert {"epoch", "state_dict", "optimizer", "scheduler", "best_acc", "cross_vit", "cross_cnn", "backbone_encoder"} == set(ck)
+    assert all(k.startswith("module.") for k in ck["cross_vit"]) and len(ck["optimizer"]["state"]) == 3
+    T._ENGINES.clear()
+    torch.manual_seed(1234)                          # the re-created modules start from a different random init
+    args = T.get_args_parser().parse_args(argv)
+    args.evaluate = True
+    T.train_seg(args)
+    (eng2,) = T._ENGINES.values()
+    assert eng2 is not eng
+    assert torch.equal(eng2.cross_vit.state_dict()["attn.value_proj.weight"].cpu(), want["cv"])
+    assert torch.equal(eng2.cross_cnn.state_dict()["ffn.fc2.weight"].cpu(), want["cn"])
+    assert torch.equal(eng2.backbone_encoder.state_dict()["conv3.0.weight"].cpu(), want["enc"])
+    assert torch.equal(eng2.backbone_encoder.state_dict()["stem.1.running_mean"].cpu(), want["rm"])
+    for b, m in zip(eng2.optimizer.buckets, want["mom"]):
+        assert torch.equal(b.momentum.cpu(), m)
+    T._ENGINES.clear()
+
+
+def test_sgd_overflow_guard_skips_the_step(dev):
+    """A non-finite gradient anywhere in the buckets (saturated 16-bit gradient tensor under the static loss scale) leaves
+    parameters and momentum untouched and is counted; the next finite step proceeds."""
+    from adaptersis_amd import optim
+    lin = torch.nn.Linear(8, 8).to(dev)
+    lin2 = torch.nn.Linear(8, 4).to(dev)
+    b1, b2 = optim.FlatBucket(list(lin.named_parameters())), optim.FlatBucket(list(lin2.named_parameters()))
+    opt = optim.SGD([b1, b2], lr=0.1, momentum=0.9)
+    w0, v0 = b1.flat.clone(), b2.flat.clone()
+    b1.grad.fill_(1.0); b2.grad.fill_(1.0)
+    b2.grad[3] = float("inf")
+    opt.step()
+    assert torch.equal(b1.flat, w0) and torch.equal(b2.flat, v0) and opt.skipped_steps == 1
+    b2.grad[3] = float("nan")
+    opt.step()
+    assert torch.equal(b1.flat, w0) and opt.skipped_steps == 2
+    b2.grad[3] = 1.0
+    opt.step()
+    assert torch.allclose(b1.flat, w0 - 0.1) and torch.allclose(b2.flat, v0 - 0.1) and opt.skipped_steps == 2
