@@ -93,6 +93,7 @@ SIGNATURES = {
     "asis_ls_linear_finish": [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _i],
     "asis_attention_fwd": [_vp, _i, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _i, _f],
     "asis_im2col_patch": [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i64],
+    "asis_im2col_patch_split": [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _i64],
     "asis_cast_pad": [_vp, _i, _vp, _i64, _vp, _i64, _i64, _i, _f, _i],
     "asis_add_cls_pos": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i],
     "asis_msda_fwd": [_vp, _i, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i],
@@ -143,7 +144,7 @@ SIGNATURES = {
     "asis_sgd_momentum": [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i],
     "asis_augment": [_vp] * 13 + [_i, _i],
     "asis_grad_guard": [_vp, _vp, _i64, _vp, _i],
-    "asis_sgd_momentum_guarded": [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i, _vp],
+    "asis_sgd_momentum_guarded": [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i, _vp, _i],
     "asis_scale_f32": [_vp, _vp, _i64, _f],
 }
 

@@ -31,3 +31,9 @@ def set_operand_dtype(dt: torch.dtype) -> None:
 # logits by themselves (measured), above north_star's 1e-3; split operands remove that term for
 # ~7 % more FLOPs per step.  ASIS_SPLIT_CONV=0 disables it.
 split_conv = os.environ.get("ASIS_SPLIT_CONV", "1") != "0"
+
+# Opt-in precision mode for the attention branch of the ViT blocks (ASIS_PRECISE=1): the qkv and proj WEIGHTS enter their
+# GEMMs as hi + lo 16-bit halves (one extra MFMA pass over the weight correction).  tests/precision_probe.py: rounding the
+# weights to 16 bits is the largest error term on the adapter stream — it is the same for every token, so it adds up
+# coherently through the blocks — and qkv + proj carry 55 % of its energy.  Off by default: +33 % linear-layer FLOPs.
+precise_attention = os.environ.get("ASIS_PRECISE", "0") not in ("0", "")

@@ -280,9 +280,9 @@ __global__ __launch_bounds__(256) void nonfinite_kernel(const float* __restrict_
 
 __global__ __launch_bounds__(256) void sgd_guarded_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
                                                           int64_t n, float lr, float momentum, float wd, float inv_scale, int first,
-                                                          int* __restrict__ guard) {
+                                                          int* __restrict__ guard, int count_skip) {
   if (guard[0] != 0) {   // uniform over the grid: every thread reads the same word, written by the kernel before this one
-    if (blockIdx.x == 0 && threadIdx.x == 0) guard[1] += 1;
+    if (count_skip && blockIdx.x == 0 && threadIdx.x == 0) guard[1] += 1;
     return;
   }
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -418,11 +418,11 @@ extern "C" int asis_grad_guard(void* stream, const float* g, int64_t n, int32_t*
 }
 
 extern "C" int asis_sgd_momentum_guarded(void* stream, float* p, const float* g, float* buf, int64_t n, float lr, float momentum,
-                                         float weight_decay, float inv_scale, int first_step, int32_t* guard) {
+                                         float weight_decay, float inv_scale, int first_step, int32_t* guard, int count_skip) {
   ASIS_REQUIRE(p && g && buf && guard && n >= 0, "asis_sgd_momentum_guarded: bad arguments");
   if (n == 0) return ASIS_OK;
   hipLaunchKernelGGL(sgd_guarded_kernel, dim3(grid_for(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p, g, buf, n,
-                     lr, momentum, weight_decay, inv_scale, first_step, reinterpret_cast<int*>(guard));
+                     lr, momentum, weight_decay, inv_scale, first_step, reinterpret_cast<int*>(guard), count_skip);
   ASIS_CHECK_LAUNCH("asis_sgd_momentum_guarded");
   return ASIS_OK;
 }

@@ -214,7 +214,7 @@ int launch(hipStream_t s, const asis_gemm_desc& d) {
   static const int group_m = [] { const char* e = getenv("ASIS_GEMM_GROUPM"); return e && atoi(e) > 0 ? atoi(e) : 4; }();
   static const int big_mode = [] { const char* e = getenv("ASIS_GEMM_BIG"); return e ? atoi(e) : 1; }();
   const bool vec_ok = (d.N % 4 == 0) && (d.ldc % 4 == 0);
-  const bool split = d.A_lo != nullptr;
+  const bool split = d.A_lo != nullptr || d.B_lo != nullptr;
   if (d.act == ASIS_ACT_GELU_GRAD) {  // only the vector epilogue of the large-tile kernels implements it
     const bool ok = big_mode && !d.conv && !split && !d.stats && d.aux && d.K % 32 == 0 && d.M >= 256 && d.N >= 128 && vec_ok &&
                     d.ld_aux % 4 == 0 && d.batch == 1 && (reinterpret_cast<uintptr_t>(d.aux) & 7) == 0 &&
@@ -223,7 +223,8 @@ int launch(hipStream_t s, const asis_gemm_desc& d) {
   }
   if (d.ksplit > 1 && !(big_mode && d.conv)) return ASIS_EINVAL;
   if (split) {  // one pass over the virtual 3K reduction; only on the large-tile kernel
-    const bool ok = big_mode && d.K % BK == 0 && d.M >= 256 && d.N >= 32 && vec_ok && d.out_f32 && (!d.conv || d.Cin % BK == 0);
+    const bool ok = big_mode && d.K % BK == 0 && d.M >= 256 && d.N >= 32 && vec_ok && (d.out_f32 || !d.conv) &&
+                    (!d.conv || (d.Cin % BK == 0 && d.A_lo && d.B_lo));
     if (!ok) return ASIS_EINVAL;
     const int bm = 256, bn = d.N > 64 ? 128 : 64;
     if (d.ksplit > 1 && (d.batch != 1 || d.stats || (d.KH * d.KW) % d.ksplit != 0 || !d.out_f32 || d.res)) return ASIS_EINVAL;
@@ -334,8 +335,8 @@ extern "C" int asis_gemm(void* stream, const asis_gemm_desc* dp) {
   const int64_t tiles = (int64_t)asis_cdiv(d.M, BM) * asis_cdiv(d.N, BN);
   ASIS_REQUIRE(tiles < (1ll << 31), "asis_gemm: too many tiles");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  ASIS_REQUIRE((d.A_lo == nullptr) == (d.B_lo == nullptr), "asis_gemm: A_lo and B_lo must be given together");
-  if (d.A_lo) ASIS_REQUIRE(asis_aligned16(d.A_lo) && asis_aligned16(d.B_lo), "asis_gemm: split halves must be 16-byte aligned");
+  ASIS_REQUIRE(!d.conv || (d.A_lo == nullptr) == (d.B_lo == nullptr), "asis_gemm: a split convolution needs both A_lo and B_lo");
+  ASIS_REQUIRE((!d.A_lo || asis_aligned16(d.A_lo)) && (!d.B_lo || asis_aligned16(d.B_lo)), "asis_gemm: split halves must be 16-byte aligned");
   const int rc = (d.dtype == ASIS_F16) ? launch<f16>(s, d) : launch<bf16>(s, d);
   if (rc != 0) ASIS_FAIL(ASIS_EINVAL, "asis_gemm: split-precision operands / ASIS_ACT_GELU_GRAD / ksplit need the large-tile path (K %% 64 "
                                         "== 0 (GELU_GRAD: 32), M >= 256, N >= 32 (128), N and ldc multiples of 4, fp32 output for "

@@ -108,8 +108,16 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_big_kernel(const asis_
   }
   // SPLIT: the reduction runs over three K-long parts: (A, B), (A_lo, B), (A, B_lo); the lo halves share the
   // layout of the hi ones, so a part only changes the base pointers by a constant element offset.
-  const int64_t a_lo_off = SPLIT ? (reinterpret_cast<const T*>(d.A_lo) - reinterpret_cast<const T*>(d.A)) : 0;
-  const int64_t b_lo_off = SPLIT ? (reinterpret_cast<const T*>(d.B_lo) - reinterpret_cast<const T*>(d.B)) : 0;
+  // One-sided split (only A_lo or only B_lo given: the WEIGHT operand of a linear layer, whose rounding error is the same
+  // for every token and therefore adds up coherently through the blocks, tests/precision_probe.py): two parts.
+  const int64_t a_lo_off = (SPLIT && d.A_lo) ? (reinterpret_cast<const T*>(d.A_lo) - reinterpret_cast<const T*>(d.A)) : 0;
+  const int64_t b_lo_off = (SPLIT && d.B_lo) ? (reinterpret_cast<const T*>(d.B_lo) - reinterpret_cast<const T*>(d.B)) : 0;
+  const int nparts = !SPLIT ? 1 : ((d.A_lo && d.B_lo) ? 3 : 2);
+  // part p > 0 of a two-part reduction adds the one lo operand that exists; of a three-part one: 1 = A_lo, 2 = B_lo
+  auto part_offs = [&](int part, int64_t& aoff, int64_t& boff) {
+    aoff = (part == 1 && d.A_lo) ? a_lo_off : 0;
+    boff = ((part == 2) || (part == 1 && !d.A_lo)) ? b_lo_off : 0;
+  };
   // ksplit > 1: blockIdx.y is a K part, not a batch entry (the host passes zero A/B batch strides)
   const int ksp = (!PH8 && d.ksplit > 1) ? d.ksplit : 1;
   const int nt1 = d.K / ksp / BKB;
@@ -131,10 +139,9 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_big_kernel(const asis_
       // had pushed them out of its 4 MB L2: 3.2x the tensor bytes in L2 fills (profiles/r01_pmc_traffic.json).
       int tt = t, part = 0;
       if (SPLIT) {
-        tt = t / 3;
-        part = t - 3 * tt;
-        aoff = part == 1 ? a_lo_off : 0;
-        boff = part == 2 ? b_lo_off : 0;
+        tt = t / nparts;
+        part = t - nparts * tt;
+        part_offs(part, aoff, boff);
       }
       const int c = tt / ntap_part, tl = tt - c * ntap_part;
       k0 = (tap_base + tl) * d.Cin + c * BKB;
@@ -142,8 +149,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_big_kernel(const asis_
       if (SPLIT) {
         const int part = t / nt1;
         kt = t - part * nt1;
-        aoff = part == 1 ? a_lo_off : 0;
-        boff = part == 2 ? b_lo_off : 0;
+        part_offs(part, aoff, boff);
       }
       k0 = (kt + kt_base) * BKB;
     }
@@ -184,7 +190,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_big_kernel(const asis_
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   }
 
-  const int nt = SPLIT ? 3 * nt1 : nt1;
+  const int nt = nparts * nt1;
   const int fr = lane & 31, fh = lane >> 5;
   if constexpr (PH8) {
     // ---- 8-phase main loop (cdna_hip_programming.md "The 256^2 8-phase template", re-derived for 32x32x16 MFMAs and

@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void cast_pad_kernel(const float* __restrict__
 
 template <typename T>
 __global__ __launch_bounds__(256) void im2col_patch_kernel(const float* __restrict__ img, int B, int Himg, int Wimg,
-                                                           int P, T* __restrict__ out, int64_t ldk) {
+                                                           int P, T* __restrict__ out, int64_t ldk, T* __restrict__ out_lo) {
   const int gh = Himg / P, gw = Wimg / P;
   const int cpr = (int)(ldk >> 3);
   const int K = 3 * P * P;
@@ -201,6 +201,14 @@ __global__ __launch_bounds__(256) void im2col_patch_kernel(const float* __restri
     p.z = pack2<T>(f[4], f[5]);
     p.w = pack2<T>(f[6], f[7]);
     *reinterpret_cast<uint4*>(out + r * ldk + k0) = p;
+    if (out_lo) {  // rounding residuals: img ~= hi + lo (split-precision patch embedding)
+      uint4 q;
+      q.x = pack2<T>(lo_part<T>(f[0]), lo_part<T>(f[1]));
+      q.y = pack2<T>(lo_part<T>(f[2]), lo_part<T>(f[3]));
+      q.z = pack2<T>(lo_part<T>(f[4]), lo_part<T>(f[5]));
+      q.w = pack2<T>(lo_part<T>(f[6]), lo_part<T>(f[7]));
+      *reinterpret_cast<uint4*>(out_lo + r * ldk + k0) = q;
+    }
   }
 }
 
@@ -295,9 +303,17 @@ extern "C" int asis_cast_pad(void* stream, int dtype, const float* src, int64_t 
   return ASIS_OK;
 }
 
+extern "C" int asis_im2col_patch_split(void* stream, int dtype, const float* img, int B, int Himg, int Wimg, int P, void* out,
+                                       void* out_lo, int64_t ldk);
 extern "C" int asis_im2col_patch(void* stream, int dtype, const float* img, int B, int Himg, int Wimg, int P, void* out,
                                  int64_t ldk) {
+  return asis_im2col_patch_split(stream, dtype, img, B, Himg, Wimg, P, out, nullptr, ldk);
+}
+
+extern "C" int asis_im2col_patch_split(void* stream, int dtype, const float* img, int B, int Himg, int Wimg, int P, void* out,
+                                       void* out_lo, int64_t ldk) {
   ASIS_REQUIRE(img && out, "asis_im2col_patch: null pointer");
+  ASIS_REQUIRE(!out_lo || asis_aligned16(out_lo), "asis_im2col_patch: out_lo must be 16-byte aligned");
   ASIS_REQUIRE(P > 0 && Himg % P == 0 && Wimg % P == 0,
                "Input image size %dx%d is not a multiple of patch size %d", Himg, Wimg, P);
   ASIS_REQUIRE(ldk % 8 == 0 && ldk >= 3 * P * P, "asis_im2col_patch: ldk=%ld must be a multiple of 8 and >= 3*P*P", (long)ldk);
@@ -307,10 +323,10 @@ extern "C" int asis_im2col_patch(void* stream, int dtype, const float* img, int 
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (dtype == ASIS_F16)
     hipLaunchKernelGGL((im2col_patch_kernel<f16>), dim3(grid_for(total)), dim3(256), 0, s, img, B, Himg, Wimg, P,
-                       reinterpret_cast<f16*>(out), ldk);
+                       reinterpret_cast<f16*>(out), ldk, reinterpret_cast<f16*>(out_lo));
   else
     hipLaunchKernelGGL((im2col_patch_kernel<bf16>), dim3(grid_for(total)), dim3(256), 0, s, img, B, Himg, Wimg, P,
-                       reinterpret_cast<bf16*>(out), ldk);
+                       reinterpret_cast<bf16*>(out), ldk, reinterpret_cast<bf16*>(out_lo));
   ASIS_CHECK_LAUNCH("asis_im2col_patch");
   return ASIS_OK;
 }

@@ -40,6 +40,13 @@ class _Packed(nn.Module):
         return _pack(self._cache, key, param,
                      lambda p: ops.cast_pad(p.reshape(p.shape[0], -1).contiguous().float(), dtype=config.operand_dtype))
 
+    def _w16lo(self, key: str, param: torch.Tensor) -> Optional[torch.Tensor]:
+        """rounding residual of ``_w16`` (same layout) when ``config.precise_attention`` is on, else None"""
+        if not config.precise_attention:
+            return None
+        return _pack(self._cache, key + ".lo", param,
+                     lambda p: ops.cast_pad(p.reshape(p.shape[0], -1).contiguous().float(), dtype=config.operand_dtype, part=1))
+
     def _f32(self, key: str, param: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
         if param is None:
             return None
@@ -108,18 +115,39 @@ class PatchEmbed(_Packed):
         if norm_layer:
             raise ValueError("PatchEmbed: norm_layer is not used on this path (vision_transformer.py:104)")
 
+    def tokens(self, x: torch.Tensor):
+        """-> (tokens fp32 (B, N, D), a16 = the 16-bit im2col operand (hi half) for the weight gradient).  With
+        ``config.split_conv`` the conv runs on hi + lo halves of pixels and weights (three MFMA passes over K = 588 -> 640):
+        its 16-bit operand rounding is the largest single error term of the step on the features (tests/precision_probe.py:
+        2.7e-4 of 3.3e-4 on the adapter stream) because it enters BOTH ViT passes at their very first layer, while the conv
+        is 0.07 % of the step's FLOPs."""
+        B, _, H, W = x.shape
+        P = self.patch_size[0]
+        K = 3 * P * P
+        dt = config.operand_dtype
+        bias = self._f32("b", self.proj.bias)
+        if config.split_conv:
+            ldk = (K + 63) // 64 * 64
+            flat = lambda p: p.reshape(p.shape[0], -1).contiguous().float()
+            w_hi = _pack(self._cache, "w64", self.proj.weight, lambda p: ops.cast_pad(flat(p), ldk, dt))
+            w_lo = _pack(self._cache, "w64lo", self.proj.weight, lambda p: ops.cast_pad(flat(p), ldk, dt, part=1))
+            a, a_lo = ops.im2col_patch(x.contiguous().float(), P, ldk, dt, split=True)
+            out = torch.empty((a.shape[0], self.embed_dim), device=x.device, dtype=torch.float32)
+            ops.gemm_split(a, a_lo, w_hi, w_lo, out=out, bias_n=bias)
+        else:
+            ldk = (K + 7) // 8 * 8
+            w16 = _pack(self._cache, "w", self.proj.weight,
+                        lambda p: ops.cast_pad(p.reshape(p.shape[0], -1).contiguous().float(), ldk, dt))
+            a = ops.im2col_patch(x.contiguous().float(), P, ldk, dt)
+            out = ops.gemm(a, w16, out_f32=True, bias_n=bias)
+        return out.view(B, (H // P) * (W // P), self.embed_dim), a
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         B, _, H, W = x.shape
         P = self.patch_size[0]
         assert H % P == 0, f"Input image height {H} is not a multiple of patch height {P}"
         assert W % P == 0, f"Input image width {W} is not a multiple of patch width: {P}"
-        K = 3 * P * P
-        ldk = (K + 7) // 8 * 8
-        w16 = _pack(self._cache, "w", self.proj.weight,
-                    lambda p: ops.cast_pad(p.reshape(p.shape[0], -1).contiguous().float(), ldk, config.operand_dtype))
-        a = ops.im2col_patch(x.contiguous().float(), P, ldk, config.operand_dtype)
-        out = ops.gemm(a, w16, out_f32=True, bias_n=self._f32("b", self.proj.bias))
-        out = out.view(B, (H // P) * (W // P), self.embed_dim)
+        out, _ = self.tokens(x)
         if not self.flatten_embedding:
             out = out.reshape(-1, H // P, W // P, self.embed_dim)
         return out
@@ -159,7 +187,8 @@ class Attention(_Packed):
         D = xn.shape[1]
         w = self._w16("qkv", self.qkv.weight)  # [3D, D] rows q | k | v
         bias = self._f32("qkv_b", self.qkv.bias)
-        qk = ops.gemm(xn, w[: 2 * D], bias_n=None if bias is None else bias[: 2 * D])
+        wlo = self._w16lo("qkv", self.qkv.weight)
+        qk = ops.gemm(xn, w[: 2 * D], bias_n=None if bias is None else bias[: 2 * D], b_lo=None if wlo is None else wlo[: 2 * D])
         o = torch.empty((xn.shape[0], D), device=xn.device, dtype=xn.dtype)
         one_launch = len(segs) == 2
         ldv_all = (max(n for _, n in segs) + 63) // 64 * 64
@@ -175,7 +204,8 @@ class Attention(_Packed):
             spare = xn.untyped_storage().nbytes() // xn.element_size() - (xn.storage_offset() + xn.shape[0] * D)
             N4 = (N + 3) // 4 * 4 if spare >= 4 * D else N
             ops.gemm(w[2 * D:], xn[r0:r1].as_strided((B, N4, D), (N * D, D, 1)),
-                     out=vt.as_strided((B, D, N4), (D * ldvt, ldvt, 1)), bias_m=None if bias is None else bias[2 * D:])
+                     out=vt.as_strided((B, D, N4), (D * ldvt, ldvt, 1)), bias_m=None if bias is None else bias[2 * D:],
+                     a_lo=None if wlo is None else wlo[2 * D:])
             if not one_launch:
                 ops.attention_fwd(qk[r0:r1, :D], qk[r0:r1, D:], vt, B, self.num_heads, N, self.scale, out=o[r0:r1])
             r0, b0 = r1, b0 + B
@@ -265,7 +295,8 @@ class Block(_Packed):
         ops.layernorm(x2, self._f32("n1w", self.norm1.weight), self._f32("n1b", self.norm1.bias), self.norm1.eps, dt, out=xn)
         o = self.attn.attend_rows(xn, segs)
         x1 = ops.gemm(o, self.attn._w16("proj", self.attn.proj.weight), out_f32=True,
-                      bias_n=self.attn._f32("proj_b", self.attn.proj.bias), scale_n=g1, res=x2)
+                      bias_n=self.attn._f32("proj_b", self.attn.proj.bias), scale_n=g1, res=x2,
+                      b_lo=self.attn._w16lo("proj", self.attn.proj.weight))
         xn2 = ops.layernorm(x1, self._f32("n2w", self.norm2.weight), self._f32("n2b", self.norm2.bias),
                             self.norm2.eps, dt)
         m = self.mlp
@@ -304,7 +335,7 @@ class Block(_Packed):
         g2 = self._f32("g2", self.ls2.gamma) if isinstance(self.ls2, LayerScale) else None
         a = self.attn
         xn = ops.layernorm(x2, self._f32("n1w", self.norm1.weight), self._f32("n1b", self.norm1.bias), self.norm1.eps, dt)
-        qkv = ops.gemm(xn, a._w16("qkv", a.qkv.weight), bias_n=a._f32("qkv_b", a.qkv.bias))
+        qkv = ops.gemm(xn, a._w16("qkv", a.qkv.weight), bias_n=a._f32("qkv_b", a.qkv.bias), b_lo=a._w16lo("qkv", a.qkv.weight))
         o = torch.empty((x2.shape[0], D), device=x2.device, dtype=dt)
         lse = []
         r0 = 0
@@ -318,7 +349,7 @@ class Block(_Packed):
         if r0 != x2.shape[0]:
             raise ValueError("forward_train_rows: segments do not cover the rows")
         x1 = ops.gemm(o, a._w16("proj", a.proj.weight), out_f32=True, bias_n=a._f32("proj_b", a.proj.bias), scale_n=g1,
-                      res=x2)
+                      res=x2, b_lo=a._w16lo("proj", a.proj.weight))
         xn2 = ops.layernorm(x1, self._f32("n2w", self.norm2.weight), self._f32("n2b", self.norm2.bias), self.norm2.eps, dt)
         if isinstance(m, Mlp):
             hpre = ops.gemm(xn2, m._w16("fc1", m.fc1.weight), bias_n=m._f32("fc1_b", m.fc1.bias))

@@ -112,14 +112,7 @@ class DinoVisionTransformer(nn.Module):
 
     def patch_tokens_train(self, x: torch.Tensor):
         """PatchEmbed keeping its im2col operand: -> (tokens fp32 (B, N, D), a16 16-bit [B*N, ldk]) for the weight gradient."""
-        B = x.shape[0]
-        pe = self.patch_embed
-        P = pe.patch_size[0]
-        a16 = ops.im2col_patch(x.contiguous().float(), P, (3 * P * P + 7) // 8 * 8, config.operand_dtype)
-        w16 = _pack(pe._cache, "w", pe.proj.weight,
-                    lambda p: ops.cast_pad(p.reshape(p.shape[0], -1).contiguous().float(), a16.shape[1], config.operand_dtype))
-        t = ops.gemm(a16, w16, out_f32=True, bias_n=pe._f32("b", pe.proj.bias)).view(B, -1, self.embed_dim)
-        return t, a16
+        return self.patch_embed.tokens(x)
 
     # -- training path: forward_features under autograd (eval_dinov2_setr_cross_ete.py:145-148,318-321) -----------
     def forward_train(self, x: torch.Tensor):

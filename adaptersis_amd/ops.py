@@ -115,10 +115,16 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, out: Optional[torch.Tensor] = None
             raise ValueError("gemm: aux must be a 16-bit [M, N] matrix of the operand dtype")
         d.aux, d.ld_aux = aux.data_ptr(), aux.stride(-2)
     flops = 2.0 * batch * M * N * K
+    if (a_lo is None) != (b_lo is None) and not (K % 64 == 0 and M >= 256 and N >= 32 and N % 4 == 0 and out.stride(-2) % 4 == 0):
+        a_lo = b_lo = None   # one-sided (weight) split is an optional refinement: shapes off the large-tile path run plain
     if a_lo is not None:
-        if a_lo.stride() != a.stride() or b_lo.stride() != b.stride():
+        if a_lo.stride() != a.stride():
             raise ValueError("gemm: split halves must share the layout of their hi parts")
-        d.A_lo, d.B_lo = a_lo.data_ptr(), b_lo.data_ptr()
+        d.A_lo = a_lo.data_ptr()
+    if b_lo is not None:
+        if b_lo.stride() != b.stride():
+            raise ValueError("gemm: split halves must share the layout of their hi parts")
+        d.B_lo = b_lo.data_ptr()
     nbytes = batch * (2.0 * (M * K + N * K) + M * N * ((4 if out_f32 else 2) + (4 if res is not None else 0)))
     check(_launch_timed("gemm", flops, lambda: lib().asis_gemm(_stream(), C.byref(d)), nbytes), "asis_gemm")
     return out
@@ -370,7 +376,8 @@ def ls_linear_finish(G: torch.Tensor, W: Optional[torch.Tensor], bias, gamma, cs
           "asis_ls_linear_finish")
 
 
-def im2col_patch(img: torch.Tensor, P: int, ldk: int, dtype: torch.dtype = T16_DEFAULT) -> torch.Tensor:
+def im2col_patch(img: torch.Tensor, P: int, ldk: int, dtype: torch.dtype = T16_DEFAULT, split: bool = False):
+    """fp32 [B,3,H,W] -> 16-bit [B*(H/P)*(W/P), ldk] (k = c*P*P + i*P + j, pad columns zero); ``split``: -> (hi, lo)."""
     _dev(img)
     if img.dtype != torch.float32 or not img.is_contiguous() or img.dim() != 4 or img.shape[1] != 3:
         raise ValueError("im2col_patch: img must be contiguous float32 [B,3,H,W]")
@@ -379,9 +386,10 @@ def im2col_patch(img: torch.Tensor, P: int, ldk: int, dtype: torch.dtype = T16_D
         # error text mirrors dinov2/layers/patch_embed.py:72-73
         raise AssertionError(f"Input image height {Hi} / width {Wi} is not a multiple of patch size {P}")
     out = torch.empty((B * (Hi // P) * (Wi // P), ldk), device=img.device, dtype=dtype)
-    check(lib().asis_im2col_patch(_stream(), _dt(dtype), img.data_ptr(), B, Hi, Wi, P, out.data_ptr(), ldk),
+    lo = torch.empty_like(out) if split else None
+    check(lib().asis_im2col_patch_split(_stream(), _dt(dtype), img.data_ptr(), B, Hi, Wi, P, out.data_ptr(), _p(lo), ldk),
           "asis_im2col_patch")
-    return out
+    return (out, lo) if split else out
 
 
 def cast_pad(src: torch.Tensor, ld_dst: Optional[int] = None, dtype: torch.dtype = T16_DEFAULT,
@@ -940,13 +948,13 @@ def grad_guard(g: torch.Tensor, guard: torch.Tensor, reset: bool) -> None:
 
 
 def sgd_momentum(p: torch.Tensor, g: torch.Tensor, buf: torch.Tensor, lr: float, momentum: float, weight_decay: float,
-                 inv_scale: float, first_step: bool, guard: Optional[torch.Tensor] = None) -> None:
+                 inv_scale: float, first_step: bool, guard: Optional[torch.Tensor] = None, count_skip: bool = True) -> None:
     _dev(p, g, buf)
     if guard is not None:
         _dev(guard)
         check(lib().asis_sgd_momentum_guarded(_stream(), _f32c(p).data_ptr(), _f32c(g).data_ptr(), _f32c(buf).data_ptr(),
                                               p.numel(), float(lr), float(momentum), float(weight_decay), float(inv_scale),
-                                              int(first_step), guard.data_ptr()), "asis_sgd_momentum_guarded")
+                                              int(first_step), guard.data_ptr(), int(count_skip)), "asis_sgd_momentum_guarded")
         return
     check(lib().asis_sgd_momentum(_stream(), _f32c(p).data_ptr(), _f32c(g).data_ptr(), _f32c(buf).data_ptr(), p.numel(),
                                   float(lr), float(momentum), float(weight_decay), float(inv_scale), int(first_step)),

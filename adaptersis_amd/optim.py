@@ -80,9 +80,9 @@ class SGD:
         if self.guard is not None:
             for i, b in enumerate(self.buckets):
                 ops.grad_guard(b.grad, self.guard, i == 0)
-        for b, g in zip(self.buckets, self.param_groups):
+        for i, (b, g) in enumerate(zip(self.buckets, self.param_groups)):
             ops.sgd_momentum(b.flat, b.grad, b.momentum, g["lr"], g["momentum"], g["weight_decay"], inv_scale,
-                             self._steps == 0, self.guard)
+                             self._steps == 0, self.guard, count_skip=(i == 0))
             for p in b.params:  # changed in place behind torch's back: invalidate the packed 16-bit copies
                 p._asis_gen = getattr(p, "_asis_gen", 0) + 1
         self._steps += 1

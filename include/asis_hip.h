@@ -89,10 +89,12 @@ typedef struct asis_gemm_desc {
   /* optional fp32 per-column partial statistics of the fp32 output (BatchNorm train mode):
    * stats[(tile_m * 2 + {0,1}) * N + n] = sum / sum of squares over the tile's valid rows. */
   float* stats;
-  /* optional split-precision halves (both or neither): A ~= A + A_lo, B ~= B + B_lo (rounding residuals, see
-   * asis_cast_pad part=1).  The kernel then accumulates A*B + A_lo*B + A*B_lo in ONE pass over a virtual
-   * 3K-long reduction (same layouts/strides as A and B).  Needs the large-tile path: K % 64 == 0, M >= 256,
-   * N >= 32 (conv: Cin % 64 == 0); otherwise ASIS_EINVAL — callers then run three accumulate passes. */
+  /* optional split-precision halves: A ~= A + A_lo, B ~= B + B_lo (rounding residuals, see asis_cast_pad part=1).
+   * Both given: the kernel accumulates A*B + A_lo*B + A*B_lo in ONE pass over a virtual 3K-long reduction (same
+   * layouts/strides as A and B).  Only one given (dense GEMMs: the weight operand of a linear layer, whose rounding
+   * error is common to all rows): A*B + that one correction, a 2K-long reduction.  Needs the large-tile path:
+   * K % 64 == 0, M >= 256, N >= 32 (conv: both halves, Cin % 64 == 0, fp32 output); otherwise ASIS_EINVAL — callers
+   * then run accumulate passes. */
   const void* A_lo;
   const void* B_lo;
   /* act == ASIS_ACT_GELU_GRAD: 16-bit [M, N] pre-activation (row stride ld_aux, elements), large-tile path only
@@ -159,6 +161,11 @@ int asis_attention_bwd(void* stream, int dtype, const void* q, const void* k, co
  * ------------------------------------------------------------------------------------------- */
 int asis_im2col_patch(void* stream, int dtype, const float* img, int B, int Himg, int Wimg, int P, void* out,
                       int64_t ldk);
+/* same, also writing the 16-bit rounding residuals (img ~= out + out_lo) for the split-precision patch embedding: the
+ * rounding of pixels and patch weights to 16 bits is the largest single error term of the whole step on the features
+ * (2.7e-4 of 3.3e-4, tests/precision_probe.py) and the conv is 0.07 % of its FLOPs; out_lo NULL = asis_im2col_patch */
+int asis_im2col_patch_split(void* stream, int dtype, const float* img, int B, int Himg, int Wimg, int P, void* out,
+                            void* out_lo, int64_t ldk);
 
 /* fp32 -> 16-bit cast (x scale) with optional zero-padded columns: src [rows, cols] (ld_src) ->
  * dst [rows, ld_dst], columns cols..ld_dst-1 are written as zero.  Used to pack weights once.
@@ -458,11 +465,12 @@ int asis_augment(void* stream, const uint8_t* img, const uint8_t* mask, const in
  * counterpart; torch.cuda.amp.GradScaler.step has the same skip semantics).  guard = int32[2] in device memory:
  *   asis_grad_guard: guard[0] |= (any element of g is inf / NaN); reset != 0 clears guard[0] first (call once per step
  *   with reset = 1 on the first bucket, reset = 0 on the others);
- *   asis_sgd_momentum_guarded: asis_sgd_momentum, except that a step with guard[0] != 0 changes nothing and adds 1 to
- *   guard[1] (the count of skipped steps, read by the host whenever it likes). */
+ *   asis_sgd_momentum_guarded: asis_sgd_momentum, except that a step with guard[0] != 0 changes nothing and, when
+ *   count_skip != 0 (set it for ONE bucket of the step), adds 1 to guard[1] = the count of skipped steps, read by the host
+ *   whenever it likes. */
 int asis_grad_guard(void* stream, const float* g, int64_t n, int32_t* guard, int reset);
 int asis_sgd_momentum_guarded(void* stream, float* p, const float* g, float* buf, int64_t n, float lr, float momentum,
-                              float weight_decay, float inv_scale, int first_step, int32_t* guard);
+                              float weight_decay, float inv_scale, int first_step, int32_t* guard, int count_skip);
 int asis_scale_f32(void* stream, float* x, int64_t n, float a);
 
 #ifdef __cplusplus

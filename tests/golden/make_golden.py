@@ -520,7 +520,11 @@ def step_case(R, out, arch, mode, tag, batch=1):
     out[f"{tag}.logits"] = sub(logits)
     out[f"{tag}.loss"] = loss.detach().clone()
     for k, p in dec.named_parameters():
-        close(osd[k].grad, p.grad, 2e-3, f"{tag} grad {k}")
+        if k.startswith("decoder_") and k.endswith(".0.bias"):
+            # conv bias in front of a train-mode BatchNorm: exact gradient 0, both sides hold cancellation noise
+            assert float(p.grad.norm()) < 1e-5 * float(dict(dec.named_parameters())[k[:-4] + "weight"].grad.norm())
+        else:
+            close(osd[k].grad, p.grad, 2e-3, f"{tag} grad {k}")
         out[f"{tag}.grad.{k}"] = sub(p.grad, 4000)
     n_adapter_grads = sum(p.grad is not None for m in (cv, cn, enc) for p in m.parameters())
     print(f"  adapter/encoder params with grad in the reference step: {n_adapter_grads} (graph cut, fact 1)")

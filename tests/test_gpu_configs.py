@@ -57,10 +57,10 @@ def test_config2_vitb_width_unet768_step_vs_reference_golden(dev):
     e_lg = golden_err(taps["logits"].permute(0, 3, 1, 2), g["c2.logits"])
     print(f"config 2 (D=768): x_final {e_x:.2e} c_final {e_c:.2e} logits {e_lg:.2e} loss {float(loss):.6f} golden {float(g['c2.loss']):.6f}")
     assert e_x < TOL and e_c < TOL
-    assert e_lg < TOL
+    assert e_lg < TOL             # 6.2e-4 measured (1.28e-3 before the patch embedding went split-precision: DESIGN.md §3)
     assert abs(float(loss) - float(g["c2.loss"])) < 1e-4
     gmax, gmed = _grad_report("config 2", eng.bucket.views, g, "c2.grad.")
-    assert gmax < 1e-1 and gmed < 3e-2     # step-level conditioning; kernels on exact inputs: test_gpu_unet.py
+    assert gmax < 1e-1 and gmed < 6e-2     # step-level conditioning; kernels on exact inputs: test_gpu_unet.py
 
 
 def test_config5_vitg_width_mla11_step_vs_reference_golden(dev):
@@ -79,7 +79,7 @@ def test_config5_vitg_width_mla11_step_vs_reference_golden(dev):
     out = ops.resize_bilinear_fwd(taps["logits"], 588, 588).permute(0, 3, 1, 2)
     e_out = golden_err(out, g["c5.output"])
     print(f"config 5: output (11 classes, 588^2) rel-L2 {e_out:.2e} loss {float(loss):.6f} golden {float(g['c5.loss']):.6f}")
-    assert e_out < TOL
+    assert e_out < TOL            # 7.3e-4 measured
     assert abs(float(loss) - float(g["c5.loss"])) < 1e-4
     gmax, gmed = _grad_report("config 5", eng.bucket.views, g, "c5.grad.")
     assert gmax < 1e-1 and gmed < 3e-2
@@ -99,7 +99,73 @@ def test_vitl_588_batch2_step_vs_reference_golden(dev, mode, tag):
          "logits": golden_err(taps["logits"].permute(0, 3, 1, 2), g[f"{tag}.logits"])}
     print(tag, {k: "%.2e" % v for k, v in e.items()}, "loss", float(loss), "golden", float(g[f"{tag}.loss"]))
     assert e["logits"] < TOL, e
-    assert e["cat"] < 2 * TOL and e["x_final"] < 2 * TOL and e["c_final"] < 2 * TOL, e
+    assert e["cat"] < TOL and e["x_final"] < TOL and e["c_final"] < TOL, e
     assert abs(float(loss) - float(g[f"{tag}.loss"])) < 1e-4
     gmax, gmed = _grad_report(tag, eng.bucket.views, g, f"{tag}.grad.")
-    assert gmax < 1e-1
+    assert gmax < (1e-2 if mode == "init" else 5e-2)
+
+
+def test_one_sided_split_gemm_removes_weight_rounding(dev):
+    """ASIS_PRECISE building block: ``gemm(a, w_hi, b_lo=w_lo)`` / ``gemm(w_hi, x, a_lo=w_lo)`` == a @ (fp32 w)^T up to the
+    rounding of the activations alone; the plain GEMM carries the weight rounding on top."""
+    M, N, K = 512, 256, 1024
+    a = W.tensor("os.a", (M, K), 1.0).to(dev)
+    w = W.tensor("os.w", (N, K), 0.05).to(dev)
+    a16 = ops.cast_pad(a, dtype=torch.float16)
+    w_hi, w_lo = ops.cast_pad(w, dtype=torch.float16), ops.cast_pad(w, dtype=torch.float16, part=1)
+    ref = a16.float() @ w.t()                       # exact weights, rounded activations
+    plain = ops.gemm(a16, w_hi, out_f32=True)
+    fine = ops.gemm(a16, w_hi, out_f32=True, b_lo=w_lo)
+    fine_t = ops.gemm(w_hi, a16, out_f32=True, a_lo=w_lo)          # weights as the A operand (the V^T GEMM)
+    e = lambda x, y: float((x.double() - y.double()).norm() / y.double().norm())
+    print(f"one-sided split: plain {e(plain, ref):.2e}  b_lo {e(fine, ref):.2e}  a_lo {e(fine_t, ref.t()):.2e}")
+    assert e(plain, ref) > 1e-4 and e(fine, ref) < 2e-6 and e(fine_t, ref.t()) < 2e-6
+    out16 = ops.gemm(a16, w_hi, b_lo=w_lo)           # 16-bit output form (qkv)
+    assert out16.dtype == torch.float16 and e(out16.float(), ref) < 4e-4
+
+
+def _stress_case(case, dev):
+    if case == "c2":
+        g = load_golden("c2")
+        D, model, enc, cv, cn = _adapter_modules("vit_base_d4", dev)
+        dec = UNet(D, 2); dec.load_state_dict(W.make_unet_state_dict(D, 2))
+        eng = SegEngine(model, enc, cv, cn, dec.to(dev), lr=0.01, loss="ce_dc")
+        img, tgt = W.synthetic_batch(2, 588)
+        taps = {}
+        eng.train_step(img.to(dev), tgt.to(dev), taps)
+        return golden_err(taps["logits"].permute(0, 3, 1, 2), g["c2.logits"])
+    if case == "c5":
+        g = load_golden("c5")
+        D, model, enc, cv, cn = _adapter_modules("vit_giant2_d4", dev)
+        dec = DecoderMLA(img_size=588, mla_channels=D, mlahead_channels=128, num_classes=11)
+        dec.load_state_dict(W.make_decoder_mla_state_dict(D, 128, 11))
+        eng = SegEngine(model, enc, cv, cn, dec.to(dev), lr=0.01, momentum=0.9, weight_decay=0.0, num_classes=11, loss="iou")
+        img, tgt = W.synthetic_batch(2, 588, 11)
+        taps = {}
+        eng.train_step(img.to(dev), tgt.to(dev), taps)
+        return golden_err(ops.resize_bilinear_fwd(taps["logits"], 588, 588).permute(0, 3, 1, 2), g["c5.output"])
+    from tests.test_gpu_step import build_engine
+    g = load_golden("step")
+    eng, _ = build_engine("vit_large", "kernel", dev)
+    img, tgt = W.synthetic_batch(1, 588)
+    taps = {}
+    eng.train_step(img.to(dev), tgt.to(dev), taps)
+    return golden_err(taps["logits"].permute(0, 3, 1, 2), g["step_kernel.logits"])
+
+
+@pytest.mark.parametrize("case", ["c2", "c5", "step_kernel"])
+def test_precise_attention_mode_lowers_the_stress_error(dev, case):
+    """``config.precise_attention`` (ASIS_PRECISE=1: qkv / proj weights as hi + lo 16-bit halves, one extra MFMA pass over the
+    weight residual) removes the next-largest error term after the patch embedding — the fp16 rounding of the attention
+    weights, which is common to all tokens (tests/precision_probe.py) — at +33 % linear-layer FLOPs; opt-in head-room for
+    checkpoints whose LayerScale / attention weights are larger than the stress goldens'."""
+    from adaptersis_amd import config
+    base = _stress_case(case, dev)
+    old = config.precise_attention
+    config.precise_attention = True
+    try:
+        err = _stress_case(case, dev)
+    finally:
+        config.precise_attention = old
+    print(f"precise attention, {case}: logits rel-L2 {base:.2e} -> {err:.2e}")
+    assert err < base and err < TOL

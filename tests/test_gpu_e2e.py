@@ -59,7 +59,7 @@ def test_unfrozen_adapter_step_vs_oracle_autograd(dev):
     torch.cuda.synchronize()
     e_lg = rel_l2(taps["logits"].permute(0, 3, 1, 2), otaps["logits"])
     print(f"unfrozen step: logits {e_lg:.2e} loss {float(loss):.6f} oracle {float(oloss):.6f}")
-    assert e_lg < 1.5e-3          # toy-width stress weights (tests/test_gpu_step.py)
+    assert e_lg < 1e-3
     assert abs(float(loss) - float(oloss)) < 1e-4
 
     def group(views, ref, strip=""):
@@ -126,7 +126,8 @@ def test_unfrozen_vitl_width_step_vs_reference_golden(dev):
               "encoder": (eng.encoder_bucket.views, "c4.grad."), "decoder": (eng.bucket.views, "c4.grad.dec.")}
     for nm, (views, pre) in groups.items():
         errs = {k: golden_err(v, g[pre + k]) for k, v in views.items()
-                if (pre + k) in g and float(g[pre + k]["sumsq"]) > 1e-20}
+                if (pre + k) in g and float(g[pre + k]["sumsq"]) > 1e-20
+                and not (nm == "decoder" and k.endswith(".0.bias"))}   # conv bias before a train-mode BatchNorm: exact gradient 0
         worst = sorted(errs.items(), key=lambda kv: -kv[1])[:4]
         print(f"  {nm}: n={len(errs)} max %.2e median %.2e  worst %s" % (*_stats(errs), [(k, "%.1e" % v) for k, v in worst]))
         assert len(errs) >= 10

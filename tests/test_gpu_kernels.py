@@ -183,7 +183,9 @@ def test_attention_fwd(dev, dt, B, H, N):
     p = torch.softmax((qf * 0.125) @ kf.transpose(-1, -2), -1)
     ref = (p @ vf).permute(0, 2, 1, 3).reshape(B * N, D)
     assert torch.isfinite(o.float()).all()
-    assert rel_l2(o, ref) < (1.5e-3 if dt == torch.float16 else 1e-2)
+    err = rel_l2(o, ref)
+    print(f"attention fwd {dt} B={B} H={H} N={N}: rel-L2 {err:.2e}")
+    assert err < (1e-3 if dt == torch.float16 else 1e-2)
 
 
 def test_attention_forces_online_softmax_rescale(dev):
@@ -203,7 +205,7 @@ def test_attention_forces_online_softmax_rescale(dev):
     o = ops.attention_fwd(qk[:, :64], qk[:, 64:], vt, B, H, N, 0.125)
     qf, kf, vf = (t.float().reshape(N, 64) for t in (q, k, v))
     ref = torch.softmax((qf * 0.125) @ kf.t(), -1) @ vf
-    assert rel_l2(o, ref) < 1.5e-3
+    assert rel_l2(o, ref) < 1e-3
     assert rel_l2(o[17], ref[17]) < 2e-3
 
 

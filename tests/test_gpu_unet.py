@@ -171,7 +171,9 @@ def test_engine_step_with_unet_head(dev):
         print(f"unet engine step {step}: x_final {e_x:.2e} logits {e_lg:.2e} loss {float(loss):.6f} {float(oloss):.6f}")
         # toy-width stress tolerance (tests/test_gpu_step.py); the second step also carries the first step's
         # parameter difference (lr 0.05 x ill-conditioned gradients) through BatchNorm over as few as 32 samples
-        assert e_lg < (1.5e-3 if step == 0 else 3e-3), step
+        # step 0 holds the north_star tolerance; step 1 starts from parameters that already differ by the first update
+        # (lr 0.05 x the ill-conditioned step-level gradients), which BatchNorm over as few as 32 samples amplifies
+        assert e_lg < (1e-3 if step == 0 else 3e-3), step
         assert abs(float(loss) - float(oloss)) < 1e-4, step
         names = [k for k, v in params.items() if v.requires_grad]
         errs = {k: rel_l2(eng.bucket.views[k], params[k].grad) for k in names}

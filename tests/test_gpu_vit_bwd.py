@@ -215,7 +215,7 @@ def test_end_to_end_engine_step_vs_oracle(dev):
     taps = {}
     loss = eng.train_step(img.to(dev), tgt.to(dev), taps)
     assert rel_l2(taps["tokens"], tok) < 1e-3
-    assert rel_l2(taps["logits"].permute(0, 3, 1, 2), oy) < 1.5e-3
+    assert rel_l2(taps["logits"].permute(0, 3, 1, 2), oy) < 1e-3
     assert abs(float(loss) - float(oloss)) < 1e-4
     # conv biases in front of a train-mode BatchNorm have an exactly-zero true gradient (rounding noise only): skipped
     derr = {k: rel_l2(v, od[k].grad) for k, v in eng.bucket.views.items() if not k.endswith(".0.bias")}
