@@ -174,6 +174,23 @@ class SegEngine(nn.Module):
             self._geom = {key: g}
         return g
 
+    def _encoder_on_side_stream(self, inp: torch.Tensor):
+        """The spatial-prior CNN (≈ 30 small, latency-bound launches + 6 SyncBatchNorm all-reduces of 2C doubles) is
+        independent of the ViT until the first adapter stage: run it on a side HIP stream so it fills the gaps of the
+        GEMM-bound block loop and — on N > 1 ranks — its six blocking statistic exchanges wait for each other there, not
+        on the compute stream.  -> (c tokens, level shapes, event recorded behind the last encoder kernel)."""
+        main = torch.cuda.current_stream()
+        if getattr(self, "_enc_stream", None) is None:
+            self._enc_stream = torch.cuda.Stream()
+        side = self._enc_stream
+        side.wait_stream(main)          # the input batch, and everything of the previous step that read recycled blocks
+        with torch.cuda.stream(side):
+            _, c, shapes = self.backbone_encoder.forward_tokens(inp, need_c1=False)
+            done = torch.cuda.Event()
+            done.record(side)
+        c.record_stream(main)           # allocated on the side stream, consumed on the compute stream
+        return c, shapes, done
+
     def _cavit(self, x2, c2, g, B, Lq, Lin):
         cv = self.cross_vit
         return cv.attn.forward16(cv._ln16("query_norm", x2), cv._ln16("feat_norm", c2), g["ref1"], g["shapes1"],
@@ -198,30 +215,37 @@ class SegEngine(nn.Module):
         N = h * w
         nb = len(m.blocks)
         nl = self.n_last_blocks
+        enc_done = None
         if self.train_encoder and adapter_saves is not None:
             c, shapes, esaved = self.backbone_encoder.forward_tokens_train(inp)
             self._esaved = (esaved, shapes)
+        elif config.encoder_stream and inp.is_cuda:
+            c, shapes, enc_done = self._encoder_on_side_stream(inp)
         else:
             _, c, shapes = self.backbone_encoder.forward_tokens(inp, need_c1=False)
         c_orig = c
         Lc = c.shape[1]
         g = self._geometry(H, W, shapes, inp.device)
         # ---- pass A (train.py:287): cls + pos-embed, all blocks, final norm on the last n outputs ----
-        tokens = m.patch_embed(inp)                       # shared by both passes: same conv on the same input
-        pos = m._pos_for(N, H, W)
-        xa = ops.add_cls_pos(tokens, m.cls_token.detach().reshape(-1).float().contiguous(),
-                             pos.detach().reshape(-1, D).float().contiguous())
         # ---- both passes stacked along the rows: every block evaluation of pass A (cls + pos-embed tokens, all
         # blocks, `train.py:287`) has a pass-B partner on the same frozen weights (raw patch tokens through
-        # blocks[0:-3], `train.py:300-302`, then one more block per adapter stage), so each launch carries 2x the rows
+        # blocks[0:-3], `train.py:300-302`, then one more block per adapter stage), so each launch carries 2x the rows.
+        # The patch embedding (shared by both passes: same conv on the same input) writes pass B's rows of the stacked
+        # buffer directly, the cls / pos-embed form goes into pass A's rows: no concatenation copy.
         Ra, Rb = B * (N + 1), B * N
         segs = [(B, N + 1), (B, N)]
-        xcat = torch.cat([xa.view(Ra, D), tokens.reshape(Rb, D)], 0)
+        xcat = torch.empty((Ra + Rb, D), device=inp.device, dtype=torch.float32)
+        tokens, _ = m.patch_embed.tokens(inp, out=xcat[Ra:])
+        pos = m._pos_for(N, H, W)
+        ops.add_cls_pos(tokens, m.cls_token.detach().reshape(-1).float().contiguous(),
+                        pos.detach().reshape(-1, D).float().contiguous(), out=xcat[:Ra].view(B, N + 1, D))
         feats = []
         for i, blk in enumerate(m.blocks[: nb - (nl - 1)]):
             xcat = blk.forward_rows(xcat, segs)
             if i >= nb - nl:
                 feats.append(m._final_norm(xcat[:Ra].view(B, N + 1, D))[:, 1:])   # [B, N, D] view, batch stride (N+1)*D
+        if enc_done is not None:
+            torch.cuda.current_stream().wait_event(enc_done)   # the pyramid tokens are first needed by adapter stage 0
         if taps is not None:
             taps.update(c=c, x_b0=xcat[Ra:].view(B, N, D).clone(), shapes=shapes)
         c2d = c.view(B * Lc, D)

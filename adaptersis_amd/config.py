@@ -37,3 +37,7 @@ split_conv = os.environ.get("ASIS_SPLIT_CONV", "1") != "0"
 # weights to 16 bits is the largest error term on the adapter stream — it is the same for every token, so it adds up
 # coherently through the blocks — and qkv + proj carry 55 % of its energy.  Off by default: +33 % linear-layer FLOPs.
 precise_attention = os.environ.get("ASIS_PRECISE", "0") not in ("0", "")
+
+# The CNN encoder of the frozen-backbone step runs on a side HIP stream, overlapped with the ViT block loop
+# (engines.SegEngine._encoder_on_side_stream).  ASIS_ENC_STREAM=0: everything on the compute stream.
+encoder_stream = os.environ.get("ASIS_ENC_STREAM", "1") not in ("0", "")

@@ -233,13 +233,16 @@ int launch(hipStream_t s, const asis_gemm_desc& d) {
     // <= 64 output channels: 512x64 tile, 8 waves of 64x64 (1 KB of LDS fragment reads per MFMA; the 256x64 form's 32x64
     // wave tiles need 1.5 KB and are LDS-bound), one workgroup per CU: +0.6 % on the step (ASIS_CONV_T512=0: old form)
     static const int t512 = [] { const char* e = getenv("ASIS_CONV_T512"); return e ? atoi(e) : 1; }();
+    static const int cm16 = [] { const char* e = getenv("ASIS_CONV_M16"); return e ? atoi(e) : 0; }();  // 16x16x32 MFMAs in the split convs
     if (d.conv && bn == 64 && t512 && d.ksplit <= 1 && d.M >= 512) {
       dim3 g512(((d.M + 511) / 512) * ((d.N + 63) / 64), 1);
-      hipLaunchKernelGGL((gemm_big_kernel<T, 8, 1, 2, 2, 2, 0, true, true, 64, 1>), g512, block, 0, s, d, group_m);
+      if (cm16) hipLaunchKernelGGL((gemm_big_kernel<T, 8, 1, 2, 2, 2, 0, true, true, 64, 1, false, true>), g512, block, 0, s, d, group_m);
+      else hipLaunchKernelGGL((gemm_big_kernel<T, 8, 1, 2, 2, 2, 0, true, true, 64, 1>), g512, block, 0, s, d, group_m);
       return 0;
     }
     if (d.conv) {
       if (conv32 && bn == 128) hipLaunchKernelGGL((gemm_big_kernel<T, 4, 2, 2, 2, 3, 0, true, true, 32, 4>), grid, block, 0, s, d, group_m);
+      else if (bn == 128 && cm16) hipLaunchKernelGGL((gemm_big_kernel<T, 4, 2, 2, 2, 3, 0, true, true, 64, 2, false, true>), grid, block, 0, s, d, group_m);
       else if (bn == 128) hipLaunchKernelGGL((gemm_big_kernel<T, 4, 2, 2, 2, 3, 0, true, true>), grid, block, 0, s, d, group_m);
       else hipLaunchKernelGGL((gemm_big_kernel<T, 8, 1, 1, 2, 3, 0, true, true>), grid, block, 0, s, d, group_m);
     } else {

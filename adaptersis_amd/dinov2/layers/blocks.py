@@ -115,8 +115,9 @@ class PatchEmbed(_Packed):
         if norm_layer:
             raise ValueError("PatchEmbed: norm_layer is not used on this path (vision_transformer.py:104)")
 
-    def tokens(self, x: torch.Tensor):
-        """-> (tokens fp32 (B, N, D), a16 = the 16-bit im2col operand (hi half) for the weight gradient).  With
+    def tokens(self, x: torch.Tensor, out: Optional[torch.Tensor] = None):
+        """-> (tokens fp32 (B, N, D) — written into ``out`` fp32 [B*N, D] when given —, a16 = the 16-bit im2col operand (hi
+        half) for the weight gradient).  With
         ``config.split_conv`` the conv runs on hi + lo halves of pixels and weights (three MFMA passes over K = 588 -> 640):
         its 16-bit operand rounding is the largest single error term of the step on the features (tests/precision_probe.py:
         2.7e-4 of 3.3e-4 on the adapter stream) because it enters BOTH ViT passes at their very first layer, while the conv
@@ -132,14 +133,15 @@ class PatchEmbed(_Packed):
             w_hi = _pack(self._cache, "w64", self.proj.weight, lambda p: ops.cast_pad(flat(p), ldk, dt))
             w_lo = _pack(self._cache, "w64lo", self.proj.weight, lambda p: ops.cast_pad(flat(p), ldk, dt, part=1))
             a, a_lo = ops.im2col_patch(x.contiguous().float(), P, ldk, dt, split=True)
-            out = torch.empty((a.shape[0], self.embed_dim), device=x.device, dtype=torch.float32)
+            if out is None:
+                out = torch.empty((a.shape[0], self.embed_dim), device=x.device, dtype=torch.float32)
             ops.gemm_split(a, a_lo, w_hi, w_lo, out=out, bias_n=bias)
         else:
             ldk = (K + 7) // 8 * 8
             w16 = _pack(self._cache, "w", self.proj.weight,
                         lambda p: ops.cast_pad(p.reshape(p.shape[0], -1).contiguous().float(), ldk, dt))
             a = ops.im2col_patch(x.contiguous().float(), P, ldk, dt)
-            out = ops.gemm(a, w16, out_f32=True, bias_n=bias)
+            out = ops.gemm(a, w16, out=out, out_f32=True, bias_n=bias)
         return out.view(B, (H // P) * (W // P), self.embed_dim), a
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:

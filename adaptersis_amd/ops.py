@@ -407,11 +407,14 @@ def cast_pad(src: torch.Tensor, ld_dst: Optional[int] = None, dtype: torch.dtype
     return out
 
 
-def add_cls_pos(x: torch.Tensor, cls: torch.Tensor, pos: torch.Tensor) -> torch.Tensor:
+def add_cls_pos(x: torch.Tensor, cls: torch.Tensor, pos: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """x [B,N,D] f32, cls [D], pos [N+1,D] -> [B,N+1,D] (vision_transformer.py:196-197)."""
-    _dev(x, cls, pos)
+    _dev(x, cls, pos, out)
     B, N, D = x.shape
-    out = torch.empty((B, N + 1, D), device=x.device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty((B, N + 1, D), device=x.device, dtype=torch.float32)
+    elif out.dtype != torch.float32 or tuple(out.shape) != (B, N + 1, D) or not out.is_contiguous():
+        raise ValueError("add_cls_pos: out must be a contiguous float32 [B, N+1, D] tensor")
     check(lib().asis_add_cls_pos(_stream(), _f32c(x).data_ptr(), _f32c(cls).data_ptr(), _f32c(pos).data_ptr(),
                                  out.data_ptr(), B, N, D), "asis_add_cls_pos")
     return out

@@ -1,3 +1,3 @@
 for a in "" "--config 2" "--config 4" "--config 5" "--train-adapters" "--train-adapters --train-encoder"; do
-  python bench.py $a --steps 8 --warmup 3 2>/dev/null | python -c "import sys,json; j=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('$a', j['value'], j['ms_per_step'], j['roofline']['achieved'])"
+  python bench.py $a --steps 8 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; j=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('$a', j['value'], j['ms_per_step'], j['roofline']['achieved'])"
 done
