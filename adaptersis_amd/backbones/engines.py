@@ -133,8 +133,12 @@ class SegEngine(nn.Module):
             # the trainable set the reference's optimiser lists for the adapters (`train.py:178-186`) and that its
             # no_grad block (`:389-406`) and forward-only MSDeformAttnFunction keep from ever training (SURVEY facts
             # 1-2): CAViT + CACNN parameters, one flat bucket, all-reduced once the adapter backward is enqueued
-            if type(seg_decoder).__name__ not in ("FeatureDecoder", "DecoderSETR"):
-                raise NotImplementedError("train_adapters is built for the train.py flow (FeatureDecoder head)")
+            if type(seg_decoder).__name__ not in ("FeatureDecoder", "DecoderSETR", "UNet"):
+                raise NotImplementedError("train_adapters is built for the train.py adapter flow (FeatureDecoder / UNet heads); "
+                                          "the train_mla.py stage order (block -> CACNN -> CAViT, repeated block) has no backward")
+            if self.stream_only and (train_encoder or train_backbone):
+                raise NotImplementedError("the UNet head trains decoder + adapters (BASELINE config 2); encoder / backbone "
+                                          "training is built for the FeatureDecoder flow")
             for p in list(cross_vit.parameters()) + list(cross_cnn.parameters()):
                 p.requires_grad_(True)
             named_a = [("cross_vit." + n, p) for n, p in cross_vit.named_parameters()] + \
@@ -362,7 +366,10 @@ class SegEngine(nn.Module):
         else:
             asaves = [] if self.mode == "train_adapters" else None
             cat = self.features(inp, taps, asaves)
-            logits, saved = dec._forward_core(cat[0], cat[1], save=True, training=True)
+            if self.stream_only and asaves is not None:
+                logits, saved = dec._forward_core(cat[0], cat[1], save=True, training=True, need_input_grad=True)
+            else:
+                logits, saved = dec._forward_core(cat[0], cat[1], save=True, training=True)
         target = target.long().contiguous()
         n_region, lmode, eps, n_ce = self.LOSSES[self.loss_kind]
         loss, coef, _ = ops.seg_loss_fwd(logits, target, n_region, lmode, eps, n_ce, None, S)
@@ -539,7 +546,9 @@ class SegEngine(nn.Module):
         self._block_done(-1)
 
     def _adapter_backward(self, asaves, dcat: torch.Tensor, inv: float) -> None:
-        """Backward of the four adapter stages (`train.py:304-387` under autograd, minus its no_grad):
+        """(``dcat`` [B, h, w, 3D] = gradient of the FeatureDecoder input concat, or [B, h, w, D] = gradient of the
+        adapter-stream map alone for the UNet head.)
+        Backward of the four adapter stages (`train.py:304-387` under autograd, minus its no_grad):
         d cat[..., :D] is the gradient of the adapter stream; the c4 and pass-A slices of the decoder input come from
         the frozen encoder / backbone.  Per stage, in reverse: x = x2 + feat (identity), CACNN (only when its output
         fed a later stage: the last one is dead code in the reference flow), CAViT, and the input gradient of the
@@ -547,7 +556,7 @@ class SegEngine(nn.Module):
         stage writes its own gradient slab and the slabs are summed in a fixed order."""
         m, cv, cn = self.model, self.cross_vit, self.cross_cnn
         B, h, w, D3 = dcat.shape
-        D = D3 // 3
+        D = m.embed_dim
         N = h * w
         nl = self.n_last_blocks
         nb = len(m.blocks)

@@ -196,15 +196,17 @@ class UNet(_Packed):
         lo = ops.cast_pad(x2, C, config.operand_dtype, part=1).view(B, H, W, C) if config.split_conv else None
         return hi, lo
 
-    def _forward_core(self, x16, x_lo, save: bool, training: Optional[bool] = None):
-        """(hi, lo|None) NHWC 16-bit [B,h,w,C] -> logits fp32 NHWC [B,4h,4w,classes] and the saved state."""
+    def _forward_core(self, x16, x_lo, save: bool, training: Optional[bool] = None, need_input_grad: bool = False):
+        """(hi, lo|None) NHWC 16-bit [B,h,w,C] -> logits fp32 NHWC [B,4h,4w,classes] and the saved state.
+        ``need_input_grad``: also keep the first MaxPool's arg-max (the input is trainable upstream: `train_adapters`)."""
         training = self.training if training is None else training
         if x16.shape[-1] != self.n_channels:
             raise ValueError(f"UNet: input has {x16.shape[-1]} channels, built for {self.n_channels}")
         split = x_lo is not None
         sv = {}
         x3 = (x16, x_lo)
-        p3h, p3l, _ = ops.maxpool2_fwd(x3[0], x3[1], save_idx=False)       # no gradient flows to the frozen input
+        p3h, p3l, sv["idx3"] = ops.maxpool2_fwd(x3[0], x3[1], save_idx=save and need_input_grad)   # frozen input: no arg-max kept
+        sv["x3_shape"] = x16.shape
         x4, sv["down3"] = self._dconv_fwd("d3", self.down3.maxpool_conv[1], (p3h, p3l), save, training)
         p4h, p4l, sv["idx4"] = ops.maxpool2_fwd(x4[0], x4[1], save_idx=save)
         x5, sv["down4"] = self._dconv_fwd("d4", self.down4.maxpool_conv[1], (p4h, p4l), save, training)
@@ -231,9 +233,11 @@ class UNet(_Packed):
         sv["x4_shape"] = x4[0].shape
         return logits.view(B, H, W, oc.out_channels), sv
 
-    def _backward_core(self, saved, d16, bias_partial, inv_scale, grads, dlogits_f32=None, stage_done=None, d_lo=None):
+    def _backward_core(self, saved, d16, bias_partial, inv_scale, grads, dlogits_f32=None, stage_done=None, d_lo=None,
+                       need_input_grad: bool = False):
         """d16 (+ d_lo): 16-bit [B,H,W,CP] = loss_scale * dL/dlogits (pad channels zero); same contract as
-        ``FeatureDecoder._backward_core``."""
+        ``FeatureDecoder._backward_core``.  ``need_input_grad`` (forward run with it too): returns loss_scale * dL/d(input)
+        fp32 NHWC = the skip gradient out of up2's concat + the MaxPool transpose of down3's input gradient."""
         dt = config.operand_dtype
         oc = self.outc.conv
         C = oc.out_channels
@@ -269,7 +273,12 @@ class UNet(_Packed):
         dU = self._up_bwd("u3", self.up3.up, saved["up3.up"], dcat, inv_scale, grads, "up3.up")
         done()
         dcat = self._dconv_bwd("u2c", self.up2.conv, saved["up2"], dU, inv_scale, grads, "up2.conv", True)
-        dU = self._up_bwd("u2", self.up2.up, saved["up2.up"], dcat, inv_scale, grads, "up2.up")  # skip part: frozen input
+        dU = self._up_bwd("u2", self.up2.up, saved["up2.up"], dcat, inv_scale, grads, "up2.up")
+        g3 = None
+        if need_input_grad:    # x3 = the head's input: skip gradient = leading channels of up2's concat
+            B3, H3, W3, C3 = saved["x3_shape"]
+            g3 = torch.empty((B3, H3, W3, C3), device=d16.device, dtype=torch.float32)
+            ops.copy_channels(dcat.view(-1, dcat.shape[-1])[:, :C3], g3.view(-1, C3))
         done()
         dcat = self._dconv_bwd("u1c", self.up1.conv, saved["up1"], dU, inv_scale, grads, "up1.conv", True)
         dU = self._up_bwd("u1", self.up1.up, saved["up1.up"], dcat, inv_scale, grads, "up1.up")
@@ -282,9 +291,12 @@ class UNet(_Packed):
                              "down4.maxpool_conv.1", True)
         ops.maxpool2_bwd(dP, saved["idx4"], g4)
         done()
-        self._dconv_bwd("d3", self.down3.maxpool_conv[1], saved["down3"], g4, inv_scale, grads, "down3.maxpool_conv.1",
-                        False)
+        dP3 = self._dconv_bwd("d3", self.down3.maxpool_conv[1], saved["down3"], g4, inv_scale, grads, "down3.maxpool_conv.1",
+                              need_input_grad)
         done()
+        if need_input_grad:
+            ops.maxpool2_bwd(dP3, saved["idx3"], g3)
+        return g3
 
     # ---- reference-shaped entry point ------------------------------------------------------------------------------
     def forward(self, x):

@@ -1,0 +1,84 @@
+"""GPU: numerics modes and operand-range stress of the whole step.
+
+* bf16 operand mode (north_star names "MFMA bf16"; DESIGN.md §3: fp16 is the default because bf16's 8-bit mantissa puts
+  ~8x the rounding error on every GEMM operand): the whole ViT-L/14 588x588 step in ``ASIS_OPERAND=bf16`` against the
+  reference goldens — holds 1e-3 on the reference configuration, not on the stress weights (bound stated below).
+* f16 operand RANGE: DINOv2 checkpoints carry "massive activation" channels (residual outliers of 1e2-1e3 out of fc2 of
+  a middle block, large fc1 pre-activations, saturated attention rows); there is no network to fetch real weights, so they are
+  injected into the synthetic ones: every 16-bit operand (LayerNorm outputs, q/k/v/P, GELU outputs) must stay finite and
+  the step within 1e-3 of the fp32 oracle."""
+import pytest
+import torch
+
+from adaptersis_amd import config
+from adaptersis_amd.utils import weights as W
+from oracle import ref_torch as O
+from tests.conftest import golden_err, load_golden, rel_l2
+from tests.test_gpu_step import build_engine
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def bf16_mode():
+    old_dt, old_ls = config.operand_dtype, config.loss_scale
+    config.set_operand_dtype(torch.bfloat16)
+    config.loss_scale = 1.0
+    yield
+    config.set_operand_dtype(old_dt)
+    config.loss_scale = old_ls
+
+
+@pytest.mark.parametrize("mode,tag,bound", [("init", "step_exact", 1e-3), ("kernel", "step_kernel", 1.2e-2)])
+def test_bf16_operand_mode_whole_step_vs_reference_golden(dev, bf16_mode, mode, tag, bound):
+    g = load_golden("step")
+    eng, _ = build_engine("vit_large", mode, dev)
+    img, tgt = W.synthetic_batch(1, 588)
+    taps = {}
+    loss = eng.train_step(img.to(dev), tgt.to(dev), taps)
+    e_cat = golden_err(taps["cat"].float().permute(0, 3, 1, 2), g[f"{tag}.cat"])
+    e_lg = golden_err(taps["logits"].permute(0, 3, 1, 2), g[f"{tag}.logits"])
+    print(f"bf16 operands, {tag}: cat {e_cat:.2e} logits {e_lg:.2e} loss {float(loss):.6f} golden {float(g[f'{tag}.loss']):.6f}")
+    assert torch.isfinite(loss).item()
+    # reference configuration (LayerScale 1e-5, adapter gamma 0): 1e-3 holds in bf16 too — the split-precision convs and patch
+    # embedding keep 16 significant bits where it matters; stress weights: bf16's 8-bit mantissa on all 48 block evaluations
+    assert e_lg < bound, (tag, e_lg)
+
+
+def _massive_weights(arch):
+    """Synthetic weights with DINOv2-like outliers: two residual channels pushed to ~+-600 by one fc2 bias and the patch-embed
+    bias, one block with 6x fc1 weights (pre-activations of +-30), one with 3x qkv weights (saturated attention rows)."""
+    D, depth, heads, _ = W.VIT_CONFIGS[arch]
+    sd = W.make_vit_state_dict(arch, layerscale="kernel")
+    sd["patch_embed.proj.bias"][5] += 300.0
+    sd["blocks.1.mlp.fc2.bias"][77] -= 2000.0            # x LayerScale gamma (0.05 .. 0.5) -> -100 .. -1000 in the residual
+    sd["blocks.2.mlp.fc1.weight"] *= 6.0
+    sd["blocks.1.attn.qkv.weight"] *= 3.0
+    return sd
+
+
+def test_f16_operand_range_with_massive_activations(dev):
+    arch, size, B = "vit_tiny_test", 224, 2
+    D, depth, heads, ffn = W.VIT_CONFIGS[arch]
+    eng, sds = build_engine(arch, "kernel", dev, (128, 32, 16, 16, 8), lr=0.05)
+    vsd = _massive_weights(arch)
+    eng.model.load_state_dict(vsd)
+    img, tgt = W.synthetic_batch(B, size, seed=4)
+    taps = {}
+    loss = eng.train_step(img.to(dev), tgt.to(dev), taps)
+    otaps = {}
+    with torch.no_grad():
+        ocat = O.adapter_forward(img, vsd, {k: v.clone() for k, v in sds["enc"].items()}, sds["cv"], sds["cn"], heads, taps=otaps)
+    params = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sds["dec"].items()}
+    oloss = O.train_step_loss(ocat, tgt, params, 2, otaps)
+    xo = otaps["x_stage3"]
+    amax = float(xo.abs().max())
+    assert amax > 100.0, amax                              # the outliers really are in the stream
+    x = taps["x_final"].float().cpu()
+    assert torch.isfinite(x).all() and torch.isfinite(taps["logits"]).all() and torch.isfinite(loss).item()
+    keep = [c for c in range(D) if c not in (5, 77)]
+    e_all, e_rest = rel_l2(x, xo), rel_l2(x[..., keep], xo[..., keep])
+    e_lg = rel_l2(taps["logits"].permute(0, 3, 1, 2), otaps["logits"])
+    print(f"massive activations (|x|max {amax:.0f}): x_final {e_all:.2e} (non-outlier channels {e_rest:.2e}) logits {e_lg:.2e}")
+    assert e_rest < 1e-3 and e_lg < 1e-3
+    assert abs(float(loss) - float(oloss)) < 1e-4

@@ -184,3 +184,53 @@ def test_engine_step_with_unet_head(dev):
             O.sgd_momentum_step({k: params[k] for k in names}, {k: params[k].grad for k in names}, bufs, 0.05)
         live = dict(eng.seg_decoder.named_parameters())
         assert max(rel_l2(live[k], params[k]) for k in names) < 1e-3, step
+
+
+def test_train_adapters_with_unet_head(dev):
+    """BASELINE config 2 with the adapters in the trainable set (VERDICT r1 missing #7): UNet head input gradient (skip out
+    of up2's concat + MaxPool transpose of down3) -> four adapter stages -> CAViT / CACNN gradients, against autograd of the
+    oracle with the graph intact."""
+    from adaptersis_amd.backbones.adapter_blocks import CACNN, CAViT
+    from adaptersis_amd.backbones.encoders import FeatureEncoder
+    from adaptersis_amd.backbones.engines import SegEngine
+    from adaptersis_amd.dinov2.models import vision_transformer as vits
+    arch, size, B = "vit_tiny_test", 224, 2
+    D, depth, heads, ffn = W.VIT_CONFIGS[arch]
+    sds = dict(vit=W.make_vit_state_dict(arch, layerscale="kernel"), enc=W.make_encoder_state_dict(D),
+               cv=W.make_cavit_state_dict(D, mode="kernel"), cn=W.make_cacnn_state_dict(D, mode="kernel"),
+               dec=W.make_unet_state_dict(D, 2))
+    model = vits.__dict__[arch](patch_size=14, img_size=518, init_values=1e-5, ffn_layer=ffn, block_chunks=0)
+    model.load_state_dict(sds["vit"])
+    enc = FeatureEncoder(embed_dim=D); enc.load_state_dict(sds["enc"])
+    cv = CAViT(dim=D, n_levels=3, num_heads=8, init_values=0.0, n_points=4); cv.load_state_dict(sds["cv"])
+    cn = CACNN(dim=D, n_levels=1, num_heads=8, n_points=4, with_cffn=True, cffn_ratio=0.25); cn.load_state_dict(sds["cn"])
+    dec = UNet(D, 2); dec.load_state_dict(sds["dec"])
+    eng = SegEngine(model.to(dev).eval(), enc.to(dev), cv.to(dev), cn.to(dev), dec.to(dev), lr=0.05, loss="ce_dc",
+                    mode="train_adapters")
+    img, tgt = W.synthetic_batch(B, size)
+    ocv = {k: v.clone().requires_grad_(True) for k, v in sds["cv"].items()}
+    ocn = {k: v.clone().requires_grad_(True) for k, v in sds["cn"].items()}
+    odec = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sds["dec"].items()}
+    otaps = {}
+    O.adapter_forward(img, sds["vit"], {k: v.clone() for k, v in sds["enc"].items()}, ocv, ocn, heads, taps=otaps)
+    xs = otaps["x_stage3"].transpose(1, 2).reshape(B, D, size // 14, size // 14)
+    oy = O.unet(xs, odec, update_bn=True)
+    oo = F.interpolate(oy, size=(size, size), mode="bilinear")
+    oloss = O.cross_entropy_nd(oo, tgt) + O.dc_loss(oo, O.one_hot(tgt, 2))
+    oloss.backward()
+    taps = {}
+    loss = eng.train_step(img.to(dev), tgt.to(dev), taps)
+    assert rel_l2(taps["logits"].permute(0, 3, 1, 2), oy) < 1e-3
+    assert abs(float(loss) - float(oloss)) < 1e-4
+    aerr = {}
+    for k, v in eng.adapter_bucket.views.items():
+        mod, name = k.split(".", 1)
+        ref = (ocv if mod == "cross_vit" else ocn)[name].grad
+        if ref is not None and float(ref.norm()) > 0:
+            aerr[k] = rel_l2(v, ref)
+    vals = sorted(aerr.values())
+    print("UNet head train_adapters: adapter grads n=%d max %.2e median %.2e" % (len(vals), vals[-1], vals[len(vals) // 2]))
+    assert len(aerr) == 33 and vals[-1] < 2.5e-1 and vals[len(vals) // 2] < 6e-2, aerr
+    derr = {k: rel_l2(v, odec[k].grad) for k, v in eng.bucket.views.items()}
+    assert max(derr.values()) < 1e-1, derr
+    assert len(eng.optimizer.param_groups) == 2
