@@ -215,7 +215,7 @@ def pmc_traffic(kernel: str, variant: str):
     """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
     WRITE_SIZE in separate runs of this very command, gfx950 read-side doubling applied: scripts/pmc_traffic.py).
     PMC counters cannot be collected from inside the timed run, so this is the figure of the last profiled run."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_traffic.json")
     if not os.path.exists(path):
         return None
     with open(path) as f:
@@ -275,6 +275,16 @@ def main():
         raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
                          f"(python bench.py --gpus N starts them itself)")
 
+    if os.environ.get("ASIS_BENCH_RANKCHECK"):
+        # launcher rehearsal without GPUs (tests/test_bench_launcher.py): rendezvous over gloo, count the ranks, stop
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"rankcheck": True, "n_gpus": a.gpus, "n_ranks_seen": dist.get_world_size(), "sum": float(t)}), flush=True)
+        dist.destroy_process_group()
+        return 0
     # the in-tree library is built (normally a no-op) BEFORE the first GPU call of this process: no compiler children
     # under an initialised HIP runtime / a preloaded profiler.  File-locked: one rank builds, the others wait.
     from adaptersis_amd.build import build_library
