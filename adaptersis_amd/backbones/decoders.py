@@ -76,6 +76,9 @@ def conv_bn_relu_up_forward(owner: _Packed, key: str, x16, x_lo, conv: nn.Conv2d
     statistics (``seg_decoder.eval()`` in validate_network, train.py:451) and nothing is saved.  ``stride`` / ``pad``:
     the 3x3 conv's geometry (the CNN encoder's stride-2 stages); ``pool``: MaxPool2d(3, 2, 1) after the ReLU (stem)."""
     dt = config.operand_dtype
+    split_out = x_lo is not None                   # the next stage's operand pair keeps the caller's precision mode
+    if key in config.unsplit_layers:
+        x_lo = None                                # this layer's conv on plain 16-bit operands (lab switch)
     split = x_lo is not None
     B, H, W, _ = x16.shape
     OH, OW = (H + 2 * pad - 3) // stride + 1, (W + 2 * pad - 3) // stride + 1
@@ -97,12 +100,12 @@ def conv_bn_relu_up_forward(owner: _Packed, key: str, x16, x_lo, conv: nn.Conv2d
         mean = invstd = count = None
         save = False
     if pool:
-        up = ops.bn_relu_maxpool(raw, scale, shift, dt, split)
+        up = ops.bn_relu_maxpool(raw, scale, shift, dt, split_out)
     elif factor > 1:
-        up = ops.bn_relu_upsample(raw, scale, shift, factor, dt, split)
+        up = ops.bn_relu_upsample(raw, scale, shift, factor, dt, split_out)
     else:
-        up = ops.bn_act(raw, scale, shift, True, dt, split)
-    if not split:
+        up = ops.bn_act(raw, scale, shift, True, dt, split_out)
+    if not split_out:
         up = (up, None)
     st = None
     if save:

@@ -55,6 +55,8 @@ class FeatureEncoder(_Packed):
     def _conv_bn(self, a, key, conv, bn, sync):
         """a = (hi, lo|None) NHWC 16-bit -> (raw fp32 NHWC, scale, shift)."""
         x16, x_lo = a
+        if key in config.unsplit_layers:
+            x_lo = None                     # lab switch: this layer's conv on plain 16-bit operands (DESIGN.md §3 table)
         B, H, W, _ = x16.shape
         s, p = conv.stride[0], conv.padding[0]
         OH, OW = (H + 2 * p - 3) // s + 1, (W + 2 * p - 3) // s + 1

@@ -41,3 +41,7 @@ precise_attention = os.environ.get("ASIS_PRECISE", "0") not in ("0", "")
 # The CNN encoder of the frozen-backbone step runs on a side HIP stream, overlapped with the ViT block loop
 # (engines.SegEngine._encoder_on_side_stream).  ASIS_ENC_STREAM=0: everything on the compute stream.
 encoder_stream = os.environ.get("ASIS_ENC_STREAM", "1") not in ("0", "")
+
+# Layers whose forward conv runs on plain 16-bit operands although split_conv is on (comma-separated stage keys: d1..d4 =
+# FeatureDecoder stages, stem3 / stem6 / conv2 / conv3 / conv4 = encoder): the lab switch behind DESIGN.md's per-layer table.
+unsplit_layers = set(filter(None, os.environ.get("ASIS_UNSPLIT", "").split(",")))

@@ -306,3 +306,69 @@ def test_vit_backward_golden():
     for k, v in sd.items():
         if f"vitbwd.grad.{k}" in g:
             assert golden_err(v.grad, g[f"vitbwd.grad.{k}"]) < 1e-4, k
+
+
+def test_round2_goldens_are_well_formed():
+    """c2 / c4 / c5 / step_b2 (full-width configs, generated by the imported reference modules): present, finite,
+    self-consistent shapes — the cheap part; the oracle re-runs below are minutes of CPU (ASIS_SLOW=1)."""
+    want = {"c2": ["c2.logits", "c2.x_final", "c2.loss", "c2.grad.outc.conv.weight", "c2.grad.down3.maxpool_conv.1.double_conv.0.weight"],
+            "c4": ["c4.logits", "c4.cat", "c4.loss", "c4.grad.vit.blocks.0.attn.qkv.weight", "c4.grad.vit.cls_token",
+                   "c4.grad.cross_vit.gamma", "c4.grad.cross_cnn.ffn.fc2.weight", "c4.grad.backbone_encoder.stem.0.weight",
+                   "c4.grad.dec.decoder_1.0.weight"],
+            "c5": ["c5.output", "c5.in0", "c5.in3", "c5.loss", "c5.grad.cls_3.weight", "c5.grad.mlahead.head2.0.weight"],
+            "step_b2": ["step_b2_exact.logits", "step_b2_kernel.logits", "step_b2_kernel.cat", "step_b2_exact.grad.final_out.weight"]}
+    for name, keys in want.items():
+        g = load_golden(name)
+        for k in keys:
+            assert k in g, (name, k)
+            e = g[k]
+            if isinstance(e, dict):
+                assert torch.isfinite(e["vals"]).all() and float(e["sumsq"]) > 0, (name, k)
+            else:
+                assert torch.isfinite(e).all()
+    assert load_golden("c2")["c2.logits"]["shape"].tolist() == [2, 2, 168, 168]          # UNet(768): 4 x 42, batch 2
+    assert load_golden("c5")["c5.output"]["shape"].tolist() == [2, 11, 588, 588]         # 11 classes
+    assert load_golden("step_b2")["step_b2_kernel.logits"]["shape"].tolist() == [2, 2, 672, 672]
+    n_vit = sum(1 for k in load_golden("c4") if k.startswith("c4.grad.vit."))
+    assert n_vit == 62                                                                   # every ViT-L-width (4 blocks) parameter
+
+
+@pytest.mark.slow
+def test_config5_width_oracle_vs_golden():
+    """ViT-g width (SwiGLU) + adapters(1536) + DecoderMLA 11 classes: the oracle reproduces the imported reference's outputs."""
+    g = load_golden("c5")
+    arch = "vit_giant2_d4"
+    D, depth, heads, _ = W.VIT_CONFIGS[arch]
+    img, tgt = W.synthetic_batch(2, 588, 11)
+    with torch.no_grad():
+        maps = O.mla_forward(img, W.make_vit_state_dict(arch, layerscale="kernel"), W.make_encoder_state_dict(D),
+                             W.make_cavit_state_dict(D, mode="kernel"), W.make_cacnn_state_dict(D, mode="kernel"), heads)
+        for i, m in enumerate(maps):
+            assert golden_err(m, g[f"c5.in{i}"]) < 5e-5
+        taps = {}
+        loss = O.train_step_loss_mla(maps, tgt, W.make_decoder_mla_state_dict(D, 128, 11), 11, "iou", taps)
+    assert golden_err(taps["out"], g["c5.output"]) < 1e-4 and abs(float(loss) - float(g["c5.loss"])) < 1e-6
+
+
+@pytest.mark.slow
+def test_config4_unfrozen_oracle_autograd_vs_golden():
+    """The oracle under autograd with the whole graph intact == the imported reference modules' gradients (c4.pt)."""
+    g = load_golden("c4")
+    arch = "vit_large_d4"
+    D, depth, heads, _ = W.VIT_CONFIGS[arch]
+    leaf = lambda sd: {k: t.clone().requires_grad_(t.is_floating_point() and "running" not in k and "num_batches" not in k)
+                       for k, t in sd.items()}
+    vit, enc = leaf(W.make_vit_state_dict(arch, layerscale="kernel")), leaf(W.make_encoder_state_dict(D))
+    cv, cn = leaf(W.make_cavit_state_dict(D, mode="kernel")), leaf(W.make_cacnn_state_dict(D, mode="kernel"))
+    dec = leaf(W.make_feature_decoder_state_dict(D, 2, features=(D, 512, 256, 128, 64)))
+    img, tgt = W.synthetic_batch(1, 588)
+    cat = O.adapter_forward(img, vit, enc, cv, cn, heads)
+    taps = {}
+    loss = O.train_step_loss(cat, tgt, dec, 2, taps)
+    loss.backward()
+    assert golden_err(taps["logits"], g["c4.logits"]) < 1e-4 and abs(float(loss) - float(g["c4.loss"])) < 1e-6
+    for pre, sd in (("vit.", vit), ("cross_vit.", cv), ("cross_cnn.", cn), ("backbone_encoder.", enc), ("dec.", dec)):
+        for k, v in sd.items():
+            key = f"c4.grad.{pre}{k}"
+            if key in g and not (pre == "dec." and k.endswith(".0.bias")):
+                assert golden_err(v.grad, g[key]) < 5e-3, key
