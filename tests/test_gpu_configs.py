@@ -169,3 +169,34 @@ def test_precise_attention_mode_lowers_the_stress_error(dev, case):
         config.precise_attention = old
     print(f"precise attention, {case}: logits rel-L2 {base:.2e} -> {err:.2e}")
     assert err < base and err < TOL
+
+
+def test_config1_vits_224_batch2_step_vs_oracle(dev):
+    """BASELINE config 1: ViT-S/14 (D = 384, 6 heads, 12 blocks; MSDA head dim 48) frozen + adapter, 224x224, batch 2 — the
+    reference's own CPU-runnable plumbing case, except that its scripts hard-code 1024 / 18x18: the
+    generalised flow against the fp32 oracle, whole step incl. SGD."""
+    from tests.test_gpu_step import build_engine
+    from oracle import ref_torch as O
+    from tests.conftest import rel_l2
+    arch, size, B = "vit_small", 224, 2
+    D, depth, heads, _ = W.VIT_CONFIGS[arch]
+    eng, sds = build_engine(arch, "kernel", dev, (D, 64, 32, 16, 8), lr=0.05)
+    img, tgt = W.synthetic_batch(B, size)
+    taps = {}
+    loss = eng.train_step(img.to(dev), tgt.to(dev), taps)
+    otaps = {}
+    with torch.no_grad():
+        ocat = O.adapter_forward(img, sds["vit"], {k: v.clone() for k, v in sds["enc"].items()}, sds["cv"], sds["cn"], heads,
+                                 taps=otaps)
+    params = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sds["dec"].items()}
+    oloss = O.train_step_loss(ocat, tgt, params, 2, otaps)
+    oloss.backward()
+    e_x = rel_l2(taps["x_final"], otaps["x_stage3"])
+    e_lg = rel_l2(taps["logits"].permute(0, 3, 1, 2), otaps["logits"])
+    print(f"config 1 (ViT-S/14, 224^2, B=2): x_final {e_x:.2e} logits {e_lg:.2e} loss {float(loss):.6f} oracle {float(oloss):.6f}")
+    assert e_x < TOL and e_lg < TOL and abs(float(loss) - float(oloss)) < 1e-4
+    with torch.no_grad():
+        names = [k for k, v in params.items() if v.requires_grad]
+        O.sgd_momentum_step({k: params[k] for k in names}, {k: params[k].grad for k in names}, {}, 0.05)
+    live = dict(eng.seg_decoder.named_parameters())
+    assert max(rel_l2(live[k], params[k]) for k in names) < 1e-3
