@@ -10,14 +10,14 @@ from __future__ import annotations
 import torch
 import torch.distributed as dist
 
-from .. import ops
+from .. import ops, parallel
 
 
 def finalize(partial: torch.Tensor, count: int, bn: torch.nn.Module, sync: bool = False, update: bool = True):
     """partial fp32 [nparts, 2, C] -> (scale, shift, mean, invstd, total_count)."""
     sums = ops.reduce_partials(partial)
     total = float(count)
-    if sync and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if sync and parallel.collectives_on():
         dist.all_reduce(sums)  # 2C doubles; every rank holds the same per-GPU batch on this path
         total = float(count) * dist.get_world_size()
     rm = bn.running_mean if (update and bn.track_running_stats) else None

@@ -24,7 +24,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import config, ops
+from .. import config, ops, parallel
 from ..dinov2.layers.blocks import _Packed, _pack
 from . import _bn
 
@@ -133,7 +133,7 @@ def conv_bn_relu_up_backward(owner: _Packed, key: str, st: _Stage, dU, conv: nn.
         g, partial = ops.upsample_bn_relu_bwd(dU, st.raw, st.scale, st.shift, st.mean, st.invstd, st.factor)
     red = ops.reduce_rows(partial.view(partial.shape[0], 2 * C))  # [2C]: sum g | sum g*xhat (scaled)
     local = red
-    if sync_bn and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if sync_bn and parallel.collectives_on():
         # SyncBatchNorm backward: the 2C global sums feed dx only; gamma / beta gradients stay LOCAL sums (the bucket
         # all-reduce averages them over ranks like every other parameter gradient — torch's SyncBatchNorm does the same)
         local = red.clone()

@@ -21,6 +21,19 @@ def world_size(group=None) -> int:
     return dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
 
 
+# Rehearsal switch (tests/test_gpu_rccl.py): issue every collective of the step even in a 1-rank process group, so the RCCL
+# calls themselves — backend init on the device, fp32 / fp64 all-reduces from the compute stream and from side streams —
+# run on a one-GPU box, where they are the identity.  Never set in production.
+FORCE_COLLECTIVES = False
+
+
+def collectives_on(group=None) -> bool:
+    """True when the data-parallel exchanges have to be issued (more than one rank, or the rehearsal switch)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or FORCE_COLLECTIVES
+
+
 class StageReducer:
     def __init__(self, flat_grad: torch.Tensor, ranges: Sequence[Tuple[int, int]], group=None):
         self.flat, self.ranges, self.group = flat_grad, list(ranges), group
@@ -36,7 +49,7 @@ class StageReducer:
         """Call after the kernels writing the next range have been enqueued on the current stream."""
         lo, hi = self.ranges[self._next]
         self._next += 1
-        if world_size(self.group) == 1:
+        if not collectives_on(self.group):
             return
         chunk = self.flat[lo:hi]
         if chunk.is_cuda:

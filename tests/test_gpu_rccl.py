@@ -1,0 +1,69 @@
+"""GPU: the RCCL code path itself on the one-GPU box.  The driver's scaling runs are the only place N > 1 ranks ever meet
+real RCCL, so this rehearses every collective call site of the step in a ONE-rank ``nccl`` process group with
+``parallel.FORCE_COLLECTIVES`` (a 1-rank all-reduce is the identity): backend initialisation on the device, the per-stage
+gradient all-reduces on the reducer's side stream, the fp64 SyncBatchNorm statistic exchanges issued from the encoder's side
+stream, the SyncBN backward exchange, the chunked backbone bucket of config 4 — and the results must equal the same step
+without any collective, bit for bit.  Runs in a child process (a process group is process-global state)."""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = textwrap.dedent('''
+    import os, sys, torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.environ["ASIS_ROOT"])
+    from adaptersis_amd import parallel
+    from adaptersis_amd.utils import weights as W
+    from tests.test_gpu_e2e import build_e2e_engine
+    from tests.test_gpu_step import build_engine
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    img, tgt = W.synthetic_batch(2, 224)
+    img, tgt = img.to(dev), tgt.to(dev)
+
+    def run(kind):
+        if kind == "frozen":
+            eng, _ = build_engine("vit_tiny_test", "kernel", dev, (128, 32, 16, 16, 8), lr=0.05)
+        else:
+            eng, _ = build_e2e_engine("vit_tiny_test", dev, (128, 32, 16, 16, 8), blocks_per_bucket=2)
+        losses = [float(eng.train_step(img, tgt)) for _ in range(2)]
+        torch.cuda.synchronize()
+        out = {"loss": losses, "w": eng.bucket.flat.clone(), "rm": eng.backbone_encoder.stem[1].running_mean.clone()}
+        if kind != "frozen":
+            out.update(vit=eng.vit_bucket.grad.clone(), ada=eng.adapter_bucket.flat.clone(), enc=eng.encoder_bucket.flat.clone())
+        return out
+
+    base = {k: run(k) for k in ("frozen", "e2e")}                       # no process group: no collective is issued
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    parallel.FORCE_COLLECTIVES = True
+    t = torch.ones(4, device=dev, dtype=torch.float64)
+    dist.all_reduce(t)                                                   # fp64 on RCCL (the SyncBN statistics dtype)
+    assert t.tolist() == [1.0] * 4
+    forced = {k: run(k) for k in ("frozen", "e2e")}
+    dist.barrier()
+    dist.destroy_process_group()
+    for k in base:
+        assert base[k]["loss"] == forced[k]["loss"], (k, base[k]["loss"], forced[k]["loss"])
+        for name in base[k]:
+            if name != "loss":
+                assert torch.equal(base[k][name], forced[k][name]), (k, name)
+    print("RCCL_REHEARSAL_OK", base["frozen"]["loss"], base["e2e"]["loss"])
+''')
+
+
+def test_every_collective_call_site_runs_on_rccl_single_rank(dev):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, ASIS_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0 and "RCCL_REHEARSAL_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
