@@ -53,6 +53,38 @@ class _SegData(torch.utils.data.Dataset):
         return self.img[i], self.msk[i], i
 
 
+_AUGMENTERS = {}
+_IDENTITY = {"crop": None, "flip": False, "rotk": 0, "alpha": 1.0, "beta": 0.0, "gamma": None}
+
+
+def _to_device_batch(inp, target, train: bool):
+    """Batch from the loader -> (float [B,3,S,S] in [0,1], long [B,S,S]) on the device.  uint8 HWC batches (``tools.dataset.Robomis``
+    without a host transform) go through the GPU augmentation pipeline (`train.py:139-163`) when training, and through the same
+    kernel with identity parameters (= `/255`, `tools/dataset.py:159`; the reference's val transform is a no-op Resize to the
+    image size, `train.py:119-122`) when validating."""
+    inp, target = inp.cuda(non_blocking=True), target.cuda(non_blocking=True)
+    if inp.dtype != torch.uint8:
+        return inp, target
+    from .tools.augment import TrainAugment
+    S = inp.shape[1]
+    aug = _AUGMENTERS.get(S)
+    if aug is None:
+        aug = _AUGMENTERS[S] = TrainAugment(size=S, seed=1000 + utils.get_rank())
+    return aug(inp.contiguous(), target.to(torch.uint8).contiguous(), None if train else [dict(_IDENTITY) for _ in range(inp.shape[0])])
+
+
+def _open_datasets(args):
+    """-> (train set, val set, collate_fn).  ``--data_path`` with the reference's layout (`images/<split>/*.png` +
+    `annotations/<split>/`, `tools/dataset.py:127-141`) or decode-free ``<split>/images.npy`` uint8 arrays -> ``Robomis`` +
+    GPU augmentation; otherwise the float ``.npy`` / synthetic set of ``_SegData``."""
+    from .tools.dataset import Robomis, collate_u8
+    p = args.data_path
+    if os.path.isdir(os.path.join(p, "images", "training")) or os.path.isfile(os.path.join(p, "training", "images.npy")):
+        return (Robomis(p, "training", transform=None, imsize=args.imsize), Robomis(p, "validation", transform=None, imsize=args.imsize),
+                collate_u8)
+    return _SegData(p, "train", args.imsize), _SegData(p, "validation", args.imsize), None
+
+
 def broadcast_module_states(modules, src: int = 0, group=None) -> None:
     """What ``DistributedDataParallel.__init__`` does for the reference (`train.py:84-116`): every parameter and buffer of
     the trainable / SyncBN modules takes rank ``src``'s value.  One flat fp32 message per module (plus one for integer
@@ -119,13 +151,14 @@ def train_seg(args, head: str = "feature"):
                              train_encoder=getattr(args, "train_encoder", False))
     optimizer = engine.optimizer
 
-    dataset_val = _SegData(args.data_path, "validation", args.imsize)
-    val_loader = torch.utils.data.DataLoader(dataset_val, batch_size=args.batch_size_per_gpu, num_workers=0, pin_memory=True)
-    dataset_train = _SegData(args.data_path, "train", args.imsize)
+    dataset_train, dataset_val, collate = _open_datasets(args)
+    workers = args.num_workers if collate is not None else 0      # PNG decode runs in loader workers; tensors in memory do not need any
+    val_loader = torch.utils.data.DataLoader(dataset_val, batch_size=args.batch_size_per_gpu, num_workers=workers, pin_memory=True,
+                                             collate_fn=collate)
     sampler = torch.utils.data.distributed.DistributedSampler(dataset_train, num_replicas=utils.get_world_size(),
                                                                rank=utils.get_rank())
     train_loader = torch.utils.data.DataLoader(dataset_train, sampler=sampler, batch_size=args.batch_size_per_gpu,
-                                               num_workers=0, pin_memory=True, drop_last=True)
+                                               num_workers=workers, pin_memory=True, drop_last=True, collate_fn=collate)
     print(f"Data loaded with {len(dataset_train)} train and {len(dataset_val)} val imgs.")
 
     class _Cosine:  # torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, epochs, eta_min=0), stepped per epoch
@@ -201,7 +234,7 @@ def train(model, feature_model, backbone_encoder, cross_vit, cross_cnn, seg_deco
     metric_logger = utils.MetricLogger(delimiter="  ")
     metric_logger.add_meter("lr", utils.SmoothedValue(window_size=1, fmt="{value:.6f}"))
     for (inp, target, idx) in metric_logger.log_every(loader, 20, "Epoch: [{}]".format(epoch)):
-        loss = engine.train_step(inp.cuda(non_blocking=True), target.cuda(non_blocking=True))
+        loss = engine.train_step(*_to_device_batch(inp, target, train=True))
         torch.cuda.synchronize()  # the reference syncs and reads the loss every step (train.py:439-440)
         metric_logger.update(loss=loss.item())
         metric_logger.update(lr=optimizer.param_groups[0]["lr"])
@@ -217,7 +250,7 @@ def validate_network(val_loader, model, feature_model, backbone_encoder, cross_v
     metric_logger = utils.MetricLogger(delimiter="  ")
     wt = torch.tensor([0.1, 10.0], device=next(seg_decoder.parameters()).device)
     for (inp, target, idx) in metric_logger.log_every(val_loader, 20, "Test:"):
-        inp, target = inp.cuda(non_blocking=True), target.cuda(non_blocking=True)
+        inp, target = _to_device_batch(inp, target, train=False)
         m, dloss = engine.validate_step(inp, target, wt)
         m = m.cpu()
         bs = inp.shape[0]

@@ -122,3 +122,29 @@ def test_sgd_overflow_guard_skips_the_step(dev):
     b2.grad[3] = 1.0
     opt.step()
     assert torch.allclose(b1.flat, w0 - 0.1) and torch.allclose(b2.flat, v0 - 0.1) and opt.skipped_steps == 2
+
+
+def test_train_seg_on_png_folder_with_gpu_augmentation(dev, tmp_path):
+    """The reference's on-disk layout (`tools/dataset.py:127-141`: images/<split>/*.png + annotations/<split>/) through the
+    drop-in script: PIL decode in the loader, uint8 batches, the augmentation kernel on the device, one epoch + validation."""
+    import numpy as np
+    from PIL import Image
+    r = np.random.RandomState(0)
+    for split, n in (("training", 8), ("validation", 4)):
+        (tmp_path / "data" / "images" / split).mkdir(parents=True)
+        (tmp_path / "data" / "annotations" / split).mkdir(parents=True)
+        for i in range(n):
+            img = (r.randint(0, 256, (56, 56, 3)).astype(np.uint8)).repeat(4, 0).repeat(4, 1)          # 224 x 224, blocky
+            msk = ((r.random_sample((56, 56)) > 0.7).astype(np.uint8) * 255).repeat(4, 0).repeat(4, 1)
+            Image.fromarray(img).save(tmp_path / "data" / "images" / split / f"f{i:03d}.png")
+            Image.fromarray(msk).save(tmp_path / "data" / "annotations" / split / f"f{i:03d}.png")
+    args = T.get_args_parser().parse_args(["--arch", "vit_tiny_test", "--imsize", "224", "--batch_size_per_gpu", "4", "--epochs", "1",
+                                           "--lr", "0.05", "--data_path", str(tmp_path / "data"), "--num_workers", "0",
+                                           "--output_dir", str(tmp_path / "out")])
+    T._ENGINES.clear()
+    T._AUGMENTERS.clear()
+    stats = T.train_seg(args)
+    assert 224 in T._AUGMENTERS                       # the uint8 path was taken
+    assert {"train_loss", "test_loss", "test_acc1", "test_dice"} <= set(stats) and stats["train_loss"] == stats["train_loss"]
+    assert 0.0 <= stats["test_acc1"] <= 1.0
+    T._ENGINES.clear()
