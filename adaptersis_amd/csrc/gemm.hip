@@ -207,6 +207,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const asis_gemm_desc 
 }
 
 #include "gemm_big.h"
+#include "gemm_persist.h"
 
 template <typename T>
 int launch(hipStream_t s, const asis_gemm_desc& d) {
@@ -257,6 +258,35 @@ int launch(hipStream_t s, const asis_gemm_desc& d) {
   // loop is 17-20 % faster in the step: 397 vs 476 us at 42348x1024x4096; at K = 1024 the two forms tie and the
   // smaller tiles of the default quantise better), 2 = wherever the shape allows
   static const int ph8 = [] { const char* e = getenv("ASIS_GEMM_8P"); return e ? atoi(e) : 1; }();
+  // ASIS_GEMM_PERSIST=1: the persistent form (gemm_persist.h) for the plain dense launches it covers
+  static const int persist = [] { const char* e = getenv("ASIS_GEMM_PERSIST"); return e ? atoi(e) : 0; }();
+  if (persist && big_mode && !d.conv && !d.stats && !d.bias_m && !d.aux && d.batch == 1 && d.K % 64 == 0 && d.K >= 256 &&
+      d.M >= 1024 && d.N >= 128 && vec_ok && (d.act == ASIS_ACT_NONE || d.act == ASIS_ACT_GELU) &&
+      (reinterpret_cast<uintptr_t>(d.C) & 15) == 0 && (!d.res || ((d.ldr & 3) == 0 && (reinterpret_cast<uintptr_t>(d.res) & 15) == 0)) &&
+      (!d.bias_n || (reinterpret_cast<uintptr_t>(d.bias_n) & 15) == 0) && (!d.scale_n || (reinterpret_cast<uintptr_t>(d.scale_n) & 15) == 0) &&
+      (persist >= 2 || d.K < 2048)) {
+    const int ntiles = ((d.M + 255) / 256) * ((d.N + 127) / 128);
+    int nwg = 256;
+    while (nwg > 8 && nwg > ntiles) nwg -= 8;
+    dim3 grid(nwg), block(512);
+    const bool gelu = d.act == ASIS_ACT_GELU, res = d.res != nullptr, o32 = d.out_f32 != 0;
+    static const int defer = [] { const char* e = getenv("ASIS_GEMM_DEFER"); return e ? atoi(e) : 1; }();
+    const bool df = defer && d.K >= 22 * 32;
+    static const int plab = [] { const char* e = getenv("ASIS_PERSIST_LAB"); return e ? atoi(e) : 0; }();
+    asis_gemm_desc dl = d;
+    if (plab) dl.ksplit = 1000 + plab;   // the deferred form spreads a tile's epilogue over the first 22 K iterations of the next
+#define PERSIST(ACT, RES, O32)                                                                                             \
+    do {                                                                                                                     \
+      if (noepi) hipLaunchKernelGGL((gemm_persist_kernel<T, ACT, RES, O32, false, 4>), grid, block, 0, s, dl, group_m);       \
+      else if (df) hipLaunchKernelGGL((gemm_persist_kernel<T, ACT, RES, O32, true, 0>), grid, block, 0, s, dl, group_m);     \
+      else hipLaunchKernelGGL((gemm_persist_kernel<T, ACT, RES, O32, false, 0>), grid, block, 0, s, dl, group_m);             \
+    } while (0)
+    if (gelu && !res && !o32) { PERSIST(ASIS_ACT_GELU, false, false); return 0; }
+    if (!gelu && !res && !o32) { PERSIST(ASIS_ACT_NONE, false, false); return 0; }
+    if (!gelu && res && o32) { PERSIST(ASIS_ACT_NONE, true, true); return 0; }
+    if (!gelu && !res && o32) { PERSIST(ASIS_ACT_NONE, false, true); return 0; }
+#undef PERSIST
+  }
   if (ph8 && (ph8 >= 2 || d.K >= 2048) && big_mode && !d.conv && !d.stats && d.K % 64 == 0 && d.M >= 256 && d.N >= 256) {
     // 256x256x64 tile, 8-phase main loop (one workgroup per CU: 128 KB of LDS)
     dim3 grid(((d.M + 255) / 256) * ((d.N + 255) / 256), d.batch), block(512);
