@@ -271,10 +271,10 @@ int launch(hipStream_t s, const asis_gemm_desc& d) {
     dim3 grid(nwg), block(512);
     const bool gelu = d.act == ASIS_ACT_GELU, res = d.res != nullptr, o32 = d.out_f32 != 0;
     static const int defer = [] { const char* e = getenv("ASIS_GEMM_DEFER"); return e ? atoi(e) : 1; }();
-    const bool df = defer && d.K >= 22 * 32;
+    const bool df = defer && d.K >= 18 * 32;   // the deferred form spreads a tile's epilogue over the first 16 K iterations of the next
     static const int plab = [] { const char* e = getenv("ASIS_PERSIST_LAB"); return e ? atoi(e) : 0; }();
     asis_gemm_desc dl = d;
-    if (plab) dl.ksplit = 1000 + plab;   // the deferred form spreads a tile's epilogue over the first 22 K iterations of the next
+    if (plab) dl.ksplit = 1000 + plab;
 #define PERSIST(ACT, RES, O32)                                                                                             \
     do {                                                                                                                     \
       if (noepi) hipLaunchKernelGGL((gemm_persist_kernel<T, ACT, RES, O32, false, 4>), grid, block, 0, s, dl, group_m);       \

@@ -4,12 +4,23 @@
 // LDS-DMA three K tiles ahead, fragments of K tile g+1 read from LDS while the MFMAs of K tile g run (register double
 // buffer), so the matrix pipe sees back-to-back MFMAs from the SIMD's two waves.  A workgroup walks its tiles as ONE stream
 // of K tiles: the DMA of the next output tile's first K tiles is issued under the last K tiles of the current one.
-// DEFER: at the end of an output tile the 64 accumulator registers change roles (new <-> old, the tile loop is unrolled by
-// two) and the old tile's epilogue is cut into 20 pieces that ride in the first 20 K iterations of the next tile: per 16-row
-// slab of the wave's tile, one piece writes the accumulators into the wave's private LDS slab (and fetches the slab's
-// residual rows), four pieces each read one 4-row pass back transposed, apply bias / GELU / LayerScale / residual and store
-// full 256-byte row segments.  Epilogue VALU work runs on the vector pipe beside the other wave's MFMAs, its HBM traffic
-// under the K loop.
+// DEFER: at the end of an output tile the 64 accumulator registers are copied to `old` and the old tile's epilogue is cut
+// into 16 pieces, one accumulator fragment each, that ride in the first 16 K iterations of the next tile: bias / GELU /
+// LayerScale / residual in registers and one store per lane straight from the fragment (the residual arrives by LDS-DMA
+// two pieces ahead).  The last tile of a workgroup has nothing to hide under and goes through the per-wave LDS slab.
+//
+// STATUS: lab form, off by default (ASIS_GEMM_PERSIST=1 selects it).  Results match the default kernel bit for bit on the
+// shapes it covers (tests/test_gpu_kernels.py), but it is NOT faster: on the stacked ViT-L shapes (M = 42348) the main
+// loop alone is 4 % ahead of the default's (194 / 97 / 340 us against 203 / 101 / 358 for qkv / proj / fc1), the whole
+// kernel 10-30 % behind (259 / 211 / 539 us against 226 / 158 / 450).  The default runs TWO 256-thread workgroups per
+// CU, so one workgroup's epilogue already overlaps the other's K loop and each has its own barrier; here all eight waves
+// meet at one barrier per K iteration, so whatever a piece costs any wave (16-way fragment select, address arithmetic,
+// the store's issue, GELU) is added to the iteration instead of being absorbed.  Lab switches (ASIS_PERSIST_LAB bits)
+// put numbers on the parts, qkv shape: no pieces at all 221 us (of which ~20 us is the pipeline drain behind the
+// compiler-scheduled bias loads at every tile end), pieces without LDS reads and with their stores sent to an L2-resident
+// page 247 us, real stores 259 us; staggering the two waves of a SIMD (pieces before / after the MFMA block) and an
+// LDS-transposed variant with full 256-byte row stores (251 / 192 / 510 us) moved nothing.  DESIGN.md section 8 has the
+// list of compiler hazards met on the way (inline-asm store data hazard, vmcnt(0) behind LDS-DMA, asm load destinations).
 #pragma once
 #include <type_traits>
 
@@ -203,133 +214,148 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const asis_gemm_de
   zero(accA);
   int sc = 1;   // LDS stage of the NEXT K tile to read fragments from
 
-  // ---- per-tile lane state of the (deferred) epilogue: pointers that advance by 4 rows per pass, bias / LayerScale columns
-  // of the wave staged in LDS (2 x 64 floats per wave), the residual rows of the next two passes.
-  // Inside the K loop every vector-memory operation of the epilogue is inline asm and ALWAYS issued — one residual load (RES
-  // kernels) and one store per iteration, a lane without a valid output element stores to a trash page — because the counted
-  // wait at the top of an iteration is only right if the number of operations behind the awaited DMA is known exactly.
+  // ---- deferred epilogue: the old tile's 16 accumulator fragments (i, j) leave one per K iteration, straight from the
+  // registers: in the D[n][m] orientation a lane holds 4 consecutive output columns (j*16 + q16*4 ..) of row i*16 + r16, so
+  // a fragment is one 8-byte (16-bit output) or 16-byte (fp32) store per lane, 32 / 64 contiguous bytes per row, and the
+  // four fragments of a row group complete its 128-byte lines in L2 within four iterations.  No LDS transpose: per piece the
+  // LDS sees one broadcast read of the bias (+ LayerScale) columns and, for RES kernels, the residual fragment.
+  // Inside the K loop every vector-memory operation of the epilogue is inline asm and ALWAYS issued — one store and (RES)
+  // one residual DMA per piece, a lane without a valid output element stores to a trash page — because the counted wait at
+  // the top of an iteration is only right if the number of operations behind the awaited DMA is known exactly.
   __shared__ __attribute__((aligned(16))) float bs_lds[8 * 128];
   float* const bsl = bs_lds + wid * 128;
-  const float* const zp = reinterpret_cast<const float*>(g_zero_page);
   char* const trash_base = reinterpret_cast<char*>(g_trash_page) + (size_t)((blockIdx.x & 255) * 8 + wid) * 1024;
   char* const Cb = reinterpret_cast<char*>(d.C);
   const char* const Rb = reinterpret_cast<const char*>(res);
   const bool has_scale = d.scale_n != nullptr, has_bias = d.bias_n != nullptr;
-  int e_row = 0;
-  bool e_cok = false;
-  uint32_t e_coff = 0, e_roff = 0;   // byte offsets into C / the residual
-  // Residual rows travel global -> LDS by LDS-DMA (one 1-KB wave-instruction = the 4 x 64 fp32 of one pass, lane-linear =
-  // the pass's own lane order) into two per-wave buffers, two iterations ahead of their use: an asynchronous load into
-  // REGISTERS cannot be expressed safely here (the compiler copies an inline-asm destination before the data has landed and
-  // then reuses the registers, e.g. as a store address, which the late data overwrites: this faulted).
+  constexpr int ESZ = OUT32 ? 4 : 2;
+  int d_row = 0, d_col = 0;        // the lane's row of fragment row group 0 and its first column of fragment column 0
+  // Residual fragments travel global -> LDS by LDS-DMA (lane-linear: each lane's own 16 bytes) into two per-wave buffers, two
+  // pieces ahead of their use: an asynchronous load into REGISTERS cannot be expressed safely here (the compiler copies an
+  // inline-asm destination before the data has landed and then reuses the registers, e.g. as a store address, which the
+  // late data overwrites: this faulted).
   __shared__ __attribute__((aligned(16))) float rbuf[8 * 2 * 256];
   float* const rb_wave = rbuf + wid * 512;
   const uint32_t rb_rd = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)rb_wave + (uint32_t)(lane * 16);
-  const uint32_t e_cstep = (uint32_t)(4 * d.ldc * (OUT32 ? 4 : 2)), e_rstep = (uint32_t)(4 * d.ldr * 4);
-  auto ld_res = [&](int buf, uint32_t off) __attribute__((always_inline)) {   // exactly one vector-memory operation
-    __builtin_amdgcn_global_load_lds((glb_ptr)(Rb + off), (lds_ptr)(rb_wave + buf * 256), 16, 0, 0);
-  };
-  auto next_rptr = [&](int cur_row) __attribute__((always_inline)) {   // residual offset of the pass 4 rows further down
-    if (RES) e_roff = (cur_row + 4 < d.M) ? e_roff + e_rstep : e_roff;   // rows beyond M re-read the last valid one
+  auto ld_res = [&](int q) __attribute__((always_inline)) {   // exactly one vector-memory operation: the residual of piece q
+    const int qq = q < 16 ? q : 15;                            // (beyond the tile: a harmless re-read)
+    const int row = d_row + 16 * (qq >> 2), col = d_col + 16 * (qq & 3);
+    const uint32_t off = (uint32_t)(((int64_t)(row < d.M ? row : d.M - 1) * d.ldr + (col < d.N ? col : 0)) * 4);
+    __builtin_amdgcn_global_load_lds((glb_ptr)(Rb + off), (lds_ptr)(rb_wave + (q & 1) * 256), 16, 0, 0);
   };
   auto epi_begin = [&](int m0o, int n0o) __attribute__((always_inline)) {
-    const int col = n0o + wn * 64 + ch * 4;
-    e_cok = col < d.N;
-    const int colc = e_cok ? col : 0;
-    e_row = m0o + wm * 64 + rr;
-    e_coff = (uint32_t)(((int64_t)e_row * d.ldc + colc) * (OUT32 ? 4 : 2));
-    if (lane < 16 && !(lab & 4)) {   // this wave's 64 bias / scale columns -> LDS (read back per pass: no registers held over the K loop)
+    d_row = m0o + wm * 64 + r16;
+    d_col = n0o + wn * 64 + q16 * 4;
+    if (lane < 16 && !(lab & 4)) {   // this wave's 64 bias / scale columns -> LDS (read back per piece: no registers held over the K loop)
+      const int col = n0o + wn * 64 + lane * 4;
+      const int colc = col < d.N ? col : 0;
       const float4 b = has_bias ? *reinterpret_cast<const float4*>(d.bias_n + colc) : make_float4(0.f, 0.f, 0.f, 0.f);
       const float4 sc4 = has_scale ? *reinterpret_cast<const float4*>(d.scale_n + colc) : make_float4(1.f, 1.f, 1.f, 1.f);
-      *reinterpret_cast<float4*>(bsl + ch * 4) = b;
-      *reinterpret_cast<float4*>(bsl + 64 + ch * 4) = sc4;
+      *reinterpret_cast<float4*>(bsl + lane * 4) = b;
+      *reinterpret_cast<float4*>(bsl + 64 + lane * 4) = sc4;
     }
-    if (RES) {         // residual rows of passes 0 and 1; e_rptr ends on pass 1's row
-      e_roff = (uint32_t)(((int64_t)(e_row < d.M ? e_row : d.M - 1) * d.ldr + colc) * 4);
-      ld_res(0, e_roff);
-      next_rptr(e_row);
-      ld_res(1, e_roff);
+    if (RES) {
+      ld_res(0);
+      ld_res(1);
     }
   };
-  const uint32_t slab_rd = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)slab + (uint32_t)((rr * SW + ch * 4) * 4);
-  const uint32_t bs_rd = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)bsl + (uint32_t)(ch * 16);
-  // LDS reads of a pass (slab rows p*4.., bias, LayerScale, residual buffer) in one asm block that ends with the wait: the
-  // outputs are valid when the statement ends, whatever the compiler does with them afterwards
-  auto epi_pass = [&](int p4, int buf) __attribute__((always_inline)) {   // p4 = pass within the slab (0..3)
-    f32x4 v, b4, s4, r4;
-    const uint32_t sa = slab_rd + (uint32_t)(p4 * 4 * SW * 4);
-    const uint32_t ra = rb_rd + (uint32_t)(buf * 1024);
-    asm volatile(
-        "ds_read_b128 %0, %4\n\t"
-        "ds_read_b128 %1, %5\n\t"
-        "ds_read_b128 %2, %5 offset:256\n\t"
-        "ds_read_b128 %3, %6\n\t"
-        "s_waitcnt lgkmcnt(0)"
-        : "=&v"(v), "=&v"(b4), "=&v"(s4), "=&v"(r4)
-        : "v"(sa), "v"(bs_rd), "v"(ra)
-        : "memory");
+  const uint32_t bs_rd = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)bsl + (uint32_t)(q16 * 16);
+  f32x4 old[4][4];                // the previous tile's accumulators while its epilogue pieces ride in this tile's K loop
+  // (each case passes its fragment through an empty asm statement: a plain switch over the array is turned into a load from
+  // a computed address, which moves the 64 registers of `old` into scratch memory)
+  auto old_frag = [&](int q) __attribute__((always_inline)) -> f32x4 {
+    f32x4 v;
+#define ASIS_FRAG(Q) case Q: asm volatile("" : "=v"(v) : "0"(old[(Q) >> 2][(Q) & 3])); break;
+    switch (q) {
+      ASIS_FRAG(0) ASIS_FRAG(1) ASIS_FRAG(2) ASIS_FRAG(3) ASIS_FRAG(4) ASIS_FRAG(5) ASIS_FRAG(6) ASIS_FRAG(7)
+      ASIS_FRAG(8) ASIS_FRAG(9) ASIS_FRAG(10) ASIS_FRAG(11) ASIS_FRAG(12) ASIS_FRAG(13) ASIS_FRAG(14)
+      default: asm volatile("" : "=v"(v) : "0"(old[3][3])); break;
+    }
+#undef ASIS_FRAG
+    return v;
+  };
+  // piece q (0..15) = fragment (q / 4, q % 4).  LDS reads in one asm block that ends with the wait: the outputs are valid
+  // when the statement ends, whatever the compiler does with them afterwards.
+  auto piece = [&](int q) __attribute__((always_inline)) {
+    const int i = q >> 2, j = q & 3;
+    f32x4 b4, s4, r4;
+    const uint32_t ba = bs_rd + (uint32_t)(j * 64);
+    if (lab & 32) {   // lab: no LDS reads in the piece
+      b4 = s4 = r4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else if (RES) {
+      const uint32_t ra = rb_rd + (uint32_t)((q & 1) * 1024);
+      asm volatile(
+          "ds_read_b128 %0, %3\n\t"
+          "ds_read_b128 %1, %3 offset:256\n\t"
+          "ds_read_b128 %2, %4\n\t"
+          "s_waitcnt lgkmcnt(0)"
+          : "=&v"(b4), "=&v"(s4), "=&v"(r4)
+          : "v"(ba), "v"(ra)
+          : "memory");
+    } else {
+      asm volatile(
+          "ds_read_b128 %0, %2\n\t"
+          "ds_read_b128 %1, %2 offset:256\n\t"
+          "s_waitcnt lgkmcnt(0)"
+          : "=&v"(b4), "=&v"(s4)
+          : "v"(ba)
+          : "memory");
+      r4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    f32x4 v = old_frag(q);
     v[0] += b4[0]; v[1] += b4[1]; v[2] += b4[2]; v[3] += b4[3];
     if (ACT == ASIS_ACT_GELU) { v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]); }
     if (has_scale) { v[0] *= s4[0]; v[1] *= s4[1]; v[2] *= s4[2]; v[3] *= s4[3]; }
     if (RES) { v[0] += r4[0]; v[1] += r4[1]; v[2] += r4[2]; v[3] += r4[3]; }
     // a lane without a valid element stores to the trash page: base and offset are selected together
-    const bool ok = e_row < d.M && e_cok && !(lab & 1);   // lab bit 0: every deferred store goes to the trash page
-    const uint32_t off = ok ? e_coff : (uint32_t)(lane * 16);
+    const int row = d_row + 16 * i, col = d_col + 16 * j;
+    const bool ok = row < d.M && col < d.N && !(lab & 1);   // lab bit 0: every deferred store goes to the trash page
+    const uint32_t off = ok ? (uint32_t)(((int64_t)row * d.ldc + col) * ESZ) : (uint32_t)(lane * 16);
     char* const base = ok ? Cb : trash_base;
     if (OUT32) {
-      asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(base + off), "v"(v) : "memory");
+      // (s_nop: a VALU write of a > 8-byte store's data registers needs 2 wait states behind the store on gfx940+; the
+      // compiler's hazard recognizer does not look inside inline asm and reused v[0..1] in the very next instruction)
+      asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(base + off), "v"(v) : "memory");
     } else {
       u32x2 pk;
       pk[0] = pack2<T>(v[0], v[1]);
       pk[1] = pack2<T>(v[2], v[3]);
       asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(base + off), "v"(pk) : "memory");
     }
-    e_row += 4;
-    e_coff += e_cstep;
+    if (RES) ld_res(q + 2);   // into the buffer just read
   };
-  // an iteration without a pass keeps the operation COUNT of one with: trash stores only (a dummy load would need a
-  // destination register that stays reserved until it lands)
-  auto idle_ops = [&]() __attribute__((always_inline)) {
-    const u32x2 z = {0u, 0u};
-    const uint32_t off = (uint32_t)(lane * 16);
-    if (RES) asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(off), "v"(z), "s"(trash_base) : "memory");
-    asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(off), "v"(z), "s"(trash_base) : "memory");
-  };
+  constexpr int NP = 16;   // pieces per tile
 
-  f32x4 old[4][4];                // the previous tile's accumulators while its epilogue pieces ride in this tile's K loop
-  // piece q (0..19) of the old tile: q = 5 i + sub; sub 0: slab i -> LDS, sub 1..4: pass 4 i + sub - 1.
-  // Pass p adds the residual buffer p % 2, which then takes the row of pass p + 2 (fetched two iterations ahead of its use).
-  auto piece = [&](int q) __attribute__((always_inline)) {
-    const int i = q / 5, sub = q - 5 * i;
-    if (sub == 0) {
-      if (i == 0) slab_write(old, 0);
-      else if (i == 1) slab_write(old, 1);
-      else if (i == 2) slab_write(old, 2);
-      else slab_write(old, 3);
-      idle_ops();
-    } else {
-      const int pass = 4 * i + sub - 1;
-      const int cur_row = e_row;
-      const int buf = pass & 1;
-      epi_pass(sub - 1, buf);
-      if (RES) { next_rptr(cur_row + 4); ld_res(buf, e_roff); }      // the row of pass + 2 (beyond the tile / M: a harmless re-read)
-    }
-  };
-
-  // one K iteration: [K tile g+1 landed] barrier | epilogue piece | DMA of g+3 | fragments of g+1 | MFMAs of g
+  // one K iteration: [K tile g+1 landed] barrier | epilogue piece (early waves) | DMA of g+3 | fragments of g+1 | MFMAs of g
+  // | epilogue piece (late waves).  The two waves of a SIMD run their pieces at opposite ends of the iteration, so that
+  // one wave's LDS wait and epilogue VALU work sit beside the other wave's MFMAs instead of both stalling in front of them.
   // `last` = no K tile g+1 exists in the whole stream; `tail` = no K tile g+2 (the youngest operations are K tile g+1's own).
-  // Counted wait (DEFER): behind K tile g+1 (issued two iterations ago, after that iteration's piece) the wave has issued
-  // exactly [piece store, piece residual DMA (RES), G operations of K tile g+2] in the previous iteration when that iteration
-  // carried a piece (q - 1 in 0..19): vmcnt(G + 1 + RES) leaves those in flight and guarantees K tile g+1, the residual
-  // fetched two iterations ago and the store of two iterations ago; otherwise only K tile g+2 is younger: vmcnt(G).
+  // Counted wait at the top; a piece issues 1 + RES vector-memory operations (a pass: store + residual DMA, a slab piece: as
+  // many trash stores), the DMA issue G:
+  //  early waves, per iteration [piece, G]: behind K tile g+1 (issued two iterations ago) come [piece of q-1, G]:
+  //      q in 1..NP: vmcnt(G + 1 + RES), which also covers the store and the residual DMA of two iterations ago; else vmcnt(G);
+  //  late waves, per iteration [G, piece]: behind K tile g+1 come [piece of q-2, G, piece of q-1]; the residual buffer of a
+  //      piece was fetched at the end of iteration q-2 or earlier, with [G, piece of q-1] = G + 2 behind it:
+  //      q in 2..NP: vmcnt(G + 2) (RES or not), q = 1 or NP + 1: vmcnt(G + 1), else vmcnt(G).
+  // (measured: staggering changes nothing, the pieces are not bound by the SIMD's issue slots; default: all waves early)
+  const bool late = DEFER && ((lab & 8) ? wid >= 4 : (lab & 16) ? (wid & 1) != 0 : false);
   auto k_iter = [&](int q, f32x4 (&acc)[4][4], v8 (&afc)[4], v8 (&bfc)[4], v8 (&afn)[4], v8 (&bfn)[4], bool last, bool tail)
       __attribute__((always_inline)) {
-    if (tail) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if (DEFER && q >= 1 && q <= 20) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G + 1 + (RES ? 1 : 0)) : "memory");   // previous iteration: a piece
-    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
+    if (tail) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if (DEFER && !late && q >= 1 && q <= NP) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G + 1 + (RES ? 1 : 0)) : "memory");
+    } else if (DEFER && late && q >= 2 && q <= NP) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G + 2) : "memory");
+    } else if (DEFER && late && (q == 1 || q == NP + 1)) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G + 1) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
+    }
     __builtin_amdgcn_s_barrier();
+    const bool has_piece = DEFER && q >= 0 && q < NP && !(lab & 64);   // lab bit 6: no pieces at all (wrong results, timing only)
     if constexpr (DEFER) {
-      if (q >= 0 && q < 20) piece(q);
+      if (has_piece && !late) piece(q);
     }
     issue();
     if (!last) rd_frags(sc, afn, bfn);
@@ -337,6 +363,9 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const asis_gemm_de
     mma(acc, afc, bfc);
     // the MFMAs are queued; by the time the wave gets here the fragment reads issued above have long returned
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if constexpr (DEFER) {
+      if (has_piece && late) piece(q);
+    }
   };
 
   const int total = my_n * nt;
