@@ -117,6 +117,8 @@ SIGNATURES = {
     "asis_add_f32": [_vp, _vp, _vp, _vp, _i64, _i, _i64, _i64, _i64],
     "asis_maxpool2_fwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i],
     "asis_maxpool2_bwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i],
+    "asis_nearest_add_relu": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i],
+    "asis_nearest_sum": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i],
     "asis_convt2x2_scatter": [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i],
     "asis_convt2x2_gather": [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i],
     "asis_convt2x2_bias_nblk": [_i64],

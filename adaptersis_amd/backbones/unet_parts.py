@@ -188,6 +188,46 @@ class UNet(_Packed):
             ops.gemm(dG, wb, out=dX)
         return dX.view(st.B, st.H, st.W, Cin)
 
+    # ---- OutConv (1x1) --------------------------------------------------------------------------------------------------
+    def _outc_fwd(self, y):
+        """y (hi, lo|None) [B,H,W,Cq] -> logits fp32 NHWC [B,H,W,classes]"""
+        oc = self.outc.conv
+        B, H, W, Cq = y[0].shape
+        logits = torch.empty((B * H * W, oc.out_channels), device=y[0].device, dtype=torch.float32)
+        w_hi = self._w16("outc.w", oc.weight)
+        bias = self._f32("outc.b", oc.bias)
+        if y[1] is not None:
+            w_lo = _pack(self._cache, "outc.wlo", oc.weight,
+                         lambda p: ops.cast_pad(p.reshape(p.shape[0], -1).contiguous().float(), dtype=config.operand_dtype, part=1))
+            ops.gemm_split(y[0].view(-1, Cq), y[1].view(-1, Cq), w_hi, w_lo, out=logits, bias_n=bias)
+        else:
+            ops.gemm(y[0].view(-1, Cq), w_hi, out=logits, bias_n=bias)
+        return logits.view(B, H, W, oc.out_channels)
+
+    def _outc_bwd(self, xl, d16, bias_partial, inv_scale, grads, dlogits_f32=None, d_lo=None):
+        """parameter gradients of the 1x1 classifier and dU fp32 [B,H,W,Cq] (scaled) for the stage below"""
+        dt = config.operand_dtype
+        oc = self.outc.conv
+        C = oc.out_channels
+        B, H, W, Cq = xl.shape
+        CP = d16.shape[-1]
+        if bias_partial is not None:
+            ops.reduce_rows(bias_partial, inv_scale, grads["outc.conv.bias"])
+        else:
+            ops.reduce_rows(dlogits_f32, 1.0, grads["outc.conv.bias"])
+        ops.wgrad(d16, xl, C, 1, 1, 1, 0, inv_scale, out=grads["outc.conv.weight"])
+        # dgrad of the 1x1 conv: dY [P, CP] x W^T; B operand [Cq, CP] = weight^T zero-padded to CP columns
+        def wt(part):
+            return lambda p: ops.cast_pad(p.float().reshape(C, Cq).t().contiguous(), CP, dt, part=part)
+        wd = _pack(self._cache, f"outc.wd{CP}", oc.weight, wt(0))
+        dU = torch.empty((B * H * W, Cq), device=d16.device, dtype=torch.float32)
+        if d_lo is not None:
+            wdlo = _pack(self._cache, f"outc.wdlo{CP}", oc.weight, wt(1))
+            ops.gemm_split(d16.view(-1, CP), d_lo.view(-1, CP), wd, wdlo, out=dU)
+        else:
+            ops.gemm(d16.view(-1, CP), wd, out=dU)
+        return dU.view(B, H, W, Cq)
+
     # ---- functional core -----------------------------------------------------------------------------------------
     def _to_nhwc16(self, x):
         B, C, H, W = x.shape
@@ -218,53 +258,21 @@ class UNet(_Packed):
         y, sv["up3"] = self._dconv_fwd("u3c", self.up3.conv, y, save, training)
         y, sv["up4.up"] = self._up_fwd("u4", self.up4.up, y, None, save)
         y, sv["up4"] = self._dconv_fwd("u4c", self.up4.conv, y, save, training)
-        oc = self.outc.conv
-        B, H, W, Cq = y[0].shape
-        logits = torch.empty((B * H * W, oc.out_channels), device=x16.device, dtype=torch.float32)
-        w_hi = self._w16("outc.w", oc.weight)
-        bias = self._f32("outc.b", oc.bias)
-        if split:
-            w_lo = _pack(self._cache, "outc.wlo", oc.weight,
-                         lambda p: ops.cast_pad(p.reshape(p.shape[0], -1).contiguous().float(), dtype=config.operand_dtype, part=1))
-            ops.gemm_split(y[0].view(-1, Cq), y[1].view(-1, Cq), w_hi, w_lo, out=logits, bias_n=bias)
-        else:
-            ops.gemm(y[0].view(-1, Cq), w_hi, out=logits, bias_n=bias)
+        logits = self._outc_fwd(y)
         sv["x_last"] = y[0] if save else None
         sv["x4_shape"] = x4[0].shape
-        return logits.view(B, H, W, oc.out_channels), sv
+        return logits, sv
 
     def _backward_core(self, saved, d16, bias_partial, inv_scale, grads, dlogits_f32=None, stage_done=None, d_lo=None,
                        need_input_grad: bool = False):
         """d16 (+ d_lo): 16-bit [B,H,W,CP] = loss_scale * dL/dlogits (pad channels zero); same contract as
         ``FeatureDecoder._backward_core``.  ``need_input_grad`` (forward run with it too): returns loss_scale * dL/d(input)
         fp32 NHWC = the skip gradient out of up2's concat + the MaxPool transpose of down3's input gradient."""
-        dt = config.operand_dtype
-        oc = self.outc.conv
-        C = oc.out_channels
-        xl = saved["x_last"]
-        B, H, W, Cq = xl.shape
-        CP = d16.shape[-1]
-
         def done():
             if stage_done is not None:
                 stage_done()
 
-        if bias_partial is not None:
-            ops.reduce_rows(bias_partial, inv_scale, grads["outc.conv.bias"])
-        else:
-            ops.reduce_rows(dlogits_f32, 1.0, grads["outc.conv.bias"])
-        ops.wgrad(d16, xl, C, 1, 1, 1, 0, inv_scale, out=grads["outc.conv.weight"])
-        # dgrad of the 1x1 conv: dY [P, CP] x W^T; B operand [Cq, CP] = weight^T zero-padded to CP columns
-        def wt(part):
-            return lambda p: ops.cast_pad(p.float().reshape(C, Cq).t().contiguous(), CP, dt, part=part)
-        wd = _pack(self._cache, f"outc.wd{CP}", oc.weight, wt(0))
-        dU = torch.empty((B * H * W, Cq), device=d16.device, dtype=torch.float32)
-        if d_lo is not None:
-            wdlo = _pack(self._cache, f"outc.wdlo{CP}", oc.weight, wt(1))
-            ops.gemm_split(d16.view(-1, CP), d_lo.view(-1, CP), wd, wdlo, out=dU)
-        else:
-            ops.gemm(d16.view(-1, CP), wd, out=dU)
-        dU = dU.view(B, H, W, Cq)
+        dU = self._outc_bwd(saved["x_last"], d16, bias_partial, inv_scale, grads, dlogits_f32, d_lo)
         done()
         dcat = self._dconv_bwd("u4c", self.up4.conv, saved["up4"], dU, inv_scale, grads, "up4.conv", True)
         dU = self._up_bwd("u4", self.up4.up, saved["up4.up"], dcat, inv_scale, grads, "up4.up")

@@ -201,6 +201,66 @@ __global__ __launch_bounds__(256) void convt2x2_bias_grad_kernel(const float* __
   }
 }
 
+// ---- FCUUp + FusionModel of the OR-UNet fuse head (eval/eval_dinov2_or_unet_fuse.py:502-530) -------------------------
+// x <- relu(x + nearest(r)) in place on the split-precision map x [B,H,W,C]; r [B,h,w,C] is the projected ViT map after
+// BatchNorm + ReLU, F.interpolate(size=(H, W)) in its default 'nearest' mode = source pixel (ys[y], xs[x]), the tables made
+// on the host with ATen's own float arithmetic.  Both addends are post-ReLU (>= 0), so the ReLU of the sum never clips; it
+// stays in the formula for the -0.0 / NaN behaviour only.
+template <typename T>
+__global__ __launch_bounds__(256) void nearest_add_relu_kernel(T* __restrict__ x, T* __restrict__ x_lo,
+                                                               const T* __restrict__ r, const T* __restrict__ r_lo,
+                                                               const int* __restrict__ ys, const int* __restrict__ xs, int B,
+                                                               int H, int W, int h, int w, int C) {
+  typedef typename T16<T>::v8 v8;
+  const int cpt = C >> 3;
+  const int64_t total = (int64_t)B * H * W * cpt;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cpt) << 3;
+    const int64_t pix = i / cpt;
+    const int xx = (int)(pix % W);
+    const int yy = (int)((pix / W) % H);
+    const int b = (int)(pix / ((int64_t)W * H));
+    const int64_t so = (((int64_t)b * h + ys[yy]) * w + xs[xx]) * C + c;
+    const int64_t o = pix * C + c;
+    v8 xh = *reinterpret_cast<const v8*>(x + o), xl, rh = *reinterpret_cast<const v8*>(r + so), rl;
+    if (x_lo) xl = *reinterpret_cast<const v8*>(x_lo + o);
+    if (r_lo) rl = *reinterpret_cast<const v8*>(r_lo + so);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      float v = ((float)xh[k] + (x_lo ? (float)xl[k] : 0.f)) + ((float)rh[k] + (r_lo ? (float)rl[k] : 0.f));
+      v = v > 0.f ? v : 0.f;
+      const T hi = (T)v;
+      xh[k] = hi;
+      if (x_lo) xl[k] = (T)(v - (float)hi);
+    }
+    *reinterpret_cast<v8*>(x + o) = xh;
+    if (x_lo) *reinterpret_cast<v8*>(x_lo + o) = xl;
+  }
+}
+
+// transpose of the nearest resize: dr[b, sy, sx, :] = sum of g over the destination pixels that read source (sy, sx) —
+// rows y0[sy] .. y0[sy+1]-1, columns x0[sx] .. x0[sx+1]-1 (the tables are monotone, so the pre-image is a rectangle)
+__global__ __launch_bounds__(256) void nearest_sum_kernel(const float* __restrict__ g, float* __restrict__ dr,
+                                                          const int* __restrict__ y0, const int* __restrict__ x0, int B, int H,
+                                                          int W, int h, int w, int C) {
+  const int cpt = C >> 2;
+  const int64_t total = (int64_t)B * h * w * cpt;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cpt) << 2;
+    const int64_t pix = i / cpt;
+    const int sx = (int)(pix % w);
+    const int sy = (int)((pix / w) % h);
+    const int b = (int)(pix / ((int64_t)w * h));
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int yy = y0[sy]; yy < y0[sy + 1]; ++yy)
+      for (int xx = x0[sx]; xx < x0[sx + 1]; ++xx) {
+        const float4 v = *reinterpret_cast<const float4*>(g + (((int64_t)b * H + yy) * W + xx) * C + c);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+    *reinterpret_cast<float4*>(dr + pix * C + c) = acc;
+  }
+}
+
 }  // namespace
 
 #define DT_OK(dtype, name) ASIS_REQUIRE(dtype == ASIS_F16 || dtype == ASIS_BF16, name ": bad dtype %d", dtype)
@@ -304,5 +364,35 @@ extern "C" int asis_convt2x2_bias_grad(void* stream, const float* dcat, float* p
   hipLaunchKernelGGL(convt2x2_bias_grad_kernel, dim3(nblk), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dcat, partial,
                      B, 2 * H, 2 * W, Cout, H2, W2, Ctot, coff, padT, padL, rpb);
   ASIS_CHECK_LAUNCH("asis_convt2x2_bias_grad");
+  return ASIS_OK;
+}
+
+extern "C" int asis_nearest_add_relu(void* stream, int dtype, void* x, void* x_lo, const void* r, const void* r_lo,
+                                     const int* ys, const int* xs, int B, int H, int W, int h, int w, int C) {
+  ASIS_REQUIRE(x && r && ys && xs, "asis_nearest_add_relu: null pointer");
+  ASIS_REQUIRE(C > 0 && C % 8 == 0 && B > 0 && H > 0 && W > 0 && h > 0 && w > 0, "asis_nearest_add_relu: bad shape (C=%d must be a multiple of 8)", C);
+  DT_OK(dtype, "asis_nearest_add_relu");
+  const int64_t total = (int64_t)B * H * W * (C / 8);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == ASIS_F16)
+    hipLaunchKernelGGL((nearest_add_relu_kernel<f16>), dim3(grid_for(total)), dim3(256), 0, s, reinterpret_cast<f16*>(x),
+                       reinterpret_cast<f16*>(x_lo), reinterpret_cast<const f16*>(r), reinterpret_cast<const f16*>(r_lo), ys, xs,
+                       B, H, W, h, w, C);
+  else
+    hipLaunchKernelGGL((nearest_add_relu_kernel<bf16>), dim3(grid_for(total)), dim3(256), 0, s, reinterpret_cast<bf16*>(x),
+                       reinterpret_cast<bf16*>(x_lo), reinterpret_cast<const bf16*>(r), reinterpret_cast<const bf16*>(r_lo), ys,
+                       xs, B, H, W, h, w, C);
+  ASIS_CHECK_LAUNCH("asis_nearest_add_relu");
+  return ASIS_OK;
+}
+
+extern "C" int asis_nearest_sum(void* stream, const float* g, float* dr, const int* y0, const int* x0, int B, int H, int W,
+                                int h, int w, int C) {
+  ASIS_REQUIRE(g && dr && y0 && x0, "asis_nearest_sum: null pointer");
+  ASIS_REQUIRE(C > 0 && C % 4 == 0 && B > 0 && H > 0 && W > 0 && h > 0 && w > 0, "asis_nearest_sum: bad shape (C=%d must be a multiple of 4)", C);
+  const int64_t total = (int64_t)B * h * w * (C / 4);
+  hipLaunchKernelGGL(nearest_sum_kernel, dim3(grid_for(total)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), g, dr, y0,
+                     x0, B, H, W, h, w, C);
+  ASIS_CHECK_LAUNCH("asis_nearest_sum");
   return ASIS_OK;
 }

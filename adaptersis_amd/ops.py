@@ -720,6 +720,49 @@ def maxpool2_bwd(dy: torch.Tensor, idx: torch.Tensor, dx: torch.Tensor) -> torch
     return dx
 
 
+
+def nearest_tables(src: int, dst: int, device) -> tuple:
+    """F.interpolate(mode='nearest') index tables for one axis: (src index of every dst index int32 [dst], first dst index of
+    every src index int32 [src + 1]).  ATen (UpSample.h nearest_idx): identity when equal, dst >> 1 for an exact doubling,
+    else min(floor(dst_index * float32(src / dst)), src - 1) in float32 arithmetic."""
+    import numpy as np
+    d = np.arange(dst, dtype=np.int64)
+    if dst == src:
+        idx = d
+    elif dst == 2 * src:
+        idx = d >> 1
+    else:
+        scale = np.float32(src) / np.float32(dst)
+        idx = np.minimum(np.floor(d.astype(np.float32) * scale).astype(np.int64), src - 1)
+    first = np.searchsorted(idx, np.arange(src + 1), side="left")
+    return (torch.from_numpy(idx.astype(np.int32)).to(device), torch.from_numpy(first.astype(np.int32)).to(device))
+
+
+def nearest_add_relu(x: torch.Tensor, x_lo: Optional[torch.Tensor], r: torch.Tensor, r_lo: Optional[torch.Tensor],
+                     ys: torch.Tensor, xs: torch.Tensor) -> None:
+    """x (+x_lo) 16-bit NHWC [B,H,W,C] <- relu(x + nearest-resized r [B,h,w,C]) in place (FCUUp + FusionModel)."""
+    _dev(x, x_lo, r, r_lo, ys, xs)
+    B, H, W, C = x.shape
+    _, h, w, Cr = r.shape
+    if Cr != C or r.shape[0] != B or ys.numel() != H or xs.numel() != W or ys.dtype != torch.int32 or xs.dtype != torch.int32:
+        raise ValueError("nearest_add_relu: shape / table mismatch")
+    if not (x.is_contiguous() and r.is_contiguous()) or r.dtype != x.dtype:
+        raise ValueError("nearest_add_relu: contiguous maps of one 16-bit dtype expected")
+    check(lib().asis_nearest_add_relu(_stream(), _dt(x.dtype), x.data_ptr(), _p(x_lo), r.data_ptr(), _p(r_lo), ys.data_ptr(),
+                                      xs.data_ptr(), B, H, W, h, w, C), "asis_nearest_add_relu")
+
+
+def nearest_sum(g: torch.Tensor, h: int, w: int, y0: torch.Tensor, x0: torch.Tensor) -> torch.Tensor:
+    """Transpose of the nearest resize: g fp32 [B,H,W,C] -> fp32 [B,h,w,C] (sums over each source pixel's destination block)."""
+    _dev(g, y0, x0)
+    B, H, W, C = g.shape
+    if g.dtype != torch.float32 or not g.is_contiguous() or y0.numel() != h + 1 or x0.numel() != w + 1:
+        raise ValueError("nearest_sum: fp32 contiguous gradient and [h+1] / [w+1] int32 tables expected")
+    out = torch.empty((B, h, w, C), device=g.device, dtype=torch.float32)
+    check(lib().asis_nearest_sum(_stream(), g.data_ptr(), out.data_ptr(), y0.data_ptr(), x0.data_ptr(), B, H, W, h, w, C),
+          "asis_nearest_sum")
+    return out
+
 def convt2x2_scatter(G: torch.Tensor, dst: torch.Tensor, dst_lo: Optional[torch.Tensor], B: int, H: int, W: int, coff: int,
                      padT: int = 0, padL: int = 0) -> None:
     """G fp32 [B*H*W, 4*Cout] (ConvTranspose2d k=2 s=2 as a GEMM) -> channels [coff, coff+Cout) of the NHWC 16-bit

@@ -271,6 +271,32 @@ def make_unet_state_dict(base: int = 384, n_classes: int = 2, seed: int = 0):
     return sd
 
 
+def make_or_unet_state_dict(embed_dim: int = 384, n_classes: int = 2, base: int = 64, seed: int = 0):
+    """OR-UNet fuse head `eval/eval_dinov2_or_unet_fuse.py:426-447` (bilinear=False): DoubleConv(3, base), four Down, four Up
+    (each with its skip), OutConv, and the FCUUp projections expand_block_2/3/4 (embed_dim -> 4*base / 2*base / base).
+    The reference's widths are base = 64; the parameter is for small test geometries only."""
+    sd = OrderedDict()
+    c = [base, 2 * base, 4 * base, 8 * base, 16 * base]
+
+    def dconv(p, cin, cout):
+        _conv(sd, p + ".double_conv.0", cout, cin, 3, seed, False); _bn(sd, p + ".double_conv.1", cout, seed)
+        _conv(sd, p + ".double_conv.3", cout, cout, 3, seed, False); _bn(sd, p + ".double_conv.4", cout, seed)
+
+    dconv("inc", 3, c[0])
+    for i in range(4):
+        dconv(f"down{i + 1}.maxpool_conv.1", c[i], c[i + 1])
+    for i in range(4):
+        cin, cout = c[4 - i], c[3 - i]
+        sd[f"up{i + 1}.up.weight"] = tensor(f"up{i + 1}.up.weight", (cin, cin // 2, 2, 2), (3.0 / (cin * 4)) ** 0.5 * 2, seed=seed)
+        sd[f"up{i + 1}.up.bias"] = tensor(f"up{i + 1}.up.bias", (cin // 2,), 0.05, seed=seed)
+        dconv(f"up{i + 1}.conv", cin, cout)
+    _conv(sd, "outc.conv", n_classes, c[0], 1, seed, True)
+    for k, cout in ((2, c[2]), (3, c[1]), (4, c[0])):
+        _conv(sd, f"expand_block_{k}.conv_project", cout, embed_dim, 1, seed, True)
+        _bn(sd, f"expand_block_{k}.bn", cout, seed)
+    return sd
+
+
 def synthetic_batch(batch: int, size: int = 588, num_classes: int = 2, seed: int = 0):
     """SURVEY.md §8d synthetic inputs: images U[0,1) (no mean/std normalisation,
     `tools/dataset.py:159`), binary masks with ~30 % foreground and one

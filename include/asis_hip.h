@@ -332,6 +332,19 @@ int asis_add_f32(void* stream, const float* a, const float* b, float* out, int64
 int asis_maxpool2_fwd(void* stream, int dtype, const void* x, const void* x_lo, void* out, void* out_lo, uint8_t* idx,
                       int B, int H, int W, int C);
 int asis_maxpool2_bwd(void* stream, const float* dy, const uint8_t* idx, float* dx, int B, int H, int W, int C);
+/* FCUUp + FusionModel of the OR-UNet fuse head (reference eval/eval_dinov2_or_unet_fuse.py:502-530, used at :448-464):
+ *   x <- relu(x + F.interpolate(r, size=(H, W)))           (default mode 'nearest')
+ * asis_nearest_add_relu: in place on the 16-bit map x (+ x_lo) [B,H,W,C]; r (+ r_lo) 16-bit [B,h,w,C]; ys int32 [H] / xs
+ *   int32 [W] = source row / column of every destination row / column (ATen: min(floor(dst * float(in) / out), in - 1),
+ *   computed by the caller in that float arithmetic).  C % 8 == 0.
+ * asis_nearest_sum: the transpose, dr fp32 [B,h,w,C] = sum of g fp32 [B,H,W,C] over each source pixel's destination
+ *   rectangle rows y0[sy] .. y0[sy+1]-1, columns x0[sx] .. x0[sx+1]-1 (y0 int32 [h+1], x0 int32 [w+1]).  C % 4 == 0.
+ *   (The ReLU of the sum needs no mask of its own in the backward: both addends are post-ReLU, so wherever the sum is 0 the
+ *   producers' own ReLU masks are 0 too.) */
+int asis_nearest_add_relu(void* stream, int dtype, void* x, void* x_lo, const void* r, const void* r_lo, const int* ys,
+                          const int* xs, int B, int H, int W, int h, int w, int C);
+int asis_nearest_sum(void* stream, const float* g, float* dr, const int* y0, const int* x0, int B, int H, int W, int h, int w,
+                     int C);
 /* nn.ConvTranspose2d(Cin, Cout, kernel_size=2, stride=2) (unet_parts.py:50,77) as one GEMM + a pixel shuffle:
  *   G[p, co*4 + di*2 + dj] = bias[co] + sum_ci x[p, ci] * w[ci, co, di, dj],   p = (b, i, j)
  * scatter: G fp32 [B*H*W, 4*Cout] -> dst/dst_lo 16-bit [B,H2,W2,Ctot], channels [coff, coff+Cout), pixel

@@ -384,6 +384,45 @@ def unet(x, sd: SD, p: str = "", update_bn: bool = False):
     return F.conv2d(y, sd[pre + "outc.conv.weight"], sd[pre + "outc.conv.bias"])
 
 
+def or_unet_fuse(img, x_o, x_t2, x_d2, sd: SD, p: str = "", update_bn: bool = False):
+    """OR-UNet multi-scale fuse head, `eval/eval_dinov2_or_unet_fuse.py:426-486` (``UNet.forward``, bilinear=False,
+    dw_stride=1): a full-resolution UNet on the image whose first three encoder levels are fused with ViT feature maps of
+    the image at scale 1.5 / 1 / 0.5 through FCUUp (1x1 conv -> BatchNorm(eps=1e-6) -> ReLU -> nearest resize, `:511-530`)
+    and FusionModel (add -> ReLU, `:502-510`).  DoubleConv / Down / Up / OutConv: `backbones/unet_parts.py:6-64,95-101`."""
+    pre = p + "." if p else ""
+
+    def dconv(x, q):
+        x = F.conv2d(x, sd[q + ".double_conv.0.weight"], None, padding=1)
+        x = F.relu(batch_norm_train(x, sd, q + ".double_conv.1", update=update_bn))
+        x = F.conv2d(x, sd[q + ".double_conv.3.weight"], None, padding=1)
+        return F.relu(batch_norm_train(x, sd, q + ".double_conv.4", update=update_bn))
+
+    def fcu(x_r, q, H, W):
+        z = F.conv2d(x_r, sd[q + ".conv_project.weight"], sd[q + ".conv_project.bias"])
+        z = F.relu(batch_norm_train(z, sd, q + ".bn", update=update_bn, eps=1e-6))
+        return F.interpolate(z, size=(H, W))
+
+    def up(x1, x2, q):
+        x1 = F.conv_transpose2d(x1, sd[q + ".up.weight"], sd[q + ".up.bias"], stride=2)
+        dY, dX = x2.size(2) - x1.size(2), x2.size(3) - x1.size(3)
+        x1 = F.pad(x1, [dX // 2, dX - dX // 2, dY // 2, dY - dY // 2])
+        return dconv(torch.cat([x2, x1], 1), q + ".conv")
+
+    x1 = dconv(img, pre + "inc")
+    x1 = F.relu(x1 + fcu(x_t2, pre + "expand_block_4", *x1.shape[2:]))
+    x2 = dconv(F.max_pool2d(x1, 2), pre + "down1.maxpool_conv.1")
+    x2 = F.relu(x2 + fcu(x_o, pre + "expand_block_3", *x2.shape[2:]))
+    x3 = dconv(F.max_pool2d(x2, 2), pre + "down2.maxpool_conv.1")
+    x3 = F.relu(x3 + fcu(x_d2, pre + "expand_block_2", *x3.shape[2:]))
+    x4 = dconv(F.max_pool2d(x3, 2), pre + "down3.maxpool_conv.1")
+    x5 = dconv(F.max_pool2d(x4, 2), pre + "down4.maxpool_conv.1")
+    y = up(x5, x4, pre + "up1")
+    y = up(y, x3, pre + "up2")
+    y = up(y, x2, pre + "up3")
+    y = up(y, x1, pre + "up4")
+    return F.conv2d(y, sd[pre + "outc.conv.weight"], sd[pre + "outc.conv.bias"])
+
+
 # ----------------------------------------------------------------------------
 # Losses / metrics
 # ----------------------------------------------------------------------------

@@ -300,6 +300,91 @@ def unet_step_case(R, out):
             out[f"unet_step.buf.{k}"] = v.clone()
 
 
+def ref_or_unet_fuse(R, embed_dim, n_classes):
+    """The OR-UNet fuse head of `eval/eval_dinov2_or_unet_fuse.py:426-486`.  The script itself cannot be imported (it needs
+    modules the repository does not ship: or_unet, setr_decoder, eval_knn, timm), so the head is assembled here from the
+    reference's own importable classes — DoubleConv / Down / Up / OutConv of `backbones/unet_parts.py` (what the script's
+    `from unet_parts import *` resolves to) and FCUUp of `backbones/decoders.py:276-296` (the same class body as the script's
+    `:511-530`) — with the script's constructor (`:432-447`) and forward (`:448-483`) restated; FusionModel (`:502-510`, no
+    parameters) is add + ReLU."""
+    import importlib
+    P = importlib.import_module("backbones.unet_parts")
+    FCUUp = importlib.import_module("backbones.decoders").FCUUp
+
+    class ORUNet(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.inc = P.DoubleConv(3, 64)
+            self.down1 = P.Down(64, 128)
+            self.down2 = P.Down(128, 256)
+            self.down3 = P.Down(256, 512)
+            self.down4 = P.Down(512, 1024)
+            self.up1 = P.Up(1024, 512, False)
+            self.up2 = P.Up(512, 256, False)
+            self.up3 = P.Up(256, 128, False)
+            self.up4 = P.Up(128, 64, False)
+            self.outc = P.OutConv(64, n_classes)
+            self.expand_block_2 = FCUUp(inplanes=embed_dim, outplanes=256, up_stride=1)
+            self.expand_block_3 = FCUUp(inplanes=embed_dim, outplanes=128, up_stride=1)
+            self.expand_block_4 = FCUUp(inplanes=embed_dim, outplanes=64, up_stride=1)
+
+        def forward(self, x, x_o, x_t2, x_d2):
+            relu = torch.relu
+            x1 = self.inc(x)
+            x1 = relu(x1 + self.expand_block_4(x_t2, *x1.shape[2:]))
+            x2 = self.down1(x1)
+            x2 = relu(x2 + self.expand_block_3(x_o, *x2.shape[2:]))
+            x3 = self.down2(x2)
+            x3 = relu(x3 + self.expand_block_2(x_d2, *x3.shape[2:]))
+            x4 = self.down3(x3)
+            x5 = self.down4(x4)
+            x = self.up1(x5, x4)
+            x = self.up2(x, x3)
+            x = self.up3(x, x2)
+            x = self.up4(x, x1)
+            return self.outc(x)
+    return ORUNet()
+
+
+def orunet_case(R, out):
+    """OR-UNet fuse head step (`eval/eval_dinov2_or_unet_fuse.py:266-322`): image + three ViT maps (scale 1 / 1.5 / 0.5 of the
+    image, last-layer patch tokens as maps, no gradient) -> logits at the image size -> CE + DC(2) -> gradients of every
+    parameter, BatchNorm buffers after the step.  Two geometries: 56 (pooled 28 / 14 / 7 / 3: the F.pad branch of Up) and
+    70 (35 / 17 / 8 / 4; nearest resizes 7 -> 70, 5 -> 35, 2 -> 17: integer and fractional ratios)."""
+    import torch.nn.functional as F
+    D, B = 384, 2
+    for HW in (56, 70):
+        tag = f"orunet{HW}"
+        sd = W.make_or_unet_state_dict(D, 2)
+        u = ref_or_unet_fuse(R, D, 2)
+        u.load_state_dict(sd, strict=True)
+        u.train()
+        img, tg = W.synthetic_batch(B, HW, 2)
+        sizes = dict(o=HW // 14, t2=HW * 3 // 28, d2=HW // 28)
+        maps = {k: W.tensor(f"{tag}.{k}", (B, D, n, n), 1.0) for k, n in sizes.items()}
+        oh = O.one_hot(tg, 2)
+        y = u(img, maps["o"], maps["t2"], maps["d2"])
+        o = F.interpolate(y, size=(HW, HW), mode="bilinear")
+        loss = torch.nn.CrossEntropyLoss()(o, tg) + R["DC"](2)(o, oh)
+        loss.backward()
+        osd = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sd.items()}
+        oy = O.or_unet_fuse(img, maps["o"], maps["t2"], maps["d2"], osd, update_bn=True)
+        oloss = O.cross_entropy_nd(oy, tg) + O.dc_loss(oy, oh)
+        oloss.backward()
+        close(oy.detach(), y.detach(), 2e-5, f"{tag} logits")
+        close(oloss.detach(), loss.detach(), 1e-5, f"{tag} loss")
+        out[f"{tag}.logits"] = sub(y)
+        out[f"{tag}.loss"] = loss.detach().clone()
+        for k, p in u.named_parameters():
+            if float(p.grad.abs().max()) > 1e-6:    # conv biases in front of a train-mode BatchNorm: exact zero + noise
+                close(osd[k].grad, p.grad, 5e-3, f"{tag} grad {k}")
+            out[f"{tag}.grad.{k}"] = sub(p.grad, 4000)
+        for k, v in u.state_dict().items():
+            if "running" in k:
+                close(osd[k], v, 1e-5, f"{tag} {k}")
+                out[f"{tag}.buf.{k}"] = v.clone()
+
+
 def loss_case(R, out):
     B, C, H = 3, 2, 40
     lg = W.tensor("loss.logits", (B, C, H, H), 3.0)
@@ -868,6 +953,10 @@ def main():
         out = {}
         print("[UNet(384) decoder step with gradients]"); unet_step_case(R, out)
         save("unet", out)
+    if want("orunet"):
+        out = {}
+        print("[OR-UNet fuse head step with gradients]"); orunet_case(R, out)
+        save("orunet", out)
     if want("loss2"):
         out = {}
         print("[losses 2: all selectable losses with gradients, IoU metrics]"); loss2_case(R, out)

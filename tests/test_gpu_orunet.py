@@ -1,0 +1,164 @@
+"""GPU: OR-UNet multi-scale fuse head (backbones/or_unet.py; reference `eval/eval_dinov2_or_unet_fuse.py:266-322,426-530`):
+the nearest-resize fuse kernels against torch, the module step against the golden captured from the reference's own part
+classes (tests/golden/orunet.pt, make_golden.py:orunet_case) and against the oracle."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from adaptersis_amd import ops
+from adaptersis_amd.backbones.or_unet import FCUUp, FusionModel, UNet
+from adaptersis_amd.segloss.dice import seg_loss
+from adaptersis_amd.utils import weights as W
+from oracle import ref_torch as O
+from tests.conftest import golden_err, load_golden, rel_l2
+
+pytestmark = pytest.mark.gpu
+DT = torch.float16
+
+
+def _split(x):
+    hi = x.to(DT)
+    return hi, (x - hi.float()).to(DT)
+
+
+@pytest.mark.parametrize("case", [(2, 6, 6, 56, 56, 16), (1, 2, 2, 17, 17, 8), (2, 5, 7, 35, 49, 32), (1, 4, 4, 8, 8, 8),
+                                  (1, 9, 9, 9, 9, 8)])
+def test_nearest_add_relu_and_transpose(dev, case):
+    """x <- relu(x + F.interpolate(r, size)) in place, and the block-sum transpose, for fractional / integer / 2x / identity
+    ratios (ATen's three nearest-index branches)."""
+    B, h, w, H, Wd, C = case
+    x = W.tensor(f"na.x{case}", (B, H, Wd, C), 1.0).abs().to(dev)
+    r = W.tensor(f"na.r{case}", (B, h, w, C), 1.0).abs().to(dev)
+    xh, xl = _split(x)
+    rh, rl = _split(r)
+    ys, y0 = ops.nearest_tables(h, H, dev)
+    xs, x0 = ops.nearest_tables(w, Wd, dev)
+    ref = F.relu((xh.float() + xl.float()).permute(0, 3, 1, 2)
+                 + F.interpolate((rh.float() + rl.float()).permute(0, 3, 1, 2), size=(H, Wd))).permute(0, 2, 3, 1)
+    ops.nearest_add_relu(xh, xl, rh, rl, ys, xs)
+    assert rel_l2(xh.float() + xl.float(), ref) < 1e-6
+    # single-precision form
+    x1, r1 = x.to(DT), r.to(DT)
+    ref1 = F.relu(x1.float().permute(0, 3, 1, 2) + F.interpolate(r1.float().permute(0, 3, 1, 2), size=(H, Wd))).permute(0, 2, 3, 1)
+    ops.nearest_add_relu(x1, None, r1, None, ys, xs)
+    assert rel_l2(x1.float(), ref1) < 1e-3
+    # transpose
+    g = W.tensor(f"na.g{case}", (B, H, Wd, C), 1.0).to(dev)
+    rr = r.permute(0, 3, 1, 2).clone().requires_grad_(True)
+    F.interpolate(rr, size=(H, Wd)).backward(g.permute(0, 3, 1, 2))
+    got = ops.nearest_sum(g, h, w, y0, x0)
+    assert rel_l2(got, rr.grad.permute(0, 2, 3, 1)) < 1e-6
+
+
+def test_container_modules_refuse_standalone_calls():
+    with pytest.raises(RuntimeError):
+        FusionModel()(torch.zeros(1), torch.zeros(1))
+    with pytest.raises(RuntimeError):
+        FCUUp(8, 8, 1)(torch.zeros(1, 8, 2, 2), 4, 4)
+
+
+def _inputs(HW, dev, D=384, B=2):
+    tag = f"orunet{HW}"
+    img, tg = W.synthetic_batch(B, HW, 2)
+    sizes = dict(o=HW // 14, t2=HW * 3 // 28, d2=HW // 28)
+    maps = {k: W.tensor(f"{tag}.{k}", (B, D, n, n), 1.0) for k, n in sizes.items()}
+    return img, tg, maps
+
+
+@pytest.mark.parametrize("HW", [56, 70])
+def test_or_unet_step_vs_reference_golden(dev, HW):
+    g = load_golden("orunet")
+    tag = f"orunet{HW}"
+    sd = W.make_or_unet_state_dict(384, 2)
+    u = UNet(n_channels=3, n_classes=2, embed_dim=384).to(dev)
+    u.load_state_dict(sd, strict=True)
+    u.train()
+    img, tg, maps = _inputs(HW, dev)
+    y = u(img.to(dev), maps["o"].to(dev), maps["t2"].to(dev), maps["d2"].to(dev))
+    assert tuple(y.shape) == (2, 2, HW, HW)
+    e = golden_err(y, g[f"{tag}.logits"])
+    loss = seg_loss(y, tg.to(dev), 1, ops.LOSS_DICE, 10e-20, n_ce=1)     # CE + DC(2) on the logits (`:311-316`)
+    loss.backward()
+    print(tag, "logits rel-L2 %.2e" % e, "loss", float(loss), float(g[f"{tag}.loss"]))
+    assert e < 1e-3
+    assert abs(float(loss) - float(g[f"{tag}.loss"])) < 1e-4
+    errs = {}
+    for k, p in u.named_parameters():
+        gold = g[f"{tag}.grad.{k}"]
+        if float(gold["sumsq"]) < 1e-12:       # conv biases in front of a train-mode BatchNorm: exactly zero + rounding noise
+            assert float(p.grad.abs().max()) < 1e-4, k
+            continue
+        errs[k] = golden_err(p.grad, gold)
+    print(tag, "grads:", {k: f"{v:.1e}" for k, v in sorted(errs.items(), key=lambda kv: -kv[1])[:8]})
+    # whole-tensor bound: the ReLU-flip conditioning argument of tests/test_gpu_unet.py applies unchanged
+    assert max(errs.values()) < 3e-2, errs
+    st = u.state_dict()
+    for k in st:
+        if "running" in k:
+            assert rel_l2(st[k].cpu(), g[f"{tag}.buf.{k}"]) < 1e-3, k
+        if "num_batches" in k:
+            assert int(st[k]) == 1
+
+
+def test_or_unet_small_width_vs_oracle_and_eval_mode(dev):
+    """base = 16 / embed_dim = 64 at 84 x 84, batch 3: every parameter gradient against oracle autograd, then eval mode
+    (running statistics, no autograd) against the oracle's eval restatement."""
+    HW, D, B = 84, 64, 3
+    sd = W.make_or_unet_state_dict(D, 2, base=16)
+    u = UNet(embed_dim=D, base=16).to(dev)
+    u.load_state_dict(sd, strict=True)
+    u.train()
+    img, tg, maps = _inputs(HW, dev, D, B)
+    y = u(img.to(dev), maps["o"].to(dev), maps["t2"].to(dev), maps["d2"].to(dev))
+    loss = seg_loss(y, tg.to(dev), 1, ops.LOSS_DICE, 10e-20, n_ce=1)
+    loss.backward()
+    osd = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sd.items()}
+    oy = O.or_unet_fuse(img, maps["o"], maps["t2"], maps["d2"], osd, update_bn=True)
+    ol = O.cross_entropy_nd(oy, tg) + O.dc_loss(oy, O.one_hot(tg, 2))
+    ol.backward()
+    assert rel_l2(y.detach().cpu(), oy.detach()) < 1e-3
+    assert abs(float(loss) - float(ol)) < 1e-4
+    errs = {k: rel_l2(p.grad.cpu(), osd[k].grad) for k, p in u.named_parameters() if float(osd[k].grad.abs().max()) > 1e-6}
+    print("small OR-UNet grads (worst):", {k: f"{v:.1e}" for k, v in sorted(errs.items(), key=lambda kv: -kv[1])[:6]})
+    assert max(errs.values()) < 3e-2, errs
+
+
+def test_or_unet_engine_two_steps_vs_oracle(dev):
+    """`eval_dinov2_or_unet_fuse.py:266-331` with a frozen tiny ViT (D = 128) at 84 x 84: three ViT passes (scale 1 / 1.5 /
+    0.5), head forward + backward, SGD with momentum — two consecutive steps, weights compared with the oracle's."""
+    from adaptersis_amd.backbones.or_unet import ORUNetFuseEngine
+    from adaptersis_amd.dinov2.models import vision_transformer as vits
+    arch, HW, B, D = "vit_tiny_test", 84, 2, 128
+    _, depth, heads, ffn = W.VIT_CONFIGS[arch]
+    vsd = W.make_vit_state_dict(arch)
+    model = vits.__dict__[arch](patch_size=14, img_size=518, init_values=1e-5, ffn_layer=ffn, block_chunks=0)
+    model.load_state_dict(vsd)
+    sd = W.make_or_unet_state_dict(D, 2, base=16)
+    u = UNet(embed_dim=D, base=16)
+    u.load_state_dict(sd, strict=True)
+    eng = ORUNetFuseEngine(model.to(dev).eval(), u.to(dev).train(), lr=0.05, momentum=0.9)
+    osd = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k and "num_batches" not in k) for k, v in sd.items()}
+    names = [k for k, v in osd.items() if v.requires_grad]
+    bufs = {}
+    for step in range(2):
+        img, tg = W.synthetic_batch(B, HW, 2, seed=step)
+        loss = eng.train_step(img.to(dev), tg.to(dev))
+        with torch.no_grad():
+            maps = []
+            for s in (1.0, 1.5, 0.5):
+                x = img if s == 1.0 else F.interpolate(img, scale_factor=(s, s), mode="bilinear", align_corners=False)
+                tok = O.get_intermediate_layers(x, vsd, heads, 1)[0][0]
+                h = x.shape[2] // 14
+                maps.append(tok.reshape(B, h, h, D).permute(0, 3, 1, 2).contiguous())
+        for k in names:
+            osd[k].grad = None
+        oy = O.or_unet_fuse(img, maps[0], maps[1], maps[2], osd, update_bn=True)
+        ol = O.cross_entropy_nd(oy, tg) + O.dc_loss(oy, O.one_hot(tg, 2))
+        ol.backward()
+        assert abs(float(loss) - float(ol)) < 2e-4, (step, float(loss), float(ol))
+        with torch.no_grad():
+            O.sgd_momentum_step({k: osd[k] for k in names}, {k: osd[k].grad for k in names}, bufs, 0.05, momentum=0.9, weight_decay=0.0)
+        got = dict(u.named_parameters())
+        errs = {k: rel_l2(got[k].detach().cpu(), osd[k].detach()) for k in names}
+        assert max(errs.values()) < 2e-3, (step, sorted(errs.items(), key=lambda kv: -kv[1])[:4])
+    assert int(u.state_dict()["inc.double_conv.1.num_batches_tracked"]) == 2

@@ -246,6 +246,33 @@ def test_unet_decoder_step():
             assert rel_l2(v, g[f"unet_step.buf.{k}"]) < 1e-5, k
 
 
+@pytest.mark.parametrize("HW", [56, 70])
+def test_or_unet_fuse_step(HW):
+    """Oracle OR-UNet fuse head == the head assembled from the reference's own DoubleConv / Down / Up / OutConv / FCUUp classes
+    with the eval script's forward (tests/golden/orunet.pt, make_golden.py:orunet_case): logits, CE + DC loss, gradients of
+    every parameter, BatchNorm running statistics after one step; two geometries (F.pad branch, fractional nearest ratios)."""
+    g = load_golden("orunet")
+    tag, D, B = f"orunet{HW}", 384, 2
+    sd = W.make_or_unet_state_dict(D, 2)
+    img, tg = W.synthetic_batch(B, HW, 2)
+    maps = {k: W.tensor(f"{tag}.{k}", (B, D, n, n), 1.0) for k, n in dict(o=HW // 14, t2=HW * 3 // 28, d2=HW // 28).items()}
+    osd = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sd.items()}
+    oy = O.or_unet_fuse(img, maps["o"], maps["t2"], maps["d2"], osd, update_bn=True)
+    loss = O.cross_entropy_nd(oy, tg) + O.dc_loss(oy, O.one_hot(tg, 2))
+    loss.backward()
+    assert golden_err(oy, g[f"{tag}.logits"]) < 1e-5
+    assert abs(float(loss) - float(g[f"{tag}.loss"])) < 1e-6
+    for k, v in osd.items():
+        if v.requires_grad:
+            gold = g[f"{tag}.grad.{k}"]
+            if float(gold["sumsq"]) < 1e-12:      # conv bias in front of a train-mode BatchNorm: zero + rounding noise
+                assert float(v.grad.abs().max()) < 1e-5, k
+            else:
+                assert golden_err(v.grad, gold) < 5e-3, k
+        elif "running" in k:
+            assert rel_l2(v, g[f"{tag}.buf.{k}"]) < 1e-5, k
+
+
 def test_decoder_setr_step():
     """`decoders.py:167-203` DecoderSETR == the FeatureDecoder restatement on its own state_dict (tests/golden/setr.pt)."""
     g = load_golden("setr")
