@@ -117,6 +117,12 @@ SIGNATURES = {
     "asis_add_f32": [_vp, _vp, _vp, _vp, _i64, _i, _i64, _i64, _i64],
     "asis_maxpool2_fwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i],
     "asis_maxpool2_bwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i],
+    "asis_cls_l2norm": [_vp, _vp, _vp, _vp, _i, _i, _i, _i],
+    "asis_cls_l2norm_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i],
+    "asis_mask_logits_fwd": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _i],
+    "asis_mask_logits_nblk": [_i, _i],
+    "asis_mask_logits_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _i],
+    "asis_mask_dchat": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i],
     "asis_nearest_add_relu": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i],
     "asis_nearest_sum": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i],
     "asis_convt2x2_scatter": [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i],

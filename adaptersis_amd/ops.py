@@ -721,6 +721,67 @@ def maxpool2_bwd(dy: torch.Tensor, idx: torch.Tensor, dx: torch.Tensor) -> torch
 
 
 
+def cls_l2norm(x: torch.Tensor, B: int, N: int, C: int):
+    """class rows of the stacked fp32 [B*(N+C), D] matrix -> (chat fp32 [B,C,D] = x / ||x||, inv_c fp32 [B*C])."""
+    _dev(x)
+    D = x.shape[1]
+    if x.dtype != torch.float32 or not x.is_contiguous() or x.shape[0] != B * (N + C):
+        raise ValueError("cls_l2norm: contiguous float32 [B*(N+C), D] expected")
+    chat = torch.empty((B, C, D), device=x.device, dtype=torch.float32)
+    inv = torch.empty((B * C,), device=x.device, dtype=torch.float32)
+    check(lib().asis_cls_l2norm(_stream(), x.data_ptr(), chat.data_ptr(), inv.data_ptr(), B, N, C, D), "asis_cls_l2norm")
+    return chat, inv
+
+
+def cls_l2norm_bwd(dchat: torch.Tensor, chat: torch.Tensor, inv_c: torch.Tensor, dx: torch.Tensor, N: int) -> None:
+    """writes the class rows of dx (stacked fp32 [B*(N+C), D]); the patch rows are left as they are."""
+    _dev(dchat, chat, inv_c, dx)
+    B, C, D = chat.shape
+    if dx.dtype != torch.float32 or not dx.is_contiguous() or tuple(dx.shape) != (B * (N + C), D) or dchat.shape != chat.shape:
+        raise ValueError("cls_l2norm_bwd: shape mismatch")
+    check(lib().asis_cls_l2norm_bwd(_stream(), _f32c(dchat).data_ptr(), chat.data_ptr(), inv_c.data_ptr(), dx.data_ptr(), B, N, C, D),
+          "asis_cls_l2norm_bwd")
+
+
+def mask_logits_fwd(P: torch.Tensor, chat: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, N: int):
+    """stacked P fp32 [B*(N+C), D] (patch rows), chat [B,C,D] -> (logits fp32 [B*N, C] = LayerNorm_C(cosines), cosm, inv_p)."""
+    _dev(P, chat, gamma, beta)
+    B, C, D = chat.shape
+    if P.dtype != torch.float32 or not P.is_contiguous() or tuple(P.shape) != (B * (N + C), D):
+        raise ValueError("mask_logits_fwd: contiguous float32 [B*(N+C), D] expected")
+    logits = torch.empty((B * N, C), device=P.device, dtype=torch.float32)
+    cosm = torch.empty((B * N, C), device=P.device, dtype=torch.float32)
+    inv_p = torch.empty((B * N,), device=P.device, dtype=torch.float32)
+    check(lib().asis_mask_logits_fwd(_stream(), P.data_ptr(), chat.data_ptr(), _f32c(gamma).data_ptr(), _f32c(beta).data_ptr(),
+                                     float(eps), logits.data_ptr(), cosm.data_ptr(), inv_p.data_ptr(), B, N, C, D),
+          "asis_mask_logits_fwd")
+    return logits, cosm, inv_p
+
+
+def mask_logits_bwd(dlogits: torch.Tensor, cosm: torch.Tensor, inv_p: torch.Tensor, P: torch.Tensor, chat: torch.Tensor,
+                    gamma: torch.Tensor, eps: float, dP: torch.Tensor, N: int):
+    """-> (dcos fp32 [B*N, C], partial fp32 [nblk, 2, C]); writes the patch rows of dP (stacked, same shape as P)."""
+    _dev(dlogits, cosm, inv_p, P, chat, gamma, dP)
+    B, C, D = chat.shape
+    if dP.shape != P.shape or dP.dtype != torch.float32 or not dP.is_contiguous() or tuple(dlogits.shape) != (B * N, C):
+        raise ValueError("mask_logits_bwd: shape mismatch")
+    dcos = torch.empty((B * N, C), device=P.device, dtype=torch.float32)
+    part = torch.empty((lib().asis_mask_logits_nblk(B, N), 2, C), device=P.device, dtype=torch.float32)
+    check(lib().asis_mask_logits_bwd(_stream(), _f32c(dlogits).data_ptr(), cosm.data_ptr(), inv_p.data_ptr(), P.data_ptr(),
+                                     chat.data_ptr(), _f32c(gamma).data_ptr(), float(eps), dP.data_ptr(), dcos.data_ptr(),
+                                     part.data_ptr(), B, N, C, D), "asis_mask_logits_bwd")
+    return dcos, part
+
+
+def mask_dchat(dcos: torch.Tensor, P: torch.Tensor, inv_p: torch.Tensor, B: int, N: int, C: int) -> torch.Tensor:
+    _dev(dcos, P, inv_p)
+    D = P.shape[1]
+    out = torch.empty((B, C, D), device=P.device, dtype=torch.float32)
+    check(lib().asis_mask_dchat(_stream(), dcos.data_ptr(), P.data_ptr(), inv_p.data_ptr(), out.data_ptr(), B, N, C, D),
+          "asis_mask_dchat")
+    return out
+
+
 def nearest_tables(src: int, dst: int, device) -> tuple:
     """F.interpolate(mode='nearest') index tables for one axis: (src index of every dst index int32 [dst], first dst index of
     every src index int32 [src + 1]).  ATen (UpSample.h nearest_idx): identity when equal, dst >> 1 for an exact doubling,

@@ -271,6 +271,39 @@ def make_unet_state_dict(base: int = 384, n_classes: int = 2, seed: int = 0):
     return sd
 
 
+def make_masktrans_state_dict(d_encoder: int, d_model: int, n_layers: int = 2, n_cls: int = 2, d_ff: int = None, seed: int = 0,
+                              mode: str = "kernel"):
+    """``MaskTransformer`` of `eval/eval_dinov2_masktrans.py:400-439` (blocks: `backbones/masktrans_block.py`).
+    mode="init": the scales of the reference's own initialisation (`:388-396,427-436`: Linear weights std 0.02 with zero bias,
+    LayerNorm 1 / 0, cls_emb std 0.02, proj_patch / proj_classes std d_model^-0.5) — the head as the reference starts training
+    it; mode="kernel": unit-gain weights, non-zero biases and LayerNorm affines, so that every term carries signal and the two
+    residual branches are as large as the stream itself (stress case for the kernels)."""
+    sd = OrderedDict()
+    d_ff = d_ff or 4 * d_model
+    init = mode == "init"
+    r3 = 3.0 ** 0.5
+    sd["cls_emb"] = tensor("mt.cls_emb", (1, n_cls, d_model), 0.02 * r3 if init else 0.5, seed=seed)
+    sd["proj_patch"] = tensor("mt.proj_patch", (d_model, d_model), (3.0 / d_model) ** 0.5, seed=seed)
+    sd["proj_classes"] = tensor("mt.proj_classes", (d_model, d_model), (3.0 / d_model) ** 0.5, seed=seed)
+
+    def lin(p, cout, cin):
+        sd[p + ".weight"] = tensor("mt." + p + ".weight", (cout, cin), 0.02 * r3 if init else (3.0 / cin) ** 0.5, seed=seed)
+        sd[p + ".bias"] = torch.zeros(cout) if init else tensor("mt." + p + ".bias", (cout,), 0.05, seed=seed)
+
+    def ln(p, c):
+        sd[p + ".weight"] = torch.ones(c) if init else tensor("mt." + p + ".weight", (c,), 0.3, 1.0, seed)
+        sd[p + ".bias"] = torch.zeros(c) if init else tensor("mt." + p + ".bias", (c,), 0.2, 0.0, seed)
+
+    for i in range(n_layers):
+        b = f"blocks.{i}"
+        ln(b + ".norm1", d_model); lin(b + ".attn.qkv", 3 * d_model, d_model); lin(b + ".attn.proj", d_model, d_model)
+        ln(b + ".norm2", d_model); lin(b + ".mlp.fc1", d_ff, d_model); lin(b + ".mlp.fc2", d_model, d_ff)
+    lin("proj_dec", d_model, d_encoder)
+    ln("decoder_norm", d_model)
+    ln("mask_norm", n_cls)
+    return sd
+
+
 def make_or_unet_state_dict(embed_dim: int = 384, n_classes: int = 2, base: int = 64, seed: int = 0):
     """OR-UNet fuse head `eval/eval_dinov2_or_unet_fuse.py:426-447` (bilinear=False): DoubleConv(3, base), four Down, four Up
     (each with its skip), OutConv, and the FCUUp projections expand_block_2/3/4 (embed_dim -> 4*base / 2*base / base).

@@ -332,6 +332,27 @@ int asis_add_f32(void* stream, const float* a, const float* b, float* out, int64
 int asis_maxpool2_fwd(void* stream, int dtype, const void* x, const void* x_lo, void* out, void* out_lo, uint8_t* idx,
                       int B, int H, int W, int C);
 int asis_maxpool2_bwd(void* stream, const float* dy, const uint8_t* idx, float* dx, int B, int H, int W, int C);
+/* Tail of the MaskTransformer decode head (reference eval/eval_dinov2_masktrans.py:452-462): L2-normalised patch and class
+ * features, their cosines, LayerNorm over the C classes (mask_norm).  Stacked token layout: batch b owns rows b*(N+C) ..
+ * +N-1 (patches) and the C rows behind them (class tokens) of an fp32 [B*(N+C), D] matrix.  C <= 16, D % 4 == 0.
+ *   asis_cls_l2norm      x (class rows of the stacked matrix) -> chat fp32 [B,C,D] = x / ||x||, inv_c fp32 [B*C]
+ *   asis_cls_l2norm_bwd  dchat, chat, inv_c -> the class rows of dx (stacked layout; patch rows untouched)
+ *   asis_mask_logits_fwd P (stacked; patch rows read), chat, mask_norm weight / bias / eps -> logits fp32 [B*N, C],
+ *                        cosm fp32 [B*N, C] (the cosines), inv_p fp32 [B*N] = 1 / ||patch row||
+ *   asis_mask_logits_bwd dlogits fp32 [B*N, C] -> dP (patch rows of the stacked layout), dcos fp32 [B*N, C], and
+ *                        part fp32 [asis_mask_logits_nblk(B, N), 2, C]: per-workgroup sums of (dlogits * xhat | dlogits) =
+ *                        mask_norm weight / bias gradients after a column sum
+ *   asis_mask_dchat      dchat fp32 [B,C,D] = sum_n dcos[b,n,:]^T (P[b,n,:] inv_p[b,n])   (zeroed inside, row slices by atomics) */
+int asis_cls_l2norm(void* stream, const float* x, float* chat, float* inv_c, int B, int N, int C, int D);
+int asis_cls_l2norm_bwd(void* stream, const float* dchat, const float* chat, const float* inv_c, float* dx, int B, int N, int C,
+                        int D);
+int asis_mask_logits_fwd(void* stream, const float* P, const float* chat, const float* gamma, const float* beta, float eps,
+                         float* logits, float* cosm, float* inv_p, int B, int N, int C, int D);
+int asis_mask_logits_nblk(int B, int N);
+int asis_mask_logits_bwd(void* stream, const float* dlogits, const float* cosm, const float* inv_p, const float* P,
+                         const float* chat, const float* gamma, float eps, float* dP, float* dcos, float* part, int B, int N, int C,
+                         int D);
+int asis_mask_dchat(void* stream, const float* dcos, const float* P, const float* inv_p, float* dchat, int B, int N, int C, int D);
 /* FCUUp + FusionModel of the OR-UNet fuse head (reference eval/eval_dinov2_or_unet_fuse.py:502-530, used at :448-464):
  *   x <- relu(x + F.interpolate(r, size=(H, W)))           (default mode 'nearest')
  * asis_nearest_add_relu: in place on the 16-bit map x (+ x_lo) [B,H,W,C]; r (+ r_lo) 16-bit [B,h,w,C]; ys int32 [H] / xs

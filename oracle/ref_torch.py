@@ -384,6 +384,51 @@ def unet(x, sd: SD, p: str = "", update_bn: bool = False):
     return F.conv2d(y, sd[pre + "outc.conv.weight"], sd[pre + "outc.conv.bias"])
 
 
+def masktrans_block(x, sd: SD, p: str, num_heads: int):
+    """`backbones/masktrans_block.py:75-89` (dropout 0, drop_path 0): pre-norm block, nn.LayerNorm default eps 1e-5, attention
+    `:34-72` = softmax((q k^T) * head_dim^-0.5) v with qkv / proj biases, FeedForward `:11-31` = fc1 -> GELU -> fc2."""
+    B, N, C = x.shape
+    hd = C // num_heads
+    h = layer_norm(x, sd, p + ".norm1", 1e-5)
+    qkv = F.linear(h, sd[p + ".attn.qkv.weight"], sd[p + ".attn.qkv.bias"]).reshape(B, N, 3, num_heads, hd).permute(2, 0, 3, 1, 4)
+    attn = ((qkv[0] @ qkv[1].transpose(-2, -1)) * hd ** -0.5).softmax(dim=-1)
+    a = (attn @ qkv[2]).transpose(1, 2).reshape(B, N, C)
+    x = x + F.linear(a, sd[p + ".attn.proj.weight"], sd[p + ".attn.proj.bias"])
+    h = layer_norm(x, sd, p + ".norm2", 1e-5)
+    h = F.gelu(F.linear(h, sd[p + ".mlp.fc1.weight"], sd[p + ".mlp.fc1.bias"]))
+    return x + F.linear(h, sd[p + ".mlp.fc2.weight"], sd[p + ".mlp.fc2.bias"])
+
+
+def mask_transformer(tok, sd: SD, num_heads: int, n_cls: int, p: str = "", taps: Optional[dict] = None):
+    """`eval/eval_dinov2_masktrans.py:441-462` ``MaskTransformer.forward``: tokens (B, N, d_encoder) -> masks (B, n_cls, GS, GS).
+    ``taps``: receives the cosines in front of mask_norm (B, N, n_cls)."""
+    pre = p + "." if p else ""
+    x = F.linear(tok, sd[pre + "proj_dec.weight"], sd[pre + "proj_dec.bias"])
+    x = torch.cat((x, sd[pre + "cls_emb"].expand(x.size(0), -1, -1)), 1)
+    i = 0
+    while f"{pre}blocks.{i}.norm1.weight" in sd:
+        x = masktrans_block(x, sd, f"{pre}blocks.{i}", num_heads)
+        i += 1
+    x = layer_norm(x, sd, pre + "decoder_norm", 1e-5)
+    patches, cls = x[:, :-n_cls] @ sd[pre + "proj_patch"], x[:, -n_cls:] @ sd[pre + "proj_classes"]
+    patches = patches / patches.norm(dim=-1, keepdim=True)
+    cls = cls / cls.norm(dim=-1, keepdim=True)
+    cos = patches @ cls.transpose(1, 2)
+    if taps is not None:
+        taps["cos"] = cos
+    masks = layer_norm(cos, sd, pre + "mask_norm", 1e-5)
+    B, N, _ = masks.shape
+    gs = int(round(N ** 0.5))
+    return masks.reshape(B, gs, gs, n_cls).permute(0, 3, 1, 2)
+
+
+def dice_of_argmax(output, target, eps: float = 1e-7):
+    """`eval/eval_dinov2_masktrans.py:83-92,306-311`: 1 - dice of the hard prediction (argmax) — a constant of the step."""
+    preds = torch.softmax(output, 1).max(1)[1]
+    o, t = preds.reshape(-1).float(), target.reshape(-1).float()
+    return 1.0 - (2.0 * (o * t).sum() + eps) / (o.sum() + t.sum() + eps)
+
+
 def or_unet_fuse(img, x_o, x_t2, x_d2, sd: SD, p: str = "", update_bn: bool = False):
     """OR-UNet multi-scale fuse head, `eval/eval_dinov2_or_unet_fuse.py:426-486` (``UNet.forward``, bilinear=False,
     dw_stride=1): a full-resolution UNet on the image whose first three encoder levels are fused with ViT feature maps of

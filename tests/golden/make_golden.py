@@ -385,6 +385,84 @@ def orunet_case(R, out):
                 out[f"{tag}.buf.{k}"] = v.clone()
 
 
+def ref_mask_transformer(R, n_cls, d_encoder, n_layers, n_heads, d_model, d_ff):
+    """``MaskTransformer`` of `eval/eval_dinov2_masktrans.py:400-462`.  Neither the script (it imports modules the repository
+    does not ship) nor `backbones/masktrans_block.py` (it needs `timm`, absent here) can be imported.  The head is assembled
+    from what the reference DOES ship importable: its transformer block is `dinov2/layers/block.py` ``Block`` with
+    ``init_values=None`` (LayerScale = Identity), ``qkv_bias=True``, nn.LayerNorm (eps 1e-5), the plain ``Attention`` and ``Mlp``
+    — the same pre-norm block, parameter for parameter (norm1, attn.qkv, attn.proj, norm2, mlp.fc1, mlp.fc2), as
+    `masktrans_block.py:75-89` with dropout 0; the script's constructor (`:414-436`) and forward (`:441-462`) are restated."""
+    import importlib
+    import torch.nn as nn
+    RBlock = importlib.import_module("dinov2.layers.block").Block
+    RAttn = importlib.import_module("dinov2.layers.attention").Attention
+
+    class MT(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.n_cls = n_cls
+            self.blocks = nn.ModuleList([RBlock(d_model, n_heads, mlp_ratio=d_ff / d_model, qkv_bias=True, proj_bias=True,
+                                                ffn_bias=True, init_values=None, norm_layer=nn.LayerNorm, attn_class=RAttn)
+                                         for _ in range(n_layers)])
+            self.cls_emb = nn.Parameter(torch.randn(1, n_cls, d_model))
+            self.proj_dec = nn.Linear(d_encoder, d_model)
+            self.proj_patch = nn.Parameter(torch.randn(d_model, d_model))
+            self.proj_classes = nn.Parameter(torch.randn(d_model, d_model))
+            self.decoder_norm = nn.LayerNorm(d_model)
+            self.mask_norm = nn.LayerNorm(n_cls)
+
+        def forward(self, x, im_size):
+            GS = im_size[0] // 14
+            x = self.proj_dec(x)
+            x = torch.cat((x, self.cls_emb.expand(x.size(0), -1, -1)), 1)
+            for blk in self.blocks:
+                x = blk(x)
+            x = self.decoder_norm(x)
+            patches, cls = x[:, :-self.n_cls] @ self.proj_patch, x[:, -self.n_cls:] @ self.proj_classes
+            patches = patches / patches.norm(dim=-1, keepdim=True)
+            cls = cls / cls.norm(dim=-1, keepdim=True)
+            masks = self.mask_norm(patches @ cls.transpose(1, 2))
+            B = masks.shape[0]
+            return masks.reshape(B, GS, GS, self.n_cls).permute(0, 3, 1, 2)
+    return MT()
+
+
+def masktrans_case(R, out):
+    """MaskTransformer head step (`eval/eval_dinov2_masktrans.py:262-322`): ViT tokens (no gradient) -> masks at 1/14 -> bilinear
+    resize to the image -> CrossEntropy(weight [0.1, 10]) (+ the constant dice of the arg-max prediction) -> gradients of every
+    parameter.  Cases: mt2 = 2 classes, d_encoder 384 -> d_model 256 (4 heads), 16 x 16 patches (224^2), weights at the scales
+    of the reference's own initialisation; mt2k = the same geometry with unit-gain "kernel" weights (stress); mt5 = 5 classes,
+    d_model 128, 9 x 9 patches, kernel weights."""
+    import torch.nn.functional as F
+    for tag, (n_cls, De, D, heads, GS, B, mode) in dict(mt2=(2, 384, 256, 4, 16, 2, "init"), mt5=(5, 64, 128, 2, 9, 3, "kernel"),
+                                                        mt2k=(2, 384, 256, 4, 16, 2, "kernel")).items():
+        sd = W.make_masktrans_state_dict(De, D, 2, n_cls, mode=mode)
+        m = ref_mask_transformer(R, n_cls, De, 2, heads, D, 4 * D)
+        m.load_state_dict(sd, strict=True)
+        m.train()
+        HW = GS * 14
+        tok = W.tensor(f"{tag}.tok", (B, GS * GS, De), 1.0)
+        tg = W.synthetic_batch(B, HW, n_cls)[1]
+        cw = torch.tensor([0.1, 10.0]) if n_cls == 2 else torch.linspace(0.5, 2.0, n_cls)
+        y = m(tok, (HW, HW))
+        o = F.interpolate(y, size=(HW, HW), mode="bilinear")
+        loss = torch.nn.CrossEntropyLoss(reduction="mean", weight=cw)(o, tg)
+        loss.backward()
+        osd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        oy = O.mask_transformer(tok, osd, heads, n_cls)
+        oo = F.interpolate(oy, size=(HW, HW), mode="bilinear")
+        oloss = F.cross_entropy(oo, tg, weight=cw)
+        oloss.backward()
+        close(oy.detach(), y.detach(), 2e-5, f"{tag} masks")
+        close(oloss.detach(), loss.detach(), 1e-5, f"{tag} loss")
+        out[f"{tag}.masks"] = sub(y)
+        out[f"{tag}.loss"] = loss.detach().clone()
+        out[f"{tag}.dice_const"] = O.dice_of_argmax(o.detach(), tg).clone()
+        for k, p in m.named_parameters():
+            close(osd[k].grad, p.grad, 5e-3, f"{tag} grad {k}")
+            out[f"{tag}.grad.{k}"] = sub(p.grad, 4000)
+
+
 def loss_case(R, out):
     B, C, H = 3, 2, 40
     lg = W.tensor("loss.logits", (B, C, H, H), 3.0)
@@ -953,6 +1031,10 @@ def main():
         out = {}
         print("[UNet(384) decoder step with gradients]"); unet_step_case(R, out)
         save("unet", out)
+    if want("masktrans"):
+        out = {}
+        print("[MaskTransformer head step with gradients]"); masktrans_case(R, out)
+        save("masktrans", out)
     if want("orunet"):
         out = {}
         print("[OR-UNet fuse head step with gradients]"); orunet_case(R, out)

@@ -273,6 +273,31 @@ def test_or_unet_fuse_step(HW):
             assert rel_l2(v, g[f"{tag}.buf.{k}"]) < 1e-5, k
 
 
+@pytest.mark.parametrize("tag,cfg", [("mt2", (2, 384, 256, 4, 16, 2, "init")), ("mt2k", (2, 384, 256, 4, 16, 2, "kernel")),
+                                     ("mt5", (5, 64, 128, 2, 9, 3, "kernel"))])
+def test_mask_transformer_step(tag, cfg):
+    """Oracle MaskTransformer == the head assembled from the reference's own dinov2 Block (init_values=None: the same pre-norm
+    block as `backbones/masktrans_block.py`, which needs `timm`) with the eval script's forward restated
+    (tests/golden/masktrans.pt, make_golden.py:masktrans_case): masks, weighted-CE loss, every parameter gradient."""
+    g = load_golden("masktrans")
+    n_cls, De, D, heads, GS, B, mode = cfg
+    sd = W.make_masktrans_state_dict(De, D, 2, n_cls, mode=mode)
+    HW = GS * 14
+    tok = W.tensor(f"{tag}.tok", (B, GS * GS, De), 1.0)
+    tg = W.synthetic_batch(B, HW, n_cls)[1]
+    cw = torch.tensor([0.1, 10.0]) if n_cls == 2 else torch.linspace(0.5, 2.0, n_cls)
+    osd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    oy = O.mask_transformer(tok, osd, heads, n_cls)
+    oo = F.interpolate(oy, size=(HW, HW), mode="bilinear")
+    loss = F.cross_entropy(oo, tg, weight=cw)
+    loss.backward()
+    assert golden_err(oy, g[f"{tag}.masks"]) < 2e-5
+    assert abs(float(loss) - float(g[f"{tag}.loss"])) < 1e-5
+    assert abs(float(O.dice_of_argmax(oo.detach(), tg)) - float(g[f"{tag}.dice_const"])) < 1e-6
+    for k, v in osd.items():
+        assert golden_err(v.grad, g[f"{tag}.grad.{k}"]) < 5e-3, k
+
+
 def test_decoder_setr_step():
     """`decoders.py:167-203` DecoderSETR == the FeatureDecoder restatement on its own state_dict (tests/golden/setr.pt)."""
     g = load_golden("setr")
