@@ -87,6 +87,7 @@ SIGNATURES = {
     "asis_rowblock_nblk": [_i64],
     "asis_layernorm_bwd": [_vp, _vp, _i64, _vp, _i64, _vp, _f, _vp, _i64, _vp, _i64, _vp, _i64, _i],
     "asis_gelu16": [_vp, _i, _vp, _vp, _vp, _i64],
+    "asis_gelu_split": [_vp, _i, _vp, _vp, _vp, _i64],
     "asis_cast_colsum": [_vp, _i, _vp, _i64, _vp, _i64, _f, _vp, _i64, _i],
     "asis_swiglu_bwd": [_vp, _i, _vp, _vp, _vp, _i64, _i],
     "asis_colsum": [_vp, _i, _vp, _i64, _vp, _i64, _i],

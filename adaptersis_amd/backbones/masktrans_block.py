@@ -15,6 +15,9 @@ backward, GEMM epilogues, weight-gradient GEMMs — the config-4 machinery) unde
 names (norm1, attn.qkv, attn.proj, norm2, mlp.fc1, mlp.fc2) are the same.  The tail runs on `csrc/maskhead.hip`.
 Tokens of all images are rows of one fp32 matrix, batch b = rows b*(N+n_cls) ..; both D x D projections run over all rows
 (one GEMM each: the class projection of the patch rows is 0.1 TFLOP of waste that buys uniform row indexing).
+Precision: ``mask_norm`` (LayerNorm over n_cls values) amplifies the error of the cosines 2.2-2.8x, so under
+``config.split_conv`` (default) every linear layer of the head runs on split-precision operands (masks 2.5e-4 .. 6.8e-4 against the
+golden; 1.4e-3 .. 2.7e-3 with single-pass 16-bit operands).
 
 Dropout: the reference script builds the head with ``dropout=0.1`` (`:139`); only ``dropout == 0`` / ``drop_path == 0`` is
 implemented (a stochastic mask inside the fused attention kernel is not) — other values raise in training mode.
@@ -58,6 +61,70 @@ class Block(L.Block):
         if self.dropout != 0.0 or self.drop_path_rate != 0.0:
             raise NotImplementedError("masktrans Block: dropout / drop_path > 0 is not implemented on the HIP path "
                                       "(build the head with dropout=0.0, drop_path_rate=0.0)")
+
+    # ---- split-precision forward ---------------------------------------------------------------------------------------
+    # The head's output goes through mask_norm, a LayerNorm over only n_cls values that amplifies a relative error of the
+    # cosines 2.2-2.8x (MaskTransformer._forward_core).  With the three GEMMs outside the blocks on hi + lo operands, the 16-bit
+    # rounding of the blocks' GEMM operands is what is left (2.9e-4 on the tokens after two blocks at the reference's init
+    # scales -> 1.4e-3 on the masks), so under ``config.split_conv`` the head's blocks run their four linear layers on
+    # split-precision operands too (LayerNorm / GELU outputs as hi + lo pairs, weights as hi + lo pairs); only the fused
+    # attention keeps 16-bit q, k, v, P and its 16-bit output.  Two layers of d_model: 3x the GEMM passes of a head that is a
+    # few per cent of the backbone.  The saved activations keep the 16-bit layout ``Block.backward`` expects.
+    def _lo(self, owner, key: str, w: torch.Tensor):
+        return _pack(owner._cache, key + ".lo2", w,
+                     lambda q: ops.cast_pad(q.reshape(q.shape[0], -1).contiguous().float(), dtype=config.operand_dtype, part=1))
+
+    @staticmethod
+    def _split_linear(a_hi, a_lo, w_hi, w_lo, bias, res=None):
+        out = torch.empty((a_hi.shape[0], w_hi.shape[0]), device=a_hi.device, dtype=torch.float32)
+        ops.gemm_split(a_hi, a_lo, w_hi, w_lo, out=out, bias_n=bias)
+        if res is not None:
+            o3 = out.view(1, *out.shape)
+            ops.add_f32(o3, res.view(1, *res.shape), out=o3)
+        return out
+
+    def _fwd_precise(self, x2: torch.Tensor, segs, save: bool):
+        dt = config.operand_dtype
+        R, D = x2.shape
+        a, m = self.attn, self.mlp
+        xn32 = ops.layernorm(x2, self._f32("n1w", self.norm1.weight), self._f32("n1b", self.norm1.bias), self.norm1.eps, torch.float32)
+        xn, xn_lo = ops.cast_pad(xn32, D, dt), ops.cast_pad(xn32, D, dt, part=1)
+        qkv32 = self._split_linear(xn, xn_lo, a._w16("qkv", a.qkv.weight), self._lo(a, "qkv", a.qkv.weight), a._f32("qkv_b", a.qkv.bias))
+        qkv = ops.cast_pad(qkv32, 3 * D, dt)
+        o = torch.empty((R, D), device=x2.device, dtype=dt)
+        lse = []
+        r0 = 0
+        for B, N in segs:
+            r1 = r0 + B * N
+            vt = ops.transpose_tokens(qkv[r0:r1, 2 * D:], B, N)
+            l = torch.empty((B, a.num_heads, N), device=x2.device, dtype=torch.float32) if save else None
+            ops.attention_fwd(qkv[r0:r1, :D], qkv[r0:r1, D:2 * D], vt, B, a.num_heads, N, a.scale, out=o[r0:r1], lse=l)
+            lse.append(l)
+            r0 = r1
+        if r0 != R:
+            raise ValueError("masktrans Block: segments do not cover the rows")
+        x1 = ops.gemm(o, a._w16("proj", a.proj.weight), out_f32=True, bias_n=a._f32("proj_b", a.proj.bias), res=x2,
+                      b_lo=self._lo(a, "proj", a.proj.weight))
+        xn2_32 = ops.layernorm(x1, self._f32("n2w", self.norm2.weight), self._f32("n2b", self.norm2.bias), self.norm2.eps, torch.float32)
+        xn2, xn2_lo = ops.cast_pad(xn2_32, D, dt), ops.cast_pad(xn2_32, D, dt, part=1)
+        hpre32 = self._split_linear(xn2, xn2_lo, m._w16("fc1", m.fc1.weight), self._lo(m, "fc1", m.fc1.weight), m._f32("fc1_b", m.fc1.bias))
+        hpost, hpost_lo = ops.gelu_split(hpre32, dt)
+        x3 = self._split_linear(hpost, hpost_lo, m._w16("fc2", m.fc2.weight), self._lo(m, "fc2", m.fc2.weight),
+                                m._f32("fc2_b", m.fc2.bias), res=x1)
+        if not save:
+            return x3, None
+        hpre = ops.cast_pad(hpre32, hpre32.shape[1], dt)
+        return x3, (x2, xn, qkv, o, lse, x1, xn2, hpre, hpost, list(segs))
+
+    def forward_rows(self, x2, segs):
+        if config.split_conv:
+            return self._fwd_precise(x2, segs, False)[0]
+        return super().forward_rows(x2, segs)
+
+    def forward_train_rows(self, x2, segs):
+        if config.split_conv:
+            return self._fwd_precise(x2, segs, True)
+        return super().forward_train_rows(x2, segs)
 
 
 def init_weights(m):

@@ -342,6 +342,36 @@ extern "C" int asis_layernorm_bwd(void* stream, const float* dy, int64_t lddy, c
   return ASIS_OK;
 }
 
+namespace {
+// erf-GELU of an fp32 pre-activation into a split-precision 16-bit operand pair (hi, lo = rounding residual of hi)
+template <typename T>
+__global__ __launch_bounds__(256) void gelu_split_kernel(const float* __restrict__ x, T* __restrict__ hi, T* __restrict__ lo, int64_t n4) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    const float g0 = gelu_erf(v.x), g1 = gelu_erf(v.y), g2 = gelu_erf(v.z), g3 = gelu_erf(v.w);
+    uint2 h;
+    h.x = pack2<T>(g0, g1); h.y = pack2<T>(g2, g3);
+    reinterpret_cast<uint2*>(hi)[i] = h;
+    if (lo) {
+      uint2 l;
+      l.x = pack2<T>(lo_part<T>(g0), lo_part<T>(g1)); l.y = pack2<T>(lo_part<T>(g2), lo_part<T>(g3));
+      reinterpret_cast<uint2*>(lo)[i] = l;
+    }
+  }
+}
+}  // namespace
+
+extern "C" int asis_gelu_split(void* stream, int dtype, const float* x, void* hi, void* lo, int64_t n) {
+  ASIS_REQUIRE(x && hi && n > 0 && n % 4 == 0, "asis_gelu_split: bad arguments (n %% 4 == 0)");
+  DT_OK(dtype, "asis_gelu_split");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int g = grid_for(n / 4);
+  if (dtype == ASIS_F16) hipLaunchKernelGGL((gelu_split_kernel<f16>), dim3(g), dim3(256), 0, s, x, (f16*)hi, (f16*)lo, n / 4);
+  else hipLaunchKernelGGL((gelu_split_kernel<bf16>), dim3(g), dim3(256), 0, s, x, (bf16*)hi, (bf16*)lo, n / 4);
+  ASIS_CHECK_LAUNCH("asis_gelu_split");
+  return ASIS_OK;
+}
+
 extern "C" int asis_gelu16(void* stream, int dtype, const void* pre, const void* dpost, void* out, int64_t n) {
   ASIS_REQUIRE(pre && out && n > 0 && n % 8 == 0, "asis_gelu16: bad arguments (n %% 8 == 0)");
   DT_OK(dtype, "asis_gelu16");

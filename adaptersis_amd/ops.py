@@ -329,6 +329,17 @@ def gelu16(pre: torch.Tensor, dpost: Optional[torch.Tensor] = None) -> torch.Ten
     return out
 
 
+def gelu_split(x: torch.Tensor, dtype: torch.dtype, split: bool = True):
+    """fp32 contiguous -> (16-bit gelu(x), its rounding residual | None): a split-precision operand pair."""
+    _dev(x)
+    if x.dtype != torch.float32 or not x.is_contiguous():
+        raise ValueError("gelu_split: contiguous float32 expected")
+    hi = torch.empty(x.shape, device=x.device, dtype=dtype)
+    lo = torch.empty_like(hi) if split else None
+    check(lib().asis_gelu_split(_stream(), _dt(dtype), x.data_ptr(), hi.data_ptr(), _p(lo), x.numel()), "asis_gelu_split")
+    return hi, lo
+
+
 def swiglu_bwd(x12: torch.Tensor, dh: torch.Tensor) -> torch.Tensor:
     """x12 fp32 [R, 2*Hd], dh 16-bit [R, Hd] -> 16-bit [R, 2*Hd] = [d x1 | d x2]."""
     _dev(x12, dh)

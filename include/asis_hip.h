@@ -197,6 +197,9 @@ int asis_rowblock_nblk(int64_t rows);
 int asis_layernorm_bwd(void* stream, const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* w, float eps,
                        const float* res, int64_t ldr, float* dx, int64_t lddx, float* partial, int64_t rows, int D);
 int asis_gelu16(void* stream, int dtype, const void* pre, const void* dpost, void* out, int64_t n);
+/* erf-GELU of an fp32 pre-activation into a split-precision operand pair: hi = 16-bit gelu(x), lo (optional) = the rounding
+ * residual of hi (the MaskTransformer head's blocks run split precision end to end, backbones/masktrans_block.py). n % 4 == 0 */
+int asis_gelu_split(void* stream, int dtype, const float* x, void* hi, void* lo, int64_t n);
 /* SwiGLU gate backward (swiglu_ffn.py:30-34): x12 fp32 [R, 2*Hd] = [x1 | x2], dh 16-bit [R, Hd] = d(silu(x1) * x2)
  * -> dx12 16-bit [R, 2*Hd] = [d x1 | d x2] */
 int asis_swiglu_bwd(void* stream, int dtype, const float* x12, const void* dh, void* dx12, int64_t R, int Hd);

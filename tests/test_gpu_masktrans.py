@@ -60,14 +60,13 @@ def test_dropout_is_refused_in_training(dev):
 
 # (n_cls, d_encoder, d_model, heads, grid, batch, weight mode).  mt2: the reference's 2-class head at the scales of its own
 # initialisation; mt2k / mt5: unit-gain "kernel" weights (the residual branches are as large as the stream: stress).
-# Bounds.  The well-conditioned output of the head is the cosine map in front of mask_norm: north_star's 1e-3 is asserted on it
-# (measured 6.1e-4 / 9.6e-4 / 9.6e-4; the three GEMMs outside the blocks run split-precision, what is left is the 16-bit
-# rounding of the blocks' activations).  mask_norm is a LayerNorm over only n_cls values with eps 1e-5 — for two classes
-# nearly the sign of the cosine difference — and amplifies a relative error of the cosines 2.2-2.8x: the fp32 oracle's own masks
-# move by 2.2e-4 .. 3.0e-4 when its cosines are perturbed by 1e-4 (scripts/masktrans_probe.py).  Masks: 3e-3 = 1e-3 x that
-# conditioning (measured 1.4e-3 / 2.7e-3 / 1.7e-3).
+# Bounds: north_star's 1e-3 on the masks (measured 2.5e-4 / 6.8e-4 / 5.3e-4), 5e-4 on the cosines in front of mask_norm
+# (1.0e-4 / 2.9e-4 / 3.1e-4).  mask_norm is a LayerNorm over only n_cls values with eps 1e-5 — for two classes nearly the sign of
+# the cosine difference — and amplifies a relative error of the cosines 2.2-2.8x (the fp32 oracle's own masks move by 2.2e-4 ..
+# 3.0e-4 when its cosines are perturbed by 1e-4, scripts/masktrans_probe.py), which is why every linear layer of this head runs
+# on split-precision operands (single-pass 16-bit operands: cosines 6.1e-4 .. 9.6e-4, masks 1.4e-3 .. 2.7e-3).
 CASES = dict(mt2=(2, 384, 256, 4, 16, 2, "init"), mt2k=(2, 384, 256, 4, 16, 2, "kernel"), mt5=(5, 64, 128, 2, 9, 3, "kernel"))
-COS_TOL, MASK_TOL, GRAD_TOL = 1e-3, 3e-3, 1.5e-2
+COS_TOL, MASK_TOL, GRAD_TOL = 5e-4, 1e-3, 5e-3
 
 
 @pytest.mark.parametrize("tag", ["mt2", "mt2k", "mt5"])
