@@ -254,9 +254,11 @@ int launch(hipStream_t s, const asis_gemm_desc& d) {
   }
   static const int m16 = [] { const char* e = getenv("ASIS_GEMM_M16"); return e ? atoi(e) : 1; }();  // 16x16x32 MFMAs in the default dense form
   static const int noepi = [] { const char* e = getenv("ASIS_GEMM_NOEPI"); return e ? atoi(e) : 0; }();  // lab: main loop only
-  // ASIS_GEMM_8P: 0 = never, 1 (default) = long reductions only (K >= 2048: fc2 / its input gradient, where the 8-phase
-  // loop is 17-20 % faster in the step: 397 vs 476 us at 42348x1024x4096; at K = 1024 the two forms tie and the
-  // smaller tiles of the default quantise better), 2 = wherever the shape allows
+  // ASIS_GEMM_8P: 0 = never; 1 (default) = K >= 2048 (fc2 / its input gradient: 343 vs 476 us at 42348x1024x4096) and,
+  // since the phases run on 16x16x32 MFMAs (ASIS_GEMM_8P_M16: fc2 391 -> 350 us in isolation), the unbatched K >= 1024
+  // GEMMs too (in the step: qk 222 -> 214 us, proj 160 -> 139, fc1 457 -> 441, adapter projections 242 -> 216; +3.5 % on the
+  // step) — the batched ragged V^T GEMM stays on the two-workgroup form (66 vs 72 us: coarser tile quantisation);
+  // 3 = K >= 2048 only (the round-1 rule); 2 = wherever the shape allows
   static const int ph8 = [] { const char* e = getenv("ASIS_GEMM_8P"); return e ? atoi(e) : 1; }();
   // ASIS_GEMM_PERSIST=1: the persistent form (gemm_persist.h) for the plain dense launches it covers
   static const int persist = [] { const char* e = getenv("ASIS_GEMM_PERSIST"); return e ? atoi(e) : 0; }();
@@ -287,9 +289,16 @@ int launch(hipStream_t s, const asis_gemm_desc& d) {
     if (!gelu && !res && o32) { PERSIST(ASIS_ACT_NONE, false, true); return 0; }
 #undef PERSIST
   }
-  if (ph8 && (ph8 >= 2 || d.K >= 2048) && big_mode && !d.conv && !d.stats && d.K % 64 == 0 && d.M >= 256 && d.N >= 256) {
+  if (ph8 && (ph8 == 2 || d.K >= 2048 || (ph8 == 1 && d.K >= 1024 && d.batch == 1)) && big_mode && !d.conv && !d.stats && d.K % 64 == 0 && d.M >= 256 && d.N >= 256) {
     // 256x256x64 tile, 8-phase main loop (one workgroup per CU: 128 KB of LDS)
     dim3 grid(((d.M + 255) / 256) * ((d.N + 255) / 256), d.batch), block(512);
+    // ASIS_GEMM_8P_M16 (default 1): the phases issue 16 v_mfma_f32_16x16x32 instead of 8 32x32x16 (same FLOP, higher clock)
+    static const int ph8_m16 = [] { const char* e = getenv("ASIS_GEMM_8P_M16"); return e ? atoi(e) : 1; }();
+    if (ph8_m16) {
+      if (noepi) hipLaunchKernelGGL((gemm_big_kernel<T, 2, 4, 4, 2, 2, 4, false, false, 64, 1, true, true>), grid, block, 0, s, d, group_m);
+      else hipLaunchKernelGGL((gemm_big_kernel<T, 2, 4, 4, 2, 2, 0, false, false, 64, 1, true, true>), grid, block, 0, s, d, group_m);
+      return 0;
+    }
     if (noepi) hipLaunchKernelGGL((gemm_big_kernel<T, 2, 4, 4, 2, 2, 4, false, false, 64, 1, true>), grid, block, 0, s, d, group_m);
     else hipLaunchKernelGGL((gemm_big_kernel<T, 2, 4, 4, 2, 2, 0, false, false, 64, 1, true>), grid, block, 0, s, d, group_m);
     return 0;
