@@ -43,6 +43,7 @@ def _conv_weights(owner: _Packed, key: str, conv: nn.Conv2d, split: bool):
 
 
 _KSPLIT = os.environ.get("ASIS_CONV_KSPLIT", "1") != "0"
+_CONV_8P = os.environ.get("ASIS_CONV_8P", "1") != "0"   # mirrors the dispatcher's switch (the K-part cost model depends on the form)
 
 
 def _conv_ksplit(P: int, Cout: int, Cin: int, split: bool) -> int:
@@ -55,8 +56,14 @@ def _conv_ksplit(P: int, Cout: int, Cin: int, split: bool) -> int:
     after an 8 % allowance for summing the parts and taking the BatchNorm statistics in a separate pass."""
     if not _KSPLIT or Cin % 64 or P < 256 or Cout < 32 or Cout % 4:
         return 1
-    tiles = ((P + 255) // 256) * ((Cout + 127) // 128 if Cout > 64 else (Cout + 63) // 64)
     cus = 256
+    if _CONV_8P and Cout >= 256 and (Cout % 256 == 0 or Cout >= 1024):
+        # the 8-phase 256x256 form (csrc/gemm.hip ASIS_CONV_8P): one workgroup per CU, so a launch lasts ceil(tiles / 256)
+        # tile times: decoder_1 (83 x 2 = 166 tiles: a third of the CUs idle) and decoder_2 (331: 1.3 rounds) are cut
+        tiles = ((P + 255) // 256) * ((Cout + 255) // 256)
+        now, cut = -(-tiles // cus), -(-3 * tiles // cus) / 3.0 * 1.08
+        return 3 if cut < 0.88 * now else 1
+    tiles = ((P + 255) // 256) * ((Cout + 127) // 128 if Cout > 64 else (Cout + 63) // 64)
 
     def cost(t):
         c = -(-t // cus)

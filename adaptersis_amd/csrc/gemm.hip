@@ -235,6 +235,14 @@ int launch(hipStream_t s, const asis_gemm_desc& d) {
     // wave tiles need 1.5 KB and are LDS-bound), one workgroup per CU: +0.6 % on the step (ASIS_CONV_T512=0: old form)
     static const int t512 = [] { const char* e = getenv("ASIS_CONV_T512"); return e ? atoi(e) : 1; }();
     static const int cm16 = [] { const char* e = getenv("ASIS_CONV_M16"); return e ? atoi(e) : 0; }();  // 16x16x32 MFMAs in the split convs
+    // ASIS_CONV_8P (default 1): convolutions with whole 256-column tiles on the 8-phase 256x256x64 main loop (gemm_big.h):
+    // the long reductions of the decoder convs are where that loop is at its best (K = 9 * Cin * 3 parts)
+    static const int conv8p = [] { const char* e = getenv("ASIS_CONV_8P"); return e ? atoi(e) : 1; }();
+    if (d.conv && conv8p && d.N >= 256 && (d.N % 256 == 0 || d.N >= 1024) && d.batch == 1) {
+      dim3 g8(((d.M + 255) / 256) * ((d.N + 255) / 256), d.ksplit > 1 ? d.ksplit : 1);
+      hipLaunchKernelGGL((gemm_big_kernel<T, 2, 4, 4, 2, 2, 0, true, true, 64, 1, true, true>), g8, block, 0, s, d, group_m);
+      return 0;
+    }
     if (d.conv && bn == 64 && t512 && d.ksplit <= 1 && d.M >= 512) {
       dim3 g512(((d.M + 511) / 512) * ((d.N + 63) / 64), 1);
       if (cm16) hipLaunchKernelGGL((gemm_big_kernel<T, 8, 1, 2, 2, 2, 0, true, true, 64, 1, false, true>), g512, block, 0, s, d, group_m);
@@ -260,6 +268,7 @@ int launch(hipStream_t s, const asis_gemm_desc& d) {
   // step) — the batched ragged V^T GEMM stays on the two-workgroup form (66 vs 72 us: coarser tile quantisation);
   // 3 = K >= 2048 only (the round-1 rule); 2 = wherever the shape allows
   static const int ph8 = [] { const char* e = getenv("ASIS_GEMM_8P"); return e ? atoi(e) : 1; }();
+  static const int ph8_mink = [] { const char* e = getenv("ASIS_GEMM_8P_MINK"); return e ? atoi(e) : 1024; }();  // lab: see above
   // ASIS_GEMM_PERSIST=1: the persistent form (gemm_persist.h) for the plain dense launches it covers
   static const int persist = [] { const char* e = getenv("ASIS_GEMM_PERSIST"); return e ? atoi(e) : 0; }();
   if (persist && big_mode && !d.conv && !d.stats && !d.bias_m && !d.aux && d.batch == 1 && d.K % 64 == 0 && d.K >= 256 &&
@@ -289,7 +298,7 @@ int launch(hipStream_t s, const asis_gemm_desc& d) {
     if (!gelu && !res && o32) { PERSIST(ASIS_ACT_NONE, false, true); return 0; }
 #undef PERSIST
   }
-  if (ph8 && (ph8 == 2 || d.K >= 2048 || (ph8 == 1 && d.K >= 1024 && d.batch == 1)) && big_mode && !d.conv && !d.stats && d.K % 64 == 0 && d.M >= 256 && d.N >= 256) {
+  if (ph8 && (ph8 == 2 || d.K >= 2048 || (ph8 == 1 && d.K >= ph8_mink && d.batch == 1)) && big_mode && !d.conv && !d.stats && d.K % 64 == 0 && d.M >= 256 && d.N >= 256) {
     // 256x256x64 tile, 8-phase main loop (one workgroup per CU: 128 KB of LDS)
     dim3 grid(((d.M + 255) / 256) * ((d.N + 255) / 256), d.batch), block(512);
     // ASIS_GEMM_8P_M16 (default 1): the phases issue 16 v_mfma_f32_16x16x32 instead of 8 32x32x16 (same FLOP, higher clock)
@@ -329,6 +338,12 @@ int launch(hipStream_t s, const asis_gemm_desc& d) {
     const int bm = 256, bn = d.N > 64 ? 128 : 64;
     if (d.ksplit > 1 && (d.stats || (d.KH * d.KW) % d.ksplit != 0 || d.res)) return ASIS_EINVAL;
     dim3 grid(((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn), d.ksplit > 1 ? d.ksplit : 1), block(512);
+    static const int conv8p = [] { const char* e = getenv("ASIS_CONV_8P"); return e ? atoi(e) : 1; }();
+    if (conv8p && d.N >= 256 && (d.N % 256 == 0 || d.N >= 1024) && d.batch == 1) {
+      dim3 g8(((d.M + 255) / 256) * ((d.N + 255) / 256), d.ksplit > 1 ? d.ksplit : 1);
+      hipLaunchKernelGGL((gemm_big_kernel<T, 2, 4, 4, 2, 2, 0, true, false, 64, 1, true, true>), g8, block, 0, s, d, group_m);
+      return 0;
+    }
     if (bn == 128) hipLaunchKernelGGL((gemm_big_kernel<T, 4, 2, 2, 2, 3, 0, true>), grid, block, 0, s, d, group_m);
     else hipLaunchKernelGGL((gemm_big_kernel<T, 8, 1, 1, 2, 3, 0, true>), grid, block, 0, s, d, group_m);
     return 0;

@@ -19,7 +19,7 @@ __device__ __attribute__((aligned(16))) uint4 g_zero_page[1];
 template <typename T, int WM, int WN, int TM, int TN, int NS, int DBG = 0, bool CONV = false, bool SPLIT = false, int BKT = 64,
           int OCC = 2, bool PH8 = false, bool M16 = false>
 __global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_big_kernel(const asis_gemm_desc d, const int GROUP_M) {
-  static_assert(!PH8 || (WM == 2 && WN == 4 && TM == 4 && TN == 2 && NS == 2 && BKT == 64 && !CONV && !SPLIT),
+  static_assert(!PH8 || (WM == 2 && WN == 4 && TM == 4 && TN == 2 && NS == 2 && BKT == 64),
                 "the 8-phase main loop is written for the 256x256x64 tile, 2x4 waves of 128x64");
   // M16: the wave tile is built from v_mfma_f32_16x16x32 (one K = 32 step per MFMA) instead of 32x32x16: same FLOP per
   // cycle and the same LDS bytes per FLOP, but the chip holds a higher clock under this shape (MI355X_MICROARCH.md,
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_big_kernel(const asis_
     boff = ((part == 2) || (part == 1 && !d.A_lo)) ? b_lo_off : 0;
   };
   // ksplit > 1: blockIdx.y is a K part, not a batch entry (the host passes zero A/B batch strides)
-  const int ksp = (!PH8 && d.ksplit > 1) ? d.ksplit : 1;
+  const int ksp = d.ksplit > 1 ? d.ksplit : 1;
   const int nt1 = d.K / ksp / BKB;
   const int kt_base = ksp > 1 ? bz * nt1 : 0;
   const int ntap_part = CONV ? (d.KH * d.KW) / ksp : 1;  // conv K parts are whole taps (kernel rows for a 3x3 in three)
@@ -204,17 +204,59 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_big_kernel(const asis_
     // B half 1 (2), A half 1 (3); a half is read two or more phases after the vmcnt + barrier that retire it:
     //     phase 0 waits for B1 of tile t (<= 4 newer instructions outstanding), phase 1 for A1 of tile t,
     //     phase 3 for A0 and B0 of tile t+1; the buffer of tile t-1 is free from its phase 3 on (no LDS reads there).
+    // Source of the K tile being staged (wave-uniform): advanced once per tile, no division in the loop.  Plain GEMM: k0 only;
+    // SPLIT: the hi/lo part offsets; CONV: channel chunk -> tap -> (SPLIT) part, the same order as `issue` of the plain loop.
+    int sk0 = kt_base * BKB, s_part = 0, s_kt = 0;           // dense: k offset, part, K tile inside the part
+    int64_t s_aoff = 0, s_boff = 0;
+    int s_tl = 0, s_c = 0;                                     // CONV: tap inside this K part, channel chunk
+    const int kh0 = CONV ? tap_base / d.KW : 0, kw0 = CONV ? tap_base - kh0 * d.KW : 0;
+    int s_kh = kh0, s_kw = kw0;
+    if (CONV) sk0 = tap_base * d.Cin;
+    auto advance_src = [&]() {
+      if (CONV) {
+        if (SPLIT) {
+          ++s_part;
+          s_aoff = s_part == 1 ? a_lo_off : 0;
+          s_boff = s_part == 2 ? b_lo_off : 0;
+          if (s_part < 3) return;
+          s_part = 0;
+          s_aoff = s_boff = 0;
+        }
+        if (++s_tl == ntap_part) {
+          s_tl = 0; ++s_c; s_kh = kh0; s_kw = kw0;
+        } else if (++s_kw == d.KW) {
+          s_kw = 0; ++s_kh;
+        }
+        sk0 = (tap_base + s_tl) * d.Cin + s_c * BKB;
+      } else {
+        if (++s_kt == nt1) {        // SPLIT only: next part, K restarts
+          s_kt = 0; ++s_part;
+          part_offs(s_part, s_aoff, s_boff);
+        }
+        sk0 = (s_kt + kt_base) * BKB;
+      }
+    };
     auto dma_a = [&](int t, int j) {
-      __builtin_amdgcn_global_load_lds((glb_ptr)(asrc[j] + t * BKB), (lds_ptr)(lds + (t & 1) * STAGE + grp_a(j) * BKB), 16, 0, 0);
+      const T* src;
+      if (CONV) {
+        const int ih = a_ih0[j] + s_kh, iw = a_iw0[j] + s_kw;
+        src = ((unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W)
+                  ? asrc[j] + s_aoff + ((int64_t)ih * d.W + iw) * d.Cin + s_c * BKB
+                  : reinterpret_cast<const T*>(g_zero_page);
+      } else {
+        src = asrc[j] + s_aoff + sk0;
+      }
+      __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(lds + (t & 1) * STAGE + grp_a(j) * BKB), 16, 0, 0);
     };
     auto dma_b = [&](int t, int j) {
-      __builtin_amdgcn_global_load_lds((glb_ptr)(bsrc[j] + t * BKB), (lds_ptr)(lds + (t & 1) * STAGE + BM2 * BKB + grp_b(j) * BKB), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_ptr)(bsrc[j] + s_boff + sk0), (lds_ptr)(lds + (t & 1) * STAGE + BM2 * BKB + grp_b(j) * BKB), 16, 0, 0);
     };
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       dma_a(0, j);
       dma_b(0, j);
     }
+    advance_src();   // the source now describes tile 1, staged during tile 0's phases
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (wm == 1) __builtin_amdgcn_s_barrier();  // stagger the second wave row by one barrier interval
@@ -306,6 +348,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_big_kernel(const asis_
       __builtin_amdgcn_s_barrier();
       // phase 3
       if (more) { dma_a(t + 1, 2); dma_a(t + 1, 3); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+      advance_src();
       __builtin_amdgcn_s_barrier();
       mma(1, 0, b0f);
       __builtin_amdgcn_s_barrier();

@@ -211,19 +211,22 @@ def cpu_baseline(arch: str, size: int, batch: int = 1):
     }
 
 
-def pmc_traffic(kernel: str, variant: str):
-    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
-    WRITE_SIZE in separate runs of this very command, gfx950 read-side doubling applied: scripts/pmc_traffic.py).
-    PMC counters cannot be collected from inside the timed run, so this is the figure of the last profiled run."""
+def pmc_traffic(kernel: str, variants):
+    """HBM-side bytes per launch of the dominant kernel — the launch-weighted mean over its listed template forms — from the
+    committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate runs of this very command, gfx950 read-side
+    doubling applied: scripts/pmc_traffic.py).  PMC counters cannot be collected from inside the timed run, so this is the
+    figure of the last profiled run."""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_traffic.json")
     if not os.path.exists(path):
         return None
     with open(path) as f:
         rows = json.load(f)["kernels"]
+    tot = n = 0
     for name, v in rows.items():
-        if kernel in name and variant in name:
-            return round(v["hbm_bytes_per_launch"])
-    return None
+        if kernel in name and any(var in name for var in variants):
+            tot += v["hbm_bytes_total"]
+            n += v["launches"]
+    return round(tot / n) if n else None
 
 
 def launch_ranks(n: int) -> int:
@@ -363,9 +366,9 @@ def main():
                 print(f"  {kind:5s} {f / 1e9:9.1f} GF {nb / 1e6:8.1f} MB  x{len(ts) // a.steps:3d}/step  avg {sum(ts) / len(ts) * 1e3:8.1f} us  "
                       f"{f / (sum(ts) / len(ts)) / 1e9:7.1f} TF/s  total {sum(ts) / a.steps:7.2f} ms/step", file=sys.stderr)
         achieved = flops / (avg_ms * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": "gemm_big_kernel (csrc/gemm_big.h): 256x128x32 LDS-DMA MFMA GEMM, 8-phase 256x256x64 form for K >= 2048 (all dense GEMM launches of the step)",
+        roof = {"bound": "mfma", "kernel": "gemm_big_kernel (csrc/gemm_big.h): LDS-DMA MFMA GEMM on v_mfma_f32_16x16x32, 8-phase 256x256x64 form for the unbatched K >= 1024 launches, 256x128x32 two-workgroup form for the rest (all dense GEMM launches of the step)",
                 "achieved": round(achieved, 1), "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / MFMA_F16_DENSE_PEAK_TFLOPS, 4), "traffic": pmc_traffic("gemm_big_kernel", "Lb0ELb0ELi32ELi4E"),
+                "frac": round(achieved / MFMA_F16_DENSE_PEAK_TFLOPS, 4), "traffic": pmc_traffic("gemm_big_kernel", ("Lb0ELb0ELi32ELi4E", "Lb0ELb0ELi64ELi1ELb1E")),
                 "launches_per_step": n // a.steps, "avg_launch_ms": round(avg_ms, 4),
                 "gflop_per_launch": round(flops / 1e9, 2), "algorithmic_bytes_per_launch": round(alg_bytes),
                 "share_of_step_time": round(sum(t for _, t in dense) / a.steps / (elapsed / a.steps * 1e3), 3),
