@@ -532,7 +532,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_big_kernel(const asis_
           if (row < d.M && cok) {
             const float bm1 = bmv[q];
             v.x += b4.x + bm1; v.y += b4.y + bm1; v.z += b4.z + bm1; v.w += b4.w + bm1;
-            if (d.act == ASIS_ACT_GELU) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
+            if (d.act == ASIS_ACT_GELU) gelu_erf4(v.x, v.y, v.z, v.w);
             else if (has_aux) {  // input-gradient GEMM of fc2 fused with GELU's backward
               float g0, g1, g2, g3;
               unpack2<T>(pw[q].x, g0, g1);

@@ -171,7 +171,7 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const asis_gemm_de
         const float4 b4 = *reinterpret_cast<const float4*>(d.bias_n + col);
         v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
       }
-      if (ACT == ASIS_ACT_GELU) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
+      if (ACT == ASIS_ACT_GELU) gelu_erf4(v.x, v.y, v.z, v.w);
       if (d.scale_n) {
         const float4 s4 = *reinterpret_cast<const float4*>(d.scale_n + col);
         v.x *= s4.x; v.y *= s4.y; v.z *= s4.z; v.w *= s4.w;

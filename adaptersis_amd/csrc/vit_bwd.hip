@@ -348,7 +348,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void gelu_split_kernel(const float* __restrict__ x, T* __restrict__ hi, T* __restrict__ lo, int64_t n4) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
     const float4 v = reinterpret_cast<const float4*>(x)[i];
-    const float g0 = gelu_erf(v.x), g1 = gelu_erf(v.y), g2 = gelu_erf(v.z), g3 = gelu_erf(v.w);
+    float g0 = v.x, g1 = v.y, g2 = v.z, g3 = v.w;
+    gelu_erf4(g0, g1, g2, g3);
     uint2 h;
     h.x = pack2<T>(g0, g1); h.y = pack2<T>(g2, g3);
     reinterpret_cast<uint2*>(hi)[i] = h;
