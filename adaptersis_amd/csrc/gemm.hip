@@ -304,7 +304,8 @@ int launch(hipStream_t s, const asis_gemm_desc& d) {
     // ASIS_GEMM_8P_M16 (default 1): the phases issue 16 v_mfma_f32_16x16x32 instead of 8 32x32x16 (same FLOP, higher clock)
     static const int ph8_m16 = [] { const char* e = getenv("ASIS_GEMM_8P_M16"); return e ? atoi(e) : 1; }();
     if (ph8_m16) {
-      if (noepi) hipLaunchKernelGGL((gemm_big_kernel<T, 2, 4, 4, 2, 2, 4, false, false, 64, 1, true, true>), grid, block, 0, s, d, group_m);
+      if (noepi == 8) hipLaunchKernelGGL((gemm_big_kernel<T, 2, 4, 4, 2, 2, 8, false, false, 64, 1, true, true>), grid, block, 0, s, d, group_m);   // lab: no global stores
+      else if (noepi) hipLaunchKernelGGL((gemm_big_kernel<T, 2, 4, 4, 2, 2, 4, false, false, 64, 1, true, true>), grid, block, 0, s, d, group_m);
       else hipLaunchKernelGGL((gemm_big_kernel<T, 2, 4, 4, 2, 2, 0, false, false, 64, 1, true, true>), grid, block, 0, s, d, group_m);
       return 0;
     }
