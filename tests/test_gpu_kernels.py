@@ -239,3 +239,17 @@ def test_persistent_gemm_lab_form_matches(dev):
     for l in lines:
         err = float(l.split("rel-L2")[1].split()[0])
         assert "non-finite 0" in l and err < (1e-6 if l.startswith("proj") else 5e-4), l
+
+
+@pytest.mark.parametrize("env", [{"ASIS_GEMM_8P": "2"}, {"ASIS_GEMM_8P": "2", "ASIS_GEMM_8P_M16": "0"}, {"ASIS_GEMM_8P": "0"}])
+def test_every_dense_gemm_form_on_the_same_cases(dev, env):
+    """The dispatcher picks a form by shape; here each form is forced (own process: the switches are read once) onto
+    ragged / small / long-K cases with every epilogue variant (scripts/gemm_forms_probe.py): fp32 outputs to 3e-6, 16-bit
+    outputs to 9e-4."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "gemm_forms_probe.py")], env={**os.environ, **env},
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:] + r.stdout[-1000:]
+    worst = [l for l in r.stdout.splitlines() if l.startswith("worst")]
+    assert worst and float(worst[0].split()[1]) < 3e-6, r.stdout
