@@ -42,6 +42,11 @@ precise_attention = os.environ.get("ASIS_PRECISE", "0") not in ("0", "")
 # (engines.SegEngine._encoder_on_side_stream).  ASIS_ENC_STREAM=0: everything on the compute stream.
 encoder_stream = os.environ.get("ASIS_ENC_STREAM", "1") not in ("0", "")
 
+# The V^T GEMMs of a stacked attention (two batched, ragged launches of 672 tiles each = 1.3 rounds of the 512 tile slots) run
+# on a side HIP stream next to the q|k GEMM (8-phase form: 5.19 rounds of 256 tiles, i.e. a last round that leaves 81 % of the
+# CUs idle): the three launches fill each other's partial rounds (blocks.Attention.attend_rows).  ASIS_VT_STREAM=0: in order.
+vt_stream = os.environ.get("ASIS_VT_STREAM", "1") not in ("0", "")
+
 # Layers whose forward conv runs on plain 16-bit operands although split_conv is on (comma-separated stage keys: d1..d4 =
 # FeatureDecoder stages, stem3 / stem6 / conv2 / conv3 / conv4 = encoder): the lab switch behind DESIGN.md's per-layer table.
 unsplit_layers = set(filter(None, os.environ.get("ASIS_UNSPLIT", "").split(",")))

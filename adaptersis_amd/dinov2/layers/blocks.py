@@ -13,12 +13,25 @@ Data flow of one eval-mode block (`block.py:111-113`), residual stream fp32 [B*N
 """
 from __future__ import annotations
 
+import contextlib
+
 from typing import Callable, Optional, Tuple, Union
 
 import torch
 from torch import nn
 
 from ... import config, ops
+
+
+_VT_STREAMS = {}
+
+
+def _vt_side_stream(device) -> "torch.cuda.Stream":
+    """one side HIP stream per device for the V^T GEMMs of the stacked attention (``Attention.attend_rows``)"""
+    key = (device.type, device.index)
+    if key not in _VT_STREAMS:
+        _VT_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _VT_STREAMS[key]
 
 
 def _pack(cache: dict, key: str, param: torch.Tensor, fn: Callable[[torch.Tensor], torch.Tensor]):
@@ -190,11 +203,18 @@ class Attention(_Packed):
         w = self._w16("qkv", self.qkv.weight)  # [3D, D] rows q | k | v
         bias = self._f32("qkv_b", self.qkv.bias)
         wlo = self._w16lo("qkv", self.qkv.weight)
-        qk = ops.gemm(xn, w[: 2 * D], bias_n=None if bias is None else bias[: 2 * D], b_lo=None if wlo is None else wlo[: 2 * D])
         o = torch.empty((xn.shape[0], D), device=xn.device, dtype=xn.dtype)
         one_launch = len(segs) == 2
         ldv_all = (max(n for _, n in segs) + 63) // 64 * 64
         vt_all = torch.empty((sum(b for b, _ in segs), D, ldv_all), device=xn.device, dtype=xn.dtype) if one_launch else None
+        # stacked form: the V^T GEMMs go to a side stream, the q|k GEMM stays on the compute stream (config.vt_stream)
+        side = None
+        if one_launch and config.vt_stream and xn.is_cuda:
+            main = torch.cuda.current_stream()
+            side = _vt_side_stream(xn.device)
+            side.wait_stream(main)      # xn, and whatever read the recycled blocks of vt_all
+        else:
+            qk = ops.gemm(xn, w[: 2 * D], bias_n=None if bias is None else bias[: 2 * D], b_lo=None if wlo is None else wlo[: 2 * D])
         r0 = b0 = 0
         for B, N in segs:
             r1 = r0 + B * N
@@ -205,12 +225,16 @@ class Attention(_Packed):
             # are the first tokens of the next image (the last image reads the spare rows behind ``xn``)
             spare = xn.untyped_storage().nbytes() // xn.element_size() - (xn.storage_offset() + xn.shape[0] * D)
             N4 = (N + 3) // 4 * 4 if spare >= 4 * D else N
-            ops.gemm(w[2 * D:], xn[r0:r1].as_strided((B, N4, D), (N * D, D, 1)),
-                     out=vt.as_strided((B, D, N4), (D * ldvt, ldvt, 1)), bias_m=None if bias is None else bias[2 * D:],
-                     a_lo=None if wlo is None else wlo[2 * D:])
+            with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+                ops.gemm(w[2 * D:], xn[r0:r1].as_strided((B, N4, D), (N * D, D, 1)),
+                         out=vt.as_strided((B, D, N4), (D * ldvt, ldvt, 1)), bias_m=None if bias is None else bias[2 * D:],
+                         a_lo=None if wlo is None else wlo[2 * D:])
             if not one_launch:
                 ops.attention_fwd(qk[r0:r1, :D], qk[r0:r1, D:], vt, B, self.num_heads, N, self.scale, out=o[r0:r1])
             r0, b0 = r1, b0 + B
+        if side is not None:
+            qk = ops.gemm(xn, w[: 2 * D], bias_n=None if bias is None else bias[: 2 * D], b_lo=None if wlo is None else wlo[: 2 * D])
+            main.wait_stream(side)
         if one_launch:  # both token batches in one launch (fewer partial rounds of workgroups)
             (B1, N1), (B2, N2) = segs
             ops.attention_fwd_seg(qk[:, :D], qk[:, D:], vt_all, B1, N1, B2, N2, self.num_heads, self.scale, out=o)

@@ -343,10 +343,12 @@ def main():
     if prof is not None:
         ops.PROFILE = prof
         enc_stream, config.encoder_stream = config.encoder_stream, False   # one stream: a launch's event pair times that launch alone
+        vt_stream, config.vt_stream = config.vt_stream, False
         for _ in range(a.steps):
             eng.train_step(img, tgt)
         barrier()
         config.encoder_stream = enc_stream
+        config.vt_stream = vt_stream
         ops.PROFILE = None
 
     # ---- roofline of the dominant kernel: the dense MFMA GEMM (csrc/gemm_big.h) ---------------------------
