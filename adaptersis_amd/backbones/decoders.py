@@ -154,7 +154,8 @@ def conv_bn_relu_up_backward(owner: _Packed, key: str, st: _Stage, dU, conv: nn.
     ops.reduce_rows(local[C:].view(1, C), inv_scale, grads[bn_name + ".weight"])
     if conv.bias is not None:
         ops.reduce_rows(bpart, inv_scale, grads[conv_name + ".bias"])
-    ops.wgrad(dx16, st.x16, C, 3, 3, stride, pad, inv_scale, out=grads[conv_name + ".weight"])
+    wout = grads[conv_name + ".weight"]
+    parallel.wgrad_on_side_stream(lambda: ops.wgrad(dx16, st.x16, C, 3, 3, stride, pad, inv_scale, out=wout), dx16, st.x16)
     if not need_dx:
         return None
     if stride == 1:
@@ -202,6 +203,8 @@ class _DecoderFn(torch.autograd.Function):
         grads = {n: torch.empty_like(p) for n, p in m.named_parameters()}
         m._backward_core(ctx.saved, d16, None, 1.0 / S, grads, dlogits_f32=d, d_lo=d_lo)
         ctx.saved = None
+        if d16.is_cuda:
+            parallel.join_grad_streams()     # weight gradients computed on the side stream (config.wgrad_stream)
         return (None, None) + tuple(grads[n] for n in ctx.names)
 
 
@@ -263,7 +266,8 @@ class FeatureDecoder(_Packed):
             ops.reduce_rows(bias_partial, inv_scale, grads["final_out.bias"])
         else:  # compatibility path: column sums of the fp32 dlogits [P, C]
             ops.reduce_rows(dlogits_f32, 1.0, grads["final_out.bias"])
-        ops.wgrad(d16, x5, C, 3, 3, 1, 1, inv_scale, out=grads["final_out.weight"])
+        wout = grads["final_out.weight"]
+        parallel.wgrad_on_side_stream(lambda: ops.wgrad(d16, x5, C, 3, 3, 1, 1, inv_scale, out=wout), d16, x5)
         fo = self.final_out
         if fo.out_channels <= 8 and fo.in_channels <= 224:
             return ops.conv3x3_smallcout_dgrad(d16, d_lo, self._f32("final.wf", fo.weight))
@@ -341,6 +345,8 @@ class _SETRFFn(torch.autograd.Function):
         ctx.saved = None
         nchw = lambda t: None if t is None else (t * (1.0 / S)).permute(0, 3, 1, 2)
         dc = [nchw(t) if need else None for t, need in zip(dcs, ctx.needs_input_grad[2:5])]
+        if d16.is_cuda:
+            parallel.join_grad_streams()
         return (None, nchw(dx), dc[0], dc[1], dc[2]) + tuple(grads[n] for n in ctx.names)
 
 
@@ -458,6 +464,8 @@ class _MLAFn(torch.autograd.Function):
         grads = {n: torch.empty_like(p) for n, p in m.named_parameters()}
         m._backward_core(ctx.saved, d16, None, 1.0 / S, grads, dlogits_f32=d2, d_lo=d_lo)
         ctx.saved = None
+        if d16.is_cuda:
+            parallel.join_grad_streams()
         return (None, None, None, None, None) + tuple(grads[n] for n in ctx.names)
 
 

@@ -80,6 +80,8 @@ class _FuseFn(torch.autograd.Function):
         grads = {n: torch.empty_like(p) for n, p in m.named_parameters()}
         m._backward_core(ctx.saved, d16, None, 1.0 / S, grads, dlogits_f32=d, d_lo=d_lo)
         ctx.saved = None
+        if d16.is_cuda:
+            parallel.join_grad_streams()     # weight gradients computed on the side stream (config.wgrad_stream)
         return (None, None, None, None, None) + tuple(grads[n] for n in ctx.names)
 
 

@@ -47,6 +47,12 @@ encoder_stream = os.environ.get("ASIS_ENC_STREAM", "1") not in ("0", "")
 # CUs idle): the three launches fill each other's partial rounds (blocks.Attention.attend_rows).  ASIS_VT_STREAM=0: in order.
 vt_stream = os.environ.get("ASIS_VT_STREAM", "1") not in ("0", "")
 
+# Conv weight gradients of the decode heads run on a side HIP stream (parallel.grad_side_stream): nothing on the backward's
+# critical path reads them — only the gradient all-reduce and the optimizer, which wait for that stream
+# (StageReducer.stage_done / finish) — so they overlap the dgrad GEMMs and the memory-bound BatchNorm / upsample transposes of
+# the stages below.  ASIS_WGRAD_STREAM=0: in order on the compute stream.
+wgrad_stream = os.environ.get("ASIS_WGRAD_STREAM", "1") not in ("0", "")
+
 # Layers whose forward conv runs on plain 16-bit operands although split_conv is on (comma-separated stage keys: d1..d4 =
 # FeatureDecoder stages, stem3 / stem6 / conv2 / conv3 / conv4 = encoder): the lab switch behind DESIGN.md's per-layer table.
 unsplit_layers = set(filter(None, os.environ.get("ASIS_UNSPLIT", "").split(",")))

@@ -34,6 +34,45 @@ def collectives_on(group=None) -> bool:
     return dist.get_world_size(group) > 1 or FORCE_COLLECTIVES
 
 
+_GRAD_STREAMS = {}
+
+
+def grad_side_stream(device) -> "torch.cuda.Stream":
+    """The side stream on which parameter-gradient kernels that are off the backward's critical path run (config.wgrad_stream).
+    Everything that consumes gradients — StageReducer (all-reduce), the optimizer behind ``finish``, autograd bridges through
+    ``join_grad_streams`` — orders itself behind it."""
+    key = (device.type, device.index)
+    if key not in _GRAD_STREAMS:
+        _GRAD_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _GRAD_STREAMS[key]
+
+
+def join_grad_streams(stream=None) -> None:
+    """``stream`` (default: the current one) waits for every gradient side stream."""
+    if not _GRAD_STREAMS:
+        return
+    stream = stream if stream is not None else torch.cuda.current_stream()
+    for s in _GRAD_STREAMS.values():
+        stream.wait_stream(s)
+
+
+def wgrad_on_side_stream(fn, *tensors) -> None:
+    """Run ``fn()`` (a weight-gradient launch reading ``tensors``) on the gradient side stream when ``config.wgrad_stream`` is on
+    and the operands live on a GPU, else in place.  The side stream first waits for the compute stream (the operands), and the
+    operands are recorded on it so that the caching allocator does not hand their memory out before the launch has read it."""
+    from . import config
+    t0 = tensors[0]
+    if not (config.wgrad_stream and t0.is_cuda):
+        fn()
+        return
+    side = grad_side_stream(t0.device)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fn()
+    for t in tensors:
+        t.record_stream(side)
+
+
 class StageReducer:
     def __init__(self, flat_grad: torch.Tensor, ranges: Sequence[Tuple[int, int]], group=None):
         self.flat, self.ranges, self.group = flat_grad, list(ranges), group
@@ -58,6 +97,7 @@ class StageReducer:
             ev = torch.cuda.Event()
             ev.record()
             self._stream.wait_event(ev)
+            join_grad_streams(self._stream)      # weight gradients of this stage enqueued on the side stream
             with torch.cuda.stream(self._stream):
                 dist.all_reduce(chunk, group=self.group)
         else:  # CPU tensors (gloo): asynchronous work handles
@@ -68,5 +108,7 @@ class StageReducer:
         assert self._next == len(self.ranges), "not every stage was reduced"
         for h in self._handles:
             h.wait()
+        if self.flat.is_cuda:
+            join_grad_streams()
         if self._stream is not None:
             torch.cuda.current_stream().wait_stream(self._stream)
