@@ -304,10 +304,13 @@ int launch(hipStream_t s, const asis_gemm_desc& d) {
     dim3 grid(((d.M + 255) / 256) * ((d.N + 255) / 256), d.batch), block(512);
     // ASIS_GEMM_8P_M16 (default 1): the phases issue 16 v_mfma_f32_16x16x32 instead of 8 32x32x16 (same FLOP, higher clock)
     static const int ph8_m16 = [] { const char* e = getenv("ASIS_GEMM_8P_M16"); return e ? atoi(e) : 1; }();
+    // ASIS_GEMM_8P_SLAB32=1 (lab): 16-bit outputs through the fp32 slab epilogue like the others
+    static const int ph8_slab32 = [] { const char* e = getenv("ASIS_GEMM_8P_SLAB32"); return e ? atoi(e) : 0; }();
+    const int group_m_f = group_m | (ph8_slab32 ? 0x10000 : 0);
     if (ph8_m16) {
       if (noepi == 8) hipLaunchKernelGGL((gemm_big_kernel<T, 2, 4, 4, 2, 2, 8, false, false, 64, 1, true, true>), grid, block, 0, s, d, group_m);   // lab: no global stores
       else if (noepi) hipLaunchKernelGGL((gemm_big_kernel<T, 2, 4, 4, 2, 2, 4, false, false, 64, 1, true, true>), grid, block, 0, s, d, group_m);
-      else hipLaunchKernelGGL((gemm_big_kernel<T, 2, 4, 4, 2, 2, 0, false, false, 64, 1, true, true>), grid, block, 0, s, d, group_m);
+      else hipLaunchKernelGGL((gemm_big_kernel<T, 2, 4, 4, 2, 2, 0, false, false, 64, 1, true, true>), grid, block, 0, s, d, group_m_f);
       return 0;
     }
     if (noepi) hipLaunchKernelGGL((gemm_big_kernel<T, 2, 4, 4, 2, 2, 4, false, false, 64, 1, true>), grid, block, 0, s, d, group_m);

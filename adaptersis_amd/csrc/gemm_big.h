@@ -18,7 +18,8 @@ __device__ __attribute__((aligned(16))) uint4 g_zero_page[1];
 
 template <typename T, int WM, int WN, int TM, int TN, int NS, int DBG = 0, bool CONV = false, bool SPLIT = false, int BKT = 64,
           int OCC = 2, bool PH8 = false, bool M16 = false>
-__global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_big_kernel(const asis_gemm_desc d, const int GROUP_M) {
+__global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_big_kernel(const asis_gemm_desc d, const int GROUP_M_FLAGS) {
+  const int GROUP_M = GROUP_M_FLAGS & 0xffff;        // raster group height; bit 16 (lab): fp32 slab epilogue for every output type
   static_assert(!PH8 || (WM == 2 && WN == 4 && TM == 4 && TN == 2 && NS == 2 && BKT == 64),
                 "the 8-phase main loop is written for the 256x256x64 tile, 2x4 waves of 128x64");
   // M16: the wave tile is built from v_mfma_f32_16x16x32 (one K = 32 step per MFMA) instead of 32x32x16: same FLOP per
@@ -457,6 +458,53 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_big_kernel(const asis_
                    ((reinterpret_cast<uintptr_t>(d.C) & 15) == 0) && (!res || (reinterpret_cast<uintptr_t>(res) & 15) == 0) &&
                    (!d.bias_n || (reinterpret_cast<uintptr_t>(d.bias_n) & 15) == 0) &&
                    (!d.scale_n || (reinterpret_cast<uintptr_t>(d.scale_n) & 15) == 0);
+  if constexpr (M16 && PH8) {
+    // 16-bit outputs without residual / statistics (q|k, fc1 + GELU): bias and activation are applied in the accumulator
+    // layout (a lane owns 4 consecutive columns of one row), the result is converted to 16 bits BEFORE the LDS transposition
+    // (half the slab bytes: 8-byte writes, 16-byte reads) and leaves as 16-byte stores, 8 rows x 128 bytes per instruction —
+    // half as many, twice as wide as the fp32 slab path's.  This form's epilogue is fully exposed (one workgroup per CU).
+    if (vec && !d.out_f32 && !res && !d.stats && !d.bias_m && !d.scale_n && d.act != ASIS_ACT_GELU_GRAD && !(DBG & 8) &&
+        (d.N & 7) == 0 && (d.ldc & 7) == 0 && (cbase & 7) == 0 && !(GROUP_M_FLAGS >> 16)) {
+      constexpr int SW16 = TN * 32 + 8;                 // slab row in 16-bit elements (144 bytes: conflict-free 8-byte writes)
+      __syncthreads();                                  // every wave is done with the staging buffers
+      T* slab16 = reinterpret_cast<T*>(lds) + wid * (32 * SW16);
+      const int r16 = lane & 15, q16 = lane >> 4;
+      const int rr8 = lane >> 3, c8 = lane & 7;
+      float4 bj[TN * 2];
+#pragma unroll
+      for (int j = 0; j < TN * 2; ++j) {
+        const int colj = n0 + (wn * TN * 2 + j) * 16 + 4 * q16;
+        bj[j] = (d.bias_n && kt_base == 0 && colj < d.N) ? *reinterpret_cast<const float4*>(d.bias_n + colj) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      const int colr = n0 + wn * TN * 32 + c8 * 8;
+      const bool cokr = colr < d.N;
+      T* const Cw = reinterpret_cast<T*>(d.C) + cbase + colr;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+          for (int j = 0; j < TN * 2; ++j) {
+            float4 v = make_float4(acc16[2 * i + ii][j][0] + bj[j].x, acc16[2 * i + ii][j][1] + bj[j].y,
+                                   acc16[2 * i + ii][j][2] + bj[j].z, acc16[2 * i + ii][j][3] + bj[j].w);
+            if (d.act == ASIS_ACT_GELU) gelu_erf4(v.x, v.y, v.z, v.w);
+            else if (d.act == ASIS_ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            uint2 pk;
+            pk.x = pack2<T>(v.x, v.y);
+            pk.y = pack2<T>(v.z, v.w);
+            *reinterpret_cast<uint2*>(slab16 + (ii * 16 + r16) * SW16 + 16 * j + 4 * q16) = pk;
+          }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const int lrow = p * 8 + rr8;
+          const int row = m0 + (wm * TM + i) * 32 + lrow;
+          const uint4 w = *reinterpret_cast<const uint4*>(slab16 + lrow * SW16 + c8 * 8);
+          if (row < d.M && cokr) *reinterpret_cast<uint4*>(Cw + (int64_t)row * d.ldc) = w;
+        }
+      }
+      return;
+    }
+  }
   if (vec) {
     // Transpose each 32 x (TN*32) slab of the wave tile through a private LDS slab so that global
     // accesses are full lines: TN*8 consecutive lanes cover one row (16 B = 4 columns per lane).
