@@ -265,7 +265,8 @@ int launch(hipStream_t s, const asis_gemm_desc& d) {
   // ASIS_GEMM_8P: 0 = never; 1 (default) = K >= 2048 (fc2 / its input gradient: 343 vs 476 us at 42348x1024x4096) and,
   // since the phases run on 16x16x32 MFMAs (ASIS_GEMM_8P_M16: fc2 391 -> 350 us in isolation), the unbatched K >= 1024
   // GEMMs too (in the step: qk 222 -> 214 us, proj 160 -> 139, fc1 457 -> 441, adapter projections 242 -> 216; +3.5 % on the
-  // step) — the batched ragged V^T GEMM stays on the two-workgroup form (66 vs 72 us: coarser tile quantisation);
+  // step) — the batched ragged V^T GEMM lost there at first (66 vs 72 us: coarser tile quantisation) and wins since the form's
+  // 16-bit outputs are converted before the LDS transposition (+0.9 % on the step);
   // (only when there are at least 128 of its 256x256 tiles: a launch that cannot fill the chip is better off with twice as
   // many 256x128 tiles); 3 = K >= 2048 only (the round-1 rule); 2 = wherever the shape allows
   static const int ph8 = [] { const char* e = getenv("ASIS_GEMM_8P"); return e ? atoi(e) : 1; }();
@@ -299,7 +300,7 @@ int launch(hipStream_t s, const asis_gemm_desc& d) {
     if (!gelu && !res && o32) { PERSIST(ASIS_ACT_NONE, false, true); return 0; }
 #undef PERSIST
   }
-  if (ph8 && (ph8 == 2 || d.K >= 2048 || (ph8 == 1 && d.K >= ph8_mink && d.batch == 1 && ((d.M + 255) / 256) * ((d.N + 255) / 256) >= 128)) && big_mode && !d.conv && !d.stats && d.K % 64 == 0 && d.M >= 256 && d.N >= 256) {
+  if (ph8 && (ph8 == 2 || d.K >= 2048 || (ph8 == 1 && d.K >= ph8_mink && (int64_t)((d.M + 255) / 256) * ((d.N + 255) / 256) * d.batch >= 128)) && big_mode && !d.conv && !d.stats && d.K % 64 == 0 && d.M >= 256 && d.N >= 256) {
     // 256x256x64 tile, 8-phase main loop (one workgroup per CU: 128 KB of LDS)
     dim3 grid(((d.M + 255) / 256) * ((d.N + 255) / 256), d.batch), block(512);
     // ASIS_GEMM_8P_M16 (default 1): the phases issue 16 v_mfma_f32_16x16x32 instead of 8 32x32x16 (same FLOP, higher clock)

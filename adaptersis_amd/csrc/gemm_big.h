@@ -463,7 +463,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_big_kernel(const asis_
     // layout (a lane owns 4 consecutive columns of one row), the result is converted to 16 bits BEFORE the LDS transposition
     // (half the slab bytes: 8-byte writes, 16-byte reads) and leaves as 16-byte stores, 8 rows x 128 bytes per instruction —
     // half as many, twice as wide as the fp32 slab path's.  This form's epilogue is fully exposed (one workgroup per CU).
-    if (vec && !d.out_f32 && !res && !d.stats && !d.bias_m && !d.scale_n && d.act != ASIS_ACT_GELU_GRAD && !(DBG & 8) &&
+    if (vec && !d.out_f32 && !res && !d.stats && !d.scale_n && d.act != ASIS_ACT_GELU_GRAD && !(DBG & 8) &&
         (d.N & 7) == 0 && (d.ldc & 7) == 0 && (cbase & 7) == 0 && !(GROUP_M_FLAGS >> 16)) {
       constexpr int SW16 = TN * 32 + 8;                 // slab row in 16-bit elements (144 bytes: conflict-free 8-byte writes)
       __syncthreads();                                  // every wave is done with the staging buffers
@@ -482,11 +482,16 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_big_kernel(const asis_
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
 #pragma unroll
-        for (int ii = 0; ii < 2; ++ii)
+        for (int ii = 0; ii < 2; ++ii) {
+          float bm1 = 0.f;
+          if (d.bias_m) {   // per-row bias (the V^T GEMM: rows are the output features)
+            const int rowb = m0 + (wm * TM + i) * 32 + ii * 16 + r16;
+            bm1 = d.bias_m[rowb < d.M ? rowb : d.M - 1];
+          }
 #pragma unroll
           for (int j = 0; j < TN * 2; ++j) {
-            float4 v = make_float4(acc16[2 * i + ii][j][0] + bj[j].x, acc16[2 * i + ii][j][1] + bj[j].y,
-                                   acc16[2 * i + ii][j][2] + bj[j].z, acc16[2 * i + ii][j][3] + bj[j].w);
+            float4 v = make_float4(acc16[2 * i + ii][j][0] + bj[j].x + bm1, acc16[2 * i + ii][j][1] + bj[j].y + bm1,
+                                   acc16[2 * i + ii][j][2] + bj[j].z + bm1, acc16[2 * i + ii][j][3] + bj[j].w + bm1);
             if (d.act == ASIS_ACT_GELU) gelu_erf4(v.x, v.y, v.z, v.w);
             else if (d.act == ASIS_ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
             uint2 pk;
@@ -494,6 +499,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_big_kernel(const asis_
             pk.y = pack2<T>(v.z, v.w);
             *reinterpret_cast<uint2*>(slab16 + (ii * 16 + r16) * SW16 + 16 * j + 4 * q16) = pk;
           }
+        }
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
           const int lrow = p * 8 + rr8;
