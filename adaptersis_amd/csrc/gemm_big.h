@@ -9,7 +9,9 @@ namespace {
 // K tile.  The 128^2 register-staged kernel above is latency/inflow bound (~10 B/clk/CU reach the CU
 // while one 32 KB tile per workgroup is in flight: 64 FLOP/B x 10 B/clk = ~15 % of the MFMA peak,
 // which is what it measures); this kernel doubles the FLOP per staged byte and keeps 2 tiles
-// (96-128 KB per CU) in flight.  LDS image = the same XOR-swizzled 128-B rows; since LDS-DMA writes
+// (96-128 KB per CU) in flight.  Forms in production (gemm.hip): PH8 + M16 = the 8-phase 256x256x64 main loop on 16x16x32 MFMAs
+// (every K >= 1024 GEMM with >= 128 tiles, wide convolutions; 16-bit outputs leave through a 16-bit LDS slab), the
+// 256x128x32 two-workgroup form for the rest.  LDS image = the same XOR-swizzled 128-B rows; since LDS-DMA writes
 // lane-linear (base + lane*16) the swizzle is applied to the per-lane SOURCE address instead
 // (cdna_hip_programming.md rule 21).  Rows/cols beyond M/N are clamped on load and masked on store.
 // ------------------------------------------------------------------------------------------------
@@ -195,7 +197,8 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_big_kernel(const asis_
   const int nt = nparts * nt1;
   const int fr = lane & 31, fh = lane >> 5;
   if constexpr (PH8) {
-    // ---- 8-phase main loop (cdna_hip_programming.md "The 256^2 8-phase template", re-derived for 32x32x16 MFMAs and
+    // ---- 8-phase main loop (cdna_hip_programming.md "The 256^2 8-phase template", re-derived for 32x32x16 MFMAs — M16: 16
+    // v_mfma_f32_16x16x32 per phase instead of 8 of 32x32x16, the production form since round 2: higher sustained clock — and
     // this kernel's C^T accumulators).  A K tile is consumed in four phases, one 64x32 quadrant of the wave's 128x64
     // tile each: (rows 0, cols 0) (rows 0, cols 1) (rows 1, cols 1) (rows 1, cols 0).  A phase is
     //     [LDS reads of the fragments this phase adds | 2 LDS-DMA instructions of the NEXT K tile | counted vmcnt]
