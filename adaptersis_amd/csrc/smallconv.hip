@@ -9,6 +9,8 @@
 namespace {
 
 constexpr int MAXCO = 16;
+// 16 zero bytes: LDS-DMA source of halo pixels outside the image / of the absent lo half
+__device__ __attribute__((aligned(16))) uint4 g_zero_page_sc[1];
 
 template <typename T>
 __device__ __forceinline__ void load8(const T* p, float* f) {
@@ -77,6 +79,93 @@ __global__ __launch_bounds__(256) void smallcout_fwd_kernel(const T* __restrict_
       for (int c = 0; c < CO; ++c) acc[c] += __shfl_xor(acc[c], o, 64);
     if (c8 == 0)
       for (int c = 0; c < Cout; ++c) out[p * Cout + c] = acc[c] + (bias ? bias[c] : 0.f);
+  }
+}
+
+// ---- forward, LDS-tiled form for the 64-channel classifier conv with <= 2 classes ------------------------------------------
+// The direct form above reads every input pixel nine times (once per tap) through L1 / L2 and runs at the L2's speed
+// (1.4 TB/s of algorithmic bytes for the 64 -> 2 conv at 12 x 672^2).  Here a workgroup stages the (8+2) x (16+2) halo of an
+// 8 x 16 output tile ONCE (LDS-DMA, hi and lo halves side by side: 256 B per pixel, 45 KiB, the halves swapped on odd pixels
+// so that the 16-byte reads of two neighbouring pixels hit disjoint banks; pixels outside the image come from the zero page)
+// and the nine taps read LDS.  thread = (pixel slot, 8-channel chunk) as above; the 9 x 8 x 2 weights of the thread's chunk
+// live in registers for the workgroup's whole (grid-strided) run of tiles.
+template <typename T>
+__global__ __launch_bounds__(256, 2) void smallcout_fwd_tiled_kernel(const T* __restrict__ xh, const T* __restrict__ xl,
+                                                                     const float* __restrict__ w, const float* __restrict__ bias,
+                                                                     float* __restrict__ out, int B, int H, int W, int Cout) {
+  constexpr int CIN = 64, TY = 8, TX = 16, HY = TY + 2, HX = TX + 2, NPIX = HY * HX;   // 180 halo pixels
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  typedef const __attribute__((address_space(1))) void* glb_ptr;
+  __shared__ __attribute__((aligned(16))) T tile[NPIX * 2 * CIN];   // [pixel][hi | lo (swapped on odd pixels)][64]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c8 = tid & 7, slot = tid >> 3;                           // chunk of 8 channels, pixel slot 0..31
+  float wr[9][8][2];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) wr[t][e][c] = c < Cout ? w[((int64_t)c * CIN + c8 * 8 + e) * 9 + t] : 0.f;
+  const float b0 = bias ? bias[0] : 0.f, b1 = (bias && Cout > 1) ? bias[1] : 0.f;
+  const int tiles_x = (W + TX - 1) / TX, tiles_y = (H + TY - 1) / TY;
+  const int ntiles = B * tiles_y * tiles_x;
+  const T* const zp = reinterpret_cast<const T*>(g_zero_page_sc);
+  // DMA lane map: one instruction = 4 halo pixels x (hi | lo) x 8 chunks
+  const int dp = lane >> 4, dhalf = (lane >> 3) & 1, dch = lane & 7;
+  for (int tl = xcd_remap(blockIdx.x, gridDim.x); tl < ntiles; tl += gridDim.x) {
+    const int tx = tl % tiles_x, ty = (tl / tiles_x) % tiles_y, b = tl / (tiles_x * tiles_y);
+    const int y0 = ty * TY - 1, x0 = tx * TX - 1;
+    for (int g = wid; g * 4 < NPIX; g += 4) {       // 45 groups of 4 pixels over the 4 waves
+      const int hp = g * 4 + dp;                    // halo pixel of this lane (NPIX is a multiple of 4)
+      const int hy = hp / HX, hx = hp - hy * HX;
+      const int yy = y0 + hy, xx = x0 + hx;
+      const bool in = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+      const bool want_lo = (dhalf ^ (hp & 1)) != 0;
+      const T* src = zp;
+      if (in && (!want_lo || xl)) src = (want_lo ? xl : xh) + (((int64_t)b * H + yy) * W + xx) * CIN + dch * 8;
+      __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(tile + g * 4 * 2 * CIN), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int pix = k * 32 + slot;
+      const int py = pix / TX, px = pix - py * TX;
+      float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int t = kh * 3 + kw;
+          const int hp = (py + kh) * HX + px + kw;
+          const T* base = tile + hp * 2 * CIN + c8 * 8;
+          const int sw = (hp & 1) * CIN;
+          const uint4 rh = *reinterpret_cast<const uint4*>(base + sw);
+          const uint4 rl = *reinterpret_cast<const uint4*>(base + (CIN - sw));
+          float f[8], gl[8];
+          unpack2<T>(rh.x, f[0], f[1]); unpack2<T>(rh.y, f[2], f[3]); unpack2<T>(rh.z, f[4], f[5]); unpack2<T>(rh.w, f[6], f[7]);
+          unpack2<T>(rl.x, gl[0], gl[1]); unpack2<T>(rl.y, gl[2], gl[3]); unpack2<T>(rl.z, gl[4], gl[5]); unpack2<T>(rl.w, gl[6], gl[7]);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float v = f[e] + gl[e];
+            a0 += v * wr[t][e][0];
+            a1 += v * wr[t][e][1];
+          }
+        }
+#pragma unroll
+      for (int o = 1; o < 8; o <<= 1) {
+        a0 += __shfl_xor(a0, o, 64);
+        a1 += __shfl_xor(a1, o, 64);
+      }
+      const int oy = ty * TY + py, ox = tx * TX + px;
+      if (c8 == 0 && oy < H && ox < W) {
+        float* o = out + (((int64_t)b * H + oy) * W + ox) * Cout;
+        o[0] = a0 + b0;
+        if (Cout > 1) o[1] = a1 + b1;
+      }
+    }
+    __syncthreads();   // the tile is overwritten by the next DMA
   }
 }
 
@@ -244,6 +333,13 @@ int launch_fwd(hipStream_t s, const void* xh, const void* xl, const float* w, co
   const int64_t total = (int64_t)B * H * W * (Cin / 8);
   const T* a = reinterpret_cast<const T*>(xh);
   const T* b = reinterpret_cast<const T*>(xl);
+  // ASIS_SMALLCOUT_TILED (default 1): the LDS-tiled form for the 64 -> (1 | 2) conv on maps of at least one tile
+  static const int tiled = [] { const char* e = getenv("ASIS_SMALLCOUT_TILED"); return e ? atoi(e) : 1; }();
+  if (tiled && Cin == 64 && Cout <= 2 && H >= 8 && W >= 16) {
+    const int ntiles = B * ((H + 7) / 8) * ((W + 15) / 16);
+    hipLaunchKernelGGL((smallcout_fwd_tiled_kernel<T>), dim3(ntiles < 512 ? ntiles : 512), dim3(256), 0, s, a, b, w, bias, out, B, H, W, Cout);
+    return 0;
+  }
 #define FWD(CO)                                                                                                    \
   hipLaunchKernelGGL((smallcout_fwd_kernel<T, CO>), dim3(grid_for(total)), dim3(256), 9 * Cin * CO * sizeof(float), s, \
                      a, b, w, bias, out, B, H, W, Cin, Cout)
