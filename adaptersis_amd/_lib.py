@@ -74,6 +74,7 @@ SIGNATURES = {
     "asis_device_count": [],
     "asis_gemm": [_vp, C.POINTER(GemmDesc)],
     "asis_gemm_tiles_m": [_i],
+    "asis_gemm_set_option": [C.c_char_p, _i],
     "asis_layernorm": [_vp, _i, _vp, _i64, _vp, _vp, _f, _vp, _i64, _i, _i64, _i],
     "asis_attention_fwd_seg": [_vp, _i, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _f, _vp],
     "asis_attention_fwd_lse": [_vp, _i, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _i, _f, _vp],

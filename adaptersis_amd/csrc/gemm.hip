@@ -208,6 +208,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const asis_gemm_desc 
 
 #include "gemm_big.h"
 #include "gemm_persist.h"
+#include "gemm_p8.h"
+
+// ASIS_GEMM_P8 / asis_gemm_set_option("p8", v): -1 = not read yet
+static int g_gemm_p8 = -1;
+static bool ph8_m16_on() { static const int v = [] { const char* e = getenv("ASIS_GEMM_8P_M16"); return e ? atoi(e) : 1; }(); return v != 0; }
 
 template <typename T>
 int launch(hipStream_t s, const asis_gemm_desc& d) {
@@ -301,6 +306,22 @@ int launch(hipStream_t s, const asis_gemm_desc& d) {
 #undef PERSIST
   }
   if (ph8 && (ph8 == 2 || d.K >= 2048 || (ph8 == 1 && d.K >= ph8_mink && (int64_t)((d.M + 255) / 256) * ((d.N + 255) / 256) * d.batch >= 128)) && big_mode && !d.conv && !d.stats && d.K % 64 == 0 && d.M >= 256 && d.N >= 256) {
+    // ASIS_GEMM_P8 (default 1): launches with at least one tile per CU run on the PERSISTENT form of the 8-phase kernel
+    // (gemm_p8.h: one workgroup per CU walks its tiles, the next tile's first K tile is staged during the last K tile of
+    // the current one, the epilogue's stores drain under the next tile); 2 = from 16 tiles on (tests); 0 = never
+    if (g_gemm_p8 < 0) { const char* e = getenv("ASIS_GEMM_P8"); g_gemm_p8 = e ? atoi(e) : 1; }
+    const int p8 = g_gemm_p8;
+    const int64_t p8_tiles = (int64_t)((d.M + 255) / 256) * ((d.N + 255) / 256);
+    auto al = [](const void* p, int a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; };
+    if (p8 && ph8_m16_on() && d.batch == 1 && !d.bias_m && p8_tiles >= (p8 == 2 ? 16 : 256) && d.K >= 128 &&
+        (int64_t)d.M * d.lda * 2 < (1ll << 32) && (int64_t)d.N * d.ldb * 2 < (1ll << 32) && d.N % 8 == 0 && d.ldc % 8 == 0 &&
+        al(d.C, 16) && (!d.res || (al(d.res, 16) && d.ldr % 4 == 0)) && (!d.bias_n || al(d.bias_n, 16)) && (!d.scale_n || al(d.scale_n, 16)) &&
+        (d.act != ASIS_ACT_GELU_GRAD || (d.aux && al(d.aux, 8) && d.ld_aux % 4 == 0))) {
+      const int nwg = p8_tiles >= 256 ? 256 : (int)(p8_tiles / 8) * 8;
+      if (noepi) hipLaunchKernelGGL((gemm_p8_kernel<T, 1>), dim3(nwg), dim3(512), 0, s, d, group_m);
+      else hipLaunchKernelGGL((gemm_p8_kernel<T, 0>), dim3(nwg), dim3(512), 0, s, d, group_m);
+      return 0;
+    }
     // 256x256x64 tile, 8-phase main loop (one workgroup per CU: 128 KB of LDS)
     dim3 grid(((d.M + 255) / 256) * ((d.N + 255) / 256), d.batch), block(512);
     // ASIS_GEMM_8P_M16 (default 1): the phases issue 16 v_mfma_f32_16x16x32 instead of 8 32x32x16 (same FLOP, higher clock)
@@ -367,6 +388,12 @@ int launch(hipStream_t s, const asis_gemm_desc& d) {
 }  // namespace
 
 extern "C" int asis_gemm_tiles_m(int M) { return (M + BM - 1) / BM; }
+
+extern "C" int asis_gemm_set_option(const char* name, int value) {
+  ASIS_REQUIRE(name != nullptr, "asis_gemm_set_option: null name");
+  if (strcmp(name, "p8") == 0) { g_gemm_p8 = value; return ASIS_OK; }
+  ASIS_FAIL(ASIS_EINVAL, "asis_gemm_set_option: unknown option '%s'", name);
+}
 
 extern "C" int asis_gemm(void* stream, const asis_gemm_desc* dp) {
   ASIS_REQUIRE(dp != nullptr, "asis_gemm: null descriptor");

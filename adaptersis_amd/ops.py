@@ -134,6 +134,11 @@ def gemm_tiles_m(M: int) -> int:
     return lib().asis_gemm_tiles_m(int(M))
 
 
+def gemm_set_option(name: str, value: int) -> None:
+    """Run-time dispatch switch of ``asis_gemm`` (``"p8"``: the persistent 8-phase form, include/asis_hip.h)."""
+    check(lib().asis_gemm_set_option(name.encode(), int(value)), "asis_gemm_set_option")
+
+
 def conv_gemm(x_nhwc: torch.Tensor, w_packed: torch.Tensor, KH: int, KW: int, stride: int, pad: int, *,
               out: Optional[torch.Tensor] = None, out_f32: bool = True, bias_n: Optional[torch.Tensor] = None,
               act: int = ACT_NONE, stats: Optional[torch.Tensor] = None, accumulate: bool = False,

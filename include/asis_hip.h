@@ -110,6 +110,10 @@ typedef struct asis_gemm_desc {
 int asis_gemm(void* stream, const asis_gemm_desc* d);
 /* number of M tiles asis_gemm uses for M rows (size of the stats buffer = tiles*2*N floats) */
 int asis_gemm_tiles_m(int M);
+/* run-time dispatch switches of asis_gemm (same meaning as the environment variable read at first use):
+ *   "p8" (ASIS_GEMM_P8): 1 = dense launches with at least one 256x256 tile per CU run on the persistent 8-phase kernel
+ *   (csrc/gemm_p8.h), 2 = from 16 tiles on, 0 = never (one workgroup per tile, csrc/gemm_big.h).  Unknown name: ASIS_EINVAL. */
+int asis_gemm_set_option(const char* name, int value);
 
 /* ---------------------------------------------------------------------------------------------
  * LayerNorm over the last dim, fp32 statistics, eps inside sqrt, biased variance

@@ -819,14 +819,14 @@ def ref_unet_wide(R, C, n_classes):
     return UNetWide()
 
 
-def c2_case(R, out, arch="vit_base_d4", batch=2, tag="c2"):
+def c2_case(R, out, arch="vit_base_d4", batch=2, tag="c2", mode="kernel"):
     """BASELINE config 2 at full WIDTH (ViT-B: D = 768, 12 heads, MSDA head dim 96; depth reduced to 4 blocks), 588x588,
     batch 2: `train.py:275-387` adapter flow with the imported reference ViT / FeatureEncoder / CAViT / CACNN at dim 768,
     adapter-stream map -> UNet(768) assembled from the reference's own parts -> resize -> CE + DC(2)
     (`eval/eval_dinov2_unet.py:286-297`), gradients of every UNet parameter."""
     import torch.nn.functional as F
     D, depth, heads, _ = W.VIT_CONFIGS[arch]
-    model, enc, cv, cn, (vsd, esd, csd, nsd) = _ref_adapter_modules(R, arch, "kernel")
+    model, enc, cv, cn, (vsd, esd, csd, nsd) = _ref_adapter_modules(R, arch, mode)
     usd = W.make_unet_state_dict(D, 2)
     u = ref_unet_wide(R, D, 2)
     u.load_state_dict(usd, strict=True)
@@ -862,13 +862,13 @@ def c2_case(R, out, arch="vit_base_d4", batch=2, tag="c2"):
         out[f"{tag}.grad.{k}"] = sub(p.grad, 3000)
 
 
-def c5_case(R, out, arch="vit_giant2_d4", batch=2, tag="c5", ncls=11):
+def c5_case(R, out, arch="vit_giant2_d4", batch=2, tag="c5", ncls=11, mode="kernel"):
     """BASELINE config 5 at full WIDTH (ViT-g: D = 1536, 24 heads, SwiGLU 8192 -> 4096, MSDA head dim 192; 4 blocks),
     588x588, batch 2, 11 classes: `train_mla.py:266-383` flow with the imported reference modules, the reference DecoderMLA
     with its classifier conv re-made for 11 classes (`decoders.py:59` forces 2), softmax -> the reference's
     ``iou_loss(num_classes=11)`` (`train_multi_class.py:391-393`), gradients of every decoder parameter."""
     D, depth, heads, _ = W.VIT_CONFIGS[arch]
-    model, enc, cv, cn, (vsd, esd, csd, nsd) = _ref_adapter_modules(R, arch, "kernel")
+    model, enc, cv, cn, (vsd, esd, csd, nsd) = _ref_adapter_modules(R, arch, mode)
     dsd = W.make_decoder_mla_state_dict(D, 128, ncls)
     dec = R["DecoderMLA"](img_size=588, mla_channels=D, mlahead_channels=128)
     dec.cls_3 = torch.nn.Conv2d(64, ncls, 3, padding=1)
@@ -919,7 +919,7 @@ def c5_case(R, out, arch="vit_giant2_d4", batch=2, tag="c5", ncls=11):
         out[f"{tag}.grad.{k}"] = sub(p.grad, 3000)
 
 
-def c4_case(R, out, arch="vit_large_d4", batch=1, tag="c4"):
+def c4_case(R, out, arch="vit_large_d4", batch=1, tag="c4", mode="kernel", grad_elems=3000):
     """BASELINE config 4: the `train.py:268-436` adapter flow with the backbone UNFROZEN — its no_grad /
     inference_mode regions (`:287,300-302,389-406`) removed, as `eval/eval_dinov2_setr_cross_ete.py:145-148,307-361` does
     for its own flow — run with the imported reference modules under autograd at ViT-L width (4 blocks), 588x588.
@@ -938,7 +938,7 @@ def c4_case(R, out, arch="vit_large_d4", batch=1, tag="c4"):
     orig = msda_mod.MSDeformAttnFunction
     msda_mod.MSDeformAttnFunction = _Differentiable
     try:
-        model, enc, cv, cn, (vsd, esd, csd, nsd) = _ref_adapter_modules(R, arch, "kernel")
+        model, enc, cv, cn, (vsd, esd, csd, nsd) = _ref_adapter_modules(R, arch, mode)
         model.train()   # eval_dinov2_setr_cross_ete.py:308; drop_path 0: same maths
         dsd = W.make_feature_decoder_state_dict(D, 2, features=(D, 512, 256, 128, 64))
         dec = R["FeatureDecoder"](embed_dim=D, num_classes=2, features=[D, 512, 256, 128, 64]); dec.load_state_dict(dsd)
@@ -981,7 +981,7 @@ def c4_case(R, out, arch="vit_large_d4", batch=1, tag="c4"):
             err = float((og.double() - p_.grad.double()).norm() / p_.grad.double().norm())
             worst = max(worst, err)
             assert err < 5e-3, (pre + k, err)
-            out[f"{tag}.grad.{pre}{k}"] = sub(p_.grad, 3000)
+            out[f"{tag}.grad.{pre}{k}"] = sub(p_.grad, grad_elems)
             n += 1
         print(f"  {pre:18s} {n} parameter gradients stored")
     print(f"  oracle vs reference gradients: worst rel-L2 {worst:.2e}")
@@ -1072,6 +1072,28 @@ def main():
         out = {}
         print("[config 5 width: ViT-g (SwiGLU) x 4 blocks + adapters(1536) + DecoderMLA 11 classes + iou_loss, 588 B=2]"); c5_case(R, out)
         save("c5", out)
+    # Full-DEPTH cases of BASELINE configs 2 / 4 / 5: every block of ViT-B (12) / ViT-L (24, unfrozen, both
+    # passes under the reference's autograd) / ViT-g (40), B = 1, with the reference-init and the stress weights.  Explicit only
+    # (CPU-minutes each; c4full holds two 24-block autograd graphs: ~40 GB).
+    if "c2full" in only:
+        out = {}
+        for mode in ("init", "kernel"):
+            print(f"[config 2 FULL depth: ViT-B/14 12 blocks + adapters(768) + UNet(768), 588 B=1, {mode} weights]")
+            c2_case(R, out, arch="vit_base", batch=1, tag=f"c2full_{mode}", mode=mode)
+        save("c2full", out)
+    if "c5full" in only:
+        out = {}
+        for mode in ("init", "kernel"):
+            print(f"[config 5 FULL depth: ViT-g/14 40 blocks (SwiGLU) + adapters(1536) + DecoderMLA 11 classes, 588 B=1, {mode} weights]")
+            c5_case(R, out, arch="vit_giant2", batch=1, tag=f"c5full_{mode}", mode=mode)
+        save("c5full", out)
+    if "c4full" in only:
+        out = {}
+        for mode in ("init", "kernel"):
+            print(f"[config 4 FULL depth: ViT-L/14 24 blocks unfrozen in the adapter flow, 588 B=1, {mode} weights, gradient sub-samples]")
+            c4_case(R, out, arch="vit_large", batch=1, tag=f"c4full_{mode}", mode=mode, grad_elems=600)
+            import gc; gc.collect()
+        save("c4full", out)
     if args.full or "step_b2" in only:
         out = {}
         print("[step ViT-L 588 B=2 reference_exact (init mode)]"); step_case(R, out, "vit_large", "init", "step_b2_exact", batch=2)

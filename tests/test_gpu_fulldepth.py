@@ -1,0 +1,119 @@
+"""GPU: BASELINE configs 2 / 4 / 5 at FULL DEPTH (ViT-B 12, ViT-L 24 unfrozen, ViT-g 40 blocks), 588x588, batch 1,
+against goldens produced by the imported reference modules (tests/golden/make_golden.py --only c2full,c4full,c5full),
+each with the reference-init weights (LayerScale 1e-5, CAViT gamma 0: `ssl_default_config.yaml:75`, `train.py:90`) and
+with the stress weights (LayerScale in [0.05, 0.5] in every block evaluation, 1.5x qkv, adapters gamma != 0).
+
+north_star tolerance: 1e-3 relative (rel-L2) on the logits."""
+import pytest
+import torch
+
+from adaptersis_amd import config, ops
+from adaptersis_amd.backbones.adapter_blocks import CACNN, CAViT
+from adaptersis_amd.backbones.decoders import DecoderMLA, FeatureDecoder
+from adaptersis_amd.backbones.encoders import FeatureEncoder
+from adaptersis_amd.backbones.engines import SegEngine
+from adaptersis_amd.backbones.unet_parts import UNet
+from adaptersis_amd.dinov2.models import vision_transformer as vits
+from adaptersis_amd.utils import weights as W
+from tests.conftest import golden_err, load_golden
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+def _modules(arch, mode, dev, train=False):
+    D, depth, heads, ffn = W.VIT_CONFIGS[arch]
+    model = vits.__dict__[arch](patch_size=14, img_size=518, init_values=1e-5, ffn_layer=ffn, block_chunks=0)
+    model.load_state_dict(W.make_vit_state_dict(arch, layerscale=("kernel" if mode == "kernel" else "init")))
+    enc = FeatureEncoder(embed_dim=D); enc.load_state_dict(W.make_encoder_state_dict(D))
+    cv = CAViT(dim=D, n_levels=3, num_heads=8, init_values=0.0, n_points=4); cv.load_state_dict(W.make_cavit_state_dict(D, mode=mode))
+    cn = CACNN(dim=D, n_levels=1, num_heads=8, n_points=4, with_cffn=True, cffn_ratio=0.25)
+    cn.load_state_dict(W.make_cacnn_state_dict(D, mode=mode))
+    model = model.to(dev)
+    return D, depth, (model if train else model.eval()), enc.to(dev), cv.to(dev), cn.to(dev)
+
+
+def _grad_stats(views, g, prefix, skip_bias0=True):
+    errs = {k: golden_err(v, g[prefix + k]) for k, v in views.items()
+            if (prefix + k) in g and float(g[prefix + k]["sumsq"]) > 1e-20 and not (skip_bias0 and k.endswith(".0.bias"))}
+    v = sorted(errs.values())
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:3]
+    return len(v), v[-1], v[len(v) // 2], [(k, "%.1e" % e) for k, e in worst]
+
+
+@pytest.mark.parametrize("mode", ["init", "kernel"])
+def test_config2_vitb_12_blocks_unet768(dev, mode):
+    """ViT-B/14 (12 blocks) frozen + adapters(768) + UNet(768), CE + DC (`train.py:275-387`, `eval/eval_dinov2_unet.py:286-297`)."""
+    g, tag = load_golden("c2full"), f"c2full_{mode}"
+    D, depth, model, enc, cv, cn = _modules("vit_base", mode, dev)
+    assert depth == 12
+    dec = UNet(D, 2); dec.load_state_dict(W.make_unet_state_dict(D, 2))
+    eng = SegEngine(model, enc, cv, cn, dec.to(dev), lr=0.01, loss="ce_dc")
+    img, tgt = W.synthetic_batch(1, 588)
+    taps = {}
+    loss = eng.train_step(img.to(dev), tgt.to(dev), taps)
+    e_x = golden_err(taps["x_final"], g[f"{tag}.x_final"])
+    e_c = golden_err(taps["c_final"], g[f"{tag}.c_final"])
+    e_lg = golden_err(taps["logits"].permute(0, 3, 1, 2), g[f"{tag}.logits"])
+    print(f"{tag}: x_final {e_x:.2e} c_final {e_c:.2e} logits {e_lg:.2e} loss {float(loss):.6f} golden {float(g[tag + '.loss']):.6f}")
+    assert e_x < TOL and e_c < TOL and e_lg < TOL
+    assert abs(float(loss) - float(g[f"{tag}.loss"])) < 1e-4
+    n, gmax, gmed, worst = _grad_stats(eng.bucket.views, g, f"{tag}.grad.")
+    print(f"{tag} UNet grads: n={n} max {gmax:.2e} median {gmed:.2e} worst {worst}")
+    assert n >= 20 and gmax < 1e-1 and gmed < 6e-2     # step-level conditioning
+
+
+@pytest.mark.parametrize("mode", ["init", "kernel"])
+def test_config5_vitg_40_blocks_mla11(dev, mode):
+    """ViT-g/14 (40 SwiGLU blocks) frozen + adapters(1536) in the `train_mla.py:266-383` stage order + DecoderMLA, 11 classes,
+    soft-IoU (`train_multi_class.py:391-393`)."""
+    g, tag = load_golden("c5full"), f"c5full_{mode}"
+    D, depth, model, enc, cv, cn = _modules("vit_giant2", mode, dev)
+    assert depth == 40
+    dec = DecoderMLA(img_size=588, mla_channels=D, mlahead_channels=128, num_classes=11)
+    dec.load_state_dict(W.make_decoder_mla_state_dict(D, 128, 11))
+    eng = SegEngine(model, enc, cv, cn, dec.to(dev), lr=0.01, momentum=0.9, weight_decay=0.0, num_classes=11, loss="iou")
+    img, tgt = W.synthetic_batch(1, 588, 11)
+    taps = {}
+    loss = eng.train_step(img.to(dev), tgt.to(dev), taps)
+    for i, t in enumerate(taps["mla_inputs"]):
+        e = golden_err(t.transpose(1, 2).reshape(1, D, 42, 42), g[f"{tag}.in{i}"])
+        print(f"{tag}: MLA input {i} rel-L2 {e:.2e}")
+        assert e < TOL, (i, e)
+    out = ops.resize_bilinear_fwd(taps["logits"], 588, 588).permute(0, 3, 1, 2)
+    e_out = golden_err(out, g[f"{tag}.output"])
+    print(f"{tag}: output (11 classes, 588^2) rel-L2 {e_out:.2e} loss {float(loss):.6f} golden {float(g[tag + '.loss']):.6f}")
+    assert e_out < TOL
+    assert abs(float(loss) - float(g[f"{tag}.loss"])) < 1e-4
+    n, gmax, gmed, worst = _grad_stats(eng.bucket.views, g, f"{tag}.grad.")
+    print(f"{tag} MLA grads: n={n} max {gmax:.2e} median {gmed:.2e} worst {worst}")
+    assert n >= 20 and gmax < 1e-1 and gmed < 3e-2
+
+
+@pytest.mark.parametrize("mode", ["init", "kernel"])
+def test_config4_vitl_24_blocks_unfrozen(dev, mode):
+    """ViT-L/14 (24 blocks) UNFROZEN inside the `train.py:268-436` adapter flow: both passes under the reference's autograd
+    (make_golden.py:c4_case), forward taps + sub-sampled gradients of all five parameter groups."""
+    g, tag = load_golden("c4full"), f"c4full_{mode}"
+    D, depth, model, enc, cv, cn = _modules("vit_large", mode, dev, train=True)
+    assert depth == 24
+    feats = (D, 512, 256, 128, 64)
+    dec = FeatureDecoder(embed_dim=D, num_classes=2, features=list(feats)); dec.load_state_dict(W.make_feature_decoder_state_dict(D, 2, features=feats))
+    eng = SegEngine(model, enc, cv, cn, dec.to(dev), lr=0.01, mode="train_adapters", train_encoder=True, train_backbone=True)
+    img, tgt = W.synthetic_batch(1, 588)
+    taps = {}
+    loss = eng.train_step(img.to(dev), tgt.to(dev), taps)
+    e_lg = golden_err(taps["logits"].permute(0, 3, 1, 2), g[f"{tag}.logits"])
+    e_cat = golden_err(taps["cat"].float().permute(0, 3, 1, 2), g[f"{tag}.cat"])
+    print(f"{tag}: cat {e_cat:.2e} logits {e_lg:.2e} loss {float(loss):.6f} golden {float(g[tag + '.loss']):.6f}")
+    assert e_lg < TOL and e_cat < TOL
+    assert abs(float(loss) - float(g[f"{tag}.loss"])) < 1e-4
+    groups = {"vit": (eng.vit_bucket.views, f"{tag}.grad.vit."), "adapter": (eng.adapter_bucket.views, f"{tag}.grad."),
+              "encoder": (eng.encoder_bucket.views, f"{tag}.grad."), "decoder": (eng.bucket.views, f"{tag}.grad.dec.")}
+    for nm, (views, pre) in groups.items():
+        n, gmax, gmed, worst = _grad_stats(views, g, pre, skip_bias0=(nm == "decoder"))
+        print(f"  {tag} {nm}: n={n} max {gmax:.2e} median {gmed:.2e} worst {worst}")
+        assert n >= 10
+        if mode == "kernel" or nm == "decoder":
+            # step-level bounds as at 4 blocks (test_gpu_e2e.py): ReLU flips of the head / MSDA cell crossings set the floor
+            assert gmax < 2.5e-1 and gmed < 5e-2, (nm, worst)
