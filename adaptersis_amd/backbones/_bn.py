@@ -18,8 +18,8 @@ def finalize(partial: torch.Tensor, count: int, bn: torch.nn.Module, sync: bool 
     sums = ops.reduce_partials(partial)
     total = float(count)
     if sync and parallel.collectives_on():
-        dist.all_reduce(sums)  # 2C doubles; every rank holds the same per-GPU batch on this path
-        total = float(count) * dist.get_world_size()
+        dist.all_reduce(sums)  # 2C doubles
+        total = float(count) * parallel.count_scale()   # x world, or x (global / local batch) after parallel.set_batch_ratio
     rm = bn.running_mean if (update and bn.track_running_stats) else None
     rv = bn.running_var if (update and bn.track_running_stats) else None
     nbt = bn.num_batches_tracked if (update and bn.track_running_stats) else None

@@ -159,7 +159,8 @@ class SegEngine(nn.Module):
             if mode != "train_adapters":
                 raise ValueError("train_backbone needs mode='train_adapters' (the unfrozen variant of the adapter flow)")
             self.vit_bucket, self.vit_reducer, self._fire_at = make_vit_bucket(model, blocks_per_bucket, process_group,
-                                                                               momentum=optimize_backbone)
+                                                                               momentum=optimize_backbone,
+                                                                               min_first_blocks=n_last_blocks)
             if optimize_backbone:
                 buckets.append(self.vit_bucket)
         self.optimizer = SGD(buckets, lr=lr, momentum=momentum, weight_decay=weight_decay)
@@ -194,6 +195,28 @@ class SegEngine(nn.Module):
             done.record(side)
         c.record_stream(main)           # allocated on the side stream, consumed on the compute stream
         return c, shapes, done
+
+    def _trunk_dual(self, xcat: torch.Tensor, Ra: int, blocks, segs) -> torch.Tensor:
+        """The trunk blocks with the two token batches on two HIP streams (config.dual_stream) -> the stacked [Ra + Rb, D]."""
+        main = torch.cuda.current_stream()
+        if getattr(self, "_dual_streams", None) is None:
+            self._dual_streams = (torch.cuda.Stream(), torch.cuda.Stream())
+        s1, s2 = self._dual_streams
+        s1.wait_stream(main)
+        s2.wait_stream(main)
+        xcat.record_stream(s1)
+        xcat.record_stream(s2)
+        xa, xb = xcat[:Ra], xcat[Ra:]
+        for blk in blocks:
+            with torch.cuda.stream(s1):
+                xa = blk.forward_rows(xa, [segs[0]])
+            with torch.cuda.stream(s2):
+                xb = blk.forward_rows(xb, [segs[1]])
+        main.wait_stream(s1)
+        main.wait_stream(s2)
+        xa.record_stream(main)
+        xb.record_stream(main)
+        return torch.cat([xa, xb], 0)
 
     def _cavit(self, x2, c2, g, B, Lq, Lin):
         cv = self.cross_vit
@@ -244,7 +267,13 @@ class SegEngine(nn.Module):
         ops.add_cls_pos(tokens, m.cls_token.detach().reshape(-1).float().contiguous(),
                         pos.detach().reshape(-1, D).float().contiguous(), out=xcat[:Ra].view(B, N + 1, D))
         feats = []
-        for i, blk in enumerate(m.blocks[: nb - (nl - 1)]):
+        trunk = list(m.blocks[: nb - (nl - 1)])
+        if config.dual_stream and inp.is_cuda and getattr(self, "_dual_warm", False) and nb - nl == len(trunk) - 1:
+            xcat = self._trunk_dual(xcat, Ra, trunk, segs)
+            feats.append(m._final_norm(xcat[:Ra].view(B, N + 1, D))[:, 1:])
+            trunk = []
+        self._dual_warm = True      # the first step runs in order: it fills the per-module operand caches on one stream
+        for i, blk in enumerate(trunk):
             xcat = blk.forward_rows(xcat, segs)
             if i >= nb - nl:
                 feats.append(m._final_norm(xcat[:Ra].view(B, N + 1, D))[:, 1:])   # [B, N, D] view, batch stride (N+1)*D
@@ -627,11 +656,13 @@ class SegEngine(nn.Module):
         return (m, loss1, counts) if with_counts else (m, loss1)
 
 
-def make_vit_bucket(model, blocks_per_bucket: int, process_group, momentum: bool = False):
+def make_vit_bucket(model, blocks_per_bucket: int, process_group, momentum: bool = False, min_first_blocks: int = 0):
     """Flat gradient bucket of the whole backbone in gradient-ready order (final norm, blocks last..first, then the token
     embedding parameters) + a reducer over ``blocks_per_bucket``-block chunks (the last chunk takes the embeddings along).
     -> (bucket, reducer, fire_at) with fire_at = block indices after whose backward the next chunk is complete (-1 = after
-    the embedding backward)."""
+    the embedding backward).  ``min_first_blocks``: the first chunk (which holds ``norm.*``) does not fire before that many
+    blocks are done — the adapter flow writes the final-norm gradients only after its ``n_last_blocks`` stages, so a smaller
+    first chunk would be all-reduced before they exist."""
     vnamed = dict(model.named_parameters())
     depth = len(model.blocks)
     groups = [[n for n in vnamed if n.startswith("norm.")]]
@@ -643,7 +674,7 @@ def make_vit_bucket(model, blocks_per_bucket: int, process_group, momentum: bool
     bucket = FlatBucket([(n, vnamed[n]) for g in groups for n in g], momentum=momentum)
     fire_at, ranges, start = [], [], 0
     for j in range(1, depth + 1):                       # j = number of blocks finished
-        if j % blocks_per_bucket == 0 and j != depth:
+        if j % blocks_per_bucket == 0 and j != depth and j >= min_first_blocks:
             names = [n for g in groups[start:j + 1] for n in g]
             ranges.append(bucket.range_of(names)); fire_at.append(depth - j); start = j + 1
     ranges.append(bucket.range_of([n for g in groups[start:] for n in g])); fire_at.append(-1)

@@ -56,3 +56,9 @@ wgrad_stream = os.environ.get("ASIS_WGRAD_STREAM", "1") not in ("0", "")
 # Layers whose forward conv runs on plain 16-bit operands although split_conv is on (comma-separated stage keys: d1..d4 =
 # FeatureDecoder stages, stem3 / stem6 / conv2 / conv3 / conv4 = encoder): the lab switch behind DESIGN.md's per-layer table.
 unsplit_layers = set(filter(None, os.environ.get("ASIS_UNSPLIT", "").split(",")))
+
+# The two ViT passes of the frozen-backbone step (cls + pos-embed tokens / raw patch tokens: `train.py:287,300-302`) as two
+# independent launch streams instead of one row-stacked stream (engines.SegEngine._trunk_dual): every dense GEMM fills the
+# chip in a non-integral number of tile rounds (q|k 5.19, proj / fc2 2.59, fc1 10.4 at 12 images), and the CUs that the tail
+# round of one stream's kernel leaves idle start the other stream's next kernel.  ASIS_DUAL_STREAM=1 turns it on (lab).
+dual_stream = os.environ.get("ASIS_DUAL_STREAM", "0") not in ("0", "")

@@ -212,6 +212,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const asis_gemm_desc 
 
 // ASIS_GEMM_P8 / asis_gemm_set_option("p8", v): -1 = not read yet
 static int g_gemm_p8 = -1;
+static int g_gemm_noepi = -1;   // ASIS_GEMM_NOEPI / "noepi" (lab: main loop only; wrong results)
 static bool ph8_m16_on() { static const int v = [] { const char* e = getenv("ASIS_GEMM_8P_M16"); return e ? atoi(e) : 1; }(); return v != 0; }
 
 template <typename T>
@@ -266,7 +267,8 @@ int launch(hipStream_t s, const asis_gemm_desc& d) {
     return 0;
   }
   static const int m16 = [] { const char* e = getenv("ASIS_GEMM_M16"); return e ? atoi(e) : 1; }();  // 16x16x32 MFMAs in the default dense form
-  static const int noepi = [] { const char* e = getenv("ASIS_GEMM_NOEPI"); return e ? atoi(e) : 0; }();  // lab: main loop only
+  if (g_gemm_noepi < 0) { const char* e = getenv("ASIS_GEMM_NOEPI"); g_gemm_noepi = e ? atoi(e) : 0; }
+  const int noepi = g_gemm_noepi;  // lab: main loop only
   // ASIS_GEMM_8P: 0 = never; 1 (default) = K >= 2048 (fc2 / its input gradient: 343 vs 476 us at 42348x1024x4096) and,
   // since the phases run on 16x16x32 MFMAs (ASIS_GEMM_8P_M16: fc2 391 -> 350 us in isolation), the unbatched K >= 1024
   // GEMMs too (in the step: qk 222 -> 214 us, proj 160 -> 139, fc1 457 -> 441, adapter projections 242 -> 216; +3.5 % on the
@@ -308,12 +310,13 @@ int launch(hipStream_t s, const asis_gemm_desc& d) {
   if (ph8 && (ph8 == 2 || d.K >= 2048 || (ph8 == 1 && d.K >= ph8_mink && (int64_t)((d.M + 255) / 256) * ((d.N + 255) / 256) * d.batch >= 128)) && big_mode && !d.conv && !d.stats && d.K % 64 == 0 && d.M >= 256 && d.N >= 256) {
     // ASIS_GEMM_P8 (default 1): launches with at least one tile per CU run on the PERSISTENT form of the 8-phase kernel
     // (gemm_p8.h: one workgroup per CU walks its tiles, the next tile's first K tile is staged during the last K tile of
-    // the current one, the epilogue's stores drain under the next tile); 2 = from 16 tiles on (tests); 0 = never
+    // the current one, the epilogue's stores drain under the next tile) when K <= 2048 (at K = 4096 a tile is 64 K tiles long and
+    // the per-tile savings no longer pay for the static tile lists: 347 vs 341 us); 2 = any K, from 16 tiles on (tests); 3 = any K; 0 = never
     if (g_gemm_p8 < 0) { const char* e = getenv("ASIS_GEMM_P8"); g_gemm_p8 = e ? atoi(e) : 1; }
     const int p8 = g_gemm_p8;
     const int64_t p8_tiles = (int64_t)((d.M + 255) / 256) * ((d.N + 255) / 256);
     auto al = [](const void* p, int a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; };
-    if (p8 && ph8_m16_on() && d.batch == 1 && !d.bias_m && p8_tiles >= (p8 == 2 ? 16 : 256) && d.K >= 128 &&
+    if (p8 && ph8_m16_on() && d.batch == 1 && !d.bias_m && p8_tiles >= (p8 == 2 ? 16 : 256) && d.K >= 128 && (p8 >= 2 || d.K <= 2048) &&
         (int64_t)d.M * d.lda * 2 < (1ll << 32) && (int64_t)d.N * d.ldb * 2 < (1ll << 32) && d.N % 8 == 0 && d.ldc % 8 == 0 &&
         al(d.C, 16) && (!d.res || (al(d.res, 16) && d.ldr % 4 == 0)) && (!d.bias_n || al(d.bias_n, 16)) && (!d.scale_n || al(d.scale_n, 16)) &&
         (d.act != ASIS_ACT_GELU_GRAD || (d.aux && al(d.aux, 8) && d.ld_aux % 4 == 0))) {
@@ -392,6 +395,7 @@ extern "C" int asis_gemm_tiles_m(int M) { return (M + BM - 1) / BM; }
 extern "C" int asis_gemm_set_option(const char* name, int value) {
   ASIS_REQUIRE(name != nullptr, "asis_gemm_set_option: null name");
   if (strcmp(name, "p8") == 0) { g_gemm_p8 = value; return ASIS_OK; }
+  if (strcmp(name, "noepi") == 0) { g_gemm_noepi = value; return ASIS_OK; }
   ASIS_FAIL(ASIS_EINVAL, "asis_gemm_set_option: unknown option '%s'", name);
 }
 

@@ -34,6 +34,33 @@ def collectives_on(group=None) -> bool:
     return dist.get_world_size(group) > 1 or FORCE_COLLECTIVES
 
 
+# SyncBatchNorm element counts (`nn.SyncBatchNorm` gathers every rank's count: `backbones/encoders.py:12-40`).  With the
+# reference's loader (`DistributedSampler`, `train.py:167-175`) every rank holds the same number of images in every iteration —
+# also in the short last batch of an epoch — so a layer's global count is its local count x world, known on the host without an
+# exchange.  A caller whose per-rank batches can differ announces it once per step with ``set_batch_ratio``: the ranks'
+# batch sizes are summed (one int all-reduce and a host read — a host sync, which is why it is opt-in) and every train-mode
+# BatchNorm of that step divides its all-reduced sums by local count x (global batch / local batch).
+_BATCH_RATIO = None
+
+
+def set_batch_ratio(local_batch=None, group=None) -> float:
+    """``local_batch`` = this rank's image count of the coming step (None: back to equal batches) -> global / local."""
+    global _BATCH_RATIO
+    if local_batch is None or not collectives_on(group):
+        _BATCH_RATIO = None
+        return float(world_size(group))
+    backend = dist.get_backend(group)
+    t = torch.tensor([int(local_batch)], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
+    dist.all_reduce(t, group=group)
+    _BATCH_RATIO = float(int(t.item())) / float(local_batch)
+    return _BATCH_RATIO
+
+
+def count_scale(group=None) -> float:
+    """global element count / local element count of a SyncBatchNorm layer in the current step."""
+    return _BATCH_RATIO if _BATCH_RATIO is not None else float(world_size(group))
+
+
 _GRAD_STREAMS = {}
 
 

@@ -25,6 +25,7 @@ from torch import nn
 from .backbones.adapter_blocks import CACNN, CAViT
 from .backbones.decoders import DecoderMLA, FeatureDecoder
 from .backbones.encoders import FeatureEncoder
+from . import config
 from .backbones.engines import SegEngine
 from .dinov2.models import vision_transformer as vits
 from .utils import misc as utils
@@ -158,7 +159,7 @@ def train_seg(args, head: str = "feature"):
     sampler = torch.utils.data.distributed.DistributedSampler(dataset_train, num_replicas=utils.get_world_size(),
                                                                rank=utils.get_rank())
     train_loader = torch.utils.data.DataLoader(dataset_train, sampler=sampler, batch_size=args.batch_size_per_gpu,
-                                               num_workers=workers, pin_memory=True, drop_last=True, collate_fn=collate)
+                                               num_workers=workers, pin_memory=True, collate_fn=collate)   # no drop_last: train.py:168-174
     print(f"Data loaded with {len(dataset_train)} train and {len(dataset_val)} val imgs.")
 
     class _Cosine:  # torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, epochs, eta_min=0), stepped per epoch
@@ -240,6 +241,18 @@ def train(model, feature_model, backbone_encoder, cross_vit, cross_cnn, seg_deco
         metric_logger.update(lr=optimizer.param_groups[0]["lr"])
     metric_logger.synchronize_between_processes()
     print("Averaged stats:", metric_logger)
+    # overflow guard of the static 16-bit loss scale (optim.SGD): a step whose gradients hold an inf / NaN is skipped on the
+    # device.  One host read per epoch; an epoch in which EVERY step was skipped means the scale is too large for this data —
+    # the reference's torch.optim.SGD has no skip, so a silent stall would be a behaviour change.
+    skipped = optimizer.skipped_steps
+    prev = getattr(optimizer, "_skipped_reported", 0)
+    optimizer._skipped_reported = skipped
+    if skipped > prev:
+        print(f"WARNING: {skipped - prev} of {len(loader)} optimizer steps of epoch {epoch} were skipped (non-finite gradients "
+              f"under loss scale {config.loss_scale:g}); lower ASIS_LOSS_SCALE if this persists")
+        if len(loader) > 0 and skipped - prev >= len(loader):
+            raise RuntimeError(f"every optimizer step of epoch {epoch} was skipped: non-finite gradients under the static loss "
+                               f"scale {config.loss_scale:g} (set ASIS_LOSS_SCALE to a smaller power of two)")
     return {k: meter.global_avg for k, meter in metric_logger.meters.items()}
 
 

@@ -129,11 +129,13 @@ def synthetic(batch: int, size: int, rank: int, dev, num_classes: int = 2):
     return img.to(dev), tgt.to(dev)
 
 
-def host_cores() -> int:
-    """Cores this process may really use: the affinity mask, cut to the cgroup CPU quota (a 1-GPU box exposes all 256
-    host threads in the mask but owns a 16-core share: 256 oracle threads on 16 cores ran 12x slower than 16),
-    ``ASIS_CPU_THREADS`` overrides."""
+def host_cores():
+    """-> (cores this process may really use, how that number was derived).  The affinity mask, cut to the cgroup CPU quota
+    when one is visible; on a box of the GPU pool (marker: ``GRAFT_REPO_ROOT``) that shows its whole host in the mask and no
+    quota, the pool's documented share of 16 cores per GPU (256 oracle threads on that share ran 12x slower than 16);
+    ``ASIS_CPU_THREADS`` overrides.  An unconstrained many-core host keeps its affinity count."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    how = "affinity mask"
     quota = None
     try:
         with open("/sys/fs/cgroup/cpu.max") as f:
@@ -148,30 +150,29 @@ def host_cores() -> int:
                     quota = max(1, int(q / per + 0.5))
         except (OSError, ValueError):
             pass
-    if quota is None and n > 64:
-        quota = 16          # no quota visible on a many-core host: the documented share of a 1-GPU box
-    if quota is not None:
-        n = min(n, quota)
+    if quota is not None and quota < n:
+        n, how = quota, "cgroup CPU quota"
+    elif quota is None and n > 64 and os.environ.get("GRAFT_REPO_ROOT"):
+        n, how = 16, "GPU-pool share (16 cores per GPU; no cgroup quota visible, affinity mask = whole host)"
     if os.environ.get("ASIS_CPU_THREADS"):
-        n = int(os.environ["ASIS_CPU_THREADS"])
-    return max(1, n)
+        n, how = int(os.environ["ASIS_CPU_THREADS"]), "ASIS_CPU_THREADS"
+    return max(1, n), how
 
 
 def cpu_baseline(arch: str, size: int, batch: int = 1):
     """Reference CPU path (the fp32 eager oracle restatement, parity-pinned to the imported reference) on this box's
-    host cores: ONE WHOLE `train.py:268-436` step at batch ``batch`` is timed end to end (encoder, ViT pass A + pass B,
-    4 adapter stages, decoder forward, loss, decoder backward, SGD) — no extrapolation; ``sample`` also lists the
-    per-part times of a short probe (one block per pass, one adapter stage) for orientation."""
+    host cores: WHOLE `train.py:268-436` steps at batch ``batch`` timed end to end (encoder, ViT pass A + pass B,
+    4 adapter stages, decoder forward, loss, decoder backward, SGD) — one untimed warm-up step, then two timed ones
+    (``value`` = batch / their mean), plus one timed step at the other batch size of {1, 2} in ``sample``."""
     from adaptersis_amd.utils import weights as W
     from oracle import ref_torch as O  # cpu_baseline leg only
 
-    cores = host_cores()
+    cores, cores_how = host_cores()
     torch.set_num_threads(cores)
     D, depth, heads, _ = W.VIT_CONFIGS[arch]
     vsd = W.make_vit_state_dict(arch, layerscale="kernel")
     esd, csd, nsd = W.make_encoder_state_dict(D), W.make_cavit_state_dict(D), W.make_cacnn_state_dict(D)
     dsd = W.make_feature_decoder_state_dict(D, 2, features=(D, 512, 256, 128, 64))
-    img, tgt = W.synthetic_batch(batch, size)
     N = (size // 14) ** 2
 
     def t(fn):
@@ -186,7 +187,8 @@ def cpu_baseline(arch: str, size: int, batch: int = 1):
     params = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in dsd.items()}
     mom = {}
 
-    def step():
+    def step(img, tgt):
+        t0 = time.perf_counter()
         with torch.no_grad():
             cat = O.adapter_forward(img, vsd, esd, csd, nsd, heads)
         t_fwd = time.perf_counter()
@@ -197,17 +199,22 @@ def cpu_baseline(arch: str, size: int, batch: int = 1):
         with torch.no_grad():   # torch.optim.SGD(momentum 0.99, wd 3e-5), train.py:178-191
             tr = {k: p_ for k, p_ in params.items() if p_.grad is not None}
             O.sgd_momentum_step(tr, {k: p_.grad for k, p_ in tr.items()}, mom, 0.01)
-        return t_fwd, float(loss)
+        return time.perf_counter() - t0, t_fwd - t0, float(loss)
 
-    t0 = time.perf_counter()
-    t_fwd, loss = step()
-    t_step = time.perf_counter() - t0
+    img, tgt = W.synthetic_batch(batch, size)
+    step(img, tgt)                                       # warm-up (allocator, thread pool, momentum buffers): not timed
+    runs = [step(img, tgt) for _ in range(2)]
+    t_step = sum(r[0] for r in runs) / len(runs)
+    other = 2 if batch == 1 else 1
+    t_other = step(*W.synthetic_batch(other, size))[0]
     return {
         "value": round(batch / t_step, 5), "unit": "img/s", "cores": cores, "kind": "port",
-        "sample": (f"one whole train.py step timed end to end at batch {batch}, {arch} {size}x{size}: {t_step:.1f}s "
-                   f"(features {t_fwd - t0:.1f}s, decoder fwd+loss+bwd+SGD {t_step - (t_fwd - t0):.1f}s; one block at "
-                   f"N={N + 1} alone: {t_a:.2f}s; loss {loss:.4f}); fp32 eager torch {torch.__version__}, "
-                   f"{cores} threads = the CPU share of this box (affinity mask cut to the cgroup quota)"),
+        "cores_from": cores_how, f"value_batch{other}": round(other / t_other, 5),
+        "sample": (f"whole train.py steps timed end to end, {arch} {size}x{size}: 1 warm-up + 2 timed steps at batch {batch} "
+                   f"({', '.join('%.1fs' % r[0] for r in runs)}; features {runs[-1][1]:.1f}s, decoder fwd+loss+bwd+SGD "
+                   f"{runs[-1][0] - runs[-1][1]:.1f}s), then one timed step at batch {other} ({t_other:.1f}s = "
+                   f"{other / t_other:.4f} img/s); one block at N={N + 1} alone: {t_a:.2f}s; loss {runs[-1][2]:.4f}; "
+                   f"fp32 eager torch {torch.__version__}, {cores} threads ({cores_how})"),
     }
 
 
@@ -233,17 +240,14 @@ def launch_ranks(n: int) -> int:
     """`python bench.py --gpus N` without torchrun: run N ranks as children of this (GPU-free) process through
     ``python -m torch.distributed.run`` on 127.0.0.1, pass their stdout / stderr through (rank 0 prints the JSON line)
     and return the launcher's exit code (non-zero when any rank failed)."""
-    import socket
     import subprocess
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this pool (RCCL needs it)
     env.pop("RANK", None)
     env.pop("LOCAL_RANK", None)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
-           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    # --standalone: torchrun's own c10d rendezvous on a port IT picks and holds (no bind-then-close race), on 127.0.0.1
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           f"--nproc-per-node={n}", os.path.abspath(__file__), *sys.argv[1:]]
     return subprocess.run(cmd, env=env).returncode
 
 
@@ -344,11 +348,15 @@ def main():
         ops.PROFILE = prof
         enc_stream, config.encoder_stream = config.encoder_stream, False   # one stream: a launch's event pair times that launch alone
         vt_stream, config.vt_stream = config.vt_stream, False
+        wg_stream, config.wgrad_stream = config.wgrad_stream, False    # weight gradients too: nothing runs beside a timed launch
+        du_stream, config.dual_stream = config.dual_stream, False
         for _ in range(a.steps):
             eng.train_step(img, tgt)
         barrier()
         config.encoder_stream = enc_stream
         config.vt_stream = vt_stream
+        config.wgrad_stream = wg_stream
+        config.dual_stream = du_stream
         ops.PROFILE = None
 
     # ---- roofline of the dominant kernel: the dense MFMA GEMM (csrc/gemm_big.h) ---------------------------
@@ -371,6 +379,8 @@ def main():
         roof = {"bound": "mfma", "kernel": "gemm_big_kernel (csrc/gemm_big.h): LDS-DMA MFMA GEMM on v_mfma_f32_16x16x32, 8-phase 256x256x64 form for the unbatched K >= 1024 launches, 256x128x32 two-workgroup form for the rest (all dense GEMM launches of the step)",
                 "achieved": round(achieved, 1), "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / MFMA_F16_DENSE_PEAK_TFLOPS, 4), "traffic": pmc_traffic("gemm_big_kernel", ("Lb0ELb0ELi32ELi4E", "Lb0ELb0ELi64ELi1ELb1E")),
+                "measured_in": "a second pass of the same steps after the timed region, every launch on ONE stream (encoder / V^T / "
+                               "weight-gradient / dual-trunk side streams off) with a HIP event pair around each GEMM launch",
                 "launches_per_step": n // a.steps, "avg_launch_ms": round(avg_ms, 4),
                 "gflop_per_launch": round(flops / 1e9, 2), "algorithmic_bytes_per_launch": round(alg_bytes),
                 "share_of_step_time": round(sum(t for _, t in dense) / a.steps / (elapsed / a.steps * 1e3), 3),
@@ -403,7 +413,8 @@ def main():
                     f"gradients) + CAViT/CACNN + encoder + FeatureDecoder all trained, {a.size}x{a.size}, batch {a.batch}/GPU "
                     "(fwd + full bwd + bucketed all-reduce of backbone/adapter/encoder/decoder gradients + SGD), random-init weights")}[a.config],
                        "global_batch": global_batch, "image_size": a.size, "parallelism": f"dp{world}",
-                       "split_precision_convs": bool(config.split_conv), "loss": loss_v},
+                       "split_precision_convs": bool(config.split_conv), "loss": loss_v,
+                       "skipped_optimizer_steps": int(eng.optimizer.skipped_steps)},
         }
         if roof:
             out["roofline"] = roof

@@ -112,7 +112,8 @@ int asis_gemm(void* stream, const asis_gemm_desc* d);
 int asis_gemm_tiles_m(int M);
 /* run-time dispatch switches of asis_gemm (same meaning as the environment variable read at first use):
  *   "p8" (ASIS_GEMM_P8): 1 = dense launches with at least one 256x256 tile per CU run on the persistent 8-phase kernel
- *   (csrc/gemm_p8.h), 2 = from 16 tiles on, 0 = never (one workgroup per tile, csrc/gemm_big.h).  Unknown name: ASIS_EINVAL. */
+ *   (csrc/gemm_p8.h) when K <= 2048, 2 = any K and from 16 tiles on, 3 = any K, 0 = never (one workgroup per tile,
+ *   csrc/gemm_big.h); "noepi" (ASIS_GEMM_NOEPI, lab): 1 = main loops only, results are wrong.  Unknown name: ASIS_EINVAL. */
 int asis_gemm_set_option(const char* name, int value);
 
 /* ---------------------------------------------------------------------------------------------

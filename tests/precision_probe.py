@@ -79,15 +79,27 @@ def patch_embed(img, sd, patch=14):
 _patch_embed = O.patch_embed
 
 
+HEAD = None   # "unet": also push x_final through the fp32 oracle UNet(D) (BASELINE config 2) and report its logits
+
+
 def run(img, sds, heads):
     taps = {}
     with torch.no_grad():
         O.adapter_forward(img, sds["vit"], {k: v.clone() for k, v in sds["enc"].items()}, sds["cv"], sds["cn"], heads, taps=taps)
-    return taps["x_stage3"], taps["c_stage3"], taps["feats"][-1]
+        x = taps["x_stage3"]
+        if HEAD == "unet":
+            B, N, D = x.shape
+            h = int(N ** 0.5)
+            y = O.unet(x.transpose(1, 2).reshape(B, D, h, h), {k: v.clone() for k, v in sds["unet"].items()}, update_bn=False)
+            return x, taps["c_stage3"], y
+    return x, taps["c_stage3"], taps["feats"][-1]
 
 
 def main():
-    global DT
+    global DT, HEAD
+    if "--unet" in sys.argv:
+        sys.argv.remove("--unet")
+        HEAD = "unet"
     arch = sys.argv[1] if len(sys.argv) > 1 else "vit_base_d4"
     size = int(sys.argv[2]) if len(sys.argv) > 2 else 224
     if len(sys.argv) > 3 and sys.argv[3] == "bf16":
@@ -95,6 +107,8 @@ def main():
     D, depth, heads, _ = W.VIT_CONFIGS[arch]
     sds = dict(vit=W.make_vit_state_dict(arch, layerscale="kernel"), enc=W.make_encoder_state_dict(D),
                cv=W.make_cavit_state_dict(D, mode="kernel"), cn=W.make_cacnn_state_dict(D, mode="kernel"))
+    if HEAD == "unet":
+        sds["unet"] = W.make_unet_state_dict(D, 2)
     img, _ = W.synthetic_batch(1, size)
     ref = run(img, sds, heads)
     O.attention, O.mlp, O.ms_deform_attn, O.conv_ffn, O.patch_embed = attention, mlp, ms_deform_attn, conv_ffn, patch_embed
@@ -102,11 +116,13 @@ def main():
     def err(tag):
         out = run(img, sds, heads)
         e = [float((a.double() - b.double()).norm() / b.double().norm()) for a, b in zip(out, ref)]
-        print(f"{tag:34s} x_final {e[0]:.2e}  c_final {e[1]:.2e}  passA feat {e[2]:.2e}", flush=True)
+        print(f"{tag:34s} x_final {e[0]:.2e}  c_final {e[1]:.2e}  {'UNet logits' if HEAD else 'passA feat'} {e[2]:.2e}", flush=True)
         return e
     print(f"{arch} {size}x{size}, operands {DT}: rounding emulated at the listed sites only")
     ON.clear(); ON.update(SITES)
     err("ALL sites")
+    ON.clear(); ON.update(s for s in SITES if s != "pe")
+    err("ALL but pe (split-precision patch embed)")
     for s in SITES:
         ON.clear(); ON.add(s)
         err("only " + s)

@@ -105,3 +105,82 @@ def test_two_rank_encoder_backward_matches_full_batch(dev):
             continue
         err = float((r0[n].double() - g.double()).norm() / g.double().norm())
         assert err < 2e-3, (n, err)
+
+
+def _worker_e2e(rank, world, port, out):
+    """Config-4 engine (backbone unfrozen) with a backbone chunk SMALLER than n_last_blocks: the first chunk holds norm.*,
+    whose gradients only exist after the four adapter stages."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from adaptersis_amd.utils import weights as W
+    from tests.test_gpu_e2e import build_e2e_engine
+    dev = torch.device("cuda:0")
+    eng, _ = build_e2e_engine("vit_tiny_test", dev, (128, 32, 16, 16, 8), blocks_per_bucket=2)
+    img, tgt = W.synthetic_batch(4, 224, seed=3)
+    sl = slice(rank * 2, rank * 2 + 2)
+    eng.train_step(img[sl].to(dev), tgt[sl].to(dev))
+    torch.cuda.synchronize()
+    out[rank] = {"vit": eng.vit_bucket.grad.cpu(), "norm_w": eng.vit_bucket.views["norm.weight"].cpu(),
+                 "fire_at": list(eng._fire_at)}
+    dist.destroy_process_group()
+
+
+def test_two_rank_unfrozen_step_reduces_final_norm_gradients(dev):
+    world = 2
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_worker_e2e, args=(world, _free_port(), out), nprocs=world, join=True)
+        r0, r1 = out[0], out[1]
+    assert max(r0["fire_at"]) <= 0, r0["fire_at"]          # depth 4, n_last_blocks 4: nothing fires before block 0 is done
+    assert float(r0["norm_w"].abs().sum()) > 0
+    assert torch.equal(r0["norm_w"], r1["norm_w"]), "final-norm gradients were not all-reduced"
+    assert torch.equal(r0["vit"], r1["vit"])
+
+
+def _worker_ragged(rank, world, port, out):
+    """SyncBatchNorm with DIFFERENT per-rank batches (1 and 2 images): parallel.set_batch_ratio announces it."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from adaptersis_amd import parallel
+    from adaptersis_amd.backbones.encoders import FeatureEncoder
+    from adaptersis_amd.utils import weights as W
+    dev = torch.device("cuda:0")
+    enc = FeatureEncoder(embed_dim=128)
+    enc.load_state_dict(W.make_encoder_state_dict(128))
+    enc = enc.to(dev)
+    img, _ = W.synthetic_batch(3, 224, seed=5)
+    sl = slice(0, 1) if rank == 0 else slice(1, 3)
+    ratio = parallel.set_batch_ratio(sl.stop - sl.start)
+    _, c, shapes = enc.forward_tokens(img[sl].to(dev), need_c1=False)
+    torch.cuda.synchronize()
+    parallel.set_batch_ratio(None)
+    out[rank] = {"c": c.cpu(), "rm": enc.stem[1].running_mean.cpu(), "rv": enc.stem[1].running_var.cpu(), "ratio": ratio}
+    dist.destroy_process_group()
+
+
+def test_two_rank_syncbn_with_ragged_batches_matches_full_batch(dev):
+    """`nn.SyncBatchNorm` weights every rank's statistics by its element count (`backbones/encoders.py:12-40`): ranks holding
+    1 and 2 images must reproduce one process normalising all 3."""
+    world = 2
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_worker_ragged, args=(world, _free_port(), out), nprocs=world, join=True)
+        r0, r1 = out[0], out[1]
+    assert r0["ratio"] == 3.0 and r1["ratio"] == 1.5
+    from adaptersis_amd.backbones.encoders import FeatureEncoder
+    from adaptersis_amd.utils import weights as W
+    enc = FeatureEncoder(embed_dim=128)
+    enc.load_state_dict(W.make_encoder_state_dict(128))
+    enc = enc.to(dev)
+    img, _ = W.synthetic_batch(3, 224, seed=5)
+    _, c, _ = enc.forward_tokens(img.to(dev), need_c1=False)
+    c = c.cpu()
+    assert torch.allclose(r0["rm"], enc.stem[1].running_mean.cpu(), rtol=1e-5, atol=1e-7)
+    assert torch.allclose(r0["rv"], enc.stem[1].running_var.cpu(), rtol=1e-5, atol=1e-7)
+    assert torch.equal(r0["rm"], r1["rm"])
+    for got, ref in ((r0["c"], c[:1]), (r1["c"], c[1:])):
+        assert float((got.double() - ref.double()).norm() / ref.double().norm()) < 1e-5
