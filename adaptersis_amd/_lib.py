@@ -77,6 +77,7 @@ SIGNATURES = {
     "asis_gemm_set_option": [C.c_char_p, _i],
     "asis_layernorm": [_vp, _i, _vp, _i64, _vp, _vp, _f, _vp, _i64, _i, _i64, _i],
     "asis_attention_fwd_seg": [_vp, _i, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _f, _vp],
+    "asis_attention_fwd_split": [_vp, _i, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i, _i, _i, _i, _i, _f, _vp],
     "asis_attention_fwd_lse": [_vp, _i, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _i, _f, _vp],
     "asis_transpose_tokens": [_vp, _i, _vp, _i64, _vp, _i64, _i, _i, _i],
     "asis_attention_bwd": [_vp, _i, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp,
@@ -153,6 +154,8 @@ SIGNATURES = {
     "asis_wgrad": [_vp, C.POINTER(WgradDesc)],
     "asis_sgd_momentum": [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i],
     "asis_augment": [_vp] * 13 + [_i, _i],
+    "asis_augment_geo_u8": [_vp] * 12 + [_i, _i],
+    "asis_clahe": [_vp] * 13 + [_i, _i, _i],
     "asis_grad_guard": [_vp, _vp, _i64, _vp, _i],
     "asis_sgd_momentum_guarded": [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i, _vp, _i],
     "asis_scale_f32": [_vp, _vp, _i64, _f],

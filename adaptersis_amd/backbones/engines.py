@@ -154,6 +154,10 @@ class SegEngine(nn.Module):
                 self.encoder_reducer = StageReducer(self.encoder_bucket.grad, [(0, self.encoder_bucket.numel)], process_group)
                 buckets.append(self.encoder_bucket)
         self.train_backbone = bool(train_backbone)
+        # precision policy of the attention output (config.split_attn_out): hi + lo halves into the projection GEMM for the
+        # heads that amplify a stream error most (UNet 3.9x, MLA 3.2x; FeatureDecoder 2x) and for the unfrozen backbone
+        self.split_attn_out = config.split_attn_out_policy if config.split_attn_out_policy is not None else \
+            bool(self.stream_only or self.is_mla or train_backbone)
         self.vit_bucket = None
         if train_backbone:
             if mode != "train_adapters":
@@ -234,6 +238,7 @@ class SegEngine(nn.Module):
         """`train.py:275-406`: image batch -> decoder input, NHWC 16-bit [B, h, w, 3D] as (hi, lo|None).
         ``adapter_saves`` (train_adapters mode): list that receives, per stage, the saved activations of the frozen
         block on pass B and of CAViT / CACNN."""
+        config.split_attn_out = self.split_attn_out
         m = self.model
         B, _, H, W = inp.shape
         inp = inp.float().contiguous()
@@ -334,6 +339,7 @@ class SegEngine(nn.Module):
     def features_mla(self, inp: torch.Tensor, taps: Optional[dict] = None):
         """`train_mla.py:266-383`: -> the four MLA inputs [(hi, lo|None)] in decoder argument order
         (output_last, output_last_2, output_last_3, output_last_4), each NHWC 16-bit [B, h, w, D]."""
+        config.split_attn_out = self.split_attn_out
         m = self.model
         B, _, H, W = inp.shape
         inp = inp.float().contiguous()
@@ -450,6 +456,7 @@ class SegEngine(nn.Module):
         ``Block.forward_train_rows`` (so each block's weight gradients are later taken over the rows of both passes in
         one GEMM), the final norm's inputs of the last ``n_last_blocks`` outputs, CAViT / CACNN activations, the encoder's
         when it trains.  -> ((cat_hi, cat_lo|None), saved)."""
+        config.split_attn_out = self.split_attn_out
         m = self.model
         B, _, H, W = inp.shape
         inp = inp.float().contiguous()

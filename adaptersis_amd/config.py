@@ -62,3 +62,16 @@ unsplit_layers = set(filter(None, os.environ.get("ASIS_UNSPLIT", "").split(","))
 # chip in a non-integral number of tile rounds (q|k 5.19, proj / fc2 2.59, fc1 10.4 at 12 images), and the CUs that the tail
 # round of one stream's kernel leaves idle start the other stream's next kernel.  ASIS_DUAL_STREAM=1 turns it on (lab).
 dual_stream = os.environ.get("ASIS_DUAL_STREAM", "0") not in ("0", "")
+
+# The attention output o = softmax(QK^T)V can leave the fused attention kernel as hi + lo 16-bit halves and enter the projection
+# GEMM as a split A operand (one extra K-long part on the persistent 8-phase GEMM: +8 % block FLOPs, -3.7 % img/s on the
+# ViT-L step).  tests/precision_probe.py (ViT-B/14 12 blocks + UNet, stress weights): rounding o to 16 bits puts 9.0e-4 on the
+# logits by itself — white noise injected into the residual stream of every block, which the decode heads amplify 8x more than
+# the smooth error of rounded weights — against 1.28e-3 for all sites together.
+# ASIS_SPLIT_O = 1 always / 0 never / "auto" (default): SegEngine turns it on where the measured head-room needs it — the
+# UNet and MLA heads (they amplify a stream error 3.9x / 3.2x, the FeatureDecoder 2x: full-depth stress goldens 1.29e-3 ->
+# 9.1e-4 for config 2) and the unfrozen backbone (config 4: 9.9e-4 -> 7.3e-4) — and leaves the frozen ViT-L + FeatureDecoder
+# step (stress golden 9.0e-4) on single 16-bit operands.
+_so = os.environ.get("ASIS_SPLIT_O", "auto").lower()
+split_attn_out_policy = None if _so == "auto" else (_so not in ("0", ""))   # None = per engine (SegEngine.split_attn_out)
+split_attn_out = bool(split_attn_out_policy)     # what the blocks read; SegEngine sets it at the top of every step

@@ -41,7 +41,7 @@ __device__ __forceinline__ uint64_t clk_after(float dep) {  // s_memtime once `d
 
 template <typename T, int OCC, int ABL = 0>   // ABL (lab only, wrong results): 1 = no exp2, 2 = no P.V MFMAs, 3 = no S MFMAs
 __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, int64_t ldqk,
-                                                       const T* __restrict__ vt, int64_t ldvt, T* __restrict__ o,
+                                                       const T* __restrict__ vt, int64_t ldvt, T* __restrict__ o, T* __restrict__ o_lo,
                                                        int64_t ldo, int H, int N1, float scale_log2e,
                                                        float* __restrict__ lse2, int B1, int N2) {
   typedef typename T16<T>::v8 v8;
@@ -277,6 +277,18 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(const T* __restrict_
         w.y = pack2<T>(oacc[db][4 * g + 2] * inv, oacc[db][4 * g + 3] * inv);
         *reinterpret_cast<uint2*>(op + db * 32 + g * 8) = w;
       }
+    if (o_lo) {  // rounding residual of the 16-bit output: o ~= o + o_lo feeds the projection GEMM as a split operand (A_lo)
+      T* lp = o_lo + (row0 + qi) * ldo + head * HD + 4 * fh;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          uint2 w;
+          w.x = pack2<T>(lo_part<T>(oacc[db][4 * g + 0] * inv), lo_part<T>(oacc[db][4 * g + 1] * inv));
+          w.y = pack2<T>(lo_part<T>(oacc[db][4 * g + 2] * inv), lo_part<T>(oacc[db][4 * g + 3] * inv));
+          *reinterpret_cast<uint2*>(lp + db * 32 + g * 8) = w;
+        }
+    }
   }
 }
 
@@ -295,7 +307,7 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(const T* __restrict_
 // fragment registers of the tail tile (P is exactly 0 there, but 0 * garbage must not make a NaN).
 template <typename T, int SCHED, int DBG = 0>
 __global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(const T* __restrict__ q, const T* __restrict__ k, int64_t ldqk,
-                                                              const T* __restrict__ vt, int64_t ldvt, T* __restrict__ o,
+                                                              const T* __restrict__ vt, int64_t ldvt, T* __restrict__ o, T* __restrict__ o_lo,
                                                               int64_t ldo, int H, int N1, float scale_log2e,
                                                               float* __restrict__ lse2, int B1, int N2) {
   typedef typename T16<T>::v8 v8;
@@ -536,15 +548,28 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(const T* __restri
         w.y = pack2<T>(oacc[db][4 * g + 2] * inv, oacc[db][4 * g + 3] * inv);
         *reinterpret_cast<uint2*>(op + db * 32 + g * 8) = w;
       }
+    if (o_lo) {  // rounding residual of the 16-bit output: o ~= o + o_lo feeds the projection GEMM as a split operand (A_lo)
+      T* lp = o_lo + (row0 + qi) * ldo + head * HD + 4 * fh;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          uint2 w;
+          w.x = pack2<T>(lo_part<T>(oacc[db][4 * g + 0] * inv), lo_part<T>(oacc[db][4 * g + 1] * inv));
+          w.y = pack2<T>(lo_part<T>(oacc[db][4 * g + 2] * inv), lo_part<T>(oacc[db][4 * g + 3] * inv));
+          *reinterpret_cast<uint2*>(lp + db * 32 + g * 8) = w;
+        }
+    }
   }
 }
 
 }  // namespace
 
-extern "C" int asis_attention_fwd_seg(void* stream, int dtype, const void* q, const void* k, int64_t ldqk, const void* vt,
-                                      int64_t ldvt, void* o, int64_t ldo, int B1, int N1, int B2, int N2, int H, float scale,
-                                      float* lse2) {
+extern "C" int asis_attention_fwd_split(void* stream, int dtype, const void* q, const void* k, int64_t ldqk, const void* vt,
+                                        int64_t ldvt, void* o, void* o_lo, int64_t ldo, int B1, int N1, int B2, int N2, int H,
+                                        float scale, float* lse2) {
   const int B = B1 + B2;
+  ASIS_REQUIRE(!o_lo || (((uintptr_t)o_lo) & 7) == 0, "asis_attention_fwd: o_lo must be 8-byte aligned");
   const int N = N1 > N2 ? N1 : N2;
   ASIS_REQUIRE(q && k && vt && o, "asis_attention_fwd: null pointer");
   ASIS_REQUIRE(B1 > 0 && B2 >= 0 && H > 0 && N1 > 0 && (B2 == 0 || N2 > 0), "asis_attention_fwd: bad shape");
@@ -563,27 +588,27 @@ extern "C" int asis_attention_fwd_seg(void* stream, int dtype, const void* q, co
   static const int occ = [] { const char* e = getenv("ASIS_ATTN_OCC"); const int v = e ? atoi(e) : 2; return v < 2 ? 2 : (v > 4 ? 4 : v); }();
 #define ASIS_ATTN_LAUNCH(TT, O)                                                                                        \
   hipLaunchKernelGGL((attn_fwd_kernel<TT, O>), grid, block, 0, s, reinterpret_cast<const TT*>(q), reinterpret_cast<const TT*>(k), \
-                     ldqk, reinterpret_cast<const TT*>(vt), ldvt, reinterpret_cast<TT*>(o), ldo, H, N1, sl, lse2, B1, N2)
+                     ldqk, reinterpret_cast<const TT*>(vt), ldvt, reinterpret_cast<TT*>(o), reinterpret_cast<TT*>(o_lo), ldo, H, N1, sl, lse2, B1, N2)
   static const int abl = [] { const char* e = getenv("ASIS_ATTN_ABLATE"); return e ? atoi(e) : 0; }();
   // ASIS_ATTN_PIPE: 0 = the two-buffer register-staged kernel, 1 = software-pipelined LDS-DMA kernel, 2 = the same with
   // an explicit MFMA / VALU interleave
   static const int pipe = [] { const char* e = getenv("ASIS_ATTN_PIPE"); return e ? atoi(e) : 1; }();
   if (pipe && abl == 6 && dtype == ASIS_F16) {
-    hipLaunchKernelGGL((attn_fwd_pipe_kernel<f16, 0, 1>), grid, block, 0, s, (const f16*)q, (const f16*)k, ldqk, (const f16*)vt, ldvt, (f16*)o, ldo, H, N1, sl, lse2, B1, N2);
+    hipLaunchKernelGGL((attn_fwd_pipe_kernel<f16, 0, 1>), grid, block, 0, s, (const f16*)q, (const f16*)k, ldqk, (const f16*)vt, ldvt, (f16*)o, (f16*)o_lo, ldo, H, N1, sl, lse2, B1, N2);
   } else if (pipe && !abl) {
 #define ASIS_ATTN_PIPE_LAUNCH(TT, SC)                                                                                   \
   hipLaunchKernelGGL((attn_fwd_pipe_kernel<TT, SC>), grid, block, 0, s, reinterpret_cast<const TT*>(q),                \
                      reinterpret_cast<const TT*>(k), ldqk, reinterpret_cast<const TT*>(vt), ldvt, reinterpret_cast<TT*>(o), \
-                     ldo, H, N1, sl, lse2, B1, N2)
+                     reinterpret_cast<TT*>(o_lo), ldo, H, N1, sl, lse2, B1, N2)
     if (dtype == ASIS_F16) { if (pipe == 2) ASIS_ATTN_PIPE_LAUNCH(f16, 1); else ASIS_ATTN_PIPE_LAUNCH(f16, 0); }
     else { if (pipe == 2) ASIS_ATTN_PIPE_LAUNCH(bf16, 1); else ASIS_ATTN_PIPE_LAUNCH(bf16, 0); }
 #undef ASIS_ATTN_PIPE_LAUNCH
   } else if (abl && dtype == ASIS_F16) {
-    if (abl == 1) hipLaunchKernelGGL((attn_fwd_kernel<f16, 2, 1>), grid, block, 0, s, (const f16*)q, (const f16*)k, ldqk, (const f16*)vt, ldvt, (f16*)o, ldo, H, N1, sl, lse2, B1, N2);
-    else if (abl == 2) hipLaunchKernelGGL((attn_fwd_kernel<f16, 2, 2>), grid, block, 0, s, (const f16*)q, (const f16*)k, ldqk, (const f16*)vt, ldvt, (f16*)o, ldo, H, N1, sl, lse2, B1, N2);
-    else if (abl == 5) hipLaunchKernelGGL((attn_fwd_kernel<f16, 2, 5>), grid, block, 0, s, (const f16*)q, (const f16*)k, ldqk, (const f16*)vt, ldvt, (f16*)o, ldo, H, N1, sl, lse2, B1, N2);
-    else if (abl == 4) hipLaunchKernelGGL((attn_fwd_kernel<f16, 2, 4>), grid, block, 0, s, (const f16*)q, (const f16*)k, ldqk, (const f16*)vt, ldvt, (f16*)o, ldo, H, N1, sl, lse2, B1, N2);
-    else hipLaunchKernelGGL((attn_fwd_kernel<f16, 2, 3>), grid, block, 0, s, (const f16*)q, (const f16*)k, ldqk, (const f16*)vt, ldvt, (f16*)o, ldo, H, N1, sl, lse2, B1, N2);
+    if (abl == 1) hipLaunchKernelGGL((attn_fwd_kernel<f16, 2, 1>), grid, block, 0, s, (const f16*)q, (const f16*)k, ldqk, (const f16*)vt, ldvt, (f16*)o, (f16*)o_lo, ldo, H, N1, sl, lse2, B1, N2);
+    else if (abl == 2) hipLaunchKernelGGL((attn_fwd_kernel<f16, 2, 2>), grid, block, 0, s, (const f16*)q, (const f16*)k, ldqk, (const f16*)vt, ldvt, (f16*)o, (f16*)o_lo, ldo, H, N1, sl, lse2, B1, N2);
+    else if (abl == 5) hipLaunchKernelGGL((attn_fwd_kernel<f16, 2, 5>), grid, block, 0, s, (const f16*)q, (const f16*)k, ldqk, (const f16*)vt, ldvt, (f16*)o, (f16*)o_lo, ldo, H, N1, sl, lse2, B1, N2);
+    else if (abl == 4) hipLaunchKernelGGL((attn_fwd_kernel<f16, 2, 4>), grid, block, 0, s, (const f16*)q, (const f16*)k, ldqk, (const f16*)vt, ldvt, (f16*)o, (f16*)o_lo, ldo, H, N1, sl, lse2, B1, N2);
+    else hipLaunchKernelGGL((attn_fwd_kernel<f16, 2, 3>), grid, block, 0, s, (const f16*)q, (const f16*)k, ldqk, (const f16*)vt, ldvt, (f16*)o, (f16*)o_lo, ldo, H, N1, sl, lse2, B1, N2);
   } else if (dtype == ASIS_F16) {
     if (occ == 2) ASIS_ATTN_LAUNCH(f16, 2); else if (occ == 3) ASIS_ATTN_LAUNCH(f16, 3); else ASIS_ATTN_LAUNCH(f16, 4);
   } else {
@@ -592,6 +617,12 @@ extern "C" int asis_attention_fwd_seg(void* stream, int dtype, const void* q, co
 #undef ASIS_ATTN_LAUNCH
   ASIS_CHECK_LAUNCH("asis_attention_fwd");
   return ASIS_OK;
+}
+
+extern "C" int asis_attention_fwd_seg(void* stream, int dtype, const void* q, const void* k, int64_t ldqk, const void* vt,
+                                      int64_t ldvt, void* o, int64_t ldo, int B1, int N1, int B2, int N2, int H, float scale,
+                                      float* lse2) {
+  return asis_attention_fwd_split(stream, dtype, q, k, ldqk, vt, ldvt, o, nullptr, ldo, B1, N1, B2, N2, H, scale, lse2);
 }
 
 extern "C" int asis_attention_fwd_lse(void* stream, int dtype, const void* q, const void* k, int64_t ldqk, const void* vt,

@@ -229,6 +229,29 @@ int launch(hipStream_t s, const asis_gemm_desc& d) {
     if (!ok) return ASIS_EINVAL;
   }
   if (d.ksplit > 1 && !(big_mode && d.conv)) return ASIS_EINVAL;
+  // ASIS_GEMM_P8 (default 1): dense launches with at least one 256x256 tile per CU run on the PERSISTENT form of the 8-phase
+  // kernel (gemm_p8.h: one workgroup per CU walks its tiles, the next tile's first K tile is staged during the last K tile of
+  // the current one, the epilogue's stores drain under the next tile) when K <= 2048 (at K = 4096 a tile is 64 K tiles long
+  // and the per-tile savings no longer pay for the static tile lists: 347 vs 341 us); split-precision halves (A_lo / B_lo)
+  // are further K parts of the same stream; 2 = any K, from 16 tiles on (tests); 3 = any K; 0 = never
+  {
+    if (g_gemm_p8 < 0) { const char* e = getenv("ASIS_GEMM_P8"); g_gemm_p8 = e ? atoi(e) : 1; }
+    if (g_gemm_noepi < 0) { const char* e = getenv("ASIS_GEMM_NOEPI"); g_gemm_noepi = e ? atoi(e) : 0; }
+    const int p8 = g_gemm_p8;
+    const int64_t p8_tiles = (int64_t)((d.M + 255) / 256) * ((d.N + 255) / 256);
+    const int kparts = 1 + (d.A_lo ? 1 : 0) + (d.B_lo ? 1 : 0);
+    auto al = [](const void* p, int a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; };
+    if (p8 && big_mode && ph8_m16_on() && !d.conv && !d.stats && d.batch == 1 && !d.bias_m && d.ksplit <= 1 && d.K % 64 == 0 &&
+        d.M >= 256 && d.N >= 256 && p8_tiles >= (p8 == 2 ? 16 : 256) && d.K >= 128 && (p8 >= 2 || d.K * kparts <= 2048) &&
+        (int64_t)d.M * d.lda * 2 < (1ll << 32) && (int64_t)d.N * d.ldb * 2 < (1ll << 32) && d.N % 8 == 0 && d.ldc % 8 == 0 &&
+        al(d.C, 16) && (!d.res || (al(d.res, 16) && d.ldr % 4 == 0)) && (!d.bias_n || al(d.bias_n, 16)) && (!d.scale_n || al(d.scale_n, 16)) &&
+        (d.act != ASIS_ACT_GELU_GRAD || (d.aux && al(d.aux, 8) && d.ld_aux % 4 == 0))) {
+      const int nwg = p8_tiles >= 256 ? 256 : (int)(p8_tiles / 8) * 8;
+      if (g_gemm_noepi) hipLaunchKernelGGL((gemm_p8_kernel<T, 1>), dim3(nwg), dim3(512), 0, s, d, group_m);
+      else hipLaunchKernelGGL((gemm_p8_kernel<T, 0>), dim3(nwg), dim3(512), 0, s, d, group_m);
+      return 0;
+    }
+  }
   if (split) {  // one pass over the virtual 3K reduction; only on the large-tile kernel
     const bool ok = big_mode && d.K % BK == 0 && d.M >= 256 && d.N >= 32 && vec_ok && (d.out_f32 || !d.conv) &&
                     (!d.conv || (d.Cin % BK == 0 && d.A_lo && d.B_lo));
@@ -308,23 +331,6 @@ int launch(hipStream_t s, const asis_gemm_desc& d) {
 #undef PERSIST
   }
   if (ph8 && (ph8 == 2 || d.K >= 2048 || (ph8 == 1 && d.K >= ph8_mink && (int64_t)((d.M + 255) / 256) * ((d.N + 255) / 256) * d.batch >= 128)) && big_mode && !d.conv && !d.stats && d.K % 64 == 0 && d.M >= 256 && d.N >= 256) {
-    // ASIS_GEMM_P8 (default 1): launches with at least one tile per CU run on the PERSISTENT form of the 8-phase kernel
-    // (gemm_p8.h: one workgroup per CU walks its tiles, the next tile's first K tile is staged during the last K tile of
-    // the current one, the epilogue's stores drain under the next tile) when K <= 2048 (at K = 4096 a tile is 64 K tiles long and
-    // the per-tile savings no longer pay for the static tile lists: 347 vs 341 us); 2 = any K, from 16 tiles on (tests); 3 = any K; 0 = never
-    if (g_gemm_p8 < 0) { const char* e = getenv("ASIS_GEMM_P8"); g_gemm_p8 = e ? atoi(e) : 1; }
-    const int p8 = g_gemm_p8;
-    const int64_t p8_tiles = (int64_t)((d.M + 255) / 256) * ((d.N + 255) / 256);
-    auto al = [](const void* p, int a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; };
-    if (p8 && ph8_m16_on() && d.batch == 1 && !d.bias_m && p8_tiles >= (p8 == 2 ? 16 : 256) && d.K >= 128 && (p8 >= 2 || d.K <= 2048) &&
-        (int64_t)d.M * d.lda * 2 < (1ll << 32) && (int64_t)d.N * d.ldb * 2 < (1ll << 32) && d.N % 8 == 0 && d.ldc % 8 == 0 &&
-        al(d.C, 16) && (!d.res || (al(d.res, 16) && d.ldr % 4 == 0)) && (!d.bias_n || al(d.bias_n, 16)) && (!d.scale_n || al(d.scale_n, 16)) &&
-        (d.act != ASIS_ACT_GELU_GRAD || (d.aux && al(d.aux, 8) && d.ld_aux % 4 == 0))) {
-      const int nwg = p8_tiles >= 256 ? 256 : (int)(p8_tiles / 8) * 8;
-      if (noepi) hipLaunchKernelGGL((gemm_p8_kernel<T, 1>), dim3(nwg), dim3(512), 0, s, d, group_m);
-      else hipLaunchKernelGGL((gemm_p8_kernel<T, 0>), dim3(nwg), dim3(512), 0, s, d, group_m);
-      return 0;
-    }
     // 256x256x64 tile, 8-phase main loop (one workgroup per CU: 128 KB of LDS)
     dim3 grid(((d.M + 255) / 256) * ((d.N + 255) / 256), d.batch), block(512);
     // ASIS_GEMM_8P_M16 (default 1): the phases issue 16 v_mfma_f32_16x16x32 instead of 8 32x32x16 (same FLOP, higher clock)

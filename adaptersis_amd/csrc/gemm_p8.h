@@ -20,7 +20,9 @@
 // XCD); inside an XCD's range workgroup l takes positions l, l + 32, ...: at any time the 32 CUs of an XCD work on 32
 // consecutive positions = 8 x 4 / 4 x 8 tiles, the shape that minimises (rows + columns) of operand panels per L2.
 //
-// Host contract (gemm.hip checks it; anything else runs on gemm_big.h): dense, batch 1, no stats / bias_m / split halves,
+// Split-precision operands (asis_gemm_desc.A_lo / B_lo, include/asis_hip.h): the K stream of a tile runs over 2 or 3
+// K-long parts (A, B), (A_lo, B), (A, B_lo) — only the wave-uniform operand BASE changes between parts.
+// Host contract (gemm.hip checks it; anything else runs on gemm_big.h): dense, batch 1, no stats / bias_m,
 // K % 64 == 0, N % 8 == 0, every pointer 16-byte aligned, ldc / ldr / ld_aux multiples of 8 (no scalar epilogue here).
 #pragma once
 #include "asis_common.h"
@@ -60,8 +62,10 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(const asis_gemm_desc d,
     n0 = tn * BN;
   };
 
-  const T* __restrict__ A = reinterpret_cast<const T*>(d.A);
-  const T* __restrict__ B = reinterpret_cast<const T*>(d.B);
+  const char* A = reinterpret_cast<const char*>(d.A);     // operand bases of the K part being STAGED (wave-uniform)
+  const char* B = reinterpret_cast<const char*>(d.B);
+  const int nparts = 1 + (d.A_lo ? 1 : 0) + (d.B_lo ? 1 : 0);
+  int spart = 0;
   // staging order of the 8-phase loop (gemm_big.h): instructions 0,1 of a wave stage the row halves 0 of both wave rows,
   // 2,3 the halves 1; for B the column halves 0 / 1 of the four wave columns
   auto grp_a = [&](int j) -> int { const int g = wid * 2 + (j & 1); return (g < 8 ? 0 : 128) + (j >> 1) * 64 + (g & 7) * 8; };
@@ -98,21 +102,34 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(const asis_gemm_desc d,
   uint32_t sk0 = 0;     // K offset (bytes) of the K tile being staged
   int g = 0;            // running K tile count: K tile g lives in stage g & 1
   auto dma_a = [&](int stage, int j) {
-    __builtin_amdgcn_global_load_lds((glb_ptr)(reinterpret_cast<const char*>(A) + (asrc[j] + sk0)), (lds_ptr)(lds + stage * STAGE + grp_a(j) * BK), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((glb_ptr)(A + (asrc[j] + sk0)), (lds_ptr)(lds + stage * STAGE + grp_a(j) * BK), 16, 0, 0);
   };
   auto dma_b = [&](int stage, int j) {
-    __builtin_amdgcn_global_load_lds((glb_ptr)(reinterpret_cast<const char*>(B) + (bsrc[j] + sk0)), (lds_ptr)(lds + stage * STAGE + BM * BK + grp_b(j) * BK), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((glb_ptr)(B + (bsrc[j] + sk0)), (lds_ptr)(lds + stage * STAGE + BM * BK + grp_b(j) * BK), 16, 0, 0);
   };
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     dma_a(0, j);
     dma_b(0, j);
   }
-  sk0 = BK * 2;
+  // source of the next K tile to stage: K offset, then the next part (its operand bases), wrapping to part 0 = the next tile
+  auto advance = [&]() {
+    sk0 += BK * 2;
+    if (sk0 == (uint32_t)d.K * 2u) {
+      sk0 = 0;
+      if (nparts > 1) {
+        spart = spart + 1 == nparts ? 0 : spart + 1;
+        const bool alo = spart == 1 && d.A_lo, blo = spart != 0 && !alo;
+        A = reinterpret_cast<const char*>(alo ? d.A_lo : d.A);
+        B = reinterpret_cast<const char*>(blo ? d.B_lo : d.B);
+      }
+    }
+  };
+  advance();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
-  const int nt = d.K / BK;
+  const int nt = nparts * (d.K / BK);
   f32x4 acc[8][4];      // 16x16 C^T tiles: lane (r16, q16) owns row r16, columns 4 q16 .. 4 q16 + 3
   v8 af[2][4], b0f[4], b1f[4];
   auto rd_a = [&](const T* As, int rh) {
@@ -204,8 +221,7 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(const asis_gemm_desc d,
         dma_a(ns, 2); dma_a(ns, 3);
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       }
-      sk0 += BK * 2;
-      if (sk0 == (uint32_t)d.K * 2u) sk0 = 0;
+      advance();
       __builtin_amdgcn_s_barrier();
       mma(1, 0, b0f);
       __builtin_amdgcn_s_barrier();

@@ -194,16 +194,18 @@ class Attention(_Packed):
 
     def attend(self, xn: torch.Tensor, B: int, N: int) -> torch.Tensor:
         """xn: 16-bit [B*N, D] (already normalised) -> 16-bit attention output [B*N, D] (before proj)."""
-        return self.attend_rows(xn, [(B, N)])
+        return self.attend_rows(xn, [(B, N)])[0]
 
-    def attend_rows(self, xn: torch.Tensor, segs) -> torch.Tensor:
+    def attend_rows(self, xn: torch.Tensor, segs):
         """Several token batches stacked along the rows (``segs`` = [(B, N), ...], e.g. the cls+pos pass and the raw
-        patch-token pass of `train.py:287,300-302`): one q|k GEMM over all rows, attention per batch."""
+        patch-token pass of `train.py:287,300-302`): one q|k GEMM over all rows, attention per batch.
+        -> (o, o_lo): o_lo = the rounding residual of o (config.split_attn_out) or None."""
         D = xn.shape[1]
         w = self._w16("qkv", self.qkv.weight)  # [3D, D] rows q | k | v
         bias = self._f32("qkv_b", self.qkv.bias)
         wlo = self._w16lo("qkv", self.qkv.weight)
         o = torch.empty((xn.shape[0], D), device=xn.device, dtype=xn.dtype)
+        o_lo = torch.empty_like(o) if config.split_attn_out else None   # rounding residual of o: proj's split A operand
         one_launch = len(segs) == 2
         ldv_all = (max(n for _, n in segs) + 63) // 64 * 64
         vt_all = torch.empty((sum(b for b, _ in segs), D, ldv_all), device=xn.device, dtype=xn.dtype) if one_launch else None
@@ -230,17 +232,18 @@ class Attention(_Packed):
                          out=vt.as_strided((B, D, N4), (D * ldvt, ldvt, 1)), bias_m=None if bias is None else bias[2 * D:],
                          a_lo=None if wlo is None else wlo[2 * D:])
             if not one_launch:
-                ops.attention_fwd(qk[r0:r1, :D], qk[r0:r1, D:], vt, B, self.num_heads, N, self.scale, out=o[r0:r1])
+                ops.attention_fwd(qk[r0:r1, :D], qk[r0:r1, D:], vt, B, self.num_heads, N, self.scale, out=o[r0:r1],
+                                  out_lo=None if o_lo is None else o_lo[r0:r1])
             r0, b0 = r1, b0 + B
         if side is not None:
             qk = ops.gemm(xn, w[: 2 * D], bias_n=None if bias is None else bias[: 2 * D], b_lo=None if wlo is None else wlo[: 2 * D])
             main.wait_stream(side)
         if one_launch:  # both token batches in one launch (fewer partial rounds of workgroups)
             (B1, N1), (B2, N2) = segs
-            ops.attention_fwd_seg(qk[:, :D], qk[:, D:], vt_all, B1, N1, B2, N2, self.num_heads, self.scale, out=o)
+            ops.attention_fwd_seg(qk[:, :D], qk[:, D:], vt_all, B1, N1, B2, N2, self.num_heads, self.scale, out=o, out_lo=o_lo)
         if r0 != xn.shape[0]:
             raise ValueError("attend_rows: segments do not cover the rows")
-        return o
+        return o, o_lo
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         raise RuntimeError("Attention is driven by Block.forward (LayerNorm / LayerScale / residual are fused around it)")
@@ -319,9 +322,9 @@ class Block(_Packed):
         g2 = self._f32("g2", self.ls2.gamma) if isinstance(self.ls2, LayerScale) else None
         xn = torch.empty((x2.shape[0] + 4, D), device=x2.device, dtype=dt)[: x2.shape[0]]   # 4 spare rows: see attend_rows
         ops.layernorm(x2, self._f32("n1w", self.norm1.weight), self._f32("n1b", self.norm1.bias), self.norm1.eps, dt, out=xn)
-        o = self.attn.attend_rows(xn, segs)
+        o, o_lo = self.attn.attend_rows(xn, segs)
         x1 = ops.gemm(o, self.attn._w16("proj", self.attn.proj.weight), out_f32=True,
-                      bias_n=self.attn._f32("proj_b", self.attn.proj.bias), scale_n=g1, res=x2,
+                      bias_n=self.attn._f32("proj_b", self.attn.proj.bias), scale_n=g1, res=x2, a_lo=o_lo,
                       b_lo=self.attn._w16lo("proj", self.attn.proj.weight))
         xn2 = ops.layernorm(x1, self._f32("n2w", self.norm2.weight), self._f32("n2b", self.norm2.bias),
                             self.norm2.eps, dt)
@@ -363,19 +366,21 @@ class Block(_Packed):
         xn = ops.layernorm(x2, self._f32("n1w", self.norm1.weight), self._f32("n1b", self.norm1.bias), self.norm1.eps, dt)
         qkv = ops.gemm(xn, a._w16("qkv", a.qkv.weight), bias_n=a._f32("qkv_b", a.qkv.bias), b_lo=a._w16lo("qkv", a.qkv.weight))
         o = torch.empty((x2.shape[0], D), device=x2.device, dtype=dt)
+        o_lo = torch.empty_like(o) if config.split_attn_out else None
         lse = []
         r0 = 0
         for B, N in segs:
             r1 = r0 + B * N
             vt = ops.transpose_tokens(qkv[r0:r1, 2 * D:], B, N)
             l = torch.empty((B, a.num_heads, N), device=x2.device, dtype=torch.float32)
-            ops.attention_fwd(qkv[r0:r1, :D], qkv[r0:r1, D:2 * D], vt, B, a.num_heads, N, a.scale, out=o[r0:r1], lse=l)
+            ops.attention_fwd(qkv[r0:r1, :D], qkv[r0:r1, D:2 * D], vt, B, a.num_heads, N, a.scale, out=o[r0:r1], lse=l,
+                              out_lo=None if o_lo is None else o_lo[r0:r1])
             lse.append(l)
             r0 = r1
         if r0 != x2.shape[0]:
             raise ValueError("forward_train_rows: segments do not cover the rows")
         x1 = ops.gemm(o, a._w16("proj", a.proj.weight), out_f32=True, bias_n=a._f32("proj_b", a.proj.bias), scale_n=g1,
-                      res=x2, b_lo=a._w16lo("proj", a.proj.weight))
+                      res=x2, a_lo=o_lo, b_lo=a._w16lo("proj", a.proj.weight))
         xn2 = ops.layernorm(x1, self._f32("n2w", self.norm2.weight), self._f32("n2b", self.norm2.bias), self.norm2.eps, dt)
         if isinstance(m, Mlp):
             hpre = ops.gemm(xn2, m._w16("fc1", m.fc1.weight), bias_n=m._f32("fc1_b", m.fc1.bias))

@@ -236,32 +236,42 @@ def layernorm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float = 1e
     return out
 
 
+def _check_out_lo(out: torch.Tensor, out_lo: Optional[torch.Tensor]) -> None:
+    if out_lo is not None and (out_lo.shape != out.shape or out_lo.stride() != out.stride() or out_lo.dtype != out.dtype):
+        raise ValueError("attention_fwd: out_lo must share the shape, layout and dtype of out")
+
+
 def attention_fwd(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, B: int, H: int, N: int, scale: float,
-                  out: Optional[torch.Tensor] = None, lse: Optional[torch.Tensor] = None) -> torch.Tensor:
+                  out: Optional[torch.Tensor] = None, lse: Optional[torch.Tensor] = None,
+                  out_lo: Optional[torch.Tensor] = None) -> torch.Tensor:
     """q, k: [B*N, >=H*64] views (same row stride); vt: [B, H*64, ldvt]; returns o [B*N, H*64].
-    ``lse``: optional fp32 [B,H,N] receiving the per-query log2-sum-exp (training forward)."""
-    _dev(q, k, vt, out, lse)
+    ``lse``: optional fp32 [B,H,N] receiving the per-query log2-sum-exp (training forward).
+    ``out_lo``: optional tensor laid out like ``out`` receiving the rounding residual of the 16-bit output (o ~= out + out_lo:
+    the projection GEMM's split A operand, config.split_attn_out)."""
+    _dev(q, k, vt, out, lse, out_lo)
     if q.stride(0) != k.stride(0) or q.stride(1) != 1 or k.stride(1) != 1:
         raise ValueError("attention_fwd: q and k must share a row stride and be contiguous in the last dim")
     if out is None:
         out = torch.empty((B * N, H * 64), device=q.device, dtype=q.dtype)
     if lse is not None and (lse.dtype != torch.float32 or lse.numel() != B * H * N or not lse.is_contiguous()):
         raise ValueError("attention_fwd: lse must be contiguous float32 [B,H,N]")
-    check(lib().asis_attention_fwd_lse(_stream(), _dt(q.dtype), q.data_ptr(), k.data_ptr(), q.stride(0), vt.data_ptr(),
-                                       vt.stride(1), out.data_ptr(), out.stride(0), B, H, N, float(scale), _p(lse)),
-          "asis_attention_fwd")
+    _check_out_lo(out, out_lo)
+    check(lib().asis_attention_fwd_split(_stream(), _dt(q.dtype), q.data_ptr(), k.data_ptr(), q.stride(0), vt.data_ptr(),
+                                         vt.stride(1), out.data_ptr(), _p(out_lo), out.stride(0), B, N, 0, 0, H, float(scale),
+                                         _p(lse)), "asis_attention_fwd")
     return out
 
 
 def attention_fwd_seg(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, B1: int, N1: int, B2: int, N2: int, H: int,
-                      scale: float, out: torch.Tensor) -> torch.Tensor:
+                      scale: float, out: torch.Tensor, out_lo: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Two stacked token batches in one launch: q, k [B1*N1 + B2*N2, >=H*64] row views, vt [B1+B2, H*64, ldvt]."""
-    _dev(q, k, vt, out)
+    _dev(q, k, vt, out, out_lo)
+    _check_out_lo(out, out_lo)
     if q.stride(0) != k.stride(0) or q.stride(1) != 1 or k.stride(1) != 1 or q.shape[0] != B1 * N1 + B2 * N2:
         raise ValueError("attention_fwd_seg: q and k must be row views over both batches with one row stride")
-    check(lib().asis_attention_fwd_seg(_stream(), _dt(q.dtype), q.data_ptr(), k.data_ptr(), q.stride(0), vt.data_ptr(),
-                                       vt.stride(1), out.data_ptr(), out.stride(0), B1, N1, B2, N2, H, float(scale), None),
-          "asis_attention_fwd")
+    check(lib().asis_attention_fwd_split(_stream(), _dt(q.dtype), q.data_ptr(), k.data_ptr(), q.stride(0), vt.data_ptr(),
+                                         vt.stride(1), out.data_ptr(), _p(out_lo), out.stride(0), B1, N1, B2, N2, H, float(scale),
+                                         None), "asis_attention_fwd")
     return out
 
 
@@ -1090,7 +1100,7 @@ def sgd_momentum(p: torch.Tensor, g: torch.Tensor, buf: torch.Tensor, lr: float,
 def augment(img_u8: torch.Tensor, mask_u8: torch.Tensor, tables: dict):
     """uint8 [B,S,S,3] / uint8 [B,S,S] + the per-sample tables of ``tools.augment.TrainAugment.tables`` ->
     (fp32 [B,3,S,S] in [0,1], int64 [B,S,S])."""
-    _dev(img_u8, mask_u8, *tables.values())
+    _dev(img_u8, mask_u8, *[t for t in tables.values() if torch.is_tensor(t)])
     B, S = img_u8.shape[0], img_u8.shape[1]
     if img_u8.dtype != torch.uint8 or mask_u8.dtype != torch.uint8 or img_u8.shape != (B, S, S, 3) or mask_u8.shape != (B, S, S) \
             or not img_u8.is_contiguous() or not mask_u8.is_contiguous():
@@ -1104,6 +1114,25 @@ def augment(img_u8: torch.Tensor, mask_u8: torch.Tensor, tables: dict):
             raise ValueError(f"augment: table {k} must be contiguous {dt} {shp}")
     out = torch.empty((B, 3, S, S), device=img_u8.device, dtype=torch.float32)
     mout = torch.empty((B, S, S), device=img_u8.device, dtype=torch.int64)
+    cl = tables.get("clahe")
+    if cl is not None and tables.get("clahe_any", True):
+        # CLAHE samples in the batch (train.py:161): geometric stage -> uint8, tile LUTs, blend + Lab -> RGB + tables + / 255
+        from .tools import clahe as _cl
+        if cl.dtype != torch.int32 or tuple(cl.shape) != (B, 2) or not cl.is_contiguous():
+            raise ValueError("augment: table clahe must be contiguous int32 (B, 2)")
+        _dev(cl)
+        lt = _cl.lab_tables(img_u8.device)
+        geo8 = torch.empty((B, S, S, 3), device=img_u8.device, dtype=torch.uint8)
+        check(lib().asis_augment_geo_u8(_stream(), img_u8.data_ptr(), mask_u8.data_ptr(), tables["geo"].data_ptr(),
+                                        tables["xofs"].data_ptr(), tables["yofs"].data_ptr(), tables["xa"].data_ptr(),
+                                        tables["ya"].data_ptr(), tables["mx"].data_ptr(), tables["my"].data_ptr(),
+                                        geo8.data_ptr(), mout.data_ptr(), B, S), "asis_augment_geo_u8")
+        luts = torch.empty((B, _cl.TILES, _cl.TILES, 256), device=img_u8.device, dtype=torch.uint8)
+        check(lib().asis_clahe(_stream(), geo8.data_ptr(), cl.data_ptr(), lt["gamma"].data_ptr(), lt["cbrt"].data_ptr(),
+                               lt["l2yf"].data_ptr(), lt["ab2xz"].data_ptr(), lt["invgamma"].data_ptr(),
+                               lt["fwd"].ctypes.data, lt["inv"].ctypes.data, luts.data_ptr(), tables["lut"].data_ptr(),
+                               out.data_ptr(), B, S, _cl.TILES), "asis_clahe")
+        return out, mout
     check(lib().asis_augment(_stream(), img_u8.data_ptr(), mask_u8.data_ptr(), tables["geo"].data_ptr(),
                              tables["xofs"].data_ptr(), tables["yofs"].data_ptr(), tables["xa"].data_ptr(),
                              tables["ya"].data_ptr(), tables["mx"].data_ptr(), tables["my"].data_ptr(), tables["lut"].data_ptr(),

@@ -12,8 +12,10 @@ What the reference composes (albumentations, version unpinned in `README.md:12`;
     CLAHE(p=0.8); RandomBrightnessContrast(p=0.8); RandomGamma(p=0.8)
 
 Built here: crop + cv2.resize back to S x S (INTER_LINEAR, 8-bit fixed-point form; mask INTER_NEAREST), flip, rot90,
-brightness/contrast and gamma as uint8 look-up tables (exactly how albumentations applies them to uint8 images),
-float / 255.  CLAHE (OpenCV LAB conversion + tiled histogram equalisation) is NOT built: ``clahe_p`` must stay 0.
+CLAHE (OpenCV's 8-bit RGB <-> Lab integer paths + tiled contrast-limited equalisation of L on the 8 x 8 grid, clip limit
+~ U(1, 4): ``tools/clahe.py`` + the ``asis_clahe`` kernels), brightness/contrast and gamma as uint8 look-up tables (exactly how
+albumentations applies them to uint8 images), float / 255.  A batch with CLAHE samples runs three kernels (the tile histograms
+need the whole geometrically transformed image), a batch without any runs the single fused one.
 The random draws come from this module's own ``numpy`` generator — the same distributions, not albumentations' stream.
 """
 from __future__ import annotations
@@ -24,6 +26,7 @@ import numpy as np
 import torch
 
 from .. import ops
+from . import clahe as _clahe
 
 COEF_BITS = 11   # OpenCV INTER_RESIZE_COEF_BITS
 
@@ -71,11 +74,12 @@ def gamma_lut(gamma: float) -> np.ndarray:
 
 class TrainAugment:
     def __init__(self, size: int = 588, seed: int = 0, crop_p: float = 0.5, pad_p: float = 1.0, flip_p: float = 0.5,
-                 rot_p: float = 0.5, clahe_p: float = 0.0, bc_p: float = 0.8, gamma_p: float = 0.8,
-                 min_crop: Optional[int] = None):
-        if clahe_p:
-            raise ValueError("CLAHE is not built on the GPU pipeline (OpenCV LAB + tiled equalisation): keep clahe_p = 0")
+                 rot_p: float = 0.5, clahe_p: float = 0.8, bc_p: float = 0.8, gamma_p: float = 0.8,
+                 min_crop: Optional[int] = None, clahe_clip=(1.0, 4.0)):
+        if size < 16:
+            raise ValueError("TrainAugment: size must be at least 16 (8 x 8 CLAHE tile grid)")
         self.size = size
+        self.clahe_p, self.clahe_clip = clahe_p, clahe_clip        # A.CLAHE(clip_limit=4.0) -> clip ~ U(1, 4), tiles (8, 8)
         self.min_crop = int(size * 0.5) if min_crop is None else min_crop      # min_max_height=(int(588*0.5), 588)
         self.p_crop = crop_p / (crop_p + pad_p)                                # OneOf normalises its members' p
         self.flip_p, self.rot_p, self.bc_p, self.gamma_p = flip_p, rot_p, bc_p, gamma_p
@@ -87,7 +91,7 @@ class TrainAugment:
         S, r = self.size, self.rng
         out = []
         for _ in range(n):
-            p: Dict = {"crop": None, "flip": False, "rotk": 0, "alpha": 1.0, "beta": 0.0, "gamma": None}
+            p: Dict = {"crop": None, "flip": False, "rotk": 0, "clahe": None, "alpha": 1.0, "beta": 0.0, "gamma": None}
             if r.random_sample() < self.p_crop:
                 ch = int(r.randint(self.min_crop, S + 1))          # random.randint(min, max), both inclusive
                 cw = ch                                            # w2h_ratio = 1.0
@@ -98,6 +102,8 @@ class TrainAugment:
             p["flip"] = bool(r.random_sample() < self.flip_p)
             if r.random_sample() < self.rot_p:
                 p["rotk"] = int(r.randint(0, 4))
+            if r.random_sample() < self.clahe_p:
+                p["clahe"] = float(r.uniform(*self.clahe_clip))
             if r.random_sample() < self.bc_p:
                 p["alpha"] = 1.0 + r.uniform(-0.2, 0.2)
                 p["beta"] = 0.0 + r.uniform(-0.2, 0.2)
@@ -114,7 +120,10 @@ class TrainAugment:
         xa = np.zeros((B, S, 2), np.int16); ya = np.zeros((B, S, 2), np.int16)
         mx = np.zeros((B, S), np.int32); my = np.zeros((B, S), np.int32)
         lut = np.zeros((B, 256), np.uint8)
+        clahe = np.zeros((B, 2), np.int32)
         for b, p in enumerate(params):
+            if p.get("clahe") is not None:
+                clahe[b] = (1, _clahe.clip_limit_int(p["clahe"], S))
             geo[b] = (int(p["flip"]), p["rotk"], int(p["crop"] is None), 0)
             if p["crop"] is not None:
                 x1, y1, cw, ch = p["crop"]
@@ -126,8 +135,10 @@ class TrainAugment:
             if p["gamma"] is not None:
                 l = gamma_lut(p["gamma"])[l]
             lut[b] = l
-        t = dict(geo=geo, xofs=xofs, yofs=yofs, xa=xa, ya=ya, mx=mx, my=my, lut=lut)
-        return {k: torch.from_numpy(v).to(device, non_blocking=True) for k, v in t.items()}
+        t = dict(geo=geo, xofs=xofs, yofs=yofs, xa=xa, ya=ya, mx=mx, my=my, lut=lut, clahe=clahe)
+        out = {k: torch.from_numpy(v).to(device, non_blocking=True) for k, v in t.items()}
+        out["clahe_any"] = bool(clahe[:, 0].any())      # host flag: no CLAHE sample -> the single fused kernel
+        return out
 
     def __call__(self, img_u8: torch.Tensor, mask_u8: torch.Tensor, params=None):
         """uint8 [B,S,S,3] + uint8 [B,S,S] on the device -> (fp32 [B,3,S,S] in [0,1], int64 [B,S,S])."""

@@ -35,7 +35,14 @@ class Robomis(torch.utils.data.Dataset):
             img, mask = np.array(self.arrays[0][index]), np.array(self.arrays[1][index])   # copies out of the memory map
             if img.dtype != np.uint8:                       # float [3,H,W] in [0,1] -> uint8 HWC
                 img = np.clip(np.rint(np.moveaxis(img, 0, -1) * 255.0), 0, 255).astype(np.uint8)
-            return img, (mask > 0).astype(np.uint8)
+            mask = (mask > 0).astype(np.uint8)
+            if self.imsize is not None and img.shape[:2] != (self.imsize, self.imsize):
+                # same resize as the PNG path (`tools/dataset.py:147-149`): PIL BILINEAR for the image, NEAREST for the mask
+                from PIL import Image
+                img = np.array(Image.fromarray(img).resize((self.imsize, self.imsize), resample=Image.BILINEAR)).astype(np.uint8)
+                mask = np.array(Image.fromarray(mask * 255).resize((self.imsize, self.imsize), resample=Image.NEAREST))
+                mask = (mask > 0).astype(np.uint8)
+            return img, mask
         from PIL import Image
         with open(self.img_files[index], "rb") as f:
             img = Image.open(f).convert("RGB")

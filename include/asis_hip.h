@@ -141,6 +141,12 @@ int asis_attention_fwd(void* stream, int dtype, const void* q, const void* k, in
  * B2 = 0: one batch (then lse2 may be given, see below). */
 int asis_attention_fwd_seg(void* stream, int dtype, const void* q, const void* k, int64_t ldqk, const void* vt, int64_t ldvt,
                            void* o, int64_t ldo, int B1, int N1, int B2, int N2, int H, float scale, float* lse2);
+/* same, with an optional second output o_lo (NULL = none; layout of o): the rounding residual of the 16-bit output,
+ * o_exact ~= o + o_lo with ~22 significant bits.  The projection GEMM (attention.py:67) takes it as asis_gemm_desc.A_lo:
+ * rounding the attention output to 16 bits is white noise on the residual stream of every block, which spatially
+ * sensitive decode heads amplify (tests/precision_probe.py: the largest single error term on the UNet / MLA logits). */
+int asis_attention_fwd_split(void* stream, int dtype, const void* q, const void* k, int64_t ldqk, const void* vt, int64_t ldvt,
+                             void* o, void* o_lo, int64_t ldo, int B1, int N1, int B2, int N2, int H, float scale, float* lse2);
 /* same, also writing lse2[B,H,N] = log2 sum_k exp2(log2(e) * scale * q.k) per query (what asis_attention_bwd
  * needs to rebuild the probabilities); lse2 NULL = asis_attention_fwd */
 int asis_attention_fwd_lse(void* stream, int dtype, const void* q, const void* k, int64_t ldqk, const void* vt,
@@ -502,6 +508,20 @@ int asis_sgd_momentum(void* stream, float* p, const float* g, float* buf, int64_
 int asis_augment(void* stream, const uint8_t* img, const uint8_t* mask, const int32_t* geo, const int32_t* xofs,
                  const int32_t* yofs, const int16_t* xa, const int16_t* ya, const int32_t* mx, const int32_t* my,
                  const uint8_t* lut, float* out, int64_t* mask_out, int B, int S);
+/* CLAHE stage of the same pipeline (train.py:161 A.CLAHE(p=0.8); csrc/augment.hip).  A batch with CLAHE samples runs
+ *   asis_augment_geo_u8: the geometric stage of asis_augment alone -> uint8 RGB [B,S,S,3] + the final int64 mask;
+ *   asis_clahe: clahe int32 [B,2] = (apply flag, integer clip limit of CLAHE_Impl::apply) per sample; the five look-up tables
+ *     of OpenCV's initLabTabs (device: gamma u16[256], cbrt u16[3072], l2yf u16[256*2], ab2xz i32[36864], invgamma u8[4096])
+ *     and the two 3x3 12-bit matrices of RGB2Lab_b / Lab2RGBinteger (HOST int32[9] each); luts = workspace u8 [B,tiles,tiles,256];
+ *     lut u8 [B,256] = brightness/contrast + gamma table of asis_augment; out fp32 [B,3,S,S] in [0,1].  RGB -> Lab, tiled
+ *     contrast-limited equalisation of L (tiles x tiles grid, reflect-101 padding), Lab -> RGB, lut, / 255 — integer / table
+ *     arithmetic, bit-identical to the numpy restatement oracle/augment_ref.py. */
+int asis_augment_geo_u8(void* stream, const uint8_t* img, const uint8_t* mask, const int32_t* geo, const int32_t* xofs,
+                        const int32_t* yofs, const int16_t* xa, const int16_t* ya, const int32_t* mx, const int32_t* my,
+                        uint8_t* out_u8, int64_t* mask_out, int B, int S);
+int asis_clahe(void* stream, const uint8_t* rgb, const int32_t* clahe, const uint16_t* tab_gamma, const uint16_t* tab_cbrt,
+               const uint16_t* tab_l2yf, const int32_t* tab_ab2xz, const uint8_t* tab_invgamma, const int32_t* coef_fwd,
+               const int32_t* coef_inv, uint8_t* luts, const uint8_t* lut, float* out, int B, int S, int tiles);
 
 /* Overflow guard for the static loss scale of the 16-bit gradient tensors (the reference trains in fp32 and has no
  * counterpart; torch.cuda.amp.GradScaler.step has the same skip semantics).  guard = int32[2] in device memory:

@@ -53,6 +53,26 @@ def check():
             bad = int((~torch.isfinite(c.float())).sum())
             worst = max(worst, e if bad == 0 else 1.0)
             print(f"case {M}x{N}x{K} {name}: err {e * tol_scale:.2e} non-finite {bad} stable {same}")
+        # split-precision operands as further K parts of the persistent stream: A_lo alone (the attention output of
+        # config.split_attn_out), A_lo + B_lo
+        if K <= 1024:
+            a32 = W.tensor(f"p8.a32.{M}", (M, K), 1.0).to(dev)
+            b32 = W.tensor(f"p8.b32.{N}.{K}", (N, K), 1.0).to(dev)
+            ah, bh = a32.to(dt), b32.to(dt)
+            al, bl = (a32 - ah.float()).to(dt), (b32 - bh.float()).to(dt)
+            ops.gemm_set_option("p8", 3 if M * N >= 256 * 65536 else 2)
+            for name, kw, ref in (("A_lo f32 + res", dict(a_lo=al, out_f32=True, bias_n=bn, scale_n=sc, res=res),
+                                   res + sc * ((ah.float() + al.float()) @ bh.float().t() + bn)),
+                                  ("A_lo + B_lo f32", dict(a_lo=al, b_lo=bl, out_f32=True),
+                                   (ah.float() + al.float()) @ bh.float().t() + ah.float() @ bl.float().t())):
+                outs = [ops.gemm(ah, bh, **kw) for _ in range(3)]
+                torch.cuda.synchronize()
+                same = all(torch.equal(outs[0], o) for o in outs[1:])
+                e = float((outs[0] - ref).norm() / ref.norm())
+                unstable += 0 if same else 1
+                worst = max(worst, e)
+                print(f"case {M}x{N}x{K} {name}: err {e:.2e} stable {same}")
+            ops.gemm_set_option("p8", 2)
         # bit-identical to the one-tile-per-workgroup kernel (same arithmetic order)
         ops.gemm_set_option("p8", 0)
         o0 = ops.gemm(a, b, out_f32=True, bias_n=bn, scale_n=sc, res=res)

@@ -79,11 +79,18 @@ def patch_embed(img, sd, patch=14):
 _patch_embed = O.patch_embed
 
 
-HEAD = None   # "unet": also push x_final through the fp32 oracle UNet(D) (BASELINE config 2) and report its logits
+HEAD = None   # "unet": also push x_final through the fp32 oracle UNet(D) (BASELINE config 2) and report its logits;
+              # "mla": the `train_mla.py` flow (BASELINE config 5) -> DecoderMLA, 11 classes: MLA input 0 / output
+ONLY = None   # --sites a,b,c: restrict the per-site loop
 
 
 def run(img, sds, heads):
     taps = {}
+    if HEAD == "mla":
+        with torch.no_grad():
+            maps = O.mla_forward(img, sds["vit"], {k: v.clone() for k, v in sds["enc"].items()}, sds["cv"], sds["cn"], heads)
+            out = O.decoder_mla(*maps, sd={k: v.clone() for k, v in sds["mla"].items()}, img_size=img.shape[-1], update_bn=False)
+        return maps[0], maps[3], out
     with torch.no_grad():
         O.adapter_forward(img, sds["vit"], {k: v.clone() for k, v in sds["enc"].items()}, sds["cv"], sds["cn"], heads, taps=taps)
         x = taps["x_stage3"]
@@ -97,9 +104,17 @@ def run(img, sds, heads):
 
 def main():
     global DT, HEAD
+    global ONLY
     if "--unet" in sys.argv:
         sys.argv.remove("--unet")
         HEAD = "unet"
+    if "--mla" in sys.argv:
+        sys.argv.remove("--mla")
+        HEAD = "mla"
+    if "--sites" in sys.argv:
+        i = sys.argv.index("--sites")
+        ONLY = sys.argv[i + 1].split(",")
+        del sys.argv[i:i + 2]
     arch = sys.argv[1] if len(sys.argv) > 1 else "vit_base_d4"
     size = int(sys.argv[2]) if len(sys.argv) > 2 else 224
     if len(sys.argv) > 3 and sys.argv[3] == "bf16":
@@ -109,6 +124,8 @@ def main():
                cv=W.make_cavit_state_dict(D, mode="kernel"), cn=W.make_cacnn_state_dict(D, mode="kernel"))
     if HEAD == "unet":
         sds["unet"] = W.make_unet_state_dict(D, 2)
+    if HEAD == "mla":
+        sds["mla"] = W.make_decoder_mla_state_dict(D, 128, 11)
     img, _ = W.synthetic_batch(1, size)
     ref = run(img, sds, heads)
     O.attention, O.mlp, O.ms_deform_attn, O.conv_ffn, O.patch_embed = attention, mlp, ms_deform_attn, conv_ffn, patch_embed
@@ -116,16 +133,19 @@ def main():
     def err(tag):
         out = run(img, sds, heads)
         e = [float((a.double() - b.double()).norm() / b.double().norm()) for a, b in zip(out, ref)]
-        print(f"{tag:34s} x_final {e[0]:.2e}  c_final {e[1]:.2e}  {'UNet logits' if HEAD else 'passA feat'} {e[2]:.2e}", flush=True)
+        names = {"unet": ("x_final", "c_final", "UNet logits"), "mla": ("MLA in0", "MLA in3", "MLA output")}.get(HEAD, ("x_final", "c_final", "passA feat"))
+        print(f"{tag:34s} {names[0]} {e[0]:.2e}  {names[1]} {e[1]:.2e}  {names[2]} {e[2]:.2e}", flush=True)
         return e
     print(f"{arch} {size}x{size}, operands {DT}: rounding emulated at the listed sites only")
     ON.clear(); ON.update(SITES)
     err("ALL sites")
     ON.clear(); ON.update(s for s in SITES if s != "pe")
     err("ALL but pe (split-precision patch embed)")
-    for s in SITES:
-        ON.clear(); ON.add(s)
+    for s in (ONLY if ONLY is not None else SITES):
+        ON.clear(); ON.update(s.split("+"))
         err("only " + s)
+    if ONLY is not None:
+        return
     for grp in ("vit", "msda", "cffn"):
         ON.clear(); ON.update(s for s in SITES if s.startswith(grp))
         err(f"group {grp}")

@@ -40,8 +40,32 @@ def test_draw_distributions_and_luts():
     assert all(0.8 <= p["alpha"] <= 1.2 and -0.2 <= p["beta"] <= 0.2 for p in ps)
     assert np.array_equal(A.brightness_contrast_lut(1.0, 0.0), np.arange(256, dtype=np.uint8))
     assert A.gamma_lut(1.0)[255] == 255 and A.gamma_lut(1.2)[128] < 128 < A.gamma_lut(0.8)[128]
-    with pytest.raises(ValueError):
-        A.TrainAugment(clahe_p=0.8)
+    assert abs(frac(lambda p: p["clahe"] is not None) - 0.8) < 0.03            # A.CLAHE(p=0.8), train.py:161
+    clips = [p["clahe"] for p in ps if p["clahe"] is not None]
+    assert 1.0 <= min(clips) < 1.1 and 3.9 < max(clips) <= 4.0                  # clip_limit=4.0 -> U(1, 4)
+
+
+def test_clahe_tables_and_restatement():
+    """Product-side OpenCV Lab tables (tools/clahe.py) == the independent restatement's (oracle/augment_ref.py); the
+    restatement behaves like CLAHE: greys stay grey, a flat tile histogram is the identity up to rounding, contrast grows."""
+    from adaptersis_amd.tools import clahe as C
+    t, o = C.lab_tables_np(), R.lab_tables()
+    assert np.array_equal(t["gamma"], o["gamma"]) and np.array_equal(t["cbrt"], o["cbrt"])
+    assert np.array_equal(t["l2yf"].reshape(256, 2), o["l2yf"]) and np.array_equal(t["ab2xz"], o["ab2xz"])
+    assert np.array_equal(t["invgamma"], o["invgamma"])
+    assert np.array_equal(t["fwd"].reshape(3, 3), o["rgb2xyz"]) and np.array_equal(t["inv"].reshape(3, 3), o["xyz2rgb"])
+    assert t["fwd"].reshape(3, 3).sum(1).tolist() == [4096, 4096, 4096]
+    assert C.tile_edge(588) == 74 and C.tile_edge(64) == 8 and C.clip_limit_int(2.0, 588) == int(2.0 * 74 * 74 / 256)
+    assert C.clip_limit_int(2.0, 588) == R.clahe_clip_limit(2.0, 74 * 74) and C.clip_limit_int(0.001, 64) == 1
+    grey = np.stack([np.arange(256, dtype=np.uint8)] * 3, -1)[None].repeat(4, 0)
+    lab = R.rgb2lab_u8(grey)
+    assert lab[0, 0].tolist() == [0, 128, 128] and lab[0, 255].tolist() == [255, 128, 128] and lab[0, 128, 0] == 137
+    assert np.abs(R.lab2rgb_u8(lab).astype(int) - grey.astype(int)).max() <= 1
+    r = np.random.RandomState(1)
+    low = (r.randint(100, 140, (96, 96, 3))).astype(np.uint8)                     # low-contrast image
+    out = R.clahe_rgb_u8(low, 4.0)
+    assert out.std() > 1.5 * low.std() and out.shape == low.shape
+    assert np.abs(R.clahe_rgb_u8(low, 1.0).astype(int) - low.astype(int)).mean() < np.abs(out.astype(int) - low.astype(int)).mean()
 
 
 def test_dataset_npy_and_png(tmp_path):
@@ -81,10 +105,10 @@ def test_gpu_augment_bit_exact_vs_restatement(dev, S, B):
     aug = A.TrainAugment(size=S, seed=11)
     params = aug.draw(B)
     # make sure every branch is exercised in the batch
-    params[0].update(crop=None, flip=False, rotk=0, alpha=1.0, beta=0.0, gamma=None)          # identity
-    params[1].update(crop=(3, 5, S - 9, S - 9), flip=True, rotk=1)
-    params[2].update(crop=(0, 0, S // 2, S // 2), flip=False, rotk=3, alpha=1.17, beta=-0.11, gamma=0.83)
-    params[3].update(crop=(S // 2, S // 2 - 1, S // 2, S // 2), flip=True, rotk=2, gamma=1.19)
+    params[0].update(crop=None, flip=False, rotk=0, clahe=None, alpha=1.0, beta=0.0, gamma=None)          # identity
+    params[1].update(crop=(3, 5, S - 9, S - 9), flip=True, rotk=1, clahe=3.7)
+    params[2].update(crop=(0, 0, S // 2, S // 2), flip=False, rotk=3, clahe=1.0, alpha=1.17, beta=-0.11, gamma=0.83)
+    params[3].update(crop=(S // 2, S // 2 - 1, S // 2, S // 2), flip=True, rotk=2, clahe=None, gamma=1.19)
     out, mout = aug(torch.from_numpy(img).to(dev), torch.from_numpy(mask).to(dev), params)
     torch.cuda.synchronize()
     assert out.dtype == torch.float32 and tuple(out.shape) == (B, 3, S, S) and mout.dtype == torch.int64
@@ -106,3 +130,29 @@ def test_gpu_augment_feeds_the_engine(dev):
     assert float(x.min()) >= 0.0 and float(x.max()) <= 1.0
     loss = eng.train_step(x, y)
     assert torch.isfinite(loss).item()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("S", [64, 588, 100])
+def test_gpu_clahe_bit_exact_vs_restatement(dev, S):
+    """CLAHE alone (no geometry, identity tables) at a size with whole tiles (64), at the reference's 588 (74-pixel tiles of a
+    plane padded 588 -> 592 by reflection) and at 100 (13-pixel tiles, 4 padded rows); a batch without any CLAHE sample takes
+    the single fused kernel and equals the three-kernel path with every flag off."""
+    img, mask = _data(3, S, seed=S + 1)
+    img[1] = (img[1] // 4 + 90).astype(np.uint8)                  # a low-contrast sample: the clip limit binds
+    aug = A.TrainAugment(size=S, seed=1)
+    ident = dict(crop=None, flip=False, rotk=0, alpha=1.0, beta=0.0, gamma=None)
+    params = [dict(ident, clahe=1.0), dict(ident, clahe=4.0), dict(ident, clahe=2.3)]
+    out, mout = aug(torch.from_numpy(img).to(dev), torch.from_numpy(mask).to(dev), params)
+    torch.cuda.synchronize()
+    for b in range(3):
+        ref = R.clahe_rgb_u8(img[b], params[b]["clahe"]).transpose(2, 0, 1).astype(np.float32) / np.float32(255)
+        got = out[b].cpu().numpy()
+        assert np.array_equal(got, ref), (S, b, float(np.abs(got - ref).max()) * 255)
+        assert np.array_equal(mout[b].cpu().numpy(), mask[b].astype(np.int64))
+    none = [dict(ident, clahe=None)] * 3
+    t = aug.tables(none, dev)
+    a, _ = __import__("adaptersis_amd").ops.augment(torch.from_numpy(img).to(dev), torch.from_numpy(mask).to(dev), t)
+    t["clahe_any"] = True                                          # force the three-kernel path with every flag off
+    b_, _ = __import__("adaptersis_amd").ops.augment(torch.from_numpy(img).to(dev), torch.from_numpy(mask).to(dev), t)
+    assert torch.equal(a, b_)
