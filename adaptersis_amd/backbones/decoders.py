@@ -546,10 +546,14 @@ class DecoderMLA(_Packed):
         self._last_hw = 4 * h
         return logits, saved
 
-    def _backward_core(self, saved, d16, bias_partial, inv_scale, grads, dlogits_f32=None, stage_done=None, d_lo=None):
+    def _backward_core(self, saved, d16, bias_partial, inv_scale, grads, dlogits_f32=None, stage_done=None, d_lo=None,
+                       need_input_grad: bool = False):
+        """``need_input_grad`` (train_adapters on the `train_mla.py` flow): also return the gradients of the four input
+        maps, fp32 NHWC [B, h, w, mla_channels] each (still multiplied by the loss scale), in argument order."""
         fo = self.cls_3
         C = self.num_classes
         Cm = self.mlahead_channels
+        dins = []
         if bias_partial is not None:
             ops.reduce_rows(bias_partial, inv_scale, grads["cls_3.bias"])
         else:
@@ -575,10 +579,11 @@ class DecoderMLA(_Packed):
             p = f"mlahead.{hn}"
             dx = conv_bn_relu_up_backward(self, hn + "b", s2, dh, seq[3], seq[4], inv_scale, grads, p, True, self.sync_bn,
                                           conv_name=p + ".3", bn_name=p + ".4")
-            conv_bn_relu_up_backward(self, hn + "a", s1, dx, seq[0], seq[1], inv_scale, grads, p, False, self.sync_bn,
-                                     conv_name=p + ".0", bn_name=p + ".1")
+            dins.append(conv_bn_relu_up_backward(self, hn + "a", s1, dx, seq[0], seq[1], inv_scale, grads, p, need_input_grad,
+                                                 self.sync_bn, conv_name=p + ".0", bn_name=p + ".1"))
         if stage_done is not None:
             stage_done()
+        return dins if need_input_grad else None
 
     def forward(self, input, input1, input2, input3):
         """`decoders.py:82-89`: four (B, C, h, w) maps -> logits resized to (B, classes, img_size, img_size)."""

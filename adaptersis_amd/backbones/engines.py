@@ -133,12 +133,12 @@ class SegEngine(nn.Module):
             # the trainable set the reference's optimiser lists for the adapters (`train.py:178-186`) and that its
             # no_grad block (`:389-406`) and forward-only MSDeformAttnFunction keep from ever training (SURVEY facts
             # 1-2): CAViT + CACNN parameters, one flat bucket, all-reduced once the adapter backward is enqueued
-            if type(seg_decoder).__name__ not in ("FeatureDecoder", "DecoderSETR", "UNet"):
-                raise NotImplementedError("train_adapters is built for the train.py adapter flow (FeatureDecoder / UNet heads); "
-                                          "the train_mla.py stage order (block -> CACNN -> CAViT, repeated block) has no backward")
-            if self.stream_only and (train_encoder or train_backbone):
-                raise NotImplementedError("the UNet head trains decoder + adapters (BASELINE config 2); encoder / backbone "
-                                          "training is built for the FeatureDecoder flow")
+            if type(seg_decoder).__name__ not in ("FeatureDecoder", "DecoderSETR", "UNet", "DecoderMLA"):
+                raise NotImplementedError("train_adapters is built for the train.py adapter flow (FeatureDecoder / UNet heads) and "
+                                          "the train_mla.py flow (DecoderMLA)")
+            if self.is_mla and train_backbone:
+                raise NotImplementedError("the train_mla.py flow trains decoder + adapters (+ encoder); the unfrozen backbone "
+                                          "(BASELINE config 4) is the train.py adapter flow")
             for p in list(cross_vit.parameters()) + list(cross_cnn.parameters()):
                 p.requires_grad_(True)
             named_a = [("cross_vit." + n, p) for n, p in cross_vit.named_parameters()] + \
@@ -336,9 +336,11 @@ class SegEngine(nn.Module):
 
     # ------------------------------------------------------------------------------------------
     @torch.no_grad()
-    def features_mla(self, inp: torch.Tensor, taps: Optional[dict] = None):
+    def features_mla(self, inp: torch.Tensor, taps: Optional[dict] = None, adapter_saves: Optional[list] = None):
         """`train_mla.py:266-383`: -> the four MLA inputs [(hi, lo|None)] in decoder argument order
-        (output_last, output_last_2, output_last_3, output_last_4), each NHWC 16-bit [B, h, w, D]."""
+        (output_last, output_last_2, output_last_3, output_last_4), each NHWC 16-bit [B, h, w, D].
+        ``adapter_saves`` (train_adapters): receives, per adapter use, (saved activations of the frozen block in front of it on
+        pass B | None, CAViT save, CACNN save | None) — stage 0 is CAViT alone, stages 1..3 are block -> CACNN -> CAViT."""
         config.split_attn_out = self.split_attn_out
         m = self.model
         B, _, H, W = inp.shape
@@ -347,7 +349,12 @@ class SegEngine(nn.Module):
         h, w = H // self.patch, W // self.patch
         N = h * w
         nb = len(m.blocks)
-        _, c, shapes = self.backbone_encoder.forward_tokens(inp, need_c1=False)
+        train = self.mode == "train_adapters" and adapter_saves is not None
+        if train and self.train_encoder:
+            c, shapes, esaved = self.backbone_encoder.forward_tokens_train(inp)
+            self._esaved = (esaved, shapes)
+        else:
+            _, c, shapes = self.backbone_encoder.forward_tokens(inp, need_c1=False)
         Lc = c.shape[1]
         g = self._geometry(H, W, shapes, inp.device)
         tokens = m.patch_embed(inp)
@@ -361,17 +368,36 @@ class SegEngine(nn.Module):
         for blk in m.blocks[: nb - 3]:
             xcat = blk.forward_rows(xcat, segs)
         c2d = c.view(B * Lc, D)
-        x2 = self._cavit(xcat[Ra:], c2d, g, B, N, Lc)
+        if train:
+            x2, s_cv = self.cross_vit.forward16_train(xcat[Ra:].clone(), c2d, g, B, N, Lc)
+            adapter_saves.append((None, s_cv, None))
+        else:
+            x2 = self._cavit(xcat[Ra:], c2d, g, B, N, Lc)
         outs = [x2]
         for j, bi in enumerate((nb - 3, nb - 2, nb - 2)):  # the reference's repeated [-2:-1]
-            if j < 2:
+            bsaved = None
+            if train:   # pass B through the frozen block with saved activations (its input gradient is needed), pass A plain
+                if j < 2:
+                    xa_s = m.blocks[bi].forward_rows(xcat[:Ra], [(B, N + 1)])
+                    xb_s, bsaved = m.blocks[bi].forward_train(x2.view(B, N, D))
+                    xcat = torch.cat([xa_s, xb_s.reshape(B * N, D)], 0)
+                    x2 = xcat[Ra:]
+                else:
+                    xb_s, bsaved = m.blocks[bi].forward_train(x2.view(B, N, D))
+                    x2 = xb_s.reshape(B * N, D)
+            elif j < 2:
                 xcat[Ra:].copy_(x2)
                 xcat = m.blocks[bi].forward_rows(xcat, segs)
                 x2 = xcat[Ra:]
             else:
                 x2 = m.blocks[bi](x2.view(B, N, D)).view(B * N, D)
-            c2d = self._cacnn(c2d, x2, g, B, Lc, N, shapes)
-            x2 = self._cavit(x2, c2d, g, B, N, Lc)
+            if train:
+                c2d, s_cn = self.cross_cnn.forward16_train(c2d, x2.contiguous(), g, B, Lc, N, shapes)
+                x2, s_cv = self.cross_vit.forward16_train(x2.clone(), c2d, g, B, N, Lc)
+                adapter_saves.append((bsaved, s_cv, s_cn))
+            else:
+                c2d = self._cacnn(c2d, x2, g, B, Lc, N, shapes)
+                x2 = self._cavit(x2, c2d, g, B, N, Lc)
             outs.append(x2)
         xa = m.blocks[nb - 1](xcat[:Ra].view(B, N + 1, D))
         vit_last = m._final_norm(xa)[:, 1:]
@@ -393,11 +419,16 @@ class SegEngine(nn.Module):
         tensor (no host sync)."""
         dec = self.seg_decoder
         S = config.loss_scale
+        asaves = None
         if self.is_mla:
-            logits, saved = dec._forward_core(self.features_mla(inp, taps), save=True, training=True)
+            asaves = [] if self.mode == "train_adapters" else None
+            logits, saved = dec._forward_core(self.features_mla(inp, taps, asaves), save=True, training=True)
         elif self.train_backbone:
             cat, e2e = self._features_e2e(inp, taps)
-            logits, saved = dec._forward_core(cat[0], cat[1], save=True, training=True)
+            if self.stream_only:
+                logits, saved = dec._forward_core(cat[0], cat[1], save=True, training=True, need_input_grad=True)
+            else:
+                logits, saved = dec._forward_core(cat[0], cat[1], save=True, training=True)
         else:
             asaves = [] if self.mode == "train_adapters" else None
             cat = self.features(inp, taps, asaves)
@@ -415,9 +446,28 @@ class SegEngine(nn.Module):
         world = world_size(self.process_group)
         inv = 1.0 / (S * world)  # gradient mean over ranks folded into the un-scaling (DDP semantics)
         self.reducer.begin()
-        if self.mode == "train_adapters":
+        if self.mode == "train_adapters" and self.is_mla:
+            dmaps = dec._backward_core(saved, d16, bpart, inv, self.bucket.views, stage_done=self.reducer.stage_done, d_lo=d_lo,
+                                       need_input_grad=True)
+            self.adapter_reducer.begin()
+            dc0 = self._mla_adapter_backward(asaves, dmaps, inv)
+            self.adapter_reducer.stage_done()
+            if self.train_encoder:
+                self.encoder_reducer.begin()
+                self._encoder_backward(dc0, None, inv)
+                self.encoder_reducer.stage_done()
+                self.encoder_reducer.finish()
+            self.adapter_reducer.finish()
+        elif self.mode == "train_adapters":
             dcat = dec._backward_core(saved, d16, bpart, inv, self.bucket.views, stage_done=self.reducer.stage_done, d_lo=d_lo,
                                       need_input_grad=True)
+            if self.stream_only and (self.train_backbone or self.train_encoder):
+                # UNet head: the decoder input is the adapter stream alone; the encoder / backbone backward walks take the
+                # FeatureDecoder layout [stream | c4 (padded) | pass-A feature], whose other two gradient slices are zero here
+                Bq, hq, wq, Dq = dcat.shape
+                full = torch.zeros((Bq, hq, wq, 3 * Dq), device=dcat.device, dtype=dcat.dtype)
+                ops.copy_channels(dcat.view(-1, Dq), full.view(-1, 3 * Dq)[:, :Dq])
+                dcat = full
             self.adapter_reducer.begin()
             if self.train_backbone:
                 self.vit_reducer.begin()
@@ -503,6 +553,13 @@ class SegEngine(nn.Module):
             x = ops.add_f32(x2.view(B, N, D), feats[s], out=xcat[Ra:].view(B, N, D))
         if taps is not None:
             taps.update(feats=feats)
+        if self.stream_only:     # UNet head (BASELINE config 2 with everything trainable): the adapter stream alone
+            xs = x.reshape(B * N, D)
+            hi = ops.cast_pad(xs, D, config.operand_dtype).view(B, h, w, D)
+            lo = ops.cast_pad(xs, D, config.operand_dtype, part=1).view(B, h, w, D) if config.split_conv else None
+            if taps is not None:
+                taps.update(x_final=x, c_final=c2d.view(B, Lc, D), cat=hi)
+            return (hi, lo), (a16, bsaves, fin, asaves, (B, N, H, W))
         n4 = shapes[2][0] * shapes[2][1]
         cat = ops.decoder_input(x, c_orig[:, Lc - n4:], feats[-1], (h, w), shapes[2], config.operand_dtype, config.split_conv)
         if not config.split_conv:
@@ -618,20 +675,57 @@ class SegEngine(nn.Module):
         ops.reduce_rows(slabs, 1.0, ab.grad)
         return dc_next  # gradient of the encoder's pyramid tokens c (stage-0 input), fp32 [B*Lc, D]
 
+    def _mla_adapter_backward(self, asaves, dmaps, inv: float) -> torch.Tensor:
+        """Backward of the four adapter uses of the `train_mla.py:300-383` flow: x0 = CAViT(x, c0); for j = 1..3:
+        x = block_j(x_{j-1}), c_j = CACNN(c_{j-1}, x), x_j = CAViT(x, c_j); MLA inputs (x3 + f, x2, x1, x0).
+        ``dmaps``: gradients of the four MLA inputs in decoder argument order, fp32 [B, h, w, D], times the loss scale.
+        Writes the adapter bucket; -> gradient of the encoder's pyramid tokens c0, fp32 [B * Lc, D]."""
+        m, cv, cn = self.model, self.cross_vit, self.cross_cnn
+        nb = len(m.blocks)
+        B, h, w, D = dmaps[0].shape
+        N = h * w
+        ab = self.adapter_bucket
+        slabs = torch.zeros((4, ab.numel), device=dmaps[0].device, dtype=torch.float32)
+        d_out = [dmaps[3], dmaps[2], dmaps[1], dmaps[0]]          # gradients of x0, x1, x2, x3
+        dx = d_out[3].reshape(B * N, D).contiguous()
+        dc_from_next = None                                        # gradient of c_j through CACNN_{j+1}'s query input
+        for j in (3, 2, 1):
+            bsaved, s_cv, s_cn = asaves[j]
+            gs = {n: slabs[j, o:o + p.numel()].view(p.shape) for n, p, o in zip(ab.names, ab.params, ab.offsets)}
+            dx_q, dc_j = cv.backward16(s_cv, dx, inv, gs, "cross_vit")          # query (block output) and feat (c_j)
+            if dc_from_next is not None:
+                Lc = dc_j.shape[0] // B
+                ops.add_f32(dc_j.view(B, Lc, D), dc_from_next.view(B, Lc, D), out=dc_j.view(B, Lc, D))
+            dc_from_next, dx_f = cn.backward16(s_cn, dc_j, inv, gs, "cross_cnn")  # c_{j-1} and the block output as CACNN's feat
+            dxb = ops.add_f32(dx_q.view(B, N, D), dx_f.view(B, N, D)).view(B * N, D)
+            bi = (nb - 3, nb - 2, nb - 2)[j - 1]
+            dx_prev = m.blocks[bi].backward(bsaved, dxb, inv, None)
+            dx = ops.add_f32(dx_prev.view(B, N, D), d_out[j - 1].reshape(B, N, D)).view(B * N, D)
+        _, s_cv, _ = asaves[0]
+        gs = {n: slabs[0, o:o + p.numel()].view(p.shape) for n, p, o in zip(ab.names, ab.params, ab.offsets)}
+        _, dc0 = cv.backward16(s_cv, dx, inv, gs, "cross_vit")
+        Lc = dc0.shape[0] // B
+        ops.add_f32(dc0.view(B, Lc, D), dc_from_next.view(B, Lc, D), out=dc0.view(B, Lc, D))
+        ops.reduce_rows(slabs, 1.0, ab.grad)
+        return dc0
+
     def _encoder_backward(self, dc0: torch.Tensor, dcat: torch.Tensor, inv: float) -> None:
         """d c = what the adapter stages send back + the c4 slice of the decoder input (`train.py:395-400`: c4 is
         zero-padded, centred, into channels [D, 2D) of the concat) -> FeatureEncoder.backward_tokens."""
         esaved, shapes = self._esaved
         self._esaved = None
-        B, h, w, D3 = dcat.shape
-        D = D3 // 3
-        h4, w4 = shapes[2]
-        n4 = h4 * w4
-        Lc = dc0.shape[0] // B
-        top, left = (h - h4) // 2, (w - w4) // 2
-        d4 = dcat[:, top:top + h4, left:left + w4, D:2 * D].reshape(B, n4, D).contiguous()
-        dc = dc0.view(B, Lc, D)
-        ops.add_f32(dc[:, Lc - n4:], d4, out=dc[:, Lc - n4:])
+        D = self.model.embed_dim
+        if dcat is None:            # train_mla.py flow: c reaches the head through the adapters only
+            dc = dc0.view(-1, sum(a * b for a, b in shapes), D)
+        else:
+            B, h, w, D3 = dcat.shape
+            h4, w4 = shapes[2]
+            n4 = h4 * w4
+            Lc = dc0.shape[0] // B
+            top, left = (h - h4) // 2, (w - w4) // 2
+            d4 = dcat[:, top:top + h4, left:left + w4, D:2 * D].reshape(B, n4, D).contiguous()
+            dc = dc0.view(B, Lc, D)
+            ops.add_f32(dc[:, Lc - n4:], d4, out=dc[:, Lc - n4:])
         gviews = {n[len("backbone_encoder."):]: v for n, v in self.encoder_bucket.views.items()}
         self.backbone_encoder.backward_tokens(esaved, dc, inv, gviews)
 

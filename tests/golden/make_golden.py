@@ -346,14 +346,14 @@ def ref_or_unet_fuse(R, embed_dim, n_classes):
     return ORUNet()
 
 
-def orunet_case(R, out):
+def orunet_case(R, out, geoms=(56, 70), B=2, grad_elems=4000):
     """OR-UNet fuse head step (`eval/eval_dinov2_or_unet_fuse.py:266-322`): image + three ViT maps (scale 1 / 1.5 / 0.5 of the
     image, last-layer patch tokens as maps, no gradient) -> logits at the image size -> CE + DC(2) -> gradients of every
     parameter, BatchNorm buffers after the step.  Two geometries: 56 (pooled 28 / 14 / 7 / 3: the F.pad branch of Up) and
     70 (35 / 17 / 8 / 4; nearest resizes 7 -> 70, 5 -> 35, 2 -> 17: integer and fractional ratios)."""
     import torch.nn.functional as F
-    D, B = 384, 2
-    for HW in (56, 70):
+    D = 384
+    for HW in geoms:
         tag = f"orunet{HW}"
         sd = W.make_or_unet_state_dict(D, 2)
         u = ref_or_unet_fuse(R, D, 2)
@@ -378,7 +378,7 @@ def orunet_case(R, out):
         for k, p in u.named_parameters():
             if float(p.grad.abs().max()) > 1e-6:    # conv biases in front of a train-mode BatchNorm: exact zero + noise
                 close(osd[k].grad, p.grad, 5e-3, f"{tag} grad {k}")
-            out[f"{tag}.grad.{k}"] = sub(p.grad, 4000)
+            out[f"{tag}.grad.{k}"] = sub(p.grad, grad_elems)
         for k, v in u.state_dict().items():
             if "running" in k:
                 close(osd[k], v, 1e-5, f"{tag} {k}")
@@ -427,15 +427,20 @@ def ref_mask_transformer(R, n_cls, d_encoder, n_layers, n_heads, d_model, d_ff):
     return MT()
 
 
-def masktrans_case(R, out):
+MT_CASES = dict(mt2=(2, 384, 256, 4, 16, 2, "init"), mt5=(5, 64, 128, 2, 9, 3, "kernel"), mt2k=(2, 384, 256, 4, 16, 2, "kernel"))
+# the script's own geometry (`eval/eval_dinov2_masktrans.py:136-139`): ViT-g tokens (1536) -> d_model 1536, 24 heads of 64,
+# d_ff 6144, two layers, 42 x 42 patches of a 588^2 image; reference-init scales and the unit-gain stress weights
+MT_REF_CASES = dict(mtref=(2, 1536, 1536, 24, 42, 1, "init"), mtrefk=(2, 1536, 1536, 24, 42, 1, "kernel"))
+
+
+def masktrans_case(R, out, cases=None):
     """MaskTransformer head step (`eval/eval_dinov2_masktrans.py:262-322`): ViT tokens (no gradient) -> masks at 1/14 -> bilinear
     resize to the image -> CrossEntropy(weight [0.1, 10]) (+ the constant dice of the arg-max prediction) -> gradients of every
     parameter.  Cases: mt2 = 2 classes, d_encoder 384 -> d_model 256 (4 heads), 16 x 16 patches (224^2), weights at the scales
     of the reference's own initialisation; mt2k = the same geometry with unit-gain "kernel" weights (stress); mt5 = 5 classes,
     d_model 128, 9 x 9 patches, kernel weights."""
     import torch.nn.functional as F
-    for tag, (n_cls, De, D, heads, GS, B, mode) in dict(mt2=(2, 384, 256, 4, 16, 2, "init"), mt5=(5, 64, 128, 2, 9, 3, "kernel"),
-                                                        mt2k=(2, 384, 256, 4, 16, 2, "kernel")).items():
+    for tag, (n_cls, De, D, heads, GS, B, mode) in (cases or MT_CASES).items():
         sd = W.make_masktrans_state_dict(De, D, 2, n_cls, mode=mode)
         m = ref_mask_transformer(R, n_cls, De, 2, heads, D, 4 * D)
         m.load_state_dict(sd, strict=True)
@@ -1039,6 +1044,14 @@ def main():
         out = {}
         print("[OR-UNet fuse head step with gradients]"); orunet_case(R, out)
         save("orunet", out)
+    if "masktrans_ref" in only:
+        out = {}
+        print("[MaskTransformer head at the script's geometry: d_model 1536, 24 heads, 42 x 42 patches]"); masktrans_case(R, out, MT_REF_CASES)
+        save("masktrans_ref", out)
+    if "orunet_ref" in only:
+        out = {}
+        print("[OR-UNet fuse head at the script's geometry: 588^2 image, ViT maps 42 / 63 / 21]"); orunet_case(R, out, geoms=(588,), B=1, grad_elems=1500)
+        save("orunet_ref", out)
     if want("loss2"):
         out = {}
         print("[losses 2: all selectable losses with gradients, IoU metrics]"); loss2_case(R, out)

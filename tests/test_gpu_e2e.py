@@ -177,3 +177,115 @@ def test_unfrozen_backward_on_fixed_cotangent(dev):
     assert _stats(verr)[1] < 5e-3 and _stats(verr)[0] < 5e-2, verr
     assert _stats(aerr)[1] < 5e-3 and _stats(aerr)[0] < 1e-1, aerr
     assert _stats(eerr)[1] < 2e-2 and _stats(eerr)[0] < 1e-1, eerr
+
+
+def test_mla_flow_adapter_backward_on_fixed_cotangents(dev):
+    """``train_adapters`` on the `train_mla.py:300-383` stage order (x0 = CAViT; block -> CACNN -> CAViT three times with the
+    repeated ``blocks[-2]``; MLA inputs x3 + f, x2, x1, x0): the backward walk alone, fixed cotangents injected at the four MLA
+    inputs, against autograd of the oracle's ``mla_forward`` — every CAViT / CACNN parameter and the encoder's."""
+    from adaptersis_amd.backbones.decoders import DecoderMLA
+    arch, size, B = "vit_tiny_test", 224, 2
+    D, depth, heads, ffn = W.VIT_CONFIGS[arch]
+    sds = dict(vit=W.make_vit_state_dict(arch, layerscale="kernel"), enc=W.make_encoder_state_dict(D),
+               cv=W.make_cavit_state_dict(D, mode="kernel"), cn=W.make_cacnn_state_dict(D, mode="kernel"))
+    model = vits.__dict__[arch](patch_size=14, img_size=518, init_values=1e-5, ffn_layer=ffn, block_chunks=0)
+    model.load_state_dict(sds["vit"])
+    enc = FeatureEncoder(embed_dim=D); enc.load_state_dict(sds["enc"])
+    cv = CAViT(dim=D, n_levels=3, num_heads=8, init_values=0.0, n_points=4); cv.load_state_dict(sds["cv"])
+    cn = CACNN(dim=D, n_levels=1, num_heads=8, n_points=4, with_cffn=True, cffn_ratio=0.25); cn.load_state_dict(sds["cn"])
+    dec = DecoderMLA(img_size=size, mla_channels=D, mlahead_channels=32, num_classes=2)
+    eng = SegEngine(model.to(dev).eval(), enc.to(dev), cv.to(dev), cn.to(dev), dec.to(dev), lr=0.05, momentum=0.9, weight_decay=0.0,
+                    mode="train_adapters", train_encoder=True)
+    img, _ = W.synthetic_batch(B, size)
+    h = size // 14
+    cots = [W.tensor(f"mla.cot{i}", (B, h, h, D), 1.0) for i in range(4)]
+
+    def leaf(sd):
+        return {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k and "num_batches" not in k)
+                for k, v in sd.items()}
+    oenc, ocv, ocn = leaf(sds["enc"]), leaf(sds["cv"]), leaf(sds["cn"])
+    omaps = O.mla_forward(img, sds["vit"], oenc, ocv, ocn, heads)
+    sum((m_ * c.permute(0, 3, 1, 2)).sum() for m_, c in zip(omaps, cots)).backward()
+    with torch.no_grad():
+        asaves = []
+        maps = eng.features_mla(img.to(dev), None, asaves)
+        for (hi, lo), om in zip(maps, omaps):
+            got = hi.float() + (lo.float() if lo is not None else 0)
+            assert rel_l2(got.permute(0, 3, 1, 2), om) < 1e-3
+        eng.adapter_reducer.begin(); eng.encoder_reducer.begin()
+        dc0 = eng._mla_adapter_backward(asaves, [c.to(dev).contiguous() for c in cots], 1.0)
+        eng._encoder_backward(dc0, None, 1.0)
+    torch.cuda.synchronize()
+    aerr = {}
+    for k, v in eng.adapter_bucket.views.items():
+        mod, name = k.split(".", 1)
+        r = (ocv if mod == "cross_vit" else ocn)[name].grad
+        if r is not None and float(r.norm()) > 0:
+            aerr[k] = rel_l2(v, r)
+    eerr = {k: rel_l2(v, oenc[k[len("backbone_encoder."):]].grad) for k, v in eng.encoder_bucket.views.items()
+            if oenc[k[len("backbone_encoder."):]].grad is not None and float(oenc[k[len("backbone_encoder."):]].grad.norm()) > 0}
+    for nm, e in (("adapters", aerr), ("encoder", eerr)):
+        worst = sorted(e.items(), key=lambda kv: -kv[1])[:5]
+        print(f"  MLA flow, fixed cotangents, {nm}: n={len(e)} max %.2e median %.2e  worst %s" % (*_stats(e), [(k, "%.1e" % v) for k, v in worst]))
+    assert len(aerr) == 33
+    assert _stats(aerr)[1] < 5e-3 and _stats(aerr)[0] < 1e-1, aerr     # max: the paths through d(sampling offsets), as in the train.py flow
+    assert _stats(eerr)[1] < 2e-2 and _stats(eerr)[0] < 1e-1, eerr
+    # and one whole step runs (decoder + adapters + encoder optimised)
+    img2, tgt2 = W.synthetic_batch(B, size)
+    l0 = float(eng.train_step(img2.to(dev), tgt2.to(dev)))
+    l1 = float(eng.train_step(img2.to(dev), tgt2.to(dev)))
+    assert l0 == l0 and l1 == l1 and l1 != l0 and len(eng.optimizer.param_groups) == 3
+
+
+def test_unet_head_with_everything_trainable_vs_oracle_autograd(dev):
+    """BASELINE config 2's head with the encoder AND the backbone trainable (`eval/eval_dinov2_unet.py:270-297` head on the
+    unfrozen `train.py` adapter flow): logits / loss against the oracle, gradients of all four groups against its autograd."""
+    from adaptersis_amd.backbones.unet_parts import UNet
+    arch, size, B = "vit_tiny_test", 224, 2
+    D, depth, heads, ffn = W.VIT_CONFIGS[arch]
+    sds = dict(vit=W.make_vit_state_dict(arch, layerscale="kernel"), enc=W.make_encoder_state_dict(D),
+               cv=W.make_cavit_state_dict(D, mode="kernel"), cn=W.make_cacnn_state_dict(D, mode="kernel"), dec=W.make_unet_state_dict(D, 2))
+    model = vits.__dict__[arch](patch_size=14, img_size=518, init_values=1e-5, ffn_layer=ffn, block_chunks=0)
+    model.load_state_dict(sds["vit"])
+    enc = FeatureEncoder(embed_dim=D); enc.load_state_dict(sds["enc"])
+    cv = CAViT(dim=D, n_levels=3, num_heads=8, init_values=0.0, n_points=4); cv.load_state_dict(sds["cv"])
+    cn = CACNN(dim=D, n_levels=1, num_heads=8, n_points=4, with_cffn=True, cffn_ratio=0.25); cn.load_state_dict(sds["cn"])
+    dec = UNet(D, 2); dec.load_state_dict(sds["dec"])
+    eng = SegEngine(model.to(dev), enc.to(dev), cv.to(dev), cn.to(dev), dec.to(dev), lr=0.05, loss="ce_dc", mode="train_adapters",
+                    train_encoder=True, train_backbone=True, blocks_per_bucket=2)
+    img, tgt = W.synthetic_batch(B, size)
+
+    def leaf(sd):
+        return {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k and "num_batches" not in k)
+                for k, v in sd.items()}
+    ovit, oenc, ocv, ocn, odec = leaf(sds["vit"]), leaf(sds["enc"]), leaf(sds["cv"]), leaf(sds["cn"]), leaf(sds["dec"])
+    otaps = {}
+    O.adapter_forward(img, ovit, oenc, ocv, ocn, heads, taps=otaps)
+    x = otaps["x_stage3"]
+    hh = size // 14
+    oy = O.unet(x.transpose(1, 2).reshape(B, D, hh, hh), odec, update_bn=True)
+    oo = torch.nn.functional.interpolate(oy, size=(size, size), mode="bilinear")
+    oloss = O.cross_entropy_nd(oo, tgt) + O.dc_loss(oo, O.one_hot(tgt, 2))
+    oloss.backward()
+    taps = {}
+    loss = eng.train_step(img.to(dev), tgt.to(dev), taps)
+    torch.cuda.synchronize()
+    e_lg = rel_l2(taps["logits"].permute(0, 3, 1, 2), oy)
+    print(f"UNet head, everything trainable: logits {e_lg:.2e} loss {float(loss):.6f} oracle {float(oloss):.6f}")
+    assert e_lg < 1e-3 and abs(float(loss) - float(oloss)) < 1e-4
+    verr = {k: rel_l2(v, ovit[k].grad) for k, v in eng.vit_bucket.views.items() if ovit[k].grad is not None and float(ovit[k].grad.norm()) > 0}
+    aerr = {}
+    for k, v in eng.adapter_bucket.views.items():
+        mod, name = k.split(".", 1)
+        r = (ocv if mod == "cross_vit" else ocn)[name].grad
+        if r is not None and float(r.norm()) > 0:
+            aerr[k] = rel_l2(v, r)
+    eerr = {k: rel_l2(v, oenc[k[len("backbone_encoder."):]].grad) for k, v in eng.encoder_bucket.views.items()
+            if oenc[k[len("backbone_encoder."):]].grad is not None and float(oenc[k[len("backbone_encoder."):]].grad.norm()) > 0}
+    for nm, e in (("vit", verr), ("adapters", aerr), ("encoder", eerr)):
+        worst = sorted(e.items(), key=lambda kv: -kv[1])[:4]
+        print(f"  {nm}: n={len(e)} max %.2e median %.2e  worst %s" % (*_stats(e), [(k, "%.1e" % v) for k, v in worst]))
+        assert len(e) >= 20
+        # step-level bounds of the UNet head (tests/test_gpu_unet.py: its input gradient carries ~5 % of ReLU / MaxPool branch
+        # flips, which every upstream gradient inherits uniformly; the walks themselves are pinned by the fixed-cotangent tests)
+        assert _stats(e)[0] < 2.5e-1 and _stats(e)[1] < (1e-1 if nm == "encoder" else 6e-2), (nm, worst)

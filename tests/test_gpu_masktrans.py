@@ -65,13 +65,16 @@ def test_dropout_is_refused_in_training(dev):
 # the cosine difference — and amplifies a relative error of the cosines 2.2-2.8x (the fp32 oracle's own masks move by 2.2e-4 ..
 # 3.0e-4 when its cosines are perturbed by 1e-4, scripts/masktrans_probe.py), which is why every linear layer of this head runs
 # on split-precision operands (single-pass 16-bit operands: cosines 6.1e-4 .. 9.6e-4, masks 1.4e-3 .. 2.7e-3).
-CASES = dict(mt2=(2, 384, 256, 4, 16, 2, "init"), mt2k=(2, 384, 256, 4, 16, 2, "kernel"), mt5=(5, 64, 128, 2, 9, 3, "kernel"))
+# mtref / mtrefk: the script's own geometry (`eval/eval_dinov2_masktrans.py:136-139`): d_encoder = d_model = 1536, 24 heads, d_ff 6144,
+# 42 x 42 patches of a 588^2 image (tests/golden/masktrans_ref.pt)
+CASES = dict(mt2=(2, 384, 256, 4, 16, 2, "init"), mt2k=(2, 384, 256, 4, 16, 2, "kernel"), mt5=(5, 64, 128, 2, 9, 3, "kernel"),
+             mtref=(2, 1536, 1536, 24, 42, 1, "init"), mtrefk=(2, 1536, 1536, 24, 42, 1, "kernel"))
 COS_TOL, MASK_TOL, GRAD_TOL = 5e-4, 1e-3, 5e-3
 
 
-@pytest.mark.parametrize("tag", ["mt2", "mt2k", "mt5"])
+@pytest.mark.parametrize("tag", ["mt2", "mt2k", "mt5", "mtref", "mtrefk"])
 def test_mask_transformer_step_vs_golden(dev, tag):
-    g = load_golden("masktrans")
+    g = load_golden("masktrans_ref" if tag.startswith("mtref") else "masktrans")
     n_cls, De, D, heads, GS, B, mode = CASES[tag]
     sd = W.make_masktrans_state_dict(De, D, 2, n_cls, mode=mode)
     m = MaskTransformer(n_cls=n_cls, patch_size=14, d_encoder=De, n_layers=2, n_heads=heads, d_model=D, d_ff=4 * D,

@@ -65,17 +65,20 @@ def _inputs(HW, dev, D=384, B=2):
     return img, tg, maps
 
 
-@pytest.mark.parametrize("HW", [56, 70])
+@pytest.mark.parametrize("HW", [56, 70, 588])
 def test_or_unet_step_vs_reference_golden(dev, HW):
-    g = load_golden("orunet")
+    """56 / 70: small planes (every pad / nearest-ratio branch); 588: the script's own geometry (`eval_dinov2_or_unet_fuse.py:266-322`:
+    588^2 image, ViT maps 42 / 63 / 21 of the scale-1 / 1.5 / 0.5 passes), batch 1."""
+    B = 1 if HW == 588 else 2
+    g = load_golden("orunet_ref" if HW == 588 else "orunet")
     tag = f"orunet{HW}"
     sd = W.make_or_unet_state_dict(384, 2)
     u = UNet(n_channels=3, n_classes=2, embed_dim=384).to(dev)
     u.load_state_dict(sd, strict=True)
     u.train()
-    img, tg, maps = _inputs(HW, dev)
+    img, tg, maps = _inputs(HW, dev, B=B)
     y = u(img.to(dev), maps["o"].to(dev), maps["t2"].to(dev), maps["d2"].to(dev))
-    assert tuple(y.shape) == (2, 2, HW, HW)
+    assert tuple(y.shape) == (B, 2, HW, HW)
     e = golden_err(y, g[f"{tag}.logits"])
     loss = seg_loss(y, tg.to(dev), 1, ops.LOSS_DICE, 10e-20, n_ce=1)     # CE + DC(2) on the logits (`:311-316`)
     loss.backward()

@@ -67,3 +67,60 @@ def test_every_collective_call_site_runs_on_rccl_single_rank(dev):
         env.pop(k, None)
     r = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0 and "RCCL_REHEARSAL_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+CHILD2 = textwrap.dedent('''
+    import os, sys, torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.environ["ASIS_ROOT"])
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    from adaptersis_amd.utils import weights as W
+    from tests.test_gpu_e2e import build_e2e_engine
+    from tests.test_gpu_step import build_engine
+    img, tgt = W.synthetic_batch(2 * world, 224, seed=7)
+    sl = slice(2 * rank, 2 * rank + 2)                                   # DistributedSampler-style shard
+    res = {}
+    for kind in ("frozen", "e2e"):
+        if kind == "frozen":
+            eng, _ = build_engine("vit_tiny_test", "kernel", dev, (128, 32, 16, 16, 8), lr=0.05)
+        else:
+            eng, _ = build_e2e_engine("vit_tiny_test", dev, (128, 32, 16, 16, 8), blocks_per_bucket=2)
+        for _ in range(2):
+            eng.train_step(img[sl].to(dev), tgt[sl].to(dev))
+        torch.cuda.synchronize()
+        flats = [eng.bucket.flat, eng.backbone_encoder.stem[1].running_mean]
+        if kind != "frozen":
+            flats += [eng.vit_bucket.grad, eng.adapter_bucket.flat, eng.encoder_bucket.flat]
+        for i, t in enumerate(flats):                                    # every rank must hold the same values
+            lo, hi = t.clone(), t.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            assert torch.equal(lo, hi), (kind, i)
+            assert bool(torch.isfinite(t).all()), (kind, i)
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        print("RCCL_2RANK_OK")
+''')
+
+
+def test_two_real_ranks_over_rccl_when_two_devices_are_visible():
+    """N > 1 on real RCCL (VERDICT r2 #5): two ranks, one device each, two steps of the frozen-backbone engine and of the
+    unfrozen one (SyncBN exchanges, per-stage decoder all-reduces, chunked backbone bucket with blocks_per_bucket <
+    n_last_blocks, adapter / encoder buckets) — weights, running statistics and reduced gradients must be identical on
+    both ranks.  Needs two visible devices: skipped on the one-GPU box (counting devices does not initialise HIP here)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 visible GPUs (the driver's multi-GPU node)")
+    env = dict(os.environ, ASIS_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    path = os.path.join(ROOT, "gpurun_out", "_rccl2_child.py")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    with open(path, "w") as f:
+        f.write(CHILD2)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+                        "--nproc-per-node=2", path], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0 and "RCCL_2RANK_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
