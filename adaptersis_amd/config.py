@@ -60,8 +60,10 @@ unsplit_layers = set(filter(None, os.environ.get("ASIS_UNSPLIT", "").split(","))
 # The two ViT passes of the frozen-backbone step (cls + pos-embed tokens / raw patch tokens: `train.py:287,300-302`) as two
 # independent launch streams instead of one row-stacked stream (engines.SegEngine._trunk_dual): every dense GEMM fills the
 # chip in a non-integral number of tile rounds (q|k 5.19, proj / fc2 2.59, fc1 10.4 at 12 images), and the CUs that the tail
-# round of one stream's kernel leaves idle start the other stream's next kernel.  ASIS_DUAL_STREAM=1 turns it on (lab).
-dual_stream = os.environ.get("ASIS_DUAL_STREAM", "0") not in ("0", "")
+# round of one stream's kernel leaves idle start the other stream's next kernel: +1.2 % img/s (same-box A/B, three rounds:
+# 194.0-194.5 -> 196.5-196.9).  The first step of an engine runs in order (it fills the per-module operand caches on one
+# stream).  ASIS_DUAL_STREAM=0: one stacked stream.
+dual_stream = os.environ.get("ASIS_DUAL_STREAM", "1") not in ("0", "")
 
 # The attention output o = softmax(QK^T)V can leave the fused attention kernel as hi + lo 16-bit halves and enter the projection
 # GEMM as a split A operand (one extra K-long part on the persistent 8-phase GEMM: +8 % block FLOPs, -3.7 % img/s on the

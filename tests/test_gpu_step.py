@@ -110,3 +110,27 @@ def test_vitl_588_step_vs_reference_golden(dev, mode, tag):
     # reference configuration: forward agrees to 7e-6, so no ReLU branch moves and the step-level gradients hold 1e-2
     # (1.8e-3 measured); stress golden: forward 9e-4 -> step-level conditioning bound (tests/test_grad_conditioning.py)
     assert max(gerr.values()) < (1e-2 if mode == "init" else GRAD_TOL), gerr
+
+
+def test_dual_stream_trunk_is_deterministic_and_equivalent(dev):
+    """config.dual_stream: the two ViT passes of the trunk as two concurrent launch streams (engines.SegEngine._trunk_dual)
+    instead of one row-stacked stream.  The half-size GEMMs take other tile forms than the stacked ones (fewer tiles than the
+    8-phase form's threshold), so values move by an fp16 ulp here and there — the dual path must reproduce ITSELF bit for bit
+    (a race between the streams would not) and stay within 2e-4 of the in-order path (both hold the goldens: the config /
+    step tests pass under ASIS_DUAL_STREAM=1 and 0).  ViT-L width x 4 blocks at 588^2, batch 2."""
+    from adaptersis_amd import config
+    eng, _ = build_engine("vit_large_d4", "kernel", dev)
+    img, _ = W.synthetic_batch(2, 588)
+    img = img.to(dev)
+    old = config.dual_stream
+    try:
+        config.dual_stream = False
+        a = eng.features(img)
+        config.dual_stream = True
+        outs = [eng.features(img) for _ in range(3)]
+    finally:
+        config.dual_stream = old
+    torch.cuda.synchronize()
+    for b in outs[1:]:
+        assert torch.equal(outs[0][0], b[0]) and (b[1] is None or torch.equal(outs[0][1], b[1]))
+    assert rel_l2(outs[0][0].float(), a[0].float()) < 2e-4
