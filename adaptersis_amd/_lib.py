@@ -156,6 +156,11 @@ SIGNATURES = {
     "asis_augment": [_vp] * 13 + [_i, _i],
     "asis_augment_geo_u8": [_vp] * 12 + [_i, _i],
     "asis_clahe": [_vp] * 13 + [_i, _i, _i],
+    "asis_dropout_f32": [_vp, _vp, _vp, _vp, _i64, C.c_uint64, _i, _f, _f, _vp, _i],
+    "asis_dropout_t16": [_vp, _i, _vp, _vp, _i64, C.c_uint64, _i, _f, _i],
+    "asis_dropout_mask": [_vp, _vp, _i64, C.c_uint64, _i, _f],
+    "asis_softmax_dropout_fwd": [_vp, _i, _vp, _vp, _vp, _i64, _i, _i, _f, C.c_uint64, _i, _f],
+    "asis_softmax_dropout_bwd": [_vp, _i, _vp, _vp, _vp, _vp, _i64, _i, _i, _f, C.c_uint64, _i, _f],
     "asis_grad_guard": [_vp, _vp, _i64, _vp, _i],
     "asis_sgd_momentum_guarded": [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i, _vp, _i],
     "asis_scale_f32": [_vp, _vp, _i64, _f],

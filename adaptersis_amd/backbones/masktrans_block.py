@@ -19,8 +19,13 @@ Precision: ``mask_norm`` (LayerNorm over n_cls values) amplifies the error of th
 ``config.split_conv`` (default) every linear layer of the head runs on split-precision operands (masks 2.5e-4 .. 6.8e-4 against the
 golden; 1.4e-3 .. 2.7e-3 with single-pass 16-bit operands).
 
-Dropout: the reference script builds the head with ``dropout=0.1`` (`:139`); only ``dropout == 0`` / ``drop_path == 0`` is
-implemented (a stochastic mask inside the fused attention kernel is not) — other values raise in training mode.
+Dropout: the reference script builds the head with ``dropout=0.1`` (`:139`; `masktrans_block.py:19,43-45,66,70,82`: nn.Dropout on
+the attention probabilities, the projection output, behind GELU and behind fc2).  In training mode with ``dropout > 0`` a
+block runs ``_fwd_dropout`` / ``_bwd_dropout``: counter-based masks (Philox keyed by step seed, dropout-layer number and element
+index: csrc/dropout.hip — forward, backward and the mask export regenerate them, nothing is stored), an UNFUSED attention for
+the probability dropout (scores / probabilities materialised per head through batched GEMMs + two row kernels; the fused flash
+kernels serve every path without dropout), the other three sites as one elementwise kernel each.  ``drop_path > 0``
+(`drop_path_rate=0.0` in the script) is not implemented and raises in training mode.
 """
 from __future__ import annotations
 
@@ -57,10 +62,119 @@ class Block(L.Block):
                          norm_layer=nn.LayerNorm, attn_class=L.MemEffAttention)
         self.dropout, self.drop_path_rate = float(dropout), float(drop_path)
 
+        self._drop = None          # (step seed, first dropout-layer number of this block): set by MaskTransformer per forward
+
     def check_train(self):
-        if self.dropout != 0.0 or self.drop_path_rate != 0.0:
-            raise NotImplementedError("masktrans Block: dropout / drop_path > 0 is not implemented on the HIP path "
-                                      "(build the head with dropout=0.0, drop_path_rate=0.0)")
+        if self.drop_path_rate != 0.0:
+            raise NotImplementedError("masktrans Block: drop_path > 0 is not implemented on the HIP path (the script builds the "
+                                      "head with drop_path_rate=0.0)")
+        if not (0.0 <= self.dropout < 1.0):
+            raise ValueError("masktrans Block: dropout must be in [0, 1)")
+
+    # ---- training forward / backward with dropout ----------------------------------------------------------------------
+    SITE_ATTN, SITE_PROJ, SITE_GELU, SITE_FC2 = 0, 1, 2, 3
+
+    def _fwd_dropout(self, x2: torch.Tensor, segs):
+        """`masktrans_block.py:75-89` in training mode with dropout p > 0 (see the module docstring); saves for ``_bwd_dropout``."""
+        dt = config.operand_dtype
+        seed, site0 = self._drop
+        p = self.dropout
+        R, D = x2.shape
+        a, m = self.attn, self.mlp
+        H = a.num_heads
+        xn32 = ops.layernorm(x2, self._f32("n1w", self.norm1.weight), self._f32("n1b", self.norm1.bias), self.norm1.eps, torch.float32)
+        xn, xn_lo = ops.cast_pad(xn32, D, dt), ops.cast_pad(xn32, D, dt, part=1)
+        qkv32 = self._split_linear(xn, xn_lo, a._w16("qkv", a.qkv.weight), self._lo(a, "qkv", a.qkv.weight), a._f32("qkv_b", a.qkv.bias))
+        qkv = ops.cast_pad(qkv32, 3 * D, dt)
+        o = torch.empty((R, D), device=x2.device, dtype=dt)
+        if len(segs) != 1:
+            raise ValueError("masktrans Block: the dropout path takes one token batch (the head's tokens are one batch)")
+        (B, N), = segs
+        ld = ops.token_ld(N)
+        q3 = qkv.view(B, N, 3 * D)
+        vt = ops.transpose_tokens(qkv[:, 2 * D:], B, N)                       # [B, D, ld], zero padded
+        S = torch.empty((H, B, N, ld), device=x2.device, dtype=torch.float32)
+        for h in range(H):                                                    # scores per head: q_h k_h^T, one launch per head over the batch
+            ops.gemm(q3[:, :, h * 64:(h + 1) * 64], q3[:, :, D + h * 64:D + (h + 1) * 64], out=S[h, :, :, :N], out_f32=True)
+        P, Pd = ops.softmax_dropout_fwd(S.view(H * B * N, ld), N, a.scale, seed, site0 + self.SITE_ATTN, p, dt)
+        del S
+        o3 = o.view(B, N, D)
+        Pd4 = Pd.view(H, B, N, ld)
+        for h in range(H):
+            ops.gemm(Pd4[h], vt[:, h * 64:(h + 1) * 64, :], out=o3[:, :, h * 64:(h + 1) * 64])
+        y = ops.gemm(o, a._w16("proj", a.proj.weight), out_f32=True, bias_n=a._f32("proj_b", a.proj.bias),
+                     b_lo=self._lo(a, "proj", a.proj.weight))
+        x1 = ops.dropout_f32(y, seed, site0 + self.SITE_PROJ, p, res=x2)
+        xn2_32 = ops.layernorm(x1, self._f32("n2w", self.norm2.weight), self._f32("n2b", self.norm2.bias), self.norm2.eps, torch.float32)
+        xn2, xn2_lo = ops.cast_pad(xn2_32, D, dt), ops.cast_pad(xn2_32, D, dt, part=1)
+        hpre32 = self._split_linear(xn2, xn2_lo, m._w16("fc1", m.fc1.weight), self._lo(m, "fc1", m.fc1.weight), m._f32("fc1_b", m.fc1.bias))
+        hpost, hpost_lo = ops.gelu_split(hpre32, dt)
+        hsaved = ops.dropout_t16(hpost.clone(), seed, site0 + self.SITE_GELU, p, rescale=True)      # drop(gelu) as fc2's weight gradient sees it
+        # the operand pair of fc2 is only ZEROED (hi + lo stays exact); its 1 / (1 - p) and the bias go into the next kernel
+        ops.dropout_t16(hpost, seed, site0 + self.SITE_GELU, p, x_lo=hpost_lo, rescale=False)
+        f2 = self._split_linear(hpost, hpost_lo, m._w16("fc2", m.fc2.weight), self._lo(m, "fc2", m.fc2.weight), None)
+        x3 = ops.dropout_f32(f2, seed, site0 + self.SITE_FC2, p, res=x1, alpha=1.0 / (1.0 - p), bias_n=m._f32("fc2_b", m.fc2.bias))
+        hpre = ops.cast_pad(hpre32, hpre32.shape[1], dt)
+        return x3, dict(x2=x2, xn=xn, qkv=qkv, o=o, P=P, Pd=Pd, x1=x1, xn2=xn2, hpre=hpre, hpost=hsaved, segs=list(segs),
+                        drop=(seed, site0, p))
+
+    def _bwd_dropout(self, sv, dres: torch.Tensor, inv_scale: float, grads, prefix: str) -> torch.Tensor:
+        """Backward of ``_fwd_dropout`` (structure of ``dinov2.layers.blocks.Block.backward``; every dropout mask regenerated)."""
+        dt = config.operand_dtype
+        seed, site0, p = sv["drop"]
+        x2, xn, qkv, o, x1, xn2, hpre, hpost = (sv[k] for k in ("x2", "xn", "qkv", "o", "x1", "xn2", "hpre", "hpost"))
+        R, D = x2.shape
+        a, m = self.attn, self.mlp
+        H = a.num_heads
+        pre = prefix + "." if prefix else ""
+        # ---- MLP branch: out = x1 + drop(fc2(drop(gelu(fc1(LN2 x1))))) ----
+        dy = ops.dropout_f32(dres, seed, site0 + self.SITE_FC2, p)
+        d16, cs = ops.cast_colsum(dy, dt)
+        self._linear_bwd(pre + "mlp.fc2", m.fc2, None, None, d16, cs, hpost, inv_scale, grads)
+        dh = ops.gemm(d16, self._wT16("fc2T", m.fc2.weight, None))
+        ops.dropout_t16(dh, seed, site0 + self.SITE_GELU, p, rescale=True)
+        dh = ops.gelu16(hpre, dh)
+        self._linear_bwd(pre + "mlp.fc1", m.fc1, None, None, dh, ops.colsum(dh), xn2, inv_scale, grads)
+        dln = ops.gemm(dh, self._wT16("fc1T", m.fc1.weight), out_f32=True)
+        dx1, part = ops.layernorm_bwd(dln, x1, self._f32("n2w", self.norm2.weight), self.norm2.eps, res=dres)
+        red = ops.reduce_rows(part.view(part.shape[0], 2 * D), inv_scale)
+        grads[pre + "norm2.weight"].copy_(red[:D]); grads[pre + "norm2.bias"].copy_(red[D:])
+        # ---- attention branch: x1 = x + drop(proj(drop(softmax(q k^T)) v)) ----
+        dy = ops.dropout_f32(dx1, seed, site0 + self.SITE_PROJ, p)
+        d16, cs = ops.cast_colsum(dy, dt)
+        self._linear_bwd(pre + "attn.proj", a.proj, None, None, d16, cs, o, inv_scale, grads)
+        dO = ops.gemm(d16, self._wT16("projT", a.proj.weight, None))
+        (B, N), = sv["segs"]
+        ld = ops.token_ld(N)
+        q3, dO3 = qkv.view(B, N, 3 * D), dO.view(B, N, D)
+        dqkv = torch.empty((R, 3 * D), device=x2.device, dtype=dt)
+        dq3 = dqkv.view(B, N, 3 * D)
+        qt, kt, dOt = ops.transpose_tokens(qkv[:, :D], B, N), ops.transpose_tokens(qkv[:, D:2 * D], B, N), ops.transpose_tokens(dO, B, N)
+        P4, Pd4 = sv["P"].view(H, B, N, ld), sv["Pd"].view(H, B, N, ld)
+        dPd = torch.empty((H, B, N, ld), device=x2.device, dtype=torch.float32)
+        for h in range(H):                      # d(dropped probabilities) = dO_h v_h^T
+            ops.gemm(dO3[:, :, h * 64:(h + 1) * 64], q3[:, :, 2 * D + h * 64:2 * D + (h + 1) * 64], out=dPd[h, :, :, :N], out_f32=True)
+        dS = ops.softmax_dropout_bwd(sv["P"], sv["Pd"], dPd.view(H * B * N, ld), N, a.scale, seed, site0 + self.SITE_ATTN, p)
+        del dPd
+        dS4 = dS.view(H, B, N, ld)
+        for h in range(H):
+            hs = slice(h * 64, (h + 1) * 64)
+            PdT = ops.transpose_tokens(Pd4[h].reshape(B * N, ld), B, N)[:, :N, :]       # [B, keys, ld(queries)]
+            ops.gemm(PdT, dOt[:, hs, :], out=dq3[:, :, 2 * D + h * 64:2 * D + (h + 1) * 64])          # dV = Pd^T dO
+            ops.gemm(dS4[h], kt[:, hs, :], out=dq3[:, :, hs])                                          # dQ = dS K   (scale inside dS)
+            dST = ops.transpose_tokens(dS4[h].reshape(B * N, ld), B, N)[:, :N, :]
+            ops.gemm(dST, qt[:, hs, :], out=dq3[:, :, D + h * 64:D + (h + 1) * 64])                    # dK = dS^T Q
+        self._linear_bwd(pre + "attn.qkv", a.qkv, None, None, dqkv, ops.colsum(dqkv), xn, inv_scale, grads)
+        dln = ops.gemm(dqkv, self._wT16("qkvT", a.qkv.weight), out_f32=True)
+        dx, part = ops.layernorm_bwd(dln, x2, self._f32("n1w", self.norm1.weight), self.norm1.eps, res=dx1)
+        red = ops.reduce_rows(part.view(part.shape[0], 2 * D), inv_scale)
+        grads[pre + "norm1.weight"].copy_(red[:D]); grads[pre + "norm1.bias"].copy_(red[D:])
+        return dx
+
+    def backward(self, saved, dres, inv_scale, grads=None, prefix=""):
+        if isinstance(saved, dict):
+            return self._bwd_dropout(saved, dres, inv_scale, grads, prefix)
+        return super().backward(saved, dres, inv_scale, grads, prefix)
 
     # ---- split-precision forward ---------------------------------------------------------------------------------------
     # The head's output goes through mask_norm, a LayerNorm over only n_cls values that amplifies a relative error of the
@@ -122,6 +236,8 @@ class Block(L.Block):
         return super().forward_rows(x2, segs)
 
     def forward_train_rows(self, x2, segs):
+        if self.dropout > 0.0 and self._drop is not None:
+            return self._fwd_dropout(x2, segs)
         if config.split_conv:
             return self._fwd_precise(x2, segs, True)
         return super().forward_train_rows(x2, segs)
@@ -181,6 +297,9 @@ class MaskTransformer(_Packed):
         # 1 / sqrt(eps) = 316, so the package-wide 2^16 (config.loss_scale) overflows fp16 here (the optimizer's guard then
         # skips the step); 2^10 keeps the largest operand around 1e4 and the smallest useful ones far above fp16's 6e-8.
         self.loss_scale = 1024.0
+        # dropout (training mode only): every forward draws the masks of step `drop_step` of stream `drop_seed`
+        self.dropout = float(dropout)
+        self.drop_seed, self.drop_step = 0x5EED, 0
         self.apply(init_weights)
         nn.init.trunc_normal_(self.cls_emb, std=0.02)
 
@@ -230,7 +349,11 @@ class MaskTransformer(_Packed):
             ops.gemm(a16, self._w16("pd", pd.weight), out=x, bias_n=self._f32("pd_b", pd.bias))
         x.view(B, RB, D)[:, N:] = self.cls_emb.detach().float()           # the class tokens behind every image's patches
         saves = []
-        for blk in self.blocks:
+        drop = save and self.training and self.dropout > 0.0
+        if drop:
+            self.drop_step += 1
+        for i, blk in enumerate(self.blocks):
+            blk._drop = (self._step_seed(), 4 * i) if drop else None
             if save:
                 x, sv = blk.forward_train_rows(x, [(B, RB)])
                 saves.append(sv)
@@ -310,6 +433,24 @@ class MaskTransformer(_Packed):
         ops.reduce_rows(cs, inv_scale, grads["proj_dec.bias"])
         grads["proj_dec.bias"].sub_(grads["cls_emb"].view(C, D).sum(0))          # the bias does not reach the class rows
         done()
+
+    def _step_seed(self) -> int:
+        return ((int(self.drop_seed) & 0xFFFFFFFF) << 32) | (int(self.drop_step) & 0xFFFFFFFF)
+
+    def dropout_masks(self, B: int, N: int, device):
+        """Keep masks of the LAST training forward (test infrastructure: the oracle replays them) for ``B`` images of ``N``
+        patches: per block a dict attn bool [B, H, T, T], proj [B, T, D], gelu [B, T, d_ff], fc2 [B, T, D], T = N + n_cls."""
+        T = N + self.n_cls
+        ld = ops.token_ld(T)
+        seed, p, out = self._step_seed(), self.dropout, []
+        for i, blk in enumerate(self.blocks):
+            H, D, F_ = blk.attn.num_heads, self.d_model, blk.mlp.fc1.out_features
+            s0 = 4 * i
+            am = ops.dropout_mask(H * B * T * ld, seed, s0 + Block.SITE_ATTN, p, device).view(H, B, T, ld)[..., :T].permute(1, 0, 2, 3)
+            out.append(dict(attn=am.bool(), proj=ops.dropout_mask(B * T * D, seed, s0 + Block.SITE_PROJ, p, device).view(B, T, D).bool(),
+                            gelu=ops.dropout_mask(B * T * F_, seed, s0 + Block.SITE_GELU, p, device).view(B, T, F_).bool(),
+                            fc2=ops.dropout_mask(B * T * D, seed, s0 + Block.SITE_FC2, p, device).view(B, T, D).bool()))
+        return out
 
     # ---- reference-shaped entry point ----------------------------------------------------------------------------------
     def forward(self, x, im_size):

@@ -1138,3 +1138,60 @@ def augment(img_u8: torch.Tensor, mask_u8: torch.Tensor, tables: dict):
                              tables["ya"].data_ptr(), tables["mx"].data_ptr(), tables["my"].data_ptr(), tables["lut"].data_ptr(),
                              out.data_ptr(), mout.data_ptr(), B, S), "asis_augment")
     return out, mout
+
+
+# ---- dropout of the MaskTransformer head (csrc/dropout.hip: counter-based masks, include/asis_hip.h) -----------------------------
+def dropout_f32(x: torch.Tensor, seed: int, site: int, p: float, res: Optional[torch.Tensor] = None, alpha: float = 1.0,
+                bias_n: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """fp32 contiguous [..., C]: out = (res) + (alpha * x + bias_n) * keep / (1 - p)."""
+    _dev(x, res, bias_n, out)
+    if x.dtype != torch.float32 or not x.is_contiguous() or (res is not None and (res.shape != x.shape or not res.is_contiguous())):
+        raise ValueError("dropout_f32: contiguous float32 operands of one shape expected")
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib().asis_dropout_f32(_stream(), x.data_ptr(), _p(res), out.data_ptr(), x.numel(), int(seed), int(site), float(p),
+                                 float(alpha), _p(_f32c(bias_n)), int(x.shape[-1])), "asis_dropout_f32")
+    return out
+
+
+def dropout_t16(x: torch.Tensor, seed: int, site: int, p: float, x_lo: Optional[torch.Tensor] = None, rescale: bool = True) -> torch.Tensor:
+    """16-bit contiguous, IN PLACE: x *= keep (/ (1 - p) with ``rescale``); ``x_lo`` (split-operand residual half) zeroed alike."""
+    _dev(x, x_lo)
+    if not x.is_contiguous() or (x_lo is not None and (x_lo.shape != x.shape or not x_lo.is_contiguous() or x_lo.dtype != x.dtype)):
+        raise ValueError("dropout_t16: contiguous 16-bit operands of one shape expected")
+    check(lib().asis_dropout_t16(_stream(), _dt(x.dtype), x.data_ptr(), _p(x_lo), x.numel(), int(seed), int(site), float(p),
+                                 int(bool(rescale))), "asis_dropout_t16")
+    return x
+
+
+def dropout_mask(n: int, seed: int, site: int, p: float, device) -> torch.Tensor:
+    """uint8 [n] keep flags of dropout layer ``site`` (test infrastructure replays them in the oracle)."""
+    out = torch.empty((n,), device=device, dtype=torch.uint8)
+    check(lib().asis_dropout_mask(_stream(), out.data_ptr(), n, int(seed), int(site), float(p)), "asis_dropout_mask")
+    return out
+
+
+def softmax_dropout_fwd(S: torch.Tensor, N: int, scale: float, seed: int, site: int, p: float, dtype: torch.dtype):
+    """S fp32 [rows, ld] -> (P, P * keep / (1 - p)) 16-bit [rows, ld], P = softmax(scale * S[:, :N]), padding columns 0."""
+    _dev(S)
+    rows, ld = S.shape
+    if S.dtype != torch.float32 or not S.is_contiguous():
+        raise ValueError("softmax_dropout_fwd: contiguous float32 [rows, ld] expected")
+    p16 = torch.empty((rows, ld), device=S.device, dtype=dtype)
+    pd16 = torch.empty_like(p16)
+    check(lib().asis_softmax_dropout_fwd(_stream(), _dt(dtype), S.data_ptr(), p16.data_ptr(), pd16.data_ptr(), rows, int(N), ld,
+                                         float(scale), int(seed), int(site), float(p)), "asis_softmax_dropout_fwd")
+    return p16, pd16
+
+
+def softmax_dropout_bwd(p16: torch.Tensor, pd16: torch.Tensor, dPd: torch.Tensor, N: int, scale: float, seed: int, site: int,
+                        p: float) -> torch.Tensor:
+    """-> dS 16-bit [rows, ld] = scale * P * (keep / (1 - p) * dPd - rowsum(Pd * dPd))."""
+    _dev(p16, pd16, dPd)
+    rows, ld = p16.shape
+    if dPd.dtype != torch.float32 or dPd.shape != p16.shape or not (p16.is_contiguous() and pd16.is_contiguous() and dPd.is_contiguous()):
+        raise ValueError("softmax_dropout_bwd: contiguous [rows, ld] operands expected")
+    ds = torch.empty_like(p16)
+    check(lib().asis_softmax_dropout_bwd(_stream(), _dt(p16.dtype), p16.data_ptr(), pd16.data_ptr(), dPd.data_ptr(), ds.data_ptr(),
+                                         rows, int(N), ld, float(scale), int(seed), int(site), float(p)), "asis_softmax_dropout_bwd")
+    return ds

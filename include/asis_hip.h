@@ -523,6 +523,29 @@ int asis_clahe(void* stream, const uint8_t* rgb, const int32_t* clahe, const uin
                const uint16_t* tab_l2yf, const int32_t* tab_ab2xz, const uint8_t* tab_invgamma, const int32_t* coef_fwd,
                const int32_t* coef_inv, uint8_t* luts, const uint8_t* lut, float* out, int B, int S, int tiles);
 
+/* ---------------------------------------------------------------------------------------------
+ * Dropout of the MaskTransformer decode head (backbones/masktrans_block.py:11-89: nn.Dropout(p) on the attention probabilities,
+ * the projection output, behind GELU and behind fc2; eval_dinov2_masktrans.py:136-139 builds it with p = 0.1).  csrc/dropout.hip.
+ * Counter-based masks: keep(seed, site, i) = Philox4x32-10(key = seed, counter = (i / 4, site))[i % 4] >= p * 2^32 — a pure
+ * function of (seed, dropout-layer number, element index); forward, backward and the mask export regenerate it.
+ *   asis_dropout_f32:  out = (res ? res : 0) + (alpha * x + bias_n[col]) * keep / (1 - p), fp32 [n / ncols, ncols] contiguous
+ *                      (bias_n NULL: no affine term beyond alpha); n % 4 == 0.
+ *   asis_dropout_t16:  16-bit in place: x *= keep (rescale != 0: also / (1 - p)); x_lo (optional rounding-residual half of a
+ *                      split operand, rescale must be 0) is zeroed where x is.
+ *   asis_dropout_mask: uint8 [n] keep flags (what the oracle replays).
+ *   asis_softmax_dropout_fwd: scores S fp32 [rows, ld] (columns >= N padding) -> p16 = softmax(scale * S), pd16 = p16 * keep /
+ *                      (1 - p), 16-bit [rows, ld], padding 0; mask index = row * ld + column.
+ *   asis_softmax_dropout_bwd: ds16 = scale * P * (keep / (1 - p) * dPd - sum_k pd16 dPd), the gradient of S.
+ * ------------------------------------------------------------------------------------------- */
+int asis_dropout_f32(void* stream, const float* x, const float* res, float* out, int64_t n, uint64_t seed, int site, float p,
+                     float alpha, const float* bias_n, int ncols);
+int asis_dropout_t16(void* stream, int dtype, void* x, void* x_lo, int64_t n, uint64_t seed, int site, float p, int rescale);
+int asis_dropout_mask(void* stream, uint8_t* out, int64_t n, uint64_t seed, int site, float p);
+int asis_softmax_dropout_fwd(void* stream, int dtype, const float* S, void* p16, void* pd16, int64_t rows, int N, int ld, float scale,
+                             uint64_t seed, int site, float p);
+int asis_softmax_dropout_bwd(void* stream, int dtype, const void* p16, const void* pd16, const float* dPd, void* ds16, int64_t rows,
+                             int N, int ld, float scale, uint64_t seed, int site, float p);
+
 /* Overflow guard for the static loss scale of the 16-bit gradient tensors (the reference trains in fp32 and has no
  * counterpart; torch.cuda.amp.GradScaler.step has the same skip semantics).  guard = int32[2] in device memory:
  *   asis_grad_guard: guard[0] |= (any element of g is inf / NaN); reset != 0 clears guard[0] first (call once per step

@@ -384,22 +384,29 @@ def unet(x, sd: SD, p: str = "", update_bn: bool = False):
     return F.conv2d(y, sd[pre + "outc.conv.weight"], sd[pre + "outc.conv.bias"])
 
 
-def masktrans_block(x, sd: SD, p: str, num_heads: int):
-    """`backbones/masktrans_block.py:75-89` (dropout 0, drop_path 0): pre-norm block, nn.LayerNorm default eps 1e-5, attention
-    `:34-72` = softmax((q k^T) * head_dim^-0.5) v with qkv / proj biases, FeedForward `:11-31` = fc1 -> GELU -> fc2."""
+def masktrans_block(x, sd: SD, p: str, num_heads: int, drop=None):
+    """`backbones/masktrans_block.py:75-89` (drop_path 0): pre-norm block, nn.LayerNorm default eps 1e-5, attention `:34-72` =
+    softmax((q k^T) * head_dim^-0.5) v with qkv / proj biases, FeedForward `:11-31` = fc1 -> GELU -> fc2.
+    ``drop`` = (p, masks) replays given keep masks in place of nn.Dropout's own draws (`:19,43-45,66,70,27-29`:
+    attention probabilities, projection output, behind GELU, behind fc2): y = x * keep / (1 - p), training-mode nn.Dropout."""
+    def dr(t, key):
+        if drop is None:
+            return t
+        pr, masks = drop
+        return t * masks[key].to(t.dtype) / (1.0 - pr)
     B, N, C = x.shape
     hd = C // num_heads
     h = layer_norm(x, sd, p + ".norm1", 1e-5)
     qkv = F.linear(h, sd[p + ".attn.qkv.weight"], sd[p + ".attn.qkv.bias"]).reshape(B, N, 3, num_heads, hd).permute(2, 0, 3, 1, 4)
-    attn = ((qkv[0] @ qkv[1].transpose(-2, -1)) * hd ** -0.5).softmax(dim=-1)
+    attn = dr(((qkv[0] @ qkv[1].transpose(-2, -1)) * hd ** -0.5).softmax(dim=-1), "attn")
     a = (attn @ qkv[2]).transpose(1, 2).reshape(B, N, C)
-    x = x + F.linear(a, sd[p + ".attn.proj.weight"], sd[p + ".attn.proj.bias"])
+    x = x + dr(F.linear(a, sd[p + ".attn.proj.weight"], sd[p + ".attn.proj.bias"]), "proj")
     h = layer_norm(x, sd, p + ".norm2", 1e-5)
-    h = F.gelu(F.linear(h, sd[p + ".mlp.fc1.weight"], sd[p + ".mlp.fc1.bias"]))
-    return x + F.linear(h, sd[p + ".mlp.fc2.weight"], sd[p + ".mlp.fc2.bias"])
+    h = dr(F.gelu(F.linear(h, sd[p + ".mlp.fc1.weight"], sd[p + ".mlp.fc1.bias"])), "gelu")
+    return x + dr(F.linear(h, sd[p + ".mlp.fc2.weight"], sd[p + ".mlp.fc2.bias"]), "fc2")
 
 
-def mask_transformer(tok, sd: SD, num_heads: int, n_cls: int, p: str = "", taps: Optional[dict] = None):
+def mask_transformer(tok, sd: SD, num_heads: int, n_cls: int, p: str = "", taps: Optional[dict] = None, drop=None):
     """`eval/eval_dinov2_masktrans.py:441-462` ``MaskTransformer.forward``: tokens (B, N, d_encoder) -> masks (B, n_cls, GS, GS).
     ``taps``: receives the cosines in front of mask_norm (B, N, n_cls)."""
     pre = p + "." if p else ""
@@ -407,7 +414,7 @@ def mask_transformer(tok, sd: SD, num_heads: int, n_cls: int, p: str = "", taps:
     x = torch.cat((x, sd[pre + "cls_emb"].expand(x.size(0), -1, -1)), 1)
     i = 0
     while f"{pre}blocks.{i}.norm1.weight" in sd:
-        x = masktrans_block(x, sd, f"{pre}blocks.{i}", num_heads)
+        x = masktrans_block(x, sd, f"{pre}blocks.{i}", num_heads, None if drop is None else (drop[0], drop[1][i]))
         i += 1
     x = layer_norm(x, sd, pre + "decoder_norm", 1e-5)
     patches, cls = x[:, :-n_cls] @ sd[pre + "proj_patch"], x[:, -n_cls:] @ sd[pre + "proj_classes"]

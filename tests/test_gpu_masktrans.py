@@ -49,13 +49,88 @@ def test_mask_tail_kernels_vs_autograd(dev, case):
     assert float(dCl.view(B, N + C, D)[:, :N].abs().max()) == 0
 
 
-def test_dropout_is_refused_in_training(dev):
-    m = MaskTransformer(n_cls=2, patch_size=14, d_encoder=64, n_layers=1, n_heads=1, d_model=64, d_ff=256, drop_path_rate=0.0,
-                        dropout=0.1).to(dev).train()
+def test_drop_path_is_refused_and_head_dim_checked(dev):
+    m = MaskTransformer(n_cls=2, patch_size=14, d_encoder=64, n_layers=2, n_heads=1, d_model=64, d_ff=256, drop_path_rate=0.1,
+                        dropout=0.0).to(dev).train()
     with pytest.raises(NotImplementedError):
         m(torch.zeros(1, 16, 64, device=dev), (56, 56))
     with pytest.raises(ValueError):
         Block(96, 2, 384, 0.0, 0.0)      # head dim 48
+
+
+def test_dropout_kernels_and_counter_based_masks(dev):
+    """csrc/dropout.hip: keep rate, determinism in (seed, site), the fp32 / 16-bit / softmax kernels against torch on the exported masks."""
+    n, p = 1 << 20, 0.1
+    m0 = ops.dropout_mask(n, 7, 3, p, dev)
+    assert abs(float(m0.float().mean()) - 0.9) < 2e-3
+    assert torch.equal(m0, ops.dropout_mask(n, 7, 3, p, dev))
+    assert not torch.equal(m0, ops.dropout_mask(n, 8, 3, p, dev)) and not torch.equal(m0, ops.dropout_mask(n, 7, 4, p, dev))
+    assert torch.equal(m0[:4096], ops.dropout_mask(4096, 7, 3, p, dev))                      # a function of the element index alone
+    x, r = W.tensor("do.x", (1024, 1024), 1.0).to(dev), W.tensor("do.r", (1024, 1024), 1.0).to(dev)
+    b = W.tensor("do.b", (1024,), 1.0).to(dev)
+    keep = m0.view(1024, 1024).float()
+    y = ops.dropout_f32(x, 7, 3, p, res=r, alpha=1.25, bias_n=b)
+    assert rel_l2(y, r + (1.25 * x + b) * keep / 0.9) < 1e-6
+    h = x.half()
+    hl = (x - h.float()).half()
+    h2, hl2 = h.clone(), hl.clone()
+    ops.dropout_t16(h2, 7, 3, p, x_lo=hl2, rescale=False)
+    assert torch.equal(h2, (h.float() * keep).half()) and torch.equal(hl2, (hl.float() * keep).half())
+    h3 = ops.dropout_t16(h.clone(), 7, 3, p, rescale=True)
+    assert rel_l2(h3.float(), h.float() * keep / 0.9) < 4e-4
+    # softmax + dropout rows (N = 50 of ld = 64) and its backward
+    rows, N, ld, sc = 96, 50, 64, 0.125
+    S = torch.full((rows, ld), float("nan"), device=dev)
+    S[:, :N] = W.tensor("do.s", (rows, N), 4.0).to(dev)
+    P, Pd = ops.softmax_dropout_fwd(S, N, sc, 11, 5, p, torch.float16)
+    km = ops.dropout_mask(rows * ld, 11, 5, p, dev).view(rows, ld).float()[:, :N]
+    Sr = S[:, :N].clone().requires_grad_(True)
+    Pr = torch.softmax(Sr * sc, -1)
+    assert rel_l2(P[:, :N].float(), Pr.detach()) < 5e-4 and float(P[:, N:].abs().max()) == 0 and float(Pd[:, N:].abs().max()) == 0
+    assert rel_l2(Pd[:, :N].float(), Pr.detach() * km / 0.9) < 5e-4
+    g = torch.full((rows, ld), float("nan"), device=dev)
+    g[:, :N] = W.tensor("do.g", (rows, N), 1.0).to(dev)
+    (Pr * km / 0.9 * g[:, :N]).sum().backward()
+    dS = ops.softmax_dropout_bwd(P, Pd, g, N, sc, 11, 5, p)
+    assert float(dS[:, N:].abs().max()) == 0 and rel_l2(dS[:, :N].float(), Sr.grad) < 2e-3
+
+
+@pytest.mark.parametrize("tag", ["mt2", "mt5"])
+def test_mask_transformer_with_dropout_vs_oracle_replay(dev, tag):
+    """The head as the script builds it (`eval_dinov2_masktrans.py:136-139`: dropout = 0.1) in training mode: the masks of the step
+    are exported and replayed by the oracle (nn.Dropout semantics: y = x * keep / (1 - p)) — masks, loss and every gradient."""
+    n_cls, De, D, heads, GS, B, mode = CASES[tag]
+    sd = W.make_masktrans_state_dict(De, D, 2, n_cls, mode=mode)
+    m = MaskTransformer(n_cls=n_cls, patch_size=14, d_encoder=De, n_layers=2, n_heads=heads, d_model=D, d_ff=4 * D,
+                        drop_path_rate=0.0, dropout=0.1).to(dev)
+    m.load_state_dict(sd, strict=True)
+    m.train()
+    HW = GS * 14
+    tok = W.tensor(f"{tag}.tok", (B, GS * GS, De), 1.0).to(dev)
+    tg = W.synthetic_batch(B, HW, n_cls)[1].to(dev)
+    cw = torch.tensor([0.1, 10.0]) if n_cls == 2 else torch.linspace(0.5, 2.0, n_cls)
+    y = m(tok, (HW, HW))
+    loss = seg_loss(y, tg, 0, ops.LOSS_NONE, 0.0, n_ce=1, ce_weight=cw)
+    loss.backward()
+    masks = [{k: v.cpu() for k, v in d.items()} for d in m.dropout_masks(B, GS * GS, dev)]
+    assert abs(float(masks[0]["attn"].float().mean()) - 0.9) < 5e-3
+    osd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    oy = O.mask_transformer(tok.cpu(), osd, heads, n_cls, drop=(0.1, masks))
+    ol = F.cross_entropy(F.interpolate(oy, size=(HW, HW), mode="bilinear"), tg.cpu(), weight=cw)
+    ol.backward()
+    e = rel_l2(y.detach().cpu(), oy.detach())
+    errs = {k: rel_l2(p.grad.cpu(), osd[k].grad) for k, p in m.named_parameters()}
+    print(tag, "dropout 0.1: masks rel-L2 %.2e" % e, "loss", float(loss), float(ol), "grads:",
+          {k: f"{v:.1e}" for k, v in sorted(errs.items(), key=lambda kv: -kv[1])[:5]})
+    assert e < MASK_TOL and abs(float(loss) - float(ol)) < 1e-3 * max(1.0, float(ol))
+    assert max(errs.values()) < GRAD_TOL, errs
+    # a second step draws new masks; eval mode has none and equals the dropout-free head
+    y2 = m(tok, (HW, HW))
+    assert not torch.equal(y2, y)
+    m.eval()
+    with torch.no_grad():
+        ye = m(tok, (HW, HW))
+    assert rel_l2(ye.cpu(), O.mask_transformer(tok.cpu(), sd, heads, n_cls)) < MASK_TOL
 
 
 # (n_cls, d_encoder, d_model, heads, grid, batch, weight mode).  mt2: the reference's 2-class head at the scales of its own
