@@ -116,6 +116,7 @@ SIGNATURES = {
     "asis_pack_conv_weight": [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i64, _i],
     "asis_decoder_input": [_vp, _i, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i, _i, _i, _i, _i, _i],
     "asis_swiglu": [_vp, _i, _vp, _vp, _i64, _i],
+    "asis_swiglu_split": [_vp, _i, _vp, _vp, _vp, _i64, _i],
     "asis_copy_channels": [_vp, _vp, _i64, _vp, _i64, _i64, _i64],
     "asis_add_f32": [_vp, _vp, _vp, _vp, _i64, _i, _i64, _i64, _i64],
     "asis_maxpool2_fwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i],

@@ -77,3 +77,12 @@ dual_stream = os.environ.get("ASIS_DUAL_STREAM", "1") not in ("0", "")
 _so = os.environ.get("ASIS_SPLIT_O", "auto").lower()
 split_attn_out_policy = None if _so == "auto" else (_so not in ("0", ""))   # None = per engine (SegEngine.split_attn_out)
 split_attn_out = bool(split_attn_out_policy)     # what the blocks read; SegEngine sets it at the top of every step
+
+# Precision level of the ViT blocks (ASIS_PRECISE_LEVEL, default 0).  2 = EVERY linear layer of a block on split-precision
+# operands: LayerNorm / GELU / SwiGLU / attention outputs as hi + lo halves (A_lo) and the weights as hi + lo halves (B_lo) —
+# three K parts per GEMM on the persistent 8-phase kernel, ~2.5x the GEMM time; only q, k, v, P inside the fused attention stay
+# single 16-bit.  It exists for checkpoints / heads whose conditioning exceeds what single 16-bit operands can hold at 1e-3: the
+# full-depth stress golden of config 5 (ViT-g/14, 2 x 40 block evaluations, MLA head amplifying 3.2x) stands at 1.30e-3 on the
+# default policy because every remaining error term is an operand of a big GEMM (tests/precision_probe.py: LayerNorm outputs
+# 7.5e-4, SwiGLU hidden 5.2e-4, weights 8.8e-4 on the MLA output); tests/test_gpu_fulldepth.py runs that case on level 2 as well.
+precise_level = int(os.environ.get("ASIS_PRECISE_LEVEL", "0") or 0)

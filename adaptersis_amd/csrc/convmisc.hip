@@ -340,7 +340,8 @@ __global__ __launch_bounds__(256) void decoder_input_kernel(const float* __restr
 
 // SwiGLU gate (dinov2/layers/swiglu_ffn.py:30-34): x12 fp32 [R, 2*Hd] -> silu(x1) * x2 as 16-bit [R, Hd]
 template <typename T>
-__global__ __launch_bounds__(256) void swiglu_kernel(const float* __restrict__ x12, T* __restrict__ out, int64_t R, int Hd) {
+__global__ __launch_bounds__(256) void swiglu_kernel(const float* __restrict__ x12, T* __restrict__ out, T* __restrict__ out_lo,
+                                                     int64_t R, int Hd) {
   const int cpr = Hd >> 2;
   const int64_t total = R * cpr;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -348,10 +349,17 @@ __global__ __launch_bounds__(256) void swiglu_kernel(const float* __restrict__ x
     const int c = (int)(i - r * cpr);
     const float4 a = reinterpret_cast<const float4*>(x12 + r * 2 * Hd)[c];
     const float4 b = reinterpret_cast<const float4*>(x12 + r * 2 * Hd + Hd)[c];
+    const float h0 = a.x / (1.f + __expf(-a.x)) * b.x, h1 = a.y / (1.f + __expf(-a.y)) * b.y;
+    const float h2 = a.z / (1.f + __expf(-a.z)) * b.z, h3 = a.w / (1.f + __expf(-a.w)) * b.w;
     uint2 o;
-    o.x = pack2<T>(a.x / (1.f + __expf(-a.x)) * b.x, a.y / (1.f + __expf(-a.y)) * b.y);
-    o.y = pack2<T>(a.z / (1.f + __expf(-a.z)) * b.z, a.w / (1.f + __expf(-a.w)) * b.w);
+    o.x = pack2<T>(h0, h1);
+    o.y = pack2<T>(h2, h3);
     reinterpret_cast<uint2*>(out + r * Hd)[c] = o;
+    if (out_lo) {     // rounding residual: the second half of a split-precision operand (config.precise_level 2)
+      o.x = pack2<T>(lo_part<T>(h0), lo_part<T>(h1));
+      o.y = pack2<T>(lo_part<T>(h2), lo_part<T>(h3));
+      reinterpret_cast<uint2*>(out_lo + r * Hd)[c] = o;
+    }
   }
 }
 
@@ -538,16 +546,20 @@ extern "C" int asis_decoder_input(void* stream, int dtype, const float* xs, int6
   return ASIS_OK;
 }
 
-extern "C" int asis_swiglu(void* stream, int dtype, const float* x12, void* out, int64_t R, int Hd) {
+extern "C" int asis_swiglu_split(void* stream, int dtype, const float* x12, void* out, void* out_lo, int64_t R, int Hd) {
   ASIS_REQUIRE(x12 && out && Hd % 4 == 0 && Hd > 0, "asis_swiglu: bad arguments");
-  ASIS_REQUIRE(asis_aligned16(x12) && (((uintptr_t)out) & 7) == 0, "asis_swiglu: alignment");
+  ASIS_REQUIRE(asis_aligned16(x12) && (((uintptr_t)out) & 7) == 0 && (((uintptr_t)out_lo) & 7) == 0, "asis_swiglu: alignment");
   DT_OK(dtype, "asis_swiglu");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int64_t total = R * (Hd / 4);
-  if (dtype == ASIS_F16) hipLaunchKernelGGL((swiglu_kernel<f16>), dim3(grid_for(total)), dim3(256), 0, s, x12, reinterpret_cast<f16*>(out), R, Hd);
-  else hipLaunchKernelGGL((swiglu_kernel<bf16>), dim3(grid_for(total)), dim3(256), 0, s, x12, reinterpret_cast<bf16*>(out), R, Hd);
+  if (dtype == ASIS_F16) hipLaunchKernelGGL((swiglu_kernel<f16>), dim3(grid_for(total)), dim3(256), 0, s, x12, reinterpret_cast<f16*>(out), reinterpret_cast<f16*>(out_lo), R, Hd);
+  else hipLaunchKernelGGL((swiglu_kernel<bf16>), dim3(grid_for(total)), dim3(256), 0, s, x12, reinterpret_cast<bf16*>(out), reinterpret_cast<bf16*>(out_lo), R, Hd);
   ASIS_CHECK_LAUNCH("asis_swiglu");
   return ASIS_OK;
+}
+
+extern "C" int asis_swiglu(void* stream, int dtype, const float* x12, void* out, int64_t R, int Hd) {
+  return asis_swiglu_split(stream, dtype, x12, out, nullptr, R, Hd);
 }
 
 extern "C" int asis_copy_channels(void* stream, const void* src, int64_t src_ld_bytes, void* dst, int64_t dst_ld_bytes,

@@ -310,12 +310,58 @@ class Block(_Packed):
             x2 = x2.float().contiguous()
         return self.forward_rows(x2, [(B, N)]).view(B, N, D)
 
+    def _w16lo_any(self, owner, key: str, w: torch.Tensor):
+        """rounding residual of ``owner._w16(key, w)`` (same layout), whatever config.precise_attention says (precise_level 2)"""
+        return _pack(owner._cache, key + ".lo_any", w,
+                     lambda p: ops.cast_pad(p.reshape(p.shape[0], -1).contiguous().float(), dtype=config.operand_dtype, part=1))
+
+    def _forward_rows_precise(self, x2: torch.Tensor, segs) -> torch.Tensor:
+        """``forward_rows`` with every linear layer on split-precision operands (config.precise_level 2): LayerNorm / GELU / SwiGLU /
+        attention outputs and all weights as hi + lo halves; the fused attention keeps single 16-bit q, k, v, P."""
+        D = x2.shape[1]
+        dt = config.operand_dtype
+        a, m = self.attn, self.mlp
+        g1 = self._f32("g1", self.ls1.gamma) if isinstance(self.ls1, LayerScale) else None
+        g2 = self._f32("g2", self.ls2.gamma) if isinstance(self.ls2, LayerScale) else None
+        xn32 = ops.layernorm(x2, self._f32("n1w", self.norm1.weight), self._f32("n1b", self.norm1.bias), self.norm1.eps, torch.float32)
+        xn, xn_lo = ops.cast_pad(xn32, D, dt), ops.cast_pad(xn32, D, dt, part=1)
+        qkv32 = ops.gemm(xn, a._w16("qkv", a.qkv.weight), out_f32=True, bias_n=a._f32("qkv_b", a.qkv.bias), a_lo=xn_lo,
+                         b_lo=self._w16lo_any(a, "qkv", a.qkv.weight))
+        qkv = ops.cast_pad(qkv32, 3 * D, dt)
+        o = torch.empty((x2.shape[0], D), device=x2.device, dtype=dt)
+        o_lo = torch.empty_like(o)
+        r0 = 0
+        for B, N in segs:
+            r1 = r0 + B * N
+            vt = ops.transpose_tokens(qkv[r0:r1, 2 * D:], B, N)
+            ops.attention_fwd(qkv[r0:r1, :D], qkv[r0:r1, D:2 * D], vt, B, a.num_heads, N, a.scale, out=o[r0:r1], out_lo=o_lo[r0:r1])
+            r0 = r1
+        if r0 != x2.shape[0]:
+            raise ValueError("forward_rows: segments do not cover the rows")
+        x1 = ops.gemm(o, a._w16("proj", a.proj.weight), out_f32=True, bias_n=a._f32("proj_b", a.proj.bias), scale_n=g1, res=x2,
+                      a_lo=o_lo, b_lo=self._w16lo_any(a, "proj", a.proj.weight))
+        xn2_32 = ops.layernorm(x1, self._f32("n2w", self.norm2.weight), self._f32("n2b", self.norm2.bias), self.norm2.eps, torch.float32)
+        xn2, xn2_lo = ops.cast_pad(xn2_32, D, dt), ops.cast_pad(xn2_32, D, dt, part=1)
+        if isinstance(m, Mlp):
+            hpre = ops.gemm(xn2, m._w16("fc1", m.fc1.weight), out_f32=True, bias_n=m._f32("fc1_b", m.fc1.bias), a_lo=xn2_lo,
+                            b_lo=self._w16lo_any(m, "fc1", m.fc1.weight))
+            h, h_lo = ops.gelu_split(hpre, dt)
+            return ops.gemm(h, m._w16("fc2", m.fc2.weight), out_f32=True, bias_n=m._f32("fc2_b", m.fc2.bias), scale_n=g2, res=x1,
+                            a_lo=h_lo, b_lo=self._w16lo_any(m, "fc2", m.fc2.weight))
+        h12 = ops.gemm(xn2, m._w16("w12", m.w12.weight), out_f32=True, bias_n=m._f32("w12_b", m.w12.bias), a_lo=xn2_lo,
+                       b_lo=self._w16lo_any(m, "w12", m.w12.weight))
+        h, h_lo = ops.swiglu(h12, dt, split=True)
+        return ops.gemm(h, m._w16("w3", m.w3.weight), out_f32=True, bias_n=m._f32("w3_b", m.w3.bias), scale_n=g2, res=x1,
+                        a_lo=h_lo, b_lo=self._w16lo_any(m, "w3", m.w3.weight))
+
     def forward_rows(self, x2: torch.Tensor, segs) -> torch.Tensor:
         """The block on several token batches stacked along the rows of one fp32 [R, D] matrix (``segs`` = [(B, N), ..]).
         Everything but the attention itself is row-wise, so the two ViT passes of the training step (cls + pos-embed
         tokens and raw patch tokens, same frozen weights: `train.py:287,300-302`) share every GEMM launch: twice the
         rows per launch fill the 512 tile slots of the chip in 2.6 instead of 2 x 1.3 (-> 2 x 2) rounds on the
         N = 1024 GEMMs, and the weights are read once."""
+        if config.precise_level >= 2:
+            return self._forward_rows_precise(x2, segs)
         D = x2.shape[1]
         dt = config.operand_dtype
         g1 = self._f32("g1", self.ls1.gamma) if isinstance(self.ls1, LayerScale) else None

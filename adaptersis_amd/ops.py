@@ -685,13 +685,15 @@ def decoder_input(xs: torch.Tensor, c4: torch.Tensor, vit: torch.Tensor, hw, c4_
     return (out, lo) if split else out
 
 
-def swiglu(x12: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
-    """fp32 [R, 2*Hd] = [x1 | x2] -> 16-bit [R, Hd] = silu(x1) * x2 (dinov2/layers/swiglu_ffn.py:30-34)."""
+def swiglu(x12: torch.Tensor, dtype: torch.dtype, split: bool = False):
+    """fp32 [R, 2*Hd] = [x1 | x2] -> 16-bit [R, Hd] = silu(x1) * x2 (dinov2/layers/swiglu_ffn.py:30-34); ``split``: -> (hi, lo)
+    with lo the rounding residual (a split-precision operand pair)."""
     _dev(x12)
     R, two = x12.shape
     out = torch.empty((R, two // 2), device=x12.device, dtype=dtype)
-    check(lib().asis_swiglu(_stream(), _dt(dtype), _f32c(x12).data_ptr(), out.data_ptr(), R, two // 2), "asis_swiglu")
-    return out
+    lo = torch.empty_like(out) if split else None
+    check(lib().asis_swiglu_split(_stream(), _dt(dtype), _f32c(x12).data_ptr(), out.data_ptr(), _p(lo), R, two // 2), "asis_swiglu")
+    return (out, lo) if split else out
 
 
 def copy_channels(src: torch.Tensor, dst: torch.Tensor) -> None:

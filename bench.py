@@ -223,17 +223,23 @@ def pmc_traffic(kernel: str, variants):
     committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate runs of this very command, gfx950 read-side
     doubling applied: scripts/pmc_traffic.py).  PMC counters cannot be collected from inside the timed run, so this is the
     figure of the last profiled run."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_traffic.json")
-    if not os.path.exists(path):
-        return None
+    here = os.path.dirname(os.path.abspath(__file__))
+    for fn in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+        path = os.path.join(here, "profiles", fn)
+        if os.path.exists(path):
+            break
+    else:
+        return None, None
     with open(path) as f:
-        rows = json.load(f)["kernels"]
+        doc = json.load(f)
+    rows = doc["kernels"]
     tot = n = 0
     for name, v in rows.items():
-        if kernel in name and any(var in name for var in variants):
+        if any(k in name for k in kernel) and any(var in name for var in variants):
             tot += v["hbm_bytes_total"]
             n += v["launches"]
-    return round(tot / n) if n else None
+    src = {"file": "profiles/" + fn, "commit": doc.get("commit"), "command": doc.get("command")}
+    return (round(tot / n) if n else None), src
 
 
 def launch_ranks(n: int) -> int:
@@ -376,9 +382,10 @@ def main():
                 print(f"  {kind:5s} {f / 1e9:9.1f} GF {nb / 1e6:8.1f} MB  x{len(ts) // a.steps:3d}/step  avg {sum(ts) / len(ts) * 1e3:8.1f} us  "
                       f"{f / (sum(ts) / len(ts)) / 1e9:7.1f} TF/s  total {sum(ts) / a.steps:7.2f} ms/step", file=sys.stderr)
         achieved = flops / (avg_ms * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": "gemm_big_kernel (csrc/gemm_big.h): LDS-DMA MFMA GEMM on v_mfma_f32_16x16x32, 8-phase 256x256x64 form for the unbatched K >= 1024 launches, 256x128x32 two-workgroup form for the rest (all dense GEMM launches of the step)",
+        traffic, traffic_src = pmc_traffic(("gemm_big_kernel", "gemm_p8_kernel"), ("Lb0ELb0ELi32ELi4E", "Lb0ELb0ELi64ELi1ELb1E", "gemm_p8_kernel"))
+        roof = {"bound": "mfma", "kernel": "the dense LDS-DMA MFMA GEMM on v_mfma_f32_16x16x32 (all dense GEMM launches of the step): gemm_p8_kernel (csrc/gemm_p8.h, persistent 8-phase 256x256x64 form: K <= 2048 launches with >= 256 tiles), gemm_big_kernel (csrc/gemm_big.h: the one-tile-per-workgroup 8-phase form for K = 4096 and the batched V^T GEMMs, 256x128x32 two-workgroup form for the rest)",
                 "achieved": round(achieved, 1), "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / MFMA_F16_DENSE_PEAK_TFLOPS, 4), "traffic": pmc_traffic("gemm_big_kernel", ("Lb0ELb0ELi32ELi4E", "Lb0ELb0ELi64ELi1ELb1E")),
+                "frac": round(achieved / MFMA_F16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "measured_in": "a second pass of the same steps after the timed region, every launch on ONE stream (encoder / V^T / "
                                "weight-gradient / dual-trunk side streams off) with a HIP event pair around each GEMM launch",
                 "launches_per_step": n // a.steps, "avg_launch_ms": round(avg_ms, 4),

@@ -327,6 +327,9 @@ int asis_decoder_input(void* stream, int dtype, const float* xs, int64_t xs_bstr
                        int w, int h4, int w4, int D);
 /* SwiGLU gate (dinov2/layers/swiglu_ffn.py:30-34): x12 fp32 [R, 2*Hd] = [x1 | x2] -> out 16-bit [R, Hd] = silu(x1)*x2 */
 int asis_swiglu(void* stream, int dtype, const float* x12, void* out, int64_t R, int Hd);
+/* same with an optional second output out_lo (NULL = none): the rounding residual of the 16-bit result, so that (out, out_lo) is
+ * a split-precision A operand of the w3 GEMM (config.precise_level 2) */
+int asis_swiglu_split(void* stream, int dtype, const float* x12, void* out, void* out_lo, int64_t R, int Hd);
 /* strided row copy in bytes (channel concat / split of NHWC tensors: torch.cat(dim=1), decoders.py:47) */
 int asis_copy_channels(void* stream, const void* src, int64_t src_ld_bytes, void* dst, int64_t dst_ld_bytes, int64_t rows,
                        int64_t row_bytes);
