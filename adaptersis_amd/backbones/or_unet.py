@@ -331,14 +331,26 @@ class ORUNetFuseEngine(nn.Module):
         self.optimizer = SGD([self.bucket], lr=lr, momentum=momentum, weight_decay=weight_decay)
         self.reducer = StageReducer(self.bucket.grad, self.stage_ranges, process_group)
 
+    @staticmethod
+    def _rescale(inp: torch.Tensor, s: float) -> torch.Tensor:
+        """``F.interpolate(inp, scale_factor=(s, s), mode="bilinear", align_corners=False)`` (`:281,291`) on the HIP resize kernel:
+        each NCHW plane is an NHWC image of one channel.  With an integral output size (588 * 1.5 = 882, 588 * 0.5 = 294) the
+        scale-factor form and the kernel's size form sample the same coordinates; other sizes keep ATen's scale-factor form."""
+        B, C, H, W = inp.shape
+        Ho, Wo = H * s, W * s
+        if Ho != int(Ho) or Wo != int(Wo) or not inp.is_cuda:
+            import torch.nn.functional as F
+            return F.interpolate(inp, scale_factor=(s, s), mode="bilinear", align_corners=False)
+        x = inp.float().contiguous().view(B * C, H, W, 1)
+        return ops.resize_bilinear_fwd(x, int(Ho), int(Wo)).view(B, C, int(Ho), int(Wo))
+
     @torch.no_grad()
     def vit_maps(self, inp: torch.Tensor):
         """-> [(hi, lo|None) NHWC 16-bit maps of x_o, x_t2, x_d2] (`:279-306`)"""
-        import torch.nn.functional as F
         dt = config.operand_dtype
         maps = []
         for s in (1.0, 1.5, 0.5):
-            x = inp if s == 1.0 else F.interpolate(inp, scale_factor=(s, s), mode="bilinear", align_corners=False)
+            x = inp if s == 1.0 else self._rescale(inp, s)
             tok = self.model.get_intermediate_layers(x, 1)[0]                 # (B, h*w, D) normalised patch tokens
             B, N, D = tok.shape
             h, w = x.shape[2] // self.patch, x.shape[3] // self.patch

@@ -274,6 +274,9 @@ def main():
     ap.add_argument("--e2e-setr", action="store_true", help="config 4 as the reference's own end-to-end script: ViT -> DecoderSETR without adapters")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--single-stream", action="store_true",
+                    help="profiling aid: every launch on the compute stream (encoder / V^T / weight-gradient / dual-trunk side streams "
+                         "off), so that a rocprofv3 kernel trace of this command shows un-overlapped launch durations")
     ap.add_argument("--cpu-baseline-batch", type=int, default=1, help="batch of the timed CPU (oracle) step: 1 or 2")
     a = ap.parse_args()
 
@@ -315,6 +318,8 @@ def main():
     torch.set_num_threads(max(1, min(16, cores // max(1, world))))
 
     from adaptersis_amd import config, ops
+    if a.single_stream:
+        config.encoder_stream = config.vt_stream = config.wgrad_stream = config.dual_stream = False
     if a.operand:
         config.set_operand_dtype(torch.float16 if a.operand == "f16" else torch.bfloat16)
         config.loss_scale = 65536.0 if a.operand == "f16" else 1.0
@@ -421,6 +426,9 @@ def main():
                     "(fwd + full bwd + bucketed all-reduce of backbone/adapter/encoder/decoder gradients + SGD), random-init weights")}[a.config],
                        "global_batch": global_batch, "image_size": a.size, "parallelism": f"dp{world}",
                        "split_precision_convs": bool(config.split_conv), "loss": loss_v,
+                       "side_streams": {"encoder": bool(config.encoder_stream), "vt": bool(config.vt_stream),
+                                        "wgrad": bool(config.wgrad_stream), "dual_trunk": bool(config.dual_stream)},
+                       "split_attn_out": bool(getattr(eng, "split_attn_out", False)), "precise_level": int(config.precise_level),
                        "skipped_optimizer_steps": int(eng.optimizer.skipped_steps)},
         }
         if roof:
