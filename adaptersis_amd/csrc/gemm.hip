@@ -212,7 +212,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const asis_gemm_desc 
 
 // ASIS_GEMM_P8 / asis_gemm_set_option("p8", v): -1 = not read yet
 static int g_gemm_p8 = -1;
-static int g_gemm_p8nt = -1;    // ASIS_P8_NT / "p8nt"
 static int g_gemm_noepi = -1;   // ASIS_GEMM_NOEPI / "noepi" (lab: main loop only; wrong results)
 static bool ph8_m16_on() { static const int v = [] { const char* e = getenv("ASIS_GEMM_8P_M16"); return e ? atoi(e) : 1; }(); return v != 0; }
 
@@ -248,14 +247,8 @@ int launch(hipStream_t s, const asis_gemm_desc& d) {
         al(d.C, 16) && (!d.res || (al(d.res, 16) && d.ldr % 4 == 0)) && (!d.bias_n || al(d.bias_n, 16)) && (!d.scale_n || al(d.scale_n, 16)) &&
         (d.act != ASIS_ACT_GELU_GRAD || (d.aux && al(d.aux, 8) && d.ld_aux % 4 == 0))) {
       const int nwg = p8_tiles >= 256 ? 256 : (int)(p8_tiles / 8) * 8;
-      // cache policy of the operand streams ("p8nt" / ASIS_P8_NT: 0 = default for both, 1 = A non-temporal, 2 = B non-temporal,
-      // 3 = auto: the operand whose panels an XCD's 32-tile chunks do NOT share is streamed non-temporally)
-      if (g_gemm_p8nt < 0) { const char* e = getenv("ASIS_P8_NT"); g_gemm_p8nt = e ? atoi(e) : 0; }
-      int nt = g_gemm_p8nt;
-      if (nt == 3) nt = ((d.N + 255) / 256 <= 8) ? 1 : 2;
-      const int gm = group_m | (nt << 16);
-      if (g_gemm_noepi) hipLaunchKernelGGL((gemm_p8_kernel<T, 1>), dim3(nwg), dim3(512), 0, s, d, gm);
-      else hipLaunchKernelGGL((gemm_p8_kernel<T, 0>), dim3(nwg), dim3(512), 0, s, d, gm);
+      if (g_gemm_noepi) hipLaunchKernelGGL((gemm_p8_kernel<T, 1>), dim3(nwg), dim3(512), 0, s, d, group_m);
+      else hipLaunchKernelGGL((gemm_p8_kernel<T, 0>), dim3(nwg), dim3(512), 0, s, d, group_m);
       return 0;
     }
   }
@@ -409,7 +402,6 @@ extern "C" int asis_gemm_set_option(const char* name, int value) {
   ASIS_REQUIRE(name != nullptr, "asis_gemm_set_option: null name");
   if (strcmp(name, "p8") == 0) { g_gemm_p8 = value; return ASIS_OK; }
   if (strcmp(name, "noepi") == 0) { g_gemm_noepi = value; return ASIS_OK; }
-  if (strcmp(name, "p8nt") == 0) { g_gemm_p8nt = value; return ASIS_OK; }
   ASIS_FAIL(ASIS_EINVAL, "asis_gemm_set_option: unknown option '%s'", name);
 }
 

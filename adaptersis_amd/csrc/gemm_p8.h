@@ -30,11 +30,10 @@
 namespace {
 
 template <typename T, int LAB = 0>
-__global__ __launch_bounds__(512, 1) void gemm_p8_kernel(const asis_gemm_desc d, const int GROUP_M_FLAGS) {
-  const int GROUP_M = GROUP_M_FLAGS & 0xffff;
-  // bits 16 / 17: stream the A / B operand through L2 with the non-temporal policy (LDS-DMA aux = nt), so that the OTHER
-  // operand's panels — re-read by every chunk of 32 tiles an XCD works on — keep their L2 lines (gemm.hip picks the bit)
-  const bool nt_a = (GROUP_M_FLAGS >> 16) & 1, nt_b = (GROUP_M_FLAGS >> 17) & 1;
+__global__ __launch_bounds__(512, 1) void gemm_p8_kernel(const asis_gemm_desc d, const int GROUP_M) {
+  // (Tried in round 3 and removed: a non-temporal cache policy (LDS-DMA aux = nt) on the operand whose panels an XCD's chunks
+  // do not share.  L2 fills went UP 5-30 % with the hint on either operand, and merely having the two aux variants of the
+  // builtin behind a wave-uniform branch in the loop cost 40-60 % of the kernel's speed: profiles/r03_gemm_p8_nt_policy.txt.)
   typedef typename T16<T>::v8 v8;
   constexpr int BM = 256, BN = 256, BK = 64;
   constexpr int STAGE = (BM + BN) * BK;  // elements per LDS stage (64 KB)
@@ -106,12 +105,10 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(const asis_gemm_desc d,
   uint32_t sk0 = 0;     // K offset (bytes) of the K tile being staged
   int g = 0;            // running K tile count: K tile g lives in stage g & 1
   auto dma_a = [&](int stage, int j) {
-    if (nt_a) __builtin_amdgcn_global_load_lds((glb_ptr)(A + (asrc[j] + sk0)), (lds_ptr)(lds + stage * STAGE + grp_a(j) * BK), 16, 0, 2);
-    else __builtin_amdgcn_global_load_lds((glb_ptr)(A + (asrc[j] + sk0)), (lds_ptr)(lds + stage * STAGE + grp_a(j) * BK), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((glb_ptr)(A + (asrc[j] + sk0)), (lds_ptr)(lds + stage * STAGE + grp_a(j) * BK), 16, 0, 0);
   };
   auto dma_b = [&](int stage, int j) {
-    if (nt_b) __builtin_amdgcn_global_load_lds((glb_ptr)(B + (bsrc[j] + sk0)), (lds_ptr)(lds + stage * STAGE + BM * BK + grp_b(j) * BK), 16, 0, 2);
-    else __builtin_amdgcn_global_load_lds((glb_ptr)(B + (bsrc[j] + sk0)), (lds_ptr)(lds + stage * STAGE + BM * BK + grp_b(j) * BK), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((glb_ptr)(B + (bsrc[j] + sk0)), (lds_ptr)(lds + stage * STAGE + BM * BK + grp_b(j) * BK), 16, 0, 0);
   };
 #pragma unroll
   for (int j = 0; j < 4; ++j) {

@@ -128,53 +128,8 @@ def timing(rounds):
               f"(min {min(res[(n, 1)]):7.1f}, {fl / m1 / 1e6:5.0f} TF)   p8/big {m1 / m0:.3f}")
 
 
-def nt_sweep(rounds):
-    """"p8nt" cache-policy settings of the persistent kernel, interleaved (time); run one setting alone under rocprofv3 --pmc
-    FETCH_SIZE with `one <v>` for the traffic"""
-    fs = {}
-    for name, M, N, K, kw in SHAPES[:3]:
-        x = (torch.rand(M, K, device=dev) * 2 - 1).half()
-        w = ((torch.rand(N, K, device=dev) * 2 - 1) * 0.05).half()
-        b = torch.rand(N, device=dev)
-        extra = dict(out_f32=True, scale_n=torch.rand(N, device=dev), res=torch.rand(M, N, device=dev)) if kw.get("res") else \
-            (dict(act=ops.ACT_GELU) if kw.get("act") else {})
-        o = torch.empty(M, N, device=dev, dtype=torch.float32 if kw.get("res") else torch.float16)
-        fs[name] = (lambda x=x, w=w, o=o, b=b, extra=extra: ops.gemm(x, w, out=o, bias_n=b, **extra), 2.0 * M * N * K)
-    res = {(n, v): [] for n in fs for v in (0, 1, 2)}
-    for r in range(rounds + 1):
-        for n, (f, _) in fs.items():
-            for v in (0, 1, 2):
-                ops.gemm_set_option("p8nt", v)
-                f()
-                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                s.record()
-                for _ in range(10):
-                    f()
-                e.record()
-                torch.cuda.synchronize()
-                if r:
-                    res[(n, v)].append(s.elapsed_time(e) / 10 * 1e3)
-    for n in fs:
-        print(f"{n:12s} " + "   ".join(f"nt={v}: {statistics.median(res[(n, v)]):7.1f} us" for v in (0, 1, 2)))
-
-
-def one(v):
-    ops.gemm_set_option("p8nt", v)
-    for name, M, N, K, kw in SHAPES[:3]:
-        x = (torch.rand(M, K, device=dev) * 2 - 1).half()
-        w = ((torch.rand(N, K, device=dev) * 2 - 1) * 0.05).half()
-        o = torch.empty(M, N, device=dev, dtype=torch.float16)
-        for _ in range(3):
-            ops.gemm(x, w, out=o)
-    torch.cuda.synchronize()
-
-
 if __name__ == "__main__":
-    if sys.argv[1] == "nt":
-        nt_sweep(int(sys.argv[2]) if len(sys.argv) > 2 else 5)
-    elif sys.argv[1] == "one":
-        one(int(sys.argv[2]))
-    elif sys.argv[1] == "check":
+    if sys.argv[1] == "check":
         check()
     else:
         timing(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
