@@ -236,6 +236,148 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const asis_wgrad_des
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Large-tile form for nn.Linear weight gradients (dense, Cout % 256 == 0, Cin % 128 == 0): 256 x 128 x 32 tile, 8 waves of
+// 64 x 64, both operand tiles staged [k][m] / [k][n] by LDS-DMA (global_load_lds_dwordx4: no staging registers, no LDS
+// store pass) into a 3-stage ring with a counted vmcnt (one K tile stays in flight across the barrier), fragments by the
+// same transposing reads as above — the step that took the dense GEMM from the 128^2 register-staged kernel to the
+// 256-row LDS-DMA kernel (gemm_big.h, two workgroups per CU).  The weight gradients of the unfrozen ViT are the largest
+// kernel of BASELINE config 4 (16 % of its step at ~410 TFLOP/s on the form above).
+// A wave-instruction lands 1 KB lane-linearly: 2 k-rows of the A image (512 B each) or 4 of the B image (256 B each); the
+// 16-byte chunk swizzle (k & 3) << 2 is applied to the per-lane SOURCE address.  Rows past the split end read a zero page.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(16))) uint4 g_wgrad_zero[1];
+
+template <typename T>
+__global__ __launch_bounds__(512, 2) void wgrad_dense_big_kernel(const asis_wgrad_desc d) {
+  constexpr int TM = 256, TN = 128, TK = 32, NS = 3;
+  constexpr int STAGE = TK * (TM + TN);               // 12288 elements = 24 KB
+  constexpr int G = 3;                                // LDS-DMA instructions per wave and K tile (2 for A, 1 for B)
+  typedef typename T16<T>::v8 v8;
+  typedef s16x4 __attribute__((address_space(3))) * lds_tr_ptr;
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  typedef const __attribute__((address_space(1))) void* glb_ptr;
+  __shared__ __attribute__((aligned(16))) T lds[NS * STAGE];   // 72 KB: two workgroups per CU
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 1, wn = wid & 1;                 // 4 x 2 waves of 64 x 64
+  const int tiles_n = d.Cin / TN;
+  const int lin = xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
+  const int bx = lin % gridDim.x, by = lin / gridDim.x;
+  const int tile_m = bx / tiles_n, tile_n = bx - tile_m * tiles_n;
+  const int m0 = tile_m * TM, n0 = tile_n * TN;
+  const int64_t k_begin = (int64_t)by * d.k_per_split;
+  int64_t k_end = k_begin + d.k_per_split;
+  if (k_end > d.P) k_end = d.P;
+  const int nt = k_end > k_begin ? (int)((k_end - k_begin + TK - 1) / TK) : 0;
+
+  // per-lane sources: A instruction j of this wave = k rows 2 (2 wid + j) + (lane >> 5), chunk lane & 31;
+  //                   B instruction     = k rows 4 wid + (lane >> 4), chunk lane & 15
+  const T* zp = reinterpret_cast<const T*>(g_wgrad_zero);
+  const T* A = reinterpret_cast<const T*>(d.dy);
+  const T* X = reinterpret_cast<const T*>(d.x);
+  int ka[2], kb;
+  const T* pa[2];
+  const T* pb;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    ka[j] = 2 * (2 * wid + j) + (lane >> 5);
+    const int ch = (lane & 31) ^ ((ka[j] & 3) << 2);
+    pa[j] = A + (k_begin + ka[j]) * d.ld_dy + m0 + ch * 8;
+  }
+  kb = 4 * wid + (lane >> 4);
+  pb = X + (k_begin + kb) * (int64_t)d.Cin + n0 + (((lane & 15) ^ ((kb & 3) << 2)) * 8);
+  const int64_t a_step = (int64_t)TK * d.ld_dy, x_step = (int64_t)TK * d.Cin;
+  auto issue = [&](int t) {
+    T* st = lds + (t % NS) * STAGE;
+    const int64_t kt = k_begin + (int64_t)t * TK;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const T* src = (kt + ka[j] < k_end) ? pa[j] + (int64_t)t * a_step : zp;
+      __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(st + (2 * (2 * wid + j)) * TM), 16, 0, 0);
+    }
+    const T* srcb = (kt + kb < k_end) ? pb + (int64_t)t * x_step : zp;
+    __builtin_amdgcn_global_load_lds((glb_ptr)srcb, (lds_ptr)(st + TK * TM + (4 * wid) * TN), 16, 0, 0);
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+#pragma unroll
+  for (int s0 = 0; s0 < NS - 1; ++s0)
+    if (s0 < nt) issue(s0);
+
+  // transposed-read geometry (see wgrad_kernel): 16-lane group g reads a 4 (k) x 16 (m) block
+  const int g = lane >> 4, li = lane & 15;
+  const int fh = g >> 1, msub = 16 * (g & 1);
+  const int q = li >> 2, pc = li & 3;
+  for (int t = 0; t < nt; ++t) {
+    if (nt - t - 1 >= NS - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * G) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (t + NS - 1 < nt) issue(t + NS - 1);
+    const T* As = lds + (t % NS) * STAGE;
+    const T* Bs = As + TK * TM;
+#pragma unroll
+    for (int ks = 0; ks < TK / 16; ++ks) {
+      // The transposing reads are inline asm, waited for inside the statement: behind an LDS-DMA issue hipcc puts an
+      // `s_waitcnt vmcnt(0)` in front of every LDS read IT sees (it cannot prove the read does not touch the bytes in flight),
+      // which drained the K tile that had just been issued and serialised the ring (found in the ISA of the first build).
+      typedef short s16x8 __attribute__((ext_vector_type(8)));
+      uint32_t ad[8];
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {                      // fragments: A rows i = 0, 1 ; B columns j = 0, 1
+        const T* S = f < 2 ? As : Bs;
+        const int RS = f < 2 ? TM : TN;
+        const int c0 = (f < 2 ? wm * 64 + f * 32 : wn * 64 + (f - 2) * 32) + msub + 4 * pc;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          const int k = ks * 16 + 8 * fh + 4 * half + q;
+          const int swz = (k & 3) << 2;
+          ad[2 * f + half] = (uint32_t)(uintptr_t)(lds_tr_ptr)(S + k * RS + ((((c0 >> 3) ^ swz) << 3) | (c0 & 7)));
+        }
+      }
+      s16x4 h[8];
+      asm volatile("ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %9\n\tds_read_b64_tr_b16 %2, %10\n\tds_read_b64_tr_b16 %3, %11\n\t"
+                   "ds_read_b64_tr_b16 %4, %12\n\tds_read_b64_tr_b16 %5, %13\n\tds_read_b64_tr_b16 %6, %14\n\tds_read_b64_tr_b16 %7, %15\n\t"
+                   "s_waitcnt lgkmcnt(0)"
+                   : "=&v"(h[0]), "=&v"(h[1]), "=&v"(h[2]), "=&v"(h[3]), "=&v"(h[4]), "=&v"(h[5]), "=&v"(h[6]), "=&v"(h[7])
+                   : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3]), "v"(ad[4]), "v"(ad[5]), "v"(ad[6]), "v"(ad[7])
+                   : "memory");
+      v8 af[2], bf[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        af[i] = __builtin_bit_cast(v8, (s16x8)__builtin_shufflevector(h[2 * i], h[2 * i + 1], 0, 1, 2, 3, 4, 5, 6, 7));
+        bf[i] = __builtin_bit_cast(v8, (s16x8)__builtin_shufflevector(h[4 + 2 * i], h[5 + 2 * i], 0, 1, 2, 3, 4, 5, 6, 7));
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = T16<T>::mfma32(af[i], bf[j], acc[i][j]);
+    }
+  }
+
+  float* slab = d.out + (int64_t)by * d.Cout * d.Cin;
+  const int fr = lane & 31, fq = lane >> 5;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = n0 + wn * 64 + j * 32 + fr;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fq;
+        slab[(int64_t)m * d.Cin + n] = acc[i][j][r];
+      }
+  }
+}
+
 }  // namespace
 
 static inline int wgrad_bme(int Cout) {
@@ -275,6 +417,15 @@ extern "C" int asis_wgrad(void* stream, const asis_wgrad_desc* dp) {
   dim3 grid((unsigned)(asis_cdiv(d.Cout, bme) * asis_cdiv(Ntot, BN)), d.splits), block(NTHREADS);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const bool dense = d.KH == 1 && d.KW == 1 && d.stride == 1 && d.pad == 0;
+  // ASIS_WGRAD_BIG (default 1): nn.Linear weight gradients with whole 256 x 128 tiles on the LDS-DMA form
+  static const int big = [] { const char* e = getenv("ASIS_WGRAD_BIG"); return e ? atoi(e) : 1; }();
+  if (big && dense && d.Cout % 256 == 0 && d.Cin % 128 == 0 && d.CoP == d.Cout && d.P >= 1024 && d.k_per_split % 32 == 0) {
+    dim3 gb((unsigned)((d.Cout / 256) * (d.Cin / 128)), d.splits);
+    if (d.dtype == ASIS_F16) hipLaunchKernelGGL((wgrad_dense_big_kernel<f16>), gb, dim3(512), 0, s, d);
+    else hipLaunchKernelGGL((wgrad_dense_big_kernel<bf16>), gb, dim3(512), 0, s, d);
+    ASIS_CHECK_LAUNCH("asis_wgrad");
+    return ASIS_OK;
+  }
 #define ASIS_WGRAD_LAUNCH(TT, DN)                                                                         \
   do {                                                                                                    \
     if (bme == 32) hipLaunchKernelGGL((wgrad_kernel<TT, DN, 32>), grid, block, 0, s, d);                  \
