@@ -201,26 +201,32 @@ class SegEngine(nn.Module):
         return c, shapes, done
 
     def _trunk_dual(self, xcat: torch.Tensor, Ra: int, blocks, segs) -> torch.Tensor:
-        """The trunk blocks with the two token batches on two HIP streams (config.dual_stream) -> the stacked [Ra + Rb, D]."""
+        """The trunk blocks with the two token batches on two HIP streams (config.dual_stream; ASIS_TRUNK_STREAMS=4 cuts each
+        batch in two image groups: four streams) -> the stacked [Ra + Rb, D]."""
         main = torch.cuda.current_stream()
-        if getattr(self, "_dual_streams", None) is None:
-            self._dual_streams = (torch.cuda.Stream(), torch.cuda.Stream())
-        s1, s2 = self._dual_streams
-        s1.wait_stream(main)
-        s2.wait_stream(main)
-        xcat.record_stream(s1)
-        xcat.record_stream(s2)
-        xa, xb = xcat[:Ra], xcat[Ra:]
+        nper = 2 if config.trunk_streams >= 4 and min(b for b, _ in segs) >= 2 else 1
+        if getattr(self, "_dual_streams", None) is None or len(self._dual_streams) != 2 * nper:
+            self._dual_streams = tuple(torch.cuda.Stream() for _ in range(2 * nper))
+        parts = []                                   # (row slice, [(B, N)]) per stream, in row order
+        r0 = 0
+        for (B, N) in segs:
+            cuts = [0, B] if nper == 1 else [0, B // 2, B]
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                parts.append((slice(r0 + a * N, r0 + b * N), [(b - a, N)]))
+            r0 += B * N
+        xs = []
+        for st, (sl, _) in zip(self._dual_streams, parts):
+            st.wait_stream(main)
+            xcat.record_stream(st)
+            xs.append(xcat[sl])
         for blk in blocks:
-            with torch.cuda.stream(s1):
-                xa = blk.forward_rows(xa, [segs[0]])
-            with torch.cuda.stream(s2):
-                xb = blk.forward_rows(xb, [segs[1]])
-        main.wait_stream(s1)
-        main.wait_stream(s2)
-        xa.record_stream(main)
-        xb.record_stream(main)
-        return torch.cat([xa, xb], 0)
+            for i, (st, (_, sg)) in enumerate(zip(self._dual_streams, parts)):
+                with torch.cuda.stream(st):
+                    xs[i] = blk.forward_rows(xs[i], sg)
+        for st, x in zip(self._dual_streams, xs):
+            main.wait_stream(st)
+            x.record_stream(main)
+        return torch.cat(xs, 0)
 
     def _cavit(self, x2, c2, g, B, Lq, Lin):
         cv = self.cross_vit

@@ -86,3 +86,4 @@ split_attn_out = bool(split_attn_out_policy)     # what the blocks read; SegEngi
 # default policy because every remaining error term is an operand of a big GEMM (tests/precision_probe.py: LayerNorm outputs
 # 7.5e-4, SwiGLU hidden 5.2e-4, weights 8.8e-4 on the MLA output); tests/test_gpu_fulldepth.py runs that case on level 2 as well.
 precise_level = int(os.environ.get("ASIS_PRECISE_LEVEL", "0") or 0)
+trunk_streams = int(os.environ.get("ASIS_TRUNK_STREAMS", "2") or 2)     # 4: each ViT pass as two image groups (lab)
