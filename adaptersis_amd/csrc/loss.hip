@@ -347,20 +347,31 @@ __global__ __launch_bounds__(256) void resize_bwd_kernel(const float* __restrict
         (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
-// out[k] = scale * sum_n partial[n][k]   (double accumulate)
+// out[k] = scale * sum_n partial[n][k]   (double accumulate).  16 row groups x 16 columns per block: every load instruction
+// covers 64-byte row segments, four independent loads per thread in flight, one LDS pass over the 16 row groups at the end.
 __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ partial, int n, int K, float scale,
                                                           float* __restrict__ out) {
-  __shared__ double red[256];
-  const int k = blockIdx.x;
+  __shared__ double red[16][17];
+  const int c = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int k = blockIdx.x * 16 + c;
   double s = 0.0;
-  for (int i = threadIdx.x; i < n; i += 256) s += (double)partial[(int64_t)i * K + k];
-  red[threadIdx.x] = s;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-    __syncthreads();
+  if (k < K) {
+    const float* p = partial + k;
+    int i = g;
+    for (; i + 48 < n; i += 64) {
+      const float a0 = p[(int64_t)i * K], a1 = p[(int64_t)(i + 16) * K], a2 = p[(int64_t)(i + 32) * K], a3 = p[(int64_t)(i + 48) * K];
+      s += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
+    }
+    for (; i < n; i += 16) s += (double)p[(int64_t)i * K];
   }
-  if (threadIdx.x == 0) out[k] = (float)(red[0] * (double)scale);
+  red[g][c] = s;
+  __syncthreads();
+  if (g == 0 && k < K) {
+    double t = 0.0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) t += red[j][c];
+    out[k] = (float)(t * (double)scale);
+  }
 }
 
 // F.interpolate(x, size=(H, W), mode="bilinear") (align_corners=False) on NHWC fp32 (decoders.py:88, train.py:422)
@@ -575,8 +586,8 @@ extern "C" int asis_reduce_rows(void* stream, const float* partial, int n, int K
     hipLaunchKernelGGL(reduce_rows_wide_kernel, dim3((unsigned)g), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        partial, n, (int64_t)K, scale, out);
   } else {
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3(K), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), partial, n, K,
-                       scale, out);
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((K + 15) / 16), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), partial, n,
+                       K, scale, out);
   }
   ASIS_CHECK_LAUNCH("asis_reduce_rows");
   return ASIS_OK;

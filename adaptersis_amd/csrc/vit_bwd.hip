@@ -44,19 +44,39 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
   int64_t r1 = r0 + rows_per_block;
   if (r1 > rows) r1 = rows;
   const float invD = 1.0f / (float)D;
-  for (int64_t row = r0 + wid; row < r1; row += 4) {
+  // the next row's loads (x, dy, residual) are issued before this row's three wave reductions: two rows in flight per wave
+  constexpr bool PF = MAXC <= 6;   // 6 x MAXC float4 of row data + 3 x MAXC of sums / weight must fit 256 VGPRs
+  float4 v[MAXC], g[MAXC], e[MAXC];
+  auto load_row = [&](int64_t row, float4* vv, float4* gg, float4* ee) {
     const float4* xr = reinterpret_cast<const float4*>(x + row * ldx);
     const float4* gr = reinterpret_cast<const float4*>(dy + row * lddy);
-    float4 v[MAXC], g[MAXC];
-    float s = 0.f;
+    const float4* rr = res ? reinterpret_cast<const float4*>(res + row * ldr) : nullptr;
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) {
       const int c = lane + 64 * i;
       if (c < nchunk) {
-        v[i] = xr[c];
-        g[i] = gr[c];
-        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        vv[i] = xr[c];
+        gg[i] = gr[c];
+        if (rr) ee[i] = rr[c];
       }
+    }
+  };
+  int64_t row = r0 + wid;
+  if constexpr (PF) {
+    if (row < r1) load_row(row, v, g, e);
+  }
+  for (; row < r1; row += 4) {
+    float4 vn[PF ? MAXC : 1], gn[PF ? MAXC : 1], en[PF ? MAXC : 1];
+    if constexpr (PF) {
+      if (row + 4 < r1) load_row(row + 4, vn, gn, en);
+    } else {
+      load_row(row, v, g, e);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nchunk) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     }
     const float mean = wave_sum(s) * invD;
     float q = 0.f;
@@ -85,7 +105,6 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     a = wave_sum(a) * invD;
     bq = wave_sum(bq) * invD;
     float4* o = reinterpret_cast<float4*>(dx + row * lddx);
-    const float4* rr = res ? reinterpret_cast<const float4*>(res + row * ldr) : nullptr;
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) {
       const int c = lane + 64 * i;
@@ -95,11 +114,18 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         t.y = rstd * (g[i].y - a - v[i].y * bq);
         t.z = rstd * (g[i].z - a - v[i].z * bq);
         t.w = rstd * (g[i].w - a - v[i].w * bq);
-        if (rr) {
-          const float4 e = rr[c];
-          t.x += e.x; t.y += e.y; t.z += e.z; t.w += e.w;
+        if (res) {
+          t.x += e[i].x; t.y += e[i].y; t.z += e[i].z; t.w += e[i].w;
         }
         o[c] = t;
+      }
+    }
+    if constexpr (PF) {
+#pragma unroll
+      for (int i = 0; i < MAXC; ++i) {
+        v[i] = vn[i];
+        g[i] = gn[i];
+        e[i] = en[i];
       }
     }
   }
@@ -198,7 +224,17 @@ __global__ __launch_bounds__(256) void colsum16_kernel(const T* __restrict__ x, 
   if (r1 > rows) r1 = rows;
   for (int c8 = blockIdx.y * blockDim.x + threadIdx.x; c8 < (C >> 3); c8 += gridDim.y * blockDim.x) {
     float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int64_t r = r0; r < r1; ++r) {
+    int64_t r = r0;
+    for (; r + 3 < r1; r += 4) {   // four independent 16-byte loads in flight per thread
+      v8 v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const v8*>(x + (r + j) * ld + c8 * 8);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s[k] += (float)v[j][k];
+    }
+    for (; r < r1; ++r) {
       const v8 v = *reinterpret_cast<const v8*>(x + r * ld + c8 * 8);
 #pragma unroll
       for (int k = 0; k < 8; ++k) s[k] += (float)v[k];
@@ -334,6 +370,9 @@ extern "C" int asis_layernorm_bwd(void* stream, const float* dy, int64_t lddy, c
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (D <= 1024)
     hipLaunchKernelGGL((layernorm_bwd_kernel<4>), dim3(nblk), dim3(256), 0, s, dy, lddy, x, ldx, w, eps, res, ldr, dx, lddx,
+                       partial, rows, D, rpb);
+  else if (D <= 1536)
+    hipLaunchKernelGGL((layernorm_bwd_kernel<6>), dim3(nblk), dim3(256), 0, s, dy, lddy, x, ldx, w, eps, res, ldr, dx, lddx,
                        partial, rows, D, rpb);
   else
     hipLaunchKernelGGL((layernorm_bwd_kernel<LN_MAXC>), dim3(nblk), dim3(256), 0, s, dy, lddy, x, ldx, w, eps, res, ldr, dx,
