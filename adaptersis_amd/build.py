@@ -42,9 +42,13 @@ def _deps_mtime() -> float:
     return max(os.path.getmtime(h) for h in hdrs)
 
 
+# per-file additions to FLAGS
+FILE_FLAGS = {"attention.hip": ("-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form")}
+
+
 def _compile(src: str, verbose: bool) -> str:
     obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
-    cmd = [_hipcc(), *FLAGS, "-c", src, "-o", obj]
+    cmd = [_hipcc(), *FLAGS, *FILE_FLAGS.get(os.path.basename(src), ()), "-c", src, "-o", obj]
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)

@@ -37,6 +37,10 @@ split_conv = os.environ.get("ASIS_SPLIT_CONV", "1") != "0"
 # weights to 16 bits is the largest error term on the adapter stream — it is the same for every token, so it adds up
 # coherently through the blocks — and qkv + proj carry 55 % of its energy.  Off by default: +33 % linear-layer FLOPs.
 precise_attention = os.environ.get("ASIS_PRECISE", "0") not in ("0", "")
+# forward-only attention (frozen trunk, `Attention.attend_rows`): softmax scale * log2(e) folded into the q rows of the qkv
+# projection weight / bias before their 16-bit rounding, attention through asis_attention_fwd_prescaled (ASIS_FOLD_SCALE=0:
+# the unfolded kernel).  The training forward / backward keep the unfolded q (the backward rebuilds P from q, k, scale).
+fold_attn_scale = os.environ.get("ASIS_FOLD_SCALE", "1") not in ("0", "")
 
 # The CNN encoder of the frozen-backbone step runs on a side HIP stream, overlapped with the ViT block loop
 # (engines.SegEngine._encoder_on_side_stream).  ASIS_ENC_STREAM=0: everything on the compute stream.

@@ -309,11 +309,14 @@ template <typename T, int SCHED, int DBG = 0>
 __global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(const T* __restrict__ q, const T* __restrict__ k, int64_t ldqk,
                                                               const T* __restrict__ vt, int64_t ldvt, T* __restrict__ o, T* __restrict__ o_lo,
                                                               int64_t ldo, int H, int N1, float scale_log2e,
-                                                              float* __restrict__ lse2, int B1, int N2) {
+                                                              float* __restrict__ lse2, int B1, int N2, int prescaled) {
   typedef typename T16<T>::v8 v8;
   typedef __attribute__((address_space(3))) void* lds_ptr;
   typedef const __attribute__((address_space(1))) void* glb_ptr;
   __shared__ __attribute__((aligned(16))) T lds[5 * KT * HD];  // K ring [3][64][64] | V^T ring [2][64][64] = 40 KiB
+  // FOLD (SCHED 3): q is pre-scaled by scale * log2(e) and the running maximum enters the score MFMA chain as its initial
+  // accumulator (a 16-register block holding -m, rewritten only when m moves), so P = exp2(S') with no per-element fma.
+  constexpr bool FOLD = SCHED == 3;
   T* const Kr = lds;
   T* const Vr = lds + 3 * KT * HD;
 
@@ -334,6 +337,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(const T* __restri
     const T* qp = q + (row0 + (qi < N ? qi : N - 1)) * ldqk + head * HD + 8 * fh;
 #pragma unroll
     for (int s = 0; s < 4; ++s) qf[s] = __builtin_bit_cast(v8, *reinterpret_cast<const uint4*>(qp + 16 * s));
+    if (FOLD && !prescaled) {  // q' = q * scale * log2(e): the scores leave the MFMA already in exp2 units
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qf[s][j] = (T)((float)qf[s][j] * scale_log2e);
+    }
   }
 
   const T* kbase = k + row0 * ldqk + head * HD;
@@ -379,7 +388,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(const T* __restri
   f32x16 oacc[2];
 #pragma unroll
   for (int r = 0; r < 16; ++r) oacc[0][r] = oacc[1][r] = 0.f;
-  float m_run = -1e30f, l_run = 0.f;
+  float m_run = FOLD ? 0.f : -1e30f, l_run = 0.f;
+  f32x16 nmb;  // FOLD: -m_run in every element (the C operand that opens each score chain)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) nmb[r] = 0.f;
   const int prow = perm23(fr);
   constexpr float RESCALE_THR = 6.0f;
 
@@ -395,6 +407,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(const T* __restri
     }
   };
   auto s_mfma = [&](const v8 (&ka)[2][4], f32x16 (&sacc)[2]) {
+    if (FOLD) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) sacc[kb] = T16<T>::mfma32(ka[kb][s], qf[s], s == 0 ? nmb : sacc[kb]);
+      return;
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) sacc[0][r] = sacc[1][r] = 0.f;
 #pragma unroll
@@ -429,9 +448,32 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(const T* __restri
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, cur[kb][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * scale_log2e;
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    if (!FOLD) mx *= scale_log2e;
     if (DBG) tk[2] = clk_after(mx);
-    if (__any(mx > m_run + RESCALE_THR)) {
+    if (FOLD) {
+      // cur holds s - m_run (the offset its chain was opened with); mx is the tile maximum relative to m_run
+      if (t == 0 || __any(mx > RESCALE_THR)) {
+        const float m_new = t == 0 ? mx : fmaxf(m_run, m_run + mx);
+        const float delta = m_run - m_new;
+        if (t != 0) {
+          const float alpha = __builtin_amdgcn_exp2f(delta);
+          l_run *= alpha;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            oacc[0][r] *= alpha;
+            oacc[1][r] *= alpha;
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          cur[0][r] += delta;
+          cur[1][r] += delta;
+          nmb[r] = -m_new;
+        }
+        m_run = m_new;
+      }
+    } else if (__any(mx > m_run + RESCALE_THR)) {
       const float m_new = fmaxf(m_run, mx);
       const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
       m_run = m_new;
@@ -446,9 +488,42 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(const T* __restri
     // S(t+1) goes to the matrix pipe here, in the same basic block as the exponentials of tile t
     if (!tail) s_mfma(ka, nxt);
     typedef float f32x2 __attribute__((ext_vector_type(2)));
+    v8 pf[2][2];
+    if (FOLD) {
+      // (row sums as four more MFMAs per tile, ones[32 x keys] . P, were tried: slower than the 32 adds -- the matrix pipe is
+      // the shared resource of the two waves on a SIMD)
+      float ps0 = 0.f, ps1 = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const float p0 = __builtin_amdgcn_exp2f(cur[kb][r]), p1 = __builtin_amdgcn_exp2f(cur[kb][r + 1]);
+          ps0 += p0;
+          ps1 += p1;
+          pf[kb][r >> 3][r & 7] = (T)p0;
+          pf[kb][r >> 3][(r & 7) + 1] = (T)p1;
+        }
+      l_run += ps0 + ps1;
+    } else if (SCHED == 2) {
+      // single-issue f32 ops only: beside MFMAs a v_pk_fma_f32 / v_pk_add_f32 costs several times two plain ops
+      // (MI355X_MICROARCH.md, per-instruction constants); this file is built with -fno-slp-vectorize so they stay unpacked
+      const float nm = -m_run;
+      float ps0 = 0.f, ps1 = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const float t0 = __builtin_fmaf(cur[kb][r], scale_log2e, nm), t1 = __builtin_fmaf(cur[kb][r + 1], scale_log2e, nm);
+          const float p0 = __builtin_amdgcn_exp2f(t0), p1 = __builtin_amdgcn_exp2f(t1);
+          ps0 += p0;
+          ps1 += p1;
+          pf[kb][r >> 3][r & 7] = (T)p0;
+          pf[kb][r >> 3][(r & 7) + 1] = (T)p1;
+        }
+      l_run += ps0 + ps1;
+    } else {
     const f32x2 sc2 = {scale_log2e, scale_log2e}, nm2 = {-m_run, -m_run};
     f32x2 ps2 = {0.f, 0.f};
-    v8 pf[2][2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -463,6 +538,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(const T* __restri
         pf[kb][r >> 3][(r & 7) + 1] = (T)p2.y;
       }
     l_run += ps2.x + ps2.y;
+    }
     if (DBG) tk[4] = clk_after(l_run + (float)pf[1][1][7]);
     const T* Vs = Vr + (t & 1) * (KT * HD);
 #pragma unroll
@@ -563,11 +639,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(const T* __restri
   }
 }
 
+#include "attention_w64.h"
+
 }  // namespace
 
-extern "C" int asis_attention_fwd_split(void* stream, int dtype, const void* q, const void* k, int64_t ldqk, const void* vt,
-                                        int64_t ldvt, void* o, void* o_lo, int64_t ldo, int B1, int N1, int B2, int N2, int H,
-                                        float scale, float* lse2) {
+static int attention_fwd_impl(void* stream, int dtype, const void* q, const void* k, int64_t ldqk, const void* vt,
+                              int64_t ldvt, void* o, void* o_lo, int64_t ldo, int B1, int N1, int B2, int N2, int H,
+                              float scale, float* lse2, int prescaled) {
   const int B = B1 + B2;
   ASIS_REQUIRE(!o_lo || (((uintptr_t)o_lo) & 7) == 0, "asis_attention_fwd: o_lo must be 8-byte aligned");
   const int N = N1 > N2 ? N1 : N2;
@@ -592,16 +670,29 @@ extern "C" int asis_attention_fwd_split(void* stream, int dtype, const void* q, 
   static const int abl = [] { const char* e = getenv("ASIS_ATTN_ABLATE"); return e ? atoi(e) : 0; }();
   // ASIS_ATTN_PIPE: 0 = the two-buffer register-staged kernel, 1 = software-pipelined LDS-DMA kernel, 2 = the same with
   // an explicit MFMA / VALU interleave
+  // 3 = 1 with single-issue f32 softmax arithmetic, 4 = folded form (q pre-scaled in the kernel, -m in the score chain),
+  // 5 = one wave per SIMD (attention_w64.h, lab).  q already pre-scaled by the caller (`prescaled`): the folded form.
   static const int pipe = [] { const char* e = getenv("ASIS_ATTN_PIPE"); return e ? atoi(e) : 1; }();
-  if (pipe && abl == 6 && dtype == ASIS_F16) {
-    hipLaunchKernelGGL((attn_fwd_pipe_kernel<f16, 0, 1>), grid, block, 0, s, (const f16*)q, (const f16*)k, ldqk, (const f16*)vt, ldvt, (f16*)o, (f16*)o_lo, ldo, H, N1, sl, lse2, B1, N2);
+  ASIS_REQUIRE(!prescaled || (!abl && (pipe == 1 || pipe == 4 || pipe == 5)),
+               "asis_attention_fwd_prescaled: only the folded kernels take a pre-scaled q (ASIS_ATTN_PIPE 1 | 4 | 5, no ablation)");
+  if (pipe == 5 && !abl) {  // one wave per SIMD, 256 query rows per workgroup
+    dim3 grid64((N + 255) / 256, H, B);
+    if (dtype == ASIS_F16)
+      hipLaunchKernelGGL((attn_fwd_w64_kernel<f16>), grid64, block, 0, s, (const f16*)q, (const f16*)k, ldqk, (const f16*)vt, ldvt,
+                         (f16*)o, (f16*)o_lo, ldo, H, N1, sl, lse2, B1, N2, prescaled);
+    else
+      hipLaunchKernelGGL((attn_fwd_w64_kernel<bf16>), grid64, block, 0, s, (const bf16*)q, (const bf16*)k, ldqk, (const bf16*)vt,
+                         ldvt, (bf16*)o, (bf16*)o_lo, ldo, H, N1, sl, lse2, B1, N2, prescaled);
+  } else if (pipe && abl == 6 && dtype == ASIS_F16) {
+    hipLaunchKernelGGL((attn_fwd_pipe_kernel<f16, 0, 1>), grid, block, 0, s, (const f16*)q, (const f16*)k, ldqk, (const f16*)vt, ldvt, (f16*)o, (f16*)o_lo, ldo, H, N1, sl, lse2, B1, N2, 0);
   } else if (pipe && !abl) {
 #define ASIS_ATTN_PIPE_LAUNCH(TT, SC)                                                                                   \
   hipLaunchKernelGGL((attn_fwd_pipe_kernel<TT, SC>), grid, block, 0, s, reinterpret_cast<const TT*>(q),                \
                      reinterpret_cast<const TT*>(k), ldqk, reinterpret_cast<const TT*>(vt), ldvt, reinterpret_cast<TT*>(o), \
-                     reinterpret_cast<TT*>(o_lo), ldo, H, N1, sl, lse2, B1, N2)
-    if (dtype == ASIS_F16) { if (pipe == 2) ASIS_ATTN_PIPE_LAUNCH(f16, 1); else ASIS_ATTN_PIPE_LAUNCH(f16, 0); }
-    else { if (pipe == 2) ASIS_ATTN_PIPE_LAUNCH(bf16, 1); else ASIS_ATTN_PIPE_LAUNCH(bf16, 0); }
+                     reinterpret_cast<TT*>(o_lo), ldo, H, N1, sl, lse2, B1, N2, prescaled)
+    const bool fold = pipe == 4 || prescaled;
+    if (dtype == ASIS_F16) { if (fold) ASIS_ATTN_PIPE_LAUNCH(f16, 3); else if (pipe == 2) ASIS_ATTN_PIPE_LAUNCH(f16, 1); else if (pipe == 3) ASIS_ATTN_PIPE_LAUNCH(f16, 2); else ASIS_ATTN_PIPE_LAUNCH(f16, 0); }
+    else { if (fold) ASIS_ATTN_PIPE_LAUNCH(bf16, 3); else if (pipe == 2) ASIS_ATTN_PIPE_LAUNCH(bf16, 1); else if (pipe == 3) ASIS_ATTN_PIPE_LAUNCH(bf16, 2); else ASIS_ATTN_PIPE_LAUNCH(bf16, 0); }
 #undef ASIS_ATTN_PIPE_LAUNCH
   } else if (abl && dtype == ASIS_F16) {
     if (abl == 1) hipLaunchKernelGGL((attn_fwd_kernel<f16, 2, 1>), grid, block, 0, s, (const f16*)q, (const f16*)k, ldqk, (const f16*)vt, ldvt, (f16*)o, (f16*)o_lo, ldo, H, N1, sl, lse2, B1, N2);
@@ -617,6 +708,18 @@ extern "C" int asis_attention_fwd_split(void* stream, int dtype, const void* q, 
 #undef ASIS_ATTN_LAUNCH
   ASIS_CHECK_LAUNCH("asis_attention_fwd");
   return ASIS_OK;
+}
+
+extern "C" int asis_attention_fwd_split(void* stream, int dtype, const void* q, const void* k, int64_t ldqk, const void* vt,
+                                        int64_t ldvt, void* o, void* o_lo, int64_t ldo, int B1, int N1, int B2, int N2, int H,
+                                        float scale, float* lse2) {
+  return attention_fwd_impl(stream, dtype, q, k, ldqk, vt, ldvt, o, o_lo, ldo, B1, N1, B2, N2, H, scale, lse2, 0);
+}
+
+extern "C" int asis_attention_fwd_prescaled(void* stream, int dtype, const void* q, const void* k, int64_t ldqk, const void* vt,
+                                            int64_t ldvt, void* o, void* o_lo, int64_t ldo, int B1, int N1, int B2, int N2, int H,
+                                            float* lse2) {
+  return attention_fwd_impl(stream, dtype, q, k, ldqk, vt, ldvt, o, o_lo, ldo, B1, N1, B2, N2, H, 1.0f, lse2, 1);
 }
 
 extern "C" int asis_attention_fwd_seg(void* stream, int dtype, const void* q, const void* k, int64_t ldqk, const void* vt,

@@ -192,6 +192,27 @@ class Attention(_Packed):
         self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
         self.proj = nn.Linear(dim, dim, bias=proj_bias)
 
+    def _qkv_folded(self):
+        """(16-bit qkv weight, fp32 bias, rounding residual | None) with the q rows multiplied by scale * log2(e) in fp32
+        BEFORE the 16-bit rounding (`attention.py:58-60`: q * scale; the log2(e) turns exp into exp2): q' leaves the GEMM
+        with one rounding, the attention kernel needs neither the multiply nor the subtraction per score."""
+        c = self.scale * 1.4426950408889634
+        D = self.qkv.weight.shape[1]
+
+        def scaled(p):
+            w = p.reshape(p.shape[0], -1).float().clone()
+            w[:D] *= c
+            return w.contiguous()
+        w = _pack(self._cache, "qkv.fold", self.qkv.weight, lambda p: ops.cast_pad(scaled(p), dtype=config.operand_dtype))
+        wlo = None
+        if config.precise_attention:
+            wlo = _pack(self._cache, "qkv.fold.lo", self.qkv.weight,
+                        lambda p: ops.cast_pad(scaled(p), dtype=config.operand_dtype, part=1))
+        bias = None
+        if self.qkv.bias is not None:
+            bias = _pack(self._cache, "qkv_b.fold", self.qkv.bias, lambda p: scaled(p).reshape(-1))
+        return w, bias, wlo
+
     def attend(self, xn: torch.Tensor, B: int, N: int) -> torch.Tensor:
         """xn: 16-bit [B*N, D] (already normalised) -> 16-bit attention output [B*N, D] (before proj)."""
         return self.attend_rows(xn, [(B, N)])[0]
@@ -201,9 +222,14 @@ class Attention(_Packed):
         patch-token pass of `train.py:287,300-302`): one q|k GEMM over all rows, attention per batch.
         -> (o, o_lo): o_lo = the rounding residual of o (config.split_attn_out) or None."""
         D = xn.shape[1]
-        w = self._w16("qkv", self.qkv.weight)  # [3D, D] rows q | k | v
-        bias = self._f32("qkv_b", self.qkv.bias)
-        wlo = self._w16lo("qkv", self.qkv.weight)
+        if config.fold_attn_scale:
+            w, bias, wlo = self._qkv_folded()       # q rows carry scale * log2(e): asis_attention_fwd_prescaled
+            scale = None
+        else:
+            w = self._w16("qkv", self.qkv.weight)  # [3D, D] rows q | k | v
+            bias = self._f32("qkv_b", self.qkv.bias)
+            wlo = self._w16lo("qkv", self.qkv.weight)
+            scale = self.scale
         o = torch.empty((xn.shape[0], D), device=xn.device, dtype=xn.dtype)
         o_lo = torch.empty_like(o) if config.split_attn_out else None   # rounding residual of o: proj's split A operand
         one_launch = len(segs) == 2
@@ -232,7 +258,7 @@ class Attention(_Packed):
                          out=vt.as_strided((B, D, N4), (D * ldvt, ldvt, 1)), bias_m=None if bias is None else bias[2 * D:],
                          a_lo=None if wlo is None else wlo[2 * D:])
             if not one_launch:
-                ops.attention_fwd(qk[r0:r1, :D], qk[r0:r1, D:], vt, B, self.num_heads, N, self.scale, out=o[r0:r1],
+                ops.attention_fwd(qk[r0:r1, :D], qk[r0:r1, D:], vt, B, self.num_heads, N, scale, out=o[r0:r1],
                                   out_lo=None if o_lo is None else o_lo[r0:r1])
             r0, b0 = r1, b0 + B
         if side is not None:
@@ -240,7 +266,7 @@ class Attention(_Packed):
             main.wait_stream(side)
         if one_launch:  # both token batches in one launch (fewer partial rounds of workgroups)
             (B1, N1), (B2, N2) = segs
-            ops.attention_fwd_seg(qk[:, :D], qk[:, D:], vt_all, B1, N1, B2, N2, self.num_heads, self.scale, out=o, out_lo=o_lo)
+            ops.attention_fwd_seg(qk[:, :D], qk[:, D:], vt_all, B1, N1, B2, N2, self.num_heads, scale, out=o, out_lo=o_lo)
         if r0 != xn.shape[0]:
             raise ValueError("attend_rows: segments do not cover the rows")
         return o, o_lo

@@ -241,10 +241,23 @@ def _check_out_lo(out: torch.Tensor, out_lo: Optional[torch.Tensor]) -> None:
         raise ValueError("attention_fwd: out_lo must share the shape, layout and dtype of out")
 
 
-def attention_fwd(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, B: int, H: int, N: int, scale: float,
+def _attention_launch(q, k, vt, out, out_lo, B1, N1, B2, N2, H, scale, lse):
+    """``scale`` None: q already carries scale * log2(e) (folded into the projection weights) -> the folded kernel"""
+    if scale is None:
+        check(lib().asis_attention_fwd_prescaled(_stream(), _dt(q.dtype), q.data_ptr(), k.data_ptr(), q.stride(0), vt.data_ptr(),
+                                                 vt.stride(1), out.data_ptr(), _p(out_lo), out.stride(0), B1, N1, B2, N2, H,
+                                                 _p(lse)), "asis_attention_fwd_prescaled")
+    else:
+        check(lib().asis_attention_fwd_split(_stream(), _dt(q.dtype), q.data_ptr(), k.data_ptr(), q.stride(0), vt.data_ptr(),
+                                             vt.stride(1), out.data_ptr(), _p(out_lo), out.stride(0), B1, N1, B2, N2, H,
+                                             float(scale), _p(lse)), "asis_attention_fwd")
+
+
+def attention_fwd(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, B: int, H: int, N: int, scale: Optional[float],
                   out: Optional[torch.Tensor] = None, lse: Optional[torch.Tensor] = None,
                   out_lo: Optional[torch.Tensor] = None) -> torch.Tensor:
     """q, k: [B*N, >=H*64] views (same row stride); vt: [B, H*64, ldvt]; returns o [B*N, H*64].
+    ``scale`` None = q was produced with scale * log2(e) folded into its projection (``Attention._qkv_folded``).
     ``lse``: optional fp32 [B,H,N] receiving the per-query log2-sum-exp (training forward).
     ``out_lo``: optional tensor laid out like ``out`` receiving the rounding residual of the 16-bit output (o ~= out + out_lo:
     the projection GEMM's split A operand, config.split_attn_out)."""
@@ -256,22 +269,18 @@ def attention_fwd(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, B: int, H:
     if lse is not None and (lse.dtype != torch.float32 or lse.numel() != B * H * N or not lse.is_contiguous()):
         raise ValueError("attention_fwd: lse must be contiguous float32 [B,H,N]")
     _check_out_lo(out, out_lo)
-    check(lib().asis_attention_fwd_split(_stream(), _dt(q.dtype), q.data_ptr(), k.data_ptr(), q.stride(0), vt.data_ptr(),
-                                         vt.stride(1), out.data_ptr(), _p(out_lo), out.stride(0), B, N, 0, 0, H, float(scale),
-                                         _p(lse)), "asis_attention_fwd")
+    _attention_launch(q, k, vt, out, out_lo, B, N, 0, 0, H, scale, lse)
     return out
 
 
 def attention_fwd_seg(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, B1: int, N1: int, B2: int, N2: int, H: int,
-                      scale: float, out: torch.Tensor, out_lo: Optional[torch.Tensor] = None) -> torch.Tensor:
+                      scale: Optional[float], out: torch.Tensor, out_lo: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Two stacked token batches in one launch: q, k [B1*N1 + B2*N2, >=H*64] row views, vt [B1+B2, H*64, ldvt]."""
     _dev(q, k, vt, out, out_lo)
     _check_out_lo(out, out_lo)
     if q.stride(0) != k.stride(0) or q.stride(1) != 1 or k.stride(1) != 1 or q.shape[0] != B1 * N1 + B2 * N2:
         raise ValueError("attention_fwd_seg: q and k must be row views over both batches with one row stride")
-    check(lib().asis_attention_fwd_split(_stream(), _dt(q.dtype), q.data_ptr(), k.data_ptr(), q.stride(0), vt.data_ptr(),
-                                         vt.stride(1), out.data_ptr(), _p(out_lo), out.stride(0), B1, N1, B2, N2, H, float(scale),
-                                         None), "asis_attention_fwd")
+    _attention_launch(q, k, vt, out, out_lo, B1, N1, B2, N2, H, scale, None)
     return out
 
 

@@ -147,6 +147,12 @@ int asis_attention_fwd_seg(void* stream, int dtype, const void* q, const void* k
  * sensitive decode heads amplify (tests/precision_probe.py: the largest single error term on the UNet / MLA logits). */
 int asis_attention_fwd_split(void* stream, int dtype, const void* q, const void* k, int64_t ldqk, const void* vt, int64_t ldvt,
                              void* o, void* o_lo, int64_t ldo, int B1, int N1, int B2, int N2, int H, float scale, float* lse2);
+/* same as asis_attention_fwd_split for a q that already carries scale * log2(e) (folded into the q rows of the qkv
+ * projection weight and bias before their 16-bit rounding, dinov2/layers/attention.py:58-60: q' = x (c W_q)^T + c b_q):
+ * the scores leave the MFMA in exp2 units and the running maximum enters the score chain as its initial accumulator, so
+ * P = exp2(S') needs no per-element multiply-add (-5 % kernel time).  lse2 as below. */
+int asis_attention_fwd_prescaled(void* stream, int dtype, const void* q, const void* k, int64_t ldqk, const void* vt, int64_t ldvt,
+                                 void* o, void* o_lo, int64_t ldo, int B1, int N1, int B2, int N2, int H, float* lse2);
 /* same, also writing lse2[B,H,N] = log2 sum_k exp2(log2(e) * scale * q.k) per query (what asis_attention_bwd
  * needs to rebuild the probabilities); lse2 NULL = asis_attention_fwd */
 int asis_attention_fwd_lse(void* stream, int dtype, const void* q, const void* k, int64_t ldqk, const void* vt,
