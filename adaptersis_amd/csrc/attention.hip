@@ -639,8 +639,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(const T* __restri
   }
 }
 
-#include "attention_w64.h"
-
 }  // namespace
 
 static int attention_fwd_impl(void* stream, int dtype, const void* q, const void* k, int64_t ldqk, const void* vt,
@@ -670,20 +668,12 @@ static int attention_fwd_impl(void* stream, int dtype, const void* q, const void
   static const int abl = [] { const char* e = getenv("ASIS_ATTN_ABLATE"); return e ? atoi(e) : 0; }();
   // ASIS_ATTN_PIPE: 0 = the two-buffer register-staged kernel, 1 = software-pipelined LDS-DMA kernel, 2 = the same with
   // an explicit MFMA / VALU interleave
-  // 3 = 1 with single-issue f32 softmax arithmetic, 4 = folded form (q pre-scaled in the kernel, -m in the score chain),
-  // 5 = one wave per SIMD (attention_w64.h, lab).  q already pre-scaled by the caller (`prescaled`): the folded form.
+  // 3 = 1 with single-issue f32 softmax arithmetic, 4 = folded form (q pre-scaled in the kernel, -m in the score chain).
+  // q already pre-scaled by the caller (`prescaled`): the folded form.
   static const int pipe = [] { const char* e = getenv("ASIS_ATTN_PIPE"); return e ? atoi(e) : 1; }();
-  ASIS_REQUIRE(!prescaled || (!abl && (pipe == 1 || pipe == 4 || pipe == 5)),
-               "asis_attention_fwd_prescaled: only the folded kernels take a pre-scaled q (ASIS_ATTN_PIPE 1 | 4 | 5, no ablation)");
-  if (pipe == 5 && !abl) {  // one wave per SIMD, 256 query rows per workgroup
-    dim3 grid64((N + 255) / 256, H, B);
-    if (dtype == ASIS_F16)
-      hipLaunchKernelGGL((attn_fwd_w64_kernel<f16>), grid64, block, 0, s, (const f16*)q, (const f16*)k, ldqk, (const f16*)vt, ldvt,
-                         (f16*)o, (f16*)o_lo, ldo, H, N1, sl, lse2, B1, N2, prescaled);
-    else
-      hipLaunchKernelGGL((attn_fwd_w64_kernel<bf16>), grid64, block, 0, s, (const bf16*)q, (const bf16*)k, ldqk, (const bf16*)vt,
-                         ldvt, (bf16*)o, (bf16*)o_lo, ldo, H, N1, sl, lse2, B1, N2, prescaled);
-  } else if (pipe && abl == 6 && dtype == ASIS_F16) {
+  ASIS_REQUIRE(!prescaled || (!abl && (pipe == 1 || pipe == 4)),
+               "asis_attention_fwd_prescaled: only the folded kernel takes a pre-scaled q (ASIS_ATTN_PIPE 1 | 4, no ablation)");
+  if (pipe && abl == 6 && dtype == ASIS_F16) {
     hipLaunchKernelGGL((attn_fwd_pipe_kernel<f16, 0, 1>), grid, block, 0, s, (const f16*)q, (const f16*)k, ldqk, (const f16*)vt, ldvt, (f16*)o, (f16*)o_lo, ldo, H, N1, sl, lse2, B1, N2, 0);
   } else if (pipe && !abl) {
 #define ASIS_ATTN_PIPE_LAUNCH(TT, SC)                                                                                   \

@@ -209,6 +209,69 @@ def test_attention_forces_online_softmax_rescale(dev):
     assert rel_l2(o[17], ref[17]) < 2e-3
 
 
+C_FOLD = 0.125 * 1.4426950408889634   # scale * log2(e)
+
+
+def _fold_case(dev, dt, B, H, N, spike=False, seed="fa"):
+    D = H * 64
+    q = W.tensor(f"{seed}.q{N}", (B, N, H, 64), 2.0)
+    k = W.tensor(f"{seed}.k{N}", (B, N, H, 64), 2.0)
+    v = W.tensor(f"{seed}.v{N}", (B, N, H, 64), 1.0)
+    if spike:   # a key spike in a late tile makes the running maximum jump: the rescale branch of the folded form
+        k[0, N - 40, 0] = 5.0 * q[0, 17, 0]
+        k[0, 70, 0] = 3.0 * q[0, 18, 0]
+    qs = (q * C_FOLD).to(dev).to(dt)           # what the folded projection produces: ONE rounding of the scaled q
+    k, v = k.to(dev).to(dt), v.to(dev).to(dt)
+    qk = torch.cat([qs.reshape(B * N, D), k.reshape(B * N, D)], dim=1).contiguous()
+    ldvt = (N + 63) // 64 * 64
+    vt = torch.full((B, D, ldvt), float("nan"), device=dev, dtype=dt)
+    vt[:, :, :N] = v.reshape(B, N, D).transpose(1, 2)
+    qf, kf, vf = (t.float().permute(0, 2, 1, 3) for t in (qs, k, v))
+    s2 = qf @ kf.transpose(-1, -2)             # scores in exp2 units
+    p = torch.softmax(s2 * 0.6931471805599453, -1)
+    ref = (p @ vf).permute(0, 2, 1, 3).reshape(B * N, D)
+    lse2 = torch.logsumexp(s2 * 0.6931471805599453, -1) * 1.4426950408889634    # [B, H, N]
+    return qk, vt, ref, lse2
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("B,H,N,spike", [(1, 1, 64, False), (2, 2, 257, False), (2, 2, 1765, False), (1, 1, 100, False),
+                                         (1, 2, 300, True)])
+def test_attention_fwd_prescaled(dev, dt, B, H, N, spike):
+    """asis_attention_fwd_prescaled (scale=None): q carries scale * log2(e), the maximum rides in the score chain; output,
+    log-sum-exp and the split output against fp32 on the same 16-bit operands."""
+    D = H * 64
+    qk, vt, ref, lse_ref = _fold_case(dev, dt, B, H, N, spike)
+    lse = torch.empty((B, H, N), device=dev, dtype=torch.float32)
+    o_lo = torch.empty((B * N, D), device=dev, dtype=dt)
+    o = ops.attention_fwd(qk[:, :D], qk[:, D:], vt, B, H, N, None, lse=lse, out_lo=o_lo)
+    assert torch.isfinite(o.float()).all()
+    err, err_split = rel_l2(o, ref), rel_l2(o.float() + o_lo.float(), ref)
+    print(f"folded attention {dt} B={B} H={H} N={N} spike={spike}: rel-L2 {err:.2e} split {err_split:.2e}")
+    assert err < (1e-3 if dt == torch.float16 else 1e-2)
+    assert err_split < (4e-4 if dt == torch.float16 else 4e-3)
+    assert (lse - lse_ref).abs().max() < 2e-3
+    if spike:
+        assert rel_l2(o[17], ref[17]) < 2e-3 and rel_l2(o[18], ref[18]) < 2e-3
+
+
+def test_attention_fwd_prescaled_two_segments(dev):
+    """both token batches of the step in one launch (N1 = cls + patches, N2 = patches), folded form"""
+    dt, H = torch.float16, 2
+    D = H * 64
+    (B1, N1), (B2, N2) = (2, 257), (2, 256)
+    qk1, vt1, ref1, _ = _fold_case(dev, dt, B1, H, N1, seed="s1")
+    qk2, vt2, ref2, _ = _fold_case(dev, dt, B2, H, N2, seed="s2")
+    qk = torch.cat([qk1, qk2]).contiguous()
+    ld = 320
+    vt = torch.zeros((B1 + B2, D, ld), device=dev, dtype=dt)
+    vt[:B1, :, :N1] = vt1[:, :, :N1]
+    vt[B1:, :, :N2] = vt2[:, :, :N2]
+    o = torch.empty((qk.shape[0], D), device=dev, dtype=dt)
+    ops.attention_fwd_seg(qk[:, :D], qk[:, D:], vt, B1, N1, B2, N2, H, None, out=o)
+    assert rel_l2(o, torch.cat([ref1, ref2])) < 1e-3
+
+
 def test_im2col_and_cls_pos(dev):
     img, _ = W.synthetic_batch(2, 56)
     img = img.to(dev)
