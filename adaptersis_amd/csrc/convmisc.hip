@@ -270,6 +270,80 @@ __global__ __launch_bounds__(256) void bn_relu_upsample_kernel(const float* __re
   }
 }
 
+// Same arithmetic (tap order, weights) with the index algebra taken out: grid = (column chunks, output rows, images), eight
+// channels per thread -> no 64-bit division per element and 16-byte stores for both halves.  The generic kernel above spends
+// most of its time on i / cpt, pix / OW, pix / (OW * OH) in 64 bits for 8 bytes of output (2.7 TB/s of writes where a bare
+// 16-byte fill runs at 4.4 - 5.8 TB/s, scripts/ln_lab.hip).
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_upsample8_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                                const float* __restrict__ shift, T* __restrict__ out,
+                                                                T* __restrict__ out_lo, int H, int W, int OH, int OW, int C) {
+  constexpr int ROWS = 4;  // output rows per thread: 4x fewer waves to launch for the same bytes, source rows re-read from L1
+  const int cp8 = C >> 3;
+  // XCD-aware order: consecutive output rows re-read the same two source rows, so every XCD (one L2 each, blocks dealt
+  // round-robin) gets a contiguous run of (image, row group, column chunk) instead of every eighth block
+  const int gx = gridDim.x, gy = gridDim.y;
+  const int lin = xcd_remap(blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z), gx * gy * gridDim.z);
+  const int bx = lin % gx, og = (lin / gx) % gy, b = lin / (gx * gy);
+  const int j = bx * 256 + threadIdx.x;
+  if (j >= OW * cp8) return;
+  const int ow = j / cp8, c8 = j - ow * cp8;
+  const float rh = OH > 1 ? (float)(H - 1) / (float)(OH - 1) : 0.f;
+  const float rw = OW > 1 ? (float)(W - 1) / (float)(OW - 1) : 0.f;
+  const float w1r = rw * ow;
+  const int w1 = (int)w1r;
+  const int w1p = (w1 < W - 1) ? 1 : 0;
+  const float wl = w1r - w1;
+  float4 sc[2], sh[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    sc[h] = reinterpret_cast<const float4*>(scale)[2 * c8 + h];
+    sh[h] = reinterpret_cast<const float4*>(shift)[2 * c8 + h];
+  }
+#pragma unroll
+  for (int rr = 0; rr < ROWS; ++rr) {
+    const int oh = og * ROWS + rr;
+    if (oh >= OH) break;
+    const float h1r = rh * oh;
+    const int h1 = (int)h1r;
+    const int h1p = (h1 < H - 1) ? 1 : 0;
+    const float hl = h1r - h1;
+    const float* base = x + (((int64_t)b * H + h1) * W + w1) * C + 8 * c8;
+    float4 v[4][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int dh = (t >> 1) ? h1p : 0, dw = (t & 1) ? w1p : 0;
+      const float4* p = reinterpret_cast<const float4*>(base + ((int64_t)dh * W + dw) * C);
+      v[t][0] = p[0];
+      v[t][1] = p[1];
+    }
+    float acc[8];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float wt = ((t >> 1) ? hl : 1.f - hl) * ((t & 1) ? wl : 1.f - wl);
+        a.x += wt * fmaxf(v[t][h].x * sc[h].x + sh[h].x, 0.f);
+        a.y += wt * fmaxf(v[t][h].y * sc[h].y + sh[h].y, 0.f);
+        a.z += wt * fmaxf(v[t][h].z * sc[h].z + sh[h].z, 0.f);
+        a.w += wt * fmaxf(v[t][h].w * sc[h].w + sh[h].w, 0.f);
+      }
+      acc[4 * h + 0] = a.x; acc[4 * h + 1] = a.y; acc[4 * h + 2] = a.z; acc[4 * h + 3] = a.w;
+    }
+    const int64_t o8 = ((((int64_t)b * OH + oh) * OW + ow) * C >> 3) + c8;
+    uint4 o;
+    o.x = pack2<T>(acc[0], acc[1]); o.y = pack2<T>(acc[2], acc[3]);
+    o.z = pack2<T>(acc[4], acc[5]); o.w = pack2<T>(acc[6], acc[7]);
+    reinterpret_cast<uint4*>(out)[o8] = o;
+    if (out_lo) {
+      o.x = pack2<T>(lo_part<T>(acc[0]), lo_part<T>(acc[1])); o.y = pack2<T>(lo_part<T>(acc[2]), lo_part<T>(acc[3]));
+      o.z = pack2<T>(lo_part<T>(acc[4]), lo_part<T>(acc[5])); o.w = pack2<T>(lo_part<T>(acc[6]), lo_part<T>(acc[7]));
+      reinterpret_cast<uint4*>(out_lo)[o8] = o;
+    }
+  }
+}
+
 // ---- conv weight packing: fp32 [Cout,Cin,KH,KW] -> 16-bit GEMM B operand --------------------------
 // mode 0 (forward):  out[co][(kh*KW+kw)*Cin + ci]                       rows Cout, ld = ldo
 // mode 1 (dgrad):    out[ci][((KH-1-kh)*KW + (KW-1-kw))*CoP + co]       rows Cin,  CoP = Cout padded to 8
@@ -495,6 +569,19 @@ extern "C" int asis_bn_relu_upsample(void* stream, int dtype, const float* x, co
   const int OH = H * factor, OW = W * factor;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int64_t total = (int64_t)B * OH * OW * (C / 4);
+  const long gx8 = asis_cdiv((long)OW * (C / 8), 256);
+  if (C % 8 == 0 && OH <= 65535 && B <= 65535 && gx8 * OH * B < (1L << 31) && asis_aligned16(out) &&
+      (!out_lo || asis_aligned16(out_lo)) && asis_aligned16(x)) {
+    const dim3 grid8((unsigned)gx8, (unsigned)asis_cdiv(OH, 4), (unsigned)B);  // 4 = ROWS of the kernel
+    if (dtype == ASIS_F16)
+      hipLaunchKernelGGL((bn_relu_upsample8_kernel<f16>), grid8, dim3(256), 0, s, x, scale, shift, reinterpret_cast<f16*>(out),
+                         reinterpret_cast<f16*>(out_lo), H, W, OH, OW, C);
+    else
+      hipLaunchKernelGGL((bn_relu_upsample8_kernel<bf16>), grid8, dim3(256), 0, s, x, scale, shift, reinterpret_cast<bf16*>(out),
+                         reinterpret_cast<bf16*>(out_lo), H, W, OH, OW, C);
+    ASIS_CHECK_LAUNCH("asis_bn_relu_upsample");
+    return ASIS_OK;
+  }
   if (dtype == ASIS_F16)
     hipLaunchKernelGGL((bn_relu_upsample_kernel<f16>), dim3(grid_for(total)), dim3(256), 0, s, x, scale, shift,
                        reinterpret_cast<f16*>(out), reinterpret_cast<f16*>(out_lo), B, H, W, OH, OW, C);

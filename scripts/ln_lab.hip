@@ -29,6 +29,19 @@ __global__ __launch_bounds__(256) void copy_cvt_kernel(const float4* __restrict_
   }
 }
 
+// pure write stream: 16 bytes per lane, grid-stride (what bn_relu_upsample's hi + lo outputs look like)
+template <bool NT>
+__global__ __launch_bounds__(256) void fill_kernel(uint4* __restrict__ y, int64_t n16, uint32_t v) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  const uint4 w = make_uint4(v, v + 1, v + 2, v + 3);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride) {
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    const u4 ww = {w.x, w.y, w.z, w.w};
+    if (NT) __builtin_nontemporal_store(ww, reinterpret_cast<u4*>(y) + i);
+    else y[i] = w;
+  }
+}
+
 __device__ __forceinline__ float wave_sum_dpp(float v) {
   // row_shr / row_bcast reductions stay in the VALU (no LDS crossbar)
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));  // row_shr:1
@@ -204,6 +217,40 @@ int main(int argc, char** argv) {
     CK(hipGetLastError());                                              \
     report(name, ms, IT);                                               \
   } while (0)
+  {
+    // 1.4 GB of pure writes (two 16-bit outputs of the 294^2 x 256 decoder stage at B = 12)
+    const int64_t nbytes = (int64_t)1400 << 20;
+    uint4* big;
+    CK(hipMalloc(&big, nbytes));
+    for (int g : {2048, 8192, 32768}) {
+      for (int nt = 0; nt < 2; ++nt) {
+        for (int it = 0; it < 3; ++it) {
+          if (nt) hipLaunchKernelGGL((fill_kernel<true>), dim3(g), dim3(256), 0, s, big, nbytes / 16, 7u);
+          else hipLaunchKernelGGL((fill_kernel<false>), dim3(g), dim3(256), 0, s, big, nbytes / 16, 7u);
+        }
+        CK(hipEventRecord(e0, s));
+        for (int it = 0; it < 10; ++it) {
+          if (nt) hipLaunchKernelGGL((fill_kernel<true>), dim3(g), dim3(256), 0, s, big, nbytes / 16, 7u);
+          else hipLaunchKernelGGL((fill_kernel<false>), dim3(g), dim3(256), 0, s, big, nbytes / 16, 7u);
+        }
+        CK(hipEventRecord(e1, s));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("pure write 1.4 GB grid %5d %s: %8.1f us  %5.2f TB/s\n", g, nt ? "nontemporal" : "plain      ", ms * 1e3 / 10,
+               (double)nbytes / (ms * 1e-3 / 10) / 1e12);
+      }
+    }
+    CK(hipMemsetAsync(big, 0, nbytes, s));
+    CK(hipEventRecord(e0, s));
+    for (int it = 0; it < 10; ++it) CK(hipMemsetAsync(big, 0, nbytes, s));
+    CK(hipEventRecord(e1, s));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("hipMemsetAsync 1.4 GB: %8.1f us  %5.2f TB/s\n", ms * 1e3 / 10, (double)nbytes / (ms * 1e-3 / 10) / 1e12);
+    CK(hipFree(big));
+  }
   for (int rot = 1; rot >= 0; --rot) {
     printf("---- rows %ld D %d, %s\n", (long)rows, D, rot ? "rotating 4 buffer sets (HBM)" : "one buffer set (cache-warm)");
     const int64_t n4 = rows * D / 4;
