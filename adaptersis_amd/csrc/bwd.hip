@@ -34,10 +34,53 @@ __global__ __launch_bounds__(256) void upsample_bn_relu_bwd_kernel(const float* 
                                                                    float* __restrict__ g, float* __restrict__ partial, int B,
                                                                    int H, int W, int OH, int OW, int C, int CW, int RW) {
   __shared__ float red[2][256 * 4];
+  // Tap tables in LDS, built once per workgroup: the source index / fraction of every output row and column, and for every
+  // source row / column the exact run of output indices that touch it.  The pixel loop then looks weights up (same values,
+  // same ascending (oy, ox) order as evaluating tap_ac_true per candidate pair: bit-identical) instead of spending ~10
+  // instructions per candidate on int -> float arithmetic.
+  extern __shared__ __attribute__((aligned(16))) char dyn_lds[];
+  int* const a0y = reinterpret_cast<int*>(dyn_lds);
+  float* const l1y = reinterpret_cast<float*>(a0y + OH);
+  int* const a0x = reinterpret_cast<int*>(l1y + OH);
+  float* const l1x = reinterpret_cast<float*>(a0x + OW);
+  int* const runy = reinterpret_cast<int*>(l1x + OW);  // [H][2] first / last contributing output row
+  int* const runx = runy + 2 * H;                      // [W][2]
   const int cpt = C >> 2;
   const float rh = OH > 1 ? (float)(H - 1) / (float)(OH - 1) : 0.f;
   const float rw = OW > 1 ? (float)(W - 1) / (float)(OW - 1) : 0.f;
   const float irh = rh > 0.f ? 1.f / rh : 0.f, irw = rw > 0.f ? 1.f / rw : 0.f;
+  for (int i = threadIdx.x; i < OH; i += blockDim.x) {
+    int a0, a1; float l0, l1;
+    tap_ac_true(i, rh, H, a0, a1, l0, l1);
+    a0y[i] = a0; l1y[i] = l1;
+  }
+  for (int i = threadIdx.x; i < OW; i += blockDim.x) {
+    int a0, a1; float l0, l1;
+    tap_ac_true(i, rw, W, a0, a1, l0, l1);
+    a0x[i] = a0; l1x[i] = l1;
+  }
+  __syncthreads();
+  auto wgt = [](const int* a0t, const float* l1t, int o, int in, int i) {
+    const int a0 = a0t[o];
+    const int a1 = a0 + ((a0 < in - 1) ? 1 : 0);
+    const float l1 = l1t[o];
+    return ((a0 == i) ? 1.f - l1 : 0.f) + ((a1 == i) ? l1 : 0.f);
+  };
+  auto run = [&](const int* a0t, const float* l1t, int i, int in, int on, float r, float ir, int* out2) {
+    int lo, hi;
+    if (r > 0.f) {
+      lo = (int)floorf(((float)i - 1.f) * ir) - 1;
+      hi = (int)ceilf(((float)i + 1.f) * ir) + 1;
+    } else { lo = 0; hi = on - 1; }
+    if (lo < 0) lo = 0;
+    if (hi > on - 1) hi = on - 1;
+    while (lo <= hi && wgt(a0t, l1t, lo, in, i) == 0.f) ++lo;
+    while (hi >= lo && wgt(a0t, l1t, hi, in, i) == 0.f) --hi;
+    out2[0] = lo; out2[1] = hi;
+  };
+  for (int i = threadIdx.x; i < H; i += blockDim.x) run(a0y, l1y, i, H, OH, rh, irh, runy + 2 * i);
+  for (int i = threadIdx.x; i < W; i += blockDim.x) run(a0x, l1x, i, W, OW, rw, irw, runx + 2 * i);
+  __syncthreads();
   const int64_t rows = (int64_t)B * H * W;
   // block = CW channel chunks (blockIdx.y picks the channel tile) x RW pixel rows: a thread keeps its channel chunk
   const int cx = threadIdx.x % CW, ry = threadIdx.x / CW;
@@ -52,33 +95,41 @@ __global__ __launch_bounds__(256) void upsample_bn_relu_bwd_kernel(const float* 
     const int iw = (int)(pix % W);
     const int ih = (int)((pix / W) % H);
     const int b = (int)(pix / ((int64_t)W * H));
-    int oy_lo, oy_hi, ox_lo, ox_hi;
-    if (rh > 0.f) {
-      oy_lo = (int)floorf(((float)ih - 1.f) * irh) - 1;
-      oy_hi = (int)ceilf(((float)ih + 1.f) * irh) + 1;
-    } else { oy_lo = 0; oy_hi = OH - 1; }
-    if (rw > 0.f) {
-      ox_lo = (int)floorf(((float)iw - 1.f) * irw) - 1;
-      ox_hi = (int)ceilf(((float)iw + 1.f) * irw) + 1;
-    } else { ox_lo = 0; ox_hi = OW - 1; }
-    if (oy_lo < 0) oy_lo = 0;
-    if (ox_lo < 0) ox_lo = 0;
-    if (oy_hi > OH - 1) oy_hi = OH - 1;
-    if (ox_hi > OW - 1) ox_hi = OW - 1;
+    const int oy_lo = runy[2 * ih], oy_hi = runy[2 * ih + 1], ox_lo = runx[2 * iw], ox_hi = runx[2 * iw + 1];
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
-      int a0, a1; float l0, l1;
-      tap_ac_true(oy, rh, H, a0, a1, l0, l1);
-      const float wy = ((a0 == ih) ? l0 : 0.f) + ((a1 == ih) ? l1 : 0.f);
-      if (wy == 0.f) continue;
-      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
-        int b0, b1; float m0, m1;
-        tap_ac_true(ox, rw, W, b0, b1, m0, m1);
-        const float wx = ((b0 == iw) ? m0 : 0.f) + ((b1 == iw) ? m1 : 0.f);
-        if (wx == 0.f) continue;
-        const float4 v = reinterpret_cast<const float4*>(dU + (((int64_t)b * OH + oy) * OW + ox) * C)[c];
-        const float wt = wy * wx;
-        acc.x += wt * v.x; acc.y += wt * v.y; acc.z += wt * v.z; acc.w += wt * v.w;
+    // Loads in batches of NR rows x NB columns (the runs are <= 5 x 5 at x2): one load per trip of a data-dependent loop
+    // leaves every miss exposed.  Same values; the same ascending (oy, ox) order of the sum while a column run fits one batch
+    // (every x2 stage), by row pair and column batch beyond that.
+    constexpr int NB = 5, NR = 2;
+    for (int oy0 = oy_lo; oy0 <= oy_hi; oy0 += NR) {
+      for (int ox0 = ox_lo; ox0 <= ox_hi; ox0 += NB) {
+        float wy[NR], wx[NB];
+        float4 v[NR][NB];
+#pragma unroll
+        for (int m = 0; m < NB; ++m) wx[m] = ox0 + m <= ox_hi ? wgt(a0x, l1x, ox0 + m, W, iw) : 0.f;
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+          const int oy = oy0 + k;
+          const bool oky = oy <= oy_hi;
+          wy[k] = oky ? wgt(a0y, l1y, oy, H, ih) : 0.f;
+          const float* drow = dU + (((int64_t)b * OH + (oky ? oy : oy_hi)) * OW) * C;
+#pragma unroll
+          for (int m = 0; m < NB; ++m) {
+            const int ox = ox0 + m;
+            v[k][m] = (oky && ox <= ox_hi) ? reinterpret_cast<const float4*>(drow + (int64_t)ox * C)[c]
+                                            : make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+          if (wy[k] == 0.f) continue;
+#pragma unroll
+          for (int m = 0; m < NB; ++m) {
+            if (wx[m] == 0.f) continue;
+            const float wt = wy[k] * wx[m];
+            acc.x += wt * v[k][m].x; acc.y += wt * v[k][m].y; acc.z += wt * v[k][m].z; acc.w += wt * v[k][m].w;
+          }
+        }
       }
     }
     const float4 xv = reinterpret_cast<const float4*>(x)[i];
@@ -338,7 +389,10 @@ extern "C" int asis_upsample_bn_relu_bwd(void* stream, const float* dU, const fl
   int CW, RW, tiles;
   bn_bwd_shape(C, &CW, &RW, &tiles);
   const int nblk = asis_bn_bwd_nblk((int64_t)B * H * W, C);
-  hipLaunchKernelGGL(upsample_bn_relu_bwd_kernel, dim3(nblk, tiles), dim3(CW * RW), 0, reinterpret_cast<hipStream_t>(stream),
+  const size_t tables = (size_t)(2 * (H * factor) + 2 * (W * factor) + 2 * H + 2 * W) * 4;  // tap tables, see the kernel
+  ASIS_REQUIRE(tables <= 56 * 1024, "asis_upsample_bn_relu_bwd: %d x %d x%d needs %zu bytes of tap tables (limit 56 KiB)", H, W,
+               factor, tables);
+  hipLaunchKernelGGL(upsample_bn_relu_bwd_kernel, dim3(nblk, tiles), dim3(CW * RW), tables, reinterpret_cast<hipStream_t>(stream),
                      dU, x, scale, shift, mean, invstd, g, partial, B, H, W, H * factor, W * factor, C, CW, RW);
   ASIS_CHECK_LAUNCH("asis_upsample_bn_relu_bwd");
   return ASIS_OK;
