@@ -82,87 +82,91 @@ __global__ __launch_bounds__(256) void smallcout_fwd_kernel(const T* __restrict_
   }
 }
 
-// ---- forward, LDS-tiled form for the 64-channel classifier conv with <= 2 classes ------------------------------------------
-// The direct form above reads every input pixel nine times (once per tap) through L1 / L2 and runs at the L2's speed
-// (1.4 TB/s of algorithmic bytes for the 64 -> 2 conv at 12 x 672^2).  Here a workgroup stages the (8+2) x (16+2) halo of an
-// 8 x 16 output tile ONCE (LDS-DMA, hi and lo halves side by side: 256 B per pixel, 45 KiB, the halves swapped on odd pixels
-// so that the 16-byte reads of two neighbouring pixels hit disjoint banks; pixels outside the image come from the zero page)
-// and the nine taps read LDS.  thread = (pixel slot, 8-channel chunk) as above; the 9 x 8 x 2 weights of the thread's chunk
-// live in registers for the workgroup's whole (grid-strided) run of tiles.
+// ---- forward on the matrix pipe -------------------------------------------------------------------------------------------
+// The direct form above reads every input pixel nine times through L1 / L2 (1.4 TB/s of algorithmic bytes for the 64 -> 2 conv
+// at 12 x 672^2).  Here a workgroup stages the (8+2) x (16+2) halo of an 8 x 16 output tile ONCE by LDS-DMA (hi and lo halves:
+// 256 B per pixel, 45 KiB; pixels outside the image come from the zero page) and every output row of the tile is one 16-pixel
+// MFMA row block: D[pixel, class] += A[pixel, 32 channels of one tap] . B[32, 16 classes] with v_mfma_f32_16x16x32 (2 .. 16 of
+// the 16 columns used: the pipe is 12 % busy and still far ahead of the vector units, where unpack + add + 2 FMAs per input
+// element and class cost 450 of the 640 us of the round-2 LDS-tiled fp32 kernel, 594 with packed dot products), three passes
+// x_hi.w_hi + x_lo.w_hi + x_hi.w_lo like every other split convolution, fp32 accumulation: 397 us, 3.5 TB/s of input.
+// The halo pixel record is 16 chunks of 16 bytes (8 hi | 8 lo) with the chunk index XORed with the pixel's low bits: the
+// 16 lanes of one A-fragment column group read the same chunk of 16 consecutive pixels -> 16 different bank groups.
 template <typename T>
-__global__ __launch_bounds__(256, 2) void smallcout_fwd_tiled_kernel(const T* __restrict__ xh, const T* __restrict__ xl,
-                                                                     const float* __restrict__ w, const float* __restrict__ bias,
-                                                                     float* __restrict__ out, int B, int H, int W, int Cout) {
+__global__ __launch_bounds__(256, 2) void smallcout_fwd_mfma_kernel(const T* __restrict__ xh, const T* __restrict__ xl,
+                                                                    const float* __restrict__ w, const float* __restrict__ bias,
+                                                                    float* __restrict__ out, int B, int H, int W, int Cout) {
   constexpr int CIN = 64, TY = 8, TX = 16, HY = TY + 2, HX = TX + 2, NPIX = HY * HX;   // 180 halo pixels
+  typedef typename T16<T>::v8 v8;
   typedef __attribute__((address_space(3))) void* lds_ptr;
   typedef const __attribute__((address_space(1))) void* glb_ptr;
-  __shared__ __attribute__((aligned(16))) T tile[NPIX * 2 * CIN];   // [pixel][hi | lo (swapped on odd pixels)][64]
+  __shared__ __attribute__((aligned(16))) T tile[NPIX * 2 * CIN];   // [pixel][16 chunks, swizzled][8]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int c8 = tid & 7, slot = tid >> 3;                           // chunk of 8 channels, pixel slot 0..31
-  float wr[9][8][2];
+  const int fn = lane & 15, fq = lane >> 4;   // MFMA fragment coordinates: A row (pixel) / B, D column (class); K group
+  // B fragments: W[class fn][channel 32 ks + 8 fq + j][tap] as hi and rounding residual, zero for classes >= Cout
+  v8 wh[9][2], wl[9][2];
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll
-    for (int e = 0; e < 8; ++e)
+    for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-      for (int c = 0; c < 2; ++c) wr[t][e][c] = c < Cout ? w[((int64_t)c * CIN + c8 * 8 + e) * 9 + t] : 0.f;
-  const float b0 = bias ? bias[0] : 0.f, b1 = (bias && Cout > 1) ? bias[1] : 0.f;
+      for (int j = 0; j < 8; ++j) {
+        const float v = fn < Cout ? w[((int64_t)fn * CIN + 32 * ks + 8 * fq + j) * 9 + t] : 0.f;
+        wh[t][ks][j] = (T)v;
+        wl[t][ks][j] = (T)lo_part<T>(v);
+      }
+  const float bn = (bias && fn < Cout) ? bias[fn] : 0.f;
   const int tiles_x = (W + TX - 1) / TX, tiles_y = (H + TY - 1) / TY;
   const int ntiles = B * tiles_y * tiles_x;
   const T* const zp = reinterpret_cast<const T*>(g_zero_page_sc);
-  // DMA lane map: one instruction = 4 halo pixels x (hi | lo) x 8 chunks
-  const int dp = lane >> 4, dhalf = (lane >> 3) & 1, dch = lane & 7;
+  const int dp = lane >> 4, dslot = lane & 15;   // DMA lane map: one instruction = 4 halo pixels x 16 chunk slots
   for (int tl = xcd_remap(blockIdx.x, gridDim.x); tl < ntiles; tl += gridDim.x) {
     const int tx = tl % tiles_x, ty = (tl / tiles_x) % tiles_y, b = tl / (tiles_x * tiles_y);
     const int y0 = ty * TY - 1, x0 = tx * TX - 1;
     for (int g = wid; g * 4 < NPIX; g += 4) {       // 45 groups of 4 pixels over the 4 waves
-      const int hp = g * 4 + dp;                    // halo pixel of this lane (NPIX is a multiple of 4)
+      const int hp = g * 4 + dp;
       const int hy = hp / HX, hx = hp - hy * HX;
       const int yy = y0 + hy, xx = x0 + hx;
       const bool in = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
-      const bool want_lo = (dhalf ^ (hp & 1)) != 0;
+      const int ch = dslot ^ (hp & 15);             // the chunk this slot holds: 0..7 hi, 8..15 lo
+      const bool want_lo = ch >= 8;
       const T* src = zp;
-      if (in && (!want_lo || xl)) src = (want_lo ? xl : xh) + (((int64_t)b * H + yy) * W + xx) * CIN + dch * 8;
+      if (in && (!want_lo || xl)) src = (want_lo ? xl : xh) + (((int64_t)b * H + yy) * W + xx) * CIN + (ch & 7) * 8;
       __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(tile + g * 4 * 2 * CIN), 16, 0, 0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int pix = k * 32 + slot;
-      const int py = pix / TX, px = pix - py * TX;
-      float a0 = 0.f, a1 = 0.f;
+    for (int rr = 0; rr < 2; ++rr) {
+      const int py = wid * 2 + rr;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) {
           const int t = kh * 3 + kw;
-          const int hp = (py + kh) * HX + px + kw;
-          const T* base = tile + hp * 2 * CIN + c8 * 8;
-          const int sw = (hp & 1) * CIN;
-          const uint4 rh = *reinterpret_cast<const uint4*>(base + sw);
-          const uint4 rl = *reinterpret_cast<const uint4*>(base + (CIN - sw));
-          float f[8], gl[8];
-          unpack2<T>(rh.x, f[0], f[1]); unpack2<T>(rh.y, f[2], f[3]); unpack2<T>(rh.z, f[4], f[5]); unpack2<T>(rh.w, f[6], f[7]);
-          unpack2<T>(rl.x, gl[0], gl[1]); unpack2<T>(rl.y, gl[2], gl[3]); unpack2<T>(rl.z, gl[4], gl[5]); unpack2<T>(rl.w, gl[6], gl[7]);
+          const int hp = (py + kh) * HX + fn + kw;     // halo pixel of this lane's A row
+          const T* rec = tile + hp * 2 * CIN;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float v = f[e] + gl[e];
-            a0 += v * wr[t][e][0];
-            a1 += v * wr[t][e][1];
+          for (int ks = 0; ks < 2; ++ks) {
+            const int ch = 4 * ks + fq;
+            const v8 ah = __builtin_bit_cast(v8, *reinterpret_cast<const uint4*>(rec + ((ch ^ (hp & 15)) << 3)));
+            const v8 al = __builtin_bit_cast(v8, *reinterpret_cast<const uint4*>(rec + (((ch + 8) ^ (hp & 15)) << 3)));
+            acc = T16<T>::mfma16(ah, wh[t][ks], acc);
+            acc = T16<T>::mfma16(al, wh[t][ks], acc);
+            acc = T16<T>::mfma16(ah, wl[t][ks], acc);
           }
+          // 144 registers hold the weights: keep the fragment reads of at most one tap in flight ahead of their MFMAs
+          __builtin_amdgcn_sched_barrier(0);
         }
+      const int oy = ty * TY + py;
+      if (fn < Cout && oy < H) {
 #pragma unroll
-      for (int o = 1; o < 8; o <<= 1) {
-        a0 += __shfl_xor(a0, o, 64);
-        a1 += __shfl_xor(a1, o, 64);
-      }
-      const int oy = ty * TY + py, ox = tx * TX + px;
-      if (c8 == 0 && oy < H && ox < W) {
-        float* o = out + (((int64_t)b * H + oy) * W + ox) * Cout;
-        o[0] = a0 + b0;
-        if (Cout > 1) o[1] = a1 + b1;
+        for (int j = 0; j < 4; ++j) {
+          const int ox = tx * TX + 4 * fq + j;
+          if (ox < W) out[(((int64_t)b * H + oy) * W + ox) * Cout + fn] = acc[j] + bn;
+        }
       }
     }
     __syncthreads();   // the tile is overwritten by the next DMA
@@ -222,6 +226,123 @@ __global__ __launch_bounds__(256) void smallcout_dgrad_kernel(const T* __restric
     float4* o = reinterpret_cast<float4*>(dx + p * Cin + c8);
     o[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
     o[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+  }
+}
+
+// ---- input gradient on the matrix pipe --------------------------------------------------------------------------------------
+// dx[pixel, ci] = sum over (tap, co) of dy[pixel - tap, co] * w[co, ci, tap]: per 16-pixel output row a GEMM with K = 9 taps x 8
+// (padded) classes = 72 -> three 32-wide steps whose K group q IS one tap: the A fragment of lane (pixel, q) is the 16-byte dy
+// record of the halo pixel that tap (4 ks + q) points at, the B fragment W[co 0..7][ci][tap].  36 MFMAs per row (3 steps x 4
+// ci blocks x the three split passes) against 9 x (unpack + 16 FMA) per pixel and 8 channels on the vector units; the dy halo
+// (180 pixels x 32 B) comes in by LDS-DMA, the fp32 result leaves through a per-wave LDS transposition as whole 256-byte
+// pixel rows (the accumulator layout would store 64-byte pieces).
+template <typename T>
+__global__ __launch_bounds__(256, 2) void smallcout_dgrad_mfma_kernel(const T* __restrict__ dh, const T* __restrict__ dl,
+                                                                      const float* __restrict__ w, float* __restrict__ dx,
+                                                                      int B, int H, int W, int Cout) {
+  constexpr int CIN = 64, COP = 8, TY = 8, TX = 16, HY = TY + 2, HX = TX + 2, NPIX = HY * HX;   // 180 halo pixels
+  constexpr int NG = (NPIX + 31) / 32;                                                          // DMA groups of 32 pixels
+  typedef typename T16<T>::v8 v8;
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  typedef const __attribute__((address_space(1))) void* glb_ptr;
+  // two distinct LDS objects, not one [2][..] array: the compiler puts a vmcnt(0) in front of every LDS read that may alias an
+  // LDS-DMA in flight, and it tracks aliasing per object -- reads of tile A proceed while the DMA fills tile B
+  __shared__ __attribute__((aligned(16))) T tileA[NG * 32 * 2 * COP];   // [halo pixel][hi 8 | lo 8]
+  __shared__ __attribute__((aligned(16))) T tileB[NG * 32 * 2 * COP];
+  __shared__ __attribute__((aligned(16))) float stage[4][TX * CIN];     // per wave: one output row, [pixel][ci]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fn = lane & 15, fq = lane >> 4;
+  // B fragments: K group fq of step ks is tap 4 ks + fq (taps 9..11 do not exist: zero), its 8 K elements the classes
+  v8 wh[3][4], wl[3][4];
+#pragma unroll
+  for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int t = 4 * ks + fq;
+        const float v = (t < 9 && j < Cout) ? w[((int64_t)j * CIN + 16 * nb + fn) * 9 + t] : 0.f;
+        wh[ks][nb][j] = (T)v;
+        wl[ks][nb][j] = (T)lo_part<T>(v);
+      }
+  const int tiles_x = (W + TX - 1) / TX, tiles_y = (H + TY - 1) / TY;
+  const int ntiles = B * tiles_y * tiles_x;
+  const T* const zp = reinterpret_cast<const T*>(g_zero_page_sc);
+  const int dp = lane >> 1, dhalf = lane & 1;   // DMA lane map: one instruction = 32 halo pixels x (hi | lo)
+  auto stage_in = [&](int tl, T* tile) {
+    const int tx = tl % tiles_x, ty = (tl / tiles_x) % tiles_y, b = tl / (tiles_x * tiles_y);
+    const int y0 = ty * TY - 1, x0 = tx * TX - 1;
+    for (int g = wid; g < NG; g += 4) {
+      const int hp = g * 32 + dp;
+      const int hy = hp / HX, hx = hp - hy * HX;
+      const int yy = y0 + hy, xx = x0 + hx;
+      const bool in = hp < NPIX && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+      const T* src = zp;
+      if (in && (!dhalf || dl)) src = (dhalf ? dl : dh) + (((int64_t)b * H + yy) * W + xx) * COP;
+      __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(tile + g * 32 * 2 * COP), 16, 0, 0);
+    }
+  };
+  auto compute = [&](int tl, const T* tile) {
+    const int tx = tl % tiles_x, ty = (tl / tiles_x) % tiles_y, b = tl / (tiles_x * tiles_y);
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const int py = wid * 2 + rr;
+      f32x4 acc[4];
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) {
+        const int t = 4 * ks + fq;                  // this lane's tap (per K group)
+        const int kh = t / 3, kw = t - 3 * kh;
+        // dx[y, x] takes dy[y - (kh - 1), x - (kw - 1)]: halo coordinates (py + 2 - kh, px + 2 - kw); taps >= 9 meet zero weights
+        const int hp = t < 9 ? (py + 2 - kh) * HX + fn + 2 - kw : 0;
+        const v8 ah = __builtin_bit_cast(v8, *reinterpret_cast<const uint4*>(tile + hp * 2 * COP));
+        const v8 al = __builtin_bit_cast(v8, *reinterpret_cast<const uint4*>(tile + hp * 2 * COP + COP));
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+          acc[nb] = T16<T>::mfma16(ah, wh[ks][nb], acc[nb]);
+          acc[nb] = T16<T>::mfma16(al, wh[ks][nb], acc[nb]);
+          acc[nb] = T16<T>::mfma16(ah, wl[ks][nb], acc[nb]);
+        }
+      }
+      // D[pixel 4 fq + j][ci 16 nb + fn] -> stage[pixel][ci] -> 16-byte stores, contiguous per instruction
+      float* st = stage[wid];
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) st[(4 * fq + j) * CIN + 16 * nb + fn] = acc[nb][j];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave's own writes, then its own reads: no barrier needed
+      // one store instruction = 1 KB contiguous (4 pixel rows): lane = (pixel 4 i + lane / 16, 16-byte chunk lane % 16)
+      const int oy = ty * TY + py;
+      float4 v[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const float4*>(st + (4 * i + (lane >> 4)) * CIN + (lane & 15) * 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ox = tx * TX + 4 * i + (lane >> 4);
+        if (oy < H && ox < W)
+          *reinterpret_cast<float4*>(dx + (((int64_t)b * H + oy) * W + ox) * CIN + (lane & 15) * 4) = v[i];
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next row overwrites the stage
+    }
+  };
+  // tile t in A while t + grid lands in B, and the other way round.  The counted wait leaves the result stores of the tile
+  // just computed in flight only until the next barrier -- vmcnt counts stores too, so it is a plain vmcnt(0).
+  int tl = xcd_remap(blockIdx.x, gridDim.x);
+  if (tl < ntiles) stage_in(tl, tileA);
+  while (tl < ntiles) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                               // tile A landed; every wave is done with tile B
+    if (tl + (int)gridDim.x < ntiles) stage_in(tl + gridDim.x, tileB);
+    compute(tl, tileA);
+    tl += gridDim.x;
+    if (tl >= ntiles) break;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tl + (int)gridDim.x < ntiles) stage_in(tl + gridDim.x, tileA);
+    compute(tl, tileB);
+    tl += gridDim.x;
   }
 }
 
@@ -334,10 +455,11 @@ int launch_fwd(hipStream_t s, const void* xh, const void* xl, const float* w, co
   const T* a = reinterpret_cast<const T*>(xh);
   const T* b = reinterpret_cast<const T*>(xl);
   // ASIS_SMALLCOUT_TILED (default 1): the LDS-tiled form for the 64 -> (1 | 2) conv on maps of at least one tile
+  // ASIS_SMALLCOUT_TILED (default 1): LDS tile + MFMA for the 64 -> (<= 16) conv on maps of at least one tile, 0 = direct form
   static const int tiled = [] { const char* e = getenv("ASIS_SMALLCOUT_TILED"); return e ? atoi(e) : 1; }();
-  if (tiled && Cin == 64 && Cout <= 2 && H >= 8 && W >= 16) {
+  if (tiled && Cin == 64 && Cout <= 16 && H >= 8 && W >= 16) {
     const int ntiles = B * ((H + 7) / 8) * ((W + 15) / 16);
-    hipLaunchKernelGGL((smallcout_fwd_tiled_kernel<T>), dim3(ntiles < 512 ? ntiles : 512), dim3(256), 0, s, a, b, w, bias, out, B, H, W, Cout);
+    hipLaunchKernelGGL((smallcout_fwd_mfma_kernel<T>), dim3(ntiles < 512 ? ntiles : 512), dim3(256), 0, s, a, b, w, bias, out, B, H, W, Cout);
     return 0;
   }
 #define FWD(CO)                                                                                                    \
@@ -377,6 +499,20 @@ extern "C" int asis_conv3x3_smallcout_dgrad(void* stream, int dtype, const void*
   ASIS_REQUIRE(dtype == ASIS_F16 || dtype == ASIS_BF16, "asis_conv3x3_smallcout_dgrad: bad dtype %d", dtype);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int64_t total = (int64_t)B * H * W * (Cin / 8);
+  // ASIS_SMALLCOUT_TILED (default 1): the MFMA form for Cin = 64 with the classes in one 8-channel record
+  static const int tiled = [] { const char* e = getenv("ASIS_SMALLCOUT_TILED"); return e ? atoi(e) : 1; }();
+  if (tiled && Cin == 64 && CoP == 8 && H >= 8 && W >= 16) {
+    const int ntiles = B * ((H + 7) / 8) * ((W + 15) / 16);
+    const dim3 grid(ntiles < 512 ? ntiles : 512);
+    if (dtype == ASIS_F16)
+      hipLaunchKernelGGL((smallcout_dgrad_mfma_kernel<f16>), grid, dim3(256), 0, s, reinterpret_cast<const f16*>(dy_hi),
+                         reinterpret_cast<const f16*>(dy_lo), w, dx, B, H, W, Cout);
+    else
+      hipLaunchKernelGGL((smallcout_dgrad_mfma_kernel<bf16>), grid, dim3(256), 0, s, reinterpret_cast<const bf16*>(dy_hi),
+                         reinterpret_cast<const bf16*>(dy_lo), w, dx, B, H, W, Cout);
+    ASIS_CHECK_LAUNCH("asis_conv3x3_smallcout_dgrad");
+    return ASIS_OK;
+  }
   const int CO = Cout <= 2 ? 2 : (Cout <= 4 ? 4 : 8);
   const size_t shm = (size_t)9 * CO * Cin * sizeof(float);
 #define DG(T, C)                                                                                                  \
