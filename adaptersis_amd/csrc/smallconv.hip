@@ -441,6 +441,89 @@ __global__ __launch_bounds__(256) void smallcout_wgrad_kernel(const T* __restric
   }
 }
 
+// ---- weight gradient on the matrix pipe ----------------------------------------------------------------------------------------
+// dW[co][ci][tap] = sum over pixels of dy[p][co] * x[p + tap][ci]: the reduction runs over pixels, so both MFMA operands are
+// needed K-major (8 consecutive pixels per lane) from tiles that are stored pixel-major -- the transposing LDS read
+// ds_read_b64_tr_b16 does that (16 lanes fetch a 4 pixel x 16 column block, every lane ends up with 4 pixels of one column;
+// each lane supplies its own row address, so the tap shift of the im2col view is just address arithmetic on the halo tile).
+// Per 8 x 16 tile: four K steps of 32 pixels (two tile rows), per step one dy fragment and nine x fragments, 36 MFMAs
+// (16x16x32) per wave; wave w owns input channels 16 w .. 16 w + 15 and keeps its nine 16 x 16 accumulators (tap by tap) over
+// the workgroup's whole run of tiles.  One fp32 slab row per workgroup, summed by asis_reduce_rows in a fixed order.
+template <typename T>
+__global__ __launch_bounds__(256, 2) void smallcout_wgrad_mfma_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                                      float* __restrict__ slab, int B, int H, int W, int Cout) {
+  constexpr int CIN = 64, COP = 8, TY = 8, TX = 16, HY = TY + 2, HX = TX + 2, NPIX = HY * HX;   // 180 halo pixels
+  constexpr int NGX = (NPIX + 7) / 8;                                                           // x DMA groups of 8 pixels
+  typedef typename T16<T>::v8 v8;
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  typedef s16x4 __attribute__((address_space(3))) * lds_tr_ptr;
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  typedef const __attribute__((address_space(1))) void* glb_ptr;
+  __shared__ __attribute__((aligned(16))) T xt[NGX * 8 * CIN];     // [halo pixel][64 ci]
+  __shared__ __attribute__((aligned(16))) T dt[TY * TX * COP];     // [tile pixel][8 co]
+  __shared__ __attribute__((aligned(16))) T zt[8];                 // zeros: columns 8..15 of the dy fragment
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (tid < 8) zt[tid] = (T)0.f;
+  const int fq = lane >> 4, li = lane & 15;
+  const int rq = li >> 2, pc = li & 3;    // transposed read: this lane supplies row rq of its group's 4-row block, columns 4 pc ..
+  f32x4 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int tiles_x = (W + TX - 1) / TX, tiles_y = (H + TY - 1) / TY;
+  const int ntiles = B * tiles_y * tiles_x;
+  const T* const zp = reinterpret_cast<const T*>(g_zero_page_sc);
+  for (int tl = xcd_remap(blockIdx.x, gridDim.x); tl < ntiles; tl += gridDim.x) {
+    const int tx = tl % tiles_x, ty = (tl / tiles_x) % tiles_y, b = tl / (tiles_x * tiles_y);
+    const int y0 = ty * TY - 1, x0 = tx * TX - 1;
+    for (int g = wid; g < NGX; g += 4) {             // x halo: one instruction = 8 pixels x 8 chunks
+      const int hp = g * 8 + (lane >> 3);
+      const int hy = hp / HX, hx = hp - hy * HX;
+      const int yy = y0 + hy, xx = x0 + hx;
+      const bool in = hp < NPIX && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+      const T* src = in ? x + (((int64_t)b * H + yy) * W + xx) * CIN + (lane & 7) * 8 : zp;
+      __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(xt + g * 8 * CIN), 16, 0, 0);
+    }
+    if (wid < 2) {                                    // dy: one instruction = 64 tile pixels x 16 bytes
+      const int pt = wid * 64 + lane;
+      const int yy = ty * TY + (pt >> 4), xx = tx * TX + (pt & 15);
+      const T* src = (yy < H && xx < W) ? dy + (((int64_t)b * H + yy) * W + xx) * COP : zp;
+      __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(dt + wid * 64 * COP), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {                  // K step = tile rows 2 ks, 2 ks + 1
+      auto tr2 = [&](const T* p0, const T* p1) -> v8 {
+        const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)p0);
+        const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)p1);
+        return __builtin_bit_cast(v8, (s16x8)__builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
+      };
+      // this lane's two source rows of the step: k = 8 fq + 4 half + rq  ->  tile pixel (2 ks + (k >> 4), k & 15)
+      const int k0 = 8 * fq + rq, k1 = k0 + 4;
+      const v8 bf = tr2(pc < 2 ? dt + (32 * ks + k0) * COP + 4 * pc : zt, pc < 2 ? dt + (32 * ks + k1) * COP + 4 * pc : zt);
+      const int h0 = (2 * ks + (k0 >> 4)) * HX + (k0 & 15), h1 = (2 * ks + (k1 >> 4)) * HX + (k1 & 15);
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int sh = kh * HX + kw;
+          const v8 af = tr2(xt + (h0 + sh) * CIN + 16 * wid + 4 * pc, xt + (h1 + sh) * CIN + 16 * wid + 4 * pc);
+          acc[kh * 3 + kw] = T16<T>::mfma16(af, bf, acc[kh * 3 + kw]);
+        }
+    }
+    __syncthreads();   // the tiles are overwritten by the next DMA
+  }
+  // D[m = ci 16 wid + 4 fq + j][n = co li]  ->  slab row in the parameter's [Cout][Cin][3][3] layout
+  float* row = slab + (int64_t)blockIdx.x * Cout * CIN * 9;
+  if (li < Cout) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) row[((int64_t)li * CIN + 16 * wid + 4 * fq + j) * 9 + t] = acc[t][j];
+  }
+}
+
 inline int grid_for(int64_t total, int cap = 256 * 32) {
   int64_t g = (total + 255) / 256;
   if (g > cap) g = cap;
@@ -538,6 +621,18 @@ extern "C" int asis_conv3x3_smallcout_wgrad(void* stream, int dtype, const void*
   ASIS_REQUIRE(dtype == ASIS_F16 || dtype == ASIS_BF16, "asis_conv3x3_smallcout_wgrad: bad dtype %d", dtype);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   dim3 grid(nblk, (Cout + 1) / 2), block(256);
+  // ASIS_SMALLCOUT_TILED (default 1): the MFMA form for Cin = 64 with the classes in one 8-channel record
+  static const int tiled = [] { const char* e = getenv("ASIS_SMALLCOUT_TILED"); return e ? atoi(e) : 1; }();
+  if (tiled && Cin == 64 && CoP == 8 && Cout <= 8 && H >= 8 && W >= 16) {
+    if (dtype == ASIS_F16)
+      hipLaunchKernelGGL((smallcout_wgrad_mfma_kernel<f16>), dim3(nblk), block, 0, s, reinterpret_cast<const f16*>(dy),
+                         reinterpret_cast<const f16*>(x), slabs, B, H, W, Cout);
+    else
+      hipLaunchKernelGGL((smallcout_wgrad_mfma_kernel<bf16>), dim3(nblk), block, 0, s, reinterpret_cast<const bf16*>(dy),
+                         reinterpret_cast<const bf16*>(x), slabs, B, H, W, Cout);
+    ASIS_CHECK_LAUNCH("asis_conv3x3_smallcout_wgrad");
+    return ASIS_OK;
+  }
   if (dtype == ASIS_F16)
     hipLaunchKernelGGL((smallcout_wgrad_kernel<f16>), grid, block, 0, s, reinterpret_cast<const f16*>(dy), CoP,
                        reinterpret_cast<const f16*>(x), slabs, B, H, W, Cin, Cout);
