@@ -248,7 +248,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const asis_wgrad_des
 // ---------------------------------------------------------------------------------------------------------------------
 __device__ __attribute__((aligned(16))) uint4 g_wgrad_zero[1];
 
-template <typename T>
+// CONV (round 3): the same kernel for stride-1 convolutions with Cin % 128 == 0 -- a 128-column tile of the implicit im2col
+// operand then lies inside ONE tap, so the only difference is the per-lane SOURCE address of the x rows: pixel (b, oh, ow) of
+// the K tile, shifted by the tile's tap, or the zero page outside the image (tracked incrementally, 32 pixels per K tile).
+template <typename T, bool CONV = false>
 __global__ __launch_bounds__(512, 2) void wgrad_dense_big_kernel(const asis_wgrad_desc d) {
   constexpr int TM = 256, TN = 128, TK = 32, NS = 3;
   constexpr int STAGE = TK * (TM + TN);               // 12288 elements = 24 KB
@@ -262,7 +265,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_dense_big_kernel(const asis_wgra
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid >> 1, wn = wid & 1;                 // 4 x 2 waves of 64 x 64
-  const int tiles_n = d.Cin / TN;
+  const int tiles_n = (CONV ? d.KH * d.KW * d.Cin : d.Cin) / TN;
   const int lin = xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
   const int bx = lin % gridDim.x, by = lin / gridDim.x;
   const int tile_m = bx / tiles_n, tile_n = bx - tile_m * tiles_n;
@@ -287,7 +290,20 @@ __global__ __launch_bounds__(512, 2) void wgrad_dense_big_kernel(const asis_wgra
     pa[j] = A + (k_begin + ka[j]) * d.ld_dy + m0 + ch * 8;
   }
   kb = 4 * wid + (lane >> 4);
-  pb = X + (k_begin + kb) * (int64_t)d.Cin + n0 + (((lane & 15) ^ ((kb & 3) << 2)) * 8);
+  const int tap = CONV ? n0 / d.Cin : 0, ci0 = n0 - tap * d.Cin;       // a column tile sits inside one tap
+  const int tkh = CONV ? tap / d.KW : 0, tkw = tap - tkh * d.KW;
+  const int bchunk = ((lane & 15) ^ ((kb & 3) << 2)) * 8;
+  pb = X + (k_begin + kb) * (int64_t)d.Cin + n0 + bchunk;
+  // CONV: pixel (cb, coh, cow) of this lane's x row in the NEXT tile to be issued (issue() is called with t = 0, 1, 2, ...)
+  int cb = 0, coh = 0, cow = 0;
+  if (CONV) {
+    const int64_t p0 = k_begin + kb;
+    const int ohw = d.OH * d.OW;
+    cb = (int)(p0 / ohw);
+    const int rem = (int)(p0 - (int64_t)cb * ohw);
+    coh = rem / d.OW;
+    cow = rem - coh * d.OW;
+  }
   const int64_t a_step = (int64_t)TK * d.ld_dy, x_step = (int64_t)TK * d.Cin;
   auto issue = [&](int t) {
     T* st = lds + (t % NS) * STAGE;
@@ -297,7 +313,17 @@ __global__ __launch_bounds__(512, 2) void wgrad_dense_big_kernel(const asis_wgra
       const T* src = (kt + ka[j] < k_end) ? pa[j] + (int64_t)t * a_step : zp;
       __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(st + (2 * (2 * wid + j)) * TM), 16, 0, 0);
     }
-    const T* srcb = (kt + kb < k_end) ? pb + (int64_t)t * x_step : zp;
+    const T* srcb = zp;
+    if (CONV) {
+      const int ih = coh + tkh - d.pad, iw = cow + tkw - d.pad;
+      if (kt + kb < k_end && (unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W)
+        srcb = X + (((int64_t)cb * d.H + ih) * d.W + iw) * d.Cin + ci0 + bchunk;
+      cow += TK;                                  // the next tile's pixel: TK further in (b, oh, ow) order
+      while (cow >= d.OW) { cow -= d.OW; ++coh; }
+      while (coh >= d.OH) { coh -= d.OH; ++cb; }
+    } else if (kt + kb < k_end) {
+      srcb = pb + (int64_t)t * x_step;
+    }
     __builtin_amdgcn_global_load_lds((glb_ptr)srcb, (lds_ptr)(st + TK * TM + (4 * wid) * TN), 16, 0, 0);
   };
 
@@ -363,17 +389,18 @@ __global__ __launch_bounds__(512, 2) void wgrad_dense_big_kernel(const asis_wgra
     }
   }
 
-  float* slab = d.out + (int64_t)by * d.Cout * d.Cin;
+  const int taps = CONV ? d.KH * d.KW : 1;
+  float* slab = d.out + (int64_t)by * d.Cout * d.Cin * taps;
   const int fr = lane & 31, fq = lane >> 5;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    const int n = n0 + wn * 64 + j * 32 + fr;
+    const int n = (CONV ? ci0 : n0) + wn * 64 + j * 32 + fr;   // input channel
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fq;
-        slab[(int64_t)m * d.Cin + n] = acc[i][j][r];
+        slab[((int64_t)m * d.Cin + n) * taps + tap] = acc[i][j][r];   // the parameter's [Cout][Cin][KH][KW] layout
       }
   }
 }
@@ -423,6 +450,15 @@ extern "C" int asis_wgrad(void* stream, const asis_wgrad_desc* dp) {
     dim3 gb((unsigned)((d.Cout / 256) * (d.Cin / 128)), d.splits);
     if (d.dtype == ASIS_F16) hipLaunchKernelGGL((wgrad_dense_big_kernel<f16>), gb, dim3(512), 0, s, d);
     else hipLaunchKernelGGL((wgrad_dense_big_kernel<bf16>), gb, dim3(512), 0, s, d);
+    ASIS_CHECK_LAUNCH("asis_wgrad");
+    return ASIS_OK;
+  }
+  // the same tile form for stride-1 convolutions whose 128-column tiles lie inside one tap (decoder_1 .. 3)
+  if (big && !dense && d.stride == 1 && d.Cout % 256 == 0 && d.Cin % 128 == 0 && d.CoP == d.Cout && d.P >= 1024 &&
+      d.k_per_split % 32 == 0 && (int64_t)d.B_ * d.H * d.W * d.Cin < (1LL << 40)) {
+    dim3 gb((unsigned)((d.Cout / 256) * (Ntot / 128)), d.splits);
+    if (d.dtype == ASIS_F16) hipLaunchKernelGGL((wgrad_dense_big_kernel<f16, true>), gb, dim3(512), 0, s, d);
+    else hipLaunchKernelGGL((wgrad_dense_big_kernel<bf16, true>), gb, dim3(512), 0, s, d);
     ASIS_CHECK_LAUNCH("asis_wgrad");
     return ASIS_OK;
   }

@@ -1073,6 +1073,9 @@ def wgrad(dy: torch.Tensor, x_nhwc: torch.Tensor, Cout: int, KH: int, KW: int, s
         # nn.Linear weight gradients on the 256 x 128 LDS-DMA form (csrc/wgrad.hip: wgrad_dense_big_kernel, two workgroups per
         # CU): one round of the 512 workgroup slots, e.g. qkv 96 tiles x 5 pixel splits (6 would spill into a second round)
         splits = max(1, min(512 // ((Cout // 256) * (Cin // 128)), P // 256))
+    elif stride == 1 and Cout % 256 == 0 and Cin % 128 == 0 and CoP == Cout and P >= 1024:
+        # stride-1 convolutions on the same form (wgrad_dense_big_kernel<CONV>): (Cout / 256) x (taps * Cin / 128) tiles
+        splits = max(1, min(512 // ((Cout // 256) * (Ntot // 128)), P // 1024))
     slabs = torch.empty((splits, Cout * Ntot), device=dy.device, dtype=torch.float32)
     d = _lib.WgradDesc()
     d.dy, d.x, d.out = dy.data_ptr(), x_nhwc.data_ptr(), slabs.data_ptr()

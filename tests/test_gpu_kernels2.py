@@ -181,7 +181,8 @@ def test_bn_relu_upsample_backward(dev, factor):
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("Cin,Cout,H,k,pad", [(16, 24, 11, 3, 1), (64, 128, 20, 3, 1), (8, 2, 33, 3, 1), (32, 40, 10, 1, 0),
                                               (96, 32, 6, 3, 1), (64, 2, 21, 3, 1), (16, 3, 13, 3, 1), (32, 4, 9, 3, 1),
-                                              (64, 64, 12, 3, 1)])
+                                              (64, 64, 12, 3, 1), (128, 256, 20, 3, 1), (256, 512, 19, 3, 1),
+                                              (128, 256, 37, 3, 1)])
 def test_conv_wgrad_and_dgrad(dev, dt, Cin, Cout, H, k, pad):
     """wgrad (transposed-LDS-read GEMM) and dgrad (implicit GEMM with flipped weights) vs autograd."""
     Bn = 3
