@@ -383,7 +383,14 @@ class DecoderSETRF(FeatureDecoder):
             raise ValueError(f"DecoderSETRF: the skip ({H}x{Wd}) must not be smaller than the decoder map ({h}x{w})")
         top, left = dy // 2, dx // 2
         pad = (0, 0, left, dx - left, top, dy - top)
-        cat = lambda u, v: torch.cat([F.pad(u, pad), v], dim=3).contiguous()
+        def cat(u, v):
+            if dy == 0 and dx == 0:     # equal maps (every stage at 588 and the other 16-divisible sizes): two strided row copies
+                out = torch.empty((B, H, Wd, Cx + v.shape[3]), device=u.device, dtype=u.dtype)
+                o2 = out.view(-1, out.shape[3])
+                ops.copy_channels(u.reshape(-1, Cx), o2[:, :Cx])
+                ops.copy_channels(v.reshape(-1, v.shape[3]), o2[:, Cx:])
+                return out
+            return torch.cat([F.pad(u, pad), v], dim=3).contiguous()   # odd sizes: zero border through ATen (copies only)
         hi = cat(a[0], c[0])
         lo = cat(a[1], c[1]) if a[1] is not None and c[1] is not None else None
         return (hi, lo), (top, left, h, w, Cx)
