@@ -41,6 +41,11 @@ precise_attention = os.environ.get("ASIS_PRECISE", "0") not in ("0", "")
 # projection weight / bias before their 16-bit rounding, attention through asis_attention_fwd_prescaled (ASIS_FOLD_SCALE=0:
 # the unfolded kernel).  The training forward / backward keep the unfolded q (the backward rebuilds P from q, k, scale).
 fold_attn_scale = os.environ.get("ASIS_FOLD_SCALE", "1") not in ("0", "")
+# forward-only attention: q | k | v from ONE projection GEMM and V read row-major by the attention kernel (transposing LDS
+# reads, asis_attention_fwd_qkv) instead of the batched V^T GEMMs.  OFF by default: with every launch on one stream it saves
+# 1.0 ms per step (V^T GEMMs -3.5 ms, wider projection +1.9, attention +3 %), but the V^T GEMMs already hide almost completely
+# on their side stream -- same-box A/B of the default command: 201.7 -> 187.5 img/s.  ASIS_FUSED_QKV=1 for single-stream use.
+fused_qkv = os.environ.get("ASIS_FUSED_QKV", "0") not in ("0", "")
 
 # The CNN encoder of the frozen-backbone step runs on a side HIP stream, overlapped with the ViT block loop
 # (engines.SegEngine._encoder_on_side_stream).  ASIS_ENC_STREAM=0: everything on the compute stream.

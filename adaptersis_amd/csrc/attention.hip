@@ -305,7 +305,11 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(const T* __restrict_
 // Every buffer a DMA overwrites was last read before the previous barrier; everything read was waited for at it.
 // Out-of-range K rows repeat row N-1 (scores masked in the tail tile), out-of-range V^T columns are zeroed in the
 // fragment registers of the tail tile (P is exactly 0 there, but 0 * garbage must not make a NaN).
-template <typename T, int SCHED, int DBG = 0>
+// VROWS (round 3): V comes row-major ([tokens, ld] next to q and k in ONE qkv GEMM output) instead of pre-transposed: the
+// tile is staged [key][d] exactly like K and the P.V MFMA's A operand (8 consecutive keys of one d per lane) is assembled by
+// the transposing LDS read ds_read_b64_tr_b16 (two per fragment).  That removes the two batched V^T GEMMs per block of the
+// stacked trunk (149 us on a side stream against +88 us of the wider qkv GEMM).
+template <typename T, int SCHED, int DBG = 0, bool VROWS = false>
 __global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(const T* __restrict__ q, const T* __restrict__ k, int64_t ldqk,
                                                               const T* __restrict__ vt, int64_t ldvt, T* __restrict__ o, T* __restrict__ o_lo,
                                                               int64_t ldo, int H, int N1, float scale_log2e,
@@ -346,7 +350,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(const T* __restri
   }
 
   const T* kbase = k + row0 * ldqk + head * HD;
-  const T* vbase = vt + ((int64_t)b * H + head) * HD * ldvt;
+  const T* vbase = VROWS ? vt + row0 * ldvt + head * HD : vt + ((int64_t)b * H + head) * HD * ldvt;
   // LDS-DMA: one wave-instruction lands 1 KiB = 8 rows x 8 chunks linearly; lane (lr, lc) therefore fetches the chunk
   // that the XOR swizzle wants at slot lc of row r.  Wave `wid` stages rows 16 wid .. 16 wid + 15 of every tile.
   const int lr = lane >> 3, lc = lane & 7;
@@ -357,8 +361,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(const T* __restri
   // V^T), only the last tile needs the clamped addresses
   const T* const kp0 = kbase + (int64_t)r0 * ldqk + c0;
   const T* const kp1 = kbase + (int64_t)r1 * ldqk + c1;
-  const T* const vp0 = vbase + (int64_t)r0 * ldvt + c0;
-  const T* const vp1 = vbase + (int64_t)r1 * ldvt + c1;
+  // VROWS: rows are keys, 128-byte rows whose 16-byte chunks are XORed with (key & 3) << 1 -- the four key rows of one
+  // transposing read then sit in four different 32-byte bank groups
+  const int cv0 = VROWS ? (lc ^ ((r0 & 3) << 1)) << 3 : c0, cv1 = VROWS ? (lc ^ ((r1 & 3) << 1)) << 3 : c1;
+  const T* const vp0 = vbase + (int64_t)r0 * ldvt + cv0;
+  const T* const vp1 = vbase + (int64_t)r1 * ldvt + cv1;
   const int64_t kstep = (int64_t)KT * ldqk;
   auto dma_k = [&](int t, int slot) {
     T* dst = Kr + slot * (KT * HD) + wid * 16 * HD;
@@ -375,11 +382,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(const T* __restri
   };
   auto dma_v = [&](int t) {
     T* dst = Vr + (t & 1) * (KT * HD) + wid * 16 * HD;
-    const T *a = vp0 + t * KT, *bb = vp1 + t * KT;
+    const T *a = VROWS ? vp0 + (int64_t)t * KT * ldvt : vp0 + t * KT, *bb = VROWS ? vp1 + (int64_t)t * KT * ldvt : vp1 + t * KT;
     if (t == nt - 1) {
       const int key0 = t * KT;
-      if (key0 + c0 >= N) a = vbase + (int64_t)r0 * ldvt;
-      if (key0 + c1 >= N) bb = vbase + (int64_t)r1 * ldvt;
+      if (VROWS) {  // keys past N repeat row N-1 (finite values; their probabilities are exactly 0)
+        const int ka = key0 + r0 < N ? key0 + r0 : N - 1, kb = key0 + r1 < N ? key0 + r1 : N - 1;
+        a = vbase + (int64_t)ka * ldvt + cv0;
+        bb = vbase + (int64_t)kb * ldvt + cv1;
+      } else {
+        if (key0 + c0 >= N) a = vbase + (int64_t)r0 * ldvt;
+        if (key0 + c1 >= N) bb = vbase + (int64_t)r1 * ldvt;
+      }
     }
     __builtin_amdgcn_global_load_lds((glb_ptr)a, (lds_ptr)dst, 16, 0, 0);
     __builtin_amdgcn_global_load_lds((glb_ptr)bb, (lds_ptr)(dst + 8 * HD), 16, 0, 0);
@@ -550,6 +563,23 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(const T* __restri
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
           const int ch = 4 * kb + 2 * s2 + fh;
+          if (VROWS) {
+            // transposed read: the 16-lane group reads 4 keys x 16 d; lane li supplies key row li >> 2, d quad li & 3 and
+            // receives 4 consecutive keys of d = 16 (group & 1) + li; two reads = the 8 keys 8 ch .. 8 ch + 7
+            typedef s16x4 __attribute__((address_space(3))) * lds_tr_ptr;
+            typedef short s16x8 __attribute__((ext_vector_type(8)));
+            const int li = lane & 15, dcol = db * 32 + 16 * ((lane >> 4) & 1) + 4 * (li & 3);
+            s16x4 h2[2];
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+              const int key = 8 * ch + 4 * half + (li >> 2);
+              h2[half] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                  (lds_tr_ptr)(Vs + key * HD + ((((dcol >> 3) ^ ((key & 3) << 1)) << 3) | (dcol & 7))));
+            }
+            const v8 vfr = __builtin_bit_cast(v8, (s16x8)__builtin_shufflevector(h2[0], h2[1], 0, 1, 2, 3, 4, 5, 6, 7));
+            oacc[db] = T16<T>::mfma32(vfr, pf[kb][s2], oacc[db]);
+            continue;
+          }
           uint4 w = *reinterpret_cast<const uint4*>(Vs + row * HD + ((ch ^ rsw) << 3));
           if (tail) {
             const int valid = N - (key0 + ch * 8);
@@ -643,7 +673,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(const T* __restri
 
 static int attention_fwd_impl(void* stream, int dtype, const void* q, const void* k, int64_t ldqk, const void* vt,
                               int64_t ldvt, void* o, void* o_lo, int64_t ldo, int B1, int N1, int B2, int N2, int H,
-                              float scale, float* lse2, int prescaled) {
+                              float scale, float* lse2, int prescaled, int vrows = 0) {
   const int B = B1 + B2;
   ASIS_REQUIRE(!o_lo || (((uintptr_t)o_lo) & 7) == 0, "asis_attention_fwd: o_lo must be 8-byte aligned");
   const int N = N1 > N2 ? N1 : N2;
@@ -652,7 +682,8 @@ static int attention_fwd_impl(void* stream, int dtype, const void* q, const void
   ASIS_REQUIRE(!lse2 || B2 == 0, "asis_attention_fwd: the log-sum-exp output is for a single token batch");
   ASIS_REQUIRE(B <= 65535 && H <= 65535, "asis_attention_fwd: B/H too large");
   ASIS_REQUIRE(ldqk % 8 == 0 && ldqk >= (int64_t)H * HD, "asis_attention_fwd: ldqk=%ld must be a multiple of 8 and >= H*64", (long)ldqk);
-  ASIS_REQUIRE(ldvt % 8 == 0 && ldvt >= N, "asis_attention_fwd: ldvt=%ld must be a multiple of 8 and >= N=%d", (long)ldvt, N);
+  ASIS_REQUIRE(ldvt % 8 == 0 && ldvt >= (vrows ? (int64_t)H * HD : (int64_t)N),
+               "asis_attention_fwd: ldvt=%ld must be a multiple of 8 and >= %s", (long)ldvt, vrows ? "H*64" : "N");
   ASIS_REQUIRE(ldo % 4 == 0 && ldo >= (int64_t)H * HD, "asis_attention_fwd: ldo=%ld must be a multiple of 4 and >= H*64", (long)ldo);
   ASIS_REQUIRE(asis_aligned16(q) && asis_aligned16(k) && asis_aligned16(vt) && (((uintptr_t)o) & 7) == 0,
                "asis_attention_fwd: pointers must be 16-byte aligned");
@@ -673,6 +704,19 @@ static int attention_fwd_impl(void* stream, int dtype, const void* q, const void
   static const int pipe = [] { const char* e = getenv("ASIS_ATTN_PIPE"); return e ? atoi(e) : 1; }();
   ASIS_REQUIRE(!prescaled || (!abl && (pipe == 1 || pipe == 4)),
                "asis_attention_fwd_prescaled: only the folded kernel takes a pre-scaled q (ASIS_ATTN_PIPE 1 | 4, no ablation)");
+  if (vrows) {   // row-major V: the pipelined kernel in its default or folded form
+    ASIS_REQUIRE(!abl && (pipe == 1 || pipe == 4), "asis_attention_fwd_qkv: needs the pipelined kernel (ASIS_ATTN_PIPE 1 | 4, no ablation)");
+    const bool fold = pipe == 4 || prescaled;
+#define ASIS_ATTN_VROWS_LAUNCH(TT, SC)                                                                                          \
+  hipLaunchKernelGGL((attn_fwd_pipe_kernel<TT, SC, 0, true>), grid, block, 0, s, reinterpret_cast<const TT*>(q),                \
+                     reinterpret_cast<const TT*>(k), ldqk, reinterpret_cast<const TT*>(vt), ldvt, reinterpret_cast<TT*>(o),      \
+                     reinterpret_cast<TT*>(o_lo), ldo, H, N1, sl, lse2, B1, N2, prescaled)
+    if (dtype == ASIS_F16) { if (fold) ASIS_ATTN_VROWS_LAUNCH(f16, 3); else ASIS_ATTN_VROWS_LAUNCH(f16, 0); }
+    else { if (fold) ASIS_ATTN_VROWS_LAUNCH(bf16, 3); else ASIS_ATTN_VROWS_LAUNCH(bf16, 0); }
+#undef ASIS_ATTN_VROWS_LAUNCH
+    ASIS_CHECK_LAUNCH("asis_attention_fwd_qkv");
+    return ASIS_OK;
+  }
   if (pipe && abl == 6 && dtype == ASIS_F16) {
     hipLaunchKernelGGL((attn_fwd_pipe_kernel<f16, 0, 1>), grid, block, 0, s, (const f16*)q, (const f16*)k, ldqk, (const f16*)vt, ldvt, (f16*)o, (f16*)o_lo, ldo, H, N1, sl, lse2, B1, N2, 0);
   } else if (pipe && !abl) {
@@ -710,6 +754,14 @@ extern "C" int asis_attention_fwd_prescaled(void* stream, int dtype, const void*
                                             int64_t ldvt, void* o, void* o_lo, int64_t ldo, int B1, int N1, int B2, int N2, int H,
                                             float* lse2) {
   return attention_fwd_impl(stream, dtype, q, k, ldqk, vt, ldvt, o, o_lo, ldo, B1, N1, B2, N2, H, 1.0f, lse2, 1);
+}
+
+extern "C" int asis_attention_fwd_qkv(void* stream, int dtype, const void* q, const void* k, const void* v, int64_t ld, void* o,
+                                      void* o_lo, int64_t ldo, int B1, int N1, int B2, int N2, int H, float scale, int prescaled,
+                                      float* lse2) {
+  ASIS_REQUIRE(v && asis_aligned16(v), "asis_attention_fwd_qkv: v must be a 16-byte aligned pointer");
+  return attention_fwd_impl(stream, dtype, q, k, ld, v, ld, o, o_lo, ldo, B1, N1, B2, N2, H, prescaled ? 1.0f : scale, lse2,
+                            prescaled, 1);
 }
 
 extern "C" int asis_attention_fwd_seg(void* stream, int dtype, const void* q, const void* k, int64_t ldqk, const void* vt,

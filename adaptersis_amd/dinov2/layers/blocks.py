@@ -232,6 +232,13 @@ class Attention(_Packed):
             scale = self.scale
         o = torch.empty((xn.shape[0], D), device=xn.device, dtype=xn.dtype)
         o_lo = torch.empty_like(o) if config.split_attn_out else None   # rounding residual of o: proj's split A operand
+        if config.fused_qkv and len(segs) <= 2:
+            # `attention.py:58`: one qkv GEMM; the attention kernel reads V row-major out of it (asis_attention_fwd_qkv)
+            if sum(b * n for b, n in segs) != xn.shape[0]:
+                raise ValueError("attend_rows: segments do not cover the rows")
+            qkv = ops.gemm(xn, w, bias_n=bias, b_lo=wlo)
+            ops.attention_fwd_qkv(qkv, list(segs), self.num_heads, scale, o, out_lo=o_lo)
+            return o, o_lo
         one_launch = len(segs) == 2
         ldv_all = (max(n for _, n in segs) + 63) // 64 * 64
         vt_all = torch.empty((sum(b for b, _ in segs), D, ldv_all), device=xn.device, dtype=xn.dtype) if one_launch else None

@@ -253,6 +253,26 @@ def _attention_launch(q, k, vt, out, out_lo, B1, N1, B2, N2, H, scale, lse):
                                              float(scale), _p(lse)), "asis_attention_fwd")
 
 
+def attention_fwd_qkv(qkv: torch.Tensor, segs, H: int, scale: Optional[float], out: torch.Tensor,
+                      out_lo: Optional[torch.Tensor] = None, lse: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """qkv: 16-bit [rows, 3*H*64] = q | k | v of ONE projection GEMM (V row-major: no transposed copy); ``segs`` one or two
+    (B, N) token batches stacked along the rows; ``scale`` None = q carries scale * log2(e) (folded projection)."""
+    _dev(qkv, out, out_lo, lse)
+    D = H * 64
+    if qkv.dim() != 2 or qkv.shape[1] < 3 * D or qkv.stride(1) != 1 or len(segs) not in (1, 2):
+        raise ValueError("attention_fwd_qkv: qkv must be [rows, >= 3*H*64] with contiguous rows, one or two segments")
+    (B1, N1), (B2, N2) = (segs[0], segs[1]) if len(segs) == 2 else (segs[0], (0, 0))
+    if qkv.shape[0] != B1 * N1 + B2 * N2:
+        raise ValueError("attention_fwd_qkv: segments do not cover the rows")
+    _check_out_lo(out, out_lo)
+    es = qkv.element_size()
+    check(lib().asis_attention_fwd_qkv(_stream(), _dt(qkv.dtype), qkv.data_ptr(), qkv.data_ptr() + D * es,
+                                       qkv.data_ptr() + 2 * D * es, qkv.stride(0), out.data_ptr(), _p(out_lo), out.stride(0),
+                                       B1, N1, B2, N2, H, 0.0 if scale is None else float(scale), int(scale is None), _p(lse)),
+          "asis_attention_fwd_qkv")
+    return out
+
+
 def attention_fwd(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, B: int, H: int, N: int, scale: Optional[float],
                   out: Optional[torch.Tensor] = None, lse: Optional[torch.Tensor] = None,
                   out_lo: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -153,6 +153,11 @@ int asis_attention_fwd_split(void* stream, int dtype, const void* q, const void*
  * P = exp2(S') needs no per-element multiply-add (-5 % kernel time).  lse2 as below. */
 int asis_attention_fwd_prescaled(void* stream, int dtype, const void* q, const void* k, int64_t ldqk, const void* vt, int64_t ldvt,
                                  void* o, void* o_lo, int64_t ldo, int B1, int N1, int B2, int N2, int H, float* lse2);
+/* the same attention with V row-major: q, k, v are three column blocks of ONE projection output [tokens, ld]
+ * (attention.py:58 `qkv = self.qkv(x)`), no transposed copy of V; prescaled != 0: q already carries scale * log2(e) (scale
+ * ignored), as in asis_attention_fwd_prescaled.  o_lo / lse2 as above. */
+int asis_attention_fwd_qkv(void* stream, int dtype, const void* q, const void* k, const void* v, int64_t ld, void* o, void* o_lo,
+                           int64_t ldo, int B1, int N1, int B2, int N2, int H, float scale, int prescaled, float* lse2);
 /* same, also writing lse2[B,H,N] = log2 sum_k exp2(log2(e) * scale * q.k) per query (what asis_attention_bwd
  * needs to rebuild the probabilities); lse2 NULL = asis_attention_fwd */
 int asis_attention_fwd_lse(void* stream, int dtype, const void* q, const void* k, int64_t ldqk, const void* vt,

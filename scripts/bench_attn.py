@@ -16,6 +16,9 @@ def main():
     vt[:, :, :N] = torch.randn(B, D, N, device=dev).to(dt)
     o = torch.empty(M, D, device=dev, dtype=dt)
     f = lambda: ops.attention_fwd(qk[:, :D], qk[:, D:], vt, B, H, N, 0.125, out=o)
+    if os.environ.get("ASIS_ATTN_VAR") == "qkv":   # row-major V out of one [tokens, 3 D] matrix
+        qkv = torch.cat([qk, vt[:, :, :N].transpose(1, 2).reshape(M, D)], dim=1).contiguous()
+        f = lambda: ops.attention_fwd_qkv(qkv, [(B, N)], H, 0.125, o)
     f()
     q = qk[:, :D].float().view(B, N, H, 64).transpose(1, 2)
     k = qk[:, D:].float().view(B, N, H, 64).transpose(1, 2)

@@ -272,6 +272,57 @@ def test_attention_fwd_prescaled_two_segments(dev):
     assert rel_l2(o, torch.cat([ref1, ref2])) < 1e-3
 
 
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("folded", [False, True])
+@pytest.mark.parametrize("B,H,N,spike", [(1, 1, 64, False), (2, 2, 257, False), (1, 2, 1765, False), (1, 1, 100, False),
+                                         (1, 2, 300, True), (1, 1, 700, False)])
+def test_attention_fwd_qkv_row_major_v(dev, dt, folded, B, H, N, spike):
+    """asis_attention_fwd_qkv: q | k | v as column blocks of one [tokens, 3 D] matrix, V row-major (transposing LDS reads in
+    the kernel), folded (scale=None) and unfolded; output, split output and log-sum-exp against fp32 on the same operands."""
+    D = H * 64
+    q = W.tensor(f"qv.q{N}", (B, N, H, 64), 2.0)
+    k = W.tensor(f"qv.k{N}", (B, N, H, 64), 2.0)
+    v = W.tensor(f"qv.v{N}", (B, N, H, 64), 1.0)
+    if spike:
+        k[0, N - 40, 0] = 5.0 * q[0, 17, 0]
+        k[0, 70, 0] = 3.0 * q[0, 18, 0]
+    qs = ((q * C_FOLD) if folded else q).to(dev).to(dt)
+    k, v = k.to(dev).to(dt), v.to(dev).to(dt)
+    qkv = torch.cat([qs.reshape(B * N, D), k.reshape(B * N, D), v.reshape(B * N, D)], dim=1).contiguous()
+    qf, kf, vf = (t.float().permute(0, 2, 1, 3) for t in (qs, k, v))
+    s2 = (qf @ kf.transpose(-1, -2)) * (1.0 if folded else C_FOLD)          # exp2 units
+    ref = (torch.softmax(s2 * 0.6931471805599453, -1) @ vf).permute(0, 2, 1, 3).reshape(B * N, D)
+    lse_ref = torch.logsumexp(s2 * 0.6931471805599453, -1) * 1.4426950408889634
+    o = torch.empty((B * N, D), device=dev, dtype=dt)
+    o_lo = torch.empty_like(o)
+    lse = torch.empty((B, H, N), device=dev, dtype=torch.float32)
+    ops.attention_fwd_qkv(qkv, [(B, N)], H, None if folded else 0.125, o, out_lo=o_lo, lse=lse)
+    assert torch.isfinite(o.float()).all()
+    err, err_split = rel_l2(o, ref), rel_l2(o.float() + o_lo.float(), ref)
+    print(f"qkv attention {dt} folded={folded} B={B} H={H} N={N}: rel-L2 {err:.2e} split {err_split:.2e}")
+    assert err < (1e-3 if dt == torch.float16 else 1e-2)
+    assert err_split < (4e-4 if dt == torch.float16 else 4e-3)
+    assert (lse - lse_ref).abs().max() < 2e-3
+    if spike:
+        assert rel_l2(o[17], ref[17]) < 2e-3 and rel_l2(o[18], ref[18]) < 2e-3
+
+
+def test_attention_fwd_qkv_two_segments(dev):
+    dt, H = torch.float16, 2
+    D = H * 64
+    (B1, N1), (B2, N2) = (2, 257), (2, 256)
+    parts, refs = [], []
+    for tag, (B, N) in (("a", (B1, N1)), ("b", (B2, N2))):
+        q, k, v = (W.tensor(f"qv2.{tag}{i}", (B, N, H, 64), 2.0 if i < 2 else 1.0).to(dev).to(dt) for i in range(3))
+        parts.append(torch.cat([t.reshape(B * N, D) for t in (q, k, v)], dim=1))
+        qf, kf, vf = (t.float().permute(0, 2, 1, 3) for t in (q, k, v))
+        refs.append((torch.softmax((qf * 0.125) @ kf.transpose(-1, -2), -1) @ vf).permute(0, 2, 1, 3).reshape(B * N, D))
+    qkv = torch.cat(parts).contiguous()
+    o = torch.empty((qkv.shape[0], D), device=dev, dtype=dt)
+    ops.attention_fwd_qkv(qkv, [(B1, N1), (B2, N2)], H, 0.125, o)
+    assert rel_l2(o, torch.cat(refs)) < 1e-3
+
+
 def test_im2col_and_cls_pos(dev):
     img, _ = W.synthetic_batch(2, 56)
     img = img.to(dev)
