@@ -32,6 +32,27 @@ def test_block_vs_oracle(dev):
     assert rel_l2(y, ref) < TOL / 2
 
 
+@pytest.mark.parametrize("fold", [True, False])
+def test_block_with_fused_qkv_projection(dev, fold):
+    """config.fused_qkv: one qkv GEMM + asis_attention_fwd_qkv (V row-major) against the oracle and against the default
+    path (q | k GEMM + batched V^T GEMMs): same projection arithmetic, another attention data path."""
+    from adaptersis_amd import config
+    m, sd = build("vit_tiny_test", dev)
+    x = W.tensor("blk.x", (2, 257, 128), 1.0)
+    ref = O.block(x, sd, "blocks.0", 2)
+    keep = (config.fused_qkv, config.fold_attn_scale)
+    try:
+        config.fold_attn_scale = fold
+        config.fused_qkv = False
+        y0 = m.blocks[0](x.to(dev))
+        config.fused_qkv = True
+        y1 = m.blocks[0](x.to(dev))
+    finally:
+        config.fused_qkv, config.fold_attn_scale = keep
+    assert rel_l2(y1, ref) < TOL / 2
+    assert rel_l2(y1, y0) < 1e-5
+
+
 def test_patch_embed_vs_oracle(dev):
     m, sd = build("vit_tiny_test", dev)
     img, _ = W.synthetic_batch(2, 224)
