@@ -429,6 +429,7 @@ def main():
                        "side_streams": {"encoder": bool(config.encoder_stream), "vt": bool(config.vt_stream),
                                         "wgrad": bool(config.wgrad_stream), "dual_trunk": bool(config.dual_stream)},
                        "split_attn_out": bool(getattr(eng, "split_attn_out", False)), "precise_level": int(config.precise_level),
+                       "fold_attn_scale": bool(config.fold_attn_scale), "fused_qkv": bool(config.fused_qkv),
                        "skipped_optimizer_steps": int(eng.optimizer.skipped_steps)},
         }
         if roof:
