@@ -264,9 +264,11 @@ def test_split_precision_conv_matches_fp32(dev):
     assert rel_l2(y1, ref) > 1e-4  # single pass is limited by the 16-bit rounding of the operands
 
 
+@pytest.mark.parametrize("dt16,tol", [(torch.float16, 2e-6), (torch.bfloat16, 6e-5)])
 @pytest.mark.parametrize("Cout", [2, 3, 8, 11])
-def test_smallcout_direct_conv_fwd_and_dgrad(dev, Cout):
-    """Direct fp32 kernels of the classifier conv (few output channels) vs autograd, split input halves."""
+def test_smallcout_direct_conv_fwd_and_dgrad(dev, Cout, dt16, tol):
+    """Classifier conv (few output channels; MFMA tile kernels at Cin = 64, fp32 vector kernels otherwise) vs autograd,
+    split input halves; bf16 halves carry 16 mantissa bits together, hence the wider tolerance."""
     Bn, Cin, H, Wd = 2, 64, 23, 19
     x = W.tensor("sc.x", (Bn, Cin, H, Wd), 1.0).requires_grad_()
     w = W.tensor(f"sc.w{Cout}", (Cout, Cin, 3, 3), 0.3)
@@ -275,18 +277,18 @@ def test_smallcout_direct_conv_fwd_and_dgrad(dev, Cout):
     dy = W.tensor(f"sc.dy{Cout}", tuple(y.shape), 1.0)
     y.backward(dy)
     xn = x.detach().permute(0, 2, 3, 1).contiguous().view(-1, Cin).to(dev)
-    x_hi = ops.cast_pad(xn, Cin, torch.float16).view(Bn, H, Wd, Cin)
-    x_lo = ops.cast_pad(xn, Cin, torch.float16, part=1).view(Bn, H, Wd, Cin)
+    x_hi = ops.cast_pad(xn, Cin, dt16).view(Bn, H, Wd, Cin)
+    x_lo = ops.cast_pad(xn, Cin, dt16, part=1).view(Bn, H, Wd, Cin)
     out = ops.conv3x3_smallcout_fwd(x_hi, x_lo, w.to(dev), bias.to(dev))
-    assert rel_l2(out, y.detach().permute(0, 2, 3, 1)) < 2e-6
+    assert rel_l2(out, y.detach().permute(0, 2, 3, 1)) < tol
     out1 = ops.conv3x3_smallcout_fwd(x_hi, None, w.to(dev), None)
-    assert rel_l2(out1, F.conv2d(rnd(x.detach(), torch.float16), w, None, padding=1).permute(0, 2, 3, 1)) < 2e-6
+    assert rel_l2(out1, F.conv2d(rnd(x.detach(), dt16), w, None, padding=1).permute(0, 2, 3, 1)) < tol
     if Cout <= 8:
         dn = dy.permute(0, 2, 3, 1).contiguous().view(-1, Cout).to(dev)
-        d_hi = ops.cast_pad(dn, 8, torch.float16).view(Bn, H, Wd, 8)
-        d_lo = ops.cast_pad(dn, 8, torch.float16, part=1).view(Bn, H, Wd, 8)
+        d_hi = ops.cast_pad(dn, 8, dt16).view(Bn, H, Wd, 8)
+        d_lo = ops.cast_pad(dn, 8, dt16, part=1).view(Bn, H, Wd, 8)
         dx = ops.conv3x3_smallcout_dgrad(d_hi, d_lo, w.to(dev))
-        assert rel_l2(dx, x.grad.permute(0, 2, 3, 1)) < 2e-6
+        assert rel_l2(dx, x.grad.permute(0, 2, 3, 1)) < tol
 
 
 @pytest.mark.parametrize("Cin,Cout,H,stride,pad", [(64, 48, 19, 1, 1), (128, 128, 24, 1, 1), (64, 64, 37, 2, 0)])
