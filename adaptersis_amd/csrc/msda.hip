@@ -15,15 +15,17 @@ namespace {
 
 constexpr int MAX_LP = 16;
 
-template <typename T>
+// NC: 16-byte chunks per thread (1 or 2).  The softmax over the L*P points and the tap arithmetic are repeated by every thread
+// of a (query, head) group; two chunks per thread halve that share of the work (Dh % 16 == 0).
+template <typename T, int NC = 1>
 __global__ __launch_bounds__(256) void msda_fwd_kernel(const T* __restrict__ value, const float* __restrict__ offaw,
                                                        int64_t ld_offaw, const float* __restrict__ ref,
                                                        const int* __restrict__ shapes, const int* __restrict__ starts,
                                                        T* __restrict__ out, int B, int Lq, int Lin, int M, int L, int P,
                                                        int Dh) {
   const int D = M * Dh;
-  const int cpq = D >> 3;   // chunks per query
-  const int cph = Dh >> 3;  // chunks per head
+  const int cpq = D / (8 * NC);   // thread slots per query
+  const int cph = Dh / (8 * NC);  // thread slots per head
   const int64_t total = (int64_t)B * Lq * cpq;
   const int LP = L * P;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -51,10 +53,10 @@ __global__ __launch_bounds__(256) void msda_fwd_kernel(const T* __restrict__ val
       }
     const float inv = 1.0f / den;
     const float rx = ref[2 * q], ry = ref[2 * q + 1];
-    float acc[8];
+    float acc[8 * NC];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-    const T* vb = value + (int64_t)b * Lin * D + c * 8;
+    for (int e = 0; e < 8 * NC; ++e) acc[e] = 0.f;
+    const T* vb = value + (int64_t)b * Lin * D + c * 8 * NC;
     for (int l = 0; l < L; ++l) {
       const int Hl = shapes[2 * l], Wl = shapes[2 * l + 1];
       const T* vl = vb + (int64_t)starts[l] * D;
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(256) void msda_fwd_kernel(const T* __restrict__ val
         const float aw = w[j] * inv;
         // the four corners are fetched unconditionally from coordinates clamped into the level, an out-of-range
         // corner only loses its weight: a load under `if (in range)` is waited for on the spot, one at a time
-        uint4 raw[4];
+        uint4 raw[4][NC];
         float wt[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -80,28 +82,34 @@ __global__ __launch_bounds__(256) void msda_fwd_kernel(const T* __restrict__ val
           const bool inb = (unsigned)xx < (unsigned)Wl && (unsigned)yy < (unsigned)Hl;
           const int xc = xx < 0 ? 0 : (xx >= Wl ? Wl - 1 : xx), yc = yy < 0 ? 0 : (yy >= Hl ? Hl - 1 : yy);
           wt[t] = inb ? ((t & 1) ? ax : 1.f - ax) * ((t >> 1) ? ay : 1.f - ay) * aw : 0.f;
-          raw[t] = *reinterpret_cast<const uint4*>(vl + ((int64_t)yc * Wl + xc) * D);
+#pragma unroll
+          for (int h = 0; h < NC; ++h) raw[t][h] = *reinterpret_cast<const uint4*>(vl + ((int64_t)yc * Wl + xc) * D + 8 * h);
         }
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          float f0, f1;
-          unpack2<T>(raw[t].x, f0, f1);
-          acc[0] += wt[t] * f0; acc[1] += wt[t] * f1;
-          unpack2<T>(raw[t].y, f0, f1);
-          acc[2] += wt[t] * f0; acc[3] += wt[t] * f1;
-          unpack2<T>(raw[t].z, f0, f1);
-          acc[4] += wt[t] * f0; acc[5] += wt[t] * f1;
-          unpack2<T>(raw[t].w, f0, f1);
-          acc[6] += wt[t] * f0; acc[7] += wt[t] * f1;
-        }
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int h = 0; h < NC; ++h) {
+            float f0, f1;
+            unpack2<T>(raw[t][h].x, f0, f1);
+            acc[8 * h + 0] += wt[t] * f0; acc[8 * h + 1] += wt[t] * f1;
+            unpack2<T>(raw[t][h].y, f0, f1);
+            acc[8 * h + 2] += wt[t] * f0; acc[8 * h + 3] += wt[t] * f1;
+            unpack2<T>(raw[t][h].z, f0, f1);
+            acc[8 * h + 4] += wt[t] * f0; acc[8 * h + 5] += wt[t] * f1;
+            unpack2<T>(raw[t][h].w, f0, f1);
+            acc[8 * h + 6] += wt[t] * f0; acc[8 * h + 7] += wt[t] * f1;
+          }
       }
     }
-    uint4 o;
-    o.x = pack2<T>(acc[0], acc[1]);
-    o.y = pack2<T>(acc[2], acc[3]);
-    o.z = pack2<T>(acc[4], acc[5]);
-    o.w = pack2<T>(acc[6], acc[7]);
-    *reinterpret_cast<uint4*>(out + bq * D + c * 8) = o;
+#pragma unroll
+    for (int h = 0; h < NC; ++h) {
+      uint4 o;
+      o.x = pack2<T>(acc[8 * h + 0], acc[8 * h + 1]);
+      o.y = pack2<T>(acc[8 * h + 2], acc[8 * h + 3]);
+      o.z = pack2<T>(acc[8 * h + 4], acc[8 * h + 5]);
+      o.w = pack2<T>(acc[8 * h + 6], acc[8 * h + 7]);
+      *reinterpret_cast<uint4*>(out + bq * D + c * 8 * NC + 8 * h) = o;
+    }
   }
 }
 
@@ -167,16 +175,18 @@ extern "C" int asis_msda_fwd(void* stream, int dtype, const void* value, const f
   ASIS_REQUIRE(ld_offaw >= (int64_t)M * L * P * 3, "asis_msda_fwd: ld_offaw too small");
   ASIS_REQUIRE(asis_aligned16(value) && asis_aligned16(out), "asis_msda_fwd: value/out must be 16-byte aligned");
   ASIS_REQUIRE(dtype == ASIS_F16 || dtype == ASIS_BF16, "asis_msda_fwd: bad dtype %d", dtype);
-  const int64_t total = (int64_t)B * Lq * (M * Dh / 8);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == ASIS_F16)
-    hipLaunchKernelGGL((msda_fwd_kernel<f16>), dim3(grid_for(total, 256, 1 << 20)), dim3(256), 0, s,
-                       reinterpret_cast<const f16*>(value), offaw, ld_offaw, ref, shapes, starts,
-                       reinterpret_cast<f16*>(out), B, Lq, Lin, M, L, P, Dh);
-  else
-    hipLaunchKernelGGL((msda_fwd_kernel<bf16>), dim3(grid_for(total, 256, 1 << 20)), dim3(256), 0, s,
-                       reinterpret_cast<const bf16*>(value), offaw, ld_offaw, ref, shapes, starts,
-                       reinterpret_cast<bf16*>(out), B, Lq, Lin, M, L, P, Dh);
+  // ASIS_MSDA_NC (default 2): 16-byte chunks per thread when the head dim allows it
+  static const int nc_env = [] { const char* e = getenv("ASIS_MSDA_NC"); return e ? atoi(e) : 2; }();
+  const int nc = (nc_env >= 2 && Dh % 16 == 0) ? 2 : 1;
+  const int64_t total = (int64_t)B * Lq * (M * Dh / (8 * nc));
+#define ASIS_MSDA_FWD(TT, NCC)                                                                                              \
+  hipLaunchKernelGGL((msda_fwd_kernel<TT, NCC>), dim3(grid_for(total, 256, 1 << 20)), dim3(256), 0, s,                      \
+                     reinterpret_cast<const TT*>(value), offaw, ld_offaw, ref, shapes, starts, reinterpret_cast<TT*>(out), B, \
+                     Lq, Lin, M, L, P, Dh)
+  if (dtype == ASIS_F16) { if (nc == 2) ASIS_MSDA_FWD(f16, 2); else ASIS_MSDA_FWD(f16, 1); }
+  else { if (nc == 2) ASIS_MSDA_FWD(bf16, 2); else ASIS_MSDA_FWD(bf16, 1); }
+#undef ASIS_MSDA_FWD
   ASIS_CHECK_LAUNCH("asis_msda_fwd");
   return ASIS_OK;
 }
