@@ -32,6 +32,7 @@ __global__ __launch_bounds__(256) void msda_bwd_kernel(const T* __restrict__ val
   const int c = threadIdx.x;
   const bool live = c < cpq;
   const int m = live ? c / cph : 0;
+  const bool pow2 = (cph & (cph - 1)) == 0 && cph <= 64 && (cpq & 63) == 0;   // whole waves of aligned head groups
   for (int64_t bq = blockIdx.x; bq < (int64_t)B * Lq; bq += gridDim.x) {
     const int q = (int)(bq % Lq);
     const int b = (int)(bq / Lq);
@@ -69,6 +70,7 @@ __global__ __launch_bounds__(256) void msda_bwd_kernel(const T* __restrict__ val
         const int Hl = shapes[2 * l], Wl = shapes[2 * l + 1];
         const T* vl = vb + (int64_t)starts[l] * D;
         float* dvl = dvb + (int64_t)starts[l] * D;
+#pragma unroll 4
         for (int p = 0; p < P; ++p) {
           const int j = l * P + p;
           const float ox = orow[(m * LP + j) * 2], oy = orow[(m * LP + j) * 2 + 1];
@@ -80,15 +82,25 @@ __global__ __launch_bounds__(256) void msda_bwd_kernel(const T* __restrict__ val
           const int y0 = (int)fminf(fmaxf(fy0, -2.f), (float)Hl + 1.f);
           const float aw = w[j] * inv;
           float s_dot = 0.f, sx = 0.f, sy = 0.f;
+          // the four corners are fetched unconditionally from coordinates clamped into the level (as msda_fwd): a load
+          // under `if (in range)` is waited for on the spot, 48 exposed latencies per query
+          uint4 raw4[4];
+          bool inb4[4];
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
             const int xx = x0 + (t & 1), yy = y0 + (t >> 1);
-            if ((unsigned)xx < (unsigned)Wl && (unsigned)yy < (unsigned)Hl) {
+            inb4[t] = (unsigned)xx < (unsigned)Wl && (unsigned)yy < (unsigned)Hl;
+            const int xc = xx < 0 ? 0 : (xx >= Wl ? Wl - 1 : xx), yc = yy < 0 ? 0 : (yy >= Hl ? Hl - 1 : yy);
+            raw4[t] = *reinterpret_cast<const uint4*>(vl + ((int64_t)yc * Wl + xc) * D);
+          }
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int xx = x0 + (t & 1), yy = y0 + (t >> 1);
+            if (inb4[t]) {
               const float bx = (t & 1) ? ax : 1.f - ax, by = (t >> 1) ? ay : 1.f - ay;
               const float dbx = (t & 1) ? 1.f : -1.f, dby = (t >> 1) ? 1.f : -1.f;
               const int64_t o = ((int64_t)yy * Wl + xx) * D;
-              const uint4 raw = *reinterpret_cast<const uint4*>(vl + o);
-              const uint32_t* pw = reinterpret_cast<const uint32_t*>(&raw);
+              const uint32_t* pw = reinterpret_cast<const uint32_t*>(&raw4[t]);
               float dotv = 0.f;
               const float wv = aw * bx * by;
 #pragma unroll
@@ -107,9 +119,18 @@ __global__ __launch_bounds__(256) void msda_bwd_kernel(const T* __restrict__ val
             }
           }
           float* r = red + (m * LP + j) * 3;
-          atomicAdd(r + 0, s_dot);
-          atomicAdd(r + 1, sx);
-          atomicAdd(r + 2, sy);
+          if (pow2) {   // the cph lanes of a head are an aligned lane group: xor-shuffle sum, one writer (no LDS atomics)
+            for (int o = 1; o < cph; o <<= 1) {
+              s_dot += __shfl_xor(s_dot, o, 64);
+              sx += __shfl_xor(sx, o, 64);
+              sy += __shfl_xor(sy, o, 64);
+            }
+            if ((c & (cph - 1)) == 0) { r[0] = s_dot; r[1] = sx; r[2] = sy; }
+          } else {
+            atomicAdd(r + 0, s_dot);
+            atomicAdd(r + 1, sx);
+            atomicAdd(r + 2, sy);
+          }
         }
       }
     }
