@@ -347,29 +347,32 @@ __global__ __launch_bounds__(256) void resize_bwd_kernel(const float* __restrict
         (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
-// out[k] = scale * sum_n partial[n][k]   (double accumulate).  16 row groups x 16 columns per block: every load instruction
-// covers 64-byte row segments, four independent loads per thread in flight, one LDS pass over the 16 row groups at the end.
+// out[k] = scale * sum_n partial[n][k]   (double accumulate).  32 row groups x 8 columns per block (K / 8 blocks: 256 for the
+// 2048 columns of a LayerNorm-backward partial, one per CU), four independent loads per thread in flight, one LDS pass over the
+// row groups at the end.  The partials were just written: the 32-byte row segments come out of L2.
 __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ partial, int n, int K, float scale,
                                                           float* __restrict__ out) {
-  __shared__ double red[16][17];
-  const int c = threadIdx.x & 15, g = threadIdx.x >> 4;
-  const int k = blockIdx.x * 16 + c;
+  constexpr int NG = 32, NCOL = 8;
+  __shared__ double red[NG][NCOL + 1];
+  const int c = threadIdx.x & (NCOL - 1), g = threadIdx.x / NCOL;
+  const int k = blockIdx.x * NCOL + c;
   double s = 0.0;
   if (k < K) {
     const float* p = partial + k;
     int i = g;
-    for (; i + 48 < n; i += 64) {
-      const float a0 = p[(int64_t)i * K], a1 = p[(int64_t)(i + 16) * K], a2 = p[(int64_t)(i + 32) * K], a3 = p[(int64_t)(i + 48) * K];
+    for (; i + 3 * NG < n; i += 4 * NG) {
+      const float a0 = p[(int64_t)i * K], a1 = p[(int64_t)(i + NG) * K], a2 = p[(int64_t)(i + 2 * NG) * K],
+                  a3 = p[(int64_t)(i + 3 * NG) * K];
       s += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
     }
-    for (; i < n; i += 16) s += (double)p[(int64_t)i * K];
+    for (; i < n; i += NG) s += (double)p[(int64_t)i * K];
   }
   red[g][c] = s;
   __syncthreads();
   if (g == 0 && k < K) {
     double t = 0.0;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) t += red[j][c];
+    for (int j = 0; j < NG; ++j) t += red[j][c];
     out[k] = (float)(t * (double)scale);
   }
 }
@@ -586,7 +589,7 @@ extern "C" int asis_reduce_rows(void* stream, const float* partial, int n, int K
     hipLaunchKernelGGL(reduce_rows_wide_kernel, dim3((unsigned)g), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        partial, n, (int64_t)K, scale, out);
   } else {
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3((K + 15) / 16), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), partial, n,
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((K + 7) / 8), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), partial, n,
                        K, scale, out);
   }
   ASIS_CHECK_LAUNCH("asis_reduce_rows");
