@@ -27,33 +27,37 @@ __global__ __launch_bounds__(256) void conv3x3_c3_kernel(const float* __restrict
     wl[i] = w[co * 27 + k];
   }
   __syncthreads();
+  // grid = (column chunks, output rows, images): no 64-bit index division; the 27 taps are fetched unconditionally from
+  // coordinates clamped into the image and an outside tap is zeroed afterwards (a load under `if (inside)` is waited for on
+  // the spot: 27 exposed latencies per thread)
   const int cpp = Cout >> 2;
-  const int64_t total = (int64_t)B * OH * OW * cpp;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int c = (int)(i % cpp);
-    const int64_t pix = i / cpp;
-    const int ow = (int)(pix % OW);
-    const int oh = (int)((pix / OW) % OH);
-    const int b = (int)(pix / ((int64_t)OW * OH));
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= OW * cpp) return;
+  const int ow = j / cpp, c = j - ow * cpp;
+  const int oh = blockIdx.y, b = blockIdx.z;
+  float v[27];
 #pragma unroll
-    for (int ci = 0; ci < 3; ++ci)
+  for (int ci = 0; ci < 3; ++ci)
 #pragma unroll
-      for (int kh = 0; kh < 3; ++kh)
+    for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-          const int ih = oh * stride - pad + kh, iw = ow * stride - pad + kw;
-          if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) {
-            const float v = img[(((int64_t)b * 3 + ci) * H + ih) * W + iw];
-            const float4 ww = reinterpret_cast<const float4*>(wl + (ci * 9 + kh * 3 + kw) * Cout)[c];
-            acc.x += v * ww.x;
-            acc.y += v * ww.y;
-            acc.z += v * ww.z;
-            acc.w += v * ww.w;
-          }
-        }
-    reinterpret_cast<float4*>(out + pix * Cout)[c] = acc;
+      for (int kw = 0; kw < 3; ++kw) {
+        const int ih = oh * stride - pad + kh, iw = ow * stride - pad + kw;
+        const bool in = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+        const int ihc = ih < 0 ? 0 : (ih >= H ? H - 1 : ih), iwc = iw < 0 ? 0 : (iw >= W ? W - 1 : iw);
+        const float x = img[(((int64_t)b * 3 + ci) * H + ihc) * W + iwc];
+        v[ci * 9 + kh * 3 + kw] = in ? x : 0.f;
+      }
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int k = 0; k < 27; ++k) {
+    const float4 ww = reinterpret_cast<const float4*>(wl + k * Cout)[c];
+    acc.x += v[k] * ww.x;
+    acc.y += v[k] * ww.y;
+    acc.z += v[k] * ww.z;
+    acc.w += v[k] * ww.w;
   }
+  reinterpret_cast<float4*>(out + (((int64_t)b * OH + oh) * OW + ow) * Cout)[c] = acc;
 }
 
 // ---- column statistics of an fp32 [R, C] matrix: partial[blk][{sum,sumsq}][C] ------------------
@@ -471,8 +475,9 @@ extern "C" int asis_conv3x3_c3(void* stream, const float* img, const float* w, f
   ASIS_REQUIRE(stride > 0 && pad >= 0 && H + 2 * pad >= 3 && W + 2 * pad >= 3, "asis_conv3x3_c3: bad geometry");
   ASIS_REQUIRE(asis_aligned16(out), "asis_conv3x3_c3: out must be 16-byte aligned");
   const int OH = (H + 2 * pad - 3) / stride + 1, OW = (W + 2 * pad - 3) / stride + 1;
-  const int64_t total = (int64_t)B * OH * OW * (Cout / 4);
-  hipLaunchKernelGGL(conv3x3_c3_kernel, dim3(grid_for(total)), dim3(256), 27 * Cout * sizeof(float),
+  ASIS_REQUIRE(OH <= 65535 && B <= 65535, "asis_conv3x3_c3: OH=%d / B=%d exceed the grid", OH, B);
+  const dim3 grid((unsigned)asis_cdiv((long)OW * (Cout / 4), 256), (unsigned)OH, (unsigned)B);
+  hipLaunchKernelGGL(conv3x3_c3_kernel, grid, dim3(256), 27 * Cout * sizeof(float),
                      reinterpret_cast<hipStream_t>(stream), img, w, out, B, H, W, OH, OW, Cout, stride, pad);
   ASIS_CHECK_LAUNCH("asis_conv3x3_c3");
   return ASIS_OK;
