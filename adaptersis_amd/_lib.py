@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libasis_hip.so")
 
 ASIS_F16, ASIS_BF16, ASIS_F32 = 0, 1, 2
+ASIS_EINVAL, ASIS_ELAUNCH = -1, -2
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_GELU_GRAD = 0, 1, 2, 4
 
 
@@ -73,6 +74,7 @@ SIGNATURES = {
     "asis_version": [],
     "asis_device_count": [],
     "asis_gemm": [_vp, C.POINTER(GemmDesc)],
+    "asis_gemm_group": [_vp, C.POINTER(GemmDesc), _i],
     "asis_gemm_tiles_m": [_i],
     "asis_gemm_set_option": [C.c_char_p, _i],
     "asis_layernorm": [_vp, _i, _vp, _i64, _vp, _vp, _f, _vp, _i64, _i, _i64, _i],
@@ -167,6 +169,8 @@ SIGNATURES = {
     "asis_grad_guard": [_vp, _vp, _i64, _vp, _i],
     "asis_sgd_momentum_guarded": [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i, _vp, _i],
     "asis_scale_f32": [_vp, _vp, _i64, _f],
+    "asis_grad_pack_bf16": [_vp, _vp, _i64, _vp],
+    "asis_grad_unpack_bf16": [_vp, _vp, _i64, _vp],
 }
 
 

@@ -17,7 +17,7 @@ def finalize(partial: torch.Tensor, count: int, bn: torch.nn.Module, sync: bool 
     """partial fp32 [nparts, 2, C] -> (scale, shift, mean, invstd, total_count)."""
     sums = ops.reduce_partials(partial)
     total = float(count)
-    if sync and parallel.collectives_on():
+    if sync and parallel.bn_collectives_on():
         dist.all_reduce(sums)  # 2C doubles
         total = float(count) * parallel.count_scale()   # x world, or x (global / local batch) after parallel.set_batch_ratio
     rm = bn.running_mean if (update and bn.track_running_stats) else None

@@ -140,7 +140,7 @@ def conv_bn_relu_up_backward(owner: _Packed, key: str, st: _Stage, dU, conv: nn.
         g, partial = ops.upsample_bn_relu_bwd(dU, st.raw, st.scale, st.shift, st.mean, st.invstd, st.factor)
     red = ops.reduce_rows(partial.view(partial.shape[0], 2 * C))  # [2C]: sum g | sum g*xhat (scaled)
     local = red
-    if sync_bn and parallel.collectives_on():
+    if sync_bn and parallel.bn_collectives_on():
         # SyncBatchNorm backward: the 2C global sums feed dx only; gamma / beta gradients stay LOCAL sums (the bucket
         # all-reduce averages them over ranks like every other parameter gradient — torch's SyncBatchNorm does the same)
         local = red.clone()

@@ -203,7 +203,7 @@ class FeatureEncoder(_Packed):
         g, partial = ops.upsample_bn_relu_bwd(d0, raw0, scale, shift, mean, invstd, 1)
         red = ops.reduce_rows(partial.view(partial.shape[0], 2 * C0))
         local = red
-        if sync_bn and parallel.collectives_on():
+        if sync_bn and parallel.bn_collectives_on():
             local = red.clone()  # gamma / beta gradients are local sums (averaged with the bucket), dx uses the global ones
             dist.all_reduce(red)
         dx16, _ = ops.bn_bwd_apply(g, raw0, mean, invstd, self._f32("stem1.g", self.stem[1].weight), red[C0:], red[:C0], count, dt)

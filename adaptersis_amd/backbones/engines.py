@@ -17,6 +17,7 @@ Everything is a HIP kernel from libasis_hip.so; torch provides device memory, st
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -84,7 +85,7 @@ class SegEngine(nn.Module):
                  n_last_blocks: int = 4, num_classes: int = 2, lr: float = 0.01, momentum: float = 0.99,
                  weight_decay: float = 3e-5, mode: str = "reference_exact", process_group=None, loss: str = "dice",
                  train_encoder: bool = False, train_backbone: bool = False, optimize_backbone: bool = False,
-                 blocks_per_bucket: int = 4):
+                 blocks_per_bucket: int = 4, grad_compress: Optional[str] = None):
         """``seg_decoder``: ``FeatureDecoder`` -> the `train.py` flow; ``DecoderMLA`` -> the `train_mla.py` flow
         (block -> CACNN -> CAViT order, the four adapter-stream maps feed the MLA head, `blocks[-2]` is evaluated
         twice and `blocks[-1]` never: `train_mla.py:318,340`).  ``loss``: a key of ``SegEngine.LOSSES``.
@@ -96,8 +97,11 @@ class SegEngine(nn.Module):
         every block evaluation of both passes with weight gradients; the 304 M backbone gradients live in a flat
         gradient bucket all-reduced in ``blocks_per_bucket``-block chunks while earlier blocks are still in their
         backward.  Like the reference script (its optimizer lists the decoder only, `:224-229`) the backbone gradients are
-        computed and exchanged but not applied unless ``optimize_backbone`` is set."""
+        computed and exchanged but not applied unless ``optimize_backbone`` is set.  ``grad_compress="bf16"`` (default: the
+        ``ASIS_GRAD_COMPRESS`` environment variable, else off): the backbone bucket travels as bfloat16 (parallel.StageReducer)."""
         super().__init__()
+        if grad_compress is None:
+            grad_compress = os.environ.get("ASIS_GRAD_COMPRESS", "").lower() or None
         if mode not in ("reference_exact", "train_adapters"):
             raise ValueError("mode must be 'reference_exact' or 'train_adapters'")
         if loss not in self.LOSSES:
@@ -158,13 +162,19 @@ class SegEngine(nn.Module):
         # heads that amplify a stream error most (UNet 3.9x, MLA 3.2x; FeatureDecoder 2x) and for the unfrozen backbone
         self.split_attn_out = config.split_attn_out_policy if config.split_attn_out_policy is not None else \
             bool(self.stream_only or self.is_mla or train_backbone)
+        # precision level of the ViT blocks (config.precise_level): level 2 (every linear layer on hi + lo operands) for the one
+        # geometry whose full-depth stress golden needs it — the MLA head (amplifies a stream error 3.2x) behind 2 x 40 block
+        # evaluations (BASELINE config 5: 1.30e-3 on single 16-bit operands, 3.0e-4 on level 2; tests/test_gpu_fulldepth.py)
+        self.precise_level = config.precise_level_policy if config.precise_level_policy is not None else \
+            (2 if (self.is_mla and len(model.blocks) >= 40) else 0)
         self.vit_bucket = None
         if train_backbone:
             if mode != "train_adapters":
                 raise ValueError("train_backbone needs mode='train_adapters' (the unfrozen variant of the adapter flow)")
             self.vit_bucket, self.vit_reducer, self._fire_at = make_vit_bucket(model, blocks_per_bucket, process_group,
                                                                                momentum=optimize_backbone,
-                                                                               min_first_blocks=n_last_blocks)
+                                                                               min_first_blocks=n_last_blocks,
+                                                                               compress=grad_compress)
             if optimize_backbone:
                 buckets.append(self.vit_bucket)
         self.optimizer = SGD(buckets, lr=lr, momentum=momentum, weight_decay=weight_decay)
@@ -245,6 +255,7 @@ class SegEngine(nn.Module):
         ``adapter_saves`` (train_adapters mode): list that receives, per stage, the saved activations of the frozen
         block on pass B and of CAViT / CACNN."""
         config.split_attn_out = self.split_attn_out
+        config.precise_level = self.precise_level
         m = self.model
         B, _, H, W = inp.shape
         inp = inp.float().contiguous()
@@ -307,7 +318,7 @@ class SegEngine(nn.Module):
                 feats.append(m._final_norm(xcat[:Ra].view(B, N + 1, D))[:, 1:])
             # the last stage's CACNN output (`train.py:372-386`) feeds nothing: the decoder input takes c4 from the
             # ENCODER output (`:395`), so unless a caller asks for the taps it is dead code and skipped (same results)
-            dead = s == nl - 1 and taps is None
+            dead = s == nl - 1 and taps is None and config.elide_dead_cacnn
             if train:
                 # CAViT keeps its query for the LayerNorm backward; the stage output below overwrites these rows of the
                 # stacked buffer in place, so the saved copy must be its own tensor
@@ -348,6 +359,7 @@ class SegEngine(nn.Module):
         ``adapter_saves`` (train_adapters): receives, per adapter use, (saved activations of the frozen block in front of it on
         pass B | None, CAViT save, CACNN save | None) — stage 0 is CAViT alone, stages 1..3 are block -> CACNN -> CAViT."""
         config.split_attn_out = self.split_attn_out
+        config.precise_level = self.precise_level
         m = self.model
         B, _, H, W = inp.shape
         inp = inp.float().contiguous()
@@ -513,6 +525,7 @@ class SegEngine(nn.Module):
         one GEMM), the final norm's inputs of the last ``n_last_blocks`` outputs, CAViT / CACNN activations, the encoder's
         when it trains.  -> ((cat_hi, cat_lo|None), saved)."""
         config.split_attn_out = self.split_attn_out
+        config.precise_level = self.precise_level
         m = self.model
         B, _, H, W = inp.shape
         inp = inp.float().contiguous()
@@ -550,7 +563,7 @@ class SegEngine(nn.Module):
                 bsaves.append(sv)
                 feats.append(m._final_norm(xcat[:Ra].view(B, N + 1, D))[:, 1:])
                 fin.append(xcat)
-            dead = s == nl - 1 and taps is None            # see ``features``: the last CACNN output feeds nothing
+            dead = s == nl - 1 and taps is None and config.elide_dead_cacnn   # see ``features``: the last CACNN output feeds nothing
             x2, s_cv = self.cross_vit.forward16_train(xcat[Ra:].clone(), c2d, g, B, N, Lc)
             s_cn = None
             if not dead:
@@ -763,7 +776,8 @@ class SegEngine(nn.Module):
         return (m, loss1, counts) if with_counts else (m, loss1)
 
 
-def make_vit_bucket(model, blocks_per_bucket: int, process_group, momentum: bool = False, min_first_blocks: int = 0):
+def make_vit_bucket(model, blocks_per_bucket: int, process_group, momentum: bool = False, min_first_blocks: int = 0,
+                    compress: Optional[str] = None):
     """Flat gradient bucket of the whole backbone in gradient-ready order (final norm, blocks last..first, then the token
     embedding parameters) + a reducer over ``blocks_per_bucket``-block chunks (the last chunk takes the embeddings along).
     -> (bucket, reducer, fire_at) with fire_at = block indices after whose backward the next chunk is complete (-1 = after
@@ -785,7 +799,7 @@ def make_vit_bucket(model, blocks_per_bucket: int, process_group, momentum: bool
             names = [n for g in groups[start:j + 1] for n in g]
             ranges.append(bucket.range_of(names)); fire_at.append(depth - j); start = j + 1
     ranges.append(bucket.range_of([n for g in groups[start:] for n in g])); fire_at.append(-1)
-    return bucket, StageReducer(bucket.grad, ranges, process_group), fire_at
+    return bucket, StageReducer(bucket.grad, ranges, process_group, compress=compress), fire_at
 
 
 class EndToEndEngine(nn.Module):

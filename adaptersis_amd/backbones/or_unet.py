@@ -168,7 +168,7 @@ class UNet(P.UNet):
         gz, partial_ = ops.upsample_bn_relu_bwd(dr, z, sv["scale"], sv["shift"], sv["mean"], sv["invstd"], 1)
         red = ops.reduce_rows(partial_.view(partial_.shape[0], 2 * C))
         local = red
-        if self.sync_bn and parallel.collectives_on():
+        if self.sync_bn and parallel.bn_collectives_on():
             local = red.clone()
             dist.all_reduce(red)
         dz16, bpart = ops.bn_bwd_apply(gz, z, sv["mean"], sv["invstd"], self._f32(key + ".g", blk.bn.weight), red[C:], red[:C],
@@ -215,7 +215,7 @@ class UNet(P.UNet):
         gz, partial_ = ops.upsample_bn_relu_bwd(d0, raw0, scale, shift, mean, invstd, 1)
         red = ops.reduce_rows(partial_.view(partial_.shape[0], 2 * C0))
         local = red
-        if self.sync_bn and parallel.collectives_on():
+        if self.sync_bn and parallel.bn_collectives_on():
             local = red.clone()
             dist.all_reduce(red)
         dx16, _ = ops.bn_bwd_apply(gz, raw0, mean, invstd, self._f32("inc1.g", seq[1].weight), red[C0:], red[:C0], count, dt)

@@ -94,5 +94,16 @@ split_attn_out = bool(split_attn_out_policy)     # what the blocks read; SegEngi
 # full-depth stress golden of config 5 (ViT-g/14, 2 x 40 block evaluations, MLA head amplifying 3.2x) stands at 1.30e-3 on the
 # default policy because every remaining error term is an operand of a big GEMM (tests/precision_probe.py: LayerNorm outputs
 # 7.5e-4, SwiGLU hidden 5.2e-4, weights 8.8e-4 on the MLA output); tests/test_gpu_fulldepth.py runs that case on level 2 as well.
-precise_level = int(os.environ.get("ASIS_PRECISE_LEVEL", "0") or 0)
+# ASIS_PRECISE_LEVEL = "auto" (default): per engine — SegEngine runs level 2 where the measured head-room needs it (the MLA head
+# on a >= 40-block backbone, i.e. BASELINE config 5: its full-depth stress golden holds 1e-3 only there) and level 0 elsewhere;
+# a number forces that level for every engine.  Like split_attn_out, SegEngine sets ``precise_level`` at the top of every step.
+_pl = os.environ.get("ASIS_PRECISE_LEVEL", "auto").lower() or "auto"
+precise_level_policy = None if _pl == "auto" else int(_pl)
+precise_level = int(precise_level_policy or 0)
 trunk_streams = int(os.environ.get("ASIS_TRUNK_STREAMS", "2") or 2)     # 4: each ViT pass as two image groups (lab)
+
+# The LAST adapter stage's CACNN (`train.py:372-386`) writes a pyramid-token tensor that nothing reads: the decoder input takes
+# c4 from the ENCODER output (`train.py:395`), so its result cannot reach the logits, the loss or any gradient.  The engine
+# skips that one call (identical results, ~0.8 % of the step's FLOPs); ASIS_ELIDE_DEAD_CACNN=0 runs it anyway (bench.py reports
+# the setting as config.dead_cacnn_elided; A/B in DESIGN.md §6).
+elide_dead_cacnn = os.environ.get("ASIS_ELIDE_DEAD_CACNN", "1") not in ("0", "")

@@ -481,6 +481,48 @@ extern "C" int asis_sgd_momentum_guarded(void* stream, float* p, const float* g,
   return ASIS_OK;
 }
 
+// 16-bit transport form of a gradient range for the all-reduce (parallel.StageReducer(compress=...)): fp32 -> bf16 (RNE; bf16
+// keeps fp32's exponent range, so the unscaled ~1e-7 Dice gradients survive) and back.  n % 4 == 0 (bucket ranges are 16-byte
+// aligned), 16 bytes in / 8 bytes out per lane.
+__global__ void grad_pack_bf16_kernel(const float4* __restrict__ g, uint2* __restrict__ out, int64_t n4) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 v = g[i];
+    uint2 w;
+    w.x = pack2<bf16>(v.x, v.y);
+    w.y = pack2<bf16>(v.z, v.w);
+    out[i] = w;
+  }
+}
+__global__ void grad_unpack_bf16_kernel(const uint2* __restrict__ in, float4* __restrict__ g, int64_t n4) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint2 w = in[i];
+    float4 v;
+    unpack2<bf16>(w.x, v.x, v.y);
+    unpack2<bf16>(w.y, v.z, v.w);
+    g[i] = v;
+  }
+}
+
+extern "C" int asis_grad_pack_bf16(void* stream, const float* g, int64_t n, void* out) {
+  ASIS_REQUIRE(g && out && n >= 0 && n % 4 == 0, "asis_grad_pack_bf16: null pointer or n=%ld not a multiple of 4", (long)n);
+  ASIS_REQUIRE(asis_aligned16(g) && (reinterpret_cast<uintptr_t>(out) & 7) == 0, "asis_grad_pack_bf16: misaligned buffers");
+  if (n == 0) return ASIS_OK;
+  hipLaunchKernelGGL(grad_pack_bf16_kernel, dim3(grid_for(n / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     reinterpret_cast<const float4*>(g), reinterpret_cast<uint2*>(out), n / 4);
+  ASIS_CHECK_LAUNCH("asis_grad_pack_bf16");
+  return ASIS_OK;
+}
+
+extern "C" int asis_grad_unpack_bf16(void* stream, const void* in, int64_t n, float* g) {
+  ASIS_REQUIRE(g && in && n >= 0 && n % 4 == 0, "asis_grad_unpack_bf16: null pointer or n=%ld not a multiple of 4", (long)n);
+  ASIS_REQUIRE(asis_aligned16(g) && (reinterpret_cast<uintptr_t>(in) & 7) == 0, "asis_grad_unpack_bf16: misaligned buffers");
+  if (n == 0) return ASIS_OK;
+  hipLaunchKernelGGL(grad_unpack_bf16_kernel, dim3(grid_for(n / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     reinterpret_cast<const uint2*>(in), reinterpret_cast<float4*>(g), n / 4);
+  ASIS_CHECK_LAUNCH("asis_grad_unpack_bf16");
+  return ASIS_OK;
+}
+
 extern "C" int asis_scale_f32(void* stream, float* x, int64_t n, float a) {
   ASIS_REQUIRE(x && n >= 0, "asis_scale_f32: bad arguments");
   if (n == 0) return ASIS_OK;

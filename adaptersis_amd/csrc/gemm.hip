@@ -209,6 +209,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const asis_gemm_desc 
 #include "gemm_big.h"
 #include "gemm_persist.h"
 #include "gemm_p8.h"
+#include "gemm_p8g.h"
 
 // ASIS_GEMM_P8 / asis_gemm_set_option("p8", v): -1 = not read yet
 static int g_gemm_p8 = -1;
@@ -403,6 +404,59 @@ extern "C" int asis_gemm_set_option(const char* name, int value) {
   if (strcmp(name, "p8") == 0) { g_gemm_p8 = value; return ASIS_OK; }
   if (strcmp(name, "noepi") == 0) { g_gemm_noepi = value; return ASIS_OK; }
   ASIS_FAIL(ASIS_EINVAL, "asis_gemm_set_option: unknown option '%s'", name);
+}
+
+// ---- grouped persistent launch (gemm_p8g.h) ------------------------------------------------------------------------------
+template <typename T>
+static void launch_group(hipStream_t s, const p8g_args& g, int nwg, int group_m) {
+  hipLaunchKernelGGL((gemm_p8g_kernel<T>), dim3(nwg), dim3(512), 0, s, g, group_m);
+}
+
+extern "C" int asis_gemm_group(void* stream, const asis_gemm_desc* descs, int n) {
+  ASIS_REQUIRE(descs != nullptr && n >= 1 && n <= ASIS_GEMM_GROUP_MAX, "asis_gemm_group: 1..%d problems (got %d)", ASIS_GEMM_GROUP_MAX, n);
+  static const int group_m = [] { const char* e = getenv("ASIS_GEMM_GROUPM"); return e && atoi(e) > 0 ? atoi(e) : 4; }();
+  auto al = [](const void* p, int a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; };
+  p8g_args g;
+  memset(&g, 0, sizeof(g));
+  g.nprob = n;
+  int tile0 = 0;
+  for (int i = 0; i < n; ++i) {
+    const asis_gemm_desc& d = descs[i];
+    ASIS_REQUIRE(d.A && d.B && d.C, "asis_gemm_group: problem %d: null operand pointer", i);
+    ASIS_REQUIRE(d.dtype == descs[0].dtype && (d.dtype == ASIS_F16 || d.dtype == ASIS_BF16), "asis_gemm_group: one 16-bit dtype per group");
+    const int batch = d.batch > 0 ? d.batch : 1;
+    const int kparts = 1 + (d.A_lo ? 1 : 0) + (d.B_lo ? 1 : 0);
+    // the contract of the persistent 8-phase kernel (gemm_p8.h), per problem; per-row bias and batches are allowed here
+    const bool ok = !d.conv && !d.stats && d.ksplit <= 1 && d.K % 64 == 0 && d.K >= 128 && d.M >= 256 && d.N >= 256 && d.N % 8 == 0 &&
+                    d.ldc % 8 == 0 && d.lda % 8 == 0 && d.ldb % 8 == 0 && d.lda >= d.K && d.ldb >= d.K && d.ldc >= d.N &&
+                    (int64_t)d.M * d.lda * 2 < (1ll << 32) && (int64_t)d.N * d.ldb * 2 < (1ll << 32) && al(d.A, 16) && al(d.B, 16) &&
+                    al(d.C, 16) && (!d.A_lo || al(d.A_lo, 16)) && (!d.B_lo || al(d.B_lo, 16)) &&
+                    (!d.res || (al(d.res, 16) && d.ldr % 4 == 0 && d.ldr >= d.N)) && (!d.bias_n || al(d.bias_n, 16)) &&
+                    (!d.scale_n || al(d.scale_n, 16)) && d.strideA % 8 == 0 && d.strideB % 8 == 0 && d.strideC % 8 == 0 &&
+                    d.strideR % 4 == 0 && ((d.act >= 0 && d.act <= ASIS_ACT_RELU) || (d.act == ASIS_ACT_GELU_GRAD && d.aux && al(d.aux, 8) && d.ld_aux % 4 == 0));
+    ASIS_REQUIRE(ok, "asis_gemm_group: problem %d (M %d N %d K %d) is off the persistent 8-phase kernel's contract (dense, K %% 64 == 0, "
+                     "K >= 128, M, N >= 256, N and leading dimensions multiples of 8, 16-byte aligned pointers)", i, d.M, d.N, d.K);
+    p8g_prob& q = g.p[i];
+    q.A = reinterpret_cast<const char*>(d.A); q.B = reinterpret_cast<const char*>(d.B); q.C = reinterpret_cast<char*>(d.C);
+    q.A_lo = reinterpret_cast<const char*>(d.A_lo); q.B_lo = reinterpret_cast<const char*>(d.B_lo);
+    q.bias_n = d.bias_n; q.bias_m = d.bias_m; q.scale_n = d.scale_n; q.res = d.res; q.aux = reinterpret_cast<const char*>(d.aux);
+    q.strideA = d.strideA * 2; q.strideB = d.strideB * 2; q.strideC = d.strideC * (d.out_f32 ? 4 : 2); q.strideR = d.strideR;
+    q.lda_b = (uint32_t)d.lda * 2u; q.ldb_b = (uint32_t)d.ldb * 2u;
+    q.ldc = (int32_t)d.ldc; q.ldr = (int32_t)d.ldr; q.ld_aux = (int32_t)d.ld_aux;
+    q.M = d.M; q.N = d.N; q.K = d.K; q.nparts = kparts; q.act = d.act; q.out_f32 = d.out_f32;
+    q.tiles_m = (d.M + 255) / 256; q.tiles_n = (d.N + 255) / 256; q.per_batch = q.tiles_m * q.tiles_n;
+    q.tile0 = tile0;
+    ASIS_REQUIRE((int64_t)tile0 + (int64_t)q.per_batch * batch < (1ll << 30), "asis_gemm_group: too many tiles");
+    tile0 += q.per_batch * batch;
+  }
+  g.ntiles = tile0;
+  ASIS_REQUIRE(tile0 >= 16, "asis_gemm_group: %d tiles: too few for the persistent kernel", tile0);
+  const int nwg = tile0 >= 256 ? 256 : (tile0 / 8) * 8;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (descs[0].dtype == ASIS_F16) launch_group<f16>(s, g, nwg, group_m);
+  else launch_group<bf16>(s, g, nwg, group_m);
+  ASIS_CHECK_LAUNCH("asis_gemm_group");
+  return ASIS_OK;
 }
 
 extern "C" int asis_gemm(void* stream, const asis_gemm_desc* dp) {

@@ -242,6 +242,42 @@ class Attention(_Packed):
         one_launch = len(segs) == 2
         ldv_all = (max(n for _, n in segs) + 63) // 64 * 64
         vt_all = torch.empty((sum(b for b, _ in segs), D, ldv_all), device=xn.device, dtype=xn.dtype) if one_launch else None
+        spare = xn.untyped_storage().nbytes() // xn.element_size() - (xn.storage_offset() + xn.shape[0] * D)
+        if ops.GEMM_GROUP and xn.is_cuda and len(segs) <= 7:
+            # q|k and the per-image V^T projections as ONE grouped persistent launch (ops.gemm_group / csrc/gemm_p8g.h): the
+            # partial tile rounds of the three problems (5.19 + 2 x 1.31 rounds of 256 CUs at 12 images) become 7.81 rounds of one
+            # launch, in order on the compute stream.  N is rounded up to 8 (the kernel's 16-byte stores): the extra columns
+            # land in V^T's pad region, which the attention kernel zeroes in registers, and their operand rows are the first
+            # tokens of the next image (the last image reads the spare rows behind ``xn``).
+            probs = [(xn, w[: 2 * D], dict(bias_n=None if bias is None else bias[: 2 * D], b_lo=None if wlo is None else wlo[: 2 * D]))]
+            vts = []
+            r0 = b0 = 0
+            for B, N in segs:
+                r1 = r0 + B * N
+                ldvt = ldv_all if one_launch else (N + 63) // 64 * 64
+                vt = vt_all[b0:b0 + B] if one_launch else torch.empty((B, D, ldvt), device=xn.device, dtype=xn.dtype)
+                N8 = (N + 7) // 8 * 8
+                if spare < (N8 - N) * D:
+                    N8 = (N + 3) // 4 * 4 if spare >= 4 * D else N
+                probs.append((w[2 * D:], xn[r0:r1].as_strided((B, N8, D), (N * D, D, 1)),
+                              dict(out=vt.as_strided((B, D, N8), (D * ldvt, ldvt, 1)), bias_m=None if bias is None else bias[2 * D:],
+                                   a_lo=None if wlo is None else wlo[2 * D:])))
+                vts.append(vt)
+                r0, b0 = r1, b0 + B
+            if r0 != xn.shape[0]:
+                raise ValueError("attend_rows: segments do not cover the rows")
+            qk = ops.gemm_group(probs)[0]
+            if one_launch:
+                (B1, N1), (B2, N2) = segs
+                ops.attention_fwd_seg(qk[:, :D], qk[:, D:], vt_all, B1, N1, B2, N2, self.num_heads, scale, out=o, out_lo=o_lo)
+            else:
+                r0 = 0
+                for (B, N), vt in zip(segs, vts):
+                    r1 = r0 + B * N
+                    ops.attention_fwd(qk[r0:r1, :D], qk[r0:r1, D:], vt, B, self.num_heads, N, scale, out=o[r0:r1],
+                                      out_lo=None if o_lo is None else o_lo[r0:r1])
+                    r0 = r1
+            return o, o_lo
         # stacked form: the V^T GEMMs go to a side stream, the q|k GEMM stays on the compute stream (config.vt_stream)
         side = None
         if one_launch and config.vt_stream and xn.is_cuda:
@@ -258,7 +294,6 @@ class Attention(_Packed):
             # N rounded up to 4 keeps the vector epilogue (N = 1765 fell to the scalar one: 101 vs 69 us); the extra
             # columns land in V^T's pad region, which the attention kernel zeroes in registers, and their operand rows
             # are the first tokens of the next image (the last image reads the spare rows behind ``xn``)
-            spare = xn.untyped_storage().nbytes() // xn.element_size() - (xn.storage_offset() + xn.shape[0] * D)
             N4 = (N + 3) // 4 * 4 if spare >= 4 * D else N
             with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
                 ops.gemm(w[2 * D:], xn[r0:r1].as_strided((B, N4, D), (N * D, D, 1)),
@@ -399,7 +434,7 @@ class Block(_Packed):
         dt = config.operand_dtype
         g1 = self._f32("g1", self.ls1.gamma) if isinstance(self.ls1, LayerScale) else None
         g2 = self._f32("g2", self.ls2.gamma) if isinstance(self.ls2, LayerScale) else None
-        xn = torch.empty((x2.shape[0] + 4, D), device=x2.device, dtype=dt)[: x2.shape[0]]   # 4 spare rows: see attend_rows
+        xn = torch.empty((x2.shape[0] + 8, D), device=x2.device, dtype=dt)[: x2.shape[0]]   # 8 spare rows: see attend_rows
         ops.layernorm(x2, self._f32("n1w", self.norm1.weight), self._f32("n1b", self.norm1.bias), self.norm1.eps, dt, out=xn)
         o, o_lo = self.attn.attend_rows(xn, segs)
         x1 = ops.gemm(o, self.attn._w16("proj", self.attn.proj.weight), out_f32=True,

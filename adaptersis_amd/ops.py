@@ -66,16 +66,12 @@ def _f32c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
     return t
 
 
-def gemm(a: torch.Tensor, b: torch.Tensor, *, out: Optional[torch.Tensor] = None, out_f32: bool = False,
-         bias_n: Optional[torch.Tensor] = None, bias_m: Optional[torch.Tensor] = None,
-         scale_n: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None, act: int = ACT_NONE,
-         stats: Optional[torch.Tensor] = None, a_lo: Optional[torch.Tensor] = None,
-         b_lo: Optional[torch.Tensor] = None, aux: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """``out = epilogue(a @ b.T)``; a [M,K] or [batch,M,K], b [N,K] or [batch,N,K] (16-bit, K contiguous).
-    ``act=ACT_GELU_GRAD`` with ``aux`` (16-bit [M, N] pre-activation): out = (a @ b.T) * gelu'(aux).
-
-    A 2-D operand next to a 3-D one is shared by every batch element.  Row strides may exceed K.
-    """
+def _gemm_desc(a: torch.Tensor, b: torch.Tensor, *, out: Optional[torch.Tensor] = None, out_f32: bool = False,
+               bias_n: Optional[torch.Tensor] = None, bias_m: Optional[torch.Tensor] = None,
+               scale_n: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None, act: int = ACT_NONE,
+               stats: Optional[torch.Tensor] = None, a_lo: Optional[torch.Tensor] = None,
+               b_lo: Optional[torch.Tensor] = None, aux: Optional[torch.Tensor] = None):
+    """-> (filled GemmDesc, out tensor, algorithmic flops, algorithmic bytes) of one ``gemm`` call (see ``gemm``)"""
     _dev(a, b, out, bias_n, bias_m, scale_n, res, stats)
     if a.dtype != b.dtype:
         raise ValueError("gemm operands must have the same 16-bit dtype")
@@ -126,8 +122,43 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, out: Optional[torch.Tensor] = None
             raise ValueError("gemm: split halves must share the layout of their hi parts")
         d.B_lo = b_lo.data_ptr()
     nbytes = batch * (2.0 * (M * K + N * K) + M * N * ((4 if out_f32 else 2) + (4 if res is not None else 0)))
+    return d, out, flops, nbytes
+
+
+def gemm(a: torch.Tensor, b: torch.Tensor, **kw) -> torch.Tensor:
+    """``out = epilogue(a @ b.T)``; a [M,K] or [batch,M,K], b [N,K] or [batch,N,K] (16-bit, K contiguous).
+    Keywords: out, out_f32, bias_n, bias_m, scale_n, res, act, stats, a_lo, b_lo, aux (see ``_gemm_desc``).
+    ``act=ACT_GELU_GRAD`` with ``aux`` (16-bit [M, N] pre-activation): out = (a @ b.T) * gelu'(aux).
+
+    A 2-D operand next to a 3-D one is shared by every batch element.  Row strides may exceed K.
+    """
+    d, out, flops, nbytes = _gemm_desc(a, b, **kw)
     check(_launch_timed("gemm", flops, lambda: lib().asis_gemm(_stream(), C.byref(d)), nbytes), "asis_gemm")
     return out
+
+
+GEMM_GROUP = os.environ.get("ASIS_GEMM_GROUP", "1") not in ("0", "")
+
+
+def gemm_group(problems):
+    """Independent GEMMs in ONE persistent launch (include/asis_hip.h: asis_gemm_group; csrc/gemm_p8g.h).
+    ``problems`` = [(a, b, kwargs of ``gemm``), ...] -> [out tensors].  Problems the grouped kernel cannot take (its
+    contract is the persistent 8-phase kernel's) are launched one by one instead — same results either way."""
+    built = [_gemm_desc(a, b, **kw) for a, b, kw in problems]
+    outs = [o for _, o, _, _ in built]
+    if GEMM_GROUP and 1 < len(built) <= 8:
+        arr = (GemmDesc * len(built))(*[d for d, _, _, _ in built])
+        flops, nbytes = sum(f for _, _, f, _ in built), sum(nb for _, _, _, nb in built)
+        rc = _launch_timed("gemm", flops, lambda: lib().asis_gemm_group(_stream(), arr, len(built)), nbytes)
+        if rc == 0:
+            return outs
+        if rc != _lib.ASIS_EINVAL:
+            check(rc, "asis_gemm_group")
+        if PROFILE is not None:
+            PROFILE.pop()        # the refused launch timed nothing
+    for d, _, flops, nbytes in built:
+        check(_launch_timed("gemm", flops, lambda d=d: lib().asis_gemm(_stream(), C.byref(d)), nbytes), "asis_gemm")
+    return outs
 
 
 def gemm_tiles_m(M: int) -> int:
@@ -1116,6 +1147,21 @@ def grad_guard(g: torch.Tensor, guard: torch.Tensor, reset: bool) -> None:
     if guard.dtype != torch.int32 or guard.numel() < 2:
         raise ValueError("guard must be an int32 tensor of 2 elements")
     check(lib().asis_grad_guard(_stream(), _f32c(g).data_ptr(), g.numel(), guard.data_ptr(), int(reset)), "asis_grad_guard")
+
+
+def grad_pack_bf16(g: torch.Tensor, out: torch.Tensor) -> None:
+    """fp32 gradient range -> its bf16 transport form (parallel.StageReducer(compress="bf16"))"""
+    _dev(g, out)
+    if out.dtype != torch.bfloat16 or out.numel() != g.numel() or not out.is_contiguous():
+        raise ValueError("grad_pack_bf16: out must be a contiguous bfloat16 tensor of the same length")
+    check(lib().asis_grad_pack_bf16(_stream(), _f32c(g).data_ptr(), g.numel(), out.data_ptr()), "asis_grad_pack_bf16")
+
+
+def grad_unpack_bf16(src: torch.Tensor, g: torch.Tensor) -> None:
+    _dev(g, src)
+    if src.dtype != torch.bfloat16 or src.numel() != g.numel() or not src.is_contiguous():
+        raise ValueError("grad_unpack_bf16: src must be a contiguous bfloat16 tensor of the same length")
+    check(lib().asis_grad_unpack_bf16(_stream(), src.data_ptr(), g.numel(), _f32c(g).data_ptr()), "asis_grad_unpack_bf16")
 
 
 def sgd_momentum(p: torch.Tensor, g: torch.Tensor, buf: torch.Tensor, lr: float, momentum: float, weight_decay: float,

@@ -34,6 +34,32 @@ def collectives_on(group=None) -> bool:
     return dist.get_world_size(group) > 1 or FORCE_COLLECTIVES
 
 
+# SyncBatchNorm layers ask ``bn_collectives_on`` (not ``collectives_on``): inside ``local_batchnorm()`` they take LOCAL batch
+# statistics although a process group is up.  The sharded validation of ``train.validate_network`` (--shard_val) needs it: the
+# reference lets every rank evaluate the whole val set (`train.py:125-130,236-238`), so its encoder SyncBatchNorm sees world
+# copies of ONE batch — the same statistics as that batch alone; when the ranks evaluate DIFFERENT batches, local statistics
+# keep every batch's result identical to the reference's (and ranks with fewer batches issue no unmatched collective).
+_LOCAL_BN = 0
+
+
+class local_batchnorm:
+    """context manager: train-mode (Sync)BatchNorm layers use this rank's statistics only"""
+
+    def __enter__(self):
+        global _LOCAL_BN
+        _LOCAL_BN += 1
+        return self
+
+    def __exit__(self, *exc):
+        global _LOCAL_BN
+        _LOCAL_BN -= 1
+        return False
+
+
+def bn_collectives_on(group=None) -> bool:
+    return _LOCAL_BN == 0 and collectives_on(group)
+
+
 # SyncBatchNorm element counts (`nn.SyncBatchNorm` gathers every rank's count: `backbones/encoders.py:12-40`).  With the
 # reference's loader (`DistributedSampler`, `train.py:167-175`) every rank holds the same number of images in every iteration —
 # also in the short last batch of an epoch — so a layer's global count is its local count x world, known on the host without an
@@ -101,15 +127,31 @@ def wgrad_on_side_stream(fn, *tensors) -> None:
 
 
 class StageReducer:
-    def __init__(self, flat_grad: torch.Tensor, ranges: Sequence[Tuple[int, int]], group=None):
-        self.flat, self.ranges, self.group = flat_grad, list(ranges), group
+    """``compress="bf16"``: a range travels as bfloat16 (half the bytes: the 1.2 GB fp32 backbone bucket of BASELINE config 4 is
+    ~15 ms on an xGMI ring) — packed into a staging buffer right before its all-reduce, summed by the
+    collective in bf16, unpacked into the fp32 bucket behind it, all on the reducer's side stream.  bf16 keeps fp32's exponent
+    range (the unscaled ~1e-7 Dice gradients survive) at 8 significant bits: a relative error <= 2^-9 per rank term, i.e. the
+    torch-side `bf16_compress_hook`.  Off by default (the reference's DDP exchanges fp32, `train.py:84-116`);
+    ``ASIS_GRAD_COMPRESS=bf16`` / ``SegEngine(grad_compress="bf16")`` turn it on for the backbone bucket only."""
+
+    def __init__(self, flat_grad: torch.Tensor, ranges: Sequence[Tuple[int, int]], group=None, compress: Optional[str] = None):
+        if compress not in (None, "bf16"):
+            raise ValueError("StageReducer: compress must be None or 'bf16'")
+        self.flat, self.ranges, self.group, self.compress = flat_grad, list(ranges), group, compress
         self._next = 0
         self._handles: List = []
         self._stream: Optional[torch.cuda.Stream] = None
+        self._staging: Optional[torch.Tensor] = None      # bf16 transport buffer, as long as the longest range
 
     def begin(self):
         self._next = 0
         self._handles = []
+
+    def _stage_buf(self, n: int) -> torch.Tensor:
+        if self._staging is None:
+            longest = max(hi - lo for lo, hi in self.ranges)
+            self._staging = torch.empty(longest, device=self.flat.device, dtype=torch.bfloat16)
+        return self._staging[:n]
 
     def stage_done(self):
         """Call after the kernels writing the next range have been enqueued on the current stream."""
@@ -126,7 +168,20 @@ class StageReducer:
             self._stream.wait_event(ev)
             join_grad_streams(self._stream)      # weight gradients of this stage enqueued on the side stream
             with torch.cuda.stream(self._stream):
-                dist.all_reduce(chunk, group=self.group)
+                if self.compress:
+                    from . import ops
+                    # one staging buffer per reducer: ranges are reduced one after the other on this one stream
+                    buf = self._stage_buf(hi - lo)
+                    ops.grad_pack_bf16(chunk, buf)
+                    dist.all_reduce(buf, group=self.group)
+                    ops.grad_unpack_bf16(buf, chunk)
+                else:
+                    dist.all_reduce(chunk, group=self.group)
+        elif self.compress:  # CPU tensors (gloo rehearsal of the same protocol): blocking, ranges share the staging buffer
+            buf = self._stage_buf(hi - lo)
+            buf.copy_(chunk)
+            dist.all_reduce(buf, group=self.group)
+            chunk.copy_(buf)
         else:  # CPU tensors (gloo): asynchronous work handles
             self._handles.append(dist.all_reduce(chunk, group=self.group, async_op=True))
 

@@ -14,6 +14,7 @@ path does not exist) trains on the synthetic set of SURVEY.md §8d; `--data_path
 from __future__ import annotations
 
 import argparse
+import contextlib
 import json
 import math
 import os
@@ -25,7 +26,7 @@ from torch import nn
 from .backbones.adapter_blocks import CACNN, CAViT
 from .backbones.decoders import DecoderMLA, FeatureDecoder
 from .backbones.encoders import FeatureEncoder
-from . import config
+from . import config, parallel
 from .backbones.engines import SegEngine
 from .dinov2.models import vision_transformer as vits
 from .utils import misc as utils
@@ -84,6 +85,22 @@ def _open_datasets(args):
         return (Robomis(p, "training", transform=None, imsize=args.imsize), Robomis(p, "validation", transform=None, imsize=args.imsize),
                 collate_u8)
     return _SegData(p, "train", args.imsize), _SegData(p, "validation", args.imsize), None
+
+
+class BatchShardSampler(torch.utils.data.Sampler):
+    """``batch_sampler`` of the sharded validation (``--shard_val``): the val set in its natural order cut into batches of
+    ``batch_size`` exactly as the reference's sequential loader cuts it (`train.py:125-130`), rank r takes batches
+    r, r + world, ...  No padding, no duplicates: ranks may hold different batch counts (validation issues no collective per
+    batch — `parallel.local_batchnorm`); every batch has the composition, hence the BatchNorm statistics, of the reference's."""
+
+    def __init__(self, n: int, batch_size: int, rank: int, world: int):
+        self.batches = [list(range(i, min(i + batch_size, n))) for i in range(0, n, batch_size)][rank::world]
+
+    def __iter__(self):
+        return iter(self.batches)
+
+    def __len__(self):
+        return len(self.batches)
 
 
 def broadcast_module_states(modules, src: int = 0, group=None) -> None:
@@ -154,8 +171,14 @@ def train_seg(args, head: str = "feature"):
 
     dataset_train, dataset_val, collate = _open_datasets(args)
     workers = args.num_workers if collate is not None else 0      # PNG decode runs in loader workers; tensors in memory do not need any
-    val_loader = torch.utils.data.DataLoader(dataset_val, batch_size=args.batch_size_per_gpu, num_workers=workers, pin_memory=True,
-                                             collate_fn=collate)
+    if getattr(args, "shard_val", False) and utils.get_world_size() > 1:
+        # the reference lets all ranks evaluate the whole val set; here every rank takes every world-th batch
+        val_loader = torch.utils.data.DataLoader(dataset_val, num_workers=workers, pin_memory=True, collate_fn=collate,
+                                                 batch_sampler=BatchShardSampler(len(dataset_val), args.batch_size_per_gpu,
+                                                                                 utils.get_rank(), utils.get_world_size()))
+    else:
+        val_loader = torch.utils.data.DataLoader(dataset_val, batch_size=args.batch_size_per_gpu, num_workers=workers, pin_memory=True,
+                                                 collate_fn=collate)
     sampler = torch.utils.data.distributed.DistributedSampler(dataset_train, num_replicas=utils.get_world_size(),
                                                                rank=utils.get_rank())
     train_loader = torch.utils.data.DataLoader(dataset_train, sampler=sampler, batch_size=args.batch_size_per_gpu,
@@ -234,11 +257,19 @@ def train(model, feature_model, backbone_encoder, cross_vit, cross_cnn, seg_deco
         raise ValueError("train(): pass the engine's optimizer (adaptersis_amd.optim.SGD over the flat bucket)")
     metric_logger = utils.MetricLogger(delimiter="  ")
     metric_logger.add_meter("lr", utils.SmoothedValue(window_size=1, fmt="{value:.6f}"))
+    # SyncBatchNorm element counts: with the reference's DistributedSampler every rank holds the same number of images in every
+    # iteration (also in the short last batch); any other loader may not, so the ranks' batch sizes are exchanged per step
+    ragged = parallel.collectives_on() and not isinstance(getattr(loader, "sampler", None),
+                                                          torch.utils.data.distributed.DistributedSampler)
     for (inp, target, idx) in metric_logger.log_every(loader, 20, "Epoch: [{}]".format(epoch)):
+        if ragged:
+            parallel.set_batch_ratio(int(inp.shape[0]))
         loss = engine.train_step(*_to_device_batch(inp, target, train=True))
         torch.cuda.synchronize()  # the reference syncs and reads the loss every step (train.py:439-440)
         metric_logger.update(loss=loss.item())
         metric_logger.update(lr=optimizer.param_groups[0]["lr"])
+    if ragged:
+        parallel.set_batch_ratio(None)
     metric_logger.synchronize_between_processes()
     print("Averaged stats:", metric_logger)
     # overflow guard of the static 16-bit loss scale (optim.SGD): a step whose gradients hold an inf / NaN is skipped on the
@@ -262,14 +293,18 @@ def validate_network(val_loader, model, feature_model, backbone_encoder, cross_v
     engine = _engine_for(model, backbone_encoder, cross_vit, cross_cnn, seg_decoder)
     metric_logger = utils.MetricLogger(delimiter="  ")
     wt = torch.tensor([0.1, 10.0], device=next(seg_decoder.parameters()).device)
-    for (inp, target, idx) in metric_logger.log_every(val_loader, 20, "Test:"):
-        inp, target = _to_device_batch(inp, target, train=False)
-        m, dloss = engine.validate_step(inp, target, wt)
-        m = m.cpu()
-        bs = inp.shape[0]
-        metric_logger.update(loss=float(m[0] / m[1]))
-        metric_logger.meters["acc1"].update(float(m[2]) / target.numel(), n=bs)
-        metric_logger.meters["dice"].update(1.0 - float(dloss), n=bs)
+    sharded = isinstance(getattr(val_loader, "batch_sampler", None), BatchShardSampler)
+    with (parallel.local_batchnorm() if sharded else contextlib.nullcontext()):
+        for (inp, target, idx) in metric_logger.log_every(val_loader, 20, "Test:"):
+            inp, target = _to_device_batch(inp, target, train=False)
+            m, dloss = engine.validate_step(inp, target, wt)
+            m = m.cpu()
+            bs = inp.shape[0]
+            metric_logger.update(loss=float(m[0] / m[1]))
+            metric_logger.meters["acc1"].update(float(m[2]) / target.numel(), n=bs)
+            metric_logger.meters["dice"].update(1.0 - float(dloss), n=bs)
+    if sharded:   # per-rank sums -> the whole-set averages every rank of the reference computes redundantly
+        metric_logger.synchronize_between_processes()
     print("* Acc@1 {top1.global_avg:.3f} loss {losses.global_avg:.3f} Dice {dice.global_avg:.3f}".format(
         top1=metric_logger.acc1, losses=metric_logger.loss, dice=metric_logger.meters["dice"]))
     return {k: meter.global_avg for k, meter in metric_logger.meters.items()}
@@ -301,6 +336,9 @@ def get_args_parser():
     # its no_grad block keeps from training
     p.add_argument("--train_adapters", action="store_true")
     p.add_argument("--train_encoder", action="store_true", help="with --train_adapters: also the CNN encoder")
+    p.add_argument("--shard_val", action="store_true",
+                   help="validation sharded over the ranks (every world-th batch per rank, metric sums all-reduced) instead of the "
+                        "reference's whole val set on every rank (train.py:125-130,236-238); same batches, same per-batch results")
     return p
 
 

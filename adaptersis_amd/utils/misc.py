@@ -79,7 +79,7 @@ class SmoothedValue:
     def synchronize_between_processes(self):
         if not is_dist_avail_and_initialized():
             return
-        t = torch.tensor([self.count, self.total], dtype=torch.float64, device="cuda")
+        t = torch.tensor([self.count, self.total], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.barrier()
         dist.all_reduce(t)
         self.count, self.total = int(t[0].item()), t[1].item()

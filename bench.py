@@ -8,7 +8,9 @@
 One "step" = one `train.py:268-436` iteration on a batch of 12 synthetic 588x588 images per
 GPU, already resident in HBM: CNN encoder, ViT-L pass A (24 blocks, cls+pos) + pass B (21 blocks), 4 x [block,
 CAViT, CACNN], decoder forward, resize+softmax+Dice, decoder backward, gradient all-reduce (N > 1), SGD.
-Nothing is skipped or cached between steps.  Weights are random-init of the named architecture
+Nothing is cached between steps; ONE call of the reference step is elided: the last stage's CACNN (`train.py:372-386`), whose
+output no later line reads (the decoder takes c4 from the encoder, `train.py:395`) — ``--run-dead-cacnn`` runs it too; the JSON
+line reports ``config.dead_cacnn_elided``.  Weights are random-init of the named architecture
 (no network: `adaptersis_amd.utils.weights`), data is synthetic of the named shape.
 
 Output: ONE JSON line on rank 0 (see README / DESIGN.md for the fields).
@@ -277,6 +279,8 @@ def main():
     ap.add_argument("--single-stream", action="store_true",
                     help="profiling aid: every launch on the compute stream (encoder / V^T / weight-gradient / dual-trunk side streams "
                          "off), so that a rocprofv3 kernel trace of this command shows un-overlapped launch durations")
+    ap.add_argument("--run-dead-cacnn", action="store_true",
+                    help="also run the last stage's CACNN, whose output nothing reads (train.py:372-386; elided by default: identical results)")
     ap.add_argument("--cpu-baseline-batch", type=int, default=1, help="batch of the timed CPU (oracle) step: 1 or 2")
     a = ap.parse_args()
 
@@ -320,6 +324,8 @@ def main():
     from adaptersis_amd import config, ops
     if a.single_stream:
         config.encoder_stream = config.vt_stream = config.wgrad_stream = config.dual_stream = False
+    if a.run_dead_cacnn:
+        config.elide_dead_cacnn = False
     if a.operand:
         config.set_operand_dtype(torch.float16 if a.operand == "f16" else torch.bfloat16)
         config.loss_scale = 65536.0 if a.operand == "f16" else 1.0
@@ -428,8 +434,9 @@ def main():
                        "split_precision_convs": bool(config.split_conv), "loss": loss_v,
                        "side_streams": {"encoder": bool(config.encoder_stream), "vt": bool(config.vt_stream),
                                         "wgrad": bool(config.wgrad_stream), "dual_trunk": bool(config.dual_stream)},
-                       "split_attn_out": bool(getattr(eng, "split_attn_out", False)), "precise_level": int(config.precise_level),
+                       "split_attn_out": bool(getattr(eng, "split_attn_out", False)), "precise_level": int(getattr(eng, "precise_level", config.precise_level)),
                        "fold_attn_scale": bool(config.fold_attn_scale), "fused_qkv": bool(config.fused_qkv),
+                       "dead_cacnn_elided": bool(config.elide_dead_cacnn),
                        "skipped_optimizer_steps": int(eng.optimizer.skipped_steps)},
         }
         if roof:

@@ -108,6 +108,13 @@ typedef struct asis_gemm_desc {
                                         For layers whose tile count fills only part of the machine (EINVAL elsewhere). */
 } asis_gemm_desc;
 int asis_gemm(void* stream, const asis_gemm_desc* d);
+/* GROUPED launch: up to ASIS_GEMM_GROUP_MAX (8) independent dense problems (each optionally batched) in ONE persistent
+ * launch — e.g. the q|k projection and the batched V^T projections of one attention (attention.py:58: one qkv Linear, three
+ * consumers) — so that their partial tile rounds fill each other without a launch boundary or a side stream (csrc/gemm_p8g.h).
+ * Every problem must meet the persistent 8-phase kernel's contract (dense, K % 64 == 0, K >= 128, M, N >= 256, N and leading
+ * dimensions multiples of 8, 16-byte aligned pointers, no stats / ksplit; bias_m and batch > 1 are allowed; same dtype);
+ * otherwise ASIS_EINVAL and the caller launches the problems one by one.  Results are bit-identical to those launches. */
+int asis_gemm_group(void* stream, const asis_gemm_desc* descs, int n);
 /* number of M tiles asis_gemm uses for M rows (size of the stats buffer = tiles*2*N floats) */
 int asis_gemm_tiles_m(int M);
 /* run-time dispatch switches of asis_gemm (same meaning as the environment variable read at first use):
@@ -571,6 +578,11 @@ int asis_grad_guard(void* stream, const float* g, int64_t n, int32_t* guard, int
 int asis_sgd_momentum_guarded(void* stream, float* p, const float* g, float* buf, int64_t n, float lr, float momentum,
                               float weight_decay, float inv_scale, int first_step, int32_t* guard, int count_skip);
 int asis_scale_f32(void* stream, float* x, int64_t n, float a);
+/* 16-bit transport form of a gradient range for the data-parallel all-reduce (replaces nothing in the reference: DDP's
+ * bf16 compression hook `torch.distributed.algorithms.ddp_comm_hooks.default_hooks.bf16_compress_hook` is the torch-side
+ * counterpart; train.py:84-116 wraps its modules in plain fp32 DDP).  g fp32 [n] <-> out bf16 [n], n % 4 == 0, RNE. */
+int asis_grad_pack_bf16(void* stream, const float* g, int64_t n, void* out);
+int asis_grad_unpack_bf16(void* stream, const void* in, int64_t n, float* g);
 
 #ifdef __cplusplus
 }

@@ -625,9 +625,14 @@ def loss2_case(R, out):
     assert [O.ch_iou(z, z), O.ch_iou(z, o1), O.isi_iou(z, z), O.isi_iou(z, o1)] == out["loss2.ch_iou_empty"].tolist()
 
 
-def step_case(R, out, arch, mode, tag, batch=1):
-    """Whole `train.py:268-436` step re-executed with the imported reference modules."""
+def step_case(R, out, arch, mode, tag, batch=1, forward_only=False):
+    """Whole `train.py:268-436` step re-executed with the imported reference modules.
+    ``forward_only`` (the headline-batch fixture, B = 12): the same forward and loss under ``torch.no_grad()`` (no value
+    changes: the reference's graph only reaches the decoder, and no gradient is stored for this case), without the oracle
+    re-run (the oracle is pinned at B = 1 and 2) — memory and CPU time of the batch-12 case stay bounded."""
+    import contextlib
     import torch.nn.functional as F
+    grad_ctx = torch.no_grad() if forward_only else contextlib.nullcontext()
     D, depth, heads, _ = W.VIT_CONFIGS[arch]
     vsd = W.make_vit_state_dict(arch, layerscale=("kernel" if mode == "kernel" else "init"))
     esd = W.make_encoder_state_dict(D)
@@ -645,7 +650,8 @@ def step_case(R, out, arch, mode, tag, batch=1):
     H, Wd = 588, 588
     d1, d2 = R["deform_inputs"](inp, 14)
     H_c, W_c = 588 // 16, 588 // 16
-    c1, c2, c3, c4 = enc(inp)
+    with grad_ctx:
+        c1, c2, c3, c4 = enc(inp)
     c = torch.cat([c2, c3, c4], dim=1)
     with torch.no_grad():
         feats = model.get_intermediate_layers(inp, 4, return_class_token=True)
@@ -658,19 +664,29 @@ def step_case(R, out, arch, mode, tag, batch=1):
         if s:
             with torch.no_grad():
                 x = stages[s](x)
-        x = cv(query=x, reference_points=d1[0], feat=c, spatial_shapes=d1[1], level_start_index=d1[2])
-        c = cn(query=c, reference_points=d2[0], feat=x, spatial_shapes=d2[1], level_start_index=d2[2], H=H_c, W=W_c)
-        x = x + outs[s]
+        with grad_ctx:
+            x = cv(query=x, reference_points=d1[0], feat=c, spatial_shapes=d1[1], level_start_index=d1[2])
+            c = cn(query=c, reference_points=d2[0], feat=x, spatial_shapes=d2[1], level_start_index=d2[2], H=H_c, W=W_c)
+            x = x + outs[s]
     with torch.no_grad():
         a = x.transpose(1, 2).reshape(batch, D, 42, 42)
         v = outs[-1].transpose(1, 2).reshape(batch, D, 42, 42)
         cc = c4.transpose(1, 2).reshape(batch, D, 18, 18)
         cc = F.pad(cc, [12, 12, 12, 12])
         cat = torch.cat((a, cc, v), dim=1)
-    logits = dec(cat)
-    o = F.interpolate(logits, size=(H, Wd), mode="bilinear")
-    o = torch.softmax(o, 1)
-    loss = R["DC"](2)(o, O.one_hot(target, 2))
+    with grad_ctx:
+        logits = dec(cat)
+        o = F.interpolate(logits, size=(H, Wd), mode="bilinear")
+        o = torch.softmax(o, 1)
+        loss = R["DC"](2)(o, O.one_hot(target, 2))
+    if forward_only:
+        out[f"{tag}.cat"] = sub(cat)
+        out[f"{tag}.x_final"] = sub(x)
+        out[f"{tag}.c_final"] = sub(c)
+        out[f"{tag}.logits"] = sub(logits, 60000)
+        out[f"{tag}.loss"] = loss.detach().clone()
+        print(f"  {tag}: loss {float(loss):.6f}")
+        return
     loss.backward()
     # oracle
     with torch.no_grad():
@@ -1112,6 +1128,13 @@ def main():
         print("[step ViT-L 588 B=2 reference_exact (init mode)]"); step_case(R, out, "vit_large", "init", "step_b2_exact", batch=2)
         print("[step ViT-L 588 B=2 kernel-mode weights]"); step_case(R, out, "vit_large", "kernel", "step_b2_kernel", batch=2)
         save("step_b2", out)
+    # the HEADLINE batch (README.md:45-61: --batch_size_per_gpu 12): forward + loss of the reference modules at B = 12, explicit
+    # only (~25 CPU-minutes per mode, forward only, no oracle re-run)
+    if "step_b12" in only:
+        out = {}
+        for mode, tag in (("kernel", "step_b12_kernel"), ("init", "step_b12_exact")):
+            print(f"[step ViT-L 588 B=12 forward + loss, {mode} weights]"); step_case(R, out, "vit_large", mode, tag, batch=12, forward_only=True)
+            save("step_b12", out)
     if args.full or "step" in only:
         out = {}
         print("[step ViT-L 588 B=1 reference_exact (init mode)]"); step_case(R, out, "vit_large", "init", "step_exact")

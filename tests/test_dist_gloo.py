@@ -135,3 +135,76 @@ def test_broadcast_module_states_two_ranks_gloo():
         out = mgr.dict()
         mp.spawn(_worker_bcast, args=(world, _free_port(), out), nprocs=world, join=True)
         assert dict(out) == {0: True, 1: True}
+
+
+def _worker_compress(rank, world, port, out):
+    """bf16 transport of a gradient bucket (StageReducer(compress="bf16")): same protocol as the fp32 exchange,
+    result within bf16's rounding of the exact mean, tiny magnitudes (the unscaled Dice gradients) survive."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from adaptersis_amd.parallel import StageReducer
+    g = torch.Generator().manual_seed(7 + rank)
+    n = 4096
+    flat = (torch.randn(n, generator=g) * torch.logspace(-9, 0, n)) / world      # magnitudes 1e-9 .. 1, pre-divided by world
+    exact = flat.clone()
+    dist.all_reduce(exact)
+    ranges = [(0, 1024), (1024, 4096)]
+    red = StageReducer(flat, ranges, compress="bf16")
+    red.begin(); red.stage_done(); red.stage_done(); red.finish()
+    rel = ((flat - exact).abs() / (exact.abs() + 1e-30))
+    # each rank's term rounds to 8 significant bits (2^-9 relative to ITS magnitude) and the bf16 sum rounds once more; where the
+    # two terms nearly cancel the error relative to the small SUM is larger, so the bound is on the error relative to the terms
+    gathered = [torch.empty(n) for _ in range(world)]
+    mine = (torch.randn(n, generator=torch.Generator().manual_seed(7 + rank)) * torch.logspace(-9, 0, n)) / world
+    dist.all_gather(gathered, mine)
+    scale = sum(t.abs() for t in gathered)
+    ok = bool(((flat - exact).abs() <= scale * 2.0 ** -7).all()) and bool((flat != 0).sum() > n * 0.99)
+    same = [torch.empty(n) for _ in range(world)]
+    dist.all_gather(same, flat)
+    out[rank] = ok and all(torch.equal(same[0], t) for t in same)     # every rank holds the same reduced values
+    dist.destroy_process_group()
+
+
+def test_bf16_compressed_reducer_two_ranks_gloo():
+    world = 2
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_worker_compress, args=(world, _free_port(), out), nprocs=world, join=True)
+        assert dict(out) == {0: True, 1: True}
+
+
+def _worker_shard_val(rank, world, port, out):
+    """--shard_val: the ranks' batches partition the reference's sequential batches; inside
+    ``parallel.local_batchnorm()`` SyncBatchNorm layers issue no collective although a process group is up; the metric sums of the
+    shards all-reduce to the whole-set averages that every rank of the reference computes redundantly."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from adaptersis_amd import parallel
+    from adaptersis_amd.train import BatchShardSampler
+    from adaptersis_amd.utils.misc import MetricLogger
+    n, bs = 53, 12                                            # 5 batches (12, 12, 12, 12, 5): rank 0 gets 3, rank 1 gets 2
+    mine = list(BatchShardSampler(n, bs, rank, world))
+    ref = [list(range(i, min(i + bs, n))) for i in range(0, n, bs)]
+    ok = mine == ref[rank::world]
+    assert parallel.collectives_on() and parallel.bn_collectives_on()
+    with parallel.local_batchnorm():
+        ok = ok and parallel.collectives_on() and not parallel.bn_collectives_on()
+    ok = ok and parallel.bn_collectives_on()
+    per_image = torch.arange(n, dtype=torch.float64) * 0.5 + 1.0           # a per-image metric
+    ml = MetricLogger()
+    for b in mine:                                            # different batch counts per rank: no collective in the loop
+        ml.meters["acc1"].update(float(per_image[b].mean()), n=len(b))
+    ml.synchronize_between_processes()
+    ok = ok and abs(ml.meters["acc1"].global_avg - float(per_image.mean())) < 1e-12 and ml.meters["acc1"].count == n
+    out[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def test_sharded_validation_two_ranks_gloo():
+    world = 2
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_worker_shard_val, args=(world, _free_port(), out), nprocs=world, join=True)
+        assert dict(out) == {0: True, 1: True}

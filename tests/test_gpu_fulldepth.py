@@ -84,11 +84,12 @@ def test_config5_vitg_40_blocks_mla11(dev, mode):
     e_out = golden_err(out, g[f"{tag}.output"])
     print(f"{tag}: output (11 classes, 588^2) rel-L2 {e_out:.2e} loss {float(loss):.6f} golden {float(g[tag + '.loss']):.6f}")
     # Stress weights through 2 x 40 block evaluations: the head amplifies the 5.5e-4 stream error 3.2x.  tests/precision_probe.py
-    # (vit_giant2 588 --mla) splits the 1.80e-3 of single 16-bit operands into: attention output 1.22e-3 (removed by
-    # config.split_attn_out, on for this head), LayerNorm outputs 7.5e-4, SwiGLU hidden 5.2e-4, the four weights 8.8e-4 —
-    # every remaining term is an operand of the big GEMMs, i.e. costs a second MFMA pass.  Default policy: 1.30e-3 here
-    # (reference-init weights: 6e-6); DESIGN.md §3.
-    assert e_out < (TOL if mode == "init" else 1.5e-3)
+    # (vit_giant2 588 --mla) splits the 1.80e-3 of single 16-bit operands into: attention output 1.22e-3, LayerNorm outputs
+    # 7.5e-4, SwiGLU hidden 5.2e-4, the four weights 8.8e-4 — every term is an operand of a big GEMM.  The engine's DEFAULT
+    # policy for this geometry (MLA head, >= 40 blocks) is therefore precise_level 2 (hi + lo operands on every linear layer):
+    # north_star's 1e-3 holds on the default policy, and `bench.py --config 5` reports its figure on that policy.
+    assert eng.precise_level == 2 and eng.split_attn_out
+    assert e_out < TOL
     assert abs(float(loss) - float(g[f"{tag}.loss"])) < 1e-4
     n, gmax, gmed, worst = _grad_stats(eng.bucket.views, g, f"{tag}.grad.")
     print(f"{tag} MLA grads: n={n} max {gmax:.2e} median {gmed:.2e} worst {worst}")
@@ -128,12 +129,13 @@ def test_config4_vitl_24_blocks_unfrozen(dev, mode):
         assert gmax < 2.5e-1 and gmed < 5e-2, (nm, worst)
 
 
-def test_config5_stress_holds_1e3_on_precise_level_2(dev):
-    """The same ViT-g/14 40-block stress case with ``config.precise_level = 2`` (every linear layer of the ViT blocks on hi + lo
-    operands, ~2.5x the GEMM passes): the documented way to north_star's 1e-3 where single 16-bit operands stop at 1.30e-3."""
+def test_config5_stress_on_single_16bit_operands_is_the_documented_1p3e3(dev):
+    """The same ViT-g/14 40-block stress case FORCED onto level 0 (single 16-bit operands + split attention output, what every
+    other geometry runs): the record of why the default policy of this geometry is level 2 — 1.30e-3 measured, bound 1.5e-3;
+    the MLA inputs themselves (the adapter stream) hold 1e-3 on both levels."""
     g, tag = load_golden("c5full"), "c5full_kernel"
-    old = config.precise_level
-    config.precise_level = 2
+    old = config.precise_level_policy
+    config.precise_level_policy = 0
     try:
         D, depth, model, enc, cv, cn = _modules("vit_giant2", "kernel", dev)
         dec = DecoderMLA(img_size=588, mla_channels=D, mlahead_channels=128, num_classes=11)
@@ -143,9 +145,10 @@ def test_config5_stress_holds_1e3_on_precise_level_2(dev):
         taps = {}
         loss = eng.train_step(img.to(dev), tgt.to(dev), taps)
     finally:
-        config.precise_level = old
+        config.precise_level_policy = old
+    assert eng.precise_level == 0
     e_in = max(golden_err(t.transpose(1, 2).reshape(1, D, 42, 42), g[f"{tag}.in{i}"]) for i, t in enumerate(taps["mla_inputs"]))
     e_out = golden_err(ops.resize_bilinear_fwd(taps["logits"], 588, 588).permute(0, 3, 1, 2), g[f"{tag}.output"])
-    print(f"{tag} on precise_level 2: MLA inputs <= {e_in:.2e}, output {e_out:.2e}")
-    assert e_in < TOL and e_out < TOL
+    print(f"{tag} on precise_level 0: MLA inputs <= {e_in:.2e}, output {e_out:.2e}")
+    assert e_in < TOL and e_out < 1.5e-3
     assert abs(float(loss) - float(g[f"{tag}.loss"])) < 1e-4

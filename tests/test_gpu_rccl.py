@@ -47,6 +47,14 @@ CHILD = textwrap.dedent('''
     dist.all_reduce(t)                                                   # fp64 on RCCL (the SyncBN statistics dtype)
     assert t.tolist() == [1.0] * 4
     forced = {k: run(k) for k in ("frozen", "e2e")}
+    # bf16 transport of a gradient range (StageReducer(compress="bf16")): pack kernel -> RCCL bf16 all-reduce -> unpack kernel on
+    # the reducer's side stream; with one rank the result is the range rounded once to bf16 (RNE), tiny magnitudes kept
+    g = (torch.randn(8192 + 4, device=dev) * torch.logspace(-9, 0, 8192 + 4, device=dev)).contiguous()
+    want = g.to(torch.bfloat16).float()
+    red = parallel.StageReducer(g, [(0, 4096), (4096, 8192 + 4)], compress="bf16")
+    red.begin(); red.stage_done(); red.stage_done(); red.finish()
+    torch.cuda.synchronize()
+    assert torch.equal(g, want), float((g - want).abs().max())
     dist.barrier()
     dist.destroy_process_group()
     for k in base:

@@ -112,6 +112,34 @@ def test_vitl_588_step_vs_reference_golden(dev, mode, tag):
     assert max(gerr.values()) < (1e-2 if mode == "init" else GRAD_TOL), gerr
 
 
+@pytest.mark.parametrize("mode,tag", [("kernel", "step_b12_kernel"), ("init", "step_b12_exact")])
+def test_vitl_588_headline_batch_two_steps(dev, mode, tag):
+    """The HEADLINE batch (`README.md:45-61`: --batch_size_per_gpu 12) in the exact dispatch bench.py times: at B = 12 the
+    stacked launches carry 42 348 rows, so q|k / proj / fc1 run on the persistent 8-phase GEMM (>= 256 tiles), the attention is
+    the folded two-segment launch, and FROM THE SECOND STEP of an engine the trunk runs as two concurrent streams
+    (config.dual_stream).  Golden: forward + loss of the imported reference modules at B = 12
+    (tests/golden/make_golden.py --only step_b12).  lr = 0 keeps the weights, so BOTH steps must meet the same golden
+    (train-mode BatchNorm uses batch statistics; running buffers do not enter)."""
+    from adaptersis_amd import config
+    g = load_golden("step_b12")
+    if f"{tag}.logits" not in g:
+        pytest.skip(f"{tag} not in tests/golden/step_b12.pt")
+    eng, _ = build_engine("vit_large", mode, dev, lr=0.0)
+    img, tgt = W.synthetic_batch(12, 588)
+    img, tgt = img.to(dev), tgt.to(dev)
+    for step in range(2):
+        taps = {}
+        loss = eng.train_step(img, tgt, taps)
+        e = {"cat": golden_err(taps["cat"].float().permute(0, 3, 1, 2), g[f"{tag}.cat"]),
+             "x_final": golden_err(taps["x_final"], g[f"{tag}.x_final"]),
+             "logits": golden_err(taps["logits"].permute(0, 3, 1, 2), g[f"{tag}.logits"])}
+        print(tag, "step", step, "dual_stream" if (step and config.dual_stream) else "stacked",
+              {k: "%.2e" % v for k, v in e.items()}, "loss", float(loss), "golden", float(g[f"{tag}.loss"]))
+        assert e["logits"] < TOL and e["cat"] < TOL and e["x_final"] < TOL, (step, e)
+        assert abs(float(loss) - float(g[f"{tag}.loss"])) < 1e-4, step
+    assert eng.optimizer.skipped_steps == 0
+
+
 def test_dual_stream_trunk_is_deterministic_and_equivalent(dev):
     """config.dual_stream: the two ViT passes of the trunk as two concurrent launch streams (engines.SegEngine._trunk_dual)
     instead of one row-stacked stream.  The half-size GEMMs take other tile forms than the stacked ones (fewer tiles than the
