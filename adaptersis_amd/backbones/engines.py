@@ -25,7 +25,7 @@ import torch.distributed as dist
 from torch import nn
 
 from .. import config, ops
-from ..dinov2.layers.blocks import _Packed, _pack
+from ..dinov2.layers.blocks import _Packed, _pack, run_blocks
 from ..optim import SGD, FlatBucket
 from ..parallel import StageReducer, world_size
 from .adapter_blocks import CACNN, CAViT, deform_inputs
@@ -229,10 +229,17 @@ class SegEngine(nn.Module):
             st.wait_stream(main)
             xcat.record_stream(st)
             xs.append(xcat[sl])
-        for blk in blocks:
+        # block by block, alternating between the streams (the launch order the streams' kernels interleave in); inside the run
+        # the residual stream stays in the two-plane form where Block.fold_ok allows (blocks.run_blocks semantics)
+        nblk = len(blocks)
+        for bi, blk in enumerate(blocks):
             for i, (st, (_, sg)) in enumerate(zip(self._dual_streams, parts)):
                 with torch.cuda.stream(st):
-                    xs[i] = blk.forward_rows(xs[i], sg)
+                    R_i = xs[i][0].shape[0] if isinstance(xs[i], tuple) else xs[i].shape[0]
+                    if blk.fold_ok(R_i, sg):
+                        xs[i] = blk.forward_rows_fold(xs[i], sg, planes_out=bi + 1 < nblk and blocks[bi + 1].fold_ok(R_i, sg))
+                    else:
+                        xs[i] = blk.forward_rows(xs[i], sg)
         for st, x in zip(self._dual_streams, xs):
             main.wait_stream(st)
             x.record_stream(main)
@@ -295,10 +302,10 @@ class SegEngine(nn.Module):
             feats.append(m._final_norm(xcat[:Ra].view(B, N + 1, D))[:, 1:])
             trunk = []
         self._dual_warm = True      # the first step runs in order: it fills the per-module operand caches on one stream
-        for i, blk in enumerate(trunk):
-            xcat = blk.forward_rows(xcat, segs)
-            if i >= nb - nl:
-                feats.append(m._final_norm(xcat[:Ra].view(B, N + 1, D))[:, 1:])   # [B, N, D] view, batch stride (N+1)*D
+        if trunk:   # only the LAST trunk block's output is read as fp32 (final norm + adapter stage 0): one run
+            assert nb - nl == len(trunk) - 1
+            xcat = run_blocks(trunk, xcat, segs)
+            feats.append(m._final_norm(xcat[:Ra].view(B, N + 1, D))[:, 1:])   # [B, N, D] view, batch stride (N+1)*D
         if enc_done is not None:
             torch.cuda.current_stream().wait_event(enc_done)   # the pyramid tokens are first needed by adapter stage 0
         if taps is not None:
@@ -314,7 +321,7 @@ class SegEngine(nn.Module):
                     xb_s, bsaved = blk.forward_train(xcat[Ra:].view(B, N, D))
                     xcat = torch.cat([xa_s, xb_s.reshape(Rb, D)], 0)
                 else:
-                    xcat = blk.forward_rows(xcat, segs)
+                    xcat = run_blocks([blk], xcat, segs)
                 feats.append(m._final_norm(xcat[:Ra].view(B, N + 1, D))[:, 1:])
             # the last stage's CACNN output (`train.py:372-386`) feeds nothing: the decoder input takes c4 from the
             # ENCODER output (`:395`), so unless a caller asks for the taps it is dead code and skipped (same results)
@@ -383,8 +390,7 @@ class SegEngine(nn.Module):
         Ra = B * (N + 1)
         segs = [(B, N + 1), (B, N)]
         xcat = torch.cat([xa.view(Ra, D), tokens.reshape(B * N, D)], 0)
-        for blk in m.blocks[: nb - 3]:
-            xcat = blk.forward_rows(xcat, segs)
+        xcat = run_blocks(list(m.blocks[: nb - 3]), xcat, segs)
         c2d = c.view(B * Lc, D)
         if train:
             x2, s_cv = self.cross_vit.forward16_train(xcat[Ra:].clone(), c2d, g, B, N, Lc)

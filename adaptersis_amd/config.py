@@ -107,3 +107,13 @@ trunk_streams = int(os.environ.get("ASIS_TRUNK_STREAMS", "2") or 2)     # 4: eac
 # skips that one call (identical results, ~0.8 % of the step's FLOPs); ASIS_ELIDE_DEAD_CACNN=0 runs it anyway (bench.py reports
 # the setting as config.dead_cacnn_elided; A/B in DESIGN.md §6).
 elide_dead_cacnn = os.environ.get("ASIS_ELIDE_DEAD_CACNN", "1") not in ("0", "")
+
+# LayerNorm folded into the linear layers around it (include/asis_hip.h: asis_gemm_desc.C_lo / rowstats / res16 / ln_mr): inside the
+# frozen trunk the residual stream travels between GEMM epilogues as two 16-bit planes (hi + lo = the 4 bytes per element of the
+# fp32 tensor it replaces, ~22 significant bits) with per-row (mean, rstd) from the producing epilogue's partial sums; the
+# consumer takes the hi plane as its A operand, diag(ln.weight) folded into its weight, and undoes the normalisation in its
+# epilogue: rstd * (x W'^T - mean * colsum(W')) + b'.  The standalone LayerNorm launches (one read of the fp32 stream + one
+# 16-bit write each, 4.9 % of the headline step) disappear with no extra HBM traffic.  float16 operands, Mlp blocks,
+# precise_level 0, shapes on the 8-phase kernels (>= 256 tiles: the headline batch); everything else runs asis_layernorm as
+# before.  ASIS_LN_FOLD=0 disables it.
+ln_fold = os.environ.get("ASIS_LN_FOLD", "1") not in ("0", "")

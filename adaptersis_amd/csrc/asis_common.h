@@ -97,6 +97,24 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// sum over the 16 lanes of a DPP row (lanes 16 g .. 16 g + 15), result in every lane: two quad permutes, row_half_mirror,
+// row_mirror — VALU-only (no LDS crossbar); all 64 lanes must be active
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
+  return v;
+}
+
+// sum over 8 consecutive lanes (8 g .. 8 g + 7), result in every lane
+__device__ __forceinline__ float row8_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+  return v;
+}
+
 // erf-form GELU (nn.GELU() default; dinov2/layers/mlp.py:35, adapter_blocks.py:87).  erf by Abramowitz-Stegun
 // 7.1.26 (|abs err| <= 1.5e-7, i.e. fp32-epsilon level and 3 orders below the 16-bit operand rounding): one
 // v_exp + one v_rcp + 6 FMAs instead of libm erff's ~40 VALU ops, which cost the fc1 epilogue 25 % of the GEMM.

@@ -242,16 +242,34 @@ int launch(hipStream_t s, const asis_gemm_desc& d) {
     const int64_t p8_tiles = (int64_t)((d.M + 255) / 256) * ((d.N + 255) / 256);
     const int kparts = 1 + (d.A_lo ? 1 : 0) + (d.B_lo ? 1 : 0);
     auto al = [](const void* p, int a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; };
-    if (p8 && big_mode && ph8_m16_on() && !d.conv && !d.stats && d.batch == 1 && !d.bias_m && d.ksplit <= 1 && d.K % 64 == 0 &&
+    if (p8 && big_mode && ph8_m16_on() && !d.conv && !d.stats && d.batch == 1 && !d.bias_m && !d.ln_cols && !d.C_lo && !d.rowstats && !d.res16 &&
+        d.ksplit <= 1 && d.K % 64 == 0 &&
         d.M >= 256 && d.N >= 256 && p8_tiles >= (p8 == 2 ? 16 : 256) && d.K >= 128 && (p8 >= 2 || d.K * kparts <= 2048) &&
         (int64_t)d.M * d.lda * 2 < (1ll << 32) && (int64_t)d.N * d.ldb * 2 < (1ll << 32) && d.N % 8 == 0 && d.ldc % 8 == 0 &&
         al(d.C, 16) && (!d.res || (al(d.res, 16) && d.ldr % 4 == 0)) && (!d.bias_n || al(d.bias_n, 16)) && (!d.scale_n || al(d.scale_n, 16)) &&
         (d.act != ASIS_ACT_GELU_GRAD || (d.aux && al(d.aux, 8) && d.ld_aux % 4 == 0))) {
       const int nwg = p8_tiles >= 256 ? 256 : (int)(p8_tiles / 8) * 8;
       if (g_gemm_noepi) hipLaunchKernelGGL((gemm_p8_kernel<T, 1>), dim3(nwg), dim3(512), 0, s, d, group_m);
+      else if (d.ln_mr) hipLaunchKernelGGL((gemm_p8_kernel<T, 0, 1>), dim3(nwg), dim3(512), 0, s, d, group_m);   // LayerNorm-fold consumer
       else hipLaunchKernelGGL((gemm_p8_kernel<T, 0>), dim3(nwg), dim3(512), 0, s, d, group_m);
       return 0;
     }
+  }
+  // LayerNorm-fold fields (C_lo / rowstats / res16 / ln_mr): implemented by the persistent kernel above and by the dense 8-phase
+  // one-tile-per-workgroup form below; anything else is refused (the caller runs asis_layernorm and plain launches)
+  const bool lnx = d.C_lo || d.rowstats || d.res16 || d.ln_mr;
+  if (lnx) {
+    static const int ph8x = [] { const char* e = getenv("ASIS_GEMM_8P"); return e ? atoi(e) : 1; }();
+    const bool ph8_ok = ph8x && ph8_m16_on() && big_mode && !split && !d.conv && !d.stats && d.K % 64 == 0 && d.M >= 256 && d.N >= 256 &&
+                        (ph8x == 2 || d.K >= 2048 || (ph8x == 1 && d.K >= 1024 && (int64_t)((d.M + 255) / 256) * ((d.N + 255) / 256) * d.batch >= 128)) &&
+                        d.N % 8 == 0 && d.ldc % 8 == 0 && (!d.res16 || (d.res16_lo && d.ldr16 % 8 == 0 && d.ldr16 >= d.N && asis_aligned16(d.res16) && asis_aligned16(d.res16_lo))) &&
+                        (!d.C_lo || !d.out_f32) && (!d.ln_mr || d.ln_cs) &&
+                        // producer launches (dedicated 8-columns-per-lane epilogue of gemm_big.h): plain v = res + scale * (acc + bias)
+                        (!(d.C_lo || d.rowstats || d.res16) ||
+                         ((!d.res || (d.ldr % 8 == 0 && asis_aligned16(d.res))) && (!d.C_lo || asis_aligned16(d.C_lo)) && asis_aligned16(d.C) &&
+                          (!d.bias_n || asis_aligned16(d.bias_n)) && (!d.scale_n || asis_aligned16(d.scale_n)) && d.batch == 1 && !d.bias_m &&
+                          d.act == ASIS_ACT_NONE && !d.ln_mr));
+    if (!ph8_ok) return ASIS_EINVAL;
   }
   if (split) {  // one pass over the virtual 3K reduction; only on the large-tile kernel
     const bool ok = big_mode && d.K % BK == 0 && d.M >= 256 && d.N >= 32 && vec_ok && (d.out_f32 || !d.conv) &&
@@ -342,6 +360,7 @@ int launch(hipStream_t s, const asis_gemm_desc& d) {
     if (ph8_m16) {
       if (noepi == 8) hipLaunchKernelGGL((gemm_big_kernel<T, 2, 4, 4, 2, 2, 8, false, false, 64, 1, true, true>), grid, block, 0, s, d, group_m);   // lab: no global stores
       else if (noepi) hipLaunchKernelGGL((gemm_big_kernel<T, 2, 4, 4, 2, 2, 4, false, false, 64, 1, true, true>), grid, block, 0, s, d, group_m);
+      else if (lnx) hipLaunchKernelGGL((gemm_big_kernel<T, 2, 4, 4, 2, 2, 0, false, false, 64, 1, true, true, 1>), grid, block, 0, s, d, group_m);
       else hipLaunchKernelGGL((gemm_big_kernel<T, 2, 4, 4, 2, 2, 0, false, false, 64, 1, true, true>), grid, block, 0, s, d, group_m_f);
       return 0;
     }
@@ -423,6 +442,7 @@ extern "C" int asis_gemm_group(void* stream, const asis_gemm_desc* descs, int n)
   for (int i = 0; i < n; ++i) {
     const asis_gemm_desc& d = descs[i];
     ASIS_REQUIRE(d.A && d.B && d.C, "asis_gemm_group: problem %d: null operand pointer", i);
+    ASIS_REQUIRE(!d.C_lo && !d.rowstats && !d.res16 && !d.ln_mr, "asis_gemm_group: the LayerNorm-fold fields are not implemented in the grouped kernel");
     ASIS_REQUIRE(d.dtype == descs[0].dtype && (d.dtype == ASIS_F16 || d.dtype == ASIS_BF16), "asis_gemm_group: one 16-bit dtype per group");
     const int batch = d.batch > 0 ? d.batch : 1;
     const int kparts = 1 + (d.A_lo ? 1 : 0) + (d.B_lo ? 1 : 0);
@@ -486,6 +506,11 @@ extern "C" int asis_gemm(void* stream, const asis_gemm_desc* dp) {
     ASIS_REQUIRE(d.lda % 8 == 0 && d.lda >= d.K, "asis_gemm: lda=%ld must be a multiple of 8 and >= K", (long)d.lda);
   }
   if (d.stats) ASIS_REQUIRE(d.batch == 1, "asis_gemm: stats need batch == 1");
+  if (d.res16) ASIS_REQUIRE(d.res16_lo && !d.res && d.ldr16 % 4 == 0 && d.ldr16 >= d.N && (reinterpret_cast<uintptr_t>(d.res16) & 7) == 0 &&
+                            (reinterpret_cast<uintptr_t>(d.res16_lo) & 7) == 0, "asis_gemm: res16 needs res16_lo, no fp32 res, ldr16 %% 4 == 0, 8-byte aligned planes");
+  if (d.C_lo) ASIS_REQUIRE(!d.out_f32 && (reinterpret_cast<uintptr_t>(d.C_lo) & 7) == 0, "asis_gemm: C_lo is the second plane of a 16-bit output");
+  if (d.ln_mr) ASIS_REQUIRE(d.ln_cs && (reinterpret_cast<uintptr_t>(d.ln_mr) & 7) == 0 && asis_aligned16(d.ln_cs), "asis_gemm: ln_mr needs ln_cs (16-byte aligned)");
+  if (d.rowstats) ASIS_REQUIRE(d.batch == 1 && (reinterpret_cast<uintptr_t>(d.rowstats) & 7) == 0, "asis_gemm: rowstats need batch == 1");
   const int64_t tiles = (int64_t)asis_cdiv(d.M, BM) * asis_cdiv(d.N, BN);
   ASIS_REQUIRE(tiles < (1ll << 31), "asis_gemm: too many tiles");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);

@@ -19,7 +19,7 @@ namespace {
 __device__ __attribute__((aligned(16))) uint4 g_zero_page[1];
 
 template <typename T, int WM, int WN, int TM, int TN, int NS, int DBG = 0, bool CONV = false, bool SPLIT = false, int BKT = 64,
-          int OCC = 2, bool PH8 = false, bool M16 = false>
+          int OCC = 2, bool PH8 = false, bool M16 = false, int LNF = 0>
 __global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_big_kernel(const asis_gemm_desc d, const int GROUP_M_FLAGS) {
   const int GROUP_M = GROUP_M_FLAGS & 0xffff;        // raster group height; bit 16 (lab): fp32 slab epilogue for every output type
   static_assert(!PH8 || (WM == 2 && WN == 4 && TM == 4 && TN == 2 && NS == 2 && BKT == 64),
@@ -466,18 +466,31 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_big_kernel(const asis_
     // layout (a lane owns 4 consecutive columns of one row), the result is converted to 16 bits BEFORE the LDS transposition
     // (half the slab bytes: 8-byte writes, 16-byte reads) and leaves as 16-byte stores, 8 rows x 128 bytes per instruction —
     // half as many, twice as wide as the fp32 slab path's.  This form's epilogue is fully exposed (one workgroup per CU).
-    if (vec && !d.out_f32 && !res && !d.stats && !d.scale_n && d.act != ASIS_ACT_GELU_GRAD && !(DBG & 8) &&
+    if (vec && !d.out_f32 && !res && !d.res16 && !d.C_lo && !d.rowstats && !d.stats && !d.scale_n && d.act != ASIS_ACT_GELU_GRAD && !(DBG & 8) &&
         (d.N & 7) == 0 && (d.ldc & 7) == 0 && (cbase & 7) == 0 && !(GROUP_M_FLAGS >> 16)) {
       constexpr int SW16 = TN * 32 + 8;                 // slab row in 16-bit elements (144 bytes: conflict-free 8-byte writes)
       __syncthreads();                                  // every wave is done with the staging buffers
       T* slab16 = reinterpret_cast<T*>(lds) + wid * (32 * SW16);
       const int r16 = lane & 15, q16 = lane >> 4;
       const int rr8 = lane >> 3, c8 = lane & 7;
-      float4 bj[TN * 2];
+      // LayerNorm folded into the weight (asis_gemm_desc.ln_mr / ln_cs; dense launches only): v = rstd * (acc - mean * cs) +
+      // bias, statistics per output ROW (ln_cols == 0: A rows are the tokens) or per output COLUMN (ln_cols != 0: the swapped
+      // V^T GEMM, B rows are the tokens of batch entry bz; cs is then per output row).  Without it the arithmetic below is
+      // the plain acc + bias (no LN operand is touched).
+      const bool ln_on = LNF != 0 && !CONV && d.ln_mr != nullptr, ln_c = ln_on && d.ln_cols != 0;   // LNF: the instance that implements the fields
+      const float2* const mrp = reinterpret_cast<const float2*>(d.ln_mr) + (ln_c ? (int64_t)bz * (d.strideB / d.ldb) : 0);
+      float4 bj[TN * 2], cj[TN * 2];
+      float2 mc[TN * 2][4];   // ln_c: (mean, rstd) of this lane's four columns per 16-column block
 #pragma unroll
       for (int j = 0; j < TN * 2; ++j) {
         const int colj = n0 + (wn * TN * 2 + j) * 16 + 4 * q16;
         bj[j] = (d.bias_n && kt_base == 0 && colj < d.N) ? *reinterpret_cast<const float4*>(d.bias_n + colj) : make_float4(0.f, 0.f, 0.f, 0.f);
+        cj[j] = (ln_on && !ln_c && colj < d.N) ? *reinterpret_cast<const float4*>(d.ln_cs + colj) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          mc[j][e] = make_float2(0.f, 1.f);
+          if (ln_c) mc[j][e] = mrp[colj + e < d.N ? colj + e : d.N - 1];
+        }
       }
       const int colr = n0 + wn * TN * 32 + c8 * 8;
       const bool cokr = colr < d.N;
@@ -486,15 +499,33 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_big_kernel(const asis_
       for (int i = 0; i < TM; ++i) {
 #pragma unroll
         for (int ii = 0; ii < 2; ++ii) {
-          float bm1 = 0.f;
-          if (d.bias_m) {   // per-row bias (the V^T GEMM: rows are the output features)
-            const int rowb = m0 + (wm * TM + i) * 32 + ii * 16 + r16;
-            bm1 = d.bias_m[rowb < d.M ? rowb : d.M - 1];
+          float bm1 = 0.f, nmean = -0.f, rstd = 1.f, csr = 0.f;
+          const int rowb = m0 + (wm * TM + i) * 32 + ii * 16 + r16;
+          const int rowbc = rowb < d.M ? rowb : d.M - 1;
+          if (d.bias_m) bm1 = d.bias_m[rowbc];   // per-row bias (the V^T GEMM: rows are the output features)
+          if (ln_on && !ln_c) {
+            const float2 mr = mrp[rowbc];
+            nmean = -mr.x;
+            rstd = mr.y;
           }
+          if (ln_c) csr = d.ln_cs[rowbc];
 #pragma unroll
           for (int j = 0; j < TN * 2; ++j) {
-            float4 v = make_float4(acc16[2 * i + ii][j][0] + bj[j].x + bm1, acc16[2 * i + ii][j][1] + bj[j].y + bm1,
-                                   acc16[2 * i + ii][j][2] + bj[j].z + bm1, acc16[2 * i + ii][j][3] + bj[j].w + bm1);
+            float4 v;
+            if (ln_c) {
+              v = make_float4(__builtin_fmaf(__builtin_fmaf(-mc[j][0].x, csr, acc16[2 * i + ii][j][0]), mc[j][0].y, bj[j].x + bm1),
+                              __builtin_fmaf(__builtin_fmaf(-mc[j][1].x, csr, acc16[2 * i + ii][j][1]), mc[j][1].y, bj[j].y + bm1),
+                              __builtin_fmaf(__builtin_fmaf(-mc[j][2].x, csr, acc16[2 * i + ii][j][2]), mc[j][2].y, bj[j].z + bm1),
+                              __builtin_fmaf(__builtin_fmaf(-mc[j][3].x, csr, acc16[2 * i + ii][j][3]), mc[j][3].y, bj[j].w + bm1));
+            } else if (ln_on) {
+              v = make_float4(__builtin_fmaf(__builtin_fmaf(nmean, cj[j].x, acc16[2 * i + ii][j][0]), rstd, bj[j].x + bm1),
+                              __builtin_fmaf(__builtin_fmaf(nmean, cj[j].y, acc16[2 * i + ii][j][1]), rstd, bj[j].y + bm1),
+                              __builtin_fmaf(__builtin_fmaf(nmean, cj[j].z, acc16[2 * i + ii][j][2]), rstd, bj[j].z + bm1),
+                              __builtin_fmaf(__builtin_fmaf(nmean, cj[j].w, acc16[2 * i + ii][j][3]), rstd, bj[j].w + bm1));
+            } else {
+              v = make_float4(acc16[2 * i + ii][j][0] + bj[j].x + bm1, acc16[2 * i + ii][j][1] + bj[j].y + bm1,
+                              acc16[2 * i + ii][j][2] + bj[j].z + bm1, acc16[2 * i + ii][j][3] + bj[j].w + bm1);
+            }
             if (d.act == ASIS_ACT_GELU) gelu_erf4(v.x, v.y, v.z, v.w);
             else if (d.act == ASIS_ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
             uint2 pk;
@@ -509,6 +540,103 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_big_kernel(const asis_
           const int row = m0 + (wm * TM + i) * 32 + lrow;
           const uint4 w = *reinterpret_cast<const uint4*>(slab16 + lrow * SW16 + c8 * 8);
           if (row < d.M && cokr) *reinterpret_cast<uint4*>(Cw + (int64_t)row * d.ldc) = w;
+        }
+      }
+      return;
+    }
+  }
+  if constexpr (LNF != 0 && M16 && PH8 && !CONV && !SPLIT) {
+    if (d.C_lo || d.rowstats || d.res16) {
+      // LayerNorm-fold PRODUCER epilogue (proj, fc2; include/asis_hip.h): v = res + scale * (acc + bias) with the residual as
+      // fp32 or as two 16-bit planes, the result as fp32 or as two planes (+ per-row partial sums of v for the next LayerNorm).
+      // A lane owns EIGHT consecutive columns of a row here (8 lanes per row, 8 rows per pass), so that a plane access is one
+      // 16-byte instruction exactly like an fp32 access of four columns: the planes cost no more load / store instructions than
+      // the fp32 tensors they replace (the generic path below, four columns per lane, needed twice as many 8-byte ones).
+      // Host contract (asis_gemm): N % 8 == 0, ldc / ldr / ldr16 multiples of 8 elements, 16-byte aligned pointers, batch 1.
+      constexpr int SW = TN * 32 + 4;
+      __syncthreads();
+      float* slab = reinterpret_cast<float*>(lds) + wid * (32 * SW);
+      const int rr = lane >> 3, c8 = lane & 7;
+      const int col = n0 + wn * TN * 32 + c8 * 8;
+      const bool cok = col < d.N;
+      const int colc = cok ? col : 0;
+      float4 ba = make_float4(0.f, 0.f, 0.f, 0.f), bb = ba, sa = make_float4(1.f, 1.f, 1.f, 1.f), sb = sa;
+      if (cok && d.bias_n) { ba = *reinterpret_cast<const float4*>(d.bias_n + col); bb = *reinterpret_cast<const float4*>(d.bias_n + col + 4); }
+      if (cok && d.scale_n) { sa = *reinterpret_cast<const float4*>(d.scale_n + col); sb = *reinterpret_cast<const float4*>(d.scale_n + col + 4); }
+      const bool res_planes = d.res16 != nullptr;
+      const float* const zp = reinterpret_cast<const float*>(g_zero_page);
+      const float* const resp = d.res ? d.res + colc : zp;
+      const int64_t ldr_e = d.res ? d.ldr : 0;
+      const T* const r16h = reinterpret_cast<const T*>(d.res16) + colc;
+      const T* const r16l = reinterpret_cast<const T*>(d.res16_lo) + colc;
+      T* const Clo = reinterpret_cast<T*>(d.C_lo);
+      float* const rstats = d.rowstats;
+      const int sgroups = (d.N + 63) >> 6, sgrp = (n0 + wn * TN * 32) >> 6;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+          for (int j = 0; j < TN * 2; ++j)
+            *reinterpret_cast<float4*>(slab + (ii * 16 + (lane & 15)) * SW + 16 * j + 4 * (lane >> 4)) =
+                make_float4(acc16[2 * i + ii][j][0], acc16[2 * i + ii][j][1], acc16[2 * i + ii][j][2], acc16[2 * i + ii][j][3]);
+        uint4 ra[4], rb[4];   // residual of the four passes: fp32 (two 16-byte pieces) or (hi | lo) planes (16 bytes each)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int row = m0 + (wm * TM + i) * 32 + q * 8 + rr;
+          const int rowc = row < d.M ? row : d.M - 1;
+          if (res_planes) {
+            ra[q] = *reinterpret_cast<const uint4*>(r16h + (int64_t)rowc * d.ldr16);
+            rb[q] = *reinterpret_cast<const uint4*>(r16l + (int64_t)rowc * d.ldr16);
+          } else {
+            ra[q] = *reinterpret_cast<const uint4*>(resp + (int64_t)rowc * ldr_e);
+            rb[q] = *reinterpret_cast<const uint4*>(resp + (int64_t)rowc * ldr_e + (d.res ? 4 : 0));
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int lrow = q * 8 + rr;
+          const int row = m0 + (wm * TM + i) * 32 + lrow;
+          float4 va = *reinterpret_cast<const float4*>(slab + lrow * SW + c8 * 8);
+          float4 vb = *reinterpret_cast<const float4*>(slab + lrow * SW + c8 * 8 + 4);
+          float4 xa, xb;
+          if (res_planes) {   // hi + lo is exact in fp32 (two non-overlapping 11-bit pieces)
+            float h[8], l[8];
+            unpack2<T>(ra[q].x, h[0], h[1]); unpack2<T>(ra[q].y, h[2], h[3]); unpack2<T>(ra[q].z, h[4], h[5]); unpack2<T>(ra[q].w, h[6], h[7]);
+            unpack2<T>(rb[q].x, l[0], l[1]); unpack2<T>(rb[q].y, l[2], l[3]); unpack2<T>(rb[q].z, l[4], l[5]); unpack2<T>(rb[q].w, l[6], l[7]);
+            xa = make_float4(h[0] + l[0], h[1] + l[1], h[2] + l[2], h[3] + l[3]);
+            xb = make_float4(h[4] + l[4], h[5] + l[5], h[6] + l[6], h[7] + l[7]);
+          } else {
+            xa = __builtin_bit_cast(float4, ra[q]);
+            xb = __builtin_bit_cast(float4, rb[q]);
+          }
+          float st_s = 0.f, st_q = 0.f;
+          if (row < d.M && cok) {
+            va.x = (va.x + ba.x) * sa.x + xa.x; va.y = (va.y + ba.y) * sa.y + xa.y; va.z = (va.z + ba.z) * sa.z + xa.z; va.w = (va.w + ba.w) * sa.w + xa.w;
+            vb.x = (vb.x + bb.x) * sb.x + xb.x; vb.y = (vb.y + bb.y) * sb.y + xb.y; vb.z = (vb.z + bb.z) * sb.z + xb.z; vb.w = (vb.w + bb.w) * sb.w + xb.w;
+            if (d.out_f32) {
+              float* const cp = reinterpret_cast<float*>(d.C) + (int64_t)row * d.ldc + col;
+              *reinterpret_cast<float4*>(cp) = va;
+              *reinterpret_cast<float4*>(cp + 4) = vb;
+            } else {
+              uint4 ph;
+              ph.x = pack2<T>(va.x, va.y); ph.y = pack2<T>(va.z, va.w); ph.z = pack2<T>(vb.x, vb.y); ph.w = pack2<T>(vb.z, vb.w);
+              *reinterpret_cast<uint4*>(reinterpret_cast<T*>(d.C) + (int64_t)row * d.ldc + col) = ph;
+              if (Clo) {
+                uint4 pl;
+                pl.x = pack2<T>(lo_part<T>(va.x), lo_part<T>(va.y)); pl.y = pack2<T>(lo_part<T>(va.z), lo_part<T>(va.w));
+                pl.z = pack2<T>(lo_part<T>(vb.x), lo_part<T>(vb.y)); pl.w = pack2<T>(lo_part<T>(vb.z), lo_part<T>(vb.w));
+                *reinterpret_cast<uint4*>(Clo + (int64_t)row * d.ldc + col) = pl;
+              }
+            }
+            st_s = ((va.x + va.y) + (va.z + va.w)) + ((vb.x + vb.y) + (vb.z + vb.w));
+            st_q = ((va.x * va.x + va.y * va.y) + (va.z * va.z + va.w * va.w)) + ((vb.x * vb.x + vb.y * vb.y) + (vb.z * vb.z + vb.w * vb.w));
+          }
+          if (rstats) {   // wave-uniform; the 8 lanes of half a DPP row hold the 64 columns of one output row
+            st_s = row8_sum(st_s);
+            st_q = row8_sum(st_q);
+            if (c8 == 0 && row < d.M) *reinterpret_cast<float2*>(rstats + ((int64_t)row * sgroups + sgrp) * 2) = make_float2(st_s, st_q);
+          }
         }
       }
       return;

@@ -29,7 +29,11 @@
 
 namespace {
 
-template <typename T, int LAB = 0>
+// LNF: which LayerNorm-fold epilogue fields this instance implements (include/asis_hip.h; a separate instance: the plain kernel
+// has no register to spare): 0 none, 1 = ln_mr / ln_cs in the 16-bit epilogue (q|k, fc1).  The producer fields (res16 / C_lo /
+// rowstats) are NOT built here: with them this kernel spilled ~200 VGPRs into its main loop in every arrangement tried, and the
+// one-tile-per-workgroup form (gemm_big.h, LNF) runs the projection within 4 % of this one — asis_gemm sends those launches there.
+template <typename T, int LAB = 0, int LNF = 0>
 __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(const asis_gemm_desc d, const int GROUP_M) {
   // (Tried in round 3 and removed: a non-temporal cache policy (LDS-DMA aux = nt) on the operand whose panels an XCD's chunks
   // do not share.  L2 fills went UP 5-30 % with the hint on either operand, and merely having the two aux variants of the
@@ -37,7 +41,9 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(const asis_gemm_desc d,
   typedef typename T16<T>::v8 v8;
   constexpr int BM = 256, BN = 256, BK = 64;
   constexpr int STAGE = (BM + BN) * BK;  // elements per LDS stage (64 KB)
-  __shared__ __attribute__((aligned(16))) T lds[2 * STAGE];
+  // LNF == 1: + 2 KB behind the stages for the (mean, rstd) pairs of the tile's 256 rows (LDS-DMA at the tile's start: a
+  // global load issued in the epilogue itself costs a full loaded-memory round trip, ~1.5 us per tile, in the exposed epilogue)
+  __shared__ __attribute__((aligned(16))) T lds[2 * STAGE + (LNF == 1 ? 1024 : 0)];
   typedef __attribute__((address_space(3))) void* lds_ptr;
   typedef const __attribute__((address_space(1))) void* glb_ptr;
 
@@ -129,6 +135,20 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(const asis_gemm_desc d,
     }
   };
   advance();
+  float* const lds_mr = reinterpret_cast<float*>(lds + 2 * STAGE);
+  auto dma_mr = [&](int m0t) {   // LNF == 1: thread t fetches float t of the tile's [256][2] (mean, rstd) block
+    if constexpr (LNF == 1) {
+      if (d.ln_mr) {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int t = wid * 64 + ln;
+        int row = m0t + (t >> 1);
+        row = row < d.M ? row : d.M - 1;
+        __builtin_amdgcn_global_load_lds((glb_ptr)(d.ln_mr + 2 * (int64_t)row + (t & 1)), (lds_ptr)(lds_mr + wid * 64), 4, 0, 0);
+      }
+    }
+  };
+  dma_mr(m0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
@@ -248,29 +268,54 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(const asis_gemm_desc d,
 #pragma unroll
         for (int j = 0; j < 4; ++j) z += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
       if (z == 123.456f) reinterpret_cast<float*>(d.C)[tid] = z;
-    } else if (!d.out_f32 && !d.res && !d.scale_n && d.act != ASIS_ACT_GELU_GRAD) {
+    } else if (!d.out_f32 && !d.res && !d.res16 && !d.C_lo && !d.rowstats && !d.scale_n && d.act != ASIS_ACT_GELU_GRAD) {
       // 16-bit outputs (q|k, fc1 + GELU): bias and activation in the accumulator layout, converted to 16 bits BEFORE the LDS
       // transposition (8-byte writes, 16-byte reads), 16-byte stores of 8 rows x 128 B
       constexpr int SW16 = 72;                          // slab row in 16-bit elements (144 B: conflict-free 8-byte writes)
       T* slab16 = stage_free + wid * 4096;              // 8 KB per wave
       const int rr8 = lane_e >> 3, c8 = lane_e & 7;
-      float4 bj[4];
+      // LayerNorm folded into the weight (asis_gemm_desc.ln_mr / ln_cs): v = rstd * (acc - mean * cs[n]) + b'[n].  Without it
+      // mean = 0, cs = 0, rstd = 1: fma(-0, 0, acc) = acc and fma(acc, 1, b) = acc + b exactly, the same bits as before.
+      float4 bj[4], cj[4];
+      const bool mrp = LNF == 1 && d.ln_mr != nullptr;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int colj = n0 + wn * 64 + j * 16 + 4 * q16;
         bj[j] = (d.bias_n && colj < d.N) ? *reinterpret_cast<const float4*>(d.bias_n + colj) : make_float4(0.f, 0.f, 0.f, 0.f);
+        cj[j] = (mrp && colj < d.N) ? *reinterpret_cast<const float4*>(d.ln_cs + colj) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
       const int colr = n0 + wn * 64 + c8 * 8;
       const bool cokr = colr < d.N;
       T* const Cw = reinterpret_cast<T*>(d.C) + colr;
+      float2 mrv[8];     // LNF == 1: (mean, rstd) of this lane's eight rows, fetched before the first slab pass
+      if constexpr (LNF == 1) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int rowl = (wm * 4 + (k >> 1)) * 32 + (k & 1) * 16 + r16;   // staged by dma_mr at this tile's start
+          mrv[k] = mrp ? *reinterpret_cast<const float2*>(lds_mr + 2 * rowl) : make_float2(0.f, 1.f);
+        }
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
 #pragma unroll
         for (int ii = 0; ii < 2; ++ii) {
+          float nmean = -0.f, rstd = 1.f;
+          if constexpr (LNF == 1) {
+            nmean = -mrv[2 * i + ii].x;
+            rstd = mrv[2 * i + ii].y;
+          }
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            float4 v = make_float4(acc[2 * i + ii][j][0] + bj[j].x, acc[2 * i + ii][j][1] + bj[j].y,
-                                   acc[2 * i + ii][j][2] + bj[j].z, acc[2 * i + ii][j][3] + bj[j].w);
+            float4 v;
+            if constexpr (LNF == 1) {
+              v = make_float4(__builtin_fmaf(__builtin_fmaf(nmean, cj[j].x, acc[2 * i + ii][j][0]), rstd, bj[j].x),
+                              __builtin_fmaf(__builtin_fmaf(nmean, cj[j].y, acc[2 * i + ii][j][1]), rstd, bj[j].y),
+                              __builtin_fmaf(__builtin_fmaf(nmean, cj[j].z, acc[2 * i + ii][j][2]), rstd, bj[j].z),
+                              __builtin_fmaf(__builtin_fmaf(nmean, cj[j].w, acc[2 * i + ii][j][3]), rstd, bj[j].w));
+            } else {
+              v = make_float4(acc[2 * i + ii][j][0] + bj[j].x, acc[2 * i + ii][j][1] + bj[j].y,
+                              acc[2 * i + ii][j][2] + bj[j].z, acc[2 * i + ii][j][3] + bj[j].w);
+            }
             if (d.act == ASIS_ACT_GELU) gelu_erf4(v.x, v.y, v.z, v.w);
             else if (d.act == ASIS_ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
             uint2 pk;
@@ -303,6 +348,13 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(const asis_gemm_desc d,
       const int colc = cok ? col : 0;
       const float* const resp = d.res ? d.res + colc : zp;
       const int64_t ldr_e = d.res ? d.ldr : 0;
+      // LayerNorm-fold chain (include/asis_hip.h): residual as two 16-bit planes, output as two planes + per-row partial sums
+      const T* const r16h = reinterpret_cast<const T*>(d.res16) + colc;
+      const T* const r16l = reinterpret_cast<const T*>(d.res16_lo) + colc;
+      const bool res_planes = LNF == 2 && d.res16 != nullptr;
+      T* const Clo = LNF == 2 ? reinterpret_cast<T*>(d.C_lo) : nullptr;
+      float* const rstats = LNF == 2 ? d.rowstats : nullptr;
+      const int sgroups = (d.N + 63) >> 6, sgrp = (n0 + wn * 64) >> 6;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -319,7 +371,14 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(const asis_gemm_desc d,
         for (int p = 0; p < 8; ++p) {
           const int row = m0 + (wm * 4 + i) * 32 + p * 4 + rr;
           const int rowc = row < d.M ? row : d.M - 1;
-          r4[p] = *reinterpret_cast<const float4*>(resp + (int64_t)rowc * ldr_e);
+          if (LNF == 2 && res_planes) {   // (hi.xy | lo.xy) bit patterns ride in the float4's registers until the pass that uses them
+            const uint2 h = *reinterpret_cast<const uint2*>(r16h + (int64_t)rowc * d.ldr16);
+            const uint2 l = *reinterpret_cast<const uint2*>(r16l + (int64_t)rowc * d.ldr16);
+            r4[p] = make_float4(__builtin_bit_cast(float, h.x), __builtin_bit_cast(float, h.y), __builtin_bit_cast(float, l.x),
+                                __builtin_bit_cast(float, l.y));
+          } else {
+            r4[p] = *reinterpret_cast<const float4*>(resp + (int64_t)rowc * ldr_e);
+          }
           pw[p] = make_uint2(0u, 0u);
         }
         if (has_aux) {
@@ -335,6 +394,15 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(const asis_gemm_desc d,
           const int lrow = p * 4 + rr;
           const int row = m0 + (wm * 4 + i) * 32 + lrow;
           float4 v = *reinterpret_cast<const float4*>(slab + lrow * 64 + ((ch ^ (lrow & 7)) << 2));
+          if (LNF == 2 && res_planes) {   // hi + lo is exact in fp32 (two non-overlapping 11-bit pieces)
+            float h0, h1, h2, h3, l0, l1, l2, l3;
+            unpack2<T>(__builtin_bit_cast(uint32_t, r4[p].x), h0, h1);
+            unpack2<T>(__builtin_bit_cast(uint32_t, r4[p].y), h2, h3);
+            unpack2<T>(__builtin_bit_cast(uint32_t, r4[p].z), l0, l1);
+            unpack2<T>(__builtin_bit_cast(uint32_t, r4[p].w), l2, l3);
+            r4[p] = make_float4(h0 + l0, h1 + l1, h2 + l2, h3 + l3);
+          }
+          float st_s = 0.f, st_q = 0.f;
           if (row < d.M && cok) {
             v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
             if (d.act == ASIS_ACT_GELU) gelu_erf4(v.x, v.y, v.z, v.w);
@@ -354,6 +422,24 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(const asis_gemm_desc d,
               pk.x = pack2<T>(v.x, v.y);
               pk.y = pack2<T>(v.z, v.w);
               *reinterpret_cast<uint2*>(reinterpret_cast<T*>(d.C) + (int64_t)row * d.ldc + col) = pk;
+              if (LNF == 2 && Clo) {
+                uint2 pl;
+                pl.x = pack2<T>(lo_part<T>(v.x), lo_part<T>(v.y));
+                pl.y = pack2<T>(lo_part<T>(v.z), lo_part<T>(v.w));
+                *reinterpret_cast<uint2*>(Clo + (int64_t)row * d.ldc + col) = pl;
+              }
+            }
+            if constexpr (LNF == 2) {
+              st_s = (v.x + v.y) + (v.z + v.w);
+              st_q = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+            }
+          }
+          if constexpr (LNF == 2) {
+            if (rstats) {   // wave-uniform; the 16 lanes of a DPP row hold the 64 columns of one output row
+              st_s = row16_sum(st_s);
+              st_q = row16_sum(st_q);
+              if (ch == 0 && row < d.M)
+                *reinterpret_cast<float2*>(rstats + ((int64_t)row * sgroups + sgrp) * 2) = make_float2(st_s, st_q);
             }
           }
         }
@@ -365,6 +451,7 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(const asis_gemm_desc d,
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     m0 = m0n; n0 = n0n;
+    dma_mr(m0);      // every wave is past the barrier above: the epilogue's reads of the previous tile's pairs are done
     pos += nl;
     has_next = pos + nl < xcnt;
     if (has_next) decode(xbase + pos + nl, m0n, n0n);

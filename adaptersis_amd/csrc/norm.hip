@@ -221,6 +221,94 @@ inline int grid_for(int64_t total, int block = 256, int cap = 256 * 16) {
 
 }  // namespace
 
+// ---- LayerNorm-fold chain helpers (include/asis_hip.h: asis_gemm_desc.rowstats / ln_mr) ---------------------------------------
+// partial (sum, sum of squares) per 64-column group -> (mean, rstd) per row; partials combined as (count, mean, M2) triples
+__global__ __launch_bounds__(256) void ln_stats_finalize_kernel(const float* __restrict__ st, int64_t rows, int groups, int D,
+                                                                float eps, float* __restrict__ mr) {
+  const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= rows) return;
+  const float2* p = reinterpret_cast<const float2*>(st) + row * groups;
+  float tot = 0.f;
+  for (int g = 0; g < groups; ++g) tot += p[g].x;
+  const float mean = tot / (float)D;
+  float m2 = 0.f;
+  for (int g = 0; g < groups; ++g) {
+    const float n = (float)(g + 1 < groups ? 64 : D - 64 * (groups - 1));
+    const float mg = p[g].x / n;
+    const float dm = mg - mean;
+    m2 += fmaxf(p[g].y - p[g].x * mg, 0.f) + n * dm * dm;
+  }
+  reinterpret_cast<float2*>(mr)[row] = make_float2(mean, 1.0f / sqrtf(m2 / (float)D + eps));
+}
+
+// fp32 rows -> hi / lo 16-bit planes + (mean, rstd): one wave per row, the statistics of layernorm_kernel
+template <typename T>
+__global__ __launch_bounds__(256) void split_stats_kernel(const float* __restrict__ x, int64_t ldx, T* __restrict__ hi, T* __restrict__ lo,
+                                                          int64_t ld16, float* __restrict__ mr, int64_t rows, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nchunk = D >> 2;
+  const float4* xr = reinterpret_cast<const float4*>(x + row * ldx);
+  float4 v[LN_MAXC];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nchunk) {
+      v[i] = xr[c];
+      s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nchunk) {
+      const float a0 = v[i].x - mean, a1 = v[i].y - mean, a2 = v[i].z - mean, a3 = v[i].w - mean;
+      q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+      uint2 ph, pl;
+      ph.x = pack2<T>(v[i].x, v[i].y);
+      ph.y = pack2<T>(v[i].z, v[i].w);
+      pl.x = pack2<T>(lo_part<T>(v[i].x), lo_part<T>(v[i].y));
+      pl.y = pack2<T>(lo_part<T>(v[i].z), lo_part<T>(v[i].w));
+      reinterpret_cast<uint2*>(hi + row * ld16)[c] = ph;
+      reinterpret_cast<uint2*>(lo + row * ld16)[c] = pl;
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+  if (lane == 0) reinterpret_cast<float2*>(mr)[row] = make_float2(mean, rstd);
+}
+
+extern "C" int asis_ln_stats_finalize(void* stream, const float* rowstats, int64_t rows, int groups, int D, float eps, float* mr) {
+  ASIS_REQUIRE(rowstats && mr && rows >= 0 && groups >= 1 && D > 64 * (groups - 1) && D <= 64 * groups,
+               "asis_ln_stats_finalize: bad arguments (rows %ld, groups %d, D %d)", (long)rows, groups, D);
+  if (rows == 0) return ASIS_OK;
+  hipLaunchKernelGGL(ln_stats_finalize_kernel, dim3((unsigned)asis_cdiv(rows, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     rowstats, rows, groups, D, eps, mr);
+  ASIS_CHECK_LAUNCH("asis_ln_stats_finalize");
+  return ASIS_OK;
+}
+
+extern "C" int asis_split_stats(void* stream, int dtype, const float* x, int64_t ldx, void* hi, void* lo, int64_t ld16, float* mr,
+                                int64_t rows, int D, float eps) {
+  ASIS_REQUIRE(x && hi && lo && mr, "asis_split_stats: null pointer");
+  ASIS_REQUIRE(D > 0 && D % 4 == 0 && D <= 256 * LN_MAXC, "asis_split_stats: D=%d must be a multiple of 4 and <= %d", D, 256 * LN_MAXC);
+  ASIS_REQUIRE(ldx % 4 == 0 && ldx >= D && ld16 % 4 == 0 && ld16 >= D, "asis_split_stats: row strides must be multiples of 4 and >= D");
+  ASIS_REQUIRE(asis_aligned16(x) && (((uintptr_t)hi) & 7) == 0 && (((uintptr_t)lo) & 7) == 0, "asis_split_stats: misaligned pointers");
+  ASIS_REQUIRE(dtype == ASIS_F16 || dtype == ASIS_BF16, "asis_split_stats: bad dtype %d", dtype);
+  if (rows <= 0) return ASIS_OK;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  dim3 grid((unsigned)asis_cdiv(rows, 4)), block(256);
+  if (dtype == ASIS_F16)
+    hipLaunchKernelGGL((split_stats_kernel<f16>), grid, block, 0, s, x, ldx, reinterpret_cast<f16*>(hi), reinterpret_cast<f16*>(lo), ld16, mr, rows, D, eps);
+  else
+    hipLaunchKernelGGL((split_stats_kernel<bf16>), grid, block, 0, s, x, ldx, reinterpret_cast<bf16*>(hi), reinterpret_cast<bf16*>(lo), ld16, mr, rows, D, eps);
+  ASIS_CHECK_LAUNCH("asis_split_stats");
+  return ASIS_OK;
+}
+
 extern "C" int asis_layernorm(void* stream, int dtype, const float* x, int64_t ldx, const float* w, const float* b,
                               float eps, void* y, int64_t ldy, int out_f32, int64_t rows, int D) {
   ASIS_REQUIRE(x && w && b && y, "asis_layernorm: null pointer");

@@ -213,15 +213,78 @@ class Attention(_Packed):
             bias = _pack(self._cache, "qkv_b.fold", self.qkv.bias, lambda p: scaled(p).reshape(-1))
         return w, bias, wlo
 
+    def _qkv_ln_folded(self, norm: nn.LayerNorm):
+        """qkv weight with diag(norm.weight) folded in (and the q rows' scale * log2(e) when config.fold_attn_scale), for the
+        LayerNorm-fold chain (config.ln_fold): -> (W' 16-bit [3D, D], b' fp32 [3D] = b + W norm.bias, cs fp32 [3D] = row sums
+        of the ROUNDED W' — what the MFMA really multiplies the mean with)."""
+        c = self.scale * 1.4426950408889634 if config.fold_attn_scale else 1.0
+        D = self.qkv.weight.shape[1]
+        ps = [p for p in (self.qkv.weight, self.qkv.bias, norm.weight, norm.bias) if p is not None]
+        tag = tuple((t.data_ptr(), t._version, getattr(t, "_asis_gen", 0)) for t in ps) + (config.operand_dtype, c)
+        hit = self._cache.get("qkv.lnfold")
+        if hit is None or hit[0] != tag:
+            with torch.no_grad():
+                w = self.qkv.weight.detach().float().clone()
+                w[:D] *= c
+                b = self.qkv.bias.detach().float().clone() if self.qkv.bias is not None else torch.zeros(3 * D, device=w.device)
+                b[:D] *= c
+                b = b + w @ norm.bias.detach().float()
+                w16 = ops.cast_pad((w * norm.weight.detach().float()[None, :]).contiguous(), dtype=config.operand_dtype)
+                self._cache["qkv.lnfold"] = (tag, (w16, b.contiguous(), w16.float().sum(1).contiguous()))
+        return self._cache["qkv.lnfold"][1]
+
     def attend(self, xn: torch.Tensor, B: int, N: int) -> torch.Tensor:
         """xn: 16-bit [B*N, D] (already normalised) -> 16-bit attention output [B*N, D] (before proj)."""
         return self.attend_rows(xn, [(B, N)])[0]
 
-    def attend_rows(self, xn: torch.Tensor, segs):
+    def attend_rows(self, xn: torch.Tensor, segs, ln=None):
         """Several token batches stacked along the rows (``segs`` = [(B, N), ...], e.g. the cls+pos pass and the raw
         patch-token pass of `train.py:287,300-302`): one q|k GEMM over all rows, attention per batch.
-        -> (o, o_lo): o_lo = the rounding residual of o (config.split_attn_out) or None."""
+        -> (o, o_lo): o_lo = the rounding residual of o (config.split_attn_out) or None.
+        ``ln`` = (norm1, mr): ``xn`` is the hi plane of the UN-normalised stream and mr its per-row (mean, rstd): the
+        LayerNorm is folded into the projection weights and undone in the GEMM epilogues (config.ln_fold)."""
         D = xn.shape[1]
+        if ln is not None:
+            norm, mr = ln
+            w, bias, cs = self._qkv_ln_folded(norm)
+            scale = None if config.fold_attn_scale else self.scale
+            o = torch.empty((xn.shape[0], D), device=xn.device, dtype=xn.dtype)
+            o_lo = torch.empty_like(o) if config.split_attn_out else None
+            one_launch = len(segs) == 2
+            ldv_all = (max(n for _, n in segs) + 63) // 64 * 64
+            vt_all = torch.empty((sum(b for b, _ in segs), D, ldv_all), device=xn.device, dtype=xn.dtype)
+            spare = xn.untyped_storage().nbytes() // xn.element_size() - (xn.storage_offset() + xn.shape[0] * D)
+            side = None
+            if one_launch and config.vt_stream:
+                main = torch.cuda.current_stream()
+                side = _vt_side_stream(xn.device)
+                side.wait_stream(main)
+            else:
+                qk = ops.gemm(xn, w[: 2 * D], bias_n=bias[: 2 * D], ln=(mr, cs[: 2 * D], False))
+            r0 = b0 = 0
+            for B, N in segs:
+                r1 = r0 + B * N
+                vt = vt_all[b0:b0 + B]
+                N4 = (N + 7) // 8 * 8      # the 16-bit epilogue that undoes the LayerNorm stores 8 columns per lane
+                if spare < (N4 - N) * D:
+                    raise ValueError("attend_rows(ln=...): the hi plane needs 8 spare rows behind it")
+                with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+                    ops.gemm(w[2 * D:], xn[r0:r1].as_strided((B, N4, D), (N * D, D, 1)),
+                             out=vt.as_strided((B, D, N4), (D * ldv_all, ldv_all, 1)), bias_m=bias[2 * D:], ln=(mr[r0:], cs[2 * D:], True))
+                if not one_launch:
+                    ops.attention_fwd(qk[r0:r1, :D], qk[r0:r1, D:], vt, B, self.num_heads, N, scale, out=o[r0:r1],
+                                      out_lo=None if o_lo is None else o_lo[r0:r1])
+                r0, b0 = r1, b0 + B
+            if side is not None:
+                qk = ops.gemm(xn, w[: 2 * D], bias_n=bias[: 2 * D], ln=(mr, cs[: 2 * D], False))
+                main.wait_stream(side)
+                mr.record_stream(side)
+            if one_launch:
+                (B1, N1), (B2, N2) = segs
+                ops.attention_fwd_seg(qk[:, :D], qk[:, D:], vt_all, B1, N1, B2, N2, self.num_heads, scale, out=o, out_lo=o_lo)
+            if r0 != xn.shape[0]:
+                raise ValueError("attend_rows: segments do not cover the rows")
+            return o, o_lo
         if config.fold_attn_scale:
             w, bias, wlo = self._qkv_folded()       # q rows carry scale * log2(e): asis_attention_fwd_prescaled
             scale = None
@@ -422,6 +485,69 @@ class Block(_Packed):
         return ops.gemm(h, m._w16("w3", m.w3.weight), out_f32=True, bias_n=m._f32("w3_b", m.w3.bias), scale_n=g2, res=x1,
                         a_lo=h_lo, b_lo=self._w16lo_any(m, "w3", m.w3.weight))
 
+    def _lin_ln_folded(self, key: str, lin: nn.Linear, norm: nn.LayerNorm):
+        """(W diag(norm.weight) as 16 bits, b + W norm.bias, row sums of the rounded W') of a linear layer behind a LayerNorm"""
+        ps = [p for p in (lin.weight, lin.bias, norm.weight, norm.bias) if p is not None]
+        tag = tuple((t.data_ptr(), t._version, getattr(t, "_asis_gen", 0)) for t in ps) + (config.operand_dtype,)
+        hit = self._cache.get(key)
+        if hit is None or hit[0] != tag:
+            with torch.no_grad():
+                w = lin.weight.detach().float()
+                b = (lin.bias.detach().float() if lin.bias is not None else torch.zeros(w.shape[0], device=w.device)) + w @ norm.bias.detach().float()
+                w16 = ops.cast_pad((w * norm.weight.detach().float()[None, :]).contiguous(), dtype=config.operand_dtype)
+                self._cache[key] = (tag, (w16, b.contiguous(), w16.float().sum(1).contiguous()))
+        return self._cache[key][1]
+
+    def fold_ok(self, R: int, segs) -> bool:
+        """the LayerNorm-fold chain (config.ln_fold) applies to this block on ``R`` stacked rows: every GEMM involved lands on
+        a kernel that implements the epilogue fields (ops.ln_fold_supported)"""
+        if not (config.ln_fold and config.operand_dtype == torch.float16 and config.precise_level < 2 and not config.precise_attention
+                and not config.fused_qkv and not ops.GEMM_GROUP and isinstance(self.mlp, Mlp) and isinstance(self.ls1, LayerScale)
+                and isinstance(self.ls2, LayerScale) and isinstance(self.norm1, nn.LayerNorm) and isinstance(self.norm2, nn.LayerNorm)):
+            return False
+        D, Hd = self.attn.qkv.weight.shape[1], self.mlp.fc1.weight.shape[0]
+        if config.split_attn_out:      # the producer epilogue lives on the one-tile-per-workgroup form, which takes no split operands
+            return False
+        ok = ops.ln_fold_supported(R, 2 * D, D) and ops.ln_fold_supported(R, D, D, producer=True)
+        ok = ok and ops.ln_fold_supported(R, Hd, D) and ops.ln_fold_supported(R, D, Hd, producer=True)
+        return ok and all(ops.ln_fold_supported(D, (N + 7) // 8 * 8, D, batch=B) for B, N in segs) and D % 64 == 0
+
+    def forward_rows_fold(self, xin, segs, planes_out: bool):
+        """``forward_rows`` on the LayerNorm-fold chain.  ``xin``: fp32 [R, D] (norm1 runs as a kernel, as in ``forward_rows``)
+        or the planes (hi, lo, mr) a previous block left; -> fp32 [R, D], or (hi, lo, mr) when ``planes_out`` (mr = per-row
+        statistics for the NEXT block's norm1: same eps, `vision_transformer.py:89`)."""
+        dt = config.operand_dtype
+        a, m = self.attn, self.mlp
+        g1, g2 = self._f32("g1", self.ls1.gamma), self._f32("g2", self.ls2.gamma)
+        if isinstance(xin, tuple):
+            hi, lo, mr = xin
+            R, D = hi.shape
+            o, o_lo = a.attend_rows(hi, segs, ln=(self.norm1, mr))
+            res_kw = dict(res16=(hi, lo))
+        else:
+            R, D = xin.shape
+            xn = torch.empty((R + 8, D), device=xin.device, dtype=dt)[:R]
+            ops.layernorm(xin, self._f32("n1w", self.norm1.weight), self._f32("n1b", self.norm1.bias), self.norm1.eps, dt, out=xn)
+            o, o_lo = a.attend_rows(xn, segs)
+            res_kw = dict(res=xin)
+        G = (D + 63) // 64
+        x1h = torch.empty((R, D), device=o.device, dtype=dt)
+        x1l = torch.empty((R, D), device=o.device, dtype=dt)
+        st = torch.empty((R, G, 2), device=o.device, dtype=torch.float32)
+        ops.gemm(o, a._w16("proj", a.proj.weight), out=x1h, out_lo=x1l, rowstats=st, bias_n=a._f32("proj_b", a.proj.bias), scale_n=g1,
+                 a_lo=o_lo, **res_kw)
+        mr1 = ops.ln_stats_finalize(st, D, self.norm2.eps)
+        w1, b1, cs1 = self._lin_ln_folded("fc1.lnfold", m.fc1, self.norm2)
+        h = ops.gemm(x1h, w1, bias_n=b1, act=ops.ACT_GELU, ln=(mr1, cs1, False))
+        w2, b2 = m._w16("fc2", m.fc2.weight), m._f32("fc2_b", m.fc2.bias)
+        if not planes_out:
+            return ops.gemm(h, w2, out_f32=True, bias_n=b2, scale_n=g2, res16=(x1h, x1l))
+        x3h = torch.empty((R + 8, D), device=o.device, dtype=dt)[:R]      # spare rows: the next block's V^T GEMM reads past the end
+        x3l = torch.empty((R, D), device=o.device, dtype=dt)
+        st3 = torch.empty((R, G, 2), device=o.device, dtype=torch.float32)
+        ops.gemm(h, w2, out=x3h, out_lo=x3l, rowstats=st3, bias_n=b2, scale_n=g2, res16=(x1h, x1l))
+        return x3h, x3l, ops.ln_stats_finalize(st3, D, self.norm1.eps)
+
     def forward_rows(self, x2: torch.Tensor, segs) -> torch.Tensor:
         """The block on several token batches stacked along the rows of one fp32 [R, D] matrix (``segs`` = [(B, N), ..]).
         Everything but the attention itself is row-wise, so the two ViT passes of the training step (cls + pos-embed
@@ -561,6 +687,21 @@ class Block(_Packed):
             red = ops.reduce_rows(part.view(part.shape[0], 2 * D), inv_scale)
             grads[pre + "norm1.weight"].copy_(red[:D]); grads[pre + "norm1.bias"].copy_(red[D:])
         return dx
+
+
+def run_blocks(blocks, x: torch.Tensor, segs) -> torch.Tensor:
+    """fp32 [R, D] through a run of frozen blocks -> fp32 [R, D].  Where ``Block.fold_ok`` says so the residual stream stays in
+    the two-plane form between the blocks (config.ln_fold): the first block of the run reads fp32 (its norm1 is a kernel), the
+    last one writes fp32, no LayerNorm kernel in between."""
+    state = x
+    R = x.shape[0]
+    n = len(blocks)
+    for i, blk in enumerate(blocks):
+        if blk.fold_ok(R, segs):
+            state = blk.forward_rows_fold(state, segs, planes_out=i + 1 < n and blocks[i + 1].fold_ok(R, segs))
+        else:
+            state = blk.forward_rows(state, segs)
+    return state
 
 
 class NestedTensorBlock(Block):

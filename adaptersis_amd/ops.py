@@ -70,9 +70,12 @@ def _gemm_desc(a: torch.Tensor, b: torch.Tensor, *, out: Optional[torch.Tensor] 
                bias_n: Optional[torch.Tensor] = None, bias_m: Optional[torch.Tensor] = None,
                scale_n: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None, act: int = ACT_NONE,
                stats: Optional[torch.Tensor] = None, a_lo: Optional[torch.Tensor] = None,
-               b_lo: Optional[torch.Tensor] = None, aux: Optional[torch.Tensor] = None):
-    """-> (filled GemmDesc, out tensor, algorithmic flops, algorithmic bytes) of one ``gemm`` call (see ``gemm``)"""
-    _dev(a, b, out, bias_n, bias_m, scale_n, res, stats)
+               b_lo: Optional[torch.Tensor] = None, aux: Optional[torch.Tensor] = None,
+               out_lo: Optional[torch.Tensor] = None, rowstats: Optional[torch.Tensor] = None, res16=None, ln=None):
+    """-> (filled GemmDesc, out tensor, algorithmic flops, algorithmic bytes) of one ``gemm`` call (see ``gemm``).
+    LayerNorm-fold chain (include/asis_hip.h): ``out_lo`` = second 16-bit plane of the output, ``rowstats`` = fp32
+    [M, ceil(N / 64), 2] per-row partial sums, ``res16`` = (hi, lo) planes of the residual, ``ln`` = (mr [rows, 2], cs, cols)."""
+    _dev(a, b, out, bias_n, bias_m, scale_n, res, stats, out_lo, rowstats)
     if a.dtype != b.dtype:
         raise ValueError("gemm operands must have the same 16-bit dtype")
     batch = 1
@@ -121,7 +124,26 @@ def _gemm_desc(a: torch.Tensor, b: torch.Tensor, *, out: Optional[torch.Tensor] 
         if b_lo.stride() != b.stride():
             raise ValueError("gemm: split halves must share the layout of their hi parts")
         d.B_lo = b_lo.data_ptr()
-    nbytes = batch * (2.0 * (M * K + N * K) + M * N * ((4 if out_f32 else 2) + (4 if res is not None else 0)))
+    if out_lo is not None:
+        if out_lo.dtype != out.dtype or out_lo.stride() != out.stride() or out.dtype == torch.float32:
+            raise ValueError("gemm: out_lo must be a 16-bit tensor with the layout of out")
+        d.C_lo = out_lo.data_ptr()
+    if rowstats is not None:
+        if rowstats.dtype != torch.float32 or rowstats.numel() != M * ((N + 63) // 64) * 2 or not rowstats.is_contiguous():
+            raise ValueError("gemm: rowstats must be a contiguous float32 [M, ceil(N / 64), 2] tensor")
+        d.rowstats = rowstats.data_ptr()
+    if res16 is not None:
+        rh, rl = res16
+        _dev(rh, rl)
+        if rh.dtype != a.dtype or rl.dtype != a.dtype or rh.stride() != rl.stride() or rh.stride(-1) != 1 or rh.shape[-2:] != (M, N):
+            raise ValueError("gemm: res16 = (hi, lo) 16-bit [M, N] planes of the operand dtype with equal strides")
+        d.res16, d.res16_lo, d.ldr16 = rh.data_ptr(), rl.data_ptr(), rh.stride(-2)
+    if ln is not None:
+        mr, cs, cols = ln
+        _dev(mr, cs)
+        d.ln_mr, d.ln_cs, d.ln_cols = _f32c(mr).data_ptr(), _f32c(cs).data_ptr(), int(bool(cols))
+    nbytes = batch * (2.0 * (M * K + N * K) + M * N * ((4 if (out_f32 or out_lo is not None) else 2) +
+                                                    (4 if (res is not None or res16 is not None) else 0)))
     return d, out, flops, nbytes
 
 
@@ -137,7 +159,12 @@ def gemm(a: torch.Tensor, b: torch.Tensor, **kw) -> torch.Tensor:
     return out
 
 
-GEMM_GROUP = os.environ.get("ASIS_GEMM_GROUP", "1") not in ("0", "")
+# ASIS_GEMM_GROUP=1: the q|k and V^T projections of an attention as ONE grouped persistent launch (csrc/gemm_p8g.h).  Measured
+# on the headline step (same box, interleaved, profiles/r04_gemm_group_ab.txt): with every launch on one stream the group
+# takes 248 us against 178 + 82 + 67 = 327 us for the three launches (dense launches 875 -> 913 TFLOP/s), but in the timed
+# multi-stream step the V^T GEMMs were already hidden on their side stream next to the other trunk stream's kernels:
+# 209.6 -> 202.3 img/s.  So it is OFF by default and stays available for single-stream callers.
+GEMM_GROUP = os.environ.get("ASIS_GEMM_GROUP", "0") not in ("0", "")
 
 
 def gemm_group(problems):
@@ -247,6 +274,43 @@ def gemm_split(a_hi, a_lo, b_hi, b_lo, *, out: torch.Tensor, bias_n=None):
     gemm(a_lo, b_hi, out=out, res=out)
     gemm(a_hi, b_lo, out=out, res=out)
     return out
+
+
+def ln_fold_supported(M: int, N: int, K: int, batch: int = 1, producer: bool = False) -> bool:
+    """True when ``asis_gemm`` dispatches this dense shape to a kernel that implements the LayerNorm-fold epilogue fields:
+    consumers (``ln=``) the persistent 8-phase kernel or the one-tile-per-workgroup 8-phase form, producers (``out_lo`` /
+    ``rowstats`` / ``res16``) the latter only.  Mirrors csrc/gemm.hip:launch."""
+    if M < 256 or N < 256 or K % 64 or K < 128 or N % 8:
+        return False
+    tiles = ((M + 255) // 256) * ((N + 255) // 256)
+    if not producer and batch == 1 and tiles >= 256 and K <= 2048:
+        return True
+    return K >= 2048 or (K >= 1024 and tiles * batch >= 128)
+
+
+def ln_stats_finalize(rowstats: torch.Tensor, D: int, eps: float = 1e-6) -> torch.Tensor:
+    """per-row partial sums of a GEMM epilogue (``gemm(..., rowstats=)``) -> mr fp32 [rows, 2] = (mean, rstd) of nn.LayerNorm
+    (8 spare rows behind it: a V^T GEMM with a rounded-up token count reads a few statistics past the last row)"""
+    _dev(rowstats)
+    rows, groups = rowstats.shape[0], rowstats.shape[1]
+    mr = torch.empty((rows + 8, 2), device=rowstats.device, dtype=torch.float32)[:rows]
+    check(lib().asis_ln_stats_finalize(_stream(), _f32c(rowstats).data_ptr(), rows, groups, D, float(eps), mr.data_ptr()),
+          "asis_ln_stats_finalize")
+    return mr
+
+
+def split_stats(x: torch.Tensor, dtype: torch.dtype, eps: float = 1e-6):
+    """fp32 [rows, D] -> (hi, lo 16-bit planes, mr fp32 [rows, 2]): entry into the folded-LayerNorm chain"""
+    _dev(x)
+    if x.dtype != torch.float32 or x.dim() != 2 or x.stride(1) != 1:
+        raise ValueError("split_stats: x must be float32 [rows, D] contiguous in D")
+    rows, D = x.shape
+    hi = torch.empty((rows + 8, D), device=x.device, dtype=dtype)[:rows]     # spare rows: Attention.attend_rows reads past the end
+    lo = torch.empty((rows, D), device=x.device, dtype=dtype)
+    mr = torch.empty((rows + 8, 2), device=x.device, dtype=torch.float32)[:rows]
+    check(lib().asis_split_stats(_stream(), _dt(dtype), x.data_ptr(), x.stride(0), hi.data_ptr(), lo.data_ptr(), D, mr.data_ptr(),
+                                 rows, D, float(eps)), "asis_split_stats")
+    return hi, lo, mr
 
 
 def layernorm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float = 1e-6,

@@ -106,7 +106,36 @@ typedef struct asis_gemm_desc {
                                         partial map at C + p * strideC, group 0 adds bias_n; `stats` and `res` must be null.
                                         Sum the parts with asis_reduce_rows, take BatchNorm statistics with asis_colstats.
                                         For layers whose tile count fills only part of the machine (EINVAL elsewhere). */
+  /* ---- LayerNorm folded into the linear layers around it (block.py:89-114: x + ls * f(LN(x)); norm1 / norm2) -------------
+   * The residual stream between two linear layers travels as TWO 16-bit planes, x ~= hi + lo (the same 4 bytes per element as
+   * fp32), with per-row (mean, rstd); the layer that consumes LN(x) takes the hi plane as its A operand directly, with
+   * diag(ln_weight) folded into its weight, and undoes the normalisation in its epilogue:
+   *     LN(x) W^T + b  =  rstd * (x W'^T - mean * cs) + b',   W' = W diag(w_ln),  cs[n] = sum_k W'[n,k],  b' = b + W b_ln
+   * so no LayerNorm kernel (and no extra HBM pass) runs between them.  All fields optional, dense 8-phase kernels only (the
+   * persistent form and the K >= 1024 one-tile-per-workgroup form; ASIS_EINVAL elsewhere, callers then run asis_layernorm):
+   *   C_lo      16-bit output (out_f32 == 0) as two planes: C = (dtype)v, C_lo = (dtype)(v - (float)C); same ldc
+   *   rowstats  fp32 [M, ceil(N / 64), 2]: per row and 64-column group (sum, sum of squares) of the fp32 result v, the input of
+   *             asis_ln_stats_finalize
+   *   res16 / res16_lo / ldr16   the residual as two 16-bit planes instead of fp32 `res` (v += (float)hi + (float)lo)
+   *   ln_mr     fp32 [M, 2] (mean, rstd) per A row (ln_cols != 0: per B row, i.e. per output COLUMN, for the swapped V^T GEMM)
+   *   ln_cs     fp32 [N] cs (ln_cols != 0: [M], per output row); applied BEFORE bias_n / bias_m and the activation */
+  void* C_lo;
+  float* rowstats;
+  const void* res16;
+  const void* res16_lo;
+  int64_t ldr16;
+  const float* ln_mr;
+  const float* ln_cs;
+  int32_t ln_cols;
 } asis_gemm_desc;
+/* (sum, sum of squares) partials [rows, groups, 2] of asis_gemm's rowstats -> mr [rows, 2] = (mean, rstd) of nn.LayerNorm
+ * (biased variance, eps inside the sqrt; vision_transformer.py:89 eps = 1e-6); D = the row length the partials cover, each
+ * group 64 columns (the last one D - 64 (groups - 1)); partials are combined as (count, mean, M2) triples. */
+int asis_ln_stats_finalize(void* stream, const float* rowstats, int64_t rows, int groups, int D, float eps, float* mr);
+/* fp32 [rows, D] (row stride ldx) -> 16-bit planes hi, lo (row stride ld16) + mr [rows, 2]: the entry into the folded
+ * LayerNorm chain for a tensor that no GEMM epilogue produced (patch embedding output, adapter stage outputs). */
+int asis_split_stats(void* stream, int dtype, const float* x, int64_t ldx, void* hi, void* lo, int64_t ld16, float* mr,
+                     int64_t rows, int D, float eps);
 int asis_gemm(void* stream, const asis_gemm_desc* d);
 /* GROUPED launch: up to ASIS_GEMM_GROUP_MAX (8) independent dense problems (each optionally batched) in ONE persistent
  * launch — e.g. the q|k projection and the batched V^T projections of one attention (attention.py:58: one qkv Linear, three
