@@ -36,6 +36,7 @@ class GemmDesc(C.Structure):
         ("A_lo", C.c_void_p), ("B_lo", C.c_void_p),
         ("aux", C.c_void_p), ("ld_aux", C.c_int64),
         ("ksplit", C.c_int32),
+        ("mx_amax_a", C.c_void_p), ("mx_amax_b", C.c_void_p),
         ("C_lo", C.c_void_p), ("rowstats", C.c_void_p), ("res16", C.c_void_p), ("res16_lo", C.c_void_p), ("ldr16", C.c_int64),
         ("ln_mr", C.c_void_p), ("ln_cs", C.c_void_p), ("ln_cols", C.c_int32),
     ]
@@ -78,6 +79,11 @@ SIGNATURES = {
     "asis_gemm": [_vp, C.POINTER(GemmDesc)],
     "asis_gemm_group": [_vp, C.POINTER(GemmDesc), _i],
     "asis_gemm_tiles_m": [_i],
+    "asis_absmax_f32": [_vp, _vp, _i64, _i, _i64, _vp, _i],
+    "asis_bn_relu_absmax": [_vp, _vp, _vp, _vp, _i64, _i, _i, _vp],
+    "asis_bn_relu_upsample_mx": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i],
+    "asis_pack_conv_weight_mx": [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i64, _vp],
+    "asis_decoder_input_mx": [_vp, _i, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i],
     "asis_ln_stats_finalize": [_vp, _vp, _i64, _i, _i, _f, _vp],
     "asis_split_stats": [_vp, _i, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _i, _f],
     "asis_gemm_set_option": [C.c_char_p, _i],

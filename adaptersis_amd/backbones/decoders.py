@@ -76,9 +76,17 @@ def _conv_ksplit(P: int, Cout: int, Cin: int, split: bool) -> int:
     return r
 
 
+def _conv_weights_mx(owner: _Packed, key: str, conv: nn.Conv2d):
+    """(16-bit weight, its MX lo operand (weight side), absolute maximum) — config.mx_conv"""
+    dt = config.operand_dtype
+    w_hi = _pack(owner._cache, key + ".w", conv.weight, lambda p: ops.pack_conv_weight(p.float().contiguous(), 0, dt))
+    w_mx, amax = _pack(owner._cache, key + ".wmx", conv.weight, lambda p: ops.pack_conv_weight_mx(p.float().contiguous(), 0, dt))
+    return w_hi, w_mx, amax
+
+
 def conv_bn_relu_up_forward(owner: _Packed, key: str, x16, x_lo, conv: nn.Conv2d, bn: nn.BatchNorm2d, factor: int,
                             sync_bn: bool, save: bool, training: bool = True, stride: int = 1, pad: int = 1,
-                            pool: bool = False):
+                            pool: bool = False, mx_out: bool = False):
     """(x16, x_lo|None) NHWC -> ((up_hi, up_lo|None), saved stage).  training=False: BatchNorm uses its running
     statistics (``seg_decoder.eval()`` in validate_network, train.py:451) and nothing is saved.  ``stride`` / ``pad``:
     the 3x3 conv's geometry (the CNN encoder's stride-2 stages); ``pool``: MaxPool2d(3, 2, 1) after the ReLU (stem)."""
@@ -89,12 +97,20 @@ def conv_bn_relu_up_forward(owner: _Packed, key: str, x16, x_lo, conv: nn.Conv2d
     split = x_lo is not None
     B, H, W, _ = x16.shape
     OH, OW = (H + 2 * pad - 3) // stride + 1, (W + 2 * pad - 3) // stride + 1
-    w_hi, w_lo = _conv_weights(owner, key, conv, split)
+    # ``x_lo`` tagged with an absolute maximum: it is in the MX form (two fp8 bytes per element; config.mx_conv) and the
+    # weight's lo operand is built likewise — the two correction terms run as one block-scaled fp8 MFMA pass
+    mx_in = getattr(x_lo, "_asis_mx_amax", None) if split else None
+    if mx_in is not None:
+        w_hi, w_lo, w_amax = _conv_weights_mx(owner, key, conv)
+    else:
+        w_hi, w_lo = _conv_weights(owner, key, conv, split)
     bias = owner._f32(key + ".b", conv.bias)
     ks = _conv_ksplit(B * OH * OW, conv.out_channels, x16.shape[3], split)
     stats = torch.empty((ops.gemm_tiles_m(B * OH * OW), 2, conv.out_channels), device=x16.device,
                         dtype=torch.float32) if (training and ks == 1) else None
-    if split:
+    if mx_in is not None:
+        raw = ops.conv_gemm_split(x16, x_lo, w_hi, w_lo, 3, 3, stride, pad, bias_n=bias, stats=stats, ksplit=ks, mx=(mx_in, w_amax))
+    elif split:
         raw = ops.conv_gemm_split(x16, x_lo, w_hi, w_lo, 3, 3, stride, pad, bias_n=bias, stats=stats, ksplit=ks)
     else:
         raw = ops.conv_gemm(x16, w_hi, 3, 3, stride, pad, bias_n=bias, stats=stats, ksplit=ks)
@@ -108,6 +124,10 @@ def conv_bn_relu_up_forward(owner: _Packed, key: str, x16, x_lo, conv: nn.Conv2d
         save = False
     if pool:
         up = ops.bn_relu_maxpool(raw, scale, shift, dt, split_out)
+    elif factor > 1 and mx_out and split_out:
+        # the consumer is a split convolution that takes MX lo operands: the tensor's maximum first (BatchNorm + ReLU of the
+        # low-resolution map; the bilinear upsampling is a convex combination), then the fused kernel writes hi + MX
+        up = ops.bn_relu_upsample(raw, scale, shift, factor, dt, True, mx_amax=ops.bn_relu_absmax(raw, scale, shift))
     elif factor > 1:
         up = ops.bn_relu_upsample(raw, scale, shift, factor, dt, split_out)
     else:
@@ -242,7 +262,13 @@ class FeatureDecoder(_Packed):
         a = (x16, x_lo)
         for i in range(1, 5):
             seq = getattr(self, f"decoder_{i}")
-            a, st = conv_bn_relu_up_forward(self, f"d{i}", a[0], a[1], seq[0], seq[1], 2, self.sync_bn, save, training)
+            # stages 1..3 feed a split 3x3 convolution (MX lo operands where config.mx_conv and the shapes allow); stage 4 feeds
+            # the classifier conv, which takes the 16-bit residuals
+            nxt = getattr(self, f"decoder_{i + 1}")[0] if i < 4 else None
+            Bq, Hq, Wq, _ = a[0].shape
+            mx_out = bool(config.mx_conv and a[1] is not None and nxt is not None and f"d{i + 1}" not in config.unsplit_layers and
+                          ops.mx_conv_ok(Bq * 4 * Hq * Wq, nxt.in_channels, nxt.out_channels))
+            a, st = conv_bn_relu_up_forward(self, f"d{i}", a[0], a[1], seq[0], seq[1], 2, self.sync_bn, save, training, mx_out=mx_out)
             saved.append(st)
         logits = self._final_forward(a)
         saved.append(a[0] if save else None)

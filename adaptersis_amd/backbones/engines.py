@@ -350,8 +350,11 @@ class SegEngine(nn.Module):
                 taps.update(x_final=x, c_final=c2d.view(B, Lc, D), cat=hi)
             return hi, lo
         n4 = shapes[2][0] * shapes[2][1]
+        d1 = getattr(self.seg_decoder, "decoder_1", None)     # FeatureDecoder: its first conv takes MX lo operands (config.mx_conv)
+        mx = bool(config.mx_conv and config.split_conv and d1 is not None and "d1" not in config.unsplit_layers and
+                  ops.mx_conv_ok(B * h * w, 3 * D, d1[0].out_channels))
         cat = ops.decoder_input(x, c_orig[:, Lc - n4:], feats[-1], (h, w), shapes[2], config.operand_dtype,
-                                config.split_conv)
+                                config.split_conv, mx=mx)
         if not config.split_conv:
             cat = (cat, None)
         if taps is not None:

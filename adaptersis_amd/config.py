@@ -117,3 +117,11 @@ elide_dead_cacnn = os.environ.get("ASIS_ELIDE_DEAD_CACNN", "1") not in ("0", "")
 # precise_level 0, shapes on the 8-phase kernels (>= 256 tiles: the headline batch); everything else runs asis_layernorm as
 # before.  ASIS_LN_FOLD=0 disables it.
 ln_fold = os.environ.get("ASIS_LN_FOLD", "1") not in ("0", "")
+
+# MX correction operands of the split forward convolutions (include/asis_hip.h: asis_gemm_desc.mx_amax_a / mx_amax_b): the
+# rounding residuals of activations and weights travel as two fp8 (e4m3) bytes per element with ONE power-of-two scale per
+# tensor, and the two correction terms of a split convolution (x_lo w_hi + x_hi w_lo, which need ~3 significant bits) run as
+# ONE block-scaled fp8 MFMA pass (v_mfma_scale_f32_16x16x128_f8f6f4) instead of two 16-bit passes: 2/3 of the MFMA time of a
+# split convolution.  Applies where the producing kernel can write the MX form (FeatureDecoder stages; Cin % 64 == 0).
+# ASIS_MX_CONV=0: the three 16-bit parts as before.
+mx_conv = os.environ.get("ASIS_MX_CONV", "1") not in ("0", "")

@@ -85,6 +85,51 @@ template <typename T> __device__ __forceinline__ void unpack2(uint32_t w, float&
   b = (float)v[1];
 }
 
+// ----- MX correction operands (block-scaled fp8 MFMA, v_mfma_scale_f32_16x16x128_f8f6f4; layout facts: scripts/mx_probe.hip) ----
+// A split-precision product x w ~= xh wh + (xl wh + xh wl) spends two of its three MFMA passes on correction terms that need ~3
+// significant bits.  MX form of the "lo" operand: per element TWO fp8 (e4m3) bytes in the place of the one 16-bit rounding
+// residual — activations (A side) as (hi8, lo8), weights (B side) as (lo8, hi8) — so that ONE scaled-fp8 MFMA pass over the
+// same [rows][K] x 2-byte layout pairs byte with byte: hi8(x) lo8(w) + lo8(x) hi8(w) = both correction terms, at twice the f16
+// rate per byte.  hi8 = fp8(v 2^(7 - e)), lo8 = fp8((v - (T)v) 2^(LO - e)), e = floor(log2(amax of the tensor)), LO = 18 for
+// f16 (|residual| <= 2^(e - 11)), 15 for bf16: both scaled maxima stay <= 2^8 (e4m3 saturates to NaN above 448: values are
+// clamped as well), and the two terms share ONE dequantisation exponent eA + eB - 7 - LO (per-tensor power-of-two scales).
+struct MxScale { float sh, sl; };
+template <typename T> struct MxLo;
+template <> struct MxLo<f16> { static constexpr int v = 18; };
+template <> struct MxLo<bf16> { static constexpr int v = 15; };
+template <typename T> __device__ __forceinline__ constexpr int mx_lo_shift() { return MxLo<T>::v; }
+__device__ __forceinline__ int mx_exp(float amax) {
+  int e = (int)((__builtin_bit_cast(uint32_t, amax) >> 23) & 0xFF) - 127;
+  return e < -100 ? -100 : (e > 100 ? 100 : e);
+}
+template <typename T> __device__ __forceinline__ MxScale mx_scales(float amax) {
+  const int e = mx_exp(amax);
+  MxScale s;
+  s.sh = __builtin_bit_cast(float, (uint32_t)(127 + 7 - e) << 23);
+  s.sl = __builtin_bit_cast(float, (uint32_t)(127 + mx_lo_shift<T>() - e) << 23);
+  return s;
+}
+// E8M0 scale byte of the A operand of the correction pass (the B operand carries 127 = 1.0)
+template <typename T> __device__ __forceinline__ int mx_code(float amax_a, float amax_b) {
+  const int c = 127 + mx_exp(amax_a) + mx_exp(amax_b) - 7 - mx_lo_shift<T>();
+  return c < 1 ? 1 : (c > 254 ? 254 : c);
+}
+// two elements -> one 32-bit word of four fp8: (hi8, lo8) pairs, or (lo8, hi8) for the weight side
+template <typename T> __device__ __forceinline__ uint32_t mx_pack2(float x0, float x1, MxScale s, bool wside) {
+  const float h0 = (float)((T)x0), h1 = (float)((T)x1);
+  const float a0 = __builtin_amdgcn_fmed3f(h0 * s.sh, -448.f, 448.f), b0 = __builtin_amdgcn_fmed3f((x0 - h0) * s.sl, -448.f, 448.f);
+  const float a1 = __builtin_amdgcn_fmed3f(h1 * s.sh, -448.f, 448.f), b1 = __builtin_amdgcn_fmed3f((x1 - h1) * s.sl, -448.f, 448.f);
+  int w = 0;
+  w = wside ? __builtin_amdgcn_cvt_pk_fp8_f32(b0, a0, w, false) : __builtin_amdgcn_cvt_pk_fp8_f32(a0, b0, w, false);
+  w = wside ? __builtin_amdgcn_cvt_pk_fp8_f32(b1, a1, w, true) : __builtin_amdgcn_cvt_pk_fp8_f32(a1, b1, w, true);
+  return (uint32_t)w;
+}
+// the "lo" word of two elements: the 16-bit rounding residuals, or the MX form when ``amax`` is given
+template <typename T> __device__ __forceinline__ uint32_t lo_word2(float x0, float x1, const float* amax, bool wside = false) {
+  if (amax) return mx_pack2<T>(x0, x1, mx_scales<T>(*amax), wside);
+  return pack2<T>(lo_part<T>(x0), lo_part<T>(x1));
+}
+
 // ----- wave64 reductions -------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const float* __res
 template <typename T>
 __global__ __launch_bounds__(256) void bn_relu_upsample_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                                                const float* __restrict__ shift, T* __restrict__ out,
-                                                               T* __restrict__ out_lo, int B, int H, int W, int OH,
+                                                               T* __restrict__ out_lo, const float* __restrict__ mx_amax, int B, int H, int W, int OH,
                                                                int OW, int C) {
   const int cpt = C >> 2;
   const float rh = OH > 1 ? (float)(H - 1) / (float)(OH - 1) : 0.f;
@@ -267,8 +267,8 @@ __global__ __launch_bounds__(256) void bn_relu_upsample_kernel(const float* __re
     o.y = pack2<T>(acc.z, acc.w);
     reinterpret_cast<uint2*>(out + pix * C)[c] = o;
     if (out_lo) {
-      o.x = pack2<T>(lo_part<T>(acc.x), lo_part<T>(acc.y));
-      o.y = pack2<T>(lo_part<T>(acc.z), lo_part<T>(acc.w));
+      o.x = lo_word2<T>(acc.x, acc.y, mx_amax);
+      o.y = lo_word2<T>(acc.z, acc.w, mx_amax);
       reinterpret_cast<uint2*>(out_lo + pix * C)[c] = o;
     }
   }
@@ -281,7 +281,8 @@ __global__ __launch_bounds__(256) void bn_relu_upsample_kernel(const float* __re
 template <typename T>
 __global__ __launch_bounds__(256) void bn_relu_upsample8_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                                                 const float* __restrict__ shift, T* __restrict__ out,
-                                                                T* __restrict__ out_lo, int H, int W, int OH, int OW, int C) {
+                                                                T* __restrict__ out_lo, int H, int W, int OH, int OW, int C,
+                                                                const float* __restrict__ mx_amax) {
   constexpr int ROWS = 4;  // output rows per thread: 4x fewer waves to launch for the same bytes, source rows re-read from L1
   const int cp8 = C >> 3;
   // XCD-aware order: consecutive output rows re-read the same two source rows, so every XCD (one L2 each, blocks dealt
@@ -340,9 +341,9 @@ __global__ __launch_bounds__(256) void bn_relu_upsample8_kernel(const float* __r
     o.x = pack2<T>(acc[0], acc[1]); o.y = pack2<T>(acc[2], acc[3]);
     o.z = pack2<T>(acc[4], acc[5]); o.w = pack2<T>(acc[6], acc[7]);
     reinterpret_cast<uint4*>(out)[o8] = o;
-    if (out_lo) {
-      o.x = pack2<T>(lo_part<T>(acc[0]), lo_part<T>(acc[1])); o.y = pack2<T>(lo_part<T>(acc[2]), lo_part<T>(acc[3]));
-      o.z = pack2<T>(lo_part<T>(acc[4]), lo_part<T>(acc[5])); o.w = pack2<T>(lo_part<T>(acc[6]), lo_part<T>(acc[7]));
+    if (out_lo) {   // rounding residuals, or their MX form (asis_common.h) when the tensor's absolute maximum is given
+      o.x = lo_word2<T>(acc[0], acc[1], mx_amax); o.y = lo_word2<T>(acc[2], acc[3], mx_amax);
+      o.z = lo_word2<T>(acc[4], acc[5], mx_amax); o.w = lo_word2<T>(acc[6], acc[7], mx_amax);
       reinterpret_cast<uint4*>(out_lo)[o8] = o;
     }
   }
@@ -354,7 +355,7 @@ __global__ __launch_bounds__(256) void bn_relu_upsample8_kernel(const float* __r
 template <typename T>
 __global__ __launch_bounds__(256) void pack_conv_weight_kernel(const float* __restrict__ w, T* __restrict__ out,
                                                                int Cout, int Cin, int KH, int KW, int mode, int CoP,
-                                                               int64_t ldo, int rows, int part) {
+                                                               int64_t ldo, int rows, int part, const float* __restrict__ mx_amax) {
   const int64_t total = (int64_t)rows * ldo;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int r = (int)(i / ldo);
@@ -373,7 +374,12 @@ __global__ __launch_bounds__(256) void pack_conv_weight_kernel(const float* __re
         if (co < Cout) v = w[(((int64_t)co * Cin + r) * KH + kh) * KW + kw];
       }
     }
-    out[i] = to_t16<T>(part ? lo_part<T>(v) : v);
+    if (part == 2) {   // MX form of the lo operand, weight side: (lo8, hi8) in the element's two bytes
+      const uint32_t wd = mx_pack2<T>(v, 0.f, mx_scales<T>(*mx_amax), true);
+      reinterpret_cast<uint16_t*>(out)[i] = (uint16_t)(wd & 0xFFFFu);
+    } else {
+      out[i] = to_t16<T>(part ? lo_part<T>(v) : v);
+    }
   }
 }
 
@@ -383,7 +389,7 @@ __global__ __launch_bounds__(256) void decoder_input_kernel(const float* __restr
                                                             const float* __restrict__ c4, int64_t c4_bstride,
                                                             const float* __restrict__ vit, int64_t vit_bstride,
                                                             T* __restrict__ out, T* __restrict__ out_lo, int B, int h,
-                                                            int w, int h4, int w4, int D) {
+                                                            int w, int h4, int w4, int D, const float* __restrict__ mx_amax) {
   const int cpt = (3 * D) >> 2;
   const int dq = D >> 2;
   const int py = (h - h4) / 2, px = (w - w4) / 2;  // F.pad([dx//2, dx-dx//2, dy//2, dy-dy//2])
@@ -409,11 +415,44 @@ __global__ __launch_bounds__(256) void decoder_input_kernel(const float* __restr
     o.y = pack2<T>(v.z, v.w);
     reinterpret_cast<uint2*>(out + pix * 3 * D)[c] = o;
     if (out_lo) {
-      o.x = pack2<T>(lo_part<T>(v.x), lo_part<T>(v.y));
-      o.y = pack2<T>(lo_part<T>(v.z), lo_part<T>(v.w));
+      o.x = lo_word2<T>(v.x, v.y, mx_amax);
+      o.y = lo_word2<T>(v.z, v.w, mx_amax);
       reinterpret_cast<uint2*>(out_lo + pix * 3 * D)[c] = o;
     }
   }
+}
+
+// |x| maximum of an fp32 tensor [rows, cols] (row stride ld) -> atomicMax on the bit pattern (non-negative floats order like
+// their bits); the caller zeroes *amax first (asis_absmax_f32 does, unless it accumulates over several tensors)
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, int64_t rows, int cols, int64_t ld, float* __restrict__ amax) {
+  const int c4 = cols >> 2;
+  const int64_t total = rows * c4;
+  float m = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / c4;
+    const float4 v = reinterpret_cast<const float4*>(x + r * ld)[i - r * c4];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned int*>(amax), __builtin_bit_cast(unsigned int, m));
+}
+// the same of relu(x * scale[c] + shift[c]) (the tensor a BatchNorm + ReLU (+ bilinear upsampling: a convex combination) kernel
+// is about to write), x fp32 [P, C]
+__global__ __launch_bounds__(256) void bn_relu_absmax_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, int64_t P, int C, int relu, float* __restrict__ amax) {
+  const int c4 = C >> 2;
+  const int64_t total = P * c4;
+  float m = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % c4);
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    const float4 sc = reinterpret_cast<const float4*>(scale)[c], sh = reinterpret_cast<const float4*>(shift)[c];
+    float a0 = v.x * sc.x + sh.x, a1 = v.y * sc.y + sh.y, a2 = v.z * sc.z + sh.z, a3 = v.w * sc.w + sh.w;
+    if (!relu) { a0 = fabsf(a0); a1 = fabsf(a1); a2 = fabsf(a2); a3 = fabsf(a3); }
+    m = fmaxf(fmaxf(m, fmaxf(a0, a1)), fmaxf(a2, a3));
+  }
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned int*>(amax), __builtin_bit_cast(unsigned int, m));
 }
 
 // SwiGLU gate (dinov2/layers/swiglu_ffn.py:30-34): x12 fp32 [R, 2*Hd] -> silu(x1) * x2 as 16-bit [R, Hd]
@@ -566,8 +605,8 @@ extern "C" int asis_bn_relu_maxpool(void* stream, int dtype, const float* x, con
   return ASIS_OK;
 }
 
-extern "C" int asis_bn_relu_upsample(void* stream, int dtype, const float* x, const float* scale, const float* shift,
-                                     void* out, void* out_lo, int B, int H, int W, int C, int factor) {
+static int bn_relu_upsample_impl(void* stream, int dtype, const float* x, const float* scale, const float* shift, void* out, void* out_lo,
+                                 const float* mx_amax, int B, int H, int W, int C, int factor) {
   ASIS_REQUIRE(x && scale && shift && out, "asis_bn_relu_upsample: null pointer");
   ASIS_REQUIRE(C % 4 == 0 && C > 0 && factor >= 1, "asis_bn_relu_upsample: bad C=%d / factor=%d", C, factor);
   DT_OK(dtype, "asis_bn_relu_upsample");
@@ -580,26 +619,60 @@ extern "C" int asis_bn_relu_upsample(void* stream, int dtype, const float* x, co
     const dim3 grid8((unsigned)gx8, (unsigned)asis_cdiv(OH, 4), (unsigned)B);  // 4 = ROWS of the kernel
     if (dtype == ASIS_F16)
       hipLaunchKernelGGL((bn_relu_upsample8_kernel<f16>), grid8, dim3(256), 0, s, x, scale, shift, reinterpret_cast<f16*>(out),
-                         reinterpret_cast<f16*>(out_lo), H, W, OH, OW, C);
+                         reinterpret_cast<f16*>(out_lo), H, W, OH, OW, C, mx_amax);
     else
       hipLaunchKernelGGL((bn_relu_upsample8_kernel<bf16>), grid8, dim3(256), 0, s, x, scale, shift, reinterpret_cast<bf16*>(out),
-                         reinterpret_cast<bf16*>(out_lo), H, W, OH, OW, C);
+                         reinterpret_cast<bf16*>(out_lo), H, W, OH, OW, C, mx_amax);
     ASIS_CHECK_LAUNCH("asis_bn_relu_upsample");
     return ASIS_OK;
   }
   if (dtype == ASIS_F16)
     hipLaunchKernelGGL((bn_relu_upsample_kernel<f16>), dim3(grid_for(total)), dim3(256), 0, s, x, scale, shift,
-                       reinterpret_cast<f16*>(out), reinterpret_cast<f16*>(out_lo), B, H, W, OH, OW, C);
+                       reinterpret_cast<f16*>(out), reinterpret_cast<f16*>(out_lo), mx_amax, B, H, W, OH, OW, C);
   else
     hipLaunchKernelGGL((bn_relu_upsample_kernel<bf16>), dim3(grid_for(total)), dim3(256), 0, s, x, scale, shift,
-                       reinterpret_cast<bf16*>(out), reinterpret_cast<bf16*>(out_lo), B, H, W, OH, OW, C);
+                       reinterpret_cast<bf16*>(out), reinterpret_cast<bf16*>(out_lo), mx_amax, B, H, W, OH, OW, C);
   ASIS_CHECK_LAUNCH("asis_bn_relu_upsample");
   return ASIS_OK;
 }
 
-extern "C" int asis_pack_conv_weight(void* stream, int dtype, const float* w, void* out, int Cout, int Cin, int KH,
-                                     int KW, int mode, int64_t ldo, int part) {
+extern "C" int asis_bn_relu_upsample(void* stream, int dtype, const float* x, const float* scale, const float* shift,
+                                     void* out, void* out_lo, int B, int H, int W, int C, int factor) {
+  return bn_relu_upsample_impl(stream, dtype, x, scale, shift, out, out_lo, nullptr, B, H, W, C, factor);
+}
+extern "C" int asis_bn_relu_upsample_mx(void* stream, int dtype, const float* x, const float* scale, const float* shift,
+                                        void* out, void* out_mx, const float* amax, int B, int H, int W, int C, int factor) {
+  ASIS_REQUIRE(out_mx && amax, "asis_bn_relu_upsample_mx: null pointer");
+  return bn_relu_upsample_impl(stream, dtype, x, scale, shift, out, out_mx, amax, B, H, W, C, factor);
+}
+
+extern "C" int asis_absmax_f32(void* stream, const float* x, int64_t rows, int cols, int64_t ld, float* amax, int reset) {
+  ASIS_REQUIRE(x && amax && rows >= 0 && cols > 0 && cols % 4 == 0 && ld % 4 == 0 && ld >= cols && asis_aligned16(x),
+               "asis_absmax_f32: null pointer, or cols / ld not multiples of 4, or misaligned");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (reset) ASIS_REQUIRE(hipMemsetAsync(amax, 0, sizeof(float), s) == hipSuccess, "asis_absmax_f32: memset failed");
+  if (rows == 0) return ASIS_OK;
+  hipLaunchKernelGGL(absmax_kernel, dim3(grid_for(rows * (cols / 4), 256, 1024)), dim3(256), 0, s, x, rows, cols, ld, amax);
+  ASIS_CHECK_LAUNCH("asis_absmax_f32");
+  return ASIS_OK;
+}
+
+extern "C" int asis_bn_relu_absmax(void* stream, const float* x, const float* scale, const float* shift, int64_t P, int C, int relu,
+                                   float* amax) {
+  ASIS_REQUIRE(x && scale && shift && amax && P >= 0 && C > 0 && C % 4 == 0 && asis_aligned16(x) && asis_aligned16(scale) && asis_aligned16(shift),
+               "asis_bn_relu_absmax: null pointer, C not a multiple of 4, or misaligned");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  ASIS_REQUIRE(hipMemsetAsync(amax, 0, sizeof(float), s) == hipSuccess, "asis_bn_relu_absmax: memset failed");
+  if (P == 0) return ASIS_OK;
+  hipLaunchKernelGGL(bn_relu_absmax_kernel, dim3(grid_for(P * (C / 4), 256, 1024)), dim3(256), 0, s, x, scale, shift, P, C, relu, amax);
+  ASIS_CHECK_LAUNCH("asis_bn_relu_absmax");
+  return ASIS_OK;
+}
+
+static int pack_conv_weight_impl(void* stream, int dtype, const float* w, void* out, int Cout, int Cin, int KH, int KW, int mode,
+                                 int64_t ldo, int part, const float* mx_amax) {
   ASIS_REQUIRE(w && out, "asis_pack_conv_weight: null pointer");
+  ASIS_REQUIRE(part >= 0 && part <= 2 && (part != 2 || mx_amax), "asis_pack_conv_weight: part 2 (MX weight side) needs amax");
   ASIS_REQUIRE(mode == 0 || mode == 1, "asis_pack_conv_weight: bad mode %d", mode);
   DT_OK(dtype, "asis_pack_conv_weight");
   const int CoP = (Cout + 7) / 8 * 8;
@@ -610,17 +683,27 @@ extern "C" int asis_pack_conv_weight(void* stream, int dtype, const float* w, vo
   const int64_t total = (int64_t)rows * ldo;
   if (dtype == ASIS_F16)
     hipLaunchKernelGGL((pack_conv_weight_kernel<f16>), dim3(grid_for(total)), dim3(256), 0, s, w,
-                       reinterpret_cast<f16*>(out), Cout, Cin, KH, KW, mode, CoP, ldo, rows, part);
+                       reinterpret_cast<f16*>(out), Cout, Cin, KH, KW, mode, CoP, ldo, rows, part, mx_amax);
   else
     hipLaunchKernelGGL((pack_conv_weight_kernel<bf16>), dim3(grid_for(total)), dim3(256), 0, s, w,
-                       reinterpret_cast<bf16*>(out), Cout, Cin, KH, KW, mode, CoP, ldo, rows, part);
+                       reinterpret_cast<bf16*>(out), Cout, Cin, KH, KW, mode, CoP, ldo, rows, part, mx_amax);
   ASIS_CHECK_LAUNCH("asis_pack_conv_weight");
   return ASIS_OK;
 }
 
-extern "C" int asis_decoder_input(void* stream, int dtype, const float* xs, int64_t xs_bstride, const float* c4,
-                                  int64_t c4_bstride, const float* vit, int64_t vit_bstride, void* out, void* out_lo,
-                                  int B, int h, int w, int h4, int w4, int D) {
+extern "C" int asis_pack_conv_weight(void* stream, int dtype, const float* w, void* out, int Cout, int Cin, int KH,
+                                     int KW, int mode, int64_t ldo, int part) {
+  ASIS_REQUIRE(part == 0 || part == 1, "asis_pack_conv_weight: part must be 0 or 1");
+  return pack_conv_weight_impl(stream, dtype, w, out, Cout, Cin, KH, KW, mode, ldo, part, nullptr);
+}
+extern "C" int asis_pack_conv_weight_mx(void* stream, int dtype, const float* w, void* out_mx, int Cout, int Cin, int KH,
+                                        int KW, int mode, int64_t ldo, const float* amax) {
+  return pack_conv_weight_impl(stream, dtype, w, out_mx, Cout, Cin, KH, KW, mode, ldo, 2, amax);
+}
+
+static int decoder_input_impl(void* stream, int dtype, const float* xs, int64_t xs_bstride, const float* c4,
+                              int64_t c4_bstride, const float* vit, int64_t vit_bstride, void* out, void* out_lo,
+                              int B, int h, int w, int h4, int w4, int D, const float* mx_amax) {
   ASIS_REQUIRE(xs && c4 && vit && out, "asis_decoder_input: null pointer");
   ASIS_REQUIRE(D % 4 == 0 && h4 <= h && w4 <= w, "asis_decoder_input: bad shape");
   ASIS_REQUIRE(c4_bstride % 4 == 0 && xs_bstride % 4 == 0 && vit_bstride % 4 == 0 && asis_aligned16(xs) &&
@@ -630,12 +713,24 @@ extern "C" int asis_decoder_input(void* stream, int dtype, const float* xs, int6
   const int64_t total = (int64_t)B * h * w * (3 * D / 4);
   if (dtype == ASIS_F16)
     hipLaunchKernelGGL((decoder_input_kernel<f16>), dim3(grid_for(total)), dim3(256), 0, s, xs, xs_bstride, c4, c4_bstride, vit,
-                       vit_bstride, reinterpret_cast<f16*>(out), reinterpret_cast<f16*>(out_lo), B, h, w, h4, w4, D);
+                       vit_bstride, reinterpret_cast<f16*>(out), reinterpret_cast<f16*>(out_lo), B, h, w, h4, w4, D, mx_amax);
   else
     hipLaunchKernelGGL((decoder_input_kernel<bf16>), dim3(grid_for(total)), dim3(256), 0, s, xs, xs_bstride, c4, c4_bstride, vit,
-                       vit_bstride, reinterpret_cast<bf16*>(out), reinterpret_cast<bf16*>(out_lo), B, h, w, h4, w4, D);
+                       vit_bstride, reinterpret_cast<bf16*>(out), reinterpret_cast<bf16*>(out_lo), B, h, w, h4, w4, D, mx_amax);
   ASIS_CHECK_LAUNCH("asis_decoder_input");
   return ASIS_OK;
+}
+
+extern "C" int asis_decoder_input(void* stream, int dtype, const float* xs, int64_t xs_bstride, const float* c4,
+                                  int64_t c4_bstride, const float* vit, int64_t vit_bstride, void* out, void* out_lo,
+                                  int B, int h, int w, int h4, int w4, int D) {
+  return decoder_input_impl(stream, dtype, xs, xs_bstride, c4, c4_bstride, vit, vit_bstride, out, out_lo, B, h, w, h4, w4, D, nullptr);
+}
+extern "C" int asis_decoder_input_mx(void* stream, int dtype, const float* xs, int64_t xs_bstride, const float* c4,
+                                     int64_t c4_bstride, const float* vit, int64_t vit_bstride, void* out, void* out_mx,
+                                     const float* amax, int B, int h, int w, int h4, int w4, int D) {
+  ASIS_REQUIRE(out_mx && amax, "asis_decoder_input_mx: null pointer");
+  return decoder_input_impl(stream, dtype, xs, xs_bstride, c4, c4_bstride, vit, vit_bstride, out, out_mx, B, h, w, h4, w4, D, amax);
 }
 
 extern "C" int asis_swiglu_split(void* stream, int dtype, const float* x12, void* out, void* out_lo, int64_t R, int Hd) {

@@ -278,6 +278,25 @@ int launch(hipStream_t s, const asis_gemm_desc& d) {
     const int bm = 256, bn = d.N > 64 ? 128 : 64;
     if (d.ksplit > 1 && (d.batch != 1 || d.stats || (d.KH * d.KW) % d.ksplit != 0 || !d.out_f32 || d.res)) return ASIS_EINVAL;
     dim3 grid(((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn), d.ksplit > 1 ? d.ksplit : d.batch), block(512);
+    if (d.mx_amax_a || d.mx_amax_b) {
+      // MX form of the lo operands (include/asis_hip.h): two K parts, the second on the block-scaled fp8 MFMA; 16x16 MFMA
+      // instances of the three convolution tile forms
+      if (!(d.conv && d.mx_amax_a && d.mx_amax_b && d.A_lo && d.B_lo)) return ASIS_EINVAL;
+      if ((int64_t)d.B_ * d.H * d.W * d.Cin >= (1ll << 31) || (int64_t)d.N * d.ldb >= (1ll << 31) || d.H >= 65536 || d.W >= 65536) return ASIS_EINVAL;
+      static const int mx_ph8 = [] { const char* e = getenv("ASIS_MX_PH8"); return e ? atoi(e) : 1; }();   // lab: 0 = generic forms only
+      if (mx_ph8 && d.N >= 256 && (d.N % 256 == 0 || d.N >= 1024) && d.batch == 1) {
+        dim3 g8(((d.M + 255) / 256) * ((d.N + 255) / 256), d.ksplit > 1 ? d.ksplit : 1);
+        hipLaunchKernelGGL((gemm_big_kernel<T, 2, 4, 4, 2, 2, 0, true, true, 64, 1, true, true, 0, true>), g8, block, 0, s, d, group_m);
+      } else if (bn == 64 && d.ksplit <= 1 && d.M >= 512) {
+        dim3 g512(((d.M + 511) / 512) * ((d.N + 63) / 64), 1);
+        hipLaunchKernelGGL((gemm_big_kernel<T, 8, 1, 2, 2, 2, 0, true, true, 64, 1, false, true, 0, true>), g512, block, 0, s, d, group_m);
+      } else if (bn == 128) {
+        hipLaunchKernelGGL((gemm_big_kernel<T, 4, 2, 2, 2, 3, 0, true, true, 64, 1, false, true, 0, true>), grid, block, 0, s, d, group_m);
+      } else {
+        hipLaunchKernelGGL((gemm_big_kernel<T, 8, 1, 1, 2, 3, 0, true, true, 64, 1, false, true, 0, true>), grid, block, 0, s, d, group_m);
+      }
+      return 0;
+    }
     static const int conv32 = [] { const char* e = getenv("ASIS_CONV_BK32"); return e ? atoi(e) : 0; }();
     // <= 64 output channels: 512x64 tile, 8 waves of 64x64 (1 KB of LDS fragment reads per MFMA; the 256x64 form's 32x64
     // wave tiles need 1.5 KB and are LDS-bound), one workgroup per CU: +0.6 % on the step (ASIS_CONV_T512=0: old form)

@@ -1,5 +1,7 @@
 // Large-tile LDS-DMA GEMM kernel (included by gemm.hip and by scripts/gemm_lab.hip).
 #pragma once
+#include <type_traits>
+
 #include "asis_common.h"
 
 namespace {
@@ -19,11 +21,31 @@ namespace {
 __device__ __attribute__((aligned(16))) uint4 g_zero_page[1];
 
 template <typename T, int WM, int WN, int TM, int TN, int NS, int DBG = 0, bool CONV = false, bool SPLIT = false, int BKT = 64,
-          int OCC = 2, bool PH8 = false, bool M16 = false, int LNF = 0>
+          int OCC = 2, bool PH8 = false, bool M16 = false, int LNF = 0, bool MXC = false>
 __global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_big_kernel(const asis_gemm_desc d, const int GROUP_M_FLAGS) {
   const int GROUP_M = GROUP_M_FLAGS & 0xffff;        // raster group height; bit 16 (lab): fp32 slab epilogue for every output type
   static_assert(!PH8 || (WM == 2 && WN == 4 && TM == 4 && TN == 2 && NS == 2 && BKT == 64),
                 "the 8-phase main loop is written for the 256x256x64 tile, 2x4 waves of 128x64");
+  // MXC: split convolution whose lo operands are in the MX form (asis_common.h: two fp8 bytes per element, activations
+  // (hi8, lo8), weights (lo8, hi8)): TWO K parts instead of three — (A, B) on the 16-bit MFMA, then (A_mx, B_mx) on
+  // v_mfma_scale_f32_16x16x128_f8f6f4, whose byte-with-byte products are both correction terms at once.  Same LDS image, same
+  // staging and fragment reads as a 16-bit part (a row of a K tile is 128 bytes = 64 elements either way); the two ks
+  // fragments of a lane are the two halves of its 32-byte fp8 operand (K pairing: scripts/mx_probe.hip).
+  static_assert(!MXC || (CONV && SPLIT && M16 && BKT == 64), "the MX correction pass is built for split convolutions on 16x16 MFMAs");
+  typedef int v4i_ __attribute__((ext_vector_type(4)));
+  typedef int v8i_ __attribute__((ext_vector_type(8)));
+  auto cat8 = [](auto lo8, auto hi8) -> v8i_ {
+    return __builtin_shufflevector(__builtin_bit_cast(v4i_, lo8), __builtin_bit_cast(v4i_, hi8), 0, 1, 2, 3, 4, 5, 6, 7);
+  };
+  const int mx_sc = MXC ? mx_code<T>(*d.mx_amax_a, *d.mx_amax_b) : 0;   // E8M0 scale of the correction pass (wave-uniform)
+  // The scaled MFMA through inline asm with the accumulator TIED (dst = C): the builtin's result landed in a fresh register
+  // tuple (v_mfma_scale ... v[66:69], ..., v[166:169]), i.e. four copies per MFMA and 19 spilled VGPRs in the 8-phase form —
+  // the correction pass ran at half the speed of the 16-bit parts it replaces.  Operands are complete when it issues (every
+  // call site sits behind the fragment reads' s_waitcnt lgkmcnt(0)); its result is next touched tiles later.
+  auto mfma_mx = [](f32x4& acc, v8i_ a, v8i_ b, int sa, int sb) {
+    asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]" : "+v"(acc) : "v"(a), "v"(b), "v"(sa), "v"(sb));
+  };
+  const int mx_one = 127;
   // M16: the wave tile is built from v_mfma_f32_16x16x32 (one K = 32 step per MFMA) instead of 32x32x16: same FLOP per
   // cycle and the same LDS bytes per FLOP, but the chip holds a higher clock under this shape (MI355X_MICROARCH.md,
   // DVFS give-back item 7: 1.12-1.14x the FLOP/s of the 32x32x16 loop with LDS-fed operands on random data)
@@ -65,6 +87,9 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_big_kernel(const asis_
   const T* asrc[GA];
   const T* bsrc[GB];
   int a_ih0[GA], a_iw0[GA];  // CONV: top-left input pixel of this lane's output pixel
+  // MXC instances (at the register limit): the same per-lane state in half the registers — 32-bit element offsets from the
+  // wave-uniform operand bases (the host checks that both tensors hold < 2^31 elements) and (ih0 + pad, iw0 + pad) packed
+  uint32_t a_pix[GA], a_hw[GA], b_off[GB];
   const int lr = lane / CPR, lc = lane % CPR;
   // LDS image swizzle (applied to the DMA source chunk and to the fragment reads alike): chunk ^= swz(row).
   // 32x32x16 fragments (lane -> row lane&31, chunk 2ks + lane>>5): (row >> SWS) & (CPR-1).  16x16x32 fragments (lane -> row
@@ -97,6 +122,8 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_big_kernel(const asis_
       a_ih0[j] = oh * d.stride - d.pad;
       a_iw0[j] = ow * d.stride - d.pad;
       asrc[j] = A + (int64_t)b * d.H * d.W * d.Cin + ((lc ^ swz(row)) << 3);
+      a_pix[j] = (uint32_t)(b * d.H * d.W * d.Cin + ((lc ^ swz(row)) << 3));
+      a_hw[j] = ((uint32_t)(oh * d.stride) << 16) | (uint32_t)(ow * d.stride);
     } else {
       a_ih0[j] = a_iw0[j] = 0;
       asrc[j] = A + (int64_t)gr * d.lda + ((lc ^ swz(row)) << 3);
@@ -108,6 +135,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_big_kernel(const asis_
     int gr = n0 + row;
     gr = gr < d.N ? gr : d.N - 1;
     bsrc[j] = B + (int64_t)gr * d.ldb + ((lc ^ swz(row)) << 3);
+    b_off[j] = (uint32_t)(gr * (int)d.ldb + ((lc ^ swz(row)) << 3));
   }
   // SPLIT: the reduction runs over three K-long parts: (A, B), (A_lo, B), (A, B_lo); the lo halves share the
   // layout of the hi ones, so a part only changes the base pointers by a constant element offset.
@@ -115,7 +143,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_big_kernel(const asis_
   // for every token and therefore adds up coherently through the blocks, tests/precision_probe.py): two parts.
   const int64_t a_lo_off = (SPLIT && d.A_lo) ? (reinterpret_cast<const T*>(d.A_lo) - reinterpret_cast<const T*>(d.A)) : 0;
   const int64_t b_lo_off = (SPLIT && d.B_lo) ? (reinterpret_cast<const T*>(d.B_lo) - reinterpret_cast<const T*>(d.B)) : 0;
-  const int nparts = !SPLIT ? 1 : (CONV ? 3 : ((d.A_lo && d.B_lo) ? 3 : 2));   // convolutions always carry both halves
+  const int nparts = !SPLIT ? 1 : (CONV ? (MXC ? 2 : 3) : ((d.A_lo && d.B_lo) ? 3 : 2));   // convolutions always carry both halves
   // part p > 0 of a two-part reduction adds the one lo operand that exists; of a three-part one: 1 = A_lo, 2 = B_lo
   auto part_offs = [&](int part, int64_t& aoff, int64_t& boff) {
     aoff = (part == 1 && d.A_lo) ? a_lo_off : 0;
@@ -141,7 +169,12 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_big_kernel(const asis_
       // came back to the same pixels only after a whole sweep over Cin, by which time the 64 tiles resident on an XCD
       // had pushed them out of its 4 MB L2: 3.2x the tensor bytes in L2 fills (profiles/r01_pmc_traffic.json).
       int tt = t, part = 0;
-      if (SPLIT) {  // CONV: three parts, compile-time divisor (a runtime one costs ~30 instructions per issue)
+      if (SPLIT && MXC) {  // two parts: 16-bit (A, B), then the MX pair (A_mx, B_mx)
+        tt = t >> 1;
+        part = t & 1;
+        aoff = part ? a_lo_off : 0;
+        boff = part ? b_lo_off : 0;
+      } else if (SPLIT) {  // CONV: three parts, compile-time divisor (a runtime one costs ~30 instructions per issue)
         tt = t / 3;
         part = t - 3 * tt;
         aoff = part == 1 ? a_lo_off : 0;
@@ -162,10 +195,18 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_big_kernel(const asis_
       const int kh = tap / d.KW, kw = tap - kh * d.KW;
 #pragma unroll
       for (int j = 0; j < GA; ++j) {
-        const int ih = a_ih0[j] + kh, iw = a_iw0[j] + kw;
-        const T* src = ((unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W)
-                           ? asrc[j] + aoff + ((int64_t)ih * d.W + iw) * d.Cin + ci0
-                           : reinterpret_cast<const T*>(g_zero_page);
+        const T* src;
+        if constexpr (MXC) {
+          const int ih = (int)(a_hw[j] >> 16) - d.pad + kh, iw = (int)(a_hw[j] & 0xffffu) - d.pad + kw;
+          src = ((unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W)
+                    ? A + aoff + (a_pix[j] + (uint32_t)((ih * d.W + iw) * d.Cin + ci0))
+                    : reinterpret_cast<const T*>(g_zero_page);
+        } else {
+          const int ih = a_ih0[j] + kh, iw = a_iw0[j] + kw;
+          src = ((unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W)
+                    ? asrc[j] + aoff + ((int64_t)ih * d.W + iw) * d.Cin + ci0
+                    : reinterpret_cast<const T*>(g_zero_page);
+        }
         __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(st + grp_a(j) * BKB), 16, 0, 0);
       }
     } else {
@@ -174,8 +215,10 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_big_kernel(const asis_
         __builtin_amdgcn_global_load_lds((glb_ptr)(asrc[j] + aoff + k0), (lds_ptr)(st + grp_a(j) * BKB), 16, 0, 0);
     }
 #pragma unroll
-    for (int j = 0; j < GB; ++j)
-      __builtin_amdgcn_global_load_lds((glb_ptr)(bsrc[j] + boff + k0), (lds_ptr)(st + BM2 * BKB + grp_b(j) * BKB), 16, 0, 0);
+    for (int j = 0; j < GB; ++j) {
+      const T* src = MXC ? B + boff + (b_off[j] + (uint32_t)k0) : bsrc[j] + boff + k0;
+      __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(st + BM2 * BKB + grp_b(j) * BKB), 16, 0, 0);
+    }
   };
 
   f32x16 acc[M16 ? 1 : TM][M16 ? 1 : TN];
@@ -218,7 +261,13 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_big_kernel(const asis_
     if (CONV) sk0 = tap_base * d.Cin;
     auto advance_src = [&]() {
       if (CONV) {
-        if (SPLIT) {
+        if (SPLIT && MXC) {
+          ++s_part;
+          s_aoff = s_part == 1 ? a_lo_off : 0;
+          s_boff = s_part == 1 ? b_lo_off : 0;
+          if (s_part < 2) return;
+          s_part = 0;
+        } else if (SPLIT) {
           ++s_part;
           s_aoff = s_part == 1 ? a_lo_off : 0;
           s_boff = s_part == 2 ? b_lo_off : 0;
@@ -242,7 +291,12 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_big_kernel(const asis_
     };
     auto dma_a = [&](int t, int j) {
       const T* src;
-      if (CONV) {
+      if constexpr (CONV && MXC) {
+        const int ih = (int)(a_hw[j] >> 16) - d.pad + s_kh, iw = (int)(a_hw[j] & 0xffffu) - d.pad + s_kw;
+        src = ((unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W)
+                  ? A + s_aoff + (a_pix[j] + (uint32_t)((ih * d.W + iw) * d.Cin + s_c * BKB))
+                  : reinterpret_cast<const T*>(g_zero_page);
+      } else if (CONV) {
         const int ih = a_ih0[j] + s_kh, iw = a_iw0[j] + s_kw;
         src = ((unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W)
                   ? asrc[j] + s_aoff + ((int64_t)ih * d.W + iw) * d.Cin + s_c * BKB
@@ -253,7 +307,8 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_big_kernel(const asis_
       __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(lds + (t & 1) * STAGE + grp_a(j) * BKB), 16, 0, 0);
     };
     auto dma_b = [&](int t, int j) {
-      __builtin_amdgcn_global_load_lds((glb_ptr)(bsrc[j] + s_boff + sk0), (lds_ptr)(lds + (t & 1) * STAGE + BM2 * BKB + grp_b(j) * BKB), 16, 0, 0);
+      const T* src = MXC ? B + s_boff + (b_off[j] + (uint32_t)sk0) : bsrc[j] + s_boff + sk0;
+      __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(lds + (t & 1) * STAGE + BM2 * BKB + grp_b(j) * BKB), 16, 0, 0);
     };
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -325,37 +380,96 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_big_kernel(const asis_
       }
       __builtin_amdgcn_s_setprio(0);
     };
-    for (int t = 0; t < nt; ++t) {
+    // MXC: the fragments live in 8-register vectors (the two ks halves of a lane = the 32-byte operand of the scaled fp8 MFMA;
+    // the 16-bit MFMAs take the halves as sub-registers), so that no operand tuple is assembled by copies
+    v8i_ af8[4], b0f8[2], b1f8[2];
+    auto rd_a8 = [&](const T* As, int rh) {
+#pragma unroll
+      for (int t4 = 0; t4 < 4; ++t4) {
+        const int row = (wm * TM + rh * 2) * 32 + t4 * 16 + r16;
+        af8[t4] = cat8(*reinterpret_cast<const v4i_*>(As + row * BKB + (((q16) ^ ((row >> 1) & 7)) << 3)),
+                       *reinterpret_cast<const v4i_*>(As + row * BKB + (((4 + q16) ^ ((row >> 1) & 7)) << 3)));
+      }
+    };
+    auto rd_b8 = [&](const T* Bs, int ch, v8i_* bf8) {
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int col = (wn * TN + ch) * 32 + jj * 16 + r16;
+        bf8[jj] = cat8(*reinterpret_cast<const v4i_*>(Bs + col * BKB + (((q16) ^ ((col >> 1) & 7)) << 3)),
+                       *reinterpret_cast<const v4i_*>(Bs + col * BKB + (((4 + q16) ^ ((col >> 1) & 7)) << 3)));
+      }
+    };
+    auto half8 = [](v8i_ x, int ks) -> v8 {
+      return ks ? __builtin_bit_cast(v8, __builtin_shufflevector(x, x, 4, 5, 6, 7)) : __builtin_bit_cast(v8, __builtin_shufflevector(x, x, 0, 1, 2, 3));
+    };
+    auto mma8 = [&](int rh, int ch, const v8i_* bf8, auto mx_tag) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+      if constexpr (decltype(mx_tag)::value) {   // 8 scaled fp8 MFMAs (K = 128 bytes each) in place of 16 16-bit ones
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4)
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) mfma_mx(acc16[rh * 4 + t4][ch * 2 + jj], bf8[jj], af8[t4], mx_sc, mx_one);
+      } else {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int t4 = 0; t4 < 4; ++t4)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+              acc16[rh * 4 + t4][ch * 2 + jj] = T16<T>::mfma16(half8(bf8[jj], ks), half8(af8[t4], ks), acc16[rh * 4 + t4][ch * 2 + jj]);
+      }
+      __builtin_amdgcn_s_setprio(0);
+    };
+    auto RA = [&](const T* As, int rh) { if constexpr (MXC) rd_a8(As, rh); else rd_a(As, rh); };
+    auto RB = [&](const T* Bs, int ch, int which) {
+      if constexpr (MXC) rd_b8(Bs, ch, which ? b1f8 : b0f8); else rd_b(Bs, ch, which ? b1f : b0f);
+    };
+    // one K tile; MXC: even tiles are 16-bit tiles, odd tiles correction tiles — two bodies per loop trip instead of a
+    // wave-uniform branch in every phase (with the branch the allocator spilled ~30 VGPRs into this loop)
+    auto ktile = [&](int t, auto mx_tag) {
+      auto MM = [&](int rh, int ch, int which) {
+        if constexpr (MXC) mma8(rh, ch, which ? b1f8 : b0f8, mx_tag); else mma(rh, ch, which ? b1f : b0f);
+      };
       const T* As = lds + (t & 1) * STAGE;
       const T* Bs = As + BM2 * BKB;
       const bool more = t + 1 < nt;
       // phase 0
-      rd_a(As, 0);
-      rd_b(Bs, 0, b0f);
+      RA(As, 0);
+      RB(Bs, 0, 0);
       if (more) { dma_a(t + 1, 0); dma_a(t + 1, 1); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
       else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      mma(0, 0, b0f);
+      MM(0, 0, 0);
       __builtin_amdgcn_s_barrier();
       // phase 1
-      rd_b(Bs, 1, b1f);
+      RB(Bs, 1, 1);
       if (more) { dma_b(t + 1, 0); dma_b(t + 1, 1); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      mma(0, 1, b1f);
+      MM(0, 1, 1);
       __builtin_amdgcn_s_barrier();
       // phase 2
-      rd_a(As, 1);
+      RA(As, 1);
       if (more) { dma_b(t + 1, 2); dma_b(t + 1, 3); }
       __builtin_amdgcn_s_barrier();
-      mma(1, 1, b1f);
+      MM(1, 1, 1);
       __builtin_amdgcn_s_barrier();
       // phase 3
       if (more) { dma_a(t + 1, 2); dma_a(t + 1, 3); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
       advance_src();
       __builtin_amdgcn_s_barrier();
-      mma(1, 0, b0f);
+      MM(1, 0, 0);
       __builtin_amdgcn_s_barrier();
+    };
+    if constexpr (MXC) {
+      for (int t = 0; t < nt; t += 2) {     // nt = 2 x (K tiles of one part): always even
+        ktile(t, std::false_type{});
+        ktile(t + 1, std::true_type{});
+      }
+    } else {
+      for (int t = 0; t < nt; ++t) ktile(t, std::false_type{});
     }
     if (wm == 0) __builtin_amdgcn_s_barrier();  // balance the stagger
   } else {
@@ -371,7 +485,31 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_big_kernel(const asis_
     if (!(DBG & 1) && t + NS - 1 < nt) issue(t + NS - 1);
     const T* As = lds + (t % NS) * STAGE;
     const T* Bs = As + BM2 * BKB;
-    if constexpr (M16) {
+    if (MXC && (t & 1)) {
+      if constexpr (MXC) {   // correction tile: both K halves of every fragment, one scaled fp8 MFMA per 16x16 output block
+        const int r16 = lane & 15, q16 = lane >> 4;
+        v8 af0[TM * 2], af1[TM * 2], bf0[TN * 2], bf1[TN * 2];
+#pragma unroll
+        for (int i = 0; i < TM * 2; ++i) {
+          const int row = (wm * TM * 2 + i) * 16 + r16;
+          af0[i] = __builtin_bit_cast(v8, *reinterpret_cast<const uint4*>(As + row * BKB + (((q16) ^ swz(row)) << 3)));
+          af1[i] = __builtin_bit_cast(v8, *reinterpret_cast<const uint4*>(As + row * BKB + (((4 + q16) ^ swz(row)) << 3)));
+        }
+#pragma unroll
+        for (int j = 0; j < TN * 2; ++j) {
+          const int col = (wn * TN * 2 + j) * 16 + r16;
+          bf0[j] = __builtin_bit_cast(v8, *reinterpret_cast<const uint4*>(Bs + col * BKB + (((q16) ^ swz(col)) << 3)));
+          bf1[j] = __builtin_bit_cast(v8, *reinterpret_cast<const uint4*>(Bs + col * BKB + (((4 + q16) ^ swz(col)) << 3)));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < TM * 2; ++i)
+#pragma unroll
+          for (int j = 0; j < TN * 2; ++j)
+            mfma_mx(acc16[i][j], cat8(bf0[j], bf1[j]), cat8(af0[i], af1[i]), mx_sc, mx_one);
+      }
+    } else if constexpr (M16) {
       // one K = 32 step per tile: 2TM A fragments + 2TN B fragments (one ds_read_b128 each), then (2TM)(2TN) MFMAs;
       // the first MFMAs need only the first fragments, so the compiler's counted lgkmcnt lets them start early
       const int r16 = lane & 15, q16 = lane >> 4;

@@ -200,7 +200,7 @@ def gemm_set_option(name: str, value: int) -> None:
 def conv_gemm(x_nhwc: torch.Tensor, w_packed: torch.Tensor, KH: int, KW: int, stride: int, pad: int, *,
               out: Optional[torch.Tensor] = None, out_f32: bool = True, bias_n: Optional[torch.Tensor] = None,
               act: int = ACT_NONE, stats: Optional[torch.Tensor] = None, accumulate: bool = False,
-              x_lo: Optional[torch.Tensor] = None, w_lo: Optional[torch.Tensor] = None, ksplit: int = 1) -> torch.Tensor:
+              x_lo: Optional[torch.Tensor] = None, w_lo: Optional[torch.Tensor] = None, ksplit: int = 1, mx=None) -> torch.Tensor:
     """Implicit-GEMM convolution: x [B,H,W,Cin] (16-bit NHWC), w_packed [Cout, KH*KW*Cin] ->
     out [B,OH,OW,Cout] (fp32 by default: BatchNorm statistics are taken on it).
     ``ksplit`` > 1: the reduction runs as that many side-by-side parts (fp32 partial maps summed in a fixed order, then the
@@ -239,6 +239,8 @@ def conv_gemm(x_nhwc: torch.Tensor, w_packed: torch.Tensor, KH: int, KW: int, st
     flops = 2.0 * d.M * Cout * K
     if x_lo is not None:
         d.A_lo, d.B_lo = x_lo.data_ptr(), w_lo.data_ptr()
+    if mx is not None:     # x_lo / w_lo are in the MX form; mx = (amax of x, amax of w) device floats
+        d.mx_amax_a, d.mx_amax_b = _f32c(mx[0]).data_ptr(), _f32c(mx[1]).data_ptr()
     check(_launch_timed("conv", flops, lambda: lib().asis_gemm(_stream(), C.byref(d))), "asis_gemm(conv)")
     if ksplit > 1:
         out = torch.empty((Bn, OH, OW, Cout), device=x_nhwc.device, dtype=torch.float32)
@@ -250,7 +252,7 @@ _FUSED_SPLIT = os.environ.get("ASIS_GEMM_BIG", "1") != "0" and os.environ.get("A
 
 
 def conv_gemm_split(x_hi, x_lo, w_hi, w_lo, KH: int, KW: int, stride: int, pad: int, *, bias_n=None, stats=None,
-                    ksplit: int = 1):
+                    ksplit: int = 1, mx=None):
     """Split-precision convolution: x ~= x_hi + x_lo, w ~= w_hi + w_lo (16-bit halves), fp32 out =
     x_hi*w_hi + x_lo*w_hi + x_hi*w_lo (+ bias), accumulated in fp32 (the dropped x_lo*w_lo term is ~2^-22
     relative): one launch over a virtual 3K reduction on the large-tile kernel, else three accumulate passes."""
@@ -258,7 +260,9 @@ def conv_gemm_split(x_hi, x_lo, w_hi, w_lo, KH: int, KW: int, stride: int, pad: 
     OH, OW = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
     Cout = w_hi.shape[0]
     if Cin % 64 == 0 and Bn * OH * OW >= 256 and Cout >= 32 and Cout % 4 == 0 and _FUSED_SPLIT:
-        return conv_gemm(x_hi, w_hi, KH, KW, stride, pad, bias_n=bias_n, stats=stats, x_lo=x_lo, w_lo=w_lo, ksplit=ksplit)
+        return conv_gemm(x_hi, w_hi, KH, KW, stride, pad, bias_n=bias_n, stats=stats, x_lo=x_lo, w_lo=w_lo, ksplit=ksplit, mx=mx)
+    if mx is not None:
+        raise ValueError("conv_gemm_split: MX operands need the fused large-tile path (mx_conv_ok)")
     out = conv_gemm(x_hi, w_hi, KH, KW, stride, pad, bias_n=bias_n)
     conv_gemm(x_lo, w_hi, KH, KW, stride, pad, out=out, accumulate=True)
     conv_gemm(x_hi, w_lo, KH, KW, stride, pad, out=out, accumulate=True, stats=stats)
@@ -763,11 +767,60 @@ def bn_relu_maxpool(x: torch.Tensor, scale, shift, dtype: torch.dtype, split: bo
     return (out, lo) if split else out
 
 
-def bn_relu_upsample(x: torch.Tensor, scale, shift, factor: int, dtype: torch.dtype, split: bool = False):
+def mx_conv_ok(P: int, Cin: int, Cout: int) -> bool:
+    """a split 3x3 convolution with P output pixels can take MX lo operands (csrc/gemm.hip: the fused large-tile conv forms)"""
+    return Cin % 64 == 0 and P >= 256 and Cout >= 32 and Cout % 4 == 0 and _FUSED_SPLIT
+
+
+def absmax_f32(x: torch.Tensor, amax: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """|x| maximum of an fp32 tensor whose rows are contiguous ([..., cols] with ONE outer stride) -> device float [1];
+    ``amax`` given: accumulate into it (maximum over several tensors)."""
+    _dev(x, amax)
+    if x.dtype != torch.float32 or x.stride(-1) != 1:
+        raise ValueError("absmax_f32: float32 tensor with a contiguous last dim")
+    if x.is_contiguous():
+        rows, cols, ld = 1, x.numel(), x.numel()
+        if cols % 4:
+            raise ValueError("absmax_f32: element count must be a multiple of 4")
+        # rows of at most 2^20 elements keep the grid busy
+        cols = 1 << 20 if x.numel() % (1 << 20) == 0 else (x.shape[-1] if x.dim() > 1 else x.numel())
+        rows, ld = x.numel() // cols, cols
+    elif x.dim() == 3 and x[0].is_contiguous():
+        rows, cols, ld = x.shape[0], x.shape[1] * x.shape[2], x.stride(0)
+    elif x.dim() == 2:
+        rows, cols, ld = x.shape[0], x.shape[1], x.stride(0)
+    else:
+        raise ValueError("absmax_f32: unsupported layout")
+    reset = amax is None
+    if amax is None:
+        amax = torch.empty(1, device=x.device, dtype=torch.float32)
+    check(lib().asis_absmax_f32(_stream(), x.data_ptr(), rows, cols, ld, amax.data_ptr(), int(reset)), "asis_absmax_f32")
+    return amax
+
+
+def bn_relu_absmax(x: torch.Tensor, scale, shift, relu: bool = True) -> torch.Tensor:
+    """max of relu(x * scale + shift) over fp32 NHWC x -> device float [1] (the MX scale of the tensor bn_relu_upsample writes)"""
+    _dev(x, scale, shift)
+    C = x.shape[-1]
+    amax = torch.empty(1, device=x.device, dtype=torch.float32)
+    check(lib().asis_bn_relu_absmax(_stream(), _f32c(x).data_ptr(), _f32c(scale).data_ptr(), _f32c(shift).data_ptr(), x.numel() // C, C,
+                                    int(relu), amax.data_ptr()), "asis_bn_relu_absmax")
+    return amax
+
+
+def bn_relu_upsample(x: torch.Tensor, scale, shift, factor: int, dtype: torch.dtype, split: bool = False, mx_amax=None):
     _dev(x, scale, shift)
     B, H, W, Cc = x.shape
     out = torch.empty((B, H * factor, W * factor, Cc), device=x.device, dtype=dtype)
     lo = _lo(out, split)
+    if mx_amax is not None:    # lo in the MX form (two fp8 bytes per element), tagged with the tensor's absolute maximum
+        if lo is None:
+            raise ValueError("bn_relu_upsample: mx_amax needs split=True")
+        check(lib().asis_bn_relu_upsample_mx(_stream(), _dt(dtype), _f32c(x).data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                             out.data_ptr(), lo.data_ptr(), _f32c(mx_amax).data_ptr(), B, H, W, Cc, factor),
+              "asis_bn_relu_upsample_mx")
+        lo._asis_mx_amax = mx_amax
+        return out, lo
     check(lib().asis_bn_relu_upsample(_stream(), _dt(dtype), _f32c(x).data_ptr(), scale.data_ptr(), shift.data_ptr(),
                                       out.data_ptr(), _p(lo), B, H, W, Cc, factor), "asis_bn_relu_upsample")
     return (out, lo) if split else out
@@ -787,13 +840,29 @@ def pack_conv_weight(w: torch.Tensor, mode: int, dtype: torch.dtype, part: int =
     return out[:, :K] if ld != K else out
 
 
+def pack_conv_weight_mx(w: torch.Tensor, mode: int, dtype: torch.dtype):
+    """-> (MX form of the weight's lo operand (weight side: (lo8, hi8) per element), same shape as pack_conv_weight's, and the
+    weight's absolute maximum as a device float [1])"""
+    _dev(w)
+    Cout, Cin, KH, KW = w.shape
+    CoP = (Cout + 7) // 8 * 8
+    rows, K = (Cout, KH * KW * Cin) if mode == 0 else (Cin, KH * KW * CoP)
+    ld = (K + 7) // 8 * 8
+    wf = _f32c(w)
+    amax = absmax_f32(wf.view(Cout, -1) if (Cin * KH * KW) % 4 == 0 else wf.view(1, -1))
+    out = torch.empty((rows, ld), device=w.device, dtype=dtype)
+    check(lib().asis_pack_conv_weight_mx(_stream(), _dt(dtype), wf.data_ptr(), out.data_ptr(), Cout, Cin, KH, KW, mode, ld,
+                                         amax.data_ptr()), "asis_pack_conv_weight_mx")
+    return (out[:, :K] if ld != K else out), amax
+
+
 def _rows3(t: torch.Tensor, D: int, what: str):
     if t.dtype != torch.float32 or t.dim() != 3 or t.stride(2) != 1 or t.stride(1) != D:
         raise ValueError(f"{what}: expected float32 [B, n, {D}] with contiguous rows (batch stride free)")
 
 
 def decoder_input(xs: torch.Tensor, c4: torch.Tensor, vit: torch.Tensor, hw, c4_hw, dtype: torch.dtype,
-                  split: bool = False):
+                  split: bool = False, mx: bool = False):
     """train.py:389-406: xs, vit fp32 [B, h*w, D]; c4 fp32 [B, h4*w4, D] (batch strides free) -> [B,h,w,3D]."""
     _dev(xs, c4, vit)
     B, _, D = xs.shape
@@ -803,6 +872,15 @@ def decoder_input(xs: torch.Tensor, c4: torch.Tensor, vit: torch.Tensor, hw, c4_
         _rows3(t, D, "decoder_input " + n)
     out = torch.empty((B, h, w, 3 * D), device=xs.device, dtype=dtype)
     lo = _lo(out, split)
+    if mx and split:           # lo in the MX form: one absolute maximum over the three sources
+        amax = absmax_f32(xs)
+        absmax_f32(c4, amax)
+        absmax_f32(vit, amax)
+        check(lib().asis_decoder_input_mx(_stream(), _dt(dtype), xs.data_ptr(), xs.stride(0), c4.data_ptr(), c4.stride(0),
+                                          vit.data_ptr(), vit.stride(0), out.data_ptr(), lo.data_ptr(), amax.data_ptr(), B, h, w,
+                                          h4, w4, D), "asis_decoder_input_mx")
+        lo._asis_mx_amax = amax
+        return out, lo
     check(lib().asis_decoder_input(_stream(), _dt(dtype), xs.data_ptr(), xs.stride(0), c4.data_ptr(), c4.stride(0),
                                    vit.data_ptr(), vit.stride(0), out.data_ptr(), _p(lo), B, h, w, h4, w4, D),
           "asis_decoder_input")

@@ -119,6 +119,14 @@ typedef struct asis_gemm_desc {
    *   res16 / res16_lo / ldr16   the residual as two 16-bit planes instead of fp32 `res` (v += (float)hi + (float)lo)
    *   ln_mr     fp32 [M, 2] (mean, rstd) per A row (ln_cols != 0: per B row, i.e. per output COLUMN, for the swapped V^T GEMM)
    *   ln_cs     fp32 [N] cs (ln_cols != 0: [M], per output row); applied BEFORE bias_n / bias_m and the activation */
+  /* ---- MX correction operands of a split convolution (conv != 0, A_lo and B_lo given, Cin % 64 == 0) ----------------------
+   * mx_amax_a, mx_amax_b != NULL: device floats = the absolute maxima of the A and the B tensor; A_lo / B_lo then hold the MX form
+   * of the rounding residuals (csrc/asis_common.h: two fp8 e4m3 bytes per element — activations (hi8, lo8), weights (lo8, hi8);
+   * asis_bn_relu_upsample_mx / asis_decoder_input_mx / asis_pack_conv_weight_mx write them) and the reduction runs over TWO K
+   * parts: A B on the 16-bit MFMA + one block-scaled fp8 MFMA pass (v_mfma_scale_f32_16x16x128_f8f6f4, twice the 16-bit rate
+   * per byte) that yields A_hi B_lo + A_lo B_hi at ~4 significant bits — 2/3 of the MFMA time of the three 16-bit parts. */
+  const float* mx_amax_a;
+  const float* mx_amax_b;
   void* C_lo;
   float* rowstats;
   const void* res16;
@@ -146,6 +154,12 @@ int asis_gemm(void* stream, const asis_gemm_desc* d);
 int asis_gemm_group(void* stream, const asis_gemm_desc* descs, int n);
 /* number of M tiles asis_gemm uses for M rows (size of the stats buffer = tiles*2*N floats) */
 int asis_gemm_tiles_m(int M);
+/* |x| maximum of an fp32 [rows, cols] tensor (row stride ld, cols % 4 == 0) into *amax (device float; reset != 0 zeroes it
+ * first, reset == 0 accumulates over several tensors); asis_bn_relu_absmax: the maximum of relu(x * scale[c] + shift[c])
+ * (relu == 0: of |x * scale + shift|) over x fp32 [P, C] — the tensor a BatchNorm + ReLU (+ bilinear upsampling) kernel is
+ * about to write.  They feed the per-tensor power-of-two scales of the MX operands above. */
+int asis_absmax_f32(void* stream, const float* x, int64_t rows, int cols, int64_t ld, float* amax, int reset);
+int asis_bn_relu_absmax(void* stream, const float* x, const float* scale, const float* shift, int64_t P, int C, int relu, float* amax);
 /* run-time dispatch switches of asis_gemm (same meaning as the environment variable read at first use):
  *   "p8" (ASIS_GEMM_P8): 1 = dense launches with at least one 256x256 tile per CU run on the persistent 8-phase kernel
  *   (csrc/gemm_p8.h) when K <= 2048, 2 = any K and from 16 tiles on, 3 = any K, 0 = never (one workgroup per tile,
@@ -362,16 +376,26 @@ int asis_bn_relu_maxpool(void* stream, int dtype, const float* x, const float* s
 /* BN + ReLU + bilinear upsample xfactor, align_corners=True (decoders.py:112-113; MLAHead :38-45 with factor 4) */
 int asis_bn_relu_upsample(void* stream, int dtype, const float* x, const float* scale, const float* shift, void* out,
                           void* out_lo, int B, int H, int W, int C, int factor);
+/* the same with the lo output in the MX form (asis_gemm_desc.mx_amax_a / mx_amax_b); amax = device float, the tensor's absolute maximum */
+int asis_bn_relu_upsample_mx(void* stream, int dtype, const float* x, const float* scale, const float* shift, void* out,
+                             void* out_mx, const float* amax, int B, int H, int W, int C, int factor);
 /* conv weight fp32 [Cout,Cin,KH,KW] -> 16-bit GEMM operand.
  * mode 0 (forward): out[co][(kh*KW+kw)*Cin+ci], rows Cout.
  * mode 1 (dgrad):   out[ci][((KH-1-kh)*KW+(KW-1-kw))*CoP+co], rows Cin, CoP = Cout rounded up to 8. */
 int asis_pack_conv_weight(void* stream, int dtype, const float* w, void* out, int Cout, int Cin, int KH, int KW,
                           int mode, int64_t ldo, int part);
+/* the same with the lo output in the MX form (asis_gemm_desc.mx_amax_a / mx_amax_b); amax = device float, the tensor's absolute maximum */
+int asis_pack_conv_weight_mx(void* stream, int dtype, const float* w, void* out_mx, int Cout, int Cin, int KH, int KW,
+                             int mode, int64_t ldo, const float* amax);
 /* decoder input (train.py:389-406): [xs | zero-padded c4 | vit] fp32 tokens -> 16-bit NHWC [B,h,w,3D];
  * every source has its own batch stride (elements) so token slices need no copies */
 int asis_decoder_input(void* stream, int dtype, const float* xs, int64_t xs_bstride, const float* c4,
                        int64_t c4_bstride, const float* vit, int64_t vit_bstride, void* out, void* out_lo, int B, int h,
                        int w, int h4, int w4, int D);
+/* the same with the lo output in the MX form (asis_gemm_desc.mx_amax_a / mx_amax_b); amax = device float, the tensor's absolute maximum */
+int asis_decoder_input_mx(void* stream, int dtype, const float* xs, int64_t xs_bstride, const float* c4, int64_t c4_bstride,
+                          const float* vit, int64_t vit_bstride, void* out, void* out_mx, const float* amax, int B, int h,
+                          int w, int h4, int w4, int D);
 /* SwiGLU gate (dinov2/layers/swiglu_ffn.py:30-34): x12 fp32 [R, 2*Hd] = [x1 | x2] -> out 16-bit [R, Hd] = silu(x1)*x2 */
 int asis_swiglu(void* stream, int dtype, const float* x12, void* out, int64_t R, int Hd);
 /* same with an optional second output out_lo (NULL = none): the rounding residual of the 16-bit result, so that (out, out_lo) is
