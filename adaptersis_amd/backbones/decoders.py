@@ -266,7 +266,7 @@ class FeatureDecoder(_Packed):
             # the classifier conv, which takes the 16-bit residuals
             nxt = getattr(self, f"decoder_{i + 1}")[0] if i < 4 else None
             Bq, Hq, Wq, _ = a[0].shape
-            mx_out = bool(config.mx_conv and a[1] is not None and nxt is not None and f"d{i + 1}" not in config.unsplit_layers and
+            mx_out = bool(config.mx_conv_on() and a[1] is not None and nxt is not None and f"d{i + 1}" not in config.unsplit_layers and
                           ops.mx_conv_ok(Bq * 4 * Hq * Wq, nxt.in_channels, nxt.out_channels))
             a, st = conv_bn_relu_up_forward(self, f"d{i}", a[0], a[1], seq[0], seq[1], 2, self.sync_bn, save, training, mx_out=mx_out)
             saved.append(st)

@@ -351,7 +351,7 @@ class SegEngine(nn.Module):
             return hi, lo
         n4 = shapes[2][0] * shapes[2][1]
         d1 = getattr(self.seg_decoder, "decoder_1", None)     # FeatureDecoder: its first conv takes MX lo operands (config.mx_conv)
-        mx = bool(config.mx_conv and config.split_conv and d1 is not None and "d1" not in config.unsplit_layers and
+        mx = bool(config.mx_conv_on() and config.split_conv and d1 is not None and "d1" not in config.unsplit_layers and
                   ops.mx_conv_ok(B * h * w, 3 * D, d1[0].out_channels))
         cat = ops.decoder_input(x, c_orig[:, Lc - n4:], feats[-1], (h, w), shapes[2], config.operand_dtype,
                                 config.split_conv, mx=mx)

@@ -124,4 +124,12 @@ ln_fold = os.environ.get("ASIS_LN_FOLD", "1") not in ("0", "")
 # ONE block-scaled fp8 MFMA pass (v_mfma_scale_f32_16x16x128_f8f6f4) instead of two 16-bit passes: 2/3 of the MFMA time of a
 # split convolution.  Applies where the producing kernel can write the MX form (FeatureDecoder stages; Cin % 64 == 0).
 # ASIS_MX_CONV=0: the three 16-bit parts as before.
-mx_conv = os.environ.get("ASIS_MX_CONV", "1") not in ("0", "")
+# float16 operands only by default: a bfloat16 residual is 2^-9 of its value and three fp8 mantissa bits leave 2^-13 of it —
+# eight times the figure of the float16 case (2^-16); ASIS_MX_CONV=2 forces it for bfloat16 as well.
+_mx = os.environ.get("ASIS_MX_CONV", "1")
+mx_conv_all = _mx == "2"
+mx_conv = _mx not in ("0", "")
+
+
+def mx_conv_on() -> bool:
+    return mx_conv and (mx_conv_all or operand_dtype == torch.float16)
