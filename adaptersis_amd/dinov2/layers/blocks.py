@@ -76,14 +76,32 @@ class _Packed(nn.Module):
                 self._cache[key] = (tag, fn())
         return self._cache[key][1]
 
-    def _wT16(self, key: str, w: torch.Tensor, gamma: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """B operand of an input-gradient GEMM: (diag(gamma) W)^T as 16-bit [in_features, out_features]"""
+    def _wT16(self, key: str, w: torch.Tensor, gamma: Optional[torch.Tensor] = None, pow2: int = 0) -> torch.Tensor:
+        """B operand of an input-gradient GEMM: (2^pow2 diag(gamma) W)^T as 16-bit [in_features, out_features]"""
         def make():
             wf = w.detach().float()
             if gamma is not None:
-                wf = wf * gamma.detach().float()[:, None]
+                wf = wf * (gamma.detach().float() * (2.0 ** pow2))[:, None]
             return ops.cast_pad(wf.t().contiguous(), dtype=config.operand_dtype)
-        return self._pack2(key, w, gamma, make)
+        return self._pack2(key + (f"@{pow2}" if pow2 else ""), w, gamma, make)
+
+    def _ls_pow2(self, key: str, gamma: Optional[torch.Tensor]) -> int:
+        """k with max|gamma| 2^k in [1, 2): the power-of-two scale a LayerScale'd branch gradient carries through its 16-bit
+        tensors.  The reference's init is gamma = 1e-5 (`ssl_default_config.yaml:75`): gamma W ~ 2e-7 and every gradient behind
+        it sit in fp16's subnormal range even under the 2^16 loss scale, so the branch runs on 2^k gamma and the factor is
+        taken out again, exactly, where its gradients are written in fp32 (Block.backward)."""
+        if gamma is None:
+            return 0
+        def make():
+            m = float(gamma.detach().abs().max())
+            return torch.tensor(0 if not (m > 0.0) else -int(torch.floor(torch.log2(torch.tensor(m))).item()))
+        return int(self._pack2(key, gamma, None, make))
+
+    def _nw_pow2(self, key: str, w: torch.Tensor, pow2: int) -> torch.Tensor:
+        """fp32 LayerNorm weight times 2^pow2 (exact): takes a branch gradient's power-of-two scale out in the LayerNorm backward"""
+        if pow2 == 0:
+            return self._f32(key, w)
+        return _pack(self._cache, f"{key}@{pow2}", w, lambda p: (p.float() * (2.0 ** pow2)).contiguous())
 
     def _linear_bwd(self, prefix: str, lin: nn.Linear, gamma: Optional[nn.Parameter], gname: Optional[str], dy16, dy_cs,
                     a16, inv_scale: float, grads: Optional[dict]):
@@ -645,6 +663,11 @@ class Block(_Packed):
         ls1 = self.ls1.gamma if isinstance(self.ls1, LayerScale) else None
         ls2 = self.ls2.gamma if isinstance(self.ls2, LayerScale) else None
         pre = prefix + "." if prefix else ""
+        # per-branch power-of-two scales of the LayerScale'd gradients (see ``_ls_pow2``): dh / dO and everything computed from
+        # them inside the branch carry 2^k; the factor leaves through inv_scale (weight / bias / norm gradients) and through the
+        # LayerNorm backward's weight (input gradient)
+        k1, k2 = self._ls_pow2("ls1.k", ls1), self._ls_pow2("ls2.k", ls2)
+        inv1, inv2 = inv_scale * 2.0 ** -k1, inv_scale * 2.0 ** -k2
         # ---- MLP branch: out = x1 + ls2 * fc2(gelu(fc1(LN2(x1)))) ----
         d16, cs = ops.cast_colsum(dres, dt) if grads is not None else (ops.cast_pad(dres, D, dt), None)
         if isinstance(m, Mlp):
@@ -655,21 +678,21 @@ class Block(_Packed):
         R = d16.shape[0]
         if isinstance(m, Mlp) and R >= 256 and lin_out.in_features >= 128 and lin_out.in_features % 4 == 0 and D % 32 == 0:
             # fc2's input gradient with GELU's backward in the GEMM epilogue: d pre = (d16 W) * gelu'(pre)
-            dh = ops.gemm(d16, self._wT16("fc2T", lin_out.weight, ls2), act=ops.ACT_GELU_GRAD, aux=hpre)
+            dh = ops.gemm(d16, self._wT16("fc2T", lin_out.weight, ls2, k2), act=ops.ACT_GELU_GRAD, aux=hpre)
         else:
-            dh = ops.gemm(d16, self._wT16("fc2T", lin_out.weight, ls2))            # 16-bit [R, hidden]
+            dh = ops.gemm(d16, self._wT16("fc2T", lin_out.weight, ls2, k2))        # 16-bit [R, hidden], times 2^k2
             dh = act_bwd(hpre, dh)                                                 # GELU' / SwiGLU gate backward
         self._linear_bwd(pre + n_in, lin_in, None, None, dh, ops.colsum(dh) if grads is not None else None, xn2,
-                         inv_scale, grads)
-        dln = ops.gemm(dh, self._wT16("fc1T", lin_in.weight), out_f32=True)        # fp32 [R, D]
-        dx1, part = ops.layernorm_bwd(dln, x1, self._f32("n2w", self.norm2.weight), self.norm2.eps, res=dres)
+                         inv2, grads)
+        dln = ops.gemm(dh, self._wT16("fc1T", lin_in.weight), out_f32=True)        # fp32 [R, D], times 2^k2
+        dx1, part = ops.layernorm_bwd(dln, x1, self._nw_pow2("n2w", self.norm2.weight, -k2), self.norm2.eps, res=dres)
         if grads is not None:
-            red = ops.reduce_rows(part.view(part.shape[0], 2 * D), inv_scale)
+            red = ops.reduce_rows(part.view(part.shape[0], 2 * D), inv2)
             grads[pre + "norm2.weight"].copy_(red[:D]); grads[pre + "norm2.bias"].copy_(red[D:])
         # ---- attention branch: x1 = x + ls1 * proj(attn(LN1(x))) ----
         d16, cs = ops.cast_colsum(dx1, dt) if grads is not None else (ops.cast_pad(dx1, D, dt), None)
         self._linear_bwd(pre + "attn.proj", a.proj, ls1, pre + "ls1.gamma", d16, cs, o, inv_scale, grads)
-        dO = ops.gemm(d16, self._wT16("projT", a.proj.weight, ls1))                # 16-bit [R, D]
+        dO = ops.gemm(d16, self._wT16("projT", a.proj.weight, ls1, k1))            # 16-bit [R, D], times 2^k1
         dqkv = torch.empty((x2.shape[0], 3 * D), device=x2.device, dtype=dt)
         r0 = 0
         for (B, N), l in zip(segs, lse):   # attention backward per stacked token batch
@@ -680,11 +703,11 @@ class Block(_Packed):
                               dqkv=dqkv[r0:r1])
             r0 = r1
         self._linear_bwd(pre + "attn.qkv", a.qkv, None, None, dqkv, ops.colsum(dqkv) if grads is not None else None, xn,
-                         inv_scale, grads)
+                         inv1, grads)
         dln = ops.gemm(dqkv, self._wT16("qkvT", a.qkv.weight), out_f32=True)
-        dx, part = ops.layernorm_bwd(dln, x2, self._f32("n1w", self.norm1.weight), self.norm1.eps, res=dx1)
+        dx, part = ops.layernorm_bwd(dln, x2, self._nw_pow2("n1w", self.norm1.weight, -k1), self.norm1.eps, res=dx1)
         if grads is not None:
-            red = ops.reduce_rows(part.view(part.shape[0], 2 * D), inv_scale)
+            red = ops.reduce_rows(part.view(part.shape[0], 2 * D), inv1)
             grads[pre + "norm1.weight"].copy_(red[:D]); grads[pre + "norm1.bias"].copy_(red[D:])
         return dx
 

@@ -119,10 +119,13 @@ def test_config4_vitl_24_blocks_unfrozen(dev, mode):
     for nm, (views, pre) in groups.items():
         n, gmax, gmed, worst = _grad_stats(views, g, pre, skip_bias0=(nm == "decoder"))
         print(f"  {tag} {nm}: n={n} max {gmax:.2e} median {gmed:.2e} worst {worst}")
-        if mode == "init" and nm != "decoder":
-            # reference-init weights: CAViT gamma = 0 leaves `cross_vit.gamma` as the only adapter gradient, and the ViT's
-            # parameter gradients are LayerScale (1e-5) x a 16-bit gradient of ~1e-3 x loss scale: below fp16's subnormal
-            # range (`--operand bf16` keeps them) — the forward, the loss and the decoder gradients are the check
+        if mode == "init":
+            # reference-init weights (LayerScale 1e-5, CAViT gamma 0: `cross_vit.gamma` is the only adapter gradient).  Since
+            # round 4 every group is checked at this init too: the ViT's LayerScale'd branch gradients (gamma W ~ 2e-7, below
+            # fp16's subnormal range even under the 2^16 loss scale: rel-L2 0.44 median in round 3) carry a per-branch
+            # power-of-two scale through their 16-bit tensors (blocks.Block._ls_pow2): measured median 5.5e-3, max 6.3e-2
+            assert n >= (1 if nm == "adapter" else 10)
+            assert gmax < 1e-1 and gmed < 2e-2, (nm, worst)
             continue
         assert n >= 10
         # step-level bounds as at 4 blocks (test_gpu_e2e.py): ReLU flips of the head / MSDA cell crossings set the floor
