@@ -97,6 +97,8 @@ SIGNATURES = {
     "asis_attention_bwd": [_vp, _i, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp,
                            _i64, _i, _i, _i, _f],
     "asis_msda_bwd": [_vp, _i, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i],
+    "asis_msda_vgrad_cap": [_i, _i, _i],
+    "asis_msda_value_grad": [_vp, _i, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i],
     "asis_msda_sampling_matrix": [_vp, _i, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i],
     "asis_dwconv_bwd_nblk": [_i64],
     "asis_dwconv_gelu_bwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i],

@@ -314,6 +314,153 @@ __global__ __launch_bounds__(256) void msda_sampling_matrix_kernel(const float* 
   }
 }
 
+// ---- d value as a gather over taps grouped by destination pixel (round 4) ------------------------------------------------------
+// The dense form above spends a 2.4 GB matrix (99 % zeros), its memset and 8 batched GEMMs on what is a sparse sum:
+//     d value[b, pix, m, :] = sum over the taps (q, l, p, corner) that land on pix of  w_tap * d out[b, q, m, :].
+// Here the <= 4 L P taps of every (b, q, m) are bucketed by pixel with a counting sort — (1) histogram per (b, m, pix),
+// (2) exclusive scan per (b, m), (3) fill of (q, weight) records at positions drawn from per-pixel cursors — and (4) one wave
+// per (b, m, pix) sums its records.  The positions inside a bucket depend on the atomics' arrival order; the SUM does not: it is
+// taken in 64-bit integers (each product rounded to a fixed-point grid of 2^-30 x the operand's power-of-two range), and integer
+// addition is associative — bitwise reproducible run to run, no atomics on the output, every output element written.
+// msda_taps_kernel<FILL>: one thread per (b, q, m); the same tap arithmetic as msda_sampling_matrix_kernel.
+template <bool FILL>
+__global__ __launch_bounds__(256) void msda_taps_kernel(const float* __restrict__ offaw, int64_t ld_offaw, const float* __restrict__ ref,
+                                                        const int* __restrict__ shapes, const int* __restrict__ starts,
+                                                        int* __restrict__ cnt, int2* __restrict__ rec, int cap, int B, int Lq, int Lin,
+                                                        int M, int L, int P) {
+  const int LP = L * P;
+  const int64_t total = (int64_t)B * Lq * M;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int m = (int)(i % M);
+    const int64_t bq = i / M;
+    const int q = (int)(bq % Lq);
+    const int b = (int)(bq / Lq);
+    const float* orow = offaw + bq * ld_offaw;
+    const float* lg = orow + (int64_t)M * LP * 2 + m * LP;
+    float w[MAX_LP];
+    float mx = -1e30f;
+    for (int j = 0; j < LP; ++j) {
+      w[j] = lg[j];
+      mx = fmaxf(mx, w[j]);
+    }
+    float den = 0.f;
+    for (int j = 0; j < LP; ++j) {
+      w[j] = __expf(w[j] - mx);
+      den += w[j];
+    }
+    const float inv = 1.0f / den;
+    const float rx = ref[2 * q], ry = ref[2 * q + 1];
+    int* const cbase = cnt + (int64_t)(b * M + m) * Lin;
+    int2* const rbase = rec + (int64_t)(b * M + m) * cap;
+    for (int l = 0; l < L; ++l) {
+      const int Hl = shapes[2 * l], Wl = shapes[2 * l + 1], s0 = starts[l];
+      for (int p = 0; p < P; ++p) {
+        const int j = l * P + p;
+        const float ox = orow[(m * LP + j) * 2], oy = orow[(m * LP + j) * 2 + 1];
+        const float lx = rx + ox / (float)Wl, ly = ry + oy / (float)Hl;
+        const float px = lx * (float)Wl - 0.5f, py = ly * (float)Hl - 0.5f;
+        const float fx0 = floorf(px), fy0 = floorf(py);
+        const float ax = px - fx0, ay = py - fy0;
+        const int x0 = (int)fminf(fmaxf(fx0, -2.f), (float)Wl + 1.f);
+        const int y0 = (int)fminf(fmaxf(fy0, -2.f), (float)Hl + 1.f);
+        const float aw = w[j] * inv;
+        // the four corners' atomics are issued together and their returned positions consumed afterwards: four round trips in
+        // flight per point instead of one after the other
+        int pos[4];
+        bool ok[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int xx = x0 + (t & 1), yy = y0 + (t >> 1);
+          ok[t] = (unsigned)xx < (unsigned)Wl && (unsigned)yy < (unsigned)Hl;
+          pos[t] = ok[t] ? atomicAdd(cbase + (s0 + yy * Wl + xx), 1) : 0;      // FILL: cursors start at the bucket offsets
+        }
+        if (FILL) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            if (ok[t]) {
+              const float wv = aw * ((t & 1) ? ax : 1.f - ax) * ((t >> 1) ? ay : 1.f - ay);
+              rbase[pos[t]] = make_int2(q, __builtin_bit_cast(int, wv));
+            }
+        }
+      }
+    }
+  }
+}
+// one workgroup per (b, m): counts[Lin] -> offs[Lin + 1] (exclusive scan; offs[Lin] = the bucket total) and the fill cursors
+__global__ __launch_bounds__(256) void msda_scan_kernel(int* __restrict__ cnt, int* __restrict__ offs, int Lin) {
+  __shared__ int part[256];
+  int* c = cnt + (int64_t)blockIdx.x * Lin;
+  int* o = offs + (int64_t)blockIdx.x * (Lin + 1);
+  const int per = (Lin + 255) / 256;
+  const int i0 = threadIdx.x * per, i1 = min(i0 + per, Lin);
+  int s = 0;
+  for (int i = i0; i < i1; ++i) s += c[i];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int t = 0; t < 256; ++t) {
+      const int v = part[t];
+      part[t] = run;
+      run += v;
+    }
+    o[Lin] = run;
+  }
+  __syncthreads();
+  int run = part[threadIdx.x];
+  for (int i = i0; i < i1; ++i) {
+    const int v = c[i];
+    o[i] = run;
+    c[i] = run;          // the counts become the fill cursors
+    run += v;
+  }
+}
+// one wave per (b, m, pix): fixed-point sum of w * d out over the bucket's records
+template <typename T>
+__global__ __launch_bounds__(256) void msda_vgrad_kernel(const int* __restrict__ offs, const int2* __restrict__ rec, int cap,
+                                                         const T* __restrict__ dout16, const float* __restrict__ amax,
+                                                         float* __restrict__ dvalue, int B, int Lq, int Lin, int M, int Dh) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wv = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wv >= (int64_t)B * M * Lin) return;
+  const int pix = (int)(wv % Lin);
+  const int bm = (int)(wv / Lin);
+  const int m = bm % M, b = bm / M;
+  const int* o = offs + (int64_t)bm * (Lin + 1);
+  const int e0 = o[pix], e1 = o[pix + 1];
+  const int2* r = rec + (int64_t)bm * cap;
+  const int D = M * Dh;
+  // fixed-point grid: |w| <= 1 and |d out| <= amax < 2^(e + 1), so |w d| 2^(29 - e) < 2^30
+  int e = (int)((__builtin_bit_cast(uint32_t, *amax) >> 23) & 0xFF) - 127;
+  e = e < -100 ? -100 : (e > 90 ? 90 : e);
+  const float sc = __builtin_bit_cast(float, (uint32_t)(127 + 29 - e) << 23), isc = __builtin_bit_cast(float, (uint32_t)(127 - 29 + e) << 23);
+  for (int d0 = 2 * lane; d0 < Dh; d0 += 128) {     // Dh <= 128: one trip; wider heads: lanes loop
+    long long a0 = 0, a1 = 0;
+    // eight records at a time: their gathers are independent loads in flight together (one record per trip left every wave
+    // waiting a full memory round trip per record: the kernel ran no faster than the dense form it replaces)
+    for (int k = e0; k < e1; k += 8) {
+      int2 en[8];
+      uint32_t xv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        en[u] = r[k + u < e1 ? k + u : e1 - 1];
+        if (k + u >= e1) en[u].y = 0;        // weight 0.0f
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) xv[u] = *reinterpret_cast<const uint32_t*>(dout16 + ((int64_t)b * Lq + en[u].x) * D + m * Dh + d0);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float w = __builtin_bit_cast(float, en[u].y);
+        float x0, x1;
+        unpack2<T>(xv[u], x0, x1);
+        a0 += (long long)__float2int_rn(w * x0 * sc);
+        a1 += (long long)__float2int_rn(w * x1 * sc);
+      }
+    }
+    *reinterpret_cast<float2*>(dvalue + ((int64_t)b * Lin + pix) * D + m * Dh + d0) = make_float2((float)a0 * isc, (float)a1 * isc);
+  }
+}
+
 // ---- DWConv 3x3 + GELU backward ---------------------------------------------------------------------------------------
 __device__ __forceinline__ void locate(int tok, const int* shapes, const int* starts, int L, int& l, int& y, int& x, int& H,
                                        int& W, int& s0) {
@@ -507,6 +654,38 @@ extern "C" int asis_dwconv_gelu_bwd(void* stream, int dtype, const float* x, con
     hipLaunchKernelGGL((dwconv_t_kernel<bf16>), dim3((unsigned)gsz), dim3(256), 0, s, g, w9, shapes, starts, L,
                        reinterpret_cast<bf16*>(dx), B, Ntok, C);
   ASIS_CHECK_LAUNCH("asis_dwconv_gelu_bwd");
+  return ASIS_OK;
+}
+
+extern "C" int asis_msda_vgrad_cap(int Lq, int L, int P) { return Lq * L * P * 4; }
+
+extern "C" int asis_msda_value_grad(void* stream, int dtype, const float* offaw, int64_t ld_offaw, const float* ref,
+                                    const int32_t* shapes, const int32_t* starts, const void* dout16, const float* amax,
+                                    int32_t* cnt, int32_t* offs, void* rec, float* dvalue, int B, int Lq, int Lin, int M, int L,
+                                    int P, int Dh) {
+  ASIS_REQUIRE(offaw && ref && shapes && starts && dout16 && amax && cnt && offs && rec && dvalue, "asis_msda_value_grad: null pointer");
+  DT_OK(dtype, "asis_msda_value_grad");
+  ASIS_REQUIRE(M >= 1 && L * P >= 1 && L * P <= MAX_LP && Dh >= 2 && Dh % 2 == 0, "asis_msda_value_grad: bad shape (L*P <= %d, Dh even)", MAX_LP);
+  ASIS_REQUIRE(ld_offaw >= (int64_t)M * L * P * 3, "asis_msda_value_grad: ld_offaw too small");
+  ASIS_REQUIRE((int64_t)B * M * Lin < (1ll << 31) && (int64_t)Lq * L * P * 4 < (1ll << 31), "asis_msda_value_grad: shape too large");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int cap = asis_msda_vgrad_cap(Lq, L, P);
+  ASIS_REQUIRE(hipMemsetAsync(cnt, 0, (size_t)B * M * Lin * sizeof(int32_t), s) == hipSuccess, "asis_msda_value_grad: memset failed");
+  int64_t g = ((int64_t)B * Lq * M + 255) / 256;
+  if (g > 65535 * 8) g = 65535 * 8;
+  hipLaunchKernelGGL((msda_taps_kernel<false>), dim3((unsigned)g), dim3(256), 0, s, offaw, ld_offaw, ref, shapes, starts,
+                     reinterpret_cast<int*>(cnt), reinterpret_cast<int2*>(rec), cap, B, Lq, Lin, M, L, P);
+  hipLaunchKernelGGL(msda_scan_kernel, dim3((unsigned)(B * M)), dim3(256), 0, s, reinterpret_cast<int*>(cnt), reinterpret_cast<int*>(offs), Lin);
+  hipLaunchKernelGGL((msda_taps_kernel<true>), dim3((unsigned)g), dim3(256), 0, s, offaw, ld_offaw, ref, shapes, starts,
+                     reinterpret_cast<int*>(cnt), reinterpret_cast<int2*>(rec), cap, B, Lq, Lin, M, L, P);
+  const int64_t waves = (int64_t)B * M * Lin;
+  if (dtype == ASIS_F16)
+    hipLaunchKernelGGL((msda_vgrad_kernel<f16>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, reinterpret_cast<const int*>(offs),
+                       reinterpret_cast<const int2*>(rec), cap, reinterpret_cast<const f16*>(dout16), amax, dvalue, B, Lq, Lin, M, Dh);
+  else
+    hipLaunchKernelGGL((msda_vgrad_kernel<bf16>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, reinterpret_cast<const int*>(offs),
+                       reinterpret_cast<const int2*>(rec), cap, reinterpret_cast<const bf16*>(dout16), amax, dvalue, B, Lq, Lin, M, Dh);
+  ASIS_CHECK_LAUNCH("asis_msda_value_grad");
   return ASIS_OK;
 }
 

@@ -426,12 +426,22 @@ __global__ __launch_bounds__(256) void decoder_input_kernel(const float* __restr
 // their bits); the caller zeroes *amax first (asis_absmax_f32 does, unless it accumulates over several tensors)
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, int64_t rows, int cols, int64_t ld, float* __restrict__ amax) {
   const int c4 = cols >> 2;
-  const int64_t total = rows * c4;
   float m = 0.f;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t r = i / c4;
-    const float4 v = reinterpret_cast<const float4*>(x + r * ld)[i - r * c4];
-    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  // grid.y strides the rows, grid.x the 16-byte chunks of a row: no division per element (a flat tensor comes in as rows of
+  // 2^20 elements or as one row), two independent loads per trip
+  for (int64_t r = blockIdx.y; r < rows; r += gridDim.y) {
+    const float4* xr = reinterpret_cast<const float4*>(x + r * ld);
+    const int step = gridDim.x * blockDim.x;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + step < c4; i += 2 * step) {
+      const float4 v = xr[i], u = xr[i + step];
+      m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+      m = fmaxf(fmaxf(m, fmaxf(fabsf(u.x), fabsf(u.y))), fmaxf(fabsf(u.z), fabsf(u.w)));
+    }
+    if (i < c4) {
+      const float4 v = xr[i];
+      m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
   }
   m = wave_max(m);
   if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned int*>(amax), __builtin_bit_cast(unsigned int, m));
@@ -652,7 +662,12 @@ extern "C" int asis_absmax_f32(void* stream, const float* x, int64_t rows, int c
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (reset) ASIS_REQUIRE(hipMemsetAsync(amax, 0, sizeof(float), s) == hipSuccess, "asis_absmax_f32: memset failed");
   if (rows == 0) return ASIS_OK;
-  hipLaunchKernelGGL(absmax_kernel, dim3(grid_for(rows * (cols / 4), 256, 1024)), dim3(256), 0, s, x, rows, cols, ld, amax);
+  // ~4096 workgroups: gx over a row's chunks (at most what the row has), gy over rows
+  int gx = (int)asis_cdiv(cols / 4, 256 * 2);
+  if (gx > 4096) gx = 4096;
+  int64_t gy = asis_cdiv(4096, gx);
+  if (gy > rows) gy = rows;
+  hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, s, x, rows, cols, ld, amax);
   ASIS_CHECK_LAUNCH("asis_absmax_f32");
   return ASIS_OK;
 }
@@ -664,7 +679,7 @@ extern "C" int asis_bn_relu_absmax(void* stream, const float* x, const float* sc
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   ASIS_REQUIRE(hipMemsetAsync(amax, 0, sizeof(float), s) == hipSuccess, "asis_bn_relu_absmax: memset failed");
   if (P == 0) return ASIS_OK;
-  hipLaunchKernelGGL(bn_relu_absmax_kernel, dim3(grid_for(P * (C / 4), 256, 1024)), dim3(256), 0, s, x, scale, shift, P, C, relu, amax);
+  hipLaunchKernelGGL(bn_relu_absmax_kernel, dim3(grid_for(P * (C / 4), 256, 256 * 24)), dim3(256), 0, s, x, scale, shift, P, C, relu, amax);
   ASIS_CHECK_LAUNCH("asis_bn_relu_absmax");
   return ASIS_OK;
 }

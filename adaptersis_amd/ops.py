@@ -607,6 +607,9 @@ def dwconv_gelu(x: torch.Tensor, w9: torch.Tensor, bias: torch.Tensor, shapes_i3
 # CNN encoder / decoder companions
 # --------------------------------------------------------------------------------------------
 _ST_CACHE = {}
+# d value of MSDeformAttn as a gather over taps bucketed by destination pixel (round 4); ASIS_MSDA_SORTED=0: the dense sampling
+# matrix + batched GEMMs of round 2 (a 2.4 GB matrix at the headline batch)
+MSDA_SORTED = os.environ.get("ASIS_MSDA_SORTED", "1") not in ("0", "")
 
 
 def msda_bwd(value: torch.Tensor, offaw: torch.Tensor, ref: torch.Tensor, shapes_i32: torch.Tensor, starts_i32: torch.Tensor,
@@ -626,7 +629,25 @@ def msda_bwd(value: torch.Tensor, offaw: torch.Tensor, ref: torch.Tensor, shapes
                               _f32c(ref).data_ptr(), shapes_i32.data_ptr(), starts_i32.data_ptr(), _f32c(dout).data_ptr(),
                               None if use_dense else dvalue.data_ptr(), doffaw.data_ptr(), B, Lq, Lin, M, L, P, Dh),
           "asis_msda_bwd")
-    if use_dense:
+    if use_dense and MSDA_SORTED:
+        # taps bucketed by destination pixel + one wave per (image, head, pixel) (csrc/adapter_bwd.hip): no dense matrix
+        dt = value.dtype
+        d16 = cast_pad(dout, D, dt)
+        amax = absmax_f32(dout)
+        cap = lib().asis_msda_vgrad_cap(Lq, L, P)
+        key = ("sorted", B, M, Lin, cap, value.device)
+        ws = _ST_CACHE.get(key)
+        if ws is None:
+            for k in [k for k in _ST_CACHE if k[0] != "sorted"]:
+                del _ST_CACHE[k]
+            ws = (torch.empty(B * M * Lin, device=value.device, dtype=torch.int32),
+                  torch.empty(B * M * (Lin + 1), device=value.device, dtype=torch.int32),
+                  torch.empty((B * M * cap, 2), device=value.device, dtype=torch.int32))
+            _ST_CACHE[key] = ws
+        check(lib().asis_msda_value_grad(_stream(), _dt(dt), offaw.data_ptr(), offaw.stride(0), ref.data_ptr(), shapes_i32.data_ptr(),
+                                         starts_i32.data_ptr(), d16.data_ptr(), amax.data_ptr(), ws[0].data_ptr(), ws[1].data_ptr(),
+                                         ws[2].data_ptr(), dvalue.data_ptr(), B, Lq, Lin, M, L, P, Dh), "asis_msda_value_grad")
+    elif use_dense:
         dt = value.dtype
         ldt = token_ld(Lq)
         key = (B, M, Lin, ldt, dt, value.device)
@@ -783,7 +804,8 @@ def absmax_f32(x: torch.Tensor, amax: Optional[torch.Tensor] = None) -> torch.Te
         if cols % 4:
             raise ValueError("absmax_f32: element count must be a multiple of 4")
         # rows of at most 2^20 elements keep the grid busy
-        cols = 1 << 20 if x.numel() % (1 << 20) == 0 else (x.shape[-1] if x.dim() > 1 else x.numel())
+        # rows of 2^16 .. 2^20 elements spread the work over the grid's two dimensions
+        cols = next((c for c in (1 << 20, 1 << 18, 1 << 16) if x.numel() % c == 0), x.shape[-1] if x.dim() > 1 else x.numel())
         rows, ld = x.numel() // cols, cols
     elif x.dim() == 3 and x[0].is_contiguous():
         rows, cols, ld = x.shape[0], x.shape[1] * x.shape[2], x.stride(0)

@@ -321,6 +321,14 @@ int asis_msda_bwd(void* stream, int dtype, const void* value, const float* offaw
  * attention-weighted bilinear sampling weight of query q on pixel pix for head m; then
  *   d value[b, :, m*Dh:(m+1)*Dh] = ST[b, m] (Lin x Lq) . d out[b, :, m*Dh:(m+1)*Dh] (Lq x Dh)      (asis_gemm, batch B per head).
  * asis_msda_bwd with dvalue == NULL then only produces doffaw. */
+/* d value as a gather over taps bucketed by destination pixel (csrc/adapter_bwd.hip; replaces the dense sampling matrix, its
+ * memset and the batched GEMMs): dout16 = 16-bit copy of d out [B*Lq, M*Dh], amax = device float >= max |d out| (asis_absmax_f32);
+ * workspaces cnt int32 [B*M*Lin], offs int32 [B*M*(Lin+1)], rec 8-byte records [B*M*asis_msda_vgrad_cap(Lq, L, P)];
+ * dvalue fp32 [B, Lin, M*Dh], every element written.  Bitwise reproducible (64-bit fixed-point sums). */
+int asis_msda_vgrad_cap(int Lq, int L, int P);
+int asis_msda_value_grad(void* stream, int dtype, const float* offaw, int64_t ld_offaw, const float* ref, const int32_t* shapes,
+                         const int32_t* starts, const void* dout16, const float* amax, int32_t* cnt, int32_t* offs, void* rec,
+                         float* dvalue, int B, int Lq, int Lin, int M, int L, int P, int Dh);
 int asis_msda_sampling_matrix(void* stream, int dtype, const float* offaw, int64_t ld_offaw, const float* ref,
                               const int32_t* shapes, const int32_t* starts, void* ST, int64_t ldt, int B, int Lq, int Lin,
                               int M, int L, int P);

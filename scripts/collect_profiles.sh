@@ -2,7 +2,7 @@
 # copied into profiles/ afterwards (scripts/kernel_stats_from_db.py, scripts/pmc_traffic.py).
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"
-O=gpurun_out/r03; mkdir -p $O
+O=gpurun_out/r04; mkdir -p $O
 if [ "$1" = "A" ]; then
   echo "[A1] bench line (default command)"; python bench.py > $O/bench_line.json 2> $O/bench_line.err && tail -c 600 $O/bench_line.json &&
   echo "[A2] kernel trace, default command (side streams on: overlapped launches are stretched)" &&

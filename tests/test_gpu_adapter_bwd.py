@@ -43,13 +43,57 @@ def test_msda_backward(dev, case):
     fwd = ops.msda_fwd(value.to(dev), offaw, ref.to(dev), sh, st, B, Lq, M, L, P)
     assert rel_l2(fwd.view(B, Lq, D), out) < 2e-3
     n_off = M * L * P * 2
-    for dense in (False, True):   # scatter kernels (fp32 throughout) / dense sampling matrix + 16-bit MFMA GEMM
-        dvalue, doffaw = ops.msda_bwd(value.to(dev), offaw, ref.to(dev), sh, st, dout.reshape(B * Lq, D).contiguous().to(dev),
-                                      B, Lq, M, L, P, dense=dense)
+    # scatter kernels (fp32 throughout) / taps bucketed by pixel + 64-bit fixed-point sums (the default, round 4) / the dense
+    # sampling matrix + 16-bit MFMA GEMMs of round 2
+    dout_d = dout.reshape(B * Lq, D).contiguous().to(dev)
+    for form in ("scatter", "sorted", "matrix"):
+        old = ops.MSDA_SORTED
+        ops.MSDA_SORTED = form == "sorted"
+        try:
+            dvalue, doffaw = ops.msda_bwd(value.to(dev), offaw, ref.to(dev), sh, st, dout_d, B, Lq, M, L, P, dense=form != "scatter")
+            if form == "sorted":
+                dv2, _ = ops.msda_bwd(value.to(dev), offaw, ref.to(dev), sh, st, dout_d, B, Lq, M, L, P, dense=True)
+                assert torch.equal(dvalue, dv2), "sorted form is not reproducible run to run"
+        finally:
+            ops.MSDA_SORTED = old
         e = (rel_l2(dvalue.view(B, Lin, M, Dh), v_r.grad), rel_l2(doffaw[:, :n_off].reshape(off.shape), off_r.grad),
              rel_l2(doffaw[:, n_off:].reshape(logit.shape), lg_r.grad))
-        print(case, "dense" if dense else "scatter", "dvalue doff dlogit:", ["%.1e" % v for v in e])
-        assert e[0] < (1e-3 if dense and D % 64 == 0 else 1e-4) and max(e[1:]) < 1e-4, e
+        print(case, form, "dvalue doff dlogit:", ["%.1e" % v for v in e])
+        assert e[0] < (1e-3 if form != "scatter" and D % 64 == 0 else 1e-4) and max(e[1:]) < 1e-4, e
+
+
+def test_msda_value_grad_sorted_at_the_adapter_geometry(dev):
+    """the two MSDeformAttn geometries of the step at ViT-L width (CAViT: 1764 queries on the 73^2 / 36^2 / 18^2 pyramid; CACNN:
+    6949 queries on the 42^2 map), two images: sorted form == dense-matrix form up to the matrix's 16-bit rounding, and bit for
+    bit reproducible."""
+    for Lq, shapes in ((1764, [(73, 73), (36, 36), (18, 18)]), (6949, [(42, 42)])):
+        B, M, Dh, P = 2, 8, 128, 4
+        L, D = len(shapes), M * Dh
+        Lin = sum(a * b for a, b in shapes)
+        value = W.tensor(f"msg.v{Lq}", (B, Lin, D), 1.0).to(DT).to(dev)
+        off = W.tensor(f"msg.o{Lq}", (B * Lq, M * L * P * 2), 2.5)
+        logit = W.tensor(f"msg.l{Lq}", (B * Lq, M * L * P), 1.0)
+        offaw = torch.cat([off, logit], 1).contiguous().to(dev)
+        g = torch.arange(Lq, dtype=torch.float32)
+        ref = torch.stack([(g % 42 + 0.5) / 42 % 1.0, ((g // 42) % 42 + 0.5) / 42], -1).to(dev)
+        dout = W.tensor(f"msg.d{Lq}", (B * Lq, D), 1e-3).to(dev)          # gradient-sized values
+        starts, acc = [], 0
+        for a, b in shapes:
+            starts.append(acc); acc += a * b
+        sh = torch.tensor(shapes, dtype=torch.int32, device=dev)
+        st = torch.tensor(starts, dtype=torch.int32, device=dev)
+        outs = {}
+        for form in ("sorted", "sorted2", "matrix"):
+            old = ops.MSDA_SORTED
+            ops.MSDA_SORTED = form != "matrix"
+            try:
+                outs[form], _ = ops.msda_bwd(value, offaw, ref, sh, st, dout, B, Lq, M, L, P)
+            finally:
+                ops.MSDA_SORTED = old
+        assert torch.equal(outs["sorted"], outs["sorted2"])
+        e = rel_l2(outs["sorted"], outs["matrix"])
+        print(f"MSDA d value, Lq {Lq}: sorted vs dense matrix rel-L2 {e:.2e}")
+        assert e < 1e-3
 
 
 def test_dwconv_gelu_backward(dev):
