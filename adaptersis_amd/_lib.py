@@ -181,6 +181,7 @@ SIGNATURES = {
     "asis_grad_guard": [_vp, _vp, _i64, _vp, _i],
     "asis_sgd_momentum_guarded": [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i, _vp, _i],
     "asis_scale_f32": [_vp, _vp, _i64, _f],
+    "asis_zero": [_vp, _vp, _i64],
     "asis_grad_pack_bf16": [_vp, _vp, _i64, _vp],
     "asis_grad_unpack_bf16": [_vp, _vp, _i64, _vp],
 }

@@ -492,7 +492,7 @@ class SegEngine(nn.Module):
                 # UNet head: the decoder input is the adapter stream alone; the encoder / backbone backward walks take the
                 # FeatureDecoder layout [stream | c4 (padded) | pass-A feature], whose other two gradient slices are zero here
                 Bq, hq, wq, Dq = dcat.shape
-                full = torch.zeros((Bq, hq, wq, 3 * Dq), device=dcat.device, dtype=dcat.dtype)
+                full = ops.zeros((Bq, hq, wq, 3 * Dq), dcat.device, dcat.dtype)
                 ops.copy_channels(dcat.view(-1, Dq), full.view(-1, 3 * Dq)[:, :Dq])
                 dcat = full
             self.adapter_reducer.begin()
@@ -615,11 +615,11 @@ class SegEngine(nn.Module):
         Ra, Rb = B * (N + 1), B * N
         dev = dcat.device
         ab, vg = self.adapter_bucket, self.vit_bucket.views
-        slabs = torch.zeros((nl, ab.numel), device=dev, dtype=torch.float32)
-        nslab = torch.zeros((nl, 2 * D), device=dev, dtype=torch.float32)
+        slabs = ops.zeros((nl, ab.numel), dev)
+        nslab = ops.zeros((nl, 2 * D), dev)
         nw = m.norm.weight.detach().float().contiguous()
         dcat2 = dcat.view(B * N, D3)
-        G = torch.zeros((Ra + Rb, D), device=dev, dtype=torch.float32)
+        G = ops.zeros((Ra + Rb, D), dev)
         ops.copy_channels(dcat2[:, :D], G[Ra:])
         dvit = torch.empty((B * N, D), device=dev, dtype=torch.float32)       # pass-A slice of the decoder input
         ops.copy_channels(dcat2[:, 2 * D:], dvit)
@@ -628,7 +628,7 @@ class SegEngine(nn.Module):
             s_cv, s_cn = asaves[s]
             gs = {n: slabs[s, o:o + p.numel()].view(p.shape) for n, p, o in zip(ab.names, ab.params, ab.offsets)}
             # d f_s: the stage's residual add, + the decoder input's third slice for the last feature
-            dyA = torch.zeros((B, N + 1, D), device=dev, dtype=torch.float32)
+            dyA = ops.zeros((B, N + 1, D), dev)
             ops.copy_channels(G[Ra:].view(B, N * D), dyA.view(B, (N + 1) * D)[:, D:])
             if s == nl - 1:
                 ops.add_f32(dyA[:, 1:], dvit.view(B, N, D), out=dyA[:, 1:])
@@ -682,7 +682,7 @@ class SegEngine(nn.Module):
         nl = self.n_last_blocks
         nb = len(m.blocks)
         ab = self.adapter_bucket
-        slabs = torch.zeros((nl, ab.numel), device=dcat.device, dtype=torch.float32)
+        slabs = ops.zeros((nl, ab.numel), dcat.device)
         dx = torch.empty((B * N, D), device=dcat.device, dtype=torch.float32)
         ops.copy_channels(dcat.view(B * N, D3)[:, :D], dx)
         dc_next = None
@@ -713,7 +713,7 @@ class SegEngine(nn.Module):
         B, h, w, D = dmaps[0].shape
         N = h * w
         ab = self.adapter_bucket
-        slabs = torch.zeros((4, ab.numel), device=dmaps[0].device, dtype=torch.float32)
+        slabs = ops.zeros((4, ab.numel), dmaps[0].device)
         d_out = [dmaps[3], dmaps[2], dmaps[1], dmaps[0]]          # gradients of x0, x1, x2, x3
         dx = d_out[3].reshape(B * N, D).contiguous()
         dc_from_next = None                                        # gradient of c_j through CACNN_{j+1}'s query input

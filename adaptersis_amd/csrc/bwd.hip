@@ -523,6 +523,13 @@ extern "C" int asis_grad_unpack_bf16(void* stream, const void* in, int64_t n, fl
   return ASIS_OK;
 }
 
+extern "C" int asis_zero(void* stream, void* p, int64_t bytes) {
+  ASIS_REQUIRE(p && bytes >= 0, "asis_zero: bad arguments");
+  if (bytes == 0) return ASIS_OK;
+  ASIS_REQUIRE(hipMemsetAsync(p, 0, (size_t)bytes, reinterpret_cast<hipStream_t>(stream)) == hipSuccess, "asis_zero: hipMemsetAsync failed");
+  return ASIS_OK;
+}
+
 extern "C" int asis_scale_f32(void* stream, float* x, int64_t n, float a) {
   ASIS_REQUIRE(x && n >= 0, "asis_scale_f32: bad arguments");
   if (n == 0) return ASIS_OK;

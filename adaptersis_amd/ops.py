@@ -624,7 +624,7 @@ def msda_bwd(value: torch.Tensor, offaw: torch.Tensor, ref: torch.Tensor, shapes
     doffaw = torch.empty_like(offaw)
     use_dense = dense and Dh % 8 == 0 and D % 64 == 0   # token transpose works on 64-column tiles
     dvalue = torch.empty((B, Lin, D), device=value.device, dtype=torch.float32) if use_dense else \
-        torch.zeros((B, Lin, D), device=value.device, dtype=torch.float32)
+        zeros((B, Lin, D), value.device)
     check(lib().asis_msda_bwd(_stream(), _dt(value.dtype), value.data_ptr(), _f32c(offaw).data_ptr(), offaw.stride(0),
                               _f32c(ref).data_ptr(), shapes_i32.data_ptr(), starts_i32.data_ptr(), _f32c(dout).data_ptr(),
                               None if use_dense else dvalue.data_ptr(), doffaw.data_ptr(), B, Lq, Lin, M, L, P, Dh),
@@ -656,7 +656,7 @@ def msda_bwd(value: torch.Tensor, offaw: torch.Tensor, ref: torch.Tensor, shapes
             _ST_CACHE.clear()          # one resident sampling matrix (2.4 GB at B = 12, 588^2): the call shapes alternate
             ST = torch.empty((B * M, Lin, ldt), device=value.device, dtype=dt)
             _ST_CACHE[key] = ST
-        ST.zero_()
+        check(lib().asis_zero(_stream(), ST.data_ptr(), ST.numel() * ST.element_size()), "asis_zero")
         check(lib().asis_msda_sampling_matrix(_stream(), _dt(dt), offaw.data_ptr(), offaw.stride(0), ref.data_ptr(),
                                               shapes_i32.data_ptr(), starts_i32.data_ptr(), ST.data_ptr(), ldt, B, Lq, Lin, M, L,
                                               P), "asis_msda_sampling_matrix")
@@ -1326,6 +1326,17 @@ def grad_unpack_bf16(src: torch.Tensor, g: torch.Tensor) -> None:
     if src.dtype != torch.bfloat16 or src.numel() != g.numel() or not src.is_contiguous():
         raise ValueError("grad_unpack_bf16: src must be a contiguous bfloat16 tensor of the same length")
     check(lib().asis_grad_unpack_bf16(_stream(), src.data_ptr(), g.numel(), _f32c(g).data_ptr()), "asis_grad_unpack_bf16")
+
+
+def zeros(shape, device, dtype=torch.float32) -> torch.Tensor:
+    """zero-filled device tensor through hipMemsetAsync (asis_zero) instead of an ATen fill kernel (165 us per 173 MB in the
+    config-4 step against ~30 us): the few buffers of the step that kernels ACCUMULATE into or only partly write"""
+    t = torch.empty(shape, device=device, dtype=dtype)
+    if t.is_cuda:
+        check(lib().asis_zero(_stream(), t.data_ptr(), t.numel() * t.element_size()), "asis_zero")
+    else:
+        t.zero_()
+    return t
 
 
 def sgd_momentum(p: torch.Tensor, g: torch.Tensor, buf: torch.Tensor, lr: float, momentum: float, weight_decay: float,

@@ -220,27 +220,44 @@ def cpu_baseline(arch: str, size: int, batch: int = 1):
     }
 
 
+def gemm_sources_sha256():
+    """hash of adaptersis_amd/csrc/gemm* (the kernels the roofline figures are about): scripts/pmc_traffic.py stores it with a
+    traffic measurement, and a measurement taken on other kernel sources is not reported"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "adaptersis_amd", "csrc", "gemm*"))):
+        if f.endswith((".h", ".hip")):
+            h.update(os.path.basename(f).encode())
+            h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 def pmc_traffic(kernel: str, variants):
     """HBM-side bytes per launch of the dominant kernel — the launch-weighted mean over its listed template forms — from the
     committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate runs of this very command, gfx950 read-side
     doubling applied: scripts/pmc_traffic.py).  PMC counters cannot be collected from inside the timed run, so this is the
-    figure of the last profiled run."""
+    figure of the last profiled run — reported ONLY when that run's GEMM kernel sources are the ones of this tree (sha256 of
+    adaptersis_amd/csrc/gemm*); otherwise ``traffic`` is null and the reason is in ``traffic_source``."""
     here = os.path.dirname(os.path.abspath(__file__))
-    for fn in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
-        path = os.path.join(here, "profiles", fn)
-        if os.path.exists(path):
-            break
-    else:
-        return None, None
-    with open(path) as f:
+    cands = sorted((f for f in os.listdir(os.path.join(here, "profiles")) if f.endswith("_pmc_traffic.json")), reverse=True) \
+        if os.path.isdir(os.path.join(here, "profiles")) else []
+    if not cands:
+        return None, {"reason": "no profiles/*_pmc_traffic.json"}
+    fn = cands[0]
+    with open(os.path.join(here, "profiles", fn)) as f:
         doc = json.load(f)
+    src = {"file": "profiles/" + fn, "commit": doc.get("commit"), "command": doc.get("command")}
+    if doc.get("gemm_sources_sha256") != gemm_sources_sha256():
+        src["reason"] = ("stale: the PMC passes were taken on other GEMM kernel sources (gemm_sources_sha256 differs); re-run "
+                         "scripts/collect_profiles.sh on this tree")
+        return None, src
     rows = doc["kernels"]
     tot = n = 0
     for name, v in rows.items():
         if any(k in name for k in kernel) and any(var in name for var in variants):
             tot += v["hbm_bytes_total"]
             n += v["launches"]
-    src = {"file": "profiles/" + fn, "commit": doc.get("commit"), "command": doc.get("command")}
     return (round(tot / n) if n else None), src
 
 

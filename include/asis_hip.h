@@ -639,6 +639,8 @@ int asis_grad_guard(void* stream, const float* g, int64_t n, int32_t* guard, int
 int asis_sgd_momentum_guarded(void* stream, float* p, const float* g, float* buf, int64_t n, float lr, float momentum,
                               float weight_decay, float inv_scale, int first_step, int32_t* guard, int count_skip);
 int asis_scale_f32(void* stream, float* x, int64_t n, float a);
+/* zero `bytes` bytes at p on `stream` (hipMemsetAsync: the DMA fill, ~6 TB/s; the step's few accumulate-into buffers) */
+int asis_zero(void* stream, void* p, int64_t bytes);
 /* 16-bit transport form of a gradient range for the data-parallel all-reduce (replaces nothing in the reference: DDP's
  * bf16 compression hook `torch.distributed.algorithms.ddp_comm_hooks.default_hooks.bf16_compress_hook` is the torch-side
  * counterpart; train.py:84-116 wraps its modules in plain fp32 DDP).  g fp32 [n] <-> out bf16 [n], n % 4 == 0, RNE. */

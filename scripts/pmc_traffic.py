@@ -11,10 +11,25 @@ global loads or LDS-DMA); WRITE_SIZE is exact for 16-byte-per-lane stores.
 """
 import csv
 import glob
+import hashlib
 import json
+import os
 import re
 import sys
 from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def gemm_sources_sha256():
+    """hash of the dense-GEMM kernel sources the traffic figure belongs to (bench.py refuses a figure whose hash differs from the
+    tree it runs in: the GPU box has no .git to ask)"""
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "adaptersis_amd", "csrc", "gemm*"))):
+        if f.endswith((".h", ".hip")):
+            h.update(os.path.basename(f).encode())
+            h.update(open(f, "rb").read())
+    return h.hexdigest()
 
 
 def load(d, counter):
@@ -50,6 +65,7 @@ def main():
     rows = dict(sorted(rows.items(), key=lambda kv: -kv[1]["hbm_bytes_total"]))
     json.dump({"note": "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 per the guide's gfx950 correction; averages over all "
                        "launches of the kernel in the profiled bench.py run", "commit": commit, "command": command,
+               "gemm_sources_sha256": gemm_sources_sha256(),
                "kernels": rows}, open(out, "w"), indent=1)
     for k, v in list(rows.items())[:25]:
         print(f"{v['launches']:6d}  {v['hbm_bytes_per_launch'] / 1e6:10.2f} MB/launch  {v['hbm_bytes_total'] / 1e9:8.2f} GB  {k[:110]}")
