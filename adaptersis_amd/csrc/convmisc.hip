@@ -423,46 +423,68 @@ __global__ __launch_bounds__(256) void decoder_input_kernel(const float* __restr
 }
 
 // |x| maximum of an fp32 tensor [rows, cols] (row stride ld) -> atomicMax on the bit pattern (non-negative floats order like
-// their bits); the caller zeroes *amax first (asis_absmax_f32 does, unless it accumulates over several tensors)
+// their bits); the caller zeroes *amax first (asis_absmax_f32 does, unless it accumulates over several tensors).
+// ONE atomic per workgroup and at most ~1024 workgroups: same-address atomics retire one at a time in L2 (the first version's
+// 16-24 k per-wave atomics cost 190-285 us whatever the tensor's size).
+__device__ __forceinline__ void block_amax_commit(float m, float* __restrict__ amax) {
+  __shared__ float red[4];
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    if (m > 0.f) atomicMax(reinterpret_cast<unsigned int*>(amax), __builtin_bit_cast(unsigned int, m));
+  }
+}
+__device__ __forceinline__ float amax4(float m, const float4 v) {
+  return fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+}
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, int64_t rows, int cols, int64_t ld, float* __restrict__ amax) {
   const int c4 = cols >> 2;
   float m = 0.f;
-  // grid.y strides the rows, grid.x the 16-byte chunks of a row: no division per element (a flat tensor comes in as rows of
-  // 2^20 elements or as one row), two independent loads per trip
+  // grid.y strides the rows, grid.x the 16-byte chunks of a row: no division per element; four independent loads per trip from
+  // clamped addresses (a chunk read twice does not change a maximum)
   for (int64_t r = blockIdx.y; r < rows; r += gridDim.y) {
     const float4* xr = reinterpret_cast<const float4*>(x + r * ld);
     const int step = gridDim.x * blockDim.x;
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    for (; i + step < c4; i += 2 * step) {
-      const float4 v = xr[i], u = xr[i + step];
-      m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
-      m = fmaxf(fmaxf(m, fmaxf(fabsf(u.x), fabsf(u.y))), fmaxf(fabsf(u.z), fabsf(u.w)));
-    }
-    if (i < c4) {
-      const float4 v = xr[i];
-      m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < c4; i += 4 * step) {
+      const float4 v0 = xr[i], v1 = xr[min(i + step, c4 - 1)], v2 = xr[min(i + 2 * step, c4 - 1)], v3 = xr[min(i + 3 * step, c4 - 1)];
+      m = amax4(amax4(amax4(amax4(m, v0), v1), v2), v3);
     }
   }
-  m = wave_max(m);
-  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned int*>(amax), __builtin_bit_cast(unsigned int, m));
+  block_amax_commit(m, amax);
 }
 // the same of relu(x * scale[c] + shift[c]) (the tensor a BatchNorm + ReLU (+ bilinear upsampling: a convex combination) kernel
-// is about to write), x fp32 [P, C]
+// is about to write), x fp32 [P, C].  The grid's stride is a multiple of C / 4 whenever C / 4 divides 256, so a thread stays on
+// one channel group and keeps its scale / shift in registers.
 __global__ __launch_bounds__(256) void bn_relu_absmax_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                                              const float* __restrict__ shift, int64_t P, int C, int relu, float* __restrict__ amax) {
   const int c4 = C >> 2;
   const int64_t total = P * c4;
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   float m = 0.f;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int c = (int)(i % c4);
-    const float4 v = reinterpret_cast<const float4*>(x)[i];
-    const float4 sc = reinterpret_cast<const float4*>(scale)[c], sh = reinterpret_cast<const float4*>(shift)[c];
+  auto one = [&](const float4 v, const float4 sc, const float4 sh) {
     float a0 = v.x * sc.x + sh.x, a1 = v.y * sc.y + sh.y, a2 = v.z * sc.z + sh.z, a3 = v.w * sc.w + sh.w;
     if (!relu) { a0 = fabsf(a0); a1 = fabsf(a1); a2 = fabsf(a2); a3 = fabsf(a3); }
     m = fmaxf(fmaxf(m, fmaxf(a0, a1)), fmaxf(a2, a3));
+  };
+  if (256 % c4 == 0) {
+    const int c = (int)(i0 % c4);
+    const float4 sc = reinterpret_cast<const float4*>(scale)[c], sh = reinterpret_cast<const float4*>(shift)[c];
+    const float4* xv = reinterpret_cast<const float4*>(x);
+    const int64_t last = i0 < total ? total - 1 - (total - 1 - i0) % step : 0;   // this thread's last element (same channel group)
+    for (int64_t i = i0; i < total; i += 4 * step) {
+      const float4 v0 = xv[i], v1 = xv[min(i + step, last)], v2 = xv[min(i + 2 * step, last)], v3 = xv[min(i + 3 * step, last)];
+      one(v0, sc, sh); one(v1, sc, sh); one(v2, sc, sh); one(v3, sc, sh);
+    }
+  } else {
+    for (int64_t i = i0; i < total; i += step) {
+      const int c = (int)(i % c4);
+      one(reinterpret_cast<const float4*>(x)[i], reinterpret_cast<const float4*>(scale)[c], reinterpret_cast<const float4*>(shift)[c]);
+    }
   }
-  m = wave_max(m);
-  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned int*>(amax), __builtin_bit_cast(unsigned int, m));
+  block_amax_commit(m, amax);
 }
 
 // SwiGLU gate (dinov2/layers/swiglu_ffn.py:30-34): x12 fp32 [R, 2*Hd] -> silu(x1) * x2 as 16-bit [R, Hd]
@@ -662,10 +684,10 @@ extern "C" int asis_absmax_f32(void* stream, const float* x, int64_t rows, int c
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (reset) ASIS_REQUIRE(hipMemsetAsync(amax, 0, sizeof(float), s) == hipSuccess, "asis_absmax_f32: memset failed");
   if (rows == 0) return ASIS_OK;
-  // ~4096 workgroups: gx over a row's chunks (at most what the row has), gy over rows
-  int gx = (int)asis_cdiv(cols / 4, 256 * 2);
-  if (gx > 4096) gx = 4096;
-  int64_t gy = asis_cdiv(4096, gx);
+  // ~1024 workgroups (one atomic each): gx over a row's chunks (four per thread and trip), gy over rows
+  int gx = (int)asis_cdiv(cols / 4, 256 * 4);
+  if (gx > 1024) gx = 1024;
+  int64_t gy = asis_cdiv(1024, gx);
   if (gy > rows) gy = rows;
   hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, s, x, rows, cols, ld, amax);
   ASIS_CHECK_LAUNCH("asis_absmax_f32");
@@ -679,7 +701,7 @@ extern "C" int asis_bn_relu_absmax(void* stream, const float* x, const float* sc
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   ASIS_REQUIRE(hipMemsetAsync(amax, 0, sizeof(float), s) == hipSuccess, "asis_bn_relu_absmax: memset failed");
   if (P == 0) return ASIS_OK;
-  hipLaunchKernelGGL(bn_relu_absmax_kernel, dim3(grid_for(P * (C / 4), 256, 256 * 24)), dim3(256), 0, s, x, scale, shift, P, C, relu, amax);
+  hipLaunchKernelGGL(bn_relu_absmax_kernel, dim3(grid_for(asis_cdiv(P * (C / 4), 4), 256, 1024)), dim3(256), 0, s, x, scale, shift, P, C, relu, amax);
   ASIS_CHECK_LAUNCH("asis_bn_relu_absmax");
   return ASIS_OK;
 }

@@ -803,10 +803,9 @@ def absmax_f32(x: torch.Tensor, amax: Optional[torch.Tensor] = None) -> torch.Te
         rows, cols, ld = 1, x.numel(), x.numel()
         if cols % 4:
             raise ValueError("absmax_f32: element count must be a multiple of 4")
-        # rows of at most 2^20 elements keep the grid busy
-        # rows of 2^16 .. 2^20 elements spread the work over the grid's two dimensions
-        cols = next((c for c in (1 << 20, 1 << 18, 1 << 16) if x.numel() % c == 0), x.shape[-1] if x.dim() > 1 else x.numel())
-        rows, ld = x.numel() // cols, cols
+        if cols >= 1 << 31:    # rows of 2^16 .. 2^20 elements (the kernel's column index is an int)
+            cols = next((c for c in (1 << 20, 1 << 18, 1 << 16) if x.numel() % c == 0), x.shape[-1] if x.dim() > 1 else x.numel())
+            rows, ld = x.numel() // cols, cols
     elif x.dim() == 3 and x[0].is_contiguous():
         rows, cols, ld = x.shape[0], x.shape[1] * x.shape[2], x.stride(0)
     elif x.dim() == 2:
