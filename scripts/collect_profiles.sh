@@ -1,4 +1,4 @@
-# Round evidence on ONE box (bash scripts/collect_profiles.sh A|B): everything lands under gpurun_out/r03/, the summaries are
+# Round evidence on ONE box (bash scripts/collect_profiles.sh A|B): everything lands under gpurun_out/r04/, the summaries are
 # copied into profiles/ afterwards (scripts/kernel_stats_from_db.py, scripts/pmc_traffic.py).
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"
@@ -13,6 +13,9 @@ if [ "$1" = "A" ]; then
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --single-stream > $O/pmc_fetch.log 2>&1 &&
   echo "[A5] PMC WRITE_SIZE" &&
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --single-stream > $O/pmc_write.log 2>&1 &&
+  echo "[A5b] PMC matrix-pipe busy cycles + GRBM_GUI_ACTIVE (effective clock)" &&
+  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_mfma -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --single-stream > $O/pmc_mfma.log 2>&1 &&
+  python scripts/mfma_util.py $O/pmc_mfma $O/mfma_util.txt > /dev/null &&
   echo "[A6] per-shape GEMM table" &&
   ASIS_BENCH_SHAPES=1 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/shapes.json 2> $O/shapes.txt && grep -c "TF/s" $O/shapes.txt &&
   echo "[A done]"

@@ -132,6 +132,37 @@ def test_config4_vitl_24_blocks_unfrozen(dev, mode):
         assert gmax < 2.5e-1 and gmed < 5e-2, (nm, worst)
 
 
+def test_config4_init_bf16_operands(dev):
+    """config 4 at the reference init under ``ASIS_OPERAND=bf16``: bf16 keeps fp32's exponent range, so the
+    LayerScale'd ViT gradients need no loss scale at all; what it pays is the 8-bit mantissa on every 16-bit gradient tensor.
+    Forward at TOL (the reference-init configuration holds 1e-3 in bf16), gradients at the bounds measured."""
+    g, tag = load_golden("c4full"), "c4full_init"
+    old_dt, old_ls = config.operand_dtype, config.loss_scale
+    config.set_operand_dtype(torch.bfloat16)
+    config.loss_scale = 1.0
+    try:
+        D, depth, model, enc, cv, cn = _modules("vit_large", "init", dev, train=True)
+        feats = (D, 512, 256, 128, 64)
+        dec = FeatureDecoder(embed_dim=D, num_classes=2, features=list(feats)); dec.load_state_dict(W.make_feature_decoder_state_dict(D, 2, features=feats))
+        eng = SegEngine(model, enc, cv, cn, dec.to(dev), lr=0.01, mode="train_adapters", train_encoder=True, train_backbone=True)
+        img, tgt = W.synthetic_batch(1, 588)
+        taps = {}
+        loss = eng.train_step(img.to(dev), tgt.to(dev), taps)
+        e_lg = golden_err(taps["logits"].permute(0, 3, 1, 2), g[f"{tag}.logits"])
+        print(f"{tag} bf16 operands: logits {e_lg:.2e} loss {float(loss):.6f} golden {float(g[tag + '.loss']):.6f}")
+        assert e_lg < TOL and abs(float(loss) - float(g[f"{tag}.loss"])) < 1e-4
+        groups = {"vit": (eng.vit_bucket.views, f"{tag}.grad.vit."), "adapter": (eng.adapter_bucket.views, f"{tag}.grad."),
+                  "encoder": (eng.encoder_bucket.views, f"{tag}.grad."), "decoder": (eng.bucket.views, f"{tag}.grad.dec.")}
+        for nm, (views, pre) in groups.items():
+            n, gmax, gmed, worst = _grad_stats(views, g, pre, skip_bias0=(nm == "decoder"))
+            print(f"  {tag} bf16 {nm}: n={n} max {gmax:.2e} median {gmed:.2e} worst {worst}")
+            assert n >= (1 if nm == "adapter" else 10)
+            assert gmax < 6e-2 and gmed < 2e-2, (nm, worst)      # measured: ViT max 3.0e-2 / median 8.1e-3, encoder 1.5e-2 / 1.1e-2
+    finally:
+        config.set_operand_dtype(old_dt)
+        config.loss_scale = old_ls
+
+
 def test_config5_stress_on_single_16bit_operands_is_the_documented_1p3e3(dev):
     """The same ViT-g/14 40-block stress case FORCED onto level 0 (single 16-bit operands + split attention output, what every
     other geometry runs): the record of why the default policy of this geometry is level 2 — 1.30e-3 measured, bound 1.5e-3;
