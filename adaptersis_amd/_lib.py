@@ -81,6 +81,8 @@ SIGNATURES = {
     "asis_gemm_tiles_m": [_i],
     "asis_absmax_f32": [_vp, _vp, _i64, _i, _i64, _vp, _i],
     "asis_bn_relu_absmax": [_vp, _vp, _vp, _vp, _i64, _i, _i, _vp],
+    "asis_absmax_16": [_vp, _i, _vp, _i64, _i, _i64, _vp],
+    "asis_mx_from_pair": [_vp, _i, _vp, _vp, _i64, _vp, _i64, _i64, _i, _vp, _i],
     "asis_bn_relu_upsample_mx": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i],
     "asis_pack_conv_weight_mx": [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i64, _vp],
     "asis_decoder_input_mx": [_vp, _i, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i],
@@ -88,6 +90,7 @@ SIGNATURES = {
     "asis_split_stats": [_vp, _i, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _i, _f],
     "asis_gemm_set_option": [C.c_char_p, _i],
     "asis_layernorm": [_vp, _i, _vp, _i64, _vp, _vp, _f, _vp, _i64, _i, _i64, _i],
+    "asis_layernorm_mx": [_vp, _i, _vp, _i64, _vp, _vp, _f, _vp, _vp, _i64, _vp, _i64, _i],
     "asis_attention_fwd_seg": [_vp, _i, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _f, _vp],
     "asis_attention_fwd_split": [_vp, _i, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i, _i, _i, _i, _i, _f, _vp],
     "asis_attention_fwd_prescaled": [_vp, _i, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i, _i, _i, _i, _i, _vp],

@@ -133,3 +133,14 @@ mx_conv = _mx not in ("0", "")
 
 def mx_conv_on() -> bool:
     return mx_conv and (mx_conv_all or operand_dtype == torch.float16)
+
+
+# The same correction pass for the split-precision LINEAR layers of precise_level 2 (every nn.Linear of a ViT block on hi + lo
+# operands): hi x hi on the 16-bit MFMA + ONE block-scaled fp8 pass over the MX planes of activations and weights instead of two
+# more 16-bit passes (1.5 instead of 3 pass-equivalents).  float16 operands only, like the convolutions.  ASIS_MX_DENSE=0: three
+# 16-bit parts.
+mx_dense = os.environ.get("ASIS_MX_DENSE", "1") not in ("0", "")
+
+
+def mx_dense_on() -> bool:
+    return mx_dense and operand_dtype == torch.float16

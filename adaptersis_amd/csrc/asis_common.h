@@ -124,6 +124,15 @@ template <typename T> __device__ __forceinline__ uint32_t mx_pack2(float x0, flo
   w = wside ? __builtin_amdgcn_cvt_pk_fp8_f32(b1, a1, w, true) : __builtin_amdgcn_cvt_pk_fp8_f32(a1, b1, w, true);
   return (uint32_t)w;
 }
+// the same from a stored (hi, lo) pair of 16-bit values (no second rounding of hi + lo: the 16-bit part of the GEMM uses hi as stored)
+__device__ __forceinline__ uint32_t mx_pack2_pair(float h0, float l0, float h1, float l1, MxScale s, bool wside) {
+  const float a0 = __builtin_amdgcn_fmed3f(h0 * s.sh, -448.f, 448.f), b0 = __builtin_amdgcn_fmed3f(l0 * s.sl, -448.f, 448.f);
+  const float a1 = __builtin_amdgcn_fmed3f(h1 * s.sh, -448.f, 448.f), b1 = __builtin_amdgcn_fmed3f(l1 * s.sl, -448.f, 448.f);
+  int w = 0;
+  w = wside ? __builtin_amdgcn_cvt_pk_fp8_f32(b0, a0, w, false) : __builtin_amdgcn_cvt_pk_fp8_f32(a0, b0, w, false);
+  w = wside ? __builtin_amdgcn_cvt_pk_fp8_f32(b1, a1, w, true) : __builtin_amdgcn_cvt_pk_fp8_f32(a1, b1, w, true);
+  return (uint32_t)w;
+}
 // the "lo" word of two elements: the 16-bit rounding residuals, or the MX form when ``amax`` is given
 template <typename T> __device__ __forceinline__ uint32_t lo_word2(float x0, float x1, const float* amax, bool wside = false) {
   if (amax) return mx_pack2<T>(x0, x1, mx_scales<T>(*amax), wside);

@@ -454,6 +454,49 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
   }
   block_amax_commit(m, amax);
 }
+// |x| maximum of a 16-bit tensor [rows, cols] (row stride ld, cols % 8 == 0): the hi plane of a split-precision operand pair
+template <typename T>
+__global__ __launch_bounds__(256) void absmax16_kernel(const T* __restrict__ x, int64_t rows, int cols, int64_t ld, float* __restrict__ amax) {
+  const int c8 = cols >> 3;
+  float m = 0.f;
+  auto one = [&](const uint4 v) {
+    float a, b;
+    unpack2<T>(v.x, a, b); m = fmaxf(m, fmaxf(fabsf(a), fabsf(b)));
+    unpack2<T>(v.y, a, b); m = fmaxf(m, fmaxf(fabsf(a), fabsf(b)));
+    unpack2<T>(v.z, a, b); m = fmaxf(m, fmaxf(fabsf(a), fabsf(b)));
+    unpack2<T>(v.w, a, b); m = fmaxf(m, fmaxf(fabsf(a), fabsf(b)));
+  };
+  for (int64_t r = blockIdx.y; r < rows; r += gridDim.y) {
+    const uint4* xr = reinterpret_cast<const uint4*>(x + r * ld);
+    const int step = gridDim.x * blockDim.x;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < c8; i += 4 * step) {
+      const uint4 v0 = xr[i], v1 = xr[min(i + step, c8 - 1)], v2 = xr[min(i + 2 * step, c8 - 1)], v3 = xr[min(i + 3 * step, c8 - 1)];
+      one(v0); one(v1); one(v2); one(v3);
+    }
+  }
+  block_amax_commit(m, amax);
+}
+// (hi, lo) 16-bit planes of a split-precision operand -> its MX plane (asis_common.h: two e4m3 bytes per element; activations
+// (hi8, lo8), ``wside`` (lo8, hi8)); amax = the tensor's absolute maximum (device float)
+template <typename T>
+__global__ __launch_bounds__(256) void mx_from_pair_kernel(const T* __restrict__ hi, const T* __restrict__ lo, int64_t ld_in, T* __restrict__ out,
+                                                           int64_t ld_out, int64_t rows, int cols, const float* __restrict__ amax, int wside) {
+  const int c8 = cols >> 3;
+  const MxScale sc = mx_scales<T>(*amax);
+  const int64_t total = rows * c8;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / c8;
+    const int c = (int)(i - r * c8);
+    const uint4 h = reinterpret_cast<const uint4*>(hi + r * ld_in)[c], l = reinterpret_cast<const uint4*>(lo + r * ld_in)[c];
+    uint4 o;
+    float h0, h1, l0, l1;
+    unpack2<T>(h.x, h0, h1); unpack2<T>(l.x, l0, l1); o.x = mx_pack2_pair(h0, l0, h1, l1, sc, wside != 0);
+    unpack2<T>(h.y, h0, h1); unpack2<T>(l.y, l0, l1); o.y = mx_pack2_pair(h0, l0, h1, l1, sc, wside != 0);
+    unpack2<T>(h.z, h0, h1); unpack2<T>(l.z, l0, l1); o.z = mx_pack2_pair(h0, l0, h1, l1, sc, wside != 0);
+    unpack2<T>(h.w, h0, h1); unpack2<T>(l.w, l0, l1); o.w = mx_pack2_pair(h0, l0, h1, l1, sc, wside != 0);
+    reinterpret_cast<uint4*>(out + r * ld_out)[c] = o;
+  }
+}
 // the same of relu(x * scale[c] + shift[c]) (the tensor a BatchNorm + ReLU (+ bilinear upsampling: a convex combination) kernel
 // is about to write), x fp32 [P, C].  The grid's stride is a multiple of C / 4 whenever C / 4 divides 256, so a thread stays on
 // one channel group and keeps its scale / shift in registers.
@@ -703,6 +746,44 @@ extern "C" int asis_bn_relu_absmax(void* stream, const float* x, const float* sc
   if (P == 0) return ASIS_OK;
   hipLaunchKernelGGL(bn_relu_absmax_kernel, dim3(grid_for(asis_cdiv(P * (C / 4), 4), 256, 1024)), dim3(256), 0, s, x, scale, shift, P, C, relu, amax);
   ASIS_CHECK_LAUNCH("asis_bn_relu_absmax");
+  return ASIS_OK;
+}
+
+extern "C" int asis_absmax_16(void* stream, int dtype, const void* x, int64_t rows, int cols, int64_t ld, float* amax) {
+  ASIS_REQUIRE(x && amax && rows >= 0 && cols > 0 && cols % 8 == 0 && ld % 8 == 0 && ld >= cols && asis_aligned16(x),
+               "asis_absmax_16: null pointer, or cols / ld not multiples of 8, or misaligned");
+  DT_OK(dtype, "asis_absmax_16");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  ASIS_REQUIRE(hipMemsetAsync(amax, 0, sizeof(float), s) == hipSuccess, "asis_absmax_16: memset failed");
+  if (rows == 0) return ASIS_OK;
+  int gx = (int)asis_cdiv(cols / 8, 256 * 4);
+  if (gx > 1024) gx = 1024;
+  int64_t gy = asis_cdiv(1024, gx);
+  if (gy > rows) gy = rows;
+  if (dtype == ASIS_F16)
+    hipLaunchKernelGGL((absmax16_kernel<f16>), dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, s, reinterpret_cast<const f16*>(x), rows, cols, ld, amax);
+  else
+    hipLaunchKernelGGL((absmax16_kernel<bf16>), dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, s, reinterpret_cast<const bf16*>(x), rows, cols, ld, amax);
+  ASIS_CHECK_LAUNCH("asis_absmax_16");
+  return ASIS_OK;
+}
+
+extern "C" int asis_mx_from_pair(void* stream, int dtype, const void* hi, const void* lo, int64_t ld_in, void* out_mx, int64_t ld_out,
+                                 int64_t rows, int cols, const float* amax, int wside) {
+  ASIS_REQUIRE(hi && lo && out_mx && amax && rows >= 0 && cols > 0 && cols % 8 == 0 && ld_in % 8 == 0 && ld_out % 8 == 0 && ld_in >= cols &&
+                   ld_out >= cols && asis_aligned16(hi) && asis_aligned16(lo) && asis_aligned16(out_mx),
+               "asis_mx_from_pair: null pointer, or cols / leading dimensions not multiples of 8, or misaligned");
+  DT_OK(dtype, "asis_mx_from_pair");
+  if (rows == 0) return ASIS_OK;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int64_t total = rows * (cols / 8);
+  if (dtype == ASIS_F16)
+    hipLaunchKernelGGL((mx_from_pair_kernel<f16>), dim3(grid_for(total)), dim3(256), 0, s, reinterpret_cast<const f16*>(hi),
+                       reinterpret_cast<const f16*>(lo), ld_in, reinterpret_cast<f16*>(out_mx), ld_out, rows, cols, amax, wside);
+  else
+    hipLaunchKernelGGL((mx_from_pair_kernel<bf16>), dim3(grid_for(total)), dim3(256), 0, s, reinterpret_cast<const bf16*>(hi),
+                       reinterpret_cast<const bf16*>(lo), ld_in, reinterpret_cast<bf16*>(out_mx), ld_out, rows, cols, amax, wside);
+  ASIS_CHECK_LAUNCH("asis_mx_from_pair");
   return ASIS_OK;
 }
 

@@ -243,6 +243,7 @@ int launch(hipStream_t s, const asis_gemm_desc& d) {
     const int kparts = 1 + (d.A_lo ? 1 : 0) + (d.B_lo ? 1 : 0);
     auto al = [](const void* p, int a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; };
     if (p8 && big_mode && ph8_m16_on() && !d.conv && !d.stats && d.batch == 1 && !d.bias_m && !d.ln_cols && !d.C_lo && !d.rowstats && !d.res16 &&
+        !d.mx_amax_a && !d.mx_amax_b &&
         d.ksplit <= 1 && d.K % 64 == 0 &&
         d.M >= 256 && d.N >= 256 && p8_tiles >= (p8 == 2 ? 16 : 256) && d.K >= 128 && (p8 >= 2 || d.K * kparts <= 2048) &&
         (int64_t)d.M * d.lda * 2 < (1ll << 32) && (int64_t)d.N * d.ldb * 2 < (1ll << 32) && d.N % 8 == 0 && d.ldc % 8 == 0 &&
@@ -281,7 +282,13 @@ int launch(hipStream_t s, const asis_gemm_desc& d) {
     if (d.mx_amax_a || d.mx_amax_b) {
       // MX form of the lo operands (include/asis_hip.h): two K parts, the second on the block-scaled fp8 MFMA; 16x16 MFMA
       // instances of the three convolution tile forms
-      if (!(d.conv && d.mx_amax_a && d.mx_amax_b && d.A_lo && d.B_lo)) return ASIS_EINVAL;
+      if (!(d.mx_amax_a && d.mx_amax_b && d.A_lo && d.B_lo)) return ASIS_EINVAL;
+      if (!d.conv) {   // dense: the 8-phase one-tile-per-workgroup form, K tiles alternating 16-bit / MX
+        if (!(d.K % 64 == 0 && d.N >= 256 && d.batch == 1 && d.ksplit <= 1 && !d.stats && (int64_t)d.N * d.ldb < (1ll << 31))) return ASIS_EINVAL;
+        dim3 g8(((d.M + 255) / 256) * ((d.N + 255) / 256), 1);
+        hipLaunchKernelGGL((gemm_big_kernel<T, 2, 4, 4, 2, 2, 0, false, true, 64, 1, true, true, 0, true>), g8, block, 0, s, d, group_m);
+        return 0;
+      }
       if ((int64_t)d.B_ * d.H * d.W * d.Cin >= (1ll << 31) || (int64_t)d.N * d.ldb >= (1ll << 31) || d.H >= 65536 || d.W >= 65536) return ASIS_EINVAL;
       static const int mx_ph8 = [] { const char* e = getenv("ASIS_MX_PH8"); return e ? atoi(e) : 1; }();   // lab: 0 = generic forms only
       if (mx_ph8 && d.N >= 256 && (d.N % 256 == 0 || d.N >= 1024) && d.batch == 1) {

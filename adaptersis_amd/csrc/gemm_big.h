@@ -31,7 +31,9 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_big_kernel(const asis_
   // v_mfma_scale_f32_16x16x128_f8f6f4, whose byte-with-byte products are both correction terms at once.  Same LDS image, same
   // staging and fragment reads as a 16-bit part (a row of a K tile is 128 bytes = 64 elements either way); the two ks
   // fragments of a lane are the two halves of its 32-byte fp8 operand (K pairing: scripts/mx_probe.hip).
-  static_assert(!MXC || (CONV && SPLIT && M16 && BKT == 64), "the MX correction pass is built for split convolutions on 16x16 MFMAs");
+  // Dense MXC (round 4: the split-precision linear layers of config.precise_level 2): the same two parts, K tiles alternating
+  // 16-bit / MX over the same k offset, A rows by plain per-lane pointers.
+  static_assert(!MXC || (SPLIT && M16 && BKT == 64 && (CONV || PH8)), "the MX correction pass is built for split operands on 16x16 MFMAs");
   typedef int v4i_ __attribute__((ext_vector_type(4)));
   typedef int v8i_ __attribute__((ext_vector_type(8)));
   auto cat8 = [](auto lo8, auto hi8) -> v8i_ {
@@ -143,7 +145,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_big_kernel(const asis_
   // for every token and therefore adds up coherently through the blocks, tests/precision_probe.py): two parts.
   const int64_t a_lo_off = (SPLIT && d.A_lo) ? (reinterpret_cast<const T*>(d.A_lo) - reinterpret_cast<const T*>(d.A)) : 0;
   const int64_t b_lo_off = (SPLIT && d.B_lo) ? (reinterpret_cast<const T*>(d.B_lo) - reinterpret_cast<const T*>(d.B)) : 0;
-  const int nparts = !SPLIT ? 1 : (CONV ? (MXC ? 2 : 3) : ((d.A_lo && d.B_lo) ? 3 : 2));   // convolutions always carry both halves
+  const int nparts = !SPLIT ? 1 : (MXC ? 2 : (CONV ? 3 : ((d.A_lo && d.B_lo) ? 3 : 2)));   // convolutions always carry both halves
   // part p > 0 of a two-part reduction adds the one lo operand that exists; of a three-part one: 1 = A_lo, 2 = B_lo
   auto part_offs = [&](int part, int64_t& aoff, int64_t& boff) {
     aoff = (part == 1 && d.A_lo) ? a_lo_off : 0;
@@ -183,7 +185,11 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_big_kernel(const asis_
       const int c = tt / ntap_part, tl = tt - c * ntap_part;
       k0 = (tap_base + tl) * d.Cin + c * BKB;
     } else {
-      if (SPLIT) {
+      if (SPLIT && MXC) {
+        kt = t >> 1;
+        aoff = (t & 1) ? a_lo_off : 0;
+        boff = (t & 1) ? b_lo_off : 0;
+      } else if (SPLIT) {
         const int part = t / nt1;
         kt = t - part * nt1;
         part_offs(part, aoff, boff);
@@ -281,6 +287,14 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_big_kernel(const asis_
           s_kw = 0; ++s_kh;
         }
         sk0 = (tap_base + s_tl) * d.Cin + s_c * BKB;
+      } else if constexpr (MXC) {   // dense MX: the 16-bit tile and the correction tile of one k offset back to back
+        ++s_part;
+        s_aoff = s_part == 1 ? a_lo_off : 0;
+        s_boff = s_part == 1 ? b_lo_off : 0;
+        if (s_part < 2) return;
+        s_part = 0;
+        ++s_kt;
+        sk0 = (s_kt + kt_base) * BKB;
       } else {
         if (++s_kt == nt1) {        // SPLIT only: next part, K restarts
           s_kt = 0; ++s_part;

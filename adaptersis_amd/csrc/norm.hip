@@ -358,6 +358,79 @@ extern "C" int asis_layernorm(void* stream, int dtype, const float* x, int64_t l
   return ASIS_OK;
 }
 
+// LayerNorm -> the 16-bit hi plane AND the MX plane of the output (asis_common.h: (hi8, lo8) per element) in one pass: the A operand
+// pair of a split-precision linear layer (config.precise_level 2 on the MX correction pass).  amax = an upper bound of |y|.
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_mx_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ w,
+                                                           const float* __restrict__ b, float eps, T* __restrict__ y, T* __restrict__ y_mx,
+                                                           int64_t ldy, const float* __restrict__ amax, int64_t rows, int D) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const MxScale sc = mx_scales<T>(*amax);
+  const int nchunk = D >> 2;
+  const float4* xr = reinterpret_cast<const float4*>(x + row * ldx);
+  float4 v[LN_MAXC];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nchunk) {
+      v[i] = xr[c];
+      s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nchunk) {
+      const float a0 = v[i].x - mean, a1 = v[i].y - mean, a2 = v[i].z - mean, a3 = v[i].w - mean;
+      q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+  const float4* w4 = reinterpret_cast<const float4*>(w);
+  const float4* b4 = reinterpret_cast<const float4*>(b);
+#pragma unroll
+  for (int i = 0; i < LN_MAXC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nchunk) {
+      const float4 ww = w4[c], bb = b4[c];
+      const float o0 = (v[i].x - mean) * rstd * ww.x + bb.x;
+      const float o1 = (v[i].y - mean) * rstd * ww.y + bb.y;
+      const float o2 = (v[i].z - mean) * rstd * ww.z + bb.z;
+      const float o3 = (v[i].w - mean) * rstd * ww.w + bb.w;
+      uint2 p, m;
+      p.x = pack2<T>(o0, o1);
+      p.y = pack2<T>(o2, o3);
+      m.x = mx_pack2<T>(o0, o1, sc, false);
+      m.y = mx_pack2<T>(o2, o3, sc, false);
+      reinterpret_cast<uint2*>(y + row * ldy)[c] = p;
+      reinterpret_cast<uint2*>(y_mx + row * ldy)[c] = m;
+    }
+  }
+}
+
+extern "C" int asis_layernorm_mx(void* stream, int dtype, const float* x, int64_t ldx, const float* w, const float* b, float eps, void* y,
+                                 void* y_mx, int64_t ldy, const float* amax, int64_t rows, int D) {
+  ASIS_REQUIRE(x && w && b && y && y_mx && amax, "asis_layernorm_mx: null pointer");
+  ASIS_REQUIRE(D > 0 && D % 4 == 0 && D <= 256 * LN_MAXC && ldx % 4 == 0 && ldy % 4 == 0 && ldx >= D && ldy >= D && asis_aligned16(x) &&
+                   asis_aligned16(w) && asis_aligned16(b) && (reinterpret_cast<uintptr_t>(y) & 7) == 0 && (reinterpret_cast<uintptr_t>(y_mx) & 7) == 0,
+               "asis_layernorm_mx: D=%d must be a multiple of 4 and <= %d, leading dimensions multiples of 4, pointers aligned", D, 256 * LN_MAXC);
+  ASIS_REQUIRE(dtype == ASIS_F16 || dtype == ASIS_BF16, "asis_layernorm_mx: bad dtype %d", dtype);
+  if (rows == 0) return ASIS_OK;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  dim3 grid((unsigned)asis_cdiv(rows, 4)), block(256);
+  if (dtype == ASIS_F16)
+    hipLaunchKernelGGL((layernorm_mx_kernel<f16>), grid, block, 0, s, x, ldx, w, b, eps, reinterpret_cast<f16*>(y), reinterpret_cast<f16*>(y_mx), ldy, amax, rows, D);
+  else
+    hipLaunchKernelGGL((layernorm_mx_kernel<bf16>), grid, block, 0, s, x, ldx, w, b, eps, reinterpret_cast<bf16*>(y), reinterpret_cast<bf16*>(y_mx), ldy, amax, rows, D);
+  ASIS_CHECK_LAUNCH("asis_layernorm_mx");
+  return ASIS_OK;
+}
+
 extern "C" int asis_add_cls_pos(void* stream, const float* x, const float* cls, const float* pos, float* out, int B,
                                 int N, int D) {
   ASIS_REQUIRE(x && cls && pos && out, "asis_add_cls_pos: null pointer");

@@ -464,20 +464,52 @@ class Block(_Packed):
         return _pack(owner._cache, key + ".lo_any", w,
                      lambda p: ops.cast_pad(p.reshape(p.shape[0], -1).contiguous().float(), dtype=config.operand_dtype, part=1))
 
+    def _w16mx_any(self, owner, key: str, w: torch.Tensor):
+        """(MX plane of the weight's (hi, lo) pair — weight side: (lo8, hi8) per element —, its absolute maximum [1])"""
+        return _pack(owner._cache, key + ".mx_any", w,
+                     lambda p: ops.mx_from_pair(owner._w16(key, w), self._w16lo_any(owner, key, w), wside=True))
+
+    def _mx_ok(self, owner, key: str, lin: nn.Linear, M: int) -> bool:
+        N, K = lin.weight.shape
+        return config.mx_dense_on() and K % 64 == 0 and N >= 256 and M >= 256 and N * K < (1 << 31)
+
+    def _split_lin(self, owner, key: str, lin: nn.Linear, a_hi, a_lo, a_mx=None, **kw):
+        """one linear layer of precise_level 2: A W^T on hi + lo operands — three 16-bit K parts, or (config.mx_dense_on) the
+        16-bit part + ONE block-scaled fp8 pass over the MX planes of both operands.  ``a_mx`` = (plane, amax) made by the
+        producer (LayerNorm), else the plane is made here from the stored (hi, lo) pair."""
+        w = owner._w16(key, lin.weight)
+        if self._mx_ok(owner, key, lin, a_hi.shape[0]):
+            a_pl, amax_a = a_mx if a_mx is not None else ops.mx_from_pair(a_hi, a_lo)
+            w_mx, amax_w = self._w16mx_any(owner, key, lin.weight)
+            return ops.gemm(a_hi, w, a_lo=a_pl, b_lo=w_mx, mx=(amax_a, amax_w), **kw)
+        return ops.gemm(a_hi, w, a_lo=a_lo, b_lo=self._w16lo_any(owner, key, lin.weight), **kw)
+
+    def _ln_split(self, key: str, norm: nn.LayerNorm, x2: torch.Tensor, mx: bool):
+        """LayerNorm output as a split-precision A operand: (hi, lo, None), or (hi, None, (MX plane, amax bound)) in ONE pass"""
+        dt = config.operand_dtype
+        w, b = self._f32(key + "w", norm.weight), self._f32(key + "b", norm.bias)
+        if mx:
+            # |LN(x)_i| <= sqrt(D - 1) |w_i| + |b_i|: a bound, not the maximum (asis_layernorm_mx: costs nothing at e4m3's range)
+            amax = _pack(self._cache, key + ".amax", norm.weight,
+                         lambda p: ((x2.shape[1] - 1) ** 0.5 * p.float().abs().max() + norm.bias.detach().float().abs().max()).reshape(1).contiguous())
+            hi, pl = ops.layernorm_mx(x2, w, b, norm.eps, dt, amax)
+            return hi, None, (pl, amax)
+        xn32 = ops.layernorm(x2, w, b, norm.eps, torch.float32)
+        D = x2.shape[1]
+        return ops.cast_pad(xn32, D, dt), ops.cast_pad(xn32, D, dt, part=1), None
+
     def _forward_rows_precise(self, x2: torch.Tensor, segs) -> torch.Tensor:
         """``forward_rows`` with every linear layer on split-precision operands (config.precise_level 2): LayerNorm / GELU / SwiGLU /
         attention outputs and all weights as hi + lo halves; the fused attention keeps single 16-bit q, k, v, P."""
         D = x2.shape[1]
+        R = x2.shape[0]
         dt = config.operand_dtype
         a, m = self.attn, self.mlp
         g1 = self._f32("g1", self.ls1.gamma) if isinstance(self.ls1, LayerScale) else None
         g2 = self._f32("g2", self.ls2.gamma) if isinstance(self.ls2, LayerScale) else None
-        xn32 = ops.layernorm(x2, self._f32("n1w", self.norm1.weight), self._f32("n1b", self.norm1.bias), self.norm1.eps, torch.float32)
-        xn, xn_lo = ops.cast_pad(xn32, D, dt), ops.cast_pad(xn32, D, dt, part=1)
-        qkv32 = ops.gemm(xn, a._w16("qkv", a.qkv.weight), out_f32=True, bias_n=a._f32("qkv_b", a.qkv.bias), a_lo=xn_lo,
-                         b_lo=self._w16lo_any(a, "qkv", a.qkv.weight))
-        qkv = ops.cast_pad(qkv32, 3 * D, dt)
-        o = torch.empty((x2.shape[0], D), device=x2.device, dtype=dt)
+        xn, xn_lo, xn_mx = self._ln_split("n1", self.norm1, x2, self._mx_ok(a, "qkv", a.qkv, R))
+        qkv = self._split_lin(a, "qkv", a.qkv, xn, xn_lo, xn_mx, bias_n=a._f32("qkv_b", a.qkv.bias))     # 16-bit out: q, k, v operands
+        o = torch.empty((R, D), device=x2.device, dtype=dt)
         o_lo = torch.empty_like(o)
         r0 = 0
         for B, N in segs:
@@ -485,23 +517,18 @@ class Block(_Packed):
             vt = ops.transpose_tokens(qkv[r0:r1, 2 * D:], B, N)
             ops.attention_fwd(qkv[r0:r1, :D], qkv[r0:r1, D:2 * D], vt, B, a.num_heads, N, a.scale, out=o[r0:r1], out_lo=o_lo[r0:r1])
             r0 = r1
-        if r0 != x2.shape[0]:
+        if r0 != R:
             raise ValueError("forward_rows: segments do not cover the rows")
-        x1 = ops.gemm(o, a._w16("proj", a.proj.weight), out_f32=True, bias_n=a._f32("proj_b", a.proj.bias), scale_n=g1, res=x2,
-                      a_lo=o_lo, b_lo=self._w16lo_any(a, "proj", a.proj.weight))
-        xn2_32 = ops.layernorm(x1, self._f32("n2w", self.norm2.weight), self._f32("n2b", self.norm2.bias), self.norm2.eps, torch.float32)
-        xn2, xn2_lo = ops.cast_pad(xn2_32, D, dt), ops.cast_pad(xn2_32, D, dt, part=1)
+        x1 = self._split_lin(a, "proj", a.proj, o, o_lo, out_f32=True, bias_n=a._f32("proj_b", a.proj.bias), scale_n=g1, res=x2)
         if isinstance(m, Mlp):
-            hpre = ops.gemm(xn2, m._w16("fc1", m.fc1.weight), out_f32=True, bias_n=m._f32("fc1_b", m.fc1.bias), a_lo=xn2_lo,
-                            b_lo=self._w16lo_any(m, "fc1", m.fc1.weight))
+            xn2, xn2_lo, xn2_mx = self._ln_split("n2", self.norm2, x1, self._mx_ok(m, "fc1", m.fc1, R))
+            hpre = self._split_lin(m, "fc1", m.fc1, xn2, xn2_lo, xn2_mx, out_f32=True, bias_n=m._f32("fc1_b", m.fc1.bias))
             h, h_lo = ops.gelu_split(hpre, dt)
-            return ops.gemm(h, m._w16("fc2", m.fc2.weight), out_f32=True, bias_n=m._f32("fc2_b", m.fc2.bias), scale_n=g2, res=x1,
-                            a_lo=h_lo, b_lo=self._w16lo_any(m, "fc2", m.fc2.weight))
-        h12 = ops.gemm(xn2, m._w16("w12", m.w12.weight), out_f32=True, bias_n=m._f32("w12_b", m.w12.bias), a_lo=xn2_lo,
-                       b_lo=self._w16lo_any(m, "w12", m.w12.weight))
+            return self._split_lin(m, "fc2", m.fc2, h, h_lo, out_f32=True, bias_n=m._f32("fc2_b", m.fc2.bias), scale_n=g2, res=x1)
+        xn2, xn2_lo, xn2_mx = self._ln_split("n2", self.norm2, x1, self._mx_ok(m, "w12", m.w12, R))
+        h12 = self._split_lin(m, "w12", m.w12, xn2, xn2_lo, xn2_mx, out_f32=True, bias_n=m._f32("w12_b", m.w12.bias))
         h, h_lo = ops.swiglu(h12, dt, split=True)
-        return ops.gemm(h, m._w16("w3", m.w3.weight), out_f32=True, bias_n=m._f32("w3_b", m.w3.bias), scale_n=g2, res=x1,
-                        a_lo=h_lo, b_lo=self._w16lo_any(m, "w3", m.w3.weight))
+        return self._split_lin(m, "w3", m.w3, h, h_lo, out_f32=True, bias_n=m._f32("w3_b", m.w3.bias), scale_n=g2, res=x1)
 
     def _lin_ln_folded(self, key: str, lin: nn.Linear, norm: nn.LayerNorm):
         """(W diag(norm.weight) as 16 bits, b + W norm.bias, row sums of the rounded W') of a linear layer behind a LayerNorm"""

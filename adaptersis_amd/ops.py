@@ -71,7 +71,7 @@ def _gemm_desc(a: torch.Tensor, b: torch.Tensor, *, out: Optional[torch.Tensor] 
                scale_n: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None, act: int = ACT_NONE,
                stats: Optional[torch.Tensor] = None, a_lo: Optional[torch.Tensor] = None,
                b_lo: Optional[torch.Tensor] = None, aux: Optional[torch.Tensor] = None,
-               out_lo: Optional[torch.Tensor] = None, rowstats: Optional[torch.Tensor] = None, res16=None, ln=None):
+               out_lo: Optional[torch.Tensor] = None, rowstats: Optional[torch.Tensor] = None, res16=None, ln=None, mx=None):
     """-> (filled GemmDesc, out tensor, algorithmic flops, algorithmic bytes) of one ``gemm`` call (see ``gemm``).
     LayerNorm-fold chain (include/asis_hip.h): ``out_lo`` = second 16-bit plane of the output, ``rowstats`` = fp32
     [M, ceil(N / 64), 2] per-row partial sums, ``res16`` = (hi, lo) planes of the residual, ``ln`` = (mr [rows, 2], cs, cols)."""
@@ -124,6 +124,11 @@ def _gemm_desc(a: torch.Tensor, b: torch.Tensor, *, out: Optional[torch.Tensor] 
         if b_lo.stride() != b.stride():
             raise ValueError("gemm: split halves must share the layout of their hi parts")
         d.B_lo = b_lo.data_ptr()
+    if mx is not None:
+        if a_lo is None or b_lo is None:
+            raise ValueError("gemm: mx needs both MX planes (a_lo and b_lo)")
+        _dev(mx[0], mx[1])
+        d.mx_amax_a, d.mx_amax_b = mx[0].data_ptr(), mx[1].data_ptr()
     if out_lo is not None:
         if out_lo.dtype != out.dtype or out_lo.stride() != out.stride() or out.dtype == torch.float32:
             raise ValueError("gemm: out_lo must be a 16-bit tensor with the layout of out")
@@ -333,6 +338,20 @@ def layernorm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float = 1e
                                _f32c(w).data_ptr(), _f32c(b).data_ptr(), float(eps), o2.data_ptr(), o2.stride(0),
                                int(f32), x2.shape[0], D), "asis_layernorm")
     return out
+
+
+def layernorm_mx(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float, out_dtype: torch.dtype, amax: torch.Tensor):
+    """Row LayerNorm of a float32 [rows, D] tensor -> (16-bit output, its MX plane) in one pass; ``amax``: device float, an upper
+    bound of |output| (include/asis_hip.h: asis_layernorm_mx)."""
+    _dev(x, w, b, amax)
+    if x.dtype != torch.float32 or x.dim() != 2 or x.stride(1) != 1:
+        raise ValueError("layernorm_mx: x must be float32 [rows, D] with contiguous columns")
+    R, D = x.shape
+    hi = torch.empty((R, D), device=x.device, dtype=out_dtype)
+    mx = torch.empty_like(hi)
+    check(lib().asis_layernorm_mx(_stream(), _dt(out_dtype), x.data_ptr(), x.stride(0), _f32c(w).data_ptr(), _f32c(b).data_ptr(), float(eps),
+                                  hi.data_ptr(), mx.data_ptr(), D, amax.data_ptr(), R, D), "asis_layernorm_mx")
+    return hi, mx
 
 
 def _check_out_lo(out: torch.Tensor, out_lo: Optional[torch.Tensor]) -> None:
@@ -859,6 +878,30 @@ def pack_conv_weight(w: torch.Tensor, mode: int, dtype: torch.dtype, part: int =
     check(lib().asis_pack_conv_weight(_stream(), _dt(dtype), _f32c(w).data_ptr(), out.data_ptr(), Cout, Cin, KH, KW,
                                       mode, ld, int(part)), "asis_pack_conv_weight")
     return out[:, :K] if ld != K else out
+
+
+def absmax16(x: torch.Tensor) -> torch.Tensor:
+    """|x| maximum of a 16-bit [rows, cols] tensor (contiguous columns, cols % 8 == 0) -> device float [1]"""
+    _dev(x)
+    if x.dtype not in (torch.float16, torch.bfloat16) or x.dim() != 2 or x.stride(1) != 1:
+        raise ValueError("absmax16: 16-bit [rows, cols] tensor with contiguous columns")
+    amax = torch.empty(1, device=x.device, dtype=torch.float32)
+    check(lib().asis_absmax_16(_stream(), _dt(x.dtype), x.data_ptr(), x.shape[0], x.shape[1], x.stride(0), amax.data_ptr()), "asis_absmax_16")
+    return amax
+
+
+def mx_from_pair(hi: torch.Tensor, lo: torch.Tensor, wside: bool = False, amax: Optional[torch.Tensor] = None):
+    """(hi, lo) 16-bit planes of a split-precision operand -> (its MX plane with the layout of ``hi``, amax [1]): the ``a_lo`` /
+    ``b_lo`` (``wside``) + ``mx`` operands of a dense ``gemm`` (include/asis_hip.h: asis_mx_from_pair)."""
+    _dev(hi, lo, amax)
+    if hi.dtype != lo.dtype or hi.dim() != 2 or hi.stride() != lo.stride() or hi.stride(1) != 1 or hi.shape != lo.shape:
+        raise ValueError("mx_from_pair: two 16-bit [rows, cols] planes with equal layout")
+    if amax is None:
+        amax = absmax16(hi)
+    out = torch.empty_strided(hi.shape, hi.stride(), device=hi.device, dtype=hi.dtype) if hi.stride(0) != hi.shape[1] else torch.empty_like(hi)
+    check(lib().asis_mx_from_pair(_stream(), _dt(hi.dtype), hi.data_ptr(), lo.data_ptr(), hi.stride(0), out.data_ptr(), out.stride(0),
+                                  hi.shape[0], hi.shape[1], amax.data_ptr(), int(wside)), "asis_mx_from_pair")
+    return out, amax
 
 
 def pack_conv_weight_mx(w: torch.Tensor, mode: int, dtype: torch.dtype):

@@ -119,7 +119,8 @@ typedef struct asis_gemm_desc {
    *   res16 / res16_lo / ldr16   the residual as two 16-bit planes instead of fp32 `res` (v += (float)hi + (float)lo)
    *   ln_mr     fp32 [M, 2] (mean, rstd) per A row (ln_cols != 0: per B row, i.e. per output COLUMN, for the swapped V^T GEMM)
    *   ln_cs     fp32 [N] cs (ln_cols != 0: [M], per output row); applied BEFORE bias_n / bias_m and the activation */
-  /* ---- MX correction operands of a split convolution (conv != 0, A_lo and B_lo given, Cin % 64 == 0) ----------------------
+  /* ---- MX correction operands of a split convolution (conv != 0, A_lo and B_lo given, Cin % 64 == 0) or of a dense split
+   * GEMM (conv == 0: K % 64 == 0, N >= 256, batch == 1; the linear layers of config.precise_level 2) -------------------------
    * mx_amax_a, mx_amax_b != NULL: device floats = the absolute maxima of the A and the B tensor; A_lo / B_lo then hold the MX form
    * of the rounding residuals (csrc/asis_common.h: two fp8 e4m3 bytes per element — activations (hi8, lo8), weights (lo8, hi8);
    * asis_bn_relu_upsample_mx / asis_decoder_input_mx / asis_pack_conv_weight_mx write them) and the reduction runs over TWO K
@@ -160,6 +161,14 @@ int asis_gemm_tiles_m(int M);
  * about to write.  They feed the per-tensor power-of-two scales of the MX operands above. */
 int asis_absmax_f32(void* stream, const float* x, int64_t rows, int cols, int64_t ld, float* amax, int reset);
 int asis_bn_relu_absmax(void* stream, const float* x, const float* scale, const float* shift, int64_t P, int C, int relu, float* amax);
+/* |x| maximum of a 16-bit [rows, cols] tensor (row stride ld, cols % 8 == 0) into *amax (zeroed first), and the MX plane of a
+ * split-precision operand from its stored (hi, lo) 16-bit planes (same shape / leading dimension ld_in; out_mx leading dimension
+ * ld_out): two e4m3 bytes per element, activations (hi8, lo8), wside != 0 (the weight operand) (lo8, hi8); amax = the
+ * absolute maximum of the hi plane.  The A_lo / B_lo + mx_amax_a / mx_amax_b operands of a dense asis_gemm
+ * (`dinov2/layers/block.py:89-114` linear layers at fp32 in the reference; config.precise_level 2 here). */
+int asis_absmax_16(void* stream, int dtype, const void* x, int64_t rows, int cols, int64_t ld, float* amax);
+int asis_mx_from_pair(void* stream, int dtype, const void* hi, const void* lo, int64_t ld_in, void* out_mx, int64_t ld_out, int64_t rows,
+                      int cols, const float* amax, int wside);
 /* run-time dispatch switches of asis_gemm (same meaning as the environment variable read at first use):
  *   "p8" (ASIS_GEMM_P8): 1 = dense launches with at least one 256x256 tile per CU run on the persistent 8-phase kernel
  *   (csrc/gemm_p8.h) when K <= 2048, 2 = any K and from 16 tiles on, 3 = any K, 0 = never (one workgroup per tile,
@@ -174,6 +183,12 @@ int asis_gemm_set_option(const char* name, int value);
  * ------------------------------------------------------------------------------------------- */
 int asis_layernorm(void* stream, int dtype, const float* x, int64_t ldx, const float* w, const float* b, float eps,
                    void* y, int64_t ldy, int out_f32, int64_t rows, int D);
+/* the same writing the 16-bit output AND its MX plane (asis_gemm_desc.mx_amax_a: two e4m3 bytes per element, (hi8, lo8)) in one
+ * pass — the A operand pair of a split-precision linear layer behind a LayerNorm (`block.py:89-114` norm1 -> qkv, norm2 -> fc1 /
+ * w12 at fp32 in the reference; config.precise_level 2).  amax: device float, an UPPER BOUND of |y| (e.g. sqrt(D) max|w| + max|b|:
+ * the scales are powers of two and e4m3 spans 17 binades, a bound a few binades high costs nothing where it matters). */
+int asis_layernorm_mx(void* stream, int dtype, const float* x, int64_t ldx, const float* w, const float* b, float eps, void* y,
+                      void* y_mx, int64_t ldy, const float* amax, int64_t rows, int D);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused softmax attention forward, head dim 64 (all DINOv2 archs), no mask, no dropout:

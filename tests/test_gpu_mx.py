@@ -83,3 +83,53 @@ def test_mx_conv_vs_fp32(dev, Cin, Cout, H, ks):
     emx = rel_l2(outs[0], ref)
     print(f"conv {Cin}->{Cout} @{H}^2 ksplit {ks}: one 16-bit pass {e1:.2e}, three parts {e3:.2e}, 16-bit + MX pass {emx:.2e}")
     assert e3 < 3e-6 and emx < 0.12 * e1 and emx < 4e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(4321, 1536, 1536), (2100, 512, 4096), (3000, 4608, 1536)])
+def test_mx_dense_gemm_vs_fp32(dev, M, N, K):
+    """the linear layers of config.precise_level 2 (`dinov2/layers/block.py:89-114` at fp32 in the reference): hi x hi on the
+    16-bit MFMA + one block-scaled fp8 pass over the MX planes made from the stored (hi, lo) pairs, with the fp32 residual /
+    LayerScale epilogue of proj / w3 — against fp32 torch on the unrounded operands, next to one 16-bit pass and three parts."""
+    dt = torch.float16
+    a32 = (W.tensor(f"mxd.a{M}.{K}", (M, K), 1.0) * 2).to(dev)
+    w32 = W.tensor(f"mxd.w{N}.{K}", (N, K), 0.04).to(dev)
+    bias, gam = W.tensor(f"mxd.b{N}", (N,), 1.0).to(dev), (0.3 + W.tensor(f"mxd.g{N}", (N,), 0.1).abs()).to(dev)
+    res = W.tensor(f"mxd.r{M}.{N}", (M, N), 2.0).to(dev)
+    ref = res + gam * (a32 @ w32.t() + bias)
+    a_hi, a_lo = ops.cast_pad(a32, K, dt), ops.cast_pad(a32, K, dt, part=1)
+    w_hi, w_lo = ops.cast_pad(w32, K, dt), ops.cast_pad(w32, K, dt, part=1)
+    a_mx, amax_a = ops.mx_from_pair(a_hi, a_lo)
+    w_mx, amax_w = ops.mx_from_pair(w_hi, w_lo, wside=True)
+    assert float(amax_a) == float(a_hi.float().abs().max()) and float(amax_w) == float(w_hi.float().abs().max())
+    dh, dl = _decode(a_mx, float(amax_a), dt, False)
+    assert rel_l2(dh, a_hi.float()) < 0.04 and rel_l2(dl, a_lo.float()) < 0.04
+    dwh, dwl = _decode(w_mx, float(amax_w), dt, True)
+    assert rel_l2(dwh, w_hi.float()) < 0.04 and rel_l2(dwl, w_lo.float()) < 0.04
+    kw = dict(out_f32=True, bias_n=bias, scale_n=gam, res=res)
+    e1 = rel_l2(ops.gemm(a_hi, w_hi, **kw) - res, ref - res)
+    e3 = rel_l2(ops.gemm(a_hi, w_hi, a_lo=a_lo, b_lo=w_lo, **kw) - res, ref - res)
+    outs = [ops.gemm(a_hi, w_hi, a_lo=a_mx, b_lo=w_mx, mx=(amax_a, amax_w), **kw) for _ in range(2)]
+    assert torch.equal(outs[0], outs[1])
+    emx = rel_l2(outs[0] - res, ref - res)
+    print(f"dense {M}x{N}x{K}: one 16-bit pass {e1:.2e}, three parts {e3:.2e}, 16-bit + MX pass {emx:.2e}")
+    assert e3 < 3e-6 and emx < 0.12 * e1 and emx < 5e-5
+    # 16-bit output (no residual): the plain epilogue
+    o16 = ops.gemm(a_hi, w_hi, a_lo=a_mx, b_lo=w_mx, mx=(amax_a, amax_w), bias_n=bias)
+    assert rel_l2(o16, a32 @ w32.t() + bias) < 6e-4
+
+
+def test_layernorm_mx_planes(dev):
+    """asis_layernorm_mx: the 16-bit output equals asis_layernorm's, the MX plane decodes to (hi, lo) of the fp32 LayerNorm at
+    e4m3 precision under an amax BOUND several binades above the true maximum."""
+    import torch.nn.functional as F
+    dt = torch.float16
+    R, D = 3001, 1536
+    x = (W.tensor("lnmx.x", (R, D), 1.0) * 3 + W.tensor("lnmx.m", (R, 1), 1.0)).to(dev)
+    w, b = (1 + 0.3 * W.tensor("lnmx.w", (D,), 1.0)).to(dev), (0.2 * W.tensor("lnmx.b", (D,), 1.0)).to(dev)
+    bound = ((D - 1) ** 0.5 * w.abs().max() + b.abs().max()).reshape(1).contiguous()
+    hi, mx = ops.layernorm_mx(x, w, b, 1e-6, dt, bound)
+    assert torch.equal(hi, ops.layernorm(x, w, b, 1e-6, dt))
+    y = F.layer_norm(x, (D,), w, b, 1e-6)
+    assert float(bound) > 4 * float(y.abs().max())                       # the bound really is loose here
+    dh, dl = _decode(mx, float(bound), dt, False)
+    assert rel_l2(dh, hi.float()) < 0.04 and rel_l2(dl, (y - hi.float())) < 0.06
