@@ -250,7 +250,10 @@ int launch(hipStream_t s, const asis_gemm_desc& d) {
         al(d.C, 16) && (!d.res || (al(d.res, 16) && d.ldr % 4 == 0)) && (!d.bias_n || al(d.bias_n, 16)) && (!d.scale_n || al(d.scale_n, 16)) &&
         (d.act != ASIS_ACT_GELU_GRAD || (d.aux && al(d.aux, 8) && d.ld_aux % 4 == 0))) {
       const int nwg = p8_tiles >= 256 ? 256 : (int)(p8_tiles / 8) * 8;
+      static const int dim_lab = [] { const char* e = getenv("ASIS_P8_DMA_MFMA"); return e ? atoi(e) : 0; }();   // lab: gemm_p8.h LAB & 2
       if (g_gemm_noepi) hipLaunchKernelGGL((gemm_p8_kernel<T, 1>), dim3(nwg), dim3(512), 0, s, d, group_m);
+      else if (dim_lab && d.ln_mr) hipLaunchKernelGGL((gemm_p8_kernel<T, 2, 1>), dim3(nwg), dim3(512), 0, s, d, group_m);
+      else if (dim_lab) hipLaunchKernelGGL((gemm_p8_kernel<T, 2>), dim3(nwg), dim3(512), 0, s, d, group_m);
       else if (d.ln_mr) hipLaunchKernelGGL((gemm_p8_kernel<T, 0, 1>), dim3(nwg), dim3(512), 0, s, d, group_m);   // LayerNorm-fold consumer
       else hipLaunchKernelGGL((gemm_p8_kernel<T, 0>), dim3(nwg), dim3(512), 0, s, d, group_m);
       return 0;
