@@ -44,7 +44,7 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(const asis_gemm_desc d,
   constexpr int STAGE = (BM + BN) * BK;  // elements per LDS stage (64 KB)
   // LNF == 1: + 2 KB behind the stages for the (mean, rstd) pairs of the tile's 256 rows (LDS-DMA at the tile's start: a
   // global load issued in the epilogue itself costs a full loaded-memory round trip, ~1.5 us per tile, in the exposed epilogue)
-  __shared__ __attribute__((aligned(16))) T lds[2 * STAGE + 1024 + ((LAB & 2) ? 512 : 0)];   // + (mean, rstd) block (LNF == 1) + LAB & 2: a 1-KB sink
+  __shared__ __attribute__((aligned(16))) T lds[2 * STAGE + 1024 + ((LAB & 2) ? 512 : 0) + ((LAB & 8) ? 2048 : 0)];   // + (mean, rstd) block (LNF == 1) + LAB & 2: a 1-KB sink + LAB & 8: stamps
   typedef __attribute__((address_space(3))) void* lds_ptr;
   typedef const __attribute__((address_space(1))) void* glb_ptr;
 
@@ -210,6 +210,22 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(const asis_gemm_desc d,
     __builtin_amdgcn_s_setprio(0);
   };
   auto nop = [] {};
+  // LAB & 8 (lab, scripts/p8_stamps.hip): s_memtime stamps of workgroup 0's first tile, K tiles 4..11 — per phase: burst start (behind
+  // the lgkmcnt(0) the burst needs anyway), burst end, end of the closing barrier; [wave][96] uint32 in LDS, dumped to d.stats
+  constexpr bool STAMP = (LAB & 8) != 0;
+  uint32_t* const stamp_lds = reinterpret_cast<uint32_t*>(lds + 2 * STAGE + 1024 + ((LAB & 2) ? 512 : 0));
+  int sidx = 0;
+  bool stamp_on = false;
+  auto stamp = [&]() {
+    if constexpr (STAMP) {
+      if (stamp_on) {
+        uint64_t c;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(c)::"memory");
+        if (lane == 0) stamp_lds[wid * 128 + sidx] = (uint32_t)c;
+        ++sidx;
+      }
+    }
+  };
 
   const float* const zp = reinterpret_cast<const float*>(g_zero_page);
   for (;;) {
@@ -267,8 +283,12 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(const asis_gemm_desc d,
         asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
       }
       __builtin_amdgcn_s_barrier();
+      if constexpr (STAMP) { stamp_on = blockIdx.x == 0 && g >= 4 && g < 12; asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+      stamp();
       mma(0, 0, b0f, nop, nop);
+      stamp();
       __builtin_amdgcn_s_barrier();
+      stamp();
       // phase 1
       rd_b(Bs, 1, b1f);
       if (more) {
@@ -279,8 +299,12 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(const asis_gemm_desc d,
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       __builtin_amdgcn_s_barrier();
+      if constexpr (STAMP) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      stamp();
       mma(0, 1, b1f, nop, nop);
+      stamp();
       __builtin_amdgcn_s_barrier();
+      stamp();
       // phase 2
       rd_a(As, 1);
       if (more) {
@@ -288,8 +312,12 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(const asis_gemm_desc d,
         dma_b(ns, 2); dma_b(ns, 3);
       }
       __builtin_amdgcn_s_barrier();
+      if constexpr (STAMP) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      stamp();
       mma(1, 1, b1f, nop, nop);
+      stamp();
       __builtin_amdgcn_s_barrier();
+      stamp();
       // phase 3
       if (more) {
         if (sw) { int ln = lane; asm volatile("" : "+v"(ln)); asrc[2] = a_ptr(2, m0n, ln); asrc[3] = a_ptr(3, m0n, ln); }
@@ -298,8 +326,18 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(const asis_gemm_desc d,
       }
       advance();
       __builtin_amdgcn_s_barrier();
+      if constexpr (STAMP) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      stamp();
       mma(1, 0, b0f, nop, nop);
+      stamp();
       __builtin_amdgcn_s_barrier();
+      stamp();
+    }
+    if constexpr (STAMP) {
+      if (blockIdx.x == 0 && g == nt && d.stats) {   // end of the first tile: dump
+        __syncthreads();
+        for (int i = tid; i < 8 * 128; i += 512) reinterpret_cast<uint32_t*>(d.stats)[i] = stamp_lds[i];
+      }
     }
     if (wm == 0) __builtin_amdgcn_s_barrier();  // level the two wave rows: all 8 waves run the epilogue together
 
