@@ -210,20 +210,22 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(const asis_gemm_desc d,
     __builtin_amdgcn_s_setprio(0);
   };
   auto nop = [] {};
-  // LAB & 8 (lab, scripts/p8_stamps.hip): s_memtime stamps of workgroup 0's first tile, K tiles 4..11 — per phase: burst start (behind
-  // the lgkmcnt(0) the burst needs anyway), burst end, end of the closing barrier; [wave][96] uint32 in LDS, dumped to d.stats
+  // LAB & 8 (lab, scripts/p8_stamps.hip): s_memtime stamps of workgroup 0, the last 8 K tiles of its last tile — per phase: start of the load part (behind
+  // the previous closing barrier), its end (in front of the burst's opening barrier), end of that barrier (burst start).  The stamps are issued
+  // without a wait (scalar memory returns them under the burst) and written to LDS behind the burst: three SMEM issues and three
+  // ds_writes per phase, no extra s_waitcnt.  [wave][64] uint32 in LDS, dumped to d.stats.
   constexpr bool STAMP = (LAB & 8) != 0;
   uint32_t* const stamp_lds = reinterpret_cast<uint32_t*>(lds + 2 * STAGE + 1024 + ((LAB & 2) ? 512 : 0));
   int sidx = 0;
-  bool stamp_on = false;
-  auto stamp = [&]() {
-    if constexpr (STAMP) {
-      if (stamp_on) {
-        uint64_t c;
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(c)::"memory");
-        if (lane == 0) stamp_lds[wid * 128 + sidx] = (uint32_t)c;
-        ++sidx;
-      }
+  uint64_t st_a = 0, st_b = 0, st_c = 0;
+  auto stamp_a = [&]() { if constexpr (STAMP) asm volatile("s_memtime %0" : "=s"(st_a)::"memory"); };
+  auto stamp_b = [&]() { if constexpr (STAMP) asm volatile("s_memtime %0" : "=s"(st_b)::"memory"); };
+  auto stamp_c = [&]() { if constexpr (STAMP) asm volatile("s_memtime %0" : "=s"(st_c)::"memory"); };
+  auto stamp_store = [&]() {   // behind a burst: its opening s_waitcnt lgkmcnt(0) has covered the stamps.  Branch-free (a wave-uniform
+    if constexpr (STAMP) {     // branch in the loop spills the kernel): every lane writes the same words, a ring of 8 K tiles per wave
+      uint32_t* q = stamp_lds + wid * 128 + sidx;
+      q[0] = (uint32_t)st_a; q[1] = (uint32_t)st_b; q[2] = (uint32_t)st_c;
+      sidx = sidx + 3 == 96 ? 0 : sidx + 3;
     }
   };
 
@@ -282,13 +284,13 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(const asis_gemm_desc d,
       } else {
         asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
       }
+      stamp_b();
       __builtin_amdgcn_s_barrier();
-      if constexpr (STAMP) { stamp_on = blockIdx.x == 0 && g >= 4 && g < 12; asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-      stamp();
+      stamp_c();
       mma(0, 0, b0f, nop, nop);
-      stamp();
+      stamp_store();
       __builtin_amdgcn_s_barrier();
-      stamp();
+      stamp_a();
       // phase 1
       rd_b(Bs, 1, b1f);
       if (more) {
@@ -298,26 +300,26 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(const asis_gemm_desc d,
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
+      stamp_b();
       __builtin_amdgcn_s_barrier();
-      if constexpr (STAMP) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      stamp();
+      stamp_c();
       mma(0, 1, b1f, nop, nop);
-      stamp();
+      stamp_store();
       __builtin_amdgcn_s_barrier();
-      stamp();
+      stamp_a();
       // phase 2
       rd_a(As, 1);
       if (more) {
         if (sw) { int ln = lane; asm volatile("" : "+v"(ln)); bsrc[2] = b_ptr(2, n0n, ln); bsrc[3] = b_ptr(3, n0n, ln); }
         dma_b(ns, 2); dma_b(ns, 3);
       }
+      stamp_b();
       __builtin_amdgcn_s_barrier();
-      if constexpr (STAMP) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      stamp();
+      stamp_c();
       mma(1, 1, b1f, nop, nop);
-      stamp();
+      stamp_store();
       __builtin_amdgcn_s_barrier();
-      stamp();
+      stamp_a();
       // phase 3
       if (more) {
         if (sw) { int ln = lane; asm volatile("" : "+v"(ln)); asrc[2] = a_ptr(2, m0n, ln); asrc[3] = a_ptr(3, m0n, ln); }
@@ -325,19 +327,13 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(const asis_gemm_desc d,
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       }
       advance();
+      stamp_b();
       __builtin_amdgcn_s_barrier();
-      if constexpr (STAMP) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      stamp();
+      stamp_c();
       mma(1, 0, b0f, nop, nop);
-      stamp();
+      stamp_store();
       __builtin_amdgcn_s_barrier();
-      stamp();
-    }
-    if constexpr (STAMP) {
-      if (blockIdx.x == 0 && g == nt && d.stats) {   // end of the first tile: dump
-        __syncthreads();
-        for (int i = tid; i < 8 * 128; i += 512) reinterpret_cast<uint32_t*>(d.stats)[i] = stamp_lds[i];
-      }
+      stamp_a();
     }
     if (wm == 0) __builtin_amdgcn_s_barrier();  // level the two wave rows: all 8 waves run the epilogue together
 
@@ -535,7 +531,15 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(const asis_gemm_desc d,
         }
       }
     }
-    if (!has_next) break;
+    if (!has_next) {
+      if constexpr (STAMP) {   // the ring now holds the last 8 K tiles of this workgroup's last tile
+        if (blockIdx.x == 0 && d.stats) {
+          __syncthreads();
+          for (int i = tid; i < 8 * 128; i += 512) reinterpret_cast<uint32_t*>(d.stats)[i] = stamp_lds[i];
+        }
+      }
+      break;
+    }
     // next tile: its K tile 0 is in stage g & 1; the slabs are dead once every wave is past this barrier, so the first
     // phase may stage K tile 1 over them
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
