@@ -16,6 +16,9 @@ if [ "$1" = "A" ]; then
   echo "[A5b] PMC matrix-pipe busy cycles + GRBM_GUI_ACTIVE (effective clock)" &&
   rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_mfma -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --single-stream > $O/pmc_mfma.log 2>&1 &&
   python scripts/mfma_util.py $O/pmc_mfma $O/mfma_util.txt > /dev/null &&
+  echo "[A5c] PMC SQ wave-cycle breakdown (issuing / issue-stalled / parked)" &&
+  rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU --output-format csv -d $O/pmc_sq -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --single-stream > $O/pmc_sq.log 2>&1 &&
+  python scripts/sq_counters.py $O/pmc_sq $O/sq_counters.txt > /dev/null &&
   echo "[A6] per-shape GEMM table" &&
   ASIS_BENCH_SHAPES=1 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/shapes.json 2> $O/shapes.txt && grep -c "TF/s" $O/shapes.txt &&
   echo "[A done]"
