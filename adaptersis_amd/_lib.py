@@ -82,6 +82,8 @@ SIGNATURES = {
     "asis_absmax_f32": [_vp, _vp, _i64, _i, _i64, _vp, _i],
     "asis_bn_relu_absmax": [_vp, _vp, _vp, _vp, _i64, _i, _i, _vp],
     "asis_absmax_16": [_vp, _i, _vp, _i64, _i, _i64, _vp],
+    "asis_conv3x3_halo_mx_tiles": [_i, _i, _i],
+    "asis_conv3x3_halo_mx": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i],
     "asis_mx_from_pair": [_vp, _i, _vp, _vp, _i64, _vp, _i64, _i64, _i, _vp, _i],
     "asis_bn_relu_upsample_mx": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i],
     "asis_pack_conv_weight_mx": [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i64, _vp],

@@ -108,7 +108,12 @@ def conv_bn_relu_up_forward(owner: _Packed, key: str, x16, x_lo, conv: nn.Conv2d
     ks = _conv_ksplit(B * OH * OW, conv.out_channels, x16.shape[3], split)
     stats = torch.empty((ops.gemm_tiles_m(B * OH * OW), 2, conv.out_channels), device=x16.device,
                         dtype=torch.float32) if (training and ks == 1) else None
-    if mx_in is not None:
+    if mx_in is not None and ks == 1 and ops.conv_halo_ok(x16, conv.out_channels, stride, pad):
+        # narrow outputs (64 / 128 channels): the halo-tile kernel stages every input element once per plane instead of nine times
+        raw = ops.conv3x3_halo_mx(x16, x_lo, w_hi, w_lo, (mx_in, w_amax), bias_n=bias, want_stats=training)
+        if training:
+            raw, stats = raw
+    elif mx_in is not None:
         raw = ops.conv_gemm_split(x16, x_lo, w_hi, w_lo, 3, 3, stride, pad, bias_n=bias, stats=stats, ksplit=ks, mx=(mx_in, w_amax))
     elif split:
         raw = ops.conv_gemm_split(x16, x_lo, w_hi, w_lo, 3, 3, stride, pad, bias_n=bias, stats=stats, ksplit=ks)

@@ -254,6 +254,9 @@ def conv_gemm(x_nhwc: torch.Tensor, w_packed: torch.Tensor, KH: int, KW: int, st
 
 
 _FUSED_SPLIT = os.environ.get("ASIS_GEMM_BIG", "1") != "0" and os.environ.get("ASIS_SPLIT_FUSED", "1") != "0"
+# narrow MX convolutions on the halo-tile kernel (csrc/convhalo.hip): OFF by default — its first form runs 128 -> 64 at 336^2 10 % faster
+# and 256 -> 128 at 168^2 12 % slower than the implicit-GEMM form (scripts/bench_conv_halo.py, profiles/r04_conv_halo_ab.txt)
+CONV_HALO = os.environ.get("ASIS_CONV_HALO", "0") not in ("0", "")
 
 
 def conv_gemm_split(x_hi, x_lo, w_hi, w_lo, KH: int, KW: int, stride: int, pad: int, *, bias_n=None, stats=None,
@@ -272,6 +275,31 @@ def conv_gemm_split(x_hi, x_lo, w_hi, w_lo, KH: int, KW: int, stride: int, pad: 
     conv_gemm(x_lo, w_hi, KH, KW, stride, pad, out=out, accumulate=True)
     conv_gemm(x_hi, w_lo, KH, KW, stride, pad, out=out, accumulate=True, stats=stats)
     return out
+
+
+def conv_halo_ok(x_hi: torch.Tensor, Cout: int, stride: int, pad: int, force: bool = False) -> bool:
+    """shapes ``conv3x3_halo_mx`` covers: float16, stride 1, pad 1, Cin % 64 == 0, Cout 64 / 128 (csrc/convhalo.hip); ``force``:
+    whatever the ASIS_CONV_HALO switch says"""
+    return ((CONV_HALO or force) and x_hi.dtype == torch.float16 and stride == 1 and pad == 1 and x_hi.shape[3] % 64 == 0 and Cout in (64, 128)
+            and x_hi.is_contiguous())
+
+
+def conv3x3_halo_mx(x_hi, x_mx, w_hi, w_mx, mx, *, bias_n=None, want_stats: bool = False):
+    """3x3 / stride 1 / pad 1 convolution of the MX operand planes on the halo-tile kernel (include/asis_hip.h:
+    asis_conv3x3_halo_mx) -> fp32 NHWC out, or (out, stats [tiles, 2, Cout]) with ``want_stats``."""
+    _dev(x_hi, x_mx, w_hi, w_mx, bias_n, mx[0], mx[1])
+    Bn, H, W, Cin = x_hi.shape
+    Cout = w_hi.shape[0]
+    if not (x_hi.is_contiguous() and x_mx.is_contiguous() and w_hi.is_contiguous() and w_mx.is_contiguous() and w_hi.shape[1] == 9 * Cin):
+        raise ValueError("conv3x3_halo_mx: contiguous NHWC planes and [Cout, 9 Cin] packed weights expected")
+    out = torch.empty((Bn, H, W, Cout), device=x_hi.device, dtype=torch.float32)
+    stats = None
+    if want_stats:
+        stats = torch.empty((lib().asis_conv3x3_halo_mx_tiles(Bn, H, W), 2, Cout), device=x_hi.device, dtype=torch.float32)
+    check(lib().asis_conv3x3_halo_mx(_stream(), _dt(x_hi.dtype), x_hi.data_ptr(), x_mx.data_ptr(), w_hi.data_ptr(), w_mx.data_ptr(),
+                                     _p(_f32c(bias_n)), mx[0].data_ptr(), mx[1].data_ptr(), out.data_ptr(), _p(stats), Bn, H, W, Cin, Cout),
+          "asis_conv3x3_halo_mx")
+    return (out, stats) if want_stats else out
 
 
 def gemm_split(a_hi, a_lo, b_hi, b_lo, *, out: torch.Tensor, bias_n=None):

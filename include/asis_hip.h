@@ -166,6 +166,17 @@ int asis_bn_relu_absmax(void* stream, const float* x, const float* scale, const 
  * ld_out): two e4m3 bytes per element, activations (hi8, lo8), wside != 0 (the weight operand) (lo8, hi8); amax = the
  * absolute maximum of the hi plane.  The A_lo / B_lo + mx_amax_a / mx_amax_b operands of a dense asis_gemm
  * (`dinov2/layers/block.py:89-114` linear layers at fp32 in the reference; config.precise_level 2 here). */
+/* 3x3, stride 1, pad 1 convolution for NARROW outputs (Cout = 64 or 128, Cin % 64 == 0) on the operand planes of an MX split
+ * convolution — x_hi / x_mx NHWC [B, H, W, Cin] (asis_bn_relu_upsample_mx), w_hi / w_mx [Cout, 9 Cin] (asis_pack_conv_weight(_mx) mode 0),
+ * amax_a / amax_b the tensors' maxima — as a halo-tile kernel: one workgroup per 16 x 16 pixel tile and all output channels, the
+ * 18 x 18 halo of a 64-channel chunk staged once per plane and read by the nine taps at shifted addresses (the implicit-GEMM form
+ * re-stages every input element nine times per plane; with 64 / 128 output columns that fill is what bounds it).
+ * out fp32 NHWC [B, H, W, Cout] (+ bias); stats != NULL: [asis_conv3x3_halo_mx_tiles(B, H, W)][2][Cout] per-tile (sum, sum of squares)
+ * of the outputs, the BatchNorm partial sums asis_reduce_partials takes.  float16 only.
+ * Replaces `backbones/decoders.py:109-135` conv3x3 of the last two FeatureDecoder stages (256 -> 128, 128 -> 64). */
+int asis_conv3x3_halo_mx_tiles(int B, int H, int W);
+int asis_conv3x3_halo_mx(void* stream, int dtype, const void* x_hi, const void* x_mx, const void* w_hi, const void* w_mx, const float* bias,
+                         const float* amax_a, const float* amax_b, float* out, float* stats, int B, int H, int W, int Cin, int Cout);
 int asis_absmax_16(void* stream, int dtype, const void* x, int64_t rows, int cols, int64_t ld, float* amax);
 int asis_mx_from_pair(void* stream, int dtype, const void* hi, const void* lo, int64_t ld_in, void* out_mx, int64_t ld_out, int64_t rows,
                       int cols, const float* amax, int wside);

@@ -133,3 +133,32 @@ def test_layernorm_mx_planes(dev):
     assert float(bound) > 4 * float(y.abs().max())                       # the bound really is loose here
     dh, dl = _decode(mx, float(bound), dt, False)
     assert rel_l2(dh, hi.float()) < 0.04 and rel_l2(dl, (y - hi.float())) < 0.06
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,Wd", [(2, 128, 64, 40, 40), (2, 256, 128, 33, 21), (1, 64, 64, 5, 70), (3, 128, 128, 16, 16)])
+def test_halo_tile_mx_conv_vs_implicit_gemm_and_fp32(dev, B, Cin, Cout, H, Wd):
+    """asis_conv3x3_halo_mx (csrc/convhalo.hip: the narrow decoder convolutions `decoders.py:109-135`, 256 -> 128 and 128 -> 64) on
+    ragged tile grids: against the implicit-GEMM MX path on the same operand planes (different summation order: fp32 rounding apart),
+    against fp32 torch on the unrounded operands, and its BatchNorm partial sums against the output's column sums."""
+    dt = torch.float16
+    x = torch.relu(W.tensor(f"halo.x{Cin}.{H}.{Wd}", (B, H, Wd, Cin), 1.0) * 2 + 0.3).to(dev)
+    w = W.tensor(f"halo.w{Cin}.{Cout}", (Cout, Cin, 3, 3), 0.03).to(dev)
+    bias = W.tensor(f"halo.b{Cout}", (Cout,), 1.0).to(dev)
+    ref = F.conv2d(x.permute(0, 3, 1, 2), w, bias, padding=1).permute(0, 2, 3, 1)
+    amax_x = ops.absmax_f32(x.view(-1, Cin))
+    one, zero = torch.ones(Cin, device=dev), torch.zeros(Cin, device=dev)
+    x_hi, x_mx = ops.bn_relu_upsample(x, one, zero, 1, dt, True, mx_amax=amax_x)
+    w_hi = ops.pack_conv_weight(w, 0, dt)
+    w_mx, amax_w = ops.pack_conv_weight_mx(w, 0, dt)
+    assert ops.conv_halo_ok(x_hi, Cout, 1, 1, force=True)
+    outs = [ops.conv3x3_halo_mx(x_hi, x_mx, w_hi, w_mx, (amax_x, amax_w), bias_n=bias, want_stats=True) for _ in range(2)]
+    out, stats = outs[0]
+    assert torch.equal(out, outs[1][0]) and torch.equal(stats, outs[1][1]), "not reproducible"
+    e32 = rel_l2(out, ref)
+    print(f"halo conv {Cin}->{Cout} @{H}x{Wd}: vs fp32 {e32:.2e}")
+    assert e32 < 4e-5
+    if B * H * Wd >= 256:
+        gem = ops.conv_gemm_split(x_hi, x_mx, w_hi, w_mx, 3, 3, 1, 1, bias_n=bias, mx=(amax_x, amax_w))
+        assert rel_l2(out, gem) < 2e-6
+    flat = out.view(-1, Cout).double()
+    assert rel_l2(stats[:, 0].double().sum(0), flat.sum(0)) < 1e-5 and rel_l2(stats[:, 1].double().sum(0), (flat * flat).sum(0)) < 1e-5
