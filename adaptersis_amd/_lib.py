@@ -124,6 +124,8 @@ SIGNATURES = {
     "asis_dwconv_gelu": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i],
     "asis_conv3x3_c3": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i],
     "asis_conv3x3_smallcout_fwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i],
+    "asis_conv3x3_smallcout_fwd_up": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i],
+    "asis_conv3x3_smallcout_wgrad_up": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i],
     "asis_conv3x3_smallcout_dgrad": [_vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i],
     "asis_conv3x3_smallcout_wgrad": [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i],
     "asis_colstats_nparts": [_i64],

@@ -86,10 +86,12 @@ def _conv_weights_mx(owner: _Packed, key: str, conv: nn.Conv2d):
 
 def conv_bn_relu_up_forward(owner: _Packed, key: str, x16, x_lo, conv: nn.Conv2d, bn: nn.BatchNorm2d, factor: int,
                             sync_bn: bool, save: bool, training: bool = True, stride: int = 1, pad: int = 1,
-                            pool: bool = False, mx_out: bool = False):
+                            pool: bool = False, mx_out: bool = False, defer_up: bool = False):
     """(x16, x_lo|None) NHWC -> ((up_hi, up_lo|None), saved stage).  training=False: BatchNorm uses its running
     statistics (``seg_decoder.eval()`` in validate_network, train.py:451) and nothing is saved.  ``stride`` / ``pad``:
-    the 3x3 conv's geometry (the CNN encoder's stride-2 stages); ``pool``: MaxPool2d(3, 2, 1) after the ReLU (stem)."""
+    the 3x3 conv's geometry (the CNN encoder's stride-2 stages); ``pool``: MaxPool2d(3, 2, 1) after the ReLU (stem).
+    ``defer_up``: do not write the BatchNorm + ReLU + upsampled operand pair — the consumer evaluates it on load from the raw map
+    (the classifier conv: ops.conv3x3_smallcout_fwd_up); returns ``(("deferred", raw, scale, shift), stage)``."""
     dt = config.operand_dtype
     split_out = x_lo is not None                   # the next stage's operand pair keeps the caller's precision mode
     if key in config.unsplit_layers:
@@ -127,7 +129,9 @@ def conv_bn_relu_up_forward(owner: _Packed, key: str, x16, x_lo, conv: nn.Conv2d
         scale, shift = ops.bn_eval_affine(bn)
         mean = invstd = count = None
         save = False
-    if pool:
+    if defer_up:
+        up = ("deferred", raw, scale, shift)
+    elif pool:
         up = ops.bn_relu_maxpool(raw, scale, shift, dt, split_out)
     elif factor > 1 and mx_out and split_out:
         # the consumer is a split convolution that takes MX lo operands: the tensor's maximum first (BatchNorm + ReLU of the
@@ -137,7 +141,7 @@ def conv_bn_relu_up_forward(owner: _Packed, key: str, x16, x_lo, conv: nn.Conv2d
         up = ops.bn_relu_upsample(raw, scale, shift, factor, dt, split_out)
     else:
         up = ops.bn_act(raw, scale, shift, True, dt, split_out)
-    if not split_out:
+    if not split_out and not defer_up:
         up = (up, None)
     st = None
     if save:
@@ -273,8 +277,19 @@ class FeatureDecoder(_Packed):
             Bq, Hq, Wq, _ = a[0].shape
             mx_out = bool(config.mx_conv_on() and a[1] is not None and nxt is not None and f"d{i + 1}" not in config.unsplit_layers and
                           ops.mx_conv_ok(Bq * 4 * Hq * Wq, nxt.in_channels, nxt.out_channels))
-            a, st = conv_bn_relu_up_forward(self, f"d{i}", a[0], a[1], seq[0], seq[1], 2, self.sync_bn, save, training, mx_out=mx_out)
+            # stage 4 -> classifier: with 64 channels, <= 8 classes and split operands the upsampled pair (4x the bytes of the raw map)
+            # is never written: the classifier conv and its weight gradient evaluate BatchNorm + ReLU + upsampling on load
+            fo = self.final_out
+            defer = bool(i == 4 and a[1] is not None and ops.FUSE_CLS_UP and seq[0].out_channels == 64 and fo.in_channels == 64 and
+                         fo.out_channels <= 8 and Hq >= 4 and Wq >= 8)
+            a, st = conv_bn_relu_up_forward(self, f"d{i}", a[0], a[1], seq[0], seq[1], 2, self.sync_bn, save, training, mx_out=mx_out,
+                                            defer_up=defer)
             saved.append(st)
+        if isinstance(a[0], str):                     # ("deferred", raw, scale, shift)
+            logits = ops.conv3x3_smallcout_fwd_up(a[1], a[2], a[3], self._f32("final.wf", self.final_out.weight),
+                                                  self._f32("final.b", self.final_out.bias), config.operand_dtype)
+            saved.append(None)                        # no classifier input tensor: _final_backward recomputes it from saved[3]
+            return logits, saved
         logits = self._final_forward(a)
         saved.append(a[0] if save else None)
         return logits, saved
@@ -290,7 +305,7 @@ class FeatureDecoder(_Packed):
             return ops.conv_gemm_split(a[0], a[1], w_hi, w_lo, 3, 3, 1, 1, bias_n=bias)
         return ops.conv_gemm(a[0], w_hi, 3, 3, 1, 1, bias_n=bias)
 
-    def _final_backward(self, x5, d16, d_lo, bias_partial, inv_scale, grads, dlogits_f32):
+    def _final_backward(self, x5, d16, d_lo, bias_partial, inv_scale, grads, dlogits_f32, st4=None):
         """Gradients of the classifier conv; returns loss_scale * dL/d(its input), fp32 NHWC."""
         C = self.num_classes
         if bias_partial is not None:
@@ -298,7 +313,11 @@ class FeatureDecoder(_Packed):
         else:  # compatibility path: column sums of the fp32 dlogits [P, C]
             ops.reduce_rows(dlogits_f32, 1.0, grads["final_out.bias"])
         wout = grads["final_out.weight"]
-        parallel.wgrad_on_side_stream(lambda: ops.wgrad(d16, x5, C, 3, 3, 1, 1, inv_scale, out=wout), d16, x5)
+        if x5 is None:      # the classifier's input was never written (upsample on load): st4 = the stage that would have produced it
+            parallel.wgrad_on_side_stream(lambda: ops.conv3x3_smallcout_wgrad_up(d16, st4.raw, st4.scale, st4.shift, C, inv_scale, out=wout),
+                                          d16, st4.raw)
+        else:
+            parallel.wgrad_on_side_stream(lambda: ops.wgrad(d16, x5, C, 3, 3, 1, 1, inv_scale, out=wout), d16, x5)
         fo = self.final_out
         if fo.out_channels <= 8 and fo.in_channels <= 224:
             return ops.conv3x3_smallcout_dgrad(d16, d_lo, self._f32("final.wf", fo.weight))
@@ -310,7 +329,7 @@ class FeatureDecoder(_Packed):
         called after the final conv and after each decoder stage (4,3,2,1) once its gradients are
         enqueued — the engine launches that stage's gradient all-reduce from it.  ``need_input_grad``: also return
         loss_scale * dL/d(input) as fp32 NHWC (end-to-end training of the backbone)."""
-        dU = self._final_backward(saved[4], d16, d_lo, bias_partial, inv_scale, grads, dlogits_f32)
+        dU = self._final_backward(saved[4], d16, d_lo, bias_partial, inv_scale, grads, dlogits_f32, st4=saved[3])
         if stage_done is not None:
             stage_done()
         for i in range(4, 0, -1):

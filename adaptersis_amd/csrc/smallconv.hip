@@ -82,25 +82,74 @@ __global__ __launch_bounds__(256) void smallcout_fwd_kernel(const T* __restrict_
   }
 }
 
-// ---- forward on the matrix pipe -------------------------------------------------------------------------------------------
-// The direct form above reads every input pixel nine times through L1 / L2 (1.4 TB/s of algorithmic bytes for the 64 -> 2 conv
-// at 12 x 672^2).  Here a workgroup stages the (8+2) x (16+2) halo of an 8 x 16 output tile ONCE by LDS-DMA (hi and lo halves:
-// 256 B per pixel, 45 KiB; pixels outside the image come from the zero page) and every output row of the tile is one 16-pixel
-// MFMA row block: D[pixel, class] += A[pixel, 32 channels of one tap] . B[32, 16 classes] with v_mfma_f32_16x16x32 (2 .. 16 of
-// the 16 columns used: the pipe is 12 % busy and still far ahead of the vector units, where unpack + add + 2 FMAs per input
-// element and class cost 450 of the 640 us of the round-2 LDS-tiled fp32 kernel, 594 with packed dot products), three passes
-// x_hi.w_hi + x_lo.w_hi + x_hi.w_lo like every other split convolution, fp32 accumulation: 397 us, 3.5 TB/s of input.
+// ---- BatchNorm + ReLU + bilinear x2 (align_corners) of the previous stage's raw conv output, evaluated ON LOAD -------------------
+// (`decoders.py:131-135`: ... BatchNorm2d, ReLU, Upsample(2, bilinear, align_corners=True), Conv2d(64, classes, 3, padding=1)).  The
+// classifier's input is 4x the bytes of the raw map it is made of (12 x 672^2 x 64 channels as hi + lo planes: 1.39 GB written by
+// asis_bn_relu_upsample and read back by the forward conv, the hi plane once more by the weight gradient); here the halo tile of
+// the upsampled map is computed from the raw fp32 map (0.35 GB, re-read from L2 by neighbouring tiles) while it is staged.
+// Same tap order and weights as bn_relu_upsample8_kernel (convmisc.hip).
+struct UpSrc {
+  const float* raw;      // fp32 NHWC [B, H, W, 64] (low resolution)
+  const float* scale;    // BatchNorm scale / shift per channel
+  const float* shift;
+  int H, W;              // low-resolution size; the conv runs on [2H, 2W]
+};
+// Two phases per tile, so that no halo value waits on a global load: (A) relu(raw * scale + shift) of the low-resolution region under
+// the tile's halo (at most UP_RY x UP_RX source pixels: 10 / 18 high-resolution rows / columns map to <= 6 / 10 source rows / columns
+// plus the +1 taps) -> fp32 in LDS; (B) every halo value = the four-tap blend of that region, read from LDS.
+constexpr int UP_RY = 8, UP_RX = 12;
+__device__ __forceinline__ void up_stage_lowres(const UpSrc& u, int b, int r0, int c0, float* __restrict__ lowr, int tid) {
+  constexpr int C = 64;
+  for (int it = tid; it < UP_RY * UP_RX * (C / 4); it += 256) {
+    const int c4 = it & 15, px = it >> 4;
+    const int ry = px / UP_RX, rx = px - ry * UP_RX;
+    const int sy = min(r0 + ry, u.H - 1), sx = min(c0 + rx, u.W - 1);
+    const float4 v = reinterpret_cast<const float4*>(u.raw + (((int64_t)b * u.H + sy) * u.W + sx) * C)[c4];
+    const float4 sc = reinterpret_cast<const float4*>(u.scale)[c4], sh = reinterpret_cast<const float4*>(u.shift)[c4];
+    reinterpret_cast<float4*>(lowr + px * C)[c4] = make_float4(fmaxf(v.x * sc.x + sh.x, 0.f), fmaxf(v.y * sc.y + sh.y, 0.f),
+                                                               fmaxf(v.z * sc.z + sh.z, 0.f), fmaxf(v.w * sc.w + sh.w, 0.f));
+  }
+}
+__device__ __forceinline__ void up8_blend(const UpSrc& u, const float* __restrict__ lowr, int r0, int c0, int oh, int ow, int c8,
+                                          float rh, float rw, float acc[8]) {
+  constexpr int C = 64;
+  const float w1r = rw * ow;
+  const int w1 = (int)w1r;
+  const int w1p = (w1 < u.W - 1) ? 1 : 0;
+  const float wl = w1r - w1;
+  const float h1r = rh * oh;
+  const int h1 = (int)h1r;
+  const int h1p = (h1 < u.H - 1) ? 1 : 0;
+  const float hl = h1r - h1;
+  const int ly = min(max(h1 - r0, 0), UP_RY - 2), lx = min(max(w1 - c0, 0), UP_RX - 2);   // inside the staged region by construction
+  const float* base = lowr + (ly * UP_RX + lx) * C + 8 * c8;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int dh = (t >> 1) ? h1p : 0, dw = (t & 1) ? w1p : 0;
+      const float4 v = reinterpret_cast<const float4*>(base + (dh * UP_RX + dw) * C)[h];
+      const float wt = ((t >> 1) ? hl : 1.f - hl) * ((t & 1) ? wl : 1.f - wl);
+      a.x += wt * v.x; a.y += wt * v.y; a.z += wt * v.z; a.w += wt * v.w;
+    }
+    acc[4 * h + 0] = a.x; acc[4 * h + 1] = a.y; acc[4 * h + 2] = a.z; acc[4 * h + 3] = a.w;
+  }
+}
+
 // The halo pixel record is 16 chunks of 16 bytes (8 hi | 8 lo) with the chunk index XORed with the pixel's low bits: the
 // 16 lanes of one A-fragment column group read the same chunk of 16 consecutive pixels -> 16 different bank groups.
-template <typename T>
+template <typename T, bool UP = false>
 __global__ __launch_bounds__(256, 2) void smallcout_fwd_mfma_kernel(const T* __restrict__ xh, const T* __restrict__ xl,
                                                                     const float* __restrict__ w, const float* __restrict__ bias,
-                                                                    float* __restrict__ out, int B, int H, int W, int Cout) {
+                                                                    float* __restrict__ out, int B, int H, int W, int Cout,
+                                                                    const UpSrc up = UpSrc{}) {
   constexpr int CIN = 64, TY = 8, TX = 16, HY = TY + 2, HX = TX + 2, NPIX = HY * HX;   // 180 halo pixels
   typedef typename T16<T>::v8 v8;
   typedef __attribute__((address_space(3))) void* lds_ptr;
   typedef const __attribute__((address_space(1))) void* glb_ptr;
   __shared__ __attribute__((aligned(16))) T tile[NPIX * 2 * CIN];   // [pixel][16 chunks, swizzled][8]
+  __shared__ __attribute__((aligned(16))) float lowr[UP ? UP_RY * UP_RX * CIN : 4];   // UP: relu(bn(raw)) of the region under the halo
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fn = lane & 15, fq = lane >> 4;   // MFMA fragment coordinates: A row (pixel) / B, D column (class); K group
@@ -124,6 +173,26 @@ __global__ __launch_bounds__(256, 2) void smallcout_fwd_mfma_kernel(const T* __r
   for (int tl = xcd_remap(blockIdx.x, gridDim.x); tl < ntiles; tl += gridDim.x) {
     const int tx = tl % tiles_x, ty = (tl / tiles_x) % tiles_y, b = tl / (tiles_x * tiles_y);
     const int y0 = ty * TY - 1, x0 = tx * TX - 1;
+    if constexpr (UP) {                               // the halo tile of the upsampled map, computed from the raw low-resolution map
+      const float rh = H > 1 ? (float)(up.H - 1) / (float)(H - 1) : 0.f, rw = W > 1 ? (float)(up.W - 1) / (float)(W - 1) : 0.f;
+      const int r0 = (int)(rh * max(y0, 0)), c0 = (int)(rw * max(x0, 0));   // first source row / column under the halo
+      up_stage_lowres(up, b, r0, c0, lowr, tid);
+      __syncthreads();
+      for (int it = tid; it < NPIX * 8; it += 256) {  // (halo pixel, 8-channel group): hi chunk c8 and lo chunk 8 + c8 of the record
+        const int hp = it >> 3, c8 = it & 7;
+        const int hy = hp / HX, hx = hp - hy * HX;
+        const int yy = y0 + hy, xx = x0 + hx;
+        float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) up8_blend(up, lowr, r0, c0, yy, xx, c8, rh, rw, a8);
+        uint4 oh, ol;
+        oh.x = pack2<T>(a8[0], a8[1]); oh.y = pack2<T>(a8[2], a8[3]); oh.z = pack2<T>(a8[4], a8[5]); oh.w = pack2<T>(a8[6], a8[7]);
+        ol.x = pack2<T>(lo_part<T>(a8[0]), lo_part<T>(a8[1])); ol.y = pack2<T>(lo_part<T>(a8[2]), lo_part<T>(a8[3]));
+        ol.z = pack2<T>(lo_part<T>(a8[4]), lo_part<T>(a8[5])); ol.w = pack2<T>(lo_part<T>(a8[6]), lo_part<T>(a8[7]));
+        T* rec = tile + hp * 2 * CIN;
+        *reinterpret_cast<uint4*>(rec + ((c8 ^ (hp & 15)) << 3)) = oh;
+        *reinterpret_cast<uint4*>(rec + (((c8 + 8) ^ (hp & 15)) << 3)) = ol;
+      }
+    } else {
     for (int g = wid; g * 4 < NPIX; g += 4) {       // 45 groups of 4 pixels over the 4 waves
       const int hp = g * 4 + dp;
       const int hy = hp / HX, hx = hp - hy * HX;
@@ -136,6 +205,7 @@ __global__ __launch_bounds__(256, 2) void smallcout_fwd_mfma_kernel(const T* __r
       __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(tile + g * 4 * 2 * CIN), 16, 0, 0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __syncthreads();
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
@@ -449,9 +519,10 @@ __global__ __launch_bounds__(256) void smallcout_wgrad_kernel(const T* __restric
 // Per 8 x 16 tile: four K steps of 32 pixels (two tile rows), per step one dy fragment and nine x fragments, 36 MFMAs
 // (16x16x32) per wave; wave w owns input channels 16 w .. 16 w + 15 and keeps its nine 16 x 16 accumulators (tap by tap) over
 // the workgroup's whole run of tiles.  One fp32 slab row per workgroup, summed by asis_reduce_rows in a fixed order.
-template <typename T>
+template <typename T, bool UP = false>
 __global__ __launch_bounds__(256, 2) void smallcout_wgrad_mfma_kernel(const T* __restrict__ dy, const T* __restrict__ x,
-                                                                      float* __restrict__ slab, int B, int H, int W, int Cout) {
+                                                                      float* __restrict__ slab, int B, int H, int W, int Cout,
+                                                                      const UpSrc up = UpSrc{}) {
   constexpr int CIN = 64, COP = 8, TY = 8, TX = 16, HY = TY + 2, HX = TX + 2, NPIX = HY * HX;   // 180 halo pixels
   constexpr int NGX = (NPIX + 7) / 8;                                                           // x DMA groups of 8 pixels
   typedef typename T16<T>::v8 v8;
@@ -460,6 +531,7 @@ __global__ __launch_bounds__(256, 2) void smallcout_wgrad_mfma_kernel(const T* _
   typedef __attribute__((address_space(3))) void* lds_ptr;
   typedef const __attribute__((address_space(1))) void* glb_ptr;
   __shared__ __attribute__((aligned(16))) T xt[NGX * 8 * CIN];     // [halo pixel][64 ci]
+  __shared__ __attribute__((aligned(16))) float lowr[UP ? UP_RY * UP_RX * CIN : 4];   // UP: relu(bn(raw)) of the region under the halo
   __shared__ __attribute__((aligned(16))) T dt[TY * TX * COP];     // [tile pixel][8 co]
   __shared__ __attribute__((aligned(16))) T zt[8];                 // zeros: columns 8..15 of the dy fragment
   const int tid = threadIdx.x, lane = tid & 63;
@@ -476,6 +548,22 @@ __global__ __launch_bounds__(256, 2) void smallcout_wgrad_mfma_kernel(const T* _
   for (int tl = xcd_remap(blockIdx.x, gridDim.x); tl < ntiles; tl += gridDim.x) {
     const int tx = tl % tiles_x, ty = (tl / tiles_x) % tiles_y, b = tl / (tiles_x * tiles_y);
     const int y0 = ty * TY - 1, x0 = tx * TX - 1;
+    if constexpr (UP) {                               // the x halo of the upsampled map, computed from the raw low-resolution map
+      const float rh = H > 1 ? (float)(up.H - 1) / (float)(H - 1) : 0.f, rw = W > 1 ? (float)(up.W - 1) / (float)(W - 1) : 0.f;
+      const int r0 = (int)(rh * max(y0, 0)), c0 = (int)(rw * max(x0, 0));
+      up_stage_lowres(up, b, r0, c0, lowr, tid);
+      __syncthreads();
+      for (int it = tid; it < NGX * 8 * 8; it += 256) {
+        const int hp = it >> 3, c8 = it & 7;
+        const int hy = hp / HX, hx = hp - hy * HX;
+        const int yy = y0 + hy, xx = x0 + hx;
+        float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (hp < NPIX && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) up8_blend(up, lowr, r0, c0, yy, xx, c8, rh, rw, a8);
+        uint4 oh;
+        oh.x = pack2<T>(a8[0], a8[1]); oh.y = pack2<T>(a8[2], a8[3]); oh.z = pack2<T>(a8[4], a8[5]); oh.w = pack2<T>(a8[6], a8[7]);
+        *reinterpret_cast<uint4*>(xt + hp * CIN + c8 * 8) = oh;
+      }
+    } else {
     for (int g = wid; g < NGX; g += 4) {             // x halo: one instruction = 8 pixels x 8 chunks
       const int hp = g * 8 + (lane >> 3);
       const int hy = hp / HX, hx = hp - hy * HX;
@@ -483,6 +571,7 @@ __global__ __launch_bounds__(256, 2) void smallcout_wgrad_mfma_kernel(const T* _
       const bool in = hp < NPIX && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
       const T* src = in ? x + (((int64_t)b * H + yy) * W + xx) * CIN + (lane & 7) * 8 : zp;
       __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(xt + g * 8 * CIN), 16, 0, 0);
+    }
     }
     if (wid < 2) {                                    // dy: one instruction = 64 tile pixels x 16 bytes
       const int pt = wid * 64 + lane;
@@ -569,6 +658,48 @@ extern "C" int asis_conv3x3_smallcout_fwd(void* stream, int dtype, const void* x
   if (dtype == ASIS_F16) launch_fwd<f16>(s, x_hi, x_lo, w, bias, out, B, H, W, Cin, Cout);
   else launch_fwd<bf16>(s, x_hi, x_lo, w, bias, out, B, H, W, Cin, Cout);
   ASIS_CHECK_LAUNCH("asis_conv3x3_smallcout_fwd");
+  return ASIS_OK;
+}
+
+extern "C" int asis_conv3x3_smallcout_fwd_up(void* stream, int dtype, const float* raw, const float* scale, const float* shift,
+                                             const float* w, const float* bias, float* out, int B, int H, int W, int Cin, int Cout) {
+  ASIS_REQUIRE(raw && scale && shift && w && out, "asis_conv3x3_smallcout_fwd_up: null pointer");
+  ASIS_REQUIRE(Cin == 64 && Cout >= 1 && Cout <= 16 && B > 0 && H >= 4 && W >= 8,
+               "asis_conv3x3_smallcout_fwd_up: Cin=%d must be 64, Cout=%d in 1..16, the low-resolution map at least 4 x 8", Cin, Cout);
+  ASIS_REQUIRE(asis_aligned16(raw) && asis_aligned16(scale) && asis_aligned16(shift), "asis_conv3x3_smallcout_fwd_up: alignment");
+  ASIS_REQUIRE(dtype == ASIS_F16 || dtype == ASIS_BF16, "asis_conv3x3_smallcout_fwd_up: bad dtype %d", dtype);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int OH = 2 * H, OW = 2 * W;
+  const int ntiles = B * ((OH + 7) / 8) * ((OW + 15) / 16);
+  const UpSrc up{raw, scale, shift, H, W};
+  const dim3 grid(ntiles < 512 ? ntiles : 512);
+  if (dtype == ASIS_F16)
+    hipLaunchKernelGGL((smallcout_fwd_mfma_kernel<f16, true>), grid, dim3(256), 0, s, (const f16*)nullptr, (const f16*)nullptr, w, bias, out, B,
+                       OH, OW, Cout, up);
+  else
+    hipLaunchKernelGGL((smallcout_fwd_mfma_kernel<bf16, true>), grid, dim3(256), 0, s, (const bf16*)nullptr, (const bf16*)nullptr, w, bias, out,
+                       B, OH, OW, Cout, up);
+  ASIS_CHECK_LAUNCH("asis_conv3x3_smallcout_fwd_up");
+  return ASIS_OK;
+}
+
+extern "C" int asis_conv3x3_smallcout_wgrad_up(void* stream, int dtype, const void* dy, int CoP, const float* raw, const float* scale,
+                                               const float* shift, float* slabs, int nblk, int B, int H, int W, int Cin, int Cout) {
+  ASIS_REQUIRE(dy && raw && scale && shift && slabs, "asis_conv3x3_smallcout_wgrad_up: null pointer");
+  ASIS_REQUIRE(Cin == 64 && CoP == 8 && Cout >= 1 && Cout <= 8 && B > 0 && H >= 4 && W >= 8,
+               "asis_conv3x3_smallcout_wgrad_up: Cin=%d must be 64, CoP=%d 8, Cout=%d <= 8, the low-resolution map at least 4 x 8", Cin, CoP, Cout);
+  ASIS_REQUIRE(nblk >= 1 && nblk <= 65535, "asis_conv3x3_smallcout_wgrad_up: bad slab count %d", nblk);
+  ASIS_REQUIRE(asis_aligned16(dy) && asis_aligned16(raw) && asis_aligned16(scale) && asis_aligned16(shift), "asis_conv3x3_smallcout_wgrad_up: alignment");
+  ASIS_REQUIRE(dtype == ASIS_F16 || dtype == ASIS_BF16, "asis_conv3x3_smallcout_wgrad_up: bad dtype %d", dtype);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const UpSrc up{raw, scale, shift, H, W};
+  if (dtype == ASIS_F16)
+    hipLaunchKernelGGL((smallcout_wgrad_mfma_kernel<f16, true>), dim3(nblk), dim3(256), 0, s, reinterpret_cast<const f16*>(dy), (const f16*)nullptr,
+                       slabs, B, 2 * H, 2 * W, Cout, up);
+  else
+    hipLaunchKernelGGL((smallcout_wgrad_mfma_kernel<bf16, true>), dim3(nblk), dim3(256), 0, s, reinterpret_cast<const bf16*>(dy),
+                       (const bf16*)nullptr, slabs, B, 2 * H, 2 * W, Cout, up);
+  ASIS_CHECK_LAUNCH("asis_conv3x3_smallcout_wgrad_up");
   return ASIS_OK;
 }
 

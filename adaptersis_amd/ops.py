@@ -752,6 +752,50 @@ def conv3x3_smallcout_fwd(x_hi: torch.Tensor, x_lo: Optional[torch.Tensor], w: t
     return out
 
 
+# classifier conv with BatchNorm + ReLU + x2 upsampling evaluated on load (csrc/smallconv.hip): OFF by default — it removes 1.4 GB of
+# writes and 2.1 GB of reads per step, but the on-load blend costs the two kernels as much as the removed pass took
+# (profiles/r04_cls_upsample_on_load_ab.txt: 211.7 / 211.1 img/s without, 211.7 / 211.4 with)
+FUSE_CLS_UP = os.environ.get("ASIS_FUSE_CLS_UP", "0") not in ("0", "")
+
+
+def cls_up_ok(raw: torch.Tensor, Cout: int) -> bool:
+    """shapes the upsample-on-load classifier kernels cover (csrc/smallconv.hip): fp32 NHWC raw map with 64 channels, <= 8 classes"""
+    return bool(raw.dtype == torch.float32 and raw.dim() == 4 and raw.shape[3] == 64 and raw.is_contiguous()
+                and Cout <= 8 and raw.shape[1] >= 4 and raw.shape[2] >= 8)
+
+
+def conv3x3_smallcout_fwd_up(raw: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, w: torch.Tensor,
+                             bias: Optional[torch.Tensor], dtype: torch.dtype) -> torch.Tensor:
+    """conv3x3(upsample2(relu(raw * scale + shift))) with the upsampled map evaluated on load (include/asis_hip.h:
+    asis_conv3x3_smallcout_fwd_up): raw fp32 NHWC [B, H, W, 64] -> fp32 [B, 2H, 2W, Cout]; ``dtype``: the 16-bit operand type."""
+    _dev(raw, scale, shift, w, bias)
+    B, H, W, Cin = raw.shape
+    Cout = w.shape[0]
+    out = torch.empty((B, 2 * H, 2 * W, Cout), device=raw.device, dtype=torch.float32)
+    check(lib().asis_conv3x3_smallcout_fwd_up(_stream(), _dt(dtype), raw.data_ptr(), _f32c(scale).data_ptr(), _f32c(shift).data_ptr(),
+                                              _f32c(w).data_ptr(), _p(_f32c(bias)), out.data_ptr(), B, H, W, Cin, Cout),
+          "asis_conv3x3_smallcout_fwd_up")
+    return out
+
+
+def conv3x3_smallcout_wgrad_up(dy: torch.Tensor, raw: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, Cout: int,
+                               inv_scale: float = 1.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """weight gradient of the same fused classifier conv: dy 16-bit [B, 2H, 2W, 8], raw fp32 [B, H, W, 64] -> dW fp32 [Cout, 64, 3, 3]"""
+    _dev(dy, raw, scale, shift, out)
+    B, H, W, Cin = raw.shape
+    if not dy.is_contiguous() or dy.shape[:3] != (B, 2 * H, 2 * W):
+        raise ValueError("conv3x3_smallcout_wgrad_up: dy must be contiguous [B, 2H, 2W, CoP]")
+    nblk = 1024
+    slabs = torch.empty((nblk, Cout * 9 * Cin), device=dy.device, dtype=torch.float32)
+    check(lib().asis_conv3x3_smallcout_wgrad_up(_stream(), _dt(dy.dtype), dy.data_ptr(), dy.shape[3], raw.data_ptr(), _f32c(scale).data_ptr(),
+                                                _f32c(shift).data_ptr(), slabs.data_ptr(), nblk, B, H, W, Cin, Cout),
+          "asis_conv3x3_smallcout_wgrad_up")
+    if out is None:
+        out = torch.empty((Cout, Cin, 3, 3), device=dy.device, dtype=torch.float32)
+    reduce_rows(slabs, inv_scale, out.view(-1))
+    return out
+
+
 def conv3x3_smallcout_dgrad(dy_hi: torch.Tensor, dy_lo: Optional[torch.Tensor], w: torch.Tensor) -> torch.Tensor:
     """Input gradient of the small-Cout conv: dy 16-bit [B,H,W,CoP] (hi [+lo]) -> dx fp32 [B,H,W,Cin]."""
     _dev(dy_hi, dy_lo, w)

@@ -382,6 +382,17 @@ int asis_conv3x3_smallcout_fwd(void* stream, int dtype, const void* x_hi, const 
 int asis_conv3x3_smallcout_dgrad(void* stream, int dtype, const void* dy_hi, const void* dy_lo, int CoP, const float* w,
                                  float* dx, int B, int H, int W, int Cin, int Cout);
 
+/* The same classifier conv and its weight gradient with the preceding BatchNorm + ReLU + bilinear x2 upsampling (align_corners = True)
+ * evaluated ON LOAD (`decoders.py:131-135`: BatchNorm2d, ReLU, Upsample(2), Conv2d(64, classes, 3, padding = 1)): raw = the previous
+ * stage's fp32 conv output NHWC [B, H, W, 64], scale / shift = its BatchNorm affine (asis_bn_finalize); the convolution runs on the
+ * [2H, 2W] map, whose halo tiles are computed from `raw` while they are staged — the upsampled operand planes (4x the bytes of
+ * `raw`, written by asis_bn_relu_upsample and read back twice) never exist.  Same arithmetic as asis_bn_relu_upsample followed by
+ * asis_conv3x3_smallcout_fwd / _wgrad.  out fp32 [B, 2H, 2W, Cout]; dy 16-bit [B, 2H, 2W, CoP = 8]. */
+int asis_conv3x3_smallcout_fwd_up(void* stream, int dtype, const float* raw, const float* scale, const float* shift, const float* w,
+                                  const float* bias, float* out, int B, int H, int W, int Cin, int Cout);
+int asis_conv3x3_smallcout_wgrad_up(void* stream, int dtype, const void* dy, int CoP, const float* raw, const float* scale,
+                                    const float* shift, float* slabs, int nblk, int B, int H, int W, int Cin, int Cout);
+
 /* Weight gradient of the same 3x3 / stride 1 / pad 1 classifier conv (`backbones/decoders.py:135` under
  * `loss.backward()`, `train.py:432`): dy 16-bit [B,H,W,CoP], x 16-bit [B,H,W,Cin] -> `nblk` fp32 slab rows of
  * [Cout,Cin,3,3] partial sums (one per workgroup; sum them with asis_reduce_rows).  Cin in {8,16,32,64}. */

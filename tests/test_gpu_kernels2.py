@@ -324,3 +324,35 @@ def test_fused_split_dense_gemm(dev):
     ops.gemm_split(a_hi, a_lo, b_hi, b_lo, out=out, bias_n=bias)
     ref = a @ b.t() + bias
     assert rel_l2(out, ref) < 3e-6
+
+
+@pytest.mark.parametrize("B,H,Wd,classes", [(2, 20, 24, 2), (1, 7, 13, 3), (3, 4, 8, 2)])
+def test_classifier_conv_with_upsample_on_load(dev, B, H, Wd, classes):
+    """asis_conv3x3_smallcout_fwd_up / _wgrad_up (`decoders.py:131-135`: BatchNorm, ReLU, Upsample(2, bilinear, align_corners), Conv2d(64,
+    classes, 3, padding=1)): the classifier conv and its weight gradient with the upsampled operand evaluated on load, against
+    asis_bn_relu_upsample followed by the plain kernels (same arithmetic: equal to fp32 rounding of the conv sums) and fp32 torch."""
+    from adaptersis_amd import config
+    dt = config.operand_dtype
+    C = 64
+    raw = (W.tensor(f"cu.raw{H}.{Wd}", (B, H, Wd, C), 1.0) * 2).to(dev)
+    scale, shift = (0.5 + W.tensor("cu.sc", (C,), 0.2).abs()).to(dev), W.tensor("cu.sh", (C,), 0.3).to(dev)
+    w = W.tensor(f"cu.w{classes}", (classes, C, 3, 3), 0.05).to(dev)
+    bias = W.tensor(f"cu.b{classes}", (classes,), 1.0).to(dev)
+    assert ops.cls_up_ok(raw, classes)
+    hi, lo = ops.bn_relu_upsample(raw, scale, shift, 2, dt, True)
+    ref = ops.conv3x3_smallcout_fwd(hi, lo, w, bias)
+    out = ops.conv3x3_smallcout_fwd_up(raw, scale, shift, w, bias, dt)
+    assert out.shape == ref.shape and rel_l2(out, ref) < 1e-6
+    up = F.interpolate(torch.relu(raw * scale + shift).permute(0, 3, 1, 2), scale_factor=2, mode="bilinear", align_corners=True)
+    assert rel_l2(out, F.conv2d(up, w, bias, padding=1).permute(0, 2, 3, 1)) < 2e-5
+    dy32 = W.tensor(f"cu.dy{H}.{Wd}", (B, 2 * H, 2 * Wd, 8), 1.0).to(dev)
+    dy32[..., classes:] = 0
+    dy = dy32.to(dt).contiguous()
+    g_ref = ops.wgrad(dy, hi, classes, 3, 3, 1, 1, 1.0)
+    g = ops.conv3x3_smallcout_wgrad_up(dy, raw, scale, shift, classes, 1.0)
+    # the on-load values and asis_bn_relu_upsample's may round to neighbouring 16-bit values here and there (FMA contraction differs
+    # between the two kernels): 1.7e-5 measured; both sit at the 16-bit operand's distance from the fp32 gradient
+    assert rel_l2(g, g_ref) < 5e-5
+    wr = w.clone().requires_grad_(True)
+    F.conv2d(up, wr, None, padding=1).backward(dy.float()[..., :classes].permute(0, 3, 1, 2))
+    assert rel_l2(g, wr.grad) < 1e-3 and rel_l2(g_ref, wr.grad) < 1e-3

@@ -3,6 +3,7 @@ generated from the imported reference and against the CPU oracle.  TOL = north_s
 import pytest
 import torch
 
+from adaptersis_amd import ops
 from adaptersis_amd.backbones.adapter_blocks import CACNN, CAViT, deform_inputs
 from adaptersis_amd.backbones.decoders import FeatureDecoder
 from adaptersis_amd.backbones.encoders import FeatureEncoder
@@ -172,3 +173,31 @@ def test_decoder_setr_vs_reference_golden(dev):
             if float(g[f"setr.grad.{k}"].norm()) > 1e-6}
     print("SETR grads:", {k: f"{v:.1e}" for k, v in errs.items()})
     assert max(errs.values()) < 3e-2, errs  # ReLU-flip floor on small maps, see tests/test_gpu_unet.py
+
+
+def test_feature_decoder_with_classifier_upsample_on_load(dev):
+    """ops.FUSE_CLS_UP (opt-in): stage 4's BatchNorm + ReLU + upsampling evaluated inside the classifier conv and its weight gradient
+    (`decoders.py:131-135`) — logits and every parameter gradient against the default path of the same module (features[4] = 64:
+    the geometry the fused kernels cover)."""
+    D, hw, B = 32, 6, 2
+    feats = [D, 32, 16, 16, 64]
+    x = W.tensor("dec_up.x", (B, 3 * D, hw, hw), 1.0).to(dev)
+    tgt = W.synthetic_batch(B, hw * 14, 2)[1].to(dev)
+    res = {}
+    old = ops.FUSE_CLS_UP
+    try:
+        for fuse in (False, True):
+            ops.FUSE_CLS_UP = fuse
+            m = FeatureDecoder(embed_dim=D, num_classes=2, features=feats)
+            m.load_state_dict(W.make_feature_decoder_state_dict(D, 2, features=tuple(feats)))
+            m = m.to(dev).train()
+            logits = m(x)
+            resize_softmax_dc(logits, tgt).backward()
+            res[fuse] = (logits.detach(), {k: p.grad.detach().clone() for k, p in m.named_parameters()})
+    finally:
+        ops.FUSE_CLS_UP = old
+    assert rel_l2(res[True][0], res[False][0]) < 1e-6
+    for k, gref in res[False][1].items():
+        if float(gref.abs().max()) < 1e-7:
+            continue
+        assert rel_l2(res[True][1][k], gref) < 2e-4, k
