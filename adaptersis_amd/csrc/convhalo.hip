@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_mx_kernel(const f16* __restr
   constexpr int HALO = HP * 64;                 // f16 elements of one halo chunk (64 channels)
   constexpr int WT = COUT * 64;                 // f16 elements of one tap's weights
   constexpr int NT = 256;
-  __shared__ __attribute__((aligned(16))) f16 lds[HALO + 2 * WT];
+  __shared__ __attribute__((aligned(16))) f16 lds[HALO + 3 * WT];   // one halo + a ring of three tap-weight buffers
   f16* const halo = lds;
   f16* const wbuf0 = lds + HALO;
 
@@ -92,46 +92,44 @@ __global__ __launch_bounds__(256, 2) void conv_halo_mx_kernel(const f16* __restr
       }
     }
   };
-  constexpr int WLOADS = COUT * 8 / NT;          // 2 (Cout 64) or 4 (Cout 128) pieces per thread and tap
-  uint4 wreg[WLOADS];
-  auto w_load = [&](int g, int tap) {
+  // weights: LDS-DMA, no staging registers — tap-step st = group * 9 + tap goes into ring buffer st % 3, issued TWO steps ahead of
+  // its use (a global load outlasts one tap of MFMAs).  One wave-instruction = 8 rows (output channels) x 128 bytes; the lane that
+  // fills slot s of row n fetches chunk s ^ ((n >> 1) & 7) (the image is swizzled on the source side, as in gemm_big.h).
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  typedef const __attribute__((address_space(1))) void* glb_ptr;
+  static_assert(COUT == 64, "two DMA pieces per wave and tap: 4 waves x 2 x 8 rows");
+  auto w_dma = [&](int st) {
+    const int g = st / 9, tap = st - g * 9;
     const f16* src = (g & 1) ? w_mx : w_hi;
     const int c0 = (g >> 1) * 64;
+    f16* dst = wbuf0 + (st % 3) * WT;
 #pragma unroll
-    for (int it = 0; it < WLOADS; ++it) {
-      const int idx = it * NT + tid;
-      const int n = idx >> 3, ch = idx & 7;
-      wreg[it] = *reinterpret_cast<const uint4*>(src + (int64_t)n * K9 + tap * Cin + c0 + ch * 8);
-    }
-  };
-  auto w_store = [&](int buf) {
-    f16* dst = wbuf0 + buf * WT;
-#pragma unroll
-    for (int it = 0; it < WLOADS; ++it) {
-      const int idx = it * NT + tid;
-      const int n = idx >> 3, ch = idx & 7;
-      *reinterpret_cast<uint4*>(dst + n * 64 + ((ch ^ ((n >> 1) & 7)) << 3)) = wreg[it];
+    for (int i = 0; i < 2; ++i) {
+      const int q = wid * 2 + i;
+      const int n = q * 8 + (lane >> 3), ch = (lane & 7) ^ ((n >> 1) & 7);
+      __builtin_amdgcn_global_load_lds((glb_ptr)(src + (int64_t)n * K9 + tap * Cin + c0 + ch * 8), (lds_ptr)(dst + q * 8 * 64), 16, 0, 0);
     }
   };
   auto mfma_mx = [](f32x4& a, v8i_ x, v8i_ y, int sx, int sy) {
     asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]" : "+v"(a) : "v"(x), "v"(y), "v"(sx), "v"(sy));
   };
 
+  const int nsteps = ngroups * 9;
+  w_dma(0);
+  w_dma(1);
   halo_load(0);
-  w_load(0, 0);
   halo_store();
-  w_store(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  int step = 0;                                  // running tap-step: weights of step s live in weight buffer s & 1
+  int step = 0;
   for (int g = 0; g < ngroups; ++g) {
     const bool next_group = g + 1 < ngroups;
-    if (next_group) halo_load(g + 1);            // lands under the nine taps of this group
 #pragma unroll 1
    for (int tap = 0; tap < 9; ++tap, ++step) {
-    const bool more = tap < 8 || next_group;
-    if (more) w_load(tap < 8 ? g : g + 1, tap < 8 ? tap + 1 : 0);
-    const f16* wt = wbuf0 + (step & 1) * WT;
+    if (step + 2 < nsteps) w_dma(step + 2);      // into ring buffer (step + 2) % 3, last read in step - 1
+    if (tap == 0 && next_group) halo_load(g + 1); // registers; lands under the nine taps of this group
+    const f16* wt = wbuf0 + (step % 3) * WT;
     const int ty = tap / 3, tx = tap - ty * 3;
     // A fragments: the wave's four tile rows (16 pixels each), tap-shifted inside the halo; a lane's two 16-byte chunks (k groups
     // q16 and 4 + q16) as ONE 8-register vector: the scaled fp8 MFMA takes it whole, the 16-bit MFMAs take its halves
@@ -170,7 +168,14 @@ __global__ __launch_bounds__(256, 2) void conv_halo_mx_kernel(const f16* __restr
           }
       }
     }
-    if (more) w_store((step + 1) & 1);           // buffer (step + 1) & 1 was last read in step - 1: every wave is past that sync
+    // the next step's weights (issued one step ago) must have landed: behind them this wave has issued this step's two pieces and,
+    // in tap 0 of a group that prefetches a halo, the halo's 11 register loads (tap 1 waits for those too: whatever order the
+    // compiler gave the two kinds of loads in tap 0, vmcnt(2) is then enough)
+    if (step + 1 < nsteps) {
+      if (step + 2 >= nsteps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (tap == 0 && next_group) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    }
     __syncthreads();
     if (tap == 8 && next_group) {                // every wave is done with this group's halo: overwrite it, then release the readers
       halo_store();

@@ -254,9 +254,10 @@ def conv_gemm(x_nhwc: torch.Tensor, w_packed: torch.Tensor, KH: int, KW: int, st
 
 
 _FUSED_SPLIT = os.environ.get("ASIS_GEMM_BIG", "1") != "0" and os.environ.get("ASIS_SPLIT_FUSED", "1") != "0"
-# narrow MX convolutions on the halo-tile kernel (csrc/convhalo.hip): OFF by default — its first form runs 128 -> 64 at 336^2 10 % faster
-# and 256 -> 128 at 168^2 12 % slower than the implicit-GEMM form (scripts/bench_conv_halo.py, profiles/r04_conv_halo_ab.txt)
-CONV_HALO = os.environ.get("ASIS_CONV_HALO", "0") not in ("0", "")
+# narrow MX convolutions (64 / 128 output channels) on the halo-tile kernel (csrc/convhalo.hip): 256 -> 128 at 168^2 544 vs 577 us,
+# 128 -> 64 at 336^2 540 vs 692 us against the implicit-GEMM form (scripts/bench_conv_halo.py, profiles/r04_conv_halo_ab.txt);
+# ASIS_CONV_HALO=0: implicit GEMM
+CONV_HALO = os.environ.get("ASIS_CONV_HALO", "1") not in ("0", "")
 
 
 def conv_gemm_split(x_hi, x_lo, w_hi, w_lo, KH: int, KW: int, stride: int, pad: int, *, bias_n=None, stats=None,
