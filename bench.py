@@ -454,6 +454,9 @@ def main():
                        "split_attn_out": bool(getattr(eng, "split_attn_out", False)), "precise_level": int(getattr(eng, "precise_level", config.precise_level)),
                        "fold_attn_scale": bool(config.fold_attn_scale), "fused_qkv": bool(config.fused_qkv),
                        "dead_cacnn_elided": bool(config.elide_dead_cacnn),
+                       "ln_fold": bool(config.ln_fold and config.operand_dtype == torch.float16),
+                       "mx_conv": bool(config.mx_conv_on()), "mx_dense": bool(config.mx_dense_on()),
+                       "conv_halo": bool(ops.CONV_HALO and config.mx_conv_on()), "fuse_cls_up": bool(ops.FUSE_CLS_UP),
                        "skipped_optimizer_steps": int(eng.optimizer.skipped_steps)},
         }
         if roof:
