@@ -134,6 +134,7 @@ SIGNATURES = {
     "asis_bn_finalize": [_vp, _vp, _d, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "asis_bn_eval_affine": [_vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _vp],
     "asis_bn_act": [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _i64, _i],
+    "asis_bn_act_mx": [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i64, _i],
     "asis_bn_relu_maxpool": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i],
     "asis_bn_relu_upsample": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i],
     "asis_pack_conv_weight": [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i64, _i],

@@ -22,6 +22,9 @@ from ..dinov2.layers.blocks import _Packed, _pack
 from . import _bn
 
 
+# ASIS_ENC_MX=0: the stem convolutions on three 16-bit parts (implicit GEMM) instead of MX operands on the halo-tile kernel
+_ENC_MX = __import__("os").environ.get("ASIS_ENC_MX", "1") not in ("0", "")
+
 class FeatureEncoder(_Packed):
     def __init__(self, inplanes=64, embed_dim=1024, with_cp=False):
         super().__init__()
@@ -61,7 +64,12 @@ class FeatureEncoder(_Packed):
         s, p = conv.stride[0], conv.padding[0]
         OH, OW = (H + 2 * p - 3) // s + 1, (W + 2 * p - 3) // s + 1
         stats = torch.empty((ops.gemm_tiles_m(B * OH * OW), 2, conv.out_channels), device=x16.device, dtype=torch.float32)
-        if x_lo is not None:
+        mx_in = getattr(x_lo, "_asis_mx_amax", None) if x_lo is not None else None
+        if mx_in is not None:
+            # MX operand planes (the 64 -> 64 stem convolutions at 294^2): the halo-tile kernel, BatchNorm partial sums included
+            w_mx, w_amax = _pack(self._cache, f"{key}.mx", conv.weight, lambda q: ops.pack_conv_weight_mx(q.float().contiguous(), 0, config.operand_dtype))
+            raw, stats = ops.conv3x3_halo_mx(x16, x_lo, self._wconv(key, conv), w_mx, (mx_in, w_amax), want_stats=True)
+        elif x_lo is not None:
             raw = ops.conv_gemm_split(x16, x_lo, self._wconv(key, conv), self._wconv(key, conv, 1), 3, 3, s, p, stats=stats)
         else:
             raw = ops.conv_gemm(x16, self._wconv(key, conv), 3, 3, s, p, stats=stats)
@@ -96,9 +104,17 @@ class FeatureEncoder(_Packed):
         st = self.stem
         raw = ops.conv3x3_c3(x, self._f32("stem0", st[0].weight), 2, 1)
         scale, shift, _, _, _ = _bn.finalize(ops.colstats(raw), raw.numel() // raw.shape[-1], st[1], sync_bn)
-        a = self._pair(ops.bn_act(raw, scale, shift, True, dt, sp), sp)
+        # the two 64 -> 64 stem convolutions (stride 1, pad 1, 294^2 for a 588^2 image: 77 GF each, the encoder's largest) take MX
+        # lo operands on the halo-tile kernel where that path is on: their inputs come out of bn_act in the MX form
+        def stem_act(raw, scale, shift, conv):
+            mx = (sp and _ENC_MX and config.mx_conv_on() and ops.CONV_HALO and dt == torch.float16 and conv.stride[0] == 1 and conv.padding[0] == 1 and
+                  conv.in_channels % 64 == 0 and conv.out_channels in (64, 128))
+            if mx:
+                return ops.bn_act(raw, scale, shift, True, dt, True, mx_amax=ops.bn_relu_absmax(raw, scale, shift))
+            return self._pair(ops.bn_act(raw, scale, shift, True, dt, sp), sp)
+        a = stem_act(raw, scale, shift, st[3])
         raw, scale, shift = self._conv_bn(a, "stem3", st[3], st[4], sync_bn)
-        a = self._pair(ops.bn_act(raw, scale, shift, True, dt, sp), sp)
+        a = stem_act(raw, scale, shift, st[6])
         raw, scale, shift = self._conv_bn(a, "stem6", st[6], st[7], sync_bn)
         s1 = self._pair(ops.bn_relu_maxpool(raw, scale, shift, dt, sp), sp)  # [B,147,147,C]
         raw, scale, shift = self._conv_bn(s1, "conv2", self.conv2[0], self.conv2[1], sync_bn)

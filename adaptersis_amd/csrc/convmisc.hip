@@ -165,7 +165,7 @@ __global__ void bn_eval_affine_kernel(const float* __restrict__ gamma, const flo
 template <typename T>
 __global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                                      const float* __restrict__ shift, int relu, T* __restrict__ out,
-                                                     T* __restrict__ out_lo, int64_t R, int C) {
+                                                     T* __restrict__ out_lo, int64_t R, int C, const float* __restrict__ mx_amax = nullptr) {
   const int cpt = C >> 2;
   const int64_t total = R * cpt;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -180,9 +180,9 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ x
     o.x = pack2<T>(a0, a1);
     o.y = pack2<T>(a2, a3);
     reinterpret_cast<uint2*>(out)[i] = o;
-    if (out_lo) {
-      o.x = pack2<T>(lo_part<T>(a0), lo_part<T>(a1));
-      o.y = pack2<T>(lo_part<T>(a2), lo_part<T>(a3));
+    if (out_lo) {   // rounding residuals, or their MX form (asis_common.h) when the tensor's absolute maximum is given
+      o.x = lo_word2<T>(a0, a1, mx_amax);
+      o.y = lo_word2<T>(a2, a3, mx_amax);
       reinterpret_cast<uint2*>(out_lo)[i] = o;
     }
   }
@@ -645,8 +645,8 @@ extern "C" int asis_bn_eval_affine(void* stream, const float* gamma, const float
   return ASIS_OK;
 }
 
-extern "C" int asis_bn_act(void* stream, int dtype, const float* x, const float* scale, const float* shift, int relu,
-                           void* out, void* out_lo, int64_t R, int C) {
+static int bn_act_impl(void* stream, int dtype, const float* x, const float* scale, const float* shift, int relu, void* out, void* out_lo,
+                       const float* mx_amax, int64_t R, int C) {
   ASIS_REQUIRE(x && scale && shift && out, "asis_bn_act: null pointer");
   ASIS_REQUIRE(C % 4 == 0 && C > 0, "asis_bn_act: C=%d must be a multiple of 4", C);
   DT_OK(dtype, "asis_bn_act");
@@ -654,12 +654,21 @@ extern "C" int asis_bn_act(void* stream, int dtype, const float* x, const float*
   const int64_t total = R * (C / 4);
   if (dtype == ASIS_F16)
     hipLaunchKernelGGL((bn_act_kernel<f16>), dim3(grid_for(total)), dim3(256), 0, s, x, scale, shift, relu,
-                       reinterpret_cast<f16*>(out), reinterpret_cast<f16*>(out_lo), R, C);
+                       reinterpret_cast<f16*>(out), reinterpret_cast<f16*>(out_lo), R, C, mx_amax);
   else
     hipLaunchKernelGGL((bn_act_kernel<bf16>), dim3(grid_for(total)), dim3(256), 0, s, x, scale, shift, relu,
-                       reinterpret_cast<bf16*>(out), reinterpret_cast<bf16*>(out_lo), R, C);
+                       reinterpret_cast<bf16*>(out), reinterpret_cast<bf16*>(out_lo), R, C, mx_amax);
   ASIS_CHECK_LAUNCH("asis_bn_act");
   return ASIS_OK;
+}
+extern "C" int asis_bn_act(void* stream, int dtype, const float* x, const float* scale, const float* shift, int relu,
+                           void* out, void* out_lo, int64_t R, int C) {
+  return bn_act_impl(stream, dtype, x, scale, shift, relu, out, out_lo, nullptr, R, C);
+}
+extern "C" int asis_bn_act_mx(void* stream, int dtype, const float* x, const float* scale, const float* shift, int relu, void* out,
+                              void* out_mx, const float* amax, int64_t R, int C) {
+  ASIS_REQUIRE(out_mx && amax, "asis_bn_act_mx: null pointer");
+  return bn_act_impl(stream, dtype, x, scale, shift, relu, out, out_mx, amax, R, C);
 }
 
 extern "C" int asis_bn_relu_maxpool(void* stream, int dtype, const float* x, const float* scale, const float* shift,

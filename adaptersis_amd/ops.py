@@ -859,12 +859,18 @@ def bn_eval_affine(bn) -> tuple:
     return out[0], out[1]
 
 
-def bn_act(x: torch.Tensor, scale, shift, relu: bool, dtype: torch.dtype, split: bool = False):
-    """-> out (and (out, out_lo) when split: the two halves of a split-precision operand)."""
-    _dev(x, scale, shift)
+def bn_act(x: torch.Tensor, scale, shift, relu: bool, dtype: torch.dtype, split: bool = False, mx_amax: Optional[torch.Tensor] = None):
+    """-> out (and (out, out_lo) when split: the two halves of a split-precision operand).  ``mx_amax`` (device float, the output's
+    absolute maximum: ``bn_relu_absmax``): the lo half in the MX form, tagged ``_asis_mx_amax`` for the consuming convolution."""
+    _dev(x, scale, shift, mx_amax)
     Cc = x.shape[-1]
     out = torch.empty(x.shape, device=x.device, dtype=dtype)
     lo = _lo(out, split)
+    if mx_amax is not None and split:
+        check(lib().asis_bn_act_mx(_stream(), _dt(dtype), _f32c(x).data_ptr(), scale.data_ptr(), shift.data_ptr(), int(relu),
+                                   out.data_ptr(), lo.data_ptr(), mx_amax.data_ptr(), x.numel() // Cc, Cc), "asis_bn_act_mx")
+        lo._asis_mx_amax = mx_amax
+        return out, lo
     check(lib().asis_bn_act(_stream(), _dt(dtype), _f32c(x).data_ptr(), scale.data_ptr(), shift.data_ptr(), int(relu),
                             out.data_ptr(), _p(lo), x.numel() // Cc, Cc), "asis_bn_act")
     return (out, lo) if split else out

@@ -415,6 +415,10 @@ int asis_bn_eval_affine(void* stream, const float* gamma, const float* beta, con
  * also writes out_lo (NULL = skip): the rounding residual of out, second half of a split operand. */
 int asis_bn_act(void* stream, int dtype, const float* x, const float* scale, const float* shift, int relu, void* out,
                 void* out_lo, int64_t R, int C);
+/* the same with the lo output in the MX form (asis_gemm_desc.mx_amax_a / asis_conv3x3_halo_mx); amax = device float, the tensor's
+ * absolute maximum (asis_bn_relu_absmax) */
+int asis_bn_act_mx(void* stream, int dtype, const float* x, const float* scale, const float* shift, int relu, void* out, void* out_mx,
+                   const float* amax, int64_t R, int C);
 /* BN + ReLU + MaxPool2d(3, stride 2, pad 1): x fp32 NHWC [B,H,W,C] -> 16-bit [B,OH,OW,C] (encoders.py:19) */
 int asis_bn_relu_maxpool(void* stream, int dtype, const float* x, const float* scale, const float* shift, void* out,
                          void* out_lo, int B, int H, int W, int C);
