@@ -175,6 +175,8 @@ SIGNATURES = {
     "asis_dilate2": [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i],
     "asis_upsample_bn_relu_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i],
     "asis_bn_bwd_apply": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _vp, _vp, _vp, _i64, _i],
+    "asis_bn_bwd_apply_mx": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _vp, _vp, _vp, _vp, _i64, _i],
+    "asis_bn_bwd_absmax": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _vp, _i64, _i],
     "asis_wgrad_splits": [_i64, _i, _i],
     "asis_wgrad": [_vp, C.POINTER(WgradDesc)],
     "asis_sgd_momentum": [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i],

@@ -29,6 +29,10 @@ from ..dinov2.layers.blocks import _Packed, _pack
 from . import _bn
 
 
+# ASIS_DGRAD_MX=0: the decoder's input-gradient convolutions on three 16-bit parts instead of 16-bit + one MX pass
+_DGRAD_MX = __import__("os").environ.get("ASIS_DGRAD_MX", "1") not in ("0", "")
+
+
 class _Stage:
     """Saved tensors of one conv -> BN -> ReLU -> upsample stage."""
     __slots__ = ("x16", "raw", "scale", "shift", "mean", "invstd", "count", "factor", "stride", "pad", "pool")
@@ -176,8 +180,11 @@ def conv_bn_relu_up_backward(owner: _Packed, key: str, st: _Stage, dU, conv: nn.
         dist.all_reduce(red)
     dbeta_s, dgamma_s = red[:C], red[C:]
     split = config.split_conv and need_dx
+    # the input-gradient convolution of a stride-1 stage takes dx's lo half in the MX form (its two correction terms as one fp8 pass)
+    P_ = st.raw.numel() // C
+    mx_bwd = bool(split and stride == 1 and _DGRAD_MX and config.mx_conv_on() and ops.mx_conv_ok(P_, C, conv.in_channels))
     r = ops.bn_bwd_apply(g, st.raw, st.mean, st.invstd, owner._f32(key + ".g", bn.weight), dgamma_s, dbeta_s,
-                         st.count, dt, split)
+                         st.count, dt, split, mx=mx_bwd)
     dx16, dx_lo, bpart = r if split else (r[0], None, r[1])
     ops.reduce_rows(local[:C].view(1, C), inv_scale, grads[bn_name + ".bias"])      # unscale (n = 1 row)
     ops.reduce_rows(local[C:].view(1, C), inv_scale, grads[bn_name + ".weight"])
@@ -204,6 +211,10 @@ def _dgrad(owner: _Packed, key: str, conv: nn.Conv2d, d16, d_lo, pad: int = 1):
     wd = _pack(owner._cache, key + ".wd", conv.weight, lambda p: ops.pack_conv_weight(p.float().contiguous(), 1, dt))
     if d_lo is None:
         return ops.conv_gemm(d16, wd, 3, 3, 1, pad)
+    mx_in = getattr(d_lo, "_asis_mx_amax", None)
+    if mx_in is not None:
+        wd_mx, w_amax = _pack(owner._cache, key + ".wdmx", conv.weight, lambda p: ops.pack_conv_weight_mx(p.float().contiguous(), 1, dt))
+        return ops.conv_gemm_split(d16, d_lo, wd, wd_mx, 3, 3, 1, pad, mx=(mx_in, w_amax))
     wd_lo = _pack(owner._cache, key + ".wdlo", conv.weight,
                   lambda p: ops.pack_conv_weight(p.float().contiguous(), 1, dt, 1))
     return ops.conv_gemm_split(d16, d_lo, wd, wd_lo, 3, 3, 1, pad)

@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ gamma, const float* __restrict__ dgamma,
                                                            const float* __restrict__ dbeta, float inv_n, T* __restrict__ out,
                                                            T* __restrict__ out_lo, float* __restrict__ partial, int64_t R,
-                                                           int C, int CW, int RW) {
+                                                           int C, int CW, int RW, const float* __restrict__ mx_amax = nullptr) {
   __shared__ float red[256 * 4];
   const int cpt = C >> 2;
   const int cx = threadIdx.x % CW, ry = threadIdx.x / CW;
@@ -288,9 +288,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     pk.x = pack2<T>(o.x, o.y);
     pk.y = pack2<T>(o.z, o.w);
     reinterpret_cast<uint2*>(out)[i] = pk;
-    if (out_lo) {
-      pk.x = pack2<T>(lo_part<T>(o.x), lo_part<T>(o.y));
-      pk.y = pack2<T>(lo_part<T>(o.z), lo_part<T>(o.w));
+    if (out_lo) {   // rounding residuals, or their MX form (asis_common.h) when the tensor's absolute maximum is given
+      pk.x = lo_word2<T>(o.x, o.y, mx_amax);
+      pk.y = lo_word2<T>(o.z, o.w, mx_amax);
       reinterpret_cast<uint2*>(out_lo)[i] = pk;
     }
     s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
@@ -303,6 +303,41 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
       s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
     }
     reinterpret_cast<float4*>(partial + (int64_t)blockIdx.x * C)[c] = s;
+  }
+}
+
+// max |dx| of the same expression (nothing written): the per-tensor scale of dx's MX form (asis_bn_bwd_apply_mx), one atomic per block
+__global__ __launch_bounds__(256) void bn_bwd_absmax_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                            const float* __restrict__ gamma, const float* __restrict__ dgamma,
+                                                            const float* __restrict__ dbeta, float inv_n, float* __restrict__ amax, int64_t R,
+                                                            int C, int CW, int RW) {
+  __shared__ float red[4];
+  const int cpt = C >> 2;
+  const int cx = threadIdx.x % CW, ry = threadIdx.x / CW;
+  const int c = blockIdx.y * CW + cx;
+  const bool live = c < cpt;
+  const int cc = live ? c : 0;
+  const float4 mu = reinterpret_cast<const float4*>(mean)[cc], is = reinterpret_cast<const float4*>(invstd)[cc];
+  const float4 ga = reinterpret_cast<const float4*>(gamma)[cc];
+  const float4 dg = reinterpret_cast<const float4*>(dgamma)[cc], db = reinterpret_cast<const float4*>(dbeta)[cc];
+  float m = 0.f;
+  for (int64_t row = (int64_t)blockIdx.x * RW + ry; live && row < R; row += (int64_t)gridDim.x * RW) {
+    const int64_t i = row * cpt + c;
+    const float4 gv = reinterpret_cast<const float4*>(g)[i], xv = reinterpret_cast<const float4*>(x)[i];
+    const float o0 = ga.x * is.x * (gv.x - db.x * inv_n - (xv.x - mu.x) * is.x * dg.x * inv_n);
+    const float o1 = ga.y * is.y * (gv.y - db.y * inv_n - (xv.y - mu.y) * is.y * dg.y * inv_n);
+    const float o2 = ga.z * is.z * (gv.z - db.z * inv_n - (xv.z - mu.z) * is.z * dg.z * inv_n);
+    const float o3 = ga.w * is.w * (gv.w - db.w * inv_n - (xv.w - mu.w) * is.w * dg.w * inv_n);
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(o0), fabsf(o1))), fmaxf(fabsf(o2), fabsf(o3)));
+  }
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int nw = (blockDim.x + 63) >> 6;
+    for (int w = 1; w < nw; ++w) m = fmaxf(m, red[w]);
+    if (m > 0.f) atomicMax(reinterpret_cast<unsigned int*>(amax), __builtin_bit_cast(unsigned int, m));
   }
 }
 
@@ -430,9 +465,9 @@ extern "C" int asis_dilate2(void* stream, int dtype, const void* in, const void*
   return ASIS_OK;
 }
 
-extern "C" int asis_bn_bwd_apply(void* stream, int dtype, const float* g, const float* x, const float* mean,
-                                 const float* invstd, const float* gamma, const float* dgamma, const float* dbeta,
-                                 double count, void* out, void* out_lo, float* partial, int64_t R, int C) {
+static int bn_bwd_apply_impl(void* stream, int dtype, const float* g, const float* x, const float* mean, const float* invstd,
+                             const float* gamma, const float* dgamma, const float* dbeta, double count, void* out, void* out_lo,
+                             const float* mx_amax, float* partial, int64_t R, int C) {
   ASIS_REQUIRE(g && x && mean && invstd && gamma && dgamma && dbeta && out && partial, "asis_bn_bwd_apply: null pointer");
   ASIS_REQUIRE(C % 4 == 0 && C >= 4, "asis_bn_bwd_apply: C=%d must be a positive multiple of 4", C);
   ASIS_REQUIRE(dtype == ASIS_F16 || dtype == ASIS_BF16, "asis_bn_bwd_apply: bad dtype %d", dtype);
@@ -443,11 +478,39 @@ extern "C" int asis_bn_bwd_apply(void* stream, int dtype, const float* g, const 
   const int nblk = asis_bn_bwd_nblk(R, C);
   if (dtype == ASIS_F16)
     hipLaunchKernelGGL((bn_bwd_apply_kernel<f16>), dim3(nblk, tiles), dim3(CW * RW), 0, s, g, x, mean, invstd, gamma, dgamma,
-                       dbeta, inv_n, reinterpret_cast<f16*>(out), reinterpret_cast<f16*>(out_lo), partial, R, C, CW, RW);
+                       dbeta, inv_n, reinterpret_cast<f16*>(out), reinterpret_cast<f16*>(out_lo), partial, R, C, CW, RW, mx_amax);
   else
     hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16>), dim3(nblk, tiles), dim3(CW * RW), 0, s, g, x, mean, invstd, gamma, dgamma,
-                       dbeta, inv_n, reinterpret_cast<bf16*>(out), reinterpret_cast<bf16*>(out_lo), partial, R, C, CW, RW);
+                       dbeta, inv_n, reinterpret_cast<bf16*>(out), reinterpret_cast<bf16*>(out_lo), partial, R, C, CW, RW, mx_amax);
   ASIS_CHECK_LAUNCH("asis_bn_bwd_apply");
+  return ASIS_OK;
+}
+extern "C" int asis_bn_bwd_apply(void* stream, int dtype, const float* g, const float* x, const float* mean,
+                                 const float* invstd, const float* gamma, const float* dgamma, const float* dbeta,
+                                 double count, void* out, void* out_lo, float* partial, int64_t R, int C) {
+  return bn_bwd_apply_impl(stream, dtype, g, x, mean, invstd, gamma, dgamma, dbeta, count, out, out_lo, nullptr, partial, R, C);
+}
+extern "C" int asis_bn_bwd_apply_mx(void* stream, int dtype, const float* g, const float* x, const float* mean, const float* invstd,
+                                    const float* gamma, const float* dgamma, const float* dbeta, double count, void* out, void* out_mx,
+                                    const float* amax, float* partial, int64_t R, int C) {
+  ASIS_REQUIRE(out_mx && amax, "asis_bn_bwd_apply_mx: null pointer");
+  return bn_bwd_apply_impl(stream, dtype, g, x, mean, invstd, gamma, dgamma, dbeta, count, out, out_mx, amax, partial, R, C);
+}
+extern "C" int asis_bn_bwd_absmax(void* stream, const float* g, const float* x, const float* mean, const float* invstd, const float* gamma,
+                                  const float* dgamma, const float* dbeta, double count, float* amax, int64_t R, int C) {
+  ASIS_REQUIRE(g && x && mean && invstd && gamma && dgamma && dbeta && amax, "asis_bn_bwd_absmax: null pointer");
+  ASIS_REQUIRE(C % 4 == 0 && C >= 4, "asis_bn_bwd_absmax: C=%d must be a positive multiple of 4", C);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  ASIS_REQUIRE(hipMemsetAsync(amax, 0, sizeof(float), s) == hipSuccess, "asis_bn_bwd_absmax: memset failed");
+  if (R == 0) return ASIS_OK;
+  const float inv_n = (float)(1.0 / count);
+  int CW, RW, tiles;
+  bn_bwd_shape(C, &CW, &RW, &tiles);
+  int nblk = asis_bn_bwd_nblk(R, C);
+  if (nblk * tiles > 2048) nblk = 2048 / tiles > 0 ? 2048 / tiles : 1;     // one atomic per block: keep their number small
+  hipLaunchKernelGGL(bn_bwd_absmax_kernel, dim3(nblk, tiles), dim3(CW * RW), 0, s, g, x, mean, invstd, gamma, dgamma, dbeta, inv_n, amax,
+                     R, C, CW, RW);
+  ASIS_CHECK_LAUNCH("asis_bn_bwd_absmax");
   return ASIS_OK;
 }
 

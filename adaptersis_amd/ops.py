@@ -1368,8 +1368,9 @@ def dilate2(x: torch.Tensor, x_lo: Optional[torch.Tensor], Hd: int, Wd: int):
 
 
 def bn_bwd_apply(g: torch.Tensor, x: torch.Tensor, mean, invstd, gamma, dgamma, dbeta, count: float,
-                 dtype: torch.dtype, split: bool = False):
-    """-> (dx 16-bit same shape as x, [dx_lo when split,] partial [nblk, C] column sums of dx)."""
+                 dtype: torch.dtype, split: bool = False, mx: bool = False):
+    """-> (dx 16-bit same shape as x, [dx_lo when split,] partial [nblk, C] column sums of dx).  ``mx`` (with ``split``): dx_lo in
+    the MX form, scaled by max |dx| from one extra pass over g and x (asis_bn_bwd_absmax), tagged ``_asis_mx_amax``."""
     _dev(g, x)
     Cc = x.shape[-1]
     R = x.numel() // Cc
@@ -1377,9 +1378,16 @@ def bn_bwd_apply(g: torch.Tensor, x: torch.Tensor, mean, invstd, gamma, dgamma, 
     out = torch.empty(x.shape, device=x.device, dtype=dtype)
     partial = torch.empty((nblk, Cc), device=x.device, dtype=torch.float32)
     lo = _lo(out, split)
-    check(lib().asis_bn_bwd_apply(_stream(), _dt(dtype), _f32c(g).data_ptr(), _f32c(x).data_ptr(), mean.data_ptr(),
-                                  invstd.data_ptr(), _f32c(gamma).data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
-                                  float(count), out.data_ptr(), _p(lo), partial.data_ptr(), R, Cc), "asis_bn_bwd_apply")
+    args = (_f32c(g).data_ptr(), _f32c(x).data_ptr(), mean.data_ptr(), invstd.data_ptr(), _f32c(gamma).data_ptr(), dgamma.data_ptr(),
+            dbeta.data_ptr(), float(count))
+    if mx and split:
+        amax = torch.empty(1, device=x.device, dtype=torch.float32)
+        check(lib().asis_bn_bwd_absmax(_stream(), *args, amax.data_ptr(), R, Cc), "asis_bn_bwd_absmax")
+        check(lib().asis_bn_bwd_apply_mx(_stream(), _dt(dtype), *args, out.data_ptr(), lo.data_ptr(), amax.data_ptr(), partial.data_ptr(),
+                                         R, Cc), "asis_bn_bwd_apply_mx")
+        lo._asis_mx_amax = amax
+        return out, lo, partial
+    check(lib().asis_bn_bwd_apply(_stream(), _dt(dtype), *args, out.data_ptr(), _p(lo), partial.data_ptr(), R, Cc), "asis_bn_bwd_apply")
     return (out, lo, partial) if split else (out, partial)
 
 

@@ -597,6 +597,13 @@ int asis_dilate2(void* stream, int dtype, const void* in, const void* in_lo, voi
 int asis_bn_bwd_apply(void* stream, int dtype, const float* g, const float* x, const float* mean, const float* invstd,
                       const float* gamma, const float* dgamma, const float* dbeta, double count, void* out,
                       void* out_lo, float* partial, int64_t R, int C);
+/* the same with dx's lo output in the MX form (asis_gemm_desc.mx_amax_a: the input-gradient convolution then runs its two correction
+ * terms as one block-scaled fp8 pass); amax = max |dx| from asis_bn_bwd_absmax (the same expression, nothing written) */
+int asis_bn_bwd_apply_mx(void* stream, int dtype, const float* g, const float* x, const float* mean, const float* invstd,
+                         const float* gamma, const float* dgamma, const float* dbeta, double count, void* out, void* out_mx,
+                         const float* amax, float* partial, int64_t R, int C);
+int asis_bn_bwd_absmax(void* stream, const float* g, const float* x, const float* mean, const float* invstd, const float* gamma,
+                       const float* dgamma, const float* dbeta, double count, float* amax, int64_t R, int C);
 
 /* Weight gradient dW[Cout,Cin,KH,KW] = sum_p dy[p,co] * x[b, oh*s+kh-pad, ow*s+kw-pad, ci]
  * (conv2d; KH=KW=1 gives the nn.Linear weight grad).  dy 16-bit [P, ld_dy] with CoP (multiple of 8)
