@@ -143,6 +143,9 @@ def conv_bn_relu_up_forward(owner: _Packed, key: str, x16, x_lo, conv: nn.Conv2d
         up = ops.bn_relu_upsample(raw, scale, shift, factor, dt, True, mx_amax=ops.bn_relu_absmax(raw, scale, shift))
     elif factor > 1:
         up = ops.bn_relu_upsample(raw, scale, shift, factor, dt, split_out)
+    elif mx_out and split_out:
+        # factor 1 (UNet DoubleConv: conv -> BN -> ReLU -> conv): the same for the plain BatchNorm + ReLU
+        up = ops.bn_act(raw, scale, shift, True, dt, True, mx_amax=ops.bn_relu_absmax(raw, scale, shift))
     else:
         up = ops.bn_act(raw, scale, shift, True, dt, split_out)
     if not split_out and not defer_up:

@@ -104,7 +104,10 @@ class UNet(_Packed):
     # ---- building blocks ---------------------------------------------------------------------------------------
     def _dconv_fwd(self, key: str, dc: DoubleConv, a, save: bool, training: bool):
         seq = dc.double_conv
-        a, s1 = conv_bn_relu_up_forward(self, key + "a", a[0], a[1], seq[0], seq[1], 1, self.sync_bn, save, training)
+        # the first conv's BatchNorm + ReLU output feeds the second 3x3 conv only: its lo half in the MX form where that conv can take it
+        Bq, Hq, Wq, _ = a[0].shape
+        mx_mid = bool(config.mx_conv_on() and a[1] is not None and ops.mx_conv_ok(Bq * Hq * Wq, seq[3].in_channels, seq[3].out_channels))
+        a, s1 = conv_bn_relu_up_forward(self, key + "a", a[0], a[1], seq[0], seq[1], 1, self.sync_bn, save, training, mx_out=mx_mid)
         a, s2 = conv_bn_relu_up_forward(self, key + "b", a[0], a[1], seq[3], seq[4], 1, self.sync_bn, save, training)
         return a, (s1, s2)
 
