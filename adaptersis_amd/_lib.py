@@ -101,6 +101,8 @@ SIGNATURES = {
     "asis_transpose_tokens": [_vp, _i, _vp, _i64, _vp, _i64, _i, _i, _i],
     "asis_attention_bwd": [_vp, _i, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp,
                            _i64, _i, _i, _i, _f],
+    "asis_attention_bwd_rows": [_vp, _i, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i,
+                                _i, _f],
     "asis_msda_bwd": [_vp, _i, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i],
     "asis_msda_vgrad_cap": [_i, _i, _i],
     "asis_msda_value_grad": [_vp, _i, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i],

@@ -45,7 +45,7 @@ def _deps_mtime() -> float:
 # per-file additions to FLAGS
 # attention.hip: beside MFMAs a packed f32 op costs several single ones (MI355X_MICROARCH.md): keep the softmax arithmetic of the
 # folded kernel unpacked
-FILE_FLAGS = {"attention.hip": ("-fno-slp-vectorize",)}
+FILE_FLAGS = {"attention.hip": ("-fno-slp-vectorize",), "attn_bwd_pipe.hip": ("-fno-slp-vectorize",)}
 
 
 def _compile(src: str, verbose: bool) -> str:

@@ -540,6 +540,8 @@ extern "C" int asis_gemm(void* stream, const asis_gemm_desc* dp) {
   if (d.C_lo) ASIS_REQUIRE(!d.out_f32 && (reinterpret_cast<uintptr_t>(d.C_lo) & 7) == 0, "asis_gemm: C_lo is the second plane of a 16-bit output");
   if (d.ln_mr) ASIS_REQUIRE(d.ln_cs && (reinterpret_cast<uintptr_t>(d.ln_mr) & 7) == 0 && asis_aligned16(d.ln_cs), "asis_gemm: ln_mr needs ln_cs (16-byte aligned)");
   if (d.rowstats) ASIS_REQUIRE(d.batch == 1 && (reinterpret_cast<uintptr_t>(d.rowstats) & 7) == 0, "asis_gemm: rowstats need batch == 1");
+  // the row statistics are per 64-column group ([M, N / 64, 2]): a ragged last group would need its own count in the finalizer
+  if (d.rowstats) ASIS_REQUIRE(d.N % 64 == 0, "asis_gemm: rowstats need N %% 64 == 0 (N = %d)", (int)d.N);
   const int64_t tiles = (int64_t)asis_cdiv(d.M, BM) * asis_cdiv(d.N, BN);
   ASIS_REQUIRE(tiles < (1ll << 31), "asis_gemm: too many tiles");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);

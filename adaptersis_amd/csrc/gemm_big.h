@@ -787,7 +787,8 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_big_kernel(const asis_
           if (rstats) {   // wave-uniform; the 8 lanes of half a DPP row hold the 64 columns of one output row
             st_s = row8_sum(st_s);
             st_q = row8_sum(st_q);
-            if (c8 == 0 && row < d.M) *reinterpret_cast<float2*>(rstats + ((int64_t)row * sgroups + sgrp) * 2) = make_float2(st_s, st_q);
+            // sgrp < sgroups: a 256-column tile that overhangs N (N % 256 != 0) holds wave column groups past the last 64-column group
+            if (c8 == 0 && row < d.M && sgrp < sgroups) *reinterpret_cast<float2*>(rstats + ((int64_t)row * sgroups + sgrp) * 2) = make_float2(st_s, st_q);
           }
         }
       }

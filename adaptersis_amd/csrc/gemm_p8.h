@@ -524,7 +524,7 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(const asis_gemm_desc d,
             if (rstats) {   // wave-uniform; the 16 lanes of a DPP row hold the 64 columns of one output row
               st_s = row16_sum(st_s);
               st_q = row16_sum(st_q);
-              if (ch == 0 && row < d.M)
+              if (ch == 0 && row < d.M && sgrp < sgroups)   // tiles that overhang N: no group past the last one
                 *reinterpret_cast<float2*>(rstats + ((int64_t)row * sgroups + sgrp) * 2) = make_float2(st_s, st_q);
             }
           }

@@ -492,6 +492,32 @@ def attention_bwd(q, k, v, qt, kt, dot, o, dO, lse, B: int, H: int, N: int, scal
     return dqkv
 
 
+def attention_bwd_rows(q, k, v, o, dO, lse, segs, H: int, scale: float, dqkv: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """-> dqkv 16-bit [R, 3*H*64] = [dQ | dK | dV] for one or two stacked token batches ``segs`` = [(B1, N1)] or
+    [(B1, N1), (B2, N2)] (rows of batch 2 behind batch 1 in every operand).  q, k, v: [R, H*64] views with one row stride
+    (the three column blocks of the qkv projection); o, dO: [R, H*64]; lse: fp32, the forward's log-sum-exp of each batch
+    ([B1, H, N1] then [B2, H, N2]) in one contiguous buffer.  No transposed operands (csrc/attn_bwd_pipe.hip)."""
+    _dev(q, k, v, o, dO, lse, dqkv)
+    Wd = H * 64
+    if len(segs) not in (1, 2):
+        raise ValueError("attention_bwd_rows: one or two stacked token batches")
+    (B1, N1), (B2, N2) = segs[0], (segs[1] if len(segs) == 2 else (0, 0))
+    R = B1 * N1 + B2 * N2
+    if not (q.stride(0) == k.stride(0) == v.stride(0)) or q.stride(1) != 1 or q.shape[0] != R:
+        raise ValueError("attention_bwd_rows: q, k, v must be [R, H*64] views sharing a row stride")
+    if lse.dtype != torch.float32 or not lse.is_contiguous() or lse.numel() != R * H:
+        raise ValueError("attention_bwd_rows: lse must be one contiguous float32 buffer of R * H values")
+    if dqkv is None:
+        dqkv = torch.empty((R, 3 * Wd), device=q.device, dtype=q.dtype)
+    D = torch.empty(R * H, device=q.device, dtype=torch.float32)
+    es = dqkv.element_size()
+    check(lib().asis_attention_bwd_rows(_stream(), _dt(q.dtype), q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0),
+                                        o.data_ptr(), o.stride(0), dO.data_ptr(), dO.stride(0), lse.data_ptr(), D.data_ptr(),
+                                        dqkv.data_ptr(), dqkv.data_ptr() + Wd * es, dqkv.data_ptr() + 2 * Wd * es,
+                                        dqkv.stride(0), B1, N1, B2, N2, H, float(scale)), "asis_attention_bwd_rows")
+    return dqkv
+
+
 def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, w: torch.Tensor, eps: float = 1e-6,
                   res: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
     """fp32 [R, D] row views -> (dx = res + LN^T(dy), partial fp32 [nblk, 2, D] = (d weight, d bias) sums)."""

@@ -287,11 +287,26 @@ def train(model, feature_model, backbone_encoder, cross_vit, cross_cnn, seg_deco
     return {k: meter.global_avg for k, meter in metric_logger.meters.items()}
 
 
+def _val_meters():
+    """The validation MetricLogger with its three meters created up front, in a fixed order, on EVERY rank: with ``--shard_val``
+    a rank whose shard is empty (fewer batches than ranks) must issue the same barrier + all-reduce per meter in
+    ``synchronize_between_processes`` as the others, or the job hangs; the summary line reads all three."""
+    ml = utils.MetricLogger(delimiter="  ")
+    for name in ("loss", "acc1", "dice"):
+        ml.meters[name]
+    return ml
+
+
+def _val_summary(metric_logger) -> str:
+    return "* Acc@1 {top1.global_avg:.3f} loss {losses.global_avg:.3f} Dice {dice.global_avg:.3f}".format(
+        top1=metric_logger.acc1, losses=metric_logger.loss, dice=metric_logger.meters["dice"])
+
+
 @torch.no_grad()
 def validate_network(val_loader, model, feature_model, backbone_encoder, cross_vit, cross_cnn, seg_decoder, n, avgpool):
     """`train.py:448-651`: weighted CE ([0.1, 10]), dice = 1 - DC(logits), pixel accuracy; decoder in eval mode."""
     engine = _engine_for(model, backbone_encoder, cross_vit, cross_cnn, seg_decoder)
-    metric_logger = utils.MetricLogger(delimiter="  ")
+    metric_logger = _val_meters()
     wt = torch.tensor([0.1, 10.0], device=next(seg_decoder.parameters()).device)
     sharded = isinstance(getattr(val_loader, "batch_sampler", None), BatchShardSampler)
     with (parallel.local_batchnorm() if sharded else contextlib.nullcontext()):
@@ -305,8 +320,7 @@ def validate_network(val_loader, model, feature_model, backbone_encoder, cross_v
             metric_logger.meters["dice"].update(1.0 - float(dloss), n=bs)
     if sharded:   # per-rank sums -> the whole-set averages every rank of the reference computes redundantly
         metric_logger.synchronize_between_processes()
-    print("* Acc@1 {top1.global_avg:.3f} loss {losses.global_avg:.3f} Dice {dice.global_avg:.3f}".format(
-        top1=metric_logger.acc1, losses=metric_logger.loss, dice=metric_logger.meters["dice"]))
+    print(_val_summary(metric_logger))
     return {k: meter.global_avg for k, meter in metric_logger.meters.items()}
 
 

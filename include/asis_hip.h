@@ -252,6 +252,14 @@ int asis_attention_bwd(void* stream, int dtype, const void* q, const void* k, co
                        const void* kt, const void* dot, int64_t ldt, const void* o, int64_t ldo, const void* dO,
                        int64_t lddo, const float* lse2, float* D, void* dq, void* dk, void* dv, int64_t lddq, int B,
                        int H, int N, float scale);
+/* The same backward on row-major operands only (round 5): no transposed images — the products that reduce over the token
+ * index read the row-major K / Q / dO tiles through transposing LDS reads — and two stacked token batches per launch, laid
+ * out as in asis_attention_fwd_split: B1 images of N1 tokens followed by B2 images of N2 tokens (B2 = 0: one batch) in
+ * every [tokens, *] operand; lse2 and the scratch D are [B1, H, N1] followed by [B2, H, N2] (D receives -scale * rowsum(dO * O),
+ * the initial accumulator of the dP chains).  Pipelined LDS-DMA kernels (csrc/attn_bwd_pipe.hip); bit-reproducible. */
+int asis_attention_bwd_rows(void* stream, int dtype, const void* q, const void* k, const void* v, int64_t ld, const void* o,
+                            int64_t ldo, const void* dO, int64_t lddo, const float* lse2, float* D, void* dq, void* dk,
+                            void* dv, int64_t lddq, int B1, int N1, int B2, int N2, int H, float scale);
 
 /* ---------------------------------------------------------------------------------------------
  * Patch-embed im2col (patch_embed.py:75: Conv2d k=s=P) : img fp32 NCHW [B,3,Himg,Wimg] ->

@@ -840,7 +840,7 @@ def ref_unet_wide(R, C, n_classes):
     return UNetWide()
 
 
-def c2_case(R, out, arch="vit_base_d4", batch=2, tag="c2", mode="kernel"):
+def c2_case(R, out, arch="vit_base_d4", batch=2, tag="c2", mode="kernel", forward_only=False):
     """BASELINE config 2 at full WIDTH (ViT-B: D = 768, 12 heads, MSDA head dim 96; depth reduced to 4 blocks), 588x588,
     batch 2: `train.py:275-387` adapter flow with the imported reference ViT / FeatureEncoder / CAViT / CACNN at dim 768,
     adapter-stream map -> UNet(768) assembled from the reference's own parts -> resize -> CE + DC(2)
@@ -856,6 +856,19 @@ def c2_case(R, out, arch="vit_base_d4", batch=2, tag="c2", mode="kernel"):
     with torch.no_grad():
         x, xs, c, c4, outs = _ref_adapter_stream(R, model, enc, cv, cn, inp)
         xm = x.transpose(1, 2).reshape(batch, D, 42, 42)
+    if forward_only:
+        # the bench batch (B = 12): forward + loss of the reference modules under no_grad (no value changes), sub-sampled;
+        # no oracle re-run (the oracle is pinned at B = 1 and 2) — as ``step_case(forward_only=True)``
+        with torch.no_grad():
+            y = u(xm)
+            o = F.interpolate(y, size=(588, 588), mode="bilinear")
+            loss = torch.nn.CrossEntropyLoss()(o, target) + R["DC"](2)(o, O.one_hot(target, 2))
+        out[f"{tag}.x_final"] = sub(x)
+        out[f"{tag}.c_final"] = sub(c)
+        out[f"{tag}.logits"] = sub(y, 60000)
+        out[f"{tag}.loss"] = loss.detach().clone()
+        print(f"  {tag}: loss {float(loss):.6f}")
+        return
     y = u(xm)
     o = F.interpolate(y, size=(588, 588), mode="bilinear")
     loss = torch.nn.CrossEntropyLoss()(o, target) + R["DC"](2)(o, O.one_hot(target, 2))
@@ -883,7 +896,7 @@ def c2_case(R, out, arch="vit_base_d4", batch=2, tag="c2", mode="kernel"):
         out[f"{tag}.grad.{k}"] = sub(p.grad, 3000)
 
 
-def c5_case(R, out, arch="vit_giant2_d4", batch=2, tag="c5", ncls=11, mode="kernel"):
+def c5_case(R, out, arch="vit_giant2_d4", batch=2, tag="c5", ncls=11, mode="kernel", forward_only=False):
     """BASELINE config 5 at full WIDTH (ViT-g: D = 1536, 24 heads, SwiGLU 8192 -> 4096, MSDA head dim 192; 4 blocks),
     588x588, batch 2, 11 classes: `train_mla.py:266-383` flow with the imported reference modules, the reference DecoderMLA
     with its classifier conv re-made for 11 classes (`decoders.py:59` forces 2), softmax -> the reference's
@@ -898,7 +911,8 @@ def c5_case(R, out, arch="vit_giant2_d4", batch=2, tag="c5", ncls=11, mode="kern
     dec.train()
     inp, target = W.synthetic_batch(batch, 588, ncls)
     d1, d2 = R["deform_inputs"](inp, 14)
-    c1, c2, c3, c4 = enc(inp)
+    with (torch.no_grad() if forward_only else torch.enable_grad()):
+        c1, c2, c3, c4 = enc(inp)
     c = torch.cat([c2, c3, c4], dim=1)
     with torch.no_grad():
         x = model.patch_embed(inp)
@@ -915,6 +929,17 @@ def c5_case(R, out, arch="vit_giant2_d4", batch=2, tag="c5", ncls=11, mode="kern
         feats = model.get_intermediate_layers(inp, 4, return_class_token=True)
         last = feats[-1][0] + outs[3]
         maps = [t.transpose(1, 2).reshape(batch, D, 42, 42) for t in (last, outs[2], outs[1], outs[0])]
+    if forward_only:
+        # the bench batch (B = 12): forward + loss under no_grad, sub-sampled, no oracle re-run (see c2_case)
+        with torch.no_grad():
+            output = dec(*maps)
+            loss = R["iou_loss"](torch.softmax(output, 1), target, num_classes=ncls)
+        for i, b in enumerate(maps):
+            out[f"{tag}.in{i}"] = sub(b)
+        out[f"{tag}.output"] = sub(output, 60000)
+        out[f"{tag}.loss"] = loss.detach().clone()
+        print(f"  {tag}: loss {float(loss):.6f}")
+        return
     output = dec(*maps)
     loss = R["iou_loss"](torch.softmax(output, 1), target, num_classes=ncls)
     loss.backward()
@@ -1135,6 +1160,20 @@ def main():
         for mode, tag in (("kernel", "step_b12_kernel"), ("init", "step_b12_exact")):
             print(f"[step ViT-L 588 B=12 forward + loss, {mode} weights]"); step_case(R, out, "vit_large", mode, tag, batch=12, forward_only=True)
             save("step_b12", out)
+    # configs 2 and 5 at the BENCH batch: forward + loss of the reference modules at B = 12, full depth, both
+    # weight sets, explicit only (c2_b12 ~10 CPU-minutes, c5_b12 ~90)
+    if "c2_b12" in only:
+        out = {}
+        for mode in ("kernel", "init"):
+            print(f"[config 2 at the bench batch: ViT-B/14 12 blocks + adapters(768) + UNet(768), 588 B=12 forward + loss, {mode} weights]")
+            c2_case(R, out, arch="vit_base", batch=12, tag=f"c2_b12_{mode}", mode=mode, forward_only=True)
+            save("c2_b12", out)
+    if "c5_b12" in only:
+        out = {}
+        for mode in ("kernel", "init"):
+            print(f"[config 5 at the bench batch: ViT-g/14 40 blocks + adapters(1536) + DecoderMLA 11 classes, 588 B=12 forward + loss, {mode} weights]")
+            c5_case(R, out, arch="vit_giant2", batch=12, tag=f"c5_b12_{mode}", mode=mode, forward_only=True)
+            save("c5_b12", out)
     if args.full or "step" in only:
         out = {}
         print("[step ViT-L 588 B=1 reference_exact (init mode)]"); step_case(R, out, "vit_large", "init", "step_exact")

@@ -208,3 +208,36 @@ def test_sharded_validation_two_ranks_gloo():
         out = mgr.dict()
         mp.spawn(_worker_shard_val, args=(world, _free_port(), out), nprocs=world, join=True)
         assert dict(out) == {0: True, 1: True}
+
+
+def _worker_shard_val_empty(rank, world, port, out):
+    """fewer validation batches than ranks.  The rank with an empty shard creates no meter inside the loop; with the
+    meters of ``train._val_meters`` made up front every rank issues the same three barrier + all-reduce pairs and the summary
+    line formats on all of them (before the fix: ranks 0 waits in a barrier the empty rank never enters)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    from adaptersis_amd.train import BatchShardSampler, _val_meters, _val_summary
+    n, bs = 7, 12                                             # ONE batch of 7 images: rank 0 gets it, rank 1 nothing
+    mine = list(BatchShardSampler(n, bs, rank, world))
+    ok = len(mine) == (1 if rank == 0 else 0)
+    ml = _val_meters()
+    for b in mine:
+        ml.update(loss=0.25)
+        ml.meters["acc1"].update(0.5, n=len(b))
+        ml.meters["dice"].update(0.75, n=len(b))
+    ml.synchronize_between_processes()
+    ok = ok and ml.meters["acc1"].count == n and abs(ml.meters["acc1"].global_avg - 0.5) < 1e-12
+    ok = ok and abs(ml.meters["dice"].global_avg - 0.75) < 1e-12 and abs(ml.meters["loss"].global_avg - 0.25) < 1e-12
+    ok = ok and _val_summary(ml) == "* Acc@1 0.500 loss 0.250 Dice 0.750"
+    out[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def test_sharded_validation_fewer_batches_than_ranks_gloo():
+    world = 2
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_worker_shard_val_empty, args=(world, _free_port(), out), nprocs=world, join=True)
+        assert dict(out) == {0: True, 1: True}

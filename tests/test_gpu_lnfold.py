@@ -28,7 +28,10 @@ def test_split_stats_planes_and_statistics(dev):
     assert rel_l2(mr[:, 0], mean.float()) < 1e-6 and rel_l2(mr[:, 1], (var + 1e-6).rsqrt().float()) < 1e-6
 
 
-@pytest.mark.parametrize("p8,M,N,K", [(1, 17645, 1024, 1024), (0, 17645, 1024, 4096), (1, 9000, 512, 2048)])
+@pytest.mark.parametrize("p8,M,N,K", [(1, 17645, 1024, 1024), (0, 17645, 1024, 4096), (1, 9000, 512, 2048),
+                                      # N % 256 in {64, 128, 192}: the last 256-column tile overhangs N, its wave column groups past
+                                      # the last 64-column group must not store statistics (they zeroed the next row's)
+                                      (0, 9001, 1088, 1024), (0, 9001, 1152, 1024), (0, 9001, 1216, 4096), (1, 17645, 1344, 1024)])
 def test_planes_rowstats_res16_epilogue(dev, p8, M, N, K):
     """proj / fc2 shaped: out = res + scale * (A B^T + bias) with the residual read from two planes and the result written as
     two planes + per-row partial sums; finalize -> LayerNorm statistics of the fp32 result."""
@@ -43,8 +46,11 @@ def test_planes_rowstats_res16_epilogue(dev, p8, M, N, K):
         outs = []
         for _ in range(2):
             oh, ol = torch.full((M, N), 7.0, device=dev, dtype=DT), torch.full((M, N), 7.0, device=dev, dtype=DT)
-            st = torch.empty((M, (N + 63) // 64, 2), device=dev, dtype=torch.float32)
+            # one guard row behind the table: a store past the last row's groups would land there
+            stg = torch.full((M + 1, (N + 63) // 64, 2), -123.0, device=dev, dtype=torch.float32)
+            st = stg[:M]
             ops.gemm(a, b, out=oh, out_lo=ol, rowstats=st, bias_n=bn, scale_n=sc, res16=(rh, rl))
+            assert bool((stg[M] == -123.0).all()), "row statistics written past the table"
             outs.append((oh, ol, st))
         oh, ol, st = outs[0]
         assert all(torch.equal(x, y) for x, y in zip(outs[0], outs[1])), "not reproducible"

@@ -44,6 +44,87 @@ def test_attention_backward(dev, shape, dt):
     assert max(errs) < tol, errs
 
 
+def _attn_ref_grads(qkv, dO, B, H, N, scale):
+    """fp32 softmax attention on the rounded operands, autograd -> (o, lse2, dq, dk, dv) as [B*N, H*64] / [B, H, N]"""
+    D = H * 64
+    qf, kf, vf = [t.float().view(B, N, H, 64).transpose(1, 2).clone().requires_grad_(True)
+                  for t in (qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:])]
+    sc = qf @ kf.transpose(-1, -2) * scale
+    o_ref = (torch.softmax(sc, -1) @ vf).transpose(1, 2).reshape(B * N, D)
+    (o_ref * dO.float()).sum().backward()
+    unhead = lambda g: g.transpose(1, 2).reshape(B * N, D)
+    lse2 = torch.logsumexp(sc.detach(), -1) * 1.4426950408889634
+    return o_ref.detach(), lse2, unhead(qf.grad), unhead(kf.grad), unhead(vf.grad)
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("segs", [[(2, 100)], [(1, 257)], [(2, 64)], [(1, 1765)], [(2, 33)], [(1, 192)],
+                                  [(1, 1765), (1, 1764)], [(2, 130), (1, 65)], [(1, 64), (2, 200)]])
+@pytest.mark.parametrize("scale", [64 ** -0.5, 0.11])
+def test_attention_backward_rows(dev, segs, dt, scale):
+    """``asis_attention_bwd_rows`` (row-major operands, transposing LDS reads, one or two stacked token batches) against fp32
+    autograd on the same rounded operands; scale 1/8 takes the folded (c dO, c V exact) kernels, 0.11 the unfolded ones."""
+    if scale != 64 ** -0.5 and (dt != torch.float16 or len(segs) == 1 and segs[0][1] > 300):
+        pytest.skip("unfolded-scale form: a few shapes are enough")
+    H = 2
+    D = H * 64
+    R = sum(b * n for b, n in segs)
+    tag = f"{segs}{scale:.3f}"
+    qkv = W.tensor(f"attnr.qkv{tag}", (R, 3 * D), 1.0).to(dt)
+    dO = W.tensor(f"attnr.do{tag}", (R, D), 1.0).to(dt)
+    refs, r0 = [], 0
+    for B, N in segs:
+        refs.append(_attn_ref_grads(qkv[r0:r0 + B * N], dO[r0:r0 + B * N], B, H, N, scale))
+        r0 += B * N
+    g, dOd = qkv.to(dev), dO.to(dev)
+    q, k, v = g[:, :D], g[:, D:2 * D], g[:, 2 * D:]
+    o = torch.empty((R, D), device=dev, dtype=dt)
+    lse = torch.empty(R * H, device=dev, dtype=torch.float32)
+    r0 = l0 = 0
+    for B, N in segs:   # forward per batch (writes its slice of the log-sum-exp buffer)
+        r1, l1 = r0 + B * N, l0 + B * H * N
+        vt = ops.transpose_tokens(v[r0:r1], B, N)
+        ops.attention_fwd(q[r0:r1], k[r0:r1], vt, B, H, N, scale, out=o[r0:r1], lse=lse[l0:l1].view(B, H, N))
+        r0, l0 = r1, l1
+    outs = []
+    for _ in range(2):
+        dqkv = torch.full((R, 3 * D), 7.0, device=dev, dtype=dt)
+        ops.attention_bwd_rows(q, k, v, o, dOd, lse, segs, H, scale, dqkv=dqkv)
+        outs.append(dqkv)
+    assert torch.equal(outs[0], outs[1]), "not reproducible"
+    dqkv = outs[0].cpu()
+    assert bool(torch.isfinite(dqkv.float()).all())
+    tol = 4e-3 if dt == torch.float16 else 2.5e-2
+    r0 = 0
+    for (B, N), (o_ref, lse_ref, dq, dk, dv) in zip(segs, refs):
+        r1 = r0 + B * N
+        errs = (rel_l2(dqkv[r0:r1, :D], dq), rel_l2(dqkv[r0:r1, D:2 * D], dk), rel_l2(dqkv[r0:r1, 2 * D:], dv))
+        print(segs, (B, N), dt, scale, "dq dk dv rel-L2:", ["%.2e" % e for e in errs])
+        assert max(errs) < tol, errs
+        r0 = r1
+
+
+def test_attention_backward_rows_matches_transposed_form(dev):
+    """the new kernels against the round-1 form (transposed operand images) on the ViT-L geometry: same mathematics, errors
+    of the same size against fp32 (the bar of VERDICT r4: <= 3.0e-4 on this case)"""
+    B, H, N = 1, 2, 1765
+    D, scale, dt = H * 64, 0.125, torch.float16
+    qkv = W.tensor("attnb.qkv(1, 2, 1765)", (B * N, 3 * D), 1.0).to(dt)
+    dO = W.tensor("attnb.do(1, 2, 1765)", (B * N, D), 1.0).to(dt)
+    _, _, dq, dk, dv = _attn_ref_grads(qkv, dO, B, H, N, scale)
+    g, dOd = qkv.to(dev), dO.to(dev)
+    q, k, v = g[:, :D], g[:, D:2 * D], g[:, 2 * D:]
+    lse = torch.empty((B, H, N), device=dev, dtype=torch.float32)
+    o = ops.attention_fwd(q, k, ops.transpose_tokens(v, B, N), B, H, N, scale, lse=lse)
+    old = ops.attention_bwd(q, k, v, ops.transpose_tokens(q, B, N), ops.transpose_tokens(k, B, N),
+                            ops.transpose_tokens(dOd, B, N), o, dOd, lse, B, H, N, scale).cpu()
+    new = ops.attention_bwd_rows(q, k, v, o, dOd, lse.view(-1), [(B, N)], H, scale).cpu()
+    for name, sl, ref in (("dq", slice(0, D), dq), ("dk", slice(D, 2 * D), dk), ("dv", slice(2 * D, 3 * D), dv)):
+        e_old, e_new = rel_l2(old[:, sl], ref), rel_l2(new[:, sl], ref)
+        print(name, "old %.2e new %.2e" % (e_old, e_new))
+        assert e_new < 3.0e-4 and e_new < 1.15 * e_old + 1e-5
+
+
 def test_transpose_tokens(dev):
     B, N, C = 2, 77, 128
     x = W.tensor("tt.x", (B * N, C + 64), 1.0).to(torch.float16).to(dev)
