@@ -83,6 +83,11 @@ dual_stream = os.environ.get("ASIS_DUAL_STREAM", "1") not in ("0", "")
 # UNet and MLA heads (they amplify a stream error 3.9x / 3.2x, the FeatureDecoder 2x: full-depth stress goldens 1.29e-3 ->
 # 9.1e-4 for config 2) and the unfrozen backbone (config 4: 9.9e-4 -> 7.3e-4) — and leaves the frozen ViT-L + FeatureDecoder
 # step (stress golden 9.0e-4) on single 16-bit operands.
+# Training forward / backward of the attention on row-major operands only (round 5): V straight out of the qkv GEMM through
+# transposing LDS reads in the forward (both stacked passes in one launch), asis_attention_bwd_rows in the backward — no
+# transpose_tokens pass anywhere.  ASIS_ATTN_ROWS=0 keeps the V^T forward (the backward is the row-major form either way).
+attn_rows = os.environ.get("ASIS_ATTN_ROWS", "1") != "0"
+
 _so = os.environ.get("ASIS_SPLIT_O", "auto").lower()
 split_attn_out_policy = None if _so == "auto" else (_so not in ("0", ""))   # None = per engine (SegEngine.split_attn_out)
 split_attn_out = bool(split_attn_out_policy)     # what the blocks read; SegEngine sets it at the top of every step

@@ -642,7 +642,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(const T* __restri
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.0f / l_tot;
   const int qi = q_base + fr;
-  if (!DBG && lse2 && qi < N && fh == 0) lse2[((int64_t)b * H + head) * N1 + qi] = m_run + __builtin_amdgcn_logf(l_tot);
+  // log2-domain log-sum-exp per query, [B1, H, N1] followed by [B2, H, N2] (the layout asis_attention_bwd_rows reads)
+  if (!DBG && lse2 && qi < N && fh == 0) {
+    const int64_t st0 = (b < B1 ? (int64_t)b * H * N1 : (int64_t)B1 * H * N1 + (int64_t)(b - B1) * H * N2) + (int64_t)head * N;
+    lse2[st0 + qi] = m_run + __builtin_amdgcn_logf(l_tot);
+  }
   if (qi < N) {
     T* op = o + (row0 + qi) * ldo + head * HD + 4 * fh;
 #pragma unroll
@@ -679,7 +683,7 @@ static int attention_fwd_impl(void* stream, int dtype, const void* q, const void
   const int N = N1 > N2 ? N1 : N2;
   ASIS_REQUIRE(q && k && vt && o, "asis_attention_fwd: null pointer");
   ASIS_REQUIRE(B1 > 0 && B2 >= 0 && H > 0 && N1 > 0 && (B2 == 0 || N2 > 0), "asis_attention_fwd: bad shape");
-  ASIS_REQUIRE(!lse2 || B2 == 0, "asis_attention_fwd: the log-sum-exp output is for a single token batch");
+  // (the pipelined kernel writes lse2 for both stacked batches; the register-staged lab kernel for one)
   ASIS_REQUIRE(B <= 65535 && H <= 65535, "asis_attention_fwd: B/H too large");
   ASIS_REQUIRE(ldqk % 8 == 0 && ldqk >= (int64_t)H * HD, "asis_attention_fwd: ldqk=%ld must be a multiple of 8 and >= H*64", (long)ldqk);
   ASIS_REQUIRE(ldvt % 8 == 0 && ldvt >= (vrows ? (int64_t)H * HD : (int64_t)N),
@@ -729,14 +733,17 @@ static int attention_fwd_impl(void* stream, int dtype, const void* q, const void
     else { if (fold) ASIS_ATTN_PIPE_LAUNCH(bf16, 3); else if (pipe == 2) ASIS_ATTN_PIPE_LAUNCH(bf16, 1); else if (pipe == 3) ASIS_ATTN_PIPE_LAUNCH(bf16, 2); else ASIS_ATTN_PIPE_LAUNCH(bf16, 0); }
 #undef ASIS_ATTN_PIPE_LAUNCH
   } else if (abl && dtype == ASIS_F16) {
+    ASIS_REQUIRE(!lse2 || B2 == 0, "asis_attention_fwd: the lab kernels write the log-sum-exp of a single token batch");
     if (abl == 1) hipLaunchKernelGGL((attn_fwd_kernel<f16, 2, 1>), grid, block, 0, s, (const f16*)q, (const f16*)k, ldqk, (const f16*)vt, ldvt, (f16*)o, (f16*)o_lo, ldo, H, N1, sl, lse2, B1, N2);
     else if (abl == 2) hipLaunchKernelGGL((attn_fwd_kernel<f16, 2, 2>), grid, block, 0, s, (const f16*)q, (const f16*)k, ldqk, (const f16*)vt, ldvt, (f16*)o, (f16*)o_lo, ldo, H, N1, sl, lse2, B1, N2);
     else if (abl == 5) hipLaunchKernelGGL((attn_fwd_kernel<f16, 2, 5>), grid, block, 0, s, (const f16*)q, (const f16*)k, ldqk, (const f16*)vt, ldvt, (f16*)o, (f16*)o_lo, ldo, H, N1, sl, lse2, B1, N2);
     else if (abl == 4) hipLaunchKernelGGL((attn_fwd_kernel<f16, 2, 4>), grid, block, 0, s, (const f16*)q, (const f16*)k, ldqk, (const f16*)vt, ldvt, (f16*)o, (f16*)o_lo, ldo, H, N1, sl, lse2, B1, N2);
     else hipLaunchKernelGGL((attn_fwd_kernel<f16, 2, 3>), grid, block, 0, s, (const f16*)q, (const f16*)k, ldqk, (const f16*)vt, ldvt, (f16*)o, (f16*)o_lo, ldo, H, N1, sl, lse2, B1, N2);
   } else if (dtype == ASIS_F16) {
+    ASIS_REQUIRE(!lse2 || B2 == 0, "asis_attention_fwd: the register-staged kernel writes the log-sum-exp of a single token batch");
     if (occ == 2) ASIS_ATTN_LAUNCH(f16, 2); else if (occ == 3) ASIS_ATTN_LAUNCH(f16, 3); else ASIS_ATTN_LAUNCH(f16, 4);
   } else {
+    ASIS_REQUIRE(!lse2 || B2 == 0, "asis_attention_fwd: the register-staged kernel writes the log-sum-exp of a single token batch");
     if (occ == 2) ASIS_ATTN_LAUNCH(bf16, 2); else if (occ == 3) ASIS_ATTN_LAUNCH(bf16, 3); else ASIS_ATTN_LAUNCH(bf16, 4);
   }
 #undef ASIS_ATTN_LAUNCH

@@ -12,14 +12,18 @@
 //     that reduce over the TOKEN index (dQ += dS K, dV += P^T dO, dK += dS^T Q) take their A operand from the same LDS
 //     image by the transposing read ds_read_b64_tr_b16 — the K^T / Q^T / dO^T tensors of the old form and the three
 //     asis_transpose_tokens passes per block are gone;
-//   * one swizzle serves both kinds of read: chunk slot = chunk ^ f(row), f(row) = (row bits 1,2) << 1 | row bit 3 — the
-//     eight same-parity rows of a ds_read_b128 service group (rows in the bit-2/3-swapped order of the accumulator ->
-//     B-operand hand-off) take eight different slots, and the four rows of a transposed 4 x 16 block differ in bit 1 of
-//     the slot's 32-byte half (f >> 1 = row bits 1,2);
+//   * one swizzle serves both kinds of read: chunk slot = chunk ^ f(row), f(row) = row bits (1, 2, 3) in slot bits
+//     (2, 1, 0) — the eight same-parity rows of a ds_read_b128 service group (rows in the bit-2/3-swapped order of the
+//     accumulator -> B-operand hand-off) take eight different slots, and the eight 32-byte pieces a 32-lane half of a
+//     transposing read touches (4 rows x 2 column blocks) fall into eight different bank octets (row bit 0 picks the
+//     128-byte half of the bank line, row bit 1 the slot's bit 2, the column block its bit 1).  The first version put row
+//     bit 1 into slot bit 1 and measured 2-way conflicts on every transposing read (SQ_LDS_BANK_CONFLICT = 25 % of
+//     SQ_LDS_IDX_ACTIVE);
 //   * the DMA is issued from an asm statement (hipcc puts an s_waitcnt vmcnt(0) in front of the first LDS read behind a
 //     DMA builtin it cannot disambiguate; here the only wait is the counted one in front of the tile's barrier) and the
-//     tile loop is unrolled three times, so every LDS address is ONE of five per-lane registers (four row-read bases, one
-//     transposed-read base: the swizzle is additive in everything but the k-step of a row read) plus an immediate;
+//     tile loop is unrolled three times, so every LDS address is ONE of six per-lane registers (four row-read bases, two
+//     transposed-read bases: the swizzle is additive in everything but the k-step of a row read and the d block of a
+//     transposed one) plus an immediate;
 //   * pipelined in half tiles of 32 tokens: the dP chain of half-step g and the score chain of half-step g + 1 go to the
 //     matrix pipe first, the exponentials of half-step g run under them, then dS (and P) feed the token-reducing products;
 //     one barrier per 64-token tile;
@@ -44,7 +48,8 @@ typedef s16x4 __attribute__((address_space(3))) * lds_tr_ptr;
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ int perm23(int r) { return (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1); }
-__device__ __forceinline__ int fsw(int row) { return (((row >> 1) & 3) << 1) | ((row >> 3) & 1); }
+// chunk-slot swizzle of a [64][64] 16-bit tile: slot = chunk ^ fsw(row), fsw = row bits (1, 2, 3) -> slot bits (2, 1, 0)
+__device__ __forceinline__ int fsw(int row) { return (((row >> 1) & 1) << 2) | (((row >> 2) & 1) << 1) | ((row >> 3) & 1); }
 
 // ---- D'[b, h, q] = -c * sum_d dO[q, h*64 + d] * O[q, h*64 + d]  (the initial accumulator of the dP chains) -----------
 template <typename T>
@@ -102,7 +107,9 @@ __device__ __forceinline__ void glds16_s(const void* sbase, unsigned voff, void*
   unsigned keep;
   const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_ptr)lds_dst);
   const uint64_t b64 = (uint64_t)(uintptr_t)sbase;
-  const uint64_t sb = ((uint64_t)__builtin_amdgcn_readfirstlane((unsigned)(b64 >> 32)) << 32) | __builtin_amdgcn_readfirstlane((unsigned)b64);
+  // (readfirstlane returns int: without the unsigned casts a low word with bit 31 set sign-extends into the high word)
+  const uint64_t sb = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(b64 >> 32)) << 32) |
+                      (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)b64);
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(voff), "s"(dst), "s"(sb) : "memory");
 }
@@ -149,15 +156,18 @@ struct TileDma {
 // constant of the unrolled tile loop (slot, 32-token half, k-step, d block).
 struct LaneOff {
   int row[4];   // row read of k-step s: row perm23(fr), chunk (2 s + fh) ^ f(row)
-  int tr;       // transposed read: row 8 (g >> 1) + q, slot bits 1..0 of the chunk, 4-element half of the chunk
+  int tr[2];    // transposed read of d block db: row 8 (g >> 1) + q, slot of chunk 4 db + 2 (g & 1) + (p >> 1), 4-element half
   __device__ __forceinline__ void init(int lane) {
     const int fr = lane & 31, fh = lane >> 5, prow = perm23(fr);
 #pragma unroll
     for (int s = 0; s < 4; ++s) row[s] = prow * HD + (((2 * s + fh) ^ fsw(prow)) << 3);
     const int g = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3;
     // row = 32 h + 16 s2 + 8 (g >> 1) + 4 half + q, chunk = 4 db + 2 (g & 1) + (p >> 1):
-    //   f(row) = (q >> 1) << 1 | half << 2 | (g >> 1), so slot = (db ^ half) << 2 | ((g & 1) ^ (q >> 1)) << 1 | ((p >> 1) ^ (g >> 1))
-    tr = (8 * (g >> 1) + q) * HD + (((((g & 1) ^ (q >> 1)) << 1) | ((p >> 1) ^ (g >> 1))) << 3) + ((p & 1) << 2);
+    //   f(row) = (q >> 1) << 2 | half << 1 | (g >> 1), so slot = (db ^ (q >> 1)) << 2 | ((g & 1) ^ half) << 1 | ((p >> 1) ^ (g >> 1)):
+    //   `half` flips slot bit 1 of a lane-constant -> one base per db, the half's bit is applied with an xor-free +/- below
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+      tr[db] = (8 * (g >> 1) + q) * HD + ((((db ^ (q >> 1)) << 2) | ((g & 1) << 1) | ((p >> 1) ^ (g >> 1))) << 3) + ((p & 1) << 2);
   }
 };
 
@@ -169,14 +179,14 @@ __device__ __forceinline__ typename T16<T>::v8 row_frag(const T* tile, const Lan
 }
 
 // A fragment of a token-reducing product (X^T . dS): A[d = 32 db + fr][token = 32 h + 16 s2 + 8 fh + j], j = 0..7, by two
-// transposing reads of 4 tokens x 16 d each
+// transposing reads of 4 tokens x 16 d each.  Rows 4 half + q: `half` toggles bit 1 of the slot, whose lane part is g & 1 —
+// +16 elements where that bit is clear, -16 where it is set, i.e. a per-lane constant sign: tr[db] carries the half = 0
+// slot and `hstep` = +-16 moves to the half = 1 slot.
 template <typename T>
-__device__ __forceinline__ typename T16<T>::v8 tr_frag(const T* tile, const LaneOff& lo, int h, int s2, int db) {
+__device__ __forceinline__ typename T16<T>::v8 tr_frag(const T* tile, const LaneOff& lo, int hstep, int h, int s2, int db) {
   s16x4 hh[2];
-#pragma unroll
-  for (int half = 0; half < 2; ++half)
-    hh[half] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-        (lds_tr_ptr)(tile + (32 * h + 16 * s2 + 4 * half) * HD + ((db ^ half) << 5) + lo.tr));
+  hh[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(tile + (32 * h + 16 * s2) * HD + lo.tr[db]));
+  hh[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(tile + (32 * h + 16 * s2 + 4) * HD + lo.tr[db] + hstep));
   return __builtin_bit_cast(typename T16<T>::v8, (s16x8)__builtin_shufflevector(hh[0], hh[1], 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
@@ -192,8 +202,8 @@ __device__ __forceinline__ f32x16 zero16() {
 //   S^T = K Q^T, dP'^T = V (c dO)^T - c D   (A = K / V rows from LDS, B = Q / dO fragments in registers; the accumulator's
 //                                            column is the query, so lse2[q] and D[q] are per-lane scalars)
 //   dS'^T = P^T * dP'^T,  dQ^T += K^T dS'^T  (A = K^T by transposing reads of the K tile, B = dS'^T from the accumulator)
-template <typename T, bool CFOLD>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_pipe_kernel(const T* __restrict__ q, const T* __restrict__ k,
+template <typename T, bool CFOLD, int OCC = 2>
+__global__ __launch_bounds__(256, OCC) void attn_bwd_dq_pipe_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                                   const T* __restrict__ v, int64_t ld,
                                                                   const T* __restrict__ dO, int64_t lddo,
                                                                   const float* __restrict__ lse2, const float* __restrict__ Dn,
@@ -249,6 +259,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_pipe_kernel(const T* __res
   const int nt = (N + TT - 1) / TT;
   LaneOff lo;
   lo.init(lane);
+  const int hstep = ((lane >> 4) & 1) ? -16 : 16;
 
   f32x16 acc[2] = {zero16(), zero16()};
   f32x16 sA, sB;   // scores of the half-step in flight and of the next one
@@ -280,7 +291,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_pipe_kernel(const T* __res
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-      for (int db = 0; db < 2; ++db) acc[db] = T16<T>::mfma32(tr_frag<T>(Kt, lo, h, s2, db), dsf[s2], acc[db]);
+      for (int db = 0; db < 2; ++db) acc[db] = T16<T>::mfma32(tr_frag<T>(Kt, lo, hstep, h, s2, db), dsf[s2], acc[db]);
   };
   // one 64-key tile.  On entry sA holds the scores of half 0 of tile t; on exit of half 0 of tile t + 1 (behind the last tile:
   // of whatever the next slot holds — never used).
@@ -386,6 +397,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_pipe_kernel(const T* __re
   const int nt = (N + TT - 1) / TT;
   LaneOff lo;
   lo.init(lane);
+  const int hstep = ((lane >> 4) & 1) ? -16 : 16;
   // statistics of tile t: wave 0 stages lse2[64 t ..], wave 1 stages -c D[64 t ..] (4 bytes per lane, one DMA each)
   auto stat_issue = [&](float* slot, int t) {
     if (wid < 2) {   // wave-uniform
@@ -442,7 +454,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_pipe_kernel(const T* __re
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-      for (int db = 0; db < 2; ++db) dvacc[db] = T16<T>::mfma32(tr_frag<T>(Gt, lo, h, s2, db), pf[s2], dvacc[db]);
+      for (int db = 0; db < 2; ++db) dvacc[db] = T16<T>::mfma32(tr_frag<T>(Gt, lo, hstep, h, s2, db), pf[s2], dvacc[db]);
     __builtin_amdgcn_sched_barrier(0);
     v8 dsf[2];
 #pragma unroll
@@ -454,7 +466,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_pipe_kernel(const T* __re
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-      for (int db = 0; db < 2; ++db) dkacc[db] = T16<T>::mfma32(tr_frag<T>(Qt, lo, h, s2, db), dsf[s2], dkacc[db]);
+      for (int db = 0; db < 2; ++db) dkacc[db] = T16<T>::mfma32(tr_frag<T>(Qt, lo, hstep, h, s2, db), dsf[s2], dkacc[db]);
   };
   auto step = [&](int t, const T* Qc, const T* Gc, const float* Sc, const T* Qn, T* Qd, T* Gd, float* Sd) {
     if (t + 2 < nt) {
@@ -518,7 +530,13 @@ static void launch_rows(hipStream_t s, const void* q, const void* k, const void*
   hipLaunchKernelGGL((attn_rowdot_neg_kernel<T>), dim3((unsigned)nd), dim3(256), 0, s, (const T*)o, ldo, (const T*)dO, lddo, D,
                      B1, N1, B2, N2, H, -scale);
   dim3 grid((N + 127) / 128, H, B), block(256);
-  if (cfold) {
+  static const int occ3 = [] { const char* e = getenv("ASIS_ATTN_BWD_OCC"); return e && atoi(e) == 3; }();   // lab
+  if (cfold && occ3) {
+    hipLaunchKernelGGL((attn_bwd_dq_pipe_kernel<T, true, 3>), grid, block, 0, s, (const T*)q, (const T*)k, (const T*)v, ld,
+                       (const T*)dO, lddo, lse2, D, (T*)dq, lddq, H, B1, N1, N2, scale, sl);
+    hipLaunchKernelGGL((attn_bwd_dkv_pipe_kernel<T, true>), grid, block, 0, s, (const T*)q, (const T*)k, (const T*)v, ld,
+                       (const T*)dO, lddo, lse2, D, (T*)dk, (T*)dv, lddq, H, B1, N1, N2, scale, sl);
+  } else if (cfold) {
     hipLaunchKernelGGL((attn_bwd_dq_pipe_kernel<T, true>), grid, block, 0, s, (const T*)q, (const T*)k, (const T*)v, ld,
                        (const T*)dO, lddo, lse2, D, (T*)dq, lddq, H, B1, N1, N2, scale, sl);
     hipLaunchKernelGGL((attn_bwd_dkv_pipe_kernel<T, true>), grid, block, 0, s, (const T*)q, (const T*)k, (const T*)v, ld,

@@ -652,18 +652,21 @@ class Block(_Packed):
         qkv = ops.gemm(xn, a._w16("qkv", a.qkv.weight), bias_n=a._f32("qkv_b", a.qkv.bias), b_lo=a._w16lo("qkv", a.qkv.weight))
         o = torch.empty((x2.shape[0], D), device=x2.device, dtype=dt)
         o_lo = torch.empty_like(o) if config.split_attn_out else None
-        lse = []
-        r0 = 0
-        for B, N in segs:
-            r1 = r0 + B * N
-            vt = ops.transpose_tokens(qkv[r0:r1, 2 * D:], B, N)
-            l = torch.empty((B, a.num_heads, N), device=x2.device, dtype=torch.float32)
-            ops.attention_fwd(qkv[r0:r1, :D], qkv[r0:r1, D:2 * D], vt, B, a.num_heads, N, a.scale, out=o[r0:r1], lse=l,
-                              out_lo=None if o_lo is None else o_lo[r0:r1])
-            lse.append(l)
-            r0 = r1
-        if r0 != x2.shape[0]:
+        if sum(B * N for B, N in segs) != x2.shape[0]:
             raise ValueError("forward_train_rows: segments do not cover the rows")
+        # the log-sum-exp of every stacked batch in ONE buffer ([B1, H, N1] then [B2, H, N2]: what attention_bwd_rows reads)
+        lse = torch.empty(x2.shape[0] * a.num_heads, device=x2.device, dtype=torch.float32)
+        if len(segs) <= 2 and config.attn_rows:
+            # V row-major straight out of the qkv GEMM (transposing LDS reads in the kernel), both batches in one launch
+            ops.attention_fwd_qkv(qkv, segs, a.num_heads, a.scale, o, out_lo=o_lo, lse=lse)
+        else:
+            r0 = l0 = 0
+            for B, N in segs:
+                r1, l1 = r0 + B * N, l0 + B * a.num_heads * N
+                vt = ops.transpose_tokens(qkv[r0:r1, 2 * D:], B, N)
+                ops.attention_fwd(qkv[r0:r1, :D], qkv[r0:r1, D:2 * D], vt, B, a.num_heads, N, a.scale, out=o[r0:r1],
+                                  lse=lse[l0:l1].view(B, a.num_heads, N), out_lo=None if o_lo is None else o_lo[r0:r1])
+                r0, l0 = r1, l1
         x1 = ops.gemm(o, a._w16("proj", a.proj.weight), out_f32=True, bias_n=a._f32("proj_b", a.proj.bias), scale_n=g1,
                       res=x2, a_lo=o_lo, b_lo=a._w16lo("proj", a.proj.weight))
         xn2 = ops.layernorm(x1, self._f32("n2w", self.norm2.weight), self._f32("n2b", self.norm2.bias), self.norm2.eps, dt)
@@ -721,14 +724,15 @@ class Block(_Packed):
         self._linear_bwd(pre + "attn.proj", a.proj, ls1, pre + "ls1.gamma", d16, cs, o, inv_scale, grads)
         dO = ops.gemm(d16, self._wT16("projT", a.proj.weight, ls1, k1))            # 16-bit [R, D], times 2^k1
         dqkv = torch.empty((x2.shape[0], 3 * D), device=x2.device, dtype=dt)
-        r0 = 0
-        for (B, N), l in zip(segs, lse):   # attention backward per stacked token batch
-            r1 = r0 + B * N
-            q, k, v = qkv[r0:r1, :D], qkv[r0:r1, D:2 * D], qkv[r0:r1, 2 * D:]
-            ops.attention_bwd(q, k, v, ops.transpose_tokens(q, B, N), ops.transpose_tokens(k, B, N),
-                              ops.transpose_tokens(dO[r0:r1], B, N), o[r0:r1], dO[r0:r1], l, B, a.num_heads, N, a.scale,
-                              dqkv=dqkv[r0:r1])
-            r0 = r1
+        if isinstance(lse, (list, tuple)):   # per-batch [B, H, N] tensors (the MaskTransformer block's forward)
+            lse = torch.cat([l.reshape(-1) for l in lse])
+        q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+        for i in range(0, len(segs), 2):     # attention backward, two stacked token batches per launch
+            part = segs[i:i + 2]
+            r0 = sum(B * N for B, N in segs[:i])
+            r1 = r0 + sum(B * N for B, N in part)
+            ops.attention_bwd_rows(q[r0:r1], k[r0:r1], v[r0:r1], o[r0:r1], dO[r0:r1], lse[r0 * a.num_heads:r1 * a.num_heads],
+                                   part, a.num_heads, a.scale, dqkv=dqkv[r0:r1])
         self._linear_bwd(pre + "attn.qkv", a.qkv, None, None, dqkv, ops.colsum(dqkv) if grads is not None else None, xn,
                          inv1, grads)
         dln = ops.gemm(dqkv, self._wT16("qkvT", a.qkv.weight), out_f32=True)
