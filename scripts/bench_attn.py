@@ -1,42 +1,62 @@
-"""Attention forward microbench (ViT-L shape): python scripts/bench_attn.py"""
+"""Attention forward microbench (ViT-L shape, the trunk's two stacked passes): python scripts/bench_attn.py
+(profiles/r05_attn_fwd_half_ab.txt holds this table for the round-3 kernel and the half-tile rebuild that was measured and dropped)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from adaptersis_amd import ops
 
 
-def main():
-    dev = torch.device("cuda:0")
-    B, H, N, D = 12, 16, 1764, 1024
-    dt = torch.float16
-    M = B * N
-    qk = (torch.randn(M, 2 * D, device=dev)).to(dt)
-    ldvt = 1792
-    vt = torch.zeros(B, D, ldvt, device=dev, dtype=dt)
-    vt[:, :, :N] = torch.randn(B, D, N, device=dev).to(dt)
-    o = torch.empty(M, D, device=dev, dtype=dt)
-    f = lambda: ops.attention_fwd(qk[:, :D], qk[:, D:], vt, B, H, N, 0.125, out=o)
-    if os.environ.get("ASIS_ATTN_VAR") == "qkv":   # row-major V out of one [tokens, 3 D] matrix
-        qkv = torch.cat([qk, vt[:, :, :N].transpose(1, 2).reshape(M, D)], dim=1).contiguous()
-        f = lambda: ops.attention_fwd_qkv(qkv, [(B, N)], H, 0.125, o)
-    f()
-    q = qk[:, :D].float().view(B, N, H, 64).transpose(1, 2)
-    k = qk[:, D:].float().view(B, N, H, 64).transpose(1, 2)
-    v = vt[:, :, :N].float().view(B, H, 64, N).transpose(2, 3)
-    ref = torch.softmax(q @ k.transpose(2, 3) * 0.125, -1) @ v
-    ref = ref.transpose(1, 2).reshape(M, D)
-    err = ((o.float() - ref).norm() / ref.norm()).item()
+def timeit(f, n=40):
     for _ in range(5):
         f()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    n = 50
     for _ in range(n):
         f()
     torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / n * 1e3
-    print(f"ABLATE={os.environ.get('ASIS_ATTN_ABLATE', '0')} VAR={os.environ.get('ASIS_ATTN_VAR', '-')}: {ms:.3f} ms  "
-          f"{4.0 * B * H * N * N * 64 / ms / 1e9:.0f} TFLOP/s  rel {err:.2e}")
+    return (time.perf_counter() - t0) / n * 1e3
+
+
+def main():
+    dev = torch.device("cuda:0")
+    H, D = 16, 1024
+    segs = [(12, 1765), (12, 1764)]
+    dt = torch.float16
+    R = sum(b * n for b, n in segs)
+    torch.manual_seed(0)
+    qkv = torch.randn(R, 3 * D, device=dev).to(dt)
+    q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+    c = 0.125 * 1.4426950408889634
+    qs = (q.float() * c).to(dt)                      # q as the folded projection delivers it
+    qks = torch.cat([qs, k], dim=1).contiguous()
+    ldvt = 1792
+    vt = torch.full((sum(b for b, _ in segs), D, ldvt), float("nan"), device=dev, dtype=dt)   # pad columns: anything
+    r0 = b0 = 0
+    refs = []
+    for B, N in segs:
+        vt[b0:b0 + B, :, :N] = v[r0:r0 + B * N].view(B, N, D).transpose(1, 2)
+        qf = q[r0:r0 + B * N].float().view(B, N, H, 64).transpose(1, 2)
+        kf = k[r0:r0 + B * N].float().view(B, N, H, 64).transpose(1, 2)
+        vf = v[r0:r0 + B * N].float().view(B, N, H, 64).transpose(1, 2)
+        refs.append((torch.softmax(qf @ kf.transpose(2, 3) * 0.125, -1) @ vf).transpose(1, 2).reshape(B * N, D))
+        r0 += B * N
+        b0 += B
+    ref = torch.cat(refs)
+    (B1, N1), (B2, N2) = segs
+    o = torch.empty(R, D, device=dev, dtype=dt)
+    forms = {
+        "unfolded, V^T, stacked": lambda: ops.attention_fwd_seg(q, k, vt, B1, N1, B2, N2, H, 0.125, out=o),
+        "pre-scaled q, V^T, stacked (the trunk)": lambda: ops.attention_fwd_seg(qks[:, :D], qks[:, D:], vt, B1, N1, B2, N2, H, None, out=o),
+        "unfolded, V rows (qkv), stacked": lambda: ops.attention_fwd_qkv(qkv, segs, H, 0.125, o),
+    }
+    fl = sum(4.0 * B * H * N * N * 64 for B, N in segs)
+    for name, f in forms.items():
+        o.zero_()
+        f()
+        err = float((o.float() - ref).norm() / ref.norm())
+        ms = timeit(f)
+        print(f"PIPE={os.environ.get('ASIS_ATTN_PIPE', '1')} NOFOLD={os.environ.get('ASIS_ATTN_NOFOLD', '0')} {name:42s} {ms * 1e3:8.1f} us  "
+              f"{fl / ms / 1e9:6.0f} TFLOP/s  rel {err:.2e}")
 
 
 if __name__ == "__main__":
