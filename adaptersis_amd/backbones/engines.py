@@ -204,7 +204,7 @@ class SegEngine(nn.Module):
         side = self._enc_stream
         side.wait_stream(main)          # the input batch, and everything of the previous step that read recycled blocks
         with torch.cuda.stream(side):
-            _, c, shapes = self.backbone_encoder.forward_tokens(inp, need_c1=False)
+            _, c, shapes = self.backbone_encoder.forward_tokens(inp, need_c1=not config.elide_c1)
             done = torch.cuda.Event()
             done.record(side)
         c.record_stream(main)           # allocated on the side stream, consumed on the compute stream
@@ -278,7 +278,7 @@ class SegEngine(nn.Module):
         elif config.encoder_stream and inp.is_cuda:
             c, shapes, enc_done = self._encoder_on_side_stream(inp)
         else:
-            _, c, shapes = self.backbone_encoder.forward_tokens(inp, need_c1=False)
+            _, c, shapes = self.backbone_encoder.forward_tokens(inp, need_c1=not config.elide_c1)
         c_orig = c
         Lc = c.shape[1]
         g = self._geometry(H, W, shapes, inp.device)
@@ -292,6 +292,8 @@ class SegEngine(nn.Module):
         segs = [(B, N + 1), (B, N)]
         xcat = torch.empty((Ra + Rb, D), device=inp.device, dtype=torch.float32)
         tokens, _ = m.patch_embed.tokens(inp, out=xcat[Ra:])
+        if not config.share_patch_embed:   # the reference's second evaluation (pass A's own, `vision_transformer.py:190`): same values
+            tokens, _ = m.patch_embed.tokens(inp)
         pos = m._pos_for(N, H, W)
         ops.add_cls_pos(tokens, m.cls_token.detach().reshape(-1).float().contiguous(),
                         pos.detach().reshape(-1, D).float().contiguous(), out=xcat[:Ra].view(B, N + 1, D))
@@ -382,10 +384,12 @@ class SegEngine(nn.Module):
             c, shapes, esaved = self.backbone_encoder.forward_tokens_train(inp)
             self._esaved = (esaved, shapes)
         else:
-            _, c, shapes = self.backbone_encoder.forward_tokens(inp, need_c1=False)
+            _, c, shapes = self.backbone_encoder.forward_tokens(inp, need_c1=not config.elide_c1)
         Lc = c.shape[1]
         g = self._geometry(H, W, shapes, inp.device)
         tokens = m.patch_embed(inp)
+        if not config.share_patch_embed:   # pass A's own evaluation in the reference (same values)
+            m.patch_embed(inp)
         # pass A (`train_mla.py:361-366`, only its last layer is used) rides along with pass B on the same weights:
         # both token batches stacked along the rows for blocks[0:-1] (see ``features``)
         xa = ops.add_cls_pos(tokens, m.cls_token.detach().reshape(-1).float().contiguous(),
@@ -546,7 +550,7 @@ class SegEngine(nn.Module):
             c, shapes, esaved = self.backbone_encoder.forward_tokens_train(inp)
             self._esaved = (esaved, shapes)
         else:
-            _, c, shapes = self.backbone_encoder.forward_tokens(inp, need_c1=False)
+            _, c, shapes = self.backbone_encoder.forward_tokens(inp, need_c1=not config.elide_c1)
         c_orig = c
         Lc = c.shape[1]
         g = self._geometry(H, W, shapes, inp.device)

@@ -112,6 +112,16 @@ trunk_streams = int(os.environ.get("ASIS_TRUNK_STREAMS", "2") or 2)     # 4: eac
 # skips that one call (identical results, ~0.8 % of the step's FLOPs); ASIS_ELIDE_DEAD_CACNN=0 runs it anyway (bench.py reports
 # the setting as config.dead_cacnn_elided; A/B in DESIGN.md §6).
 elide_dead_cacnn = os.environ.get("ASIS_ELIDE_DEAD_CACNN", "1") not in ("0", "")
+# Two more calls of the reference step whose results nothing reads or that repeat an identical computation:
+#   * the encoder's `fc1` 1x1 conv at 147^2 (`backbones/encoders.py:44,55,68` -> c1): `train.py:279` takes c2, c3, c4 only.
+#     ASIS_ELIDE_C1=0 runs it (34 GF + 1.06 GB of fp32 writes at 12 images);
+#   * the patch embedding: the reference evaluates `model.patch_embed(inp)` once inside `get_intermediate_layers` (pass A,
+#     `train.py:287`) and once for pass B (`:300`) on the same input with the same frozen weights; the engine computes it once.
+#     ASIS_SHARE_PATCH_EMBED=0 computes it twice.
+# bench.py reports both settings (config.c1_elided, config.patch_embed_shared) and times the step with EVERY reference call
+# executed as ``secondary.all_reference_calls``.
+elide_c1 = os.environ.get("ASIS_ELIDE_C1", "1") not in ("0", "")
+share_patch_embed = os.environ.get("ASIS_SHARE_PATCH_EMBED", "1") not in ("0", "")
 
 # LayerNorm folded into the linear layers around it (include/asis_hip.h: asis_gemm_desc.C_lo / rowstats / res16 / ln_mr): inside the
 # frozen trunk the residual stream travels between GEMM epilogues as two 16-bit planes (hi + lo = the 4 bytes per element of the

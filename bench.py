@@ -8,10 +8,18 @@
 One "step" = one `train.py:268-436` iteration on a batch of 12 synthetic 588x588 images per
 GPU, already resident in HBM: CNN encoder, ViT-L pass A (24 blocks, cls+pos) + pass B (21 blocks), 4 x [block,
 CAViT, CACNN], decoder forward, resize+softmax+Dice, decoder backward, gradient all-reduce (N > 1), SGD.
-Nothing is cached between steps; ONE call of the reference step is elided: the last stage's CACNN (`train.py:372-386`), whose
-output no later line reads (the decoder takes c4 from the encoder, `train.py:395`) — ``--run-dead-cacnn`` runs it too; the JSON
-line reports ``config.dead_cacnn_elided``.  Weights are random-init of the named architecture
-(no network: `adaptersis_amd.utils.weights`), data is synthetic of the named shape.
+Nothing is cached between steps.  THREE calls of the reference step are elided in the timed region, none of which can change
+a result (``config.dead_cacnn_elided``, ``config.c1_elided``, ``config.patch_embed_shared`` in the JSON line report them):
+  * the last stage's CACNN (`train.py:372-386`), whose output no later line reads (the decoder takes c4 from the encoder, `:395`);
+  * the encoder's `fc1` 1x1 conv at 147^2 -> c1 (`backbones/encoders.py:44,55,68`), which `train.py:279` drops;
+  * the second evaluation of the patch embedding (pass A computes it inside `get_intermediate_layers`, pass B again on the same
+    input and frozen weights: `train.py:287,300`) — computed once and shared.
+``--all-reference-calls`` runs all three; without it the line still carries the figure of such a run as
+``secondary.all_reference_calls`` (a short extra pass AFTER the timed region: 5 warm-up + 10 steps), next to ``secondary.bf16``
+(``--operand bf16`` on the same modules) and ``host_enqueue_ms_per_step`` (how long the host takes to enqueue one step with the
+GPU idle at the start: Python + ctypes + HIP launches; far below ms_per_step = the GPU is the limiter).
+Weights are random-init of the named architecture (no network: `adaptersis_amd.utils.weights`), data is synthetic of the
+named shape.
 
 Output: ONE JSON line on rank 0 (see README / DESIGN.md for the fields).
 """
@@ -30,6 +38,10 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 MFMA_F16_DENSE_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16/f16 (no sparsity)
+# what a bare f16 MFMA loop (operands in registers, every SIMD's matrix pipe 100 % busy) sustains on RANDOM data on this pool's
+# MI355X: the chip clocks it at 1.65 GHz (2.38 GHz and 2.49 PFLOP/s on all-zero data).  scripts/mfma_peak.hip,
+# profiles/r05_mfma_sustained_peak.txt.  Reported beside the nominal peak, never instead of it.
+MFMA_F16_SUSTAINED_RANDOM_TFLOPS = 1690.0
 
 
 def build_engine(arch: str, dev, lr: float, mode: str = "reference_exact", train_encoder: bool = False):
@@ -298,6 +310,11 @@ def main():
                          "off), so that a rocprofv3 kernel trace of this command shows un-overlapped launch durations")
     ap.add_argument("--run-dead-cacnn", action="store_true",
                     help="also run the last stage's CACNN, whose output nothing reads (train.py:372-386; elided by default: identical results)")
+    ap.add_argument("--all-reference-calls", action="store_true",
+                    help="run every call of the reference step in the timed region: the dead CACNN, the encoder's c1 conv and the "
+                         "second patch embedding (all three elided by default: identical results)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the short extra passes after the timed region (secondary.all_reference_calls, secondary.bf16, host enqueue time)")
     ap.add_argument("--cpu-baseline-batch", type=int, default=1, help="batch of the timed CPU (oracle) step: 1 or 2")
     a = ap.parse_args()
 
@@ -343,6 +360,8 @@ def main():
         config.encoder_stream = config.vt_stream = config.wgrad_stream = config.dual_stream = False
     if a.run_dead_cacnn:
         config.elide_dead_cacnn = False
+    if a.all_reference_calls:
+        config.elide_dead_cacnn = config.elide_c1 = config.share_patch_embed = False
     if a.operand:
         config.set_operand_dtype(torch.float16 if a.operand == "f16" else torch.bfloat16)
         config.loss_scale = 65536.0 if a.operand == "f16" else 1.0
@@ -393,6 +412,58 @@ def main():
         config.dual_stream = du_stream
         ops.PROFILE = None
 
+    # ---- secondary figures (never inside the timed region): short passes of 5 warm-up + 10 steps each ----------------
+    secondary, host_enqueue_ms = None, None
+    if not a.no_secondary:
+        def timed(e, warm=5, steps=10):
+            for _ in range(warm):
+                e.train_step(img, tgt)
+            barrier()
+            t_ = time.perf_counter()
+            for _ in range(steps):
+                e.train_step(img, tgt)
+            barrier()
+            dt_ = torch.tensor([time.perf_counter() - t_], dtype=torch.float64, device=dev)
+            if world > 1:
+                dist.all_reduce(dt_, op=dist.ReduceOp.MAX)
+            return float(dt_) / steps
+
+        # host enqueue time of one step: GPU idle at the start, five steps enqueued back to back, clock stopped when the last
+        # launch call returns (before any synchronisation)
+        barrier()
+        t_ = time.perf_counter()
+        for _ in range(5):
+            eng.train_step(img, tgt)
+        host_enqueue_ms = (time.perf_counter() - t_) / 5 * 1e3
+        barrier()
+        secondary = {}
+        if a.config == 3 and not a.all_reference_calls:
+            saved = (config.elide_dead_cacnn, config.elide_c1, config.share_patch_embed)
+            config.elide_dead_cacnn = config.elide_c1 = config.share_patch_embed = False
+            t_all = timed(eng)
+            config.elide_dead_cacnn, config.elide_c1, config.share_patch_embed = saved
+            secondary["all_reference_calls"] = {
+                "value": round(a.batch * world / t_all, 3), "unit": "img/s", "ms_per_step": round(t_all * 1e3, 3), "steps": 10, "warmup": 5,
+                "what": "the same step with the dead CACNN call, the encoder's c1 conv and the second patch embedding executed"}
+        if a.config == 3 and a.operand is None and not a.train_adapters:
+            # bf16 operands on the same modules (derived 16-bit operand caches are keyed by dtype); a new engine = new flat buckets
+            from adaptersis_amd.backbones.engines import SegEngine
+            old_dt, old_ls = config.operand_dtype, config.loss_scale
+            config.set_operand_dtype(torch.bfloat16)
+            config.loss_scale = 1.0
+            try:
+                eng_bf = SegEngine(eng.model, eng.backbone_encoder, eng.cross_vit, eng.cross_cnn, eng.seg_decoder, lr=0.01,
+                                   mode="reference_exact")
+                t_bf = timed(eng_bf)
+                secondary["bf16"] = {"value": round(a.batch * world / t_bf, 3), "unit": "img/s", "ms_per_step": round(t_bf * 1e3, 3),
+                                     "steps": 10, "warmup": 5,
+                                     "what": "--operand bf16 (no LayerNorm fold, no MX pass, no halo-tile convolution: f16-only paths); "
+                                             "parity of this mode: tests/test_gpu_numerics.py"}
+                del eng_bf
+            finally:
+                config.set_operand_dtype(old_dt)
+                config.loss_scale = old_ls
+
     # ---- roofline of the dominant kernel: the dense MFMA GEMM (csrc/gemm_big.h) ---------------------------
     roof = None
     if prof:
@@ -413,7 +484,11 @@ def main():
         traffic, traffic_src = pmc_traffic(("gemm_big_kernel", "gemm_p8_kernel"), ("Lb0ELb0ELi32ELi4E", "Lb0ELb0ELi64ELi1ELb1E", "gemm_p8_kernel"))
         roof = {"bound": "mfma", "kernel": "the dense LDS-DMA MFMA GEMM on v_mfma_f32_16x16x32 (all dense GEMM launches of the step): gemm_p8_kernel (csrc/gemm_p8.h, persistent 8-phase 256x256x64 form: K <= 2048 launches with >= 256 tiles), gemm_big_kernel (csrc/gemm_big.h: the one-tile-per-workgroup 8-phase form for K = 4096 and the batched V^T GEMMs, 256x128x32 two-workgroup form for the rest)",
                 "achieved": round(achieved, 1), "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / MFMA_F16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                "frac": round(achieved / MFMA_F16_DENSE_PEAK_TFLOPS, 4),
+                "peak_sustained": MFMA_F16_SUSTAINED_RANDOM_TFLOPS, "frac_of_sustained": round(achieved / MFMA_F16_SUSTAINED_RANDOM_TFLOPS, 4),
+                "peak_sustained_source": "bare f16 MFMA loop on random data, matrix pipe 100 % busy, clocked at 1.65 GHz by the chip "
+                                         "(scripts/mfma_peak.hip, profiles/r05_mfma_sustained_peak.txt); `peak` is the nominal 2.4 GHz figure",
+                "traffic": traffic, "traffic_source": traffic_src,
                 "measured_in": "a second pass of the same steps after the timed region, every launch on ONE stream (encoder / V^T / "
                                "weight-gradient / dual-trunk side streams off) with a HIP event pair around each GEMM launch",
                 "launches_per_step": n // a.steps, "avg_launch_ms": round(avg_ms, 4),
@@ -453,12 +528,17 @@ def main():
                                         "wgrad": bool(config.wgrad_stream), "dual_trunk": bool(config.dual_stream)},
                        "split_attn_out": bool(getattr(eng, "split_attn_out", False)), "precise_level": int(getattr(eng, "precise_level", config.precise_level)),
                        "fold_attn_scale": bool(config.fold_attn_scale), "fused_qkv": bool(config.fused_qkv),
-                       "dead_cacnn_elided": bool(config.elide_dead_cacnn),
+                       "dead_cacnn_elided": bool(config.elide_dead_cacnn), "c1_elided": bool(config.elide_c1),
+                       "patch_embed_shared": bool(config.share_patch_embed),
                        "ln_fold": bool(config.ln_fold and config.operand_dtype == torch.float16),
                        "mx_conv": bool(config.mx_conv_on()), "mx_dense": bool(config.mx_dense_on()),
                        "conv_halo": bool(ops.CONV_HALO and config.mx_conv_on()), "fuse_cls_up": bool(ops.FUSE_CLS_UP),
                        "skipped_optimizer_steps": int(eng.optimizer.skipped_steps)},
         }
+        if host_enqueue_ms is not None:
+            out["host_enqueue_ms_per_step"] = round(host_enqueue_ms, 2)
+        if secondary:
+            out["secondary"] = secondary
         if roof:
             out["roofline"] = roof
         if world == 1 and not a.no_cpu_baseline and a.config == 3:

@@ -116,20 +116,20 @@ def test_config4_vitl_24_blocks_unfrozen(dev, mode):
     assert abs(float(loss) - float(g[f"{tag}.loss"])) < 1e-4
     groups = {"vit": (eng.vit_bucket.views, f"{tag}.grad.vit."), "adapter": (eng.adapter_bucket.views, f"{tag}.grad."),
               "encoder": (eng.encoder_bucket.views, f"{tag}.grad."), "decoder": (eng.bucket.views, f"{tag}.grad.dec.")}
+    # Bounds per parameter group = 2x what this test measures (round 5; deterministic kernels: the figures repeat run to run):
+    #   stress weights    vit max 8.2e-2 / median 2.6e-2, adapter 4.0e-2 / 2.3e-2, encoder 3.4e-2 / 2.8e-2, decoder 3.8e-2 / 1.4e-2
+    #   reference init    vit max 6.3e-2 / median 5.5e-3, adapter 6.3e-3,          encoder 7.4e-3 / 4.7e-3, decoder 6.9e-3 / 2.1e-3
+    # The floor of the stress case is step-level conditioning (ReLU flips of the head, MSDA cell crossings: DESIGN.md §3,
+    # tests/test_grad_conditioning.py), the floor of the init case the 11 significant bits of the 16-bit gradient tensors
+    # (the ViT's LayerScale'd branch gradients carry a per-branch power-of-two scale: blocks.Block._ls_pow2; 0.44 in round 3).
+    bounds = {"kernel": {"vit": (1.7e-1, 5.2e-2), "adapter": (8.0e-2, 4.6e-2), "encoder": (7.0e-2, 5.7e-2), "decoder": (7.7e-2, 2.9e-2)},
+              "init": {"vit": (1.3e-1, 1.1e-2), "adapter": (1.3e-2, 1.3e-2), "encoder": (1.5e-2, 9.4e-3), "decoder": (1.4e-2, 4.2e-3)}}[mode]
     for nm, (views, pre) in groups.items():
         n, gmax, gmed, worst = _grad_stats(views, g, pre, skip_bias0=(nm == "decoder"))
         print(f"  {tag} {nm}: n={n} max {gmax:.2e} median {gmed:.2e} worst {worst}")
-        if mode == "init":
-            # reference-init weights (LayerScale 1e-5, CAViT gamma 0: `cross_vit.gamma` is the only adapter gradient).  Since
-            # round 4 every group is checked at this init too: the ViT's LayerScale'd branch gradients (gamma W ~ 2e-7, below
-            # fp16's subnormal range even under the 2^16 loss scale: rel-L2 0.44 median in round 3) carry a per-branch
-            # power-of-two scale through their 16-bit tensors (blocks.Block._ls_pow2): measured median 5.5e-3, max 6.3e-2
-            assert n >= (1 if nm == "adapter" else 10)
-            assert gmax < 1e-1 and gmed < 2e-2, (nm, worst)
-            continue
-        assert n >= 10
-        # step-level bounds as at 4 blocks (test_gpu_e2e.py): ReLU flips of the head / MSDA cell crossings set the floor
-        assert gmax < 2.5e-1 and gmed < 5e-2, (nm, worst)
+        # reference-init weights: LayerScale 1e-5, CAViT gamma 0 (`cross_vit.gamma` is the only adapter gradient)
+        assert n >= (1 if (nm == "adapter" and mode == "init") else 10)
+        assert gmax < bounds[nm][0] and gmed < bounds[nm][1], (nm, gmax, gmed, worst)
 
 
 def test_config4_init_bf16_operands(dev):

@@ -106,3 +106,61 @@ def test_f16_operand_range_with_massive_activations(dev):
     print(f"massive activations (|x|max {amax:.0f}): x_final {e_all:.2e} (non-outlier channels {e_rest:.2e}) logits {e_lg:.2e}")
     assert e_rest < 1e-3 and e_lg < 1e-3
     assert abs(float(loss) - float(oloss)) < 1e-4
+
+
+def test_ln_fold_chain_with_massive_activations(dev):
+    """VERDICT r4 / ADVICE r4: the LayerNorm-fold chain (residual stream as f16 hi + lo planes, hi as the ONLY A operand of q|k,
+    V^T and fc1, LayerNorm statistics from epilogue partial sums, rstd * (acc - mean * cs)) under DINOv2-like outlier channels.
+    The massive-activation step test above runs vit_tiny at 224^2, where ``Block.fold_ok`` is false; this one runs a run of four
+    ViT-L-width blocks on 17 645 stacked rows (5 + 5 images at 588^2: the smallest batch at which every GEMM of the chain takes a
+    kernel that implements the fold fields) and asserts the chain is really taken.  Outliers: one channel at +300 from the
+    input, one at -100 .. -1000 from a fc2 bias through LayerScale, 6x fc1 weights in one block (pre-activations of +-30), 3x qkv
+    in another (saturated attention rows).  Oracle: the fp32 restatement block by block on the same rows."""
+    from adaptersis_amd.dinov2.layers.blocks import run_blocks
+    from adaptersis_amd.dinov2.models import vision_transformer as vits
+    if config.operand_dtype != torch.float16 or not config.ln_fold:
+        pytest.skip("the LayerNorm fold is an f16 path (ASIS_LN_FOLD=1)")
+    arch = "vit_large_d4"
+    D, depth, heads, ffn = W.VIT_CONFIGS[arch]
+    sd = _massive_weights(arch)
+    model = vits.__dict__[arch](patch_size=14, img_size=518, init_values=1e-5, ffn_layer=ffn, block_chunks=0)
+    model.load_state_dict(sd)
+    model = model.to(dev).eval()
+    Bn, N = 5, 1764
+    segs = [(Bn, N + 1), (Bn, N)]
+    R = sum(b * n for b, n in segs)
+    x0 = W.tensor("lnfold.massive.x", (R, D), 1.0)
+    x0[:, 5] += 300.0                                     # what the patch-embed bias outlier puts into the stream
+    blocks = list(model.blocks)
+    assert all(blk.fold_ok(R, segs) for blk in blocks), "the fold chain is not taken at this shape"
+    y = run_blocks(blocks, x0.to(dev), segs).float().cpu()
+    assert torch.isfinite(y).all()
+    ref = []
+    r0 = 0
+    with torch.no_grad():
+        for b, n in segs:
+            t = x0[r0:r0 + b * n].view(b, n, D)
+            for i in range(depth):
+                t = O.block(t, sd, f"blocks.{i}", heads)
+            ref.append(t.reshape(b * n, D))
+            r0 += b * n
+    ref = torch.cat(ref)
+    amax = float(ref.abs().max())
+    assert amax > 100.0, amax                              # the outliers really are in the stream
+    keep = [c for c in range(D) if c not in (5, 77)]
+    e_all, e_rest = rel_l2(y, ref), rel_l2(y[:, keep], ref[:, keep])
+    e5, e77 = rel_l2(y[:, 5], ref[:, 5]), rel_l2(y[:, 77], ref[:, 77])
+    print(f"LayerNorm-fold chain, massive activations (|x|max {amax:.0f}, {R} rows): all {e_all:.2e} non-outlier channels {e_rest:.2e} "
+          f"channel 5 {e5:.2e} channel 77 {e77:.2e}")
+    # the same bars as the step-level test: 1e-3 on the channels that carry the signal; the outlier channels themselves are
+    # large values carried exactly by the hi + lo planes (22 significant bits)
+    assert e_rest < 1e-3 and e5 < 1e-4 and e77 < 1e-3
+    # and against the unfolded path on the same rows: the fold changes WHERE the LayerNorm is applied, not what is computed
+    old = config.ln_fold
+    try:
+        config.ln_fold = False
+        y0 = run_blocks(blocks, x0.to(dev), segs).float().cpu()
+    finally:
+        config.ln_fold = old
+    print(f"  unfolded path on the same rows: non-outlier channels {rel_l2(y0[:, keep], ref[:, keep]):.2e}; fold vs unfolded {rel_l2(y[:, keep], y0[:, keep]):.2e}")
+    assert rel_l2(y[:, keep], y0[:, keep]) < 1e-3
