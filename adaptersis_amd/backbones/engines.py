@@ -167,6 +167,13 @@ class SegEngine(nn.Module):
         # evaluations (BASELINE config 5: 1.30e-3 on single 16-bit operands, 3.0e-4 on level 2; tests/test_gpu_fulldepth.py)
         self.precise_level = config.precise_level_policy if config.precise_level_policy is not None else \
             (2 if (self.is_mla and len(model.blocks) >= 40) else 0)
+        # ... and WHICH linear layers of a block run split there (config.precise_parts): the automatic level 2 of config 5 needs
+        # the attention output (proj) and the LayerNorm output in front of w12 only — 8.3e-4 on the full-depth stress golden at
+        # 58.9 img/s against 3.1e-4 at 48.2 with all four layers split (A/B table in config.py); a level forced by
+        # ASIS_PRECISE_LEVEL keeps all four unless ASIS_PRECISE_PARTS names a subset
+        all_parts = frozenset(("qkv", "proj", "fc1", "fc2"))
+        self.precise_parts = config.precise_parts_policy if config.precise_parts_policy is not None else \
+            (frozenset(("proj", "fc1")) if (config.precise_level_policy is None and self.precise_level == 2) else all_parts)
         self.vit_bucket = None
         if train_backbone:
             if mode != "train_adapters":
@@ -263,6 +270,7 @@ class SegEngine(nn.Module):
         block on pass B and of CAViT / CACNN."""
         config.split_attn_out = self.split_attn_out
         config.precise_level = self.precise_level
+        config.precise_parts = self.precise_parts
         m = self.model
         B, _, H, W = inp.shape
         inp = inp.float().contiguous()
@@ -372,6 +380,7 @@ class SegEngine(nn.Module):
         pass B | None, CAViT save, CACNN save | None) — stage 0 is CAViT alone, stages 1..3 are block -> CACNN -> CAViT."""
         config.split_attn_out = self.split_attn_out
         config.precise_level = self.precise_level
+        config.precise_parts = self.precise_parts
         m = self.model
         B, _, H, W = inp.shape
         inp = inp.float().contiguous()
@@ -539,6 +548,7 @@ class SegEngine(nn.Module):
         when it trains.  -> ((cat_hi, cat_lo|None), saved)."""
         config.split_attn_out = self.split_attn_out
         config.precise_level = self.precise_level
+        config.precise_parts = self.precise_parts
         m = self.model
         B, _, H, W = inp.shape
         inp = inp.float().contiguous()

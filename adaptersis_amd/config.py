@@ -105,6 +105,17 @@ split_attn_out = bool(split_attn_out_policy)     # what the blocks read; SegEngi
 _pl = os.environ.get("ASIS_PRECISE_LEVEL", "auto").lower() or "auto"
 precise_level_policy = None if _pl == "auto" else int(_pl)
 precise_level = int(precise_level_policy or 0)
+# Which linear layers of a block run on split operands at precise_level 2 (ASIS_PRECISE_PARTS, comma separated, of qkv, proj,
+# fc1 / w12, fc2 / w3; "auto" (default) = per engine).  On the MX form a split layer costs 1.5 passes whether or not the weight's
+# residual takes part (the block-scaled pass pairs both planes), so the saving left is to run a whole layer single.  Measured
+# on config 5 (ViT-g/14 x 40 + MLA: full-depth stress golden at batch 1 / bench.py --config 5 at batch 12, round 5, one box,
+# profiles/r05_c5_parts_ab.txt):   all four 3.1e-4 / 48.2 img/s;  qkv,proj,fc1 6.8e-4 / 54.1;  proj,fc1,fc2 5.7e-4 / 51.9;
+# proj,fc1 8.3e-4 / 58.9;  qkv,proj 1.12e-3 (fails) / 62.1;  proj alone (= level 0 + split_attn_out) 1.21e-3 (fails) / 68.8.
+# SegEngine's automatic policy for that geometry is therefore {proj, fc1}: the attention output and the LayerNorm output in
+# front of the widest GEMM — the two largest terms of tests/precision_probe.py (1.22e-3, 7.5e-4) — and nothing else.
+_pp = os.environ.get("ASIS_PRECISE_PARTS", "auto").lower() or "auto"
+precise_parts_policy = None if _pp == "auto" else frozenset(filter(None, _pp.replace("w12", "fc1").replace("w3", "fc2").split(",")))
+precise_parts = precise_parts_policy if precise_parts_policy is not None else frozenset(("qkv", "proj", "fc1", "fc2"))
 trunk_streams = int(os.environ.get("ASIS_TRUNK_STREAMS", "2") or 2)     # 4: each ViT pass as two image groups (lab)
 
 # The LAST adapter stage's CACNN (`train.py:372-386`) writes a pyramid-token tensor that nothing reads: the decoder input takes

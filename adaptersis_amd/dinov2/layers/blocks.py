@@ -507,28 +507,44 @@ class Block(_Packed):
         a, m = self.attn, self.mlp
         g1 = self._f32("g1", self.ls1.gamma) if isinstance(self.ls1, LayerScale) else None
         g2 = self._f32("g2", self.ls2.gamma) if isinstance(self.ls2, LayerScale) else None
-        xn, xn_lo, xn_mx = self._ln_split("n1", self.norm1, x2, self._mx_ok(a, "qkv", a.qkv, R))
-        qkv = self._split_lin(a, "qkv", a.qkv, xn, xn_lo, xn_mx, bias_n=a._f32("qkv_b", a.qkv.bias))     # 16-bit out: q, k, v operands
+        parts = config.precise_parts      # which of the four linear layers run split (default: all)
+        n1w, n1b = self._f32("n1w", self.norm1.weight), self._f32("n1b", self.norm1.bias)
+        if "qkv" in parts:
+            xn, xn_lo, xn_mx = self._ln_split("n1", self.norm1, x2, self._mx_ok(a, "qkv", a.qkv, R))
+            qkv = self._split_lin(a, "qkv", a.qkv, xn, xn_lo, xn_mx, bias_n=a._f32("qkv_b", a.qkv.bias))     # 16-bit out: q, k, v operands
+        else:
+            qkv = ops.gemm(ops.layernorm(x2, n1w, n1b, self.norm1.eps, dt), a._w16("qkv", a.qkv.weight), bias_n=a._f32("qkv_b", a.qkv.bias))
         o = torch.empty((R, D), device=x2.device, dtype=dt)
-        o_lo = torch.empty_like(o)
+        o_lo = torch.empty_like(o) if "proj" in parts else None
         r0 = 0
         for B, N in segs:
             r1 = r0 + B * N
             vt = ops.transpose_tokens(qkv[r0:r1, 2 * D:], B, N)
-            ops.attention_fwd(qkv[r0:r1, :D], qkv[r0:r1, D:2 * D], vt, B, a.num_heads, N, a.scale, out=o[r0:r1], out_lo=o_lo[r0:r1])
+            ops.attention_fwd(qkv[r0:r1, :D], qkv[r0:r1, D:2 * D], vt, B, a.num_heads, N, a.scale, out=o[r0:r1],
+                              out_lo=None if o_lo is None else o_lo[r0:r1])
             r0 = r1
         if r0 != R:
             raise ValueError("forward_rows: segments do not cover the rows")
-        x1 = self._split_lin(a, "proj", a.proj, o, o_lo, out_f32=True, bias_n=a._f32("proj_b", a.proj.bias), scale_n=g1, res=x2)
+        pkw = dict(out_f32=True, bias_n=a._f32("proj_b", a.proj.bias), scale_n=g1, res=x2)
+        x1 = self._split_lin(a, "proj", a.proj, o, o_lo, **pkw) if o_lo is not None else ops.gemm(o, a._w16("proj", a.proj.weight), **pkw)
+        n2w, n2b = self._f32("n2w", self.norm2.weight), self._f32("n2b", self.norm2.bias)
+        lin_in, k_in = (m.fc1, "fc1") if isinstance(m, Mlp) else (m.w12, "w12")
+        lin_out, k_out = (m.fc2, "fc2") if isinstance(m, Mlp) else (m.w3, "w3")
+        ikw = dict(out_f32=True, bias_n=m._f32(k_in + "_b", lin_in.bias))
+        if "fc1" in parts:
+            xn2, xn2_lo, xn2_mx = self._ln_split("n2", self.norm2, x1, self._mx_ok(m, k_in, lin_in, R))
+            hpre = self._split_lin(m, k_in, lin_in, xn2, xn2_lo, xn2_mx, **ikw)
+        else:
+            hpre = ops.gemm(ops.layernorm(x1, n2w, n2b, self.norm2.eps, dt), m._w16(k_in, lin_in.weight), **ikw)
+        split_out = "fc2" in parts
         if isinstance(m, Mlp):
-            xn2, xn2_lo, xn2_mx = self._ln_split("n2", self.norm2, x1, self._mx_ok(m, "fc1", m.fc1, R))
-            hpre = self._split_lin(m, "fc1", m.fc1, xn2, xn2_lo, xn2_mx, out_f32=True, bias_n=m._f32("fc1_b", m.fc1.bias))
-            h, h_lo = ops.gelu_split(hpre, dt)
-            return self._split_lin(m, "fc2", m.fc2, h, h_lo, out_f32=True, bias_n=m._f32("fc2_b", m.fc2.bias), scale_n=g2, res=x1)
-        xn2, xn2_lo, xn2_mx = self._ln_split("n2", self.norm2, x1, self._mx_ok(m, "w12", m.w12, R))
-        h12 = self._split_lin(m, "w12", m.w12, xn2, xn2_lo, xn2_mx, out_f32=True, bias_n=m._f32("w12_b", m.w12.bias))
-        h, h_lo = ops.swiglu(h12, dt, split=True)
-        return self._split_lin(m, "w3", m.w3, h, h_lo, out_f32=True, bias_n=m._f32("w3_b", m.w3.bias), scale_n=g2, res=x1)
+            h, h_lo = ops.gelu_split(hpre, dt, split=split_out)
+        else:
+            h, h_lo = ops.swiglu(hpre, dt, split=True) if split_out else (ops.swiglu(hpre, dt), None)
+        okw = dict(out_f32=True, bias_n=m._f32(k_out + "_b", lin_out.bias), scale_n=g2, res=x1)
+        if split_out:
+            return self._split_lin(m, k_out, lin_out, h, h_lo, **okw)
+        return ops.gemm(h, m._w16(k_out, lin_out.weight), **okw)
 
     def _lin_ln_folded(self, key: str, lin: nn.Linear, norm: nn.LayerNorm):
         """(W diag(norm.weight) as 16 bits, b + W norm.bias, row sums of the rounded W') of a linear layer behind a LayerNorm"""

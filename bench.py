@@ -527,6 +527,7 @@ def main():
                        "side_streams": {"encoder": bool(config.encoder_stream), "vt": bool(config.vt_stream),
                                         "wgrad": bool(config.wgrad_stream), "dual_trunk": bool(config.dual_stream)},
                        "split_attn_out": bool(getattr(eng, "split_attn_out", False)), "precise_level": int(getattr(eng, "precise_level", config.precise_level)),
+                       "precise_parts": (sorted(getattr(eng, "precise_parts", config.precise_parts)) if int(getattr(eng, "precise_level", 0)) >= 2 else None),
                        "fold_attn_scale": bool(config.fold_attn_scale), "fused_qkv": bool(config.fused_qkv),
                        "dead_cacnn_elided": bool(config.elide_dead_cacnn), "c1_elided": bool(config.elide_c1),
                        "patch_embed_shared": bool(config.share_patch_embed),
