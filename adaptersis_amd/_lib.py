@@ -77,7 +77,6 @@ SIGNATURES = {
     "asis_version": [],
     "asis_device_count": [],
     "asis_gemm": [_vp, C.POINTER(GemmDesc)],
-    "asis_gemm_group": [_vp, C.POINTER(GemmDesc), _i],
     "asis_gemm_tiles_m": [_i],
     "asis_absmax_f32": [_vp, _vp, _i64, _i, _i64, _vp, _i],
     "asis_bn_relu_absmax": [_vp, _vp, _vp, _vp, _i64, _i, _i, _vp],
@@ -99,8 +98,6 @@ SIGNATURES = {
     "asis_attention_fwd_qkv": [_vp, _i, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i, _i, _i, _i, _i, _f, _i, _vp],
     "asis_attention_fwd_lse": [_vp, _i, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _i, _f, _vp],
     "asis_transpose_tokens": [_vp, _i, _vp, _i64, _vp, _i64, _i, _i, _i],
-    "asis_attention_bwd": [_vp, _i, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp,
-                           _i64, _i, _i, _i, _f],
     "asis_attention_bwd_rows": [_vp, _i, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i,
                                 _i, _f],
     "asis_msda_bwd": [_vp, _i, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i],
@@ -181,6 +178,8 @@ SIGNATURES = {
     "asis_bn_bwd_absmax": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _vp, _i64, _i],
     "asis_wgrad_splits": [_i64, _i, _i],
     "asis_wgrad": [_vp, C.POINTER(WgradDesc)],
+    "asis_conv3x3_wgrad_halo_nblk": [_i, _i, _i, _i, _i],
+    "asis_conv3x3_wgrad_halo": [_vp, _i, _vp, _i64, _vp, _vp, _i, _i, _i, _i, _i, _i],
     "asis_sgd_momentum": [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i],
     "asis_augment": [_vp] * 13 + [_i, _i],
     "asis_augment_geo_u8": [_vp] * 12 + [_i, _i],

@@ -3,7 +3,7 @@
 //   P = softmax(c Q K^T),  O = P V          (c = head_dim^-0.5, dinov2/layers/attention.py:60-66)
 //   dV = P^T dO ;  dP = dO V^T ;  dS = c P (dP - D),  D[q] = sum_d dO[q,d] O[q,d] ;  dQ = dS K ;  dK = dS^T Q
 //
-// Same mathematics and the same two-kernel split as attention_bwd.hip (query-stationary dQ kernel, key-stationary dK / dV
+// Same mathematics and the same two-kernel split as the round-1 form it replaces (query-stationary dQ kernel, key-stationary dK / dV
 // kernel: seven MFMA products instead of five, no atomics, bit-reproducible — with head dim 64 the f32 atomics of a
 // one-kernel form would move 86 MB of adds per key block, above the chip's atomic rate for the whole pass), rebuilt on
 // the forward kernel's structure (attention.hip: attn_fwd_pipe_kernel):
@@ -81,8 +81,8 @@ __global__ __launch_bounds__(256) void attn_rowdot_neg_kernel(const T* __restric
 //   S^T = K Q^T, dP'^T = V (c dO)^T - c D   (A = K / V rows from LDS, B = Q / dO fragments in registers; the accumulator's
 //                                            column is the query, so lse2[q] and D[q] are per-lane scalars)
 //   dS'^T = P^T * dP'^T,  dQ^T += K^T dS'^T  (A = K^T by transposing reads of the K tile, B = dS'^T from the accumulator)
-template <typename T, bool CFOLD, int OCC = 2>
-__global__ __launch_bounds__(256, OCC) void attn_bwd_dq_pipe_kernel(const T* __restrict__ q, const T* __restrict__ k,
+template <typename T, bool CFOLD>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_pipe_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                                   const T* __restrict__ v, int64_t ld,
                                                                   const T* __restrict__ dO, int64_t lddo,
                                                                   const float* __restrict__ lse2, const float* __restrict__ Dn,
@@ -409,13 +409,7 @@ static void launch_rows(hipStream_t s, const void* q, const void* k, const void*
   hipLaunchKernelGGL((attn_rowdot_neg_kernel<T>), dim3((unsigned)nd), dim3(256), 0, s, (const T*)o, ldo, (const T*)dO, lddo, D,
                      B1, N1, B2, N2, H, -scale);
   dim3 grid((N + 127) / 128, H, B), block(256);
-  static const int occ3 = [] { const char* e = getenv("ASIS_ATTN_BWD_OCC"); return e && atoi(e) == 3; }();   // lab
-  if (cfold && occ3) {
-    hipLaunchKernelGGL((attn_bwd_dq_pipe_kernel<T, true, 3>), grid, block, 0, s, (const T*)q, (const T*)k, (const T*)v, ld,
-                       (const T*)dO, lddo, lse2, D, (T*)dq, lddq, H, B1, N1, N2, scale, sl);
-    hipLaunchKernelGGL((attn_bwd_dkv_pipe_kernel<T, true>), grid, block, 0, s, (const T*)q, (const T*)k, (const T*)v, ld,
-                       (const T*)dO, lddo, lse2, D, (T*)dk, (T*)dv, lddq, H, B1, N1, N2, scale, sl);
-  } else if (cfold) {
+  if (cfold) {
     hipLaunchKernelGGL((attn_bwd_dq_pipe_kernel<T, true>), grid, block, 0, s, (const T*)q, (const T*)k, (const T*)v, ld,
                        (const T*)dO, lddo, lse2, D, (T*)dq, lddq, H, B1, N1, N2, scale, sl);
     hipLaunchKernelGGL((attn_bwd_dkv_pipe_kernel<T, true>), grid, block, 0, s, (const T*)q, (const T*)k, (const T*)v, ld,

@@ -207,13 +207,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const asis_gemm_desc 
 }
 
 #include "gemm_big.h"
-#include "gemm_persist.h"
 #include "gemm_p8.h"
-#include "gemm_p8g.h"
 
 // ASIS_GEMM_P8 / asis_gemm_set_option("p8", v): -1 = not read yet
 static int g_gemm_p8 = -1;
-static int g_gemm_noepi = -1;   // ASIS_GEMM_NOEPI / "noepi" (lab: main loop only; wrong results)
 static bool ph8_m16_on() { static const int v = [] { const char* e = getenv("ASIS_GEMM_8P_M16"); return e ? atoi(e) : 1; }(); return v != 0; }
 
 template <typename T>
@@ -237,7 +234,6 @@ int launch(hipStream_t s, const asis_gemm_desc& d) {
   // are further K parts of the same stream; 2 = any K, from 16 tiles on (tests); 3 = any K; 0 = never
   {
     if (g_gemm_p8 < 0) { const char* e = getenv("ASIS_GEMM_P8"); g_gemm_p8 = e ? atoi(e) : 1; }
-    if (g_gemm_noepi < 0) { const char* e = getenv("ASIS_GEMM_NOEPI"); g_gemm_noepi = e ? atoi(e) : 0; }
     const int p8 = g_gemm_p8;
     const int64_t p8_tiles = (int64_t)((d.M + 255) / 256) * ((d.N + 255) / 256);
     const int kparts = 1 + (d.A_lo ? 1 : 0) + (d.B_lo ? 1 : 0);
@@ -250,11 +246,7 @@ int launch(hipStream_t s, const asis_gemm_desc& d) {
         al(d.C, 16) && (!d.res || (al(d.res, 16) && d.ldr % 4 == 0)) && (!d.bias_n || al(d.bias_n, 16)) && (!d.scale_n || al(d.scale_n, 16)) &&
         (d.act != ASIS_ACT_GELU_GRAD || (d.aux && al(d.aux, 8) && d.ld_aux % 4 == 0))) {
       const int nwg = p8_tiles >= 256 ? 256 : (int)(p8_tiles / 8) * 8;
-      static const int dim_lab = [] { const char* e = getenv("ASIS_P8_DMA_MFMA"); return e ? atoi(e) : 0; }();   // lab: gemm_p8.h LAB & 2
-      if (g_gemm_noepi) hipLaunchKernelGGL((gemm_p8_kernel<T, 1>), dim3(nwg), dim3(512), 0, s, d, group_m);
-      else if (dim_lab && d.ln_mr) hipLaunchKernelGGL((gemm_p8_kernel<T, 2, 1>), dim3(nwg), dim3(512), 0, s, d, group_m);
-      else if (dim_lab) hipLaunchKernelGGL((gemm_p8_kernel<T, 2>), dim3(nwg), dim3(512), 0, s, d, group_m);
-      else if (d.ln_mr) hipLaunchKernelGGL((gemm_p8_kernel<T, 0, 1>), dim3(nwg), dim3(512), 0, s, d, group_m);   // LayerNorm-fold consumer
+      if (d.ln_mr) hipLaunchKernelGGL((gemm_p8_kernel<T, 1>), dim3(nwg), dim3(512), 0, s, d, group_m);   // LayerNorm-fold consumer
       else hipLaunchKernelGGL((gemm_p8_kernel<T, 0>), dim3(nwg), dim3(512), 0, s, d, group_m);
       return 0;
     }
@@ -338,8 +330,6 @@ int launch(hipStream_t s, const asis_gemm_desc& d) {
     return 0;
   }
   static const int m16 = [] { const char* e = getenv("ASIS_GEMM_M16"); return e ? atoi(e) : 1; }();  // 16x16x32 MFMAs in the default dense form
-  if (g_gemm_noepi < 0) { const char* e = getenv("ASIS_GEMM_NOEPI"); g_gemm_noepi = e ? atoi(e) : 0; }
-  const int noepi = g_gemm_noepi;  // lab: main loop only
   // ASIS_GEMM_8P: 0 = never; 1 (default) = K >= 2048 (fc2 / its input gradient: 343 vs 476 us at 42348x1024x4096) and,
   // since the phases run on 16x16x32 MFMAs (ASIS_GEMM_8P_M16: fc2 391 -> 350 us in isolation), the unbatched K >= 1024
   // GEMMs too (in the step: qk 222 -> 214 us, proj 160 -> 139, fc1 457 -> 441, adapter projections 242 -> 216; +3.5 % on the
@@ -349,35 +339,6 @@ int launch(hipStream_t s, const asis_gemm_desc& d) {
   // many 256x128 tiles); 3 = K >= 2048 only (the round-1 rule); 2 = wherever the shape allows
   static const int ph8 = [] { const char* e = getenv("ASIS_GEMM_8P"); return e ? atoi(e) : 1; }();
   static const int ph8_mink = [] { const char* e = getenv("ASIS_GEMM_8P_MINK"); return e ? atoi(e) : 1024; }();  // lab: see above
-  // ASIS_GEMM_PERSIST=1: the persistent form (gemm_persist.h) for the plain dense launches it covers
-  static const int persist = [] { const char* e = getenv("ASIS_GEMM_PERSIST"); return e ? atoi(e) : 0; }();
-  if (persist && big_mode && !d.conv && !d.stats && !d.bias_m && !d.aux && d.batch == 1 && d.K % 64 == 0 && d.K >= 256 &&
-      d.M >= 1024 && d.N >= 128 && vec_ok && (d.act == ASIS_ACT_NONE || d.act == ASIS_ACT_GELU) &&
-      (reinterpret_cast<uintptr_t>(d.C) & 15) == 0 && (!d.res || ((d.ldr & 3) == 0 && (reinterpret_cast<uintptr_t>(d.res) & 15) == 0)) &&
-      (!d.bias_n || (reinterpret_cast<uintptr_t>(d.bias_n) & 15) == 0) && (!d.scale_n || (reinterpret_cast<uintptr_t>(d.scale_n) & 15) == 0) &&
-      (persist >= 2 || d.K < 2048)) {
-    const int ntiles = ((d.M + 255) / 256) * ((d.N + 127) / 128);
-    int nwg = 256;
-    while (nwg > 8 && nwg > ntiles) nwg -= 8;
-    dim3 grid(nwg), block(512);
-    const bool gelu = d.act == ASIS_ACT_GELU, res = d.res != nullptr, o32 = d.out_f32 != 0;
-    static const int defer = [] { const char* e = getenv("ASIS_GEMM_DEFER"); return e ? atoi(e) : 1; }();
-    const bool df = defer && d.K >= 18 * 32;   // the deferred form spreads a tile's epilogue over the first 16 K iterations of the next
-    static const int plab = [] { const char* e = getenv("ASIS_PERSIST_LAB"); return e ? atoi(e) : 0; }();
-    asis_gemm_desc dl = d;
-    if (plab) dl.ksplit = 1000 + plab;
-#define PERSIST(ACT, RES, O32)                                                                                             \
-    do {                                                                                                                     \
-      if (noepi) hipLaunchKernelGGL((gemm_persist_kernel<T, ACT, RES, O32, false, 4>), grid, block, 0, s, dl, group_m);       \
-      else if (df) hipLaunchKernelGGL((gemm_persist_kernel<T, ACT, RES, O32, true, 0>), grid, block, 0, s, dl, group_m);     \
-      else hipLaunchKernelGGL((gemm_persist_kernel<T, ACT, RES, O32, false, 0>), grid, block, 0, s, dl, group_m);             \
-    } while (0)
-    if (gelu && !res && !o32) { PERSIST(ASIS_ACT_GELU, false, false); return 0; }
-    if (!gelu && !res && !o32) { PERSIST(ASIS_ACT_NONE, false, false); return 0; }
-    if (!gelu && res && o32) { PERSIST(ASIS_ACT_NONE, true, true); return 0; }
-    if (!gelu && !res && o32) { PERSIST(ASIS_ACT_NONE, false, true); return 0; }
-#undef PERSIST
-  }
   if (ph8 && (ph8 == 2 || d.K >= 2048 || (ph8 == 1 && d.K >= ph8_mink && (int64_t)((d.M + 255) / 256) * ((d.N + 255) / 256) * d.batch >= 128)) && big_mode && !d.conv && !d.stats && d.K % 64 == 0 && d.M >= 256 && d.N >= 256) {
     // 256x256x64 tile, 8-phase main loop (one workgroup per CU: 128 KB of LDS)
     dim3 grid(((d.M + 255) / 256) * ((d.N + 255) / 256), d.batch), block(512);
@@ -387,14 +348,11 @@ int launch(hipStream_t s, const asis_gemm_desc& d) {
     static const int ph8_slab32 = [] { const char* e = getenv("ASIS_GEMM_8P_SLAB32"); return e ? atoi(e) : 0; }();
     const int group_m_f = group_m | (ph8_slab32 ? 0x10000 : 0);
     if (ph8_m16) {
-      if (noepi == 8) hipLaunchKernelGGL((gemm_big_kernel<T, 2, 4, 4, 2, 2, 8, false, false, 64, 1, true, true>), grid, block, 0, s, d, group_m);   // lab: no global stores
-      else if (noepi) hipLaunchKernelGGL((gemm_big_kernel<T, 2, 4, 4, 2, 2, 4, false, false, 64, 1, true, true>), grid, block, 0, s, d, group_m);
-      else if (lnx) hipLaunchKernelGGL((gemm_big_kernel<T, 2, 4, 4, 2, 2, 0, false, false, 64, 1, true, true, 1>), grid, block, 0, s, d, group_m);
+      if (lnx) hipLaunchKernelGGL((gemm_big_kernel<T, 2, 4, 4, 2, 2, 0, false, false, 64, 1, true, true, 1>), grid, block, 0, s, d, group_m);
       else hipLaunchKernelGGL((gemm_big_kernel<T, 2, 4, 4, 2, 2, 0, false, false, 64, 1, true, true>), grid, block, 0, s, d, group_m_f);
       return 0;
     }
-    if (noepi) hipLaunchKernelGGL((gemm_big_kernel<T, 2, 4, 4, 2, 2, 4, false, false, 64, 1, true>), grid, block, 0, s, d, group_m);
-    else hipLaunchKernelGGL((gemm_big_kernel<T, 2, 4, 4, 2, 2, 0, false, false, 64, 1, true>), grid, block, 0, s, d, group_m);
+    hipLaunchKernelGGL((gemm_big_kernel<T, 2, 4, 4, 2, 2, 0, false, false, 64, 1, true>), grid, block, 0, s, d, group_m);
     return 0;
   }
   if (big_mode && !d.conv && !d.stats && d.K % 32 == 0 && d.M >= 256 && d.N >= 128) {
@@ -403,16 +361,8 @@ int launch(hipStream_t s, const asis_gemm_desc& d) {
     // on the fc1 shape (scripts/gemm_lab.hip).  big_mode 2/3 keep the older forms selectable for A/B runs.
     const int bm = 256, bn = (big_mode == 2 && d.N >= 2048) ? 256 : 128;
     dim3 grid(((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn), d.batch), block(512);
-    if (big_mode == 4 && !noepi) {  // lab: four waves of 128x64 (0.75 KB of LDS reads per MFMA instead of 1), two workgroups per CU
-      hipLaunchKernelGGL((gemm_big_kernel<T, 2, 2, 4, 2, 3, 0, false, false, 32, 2>), grid, dim3(256), 0, s, d, group_m);
-      return 0;
-    }
     if (big_mode == 2 && bn == 256) hipLaunchKernelGGL((gemm_big_kernel<T, 2, 4, 4, 2, 2>), grid, block, 0, s, d, group_m);
-    else if (big_mode >= 2 || d.K % 64 != 0 && false) hipLaunchKernelGGL((gemm_big_kernel<T, 4, 2, 2, 2, 3>), grid, block, 0, s, d, group_m);
-    else if (noepi == 8) hipLaunchKernelGGL((gemm_big_kernel<T, 4, 2, 2, 2, 3, 8, false, false, 32, 4>), grid, block, 0, s, d, group_m);
-    else if (noepi == 32) hipLaunchKernelGGL((gemm_big_kernel<T, 4, 2, 2, 2, 3, 32, false, false, 32, 4>), grid, block, 0, s, d, group_m);
-    else if (noepi == 40) hipLaunchKernelGGL((gemm_big_kernel<T, 4, 2, 2, 2, 3, 40, false, false, 32, 4>), grid, block, 0, s, d, group_m);
-    else if (noepi) hipLaunchKernelGGL((gemm_big_kernel<T, 4, 2, 2, 2, 3, 4, false, false, 32, 4>), grid, block, 0, s, d, group_m);
+    else if (big_mode >= 2) hipLaunchKernelGGL((gemm_big_kernel<T, 4, 2, 2, 2, 3>), grid, block, 0, s, d, group_m);
     else if (m16) hipLaunchKernelGGL((gemm_big_kernel<T, 4, 2, 2, 2, 3, 0, false, false, 32, 4, false, true>), grid, block, 0, s, d, group_m);
     else hipLaunchKernelGGL((gemm_big_kernel<T, 4, 2, 2, 2, 3, 0, false, false, 32, 4>), grid, block, 0, s, d, group_m);
     return 0;
@@ -450,63 +400,9 @@ extern "C" int asis_gemm_tiles_m(int M) { return (M + BM - 1) / BM; }
 extern "C" int asis_gemm_set_option(const char* name, int value) {
   ASIS_REQUIRE(name != nullptr, "asis_gemm_set_option: null name");
   if (strcmp(name, "p8") == 0) { g_gemm_p8 = value; return ASIS_OK; }
-  if (strcmp(name, "noepi") == 0) { g_gemm_noepi = value; return ASIS_OK; }
   ASIS_FAIL(ASIS_EINVAL, "asis_gemm_set_option: unknown option '%s'", name);
 }
 
-// ---- grouped persistent launch (gemm_p8g.h) ------------------------------------------------------------------------------
-template <typename T>
-static void launch_group(hipStream_t s, const p8g_args& g, int nwg, int group_m) {
-  hipLaunchKernelGGL((gemm_p8g_kernel<T>), dim3(nwg), dim3(512), 0, s, g, group_m);
-}
-
-extern "C" int asis_gemm_group(void* stream, const asis_gemm_desc* descs, int n) {
-  ASIS_REQUIRE(descs != nullptr && n >= 1 && n <= ASIS_GEMM_GROUP_MAX, "asis_gemm_group: 1..%d problems (got %d)", ASIS_GEMM_GROUP_MAX, n);
-  static const int group_m = [] { const char* e = getenv("ASIS_GEMM_GROUPM"); return e && atoi(e) > 0 ? atoi(e) : 4; }();
-  auto al = [](const void* p, int a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; };
-  p8g_args g;
-  memset(&g, 0, sizeof(g));
-  g.nprob = n;
-  int tile0 = 0;
-  for (int i = 0; i < n; ++i) {
-    const asis_gemm_desc& d = descs[i];
-    ASIS_REQUIRE(d.A && d.B && d.C, "asis_gemm_group: problem %d: null operand pointer", i);
-    ASIS_REQUIRE(!d.C_lo && !d.rowstats && !d.res16 && !d.ln_mr, "asis_gemm_group: the LayerNorm-fold fields are not implemented in the grouped kernel");
-    ASIS_REQUIRE(d.dtype == descs[0].dtype && (d.dtype == ASIS_F16 || d.dtype == ASIS_BF16), "asis_gemm_group: one 16-bit dtype per group");
-    const int batch = d.batch > 0 ? d.batch : 1;
-    const int kparts = 1 + (d.A_lo ? 1 : 0) + (d.B_lo ? 1 : 0);
-    // the contract of the persistent 8-phase kernel (gemm_p8.h), per problem; per-row bias and batches are allowed here
-    const bool ok = !d.conv && !d.stats && d.ksplit <= 1 && d.K % 64 == 0 && d.K >= 128 && d.M >= 256 && d.N >= 256 && d.N % 8 == 0 &&
-                    d.ldc % 8 == 0 && d.lda % 8 == 0 && d.ldb % 8 == 0 && d.lda >= d.K && d.ldb >= d.K && d.ldc >= d.N &&
-                    (int64_t)d.M * d.lda * 2 < (1ll << 32) && (int64_t)d.N * d.ldb * 2 < (1ll << 32) && al(d.A, 16) && al(d.B, 16) &&
-                    al(d.C, 16) && (!d.A_lo || al(d.A_lo, 16)) && (!d.B_lo || al(d.B_lo, 16)) &&
-                    (!d.res || (al(d.res, 16) && d.ldr % 4 == 0 && d.ldr >= d.N)) && (!d.bias_n || al(d.bias_n, 16)) &&
-                    (!d.scale_n || al(d.scale_n, 16)) && d.strideA % 8 == 0 && d.strideB % 8 == 0 && d.strideC % 8 == 0 &&
-                    d.strideR % 4 == 0 && ((d.act >= 0 && d.act <= ASIS_ACT_RELU) || (d.act == ASIS_ACT_GELU_GRAD && d.aux && al(d.aux, 8) && d.ld_aux % 4 == 0));
-    ASIS_REQUIRE(ok, "asis_gemm_group: problem %d (M %d N %d K %d) is off the persistent 8-phase kernel's contract (dense, K %% 64 == 0, "
-                     "K >= 128, M, N >= 256, N and leading dimensions multiples of 8, 16-byte aligned pointers)", i, d.M, d.N, d.K);
-    p8g_prob& q = g.p[i];
-    q.A = reinterpret_cast<const char*>(d.A); q.B = reinterpret_cast<const char*>(d.B); q.C = reinterpret_cast<char*>(d.C);
-    q.A_lo = reinterpret_cast<const char*>(d.A_lo); q.B_lo = reinterpret_cast<const char*>(d.B_lo);
-    q.bias_n = d.bias_n; q.bias_m = d.bias_m; q.scale_n = d.scale_n; q.res = d.res; q.aux = reinterpret_cast<const char*>(d.aux);
-    q.strideA = d.strideA * 2; q.strideB = d.strideB * 2; q.strideC = d.strideC * (d.out_f32 ? 4 : 2); q.strideR = d.strideR;
-    q.lda_b = (uint32_t)d.lda * 2u; q.ldb_b = (uint32_t)d.ldb * 2u;
-    q.ldc = (int32_t)d.ldc; q.ldr = (int32_t)d.ldr; q.ld_aux = (int32_t)d.ld_aux;
-    q.M = d.M; q.N = d.N; q.K = d.K; q.nparts = kparts; q.act = d.act; q.out_f32 = d.out_f32;
-    q.tiles_m = (d.M + 255) / 256; q.tiles_n = (d.N + 255) / 256; q.per_batch = q.tiles_m * q.tiles_n;
-    q.tile0 = tile0;
-    ASIS_REQUIRE((int64_t)tile0 + (int64_t)q.per_batch * batch < (1ll << 30), "asis_gemm_group: too many tiles");
-    tile0 += q.per_batch * batch;
-  }
-  g.ntiles = tile0;
-  ASIS_REQUIRE(tile0 >= 16, "asis_gemm_group: %d tiles: too few for the persistent kernel", tile0);
-  const int nwg = tile0 >= 256 ? 256 : (tile0 / 8) * 8;
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (descs[0].dtype == ASIS_F16) launch_group<f16>(s, g, nwg, group_m);
-  else launch_group<bf16>(s, g, nwg, group_m);
-  ASIS_CHECK_LAUNCH("asis_gemm_group");
-  return ASIS_OK;
-}
 
 extern "C" int asis_gemm(void* stream, const asis_gemm_desc* dp) {
   ASIS_REQUIRE(dp != nullptr, "asis_gemm: null descriptor");

@@ -34,7 +34,7 @@ namespace {
 // has no register to spare): 0 none, 1 = ln_mr / ln_cs in the 16-bit epilogue (q|k, fc1).  The producer fields (res16 / C_lo /
 // rowstats) are NOT built here: with them this kernel spilled ~200 VGPRs into its main loop in every arrangement tried, and the
 // one-tile-per-workgroup form (gemm_big.h, LNF) runs the projection within 4 % of this one — asis_gemm sends those launches there.
-template <typename T, int LAB = 0, int LNF = 0>
+template <typename T, int LNF = 0>
 __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(const asis_gemm_desc d, const int GROUP_M) {
   // (Tried in round 3 and removed: a non-temporal cache policy (LDS-DMA aux = nt) on the operand whose panels an XCD's chunks
   // do not share.  L2 fills went UP 5-30 % with the hint on either operand, and merely having the two aux variants of the
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(const asis_gemm_desc d,
   constexpr int STAGE = (BM + BN) * BK;  // elements per LDS stage (64 KB)
   // LNF == 1: + 2 KB behind the stages for the (mean, rstd) pairs of the tile's 256 rows (LDS-DMA at the tile's start: a
   // global load issued in the epilogue itself costs a full loaded-memory round trip, ~1.5 us per tile, in the exposed epilogue)
-  __shared__ __attribute__((aligned(16))) T lds[2 * STAGE + 1024 + ((LAB & 2) ? 512 : 0) + ((LAB & 8) ? 2048 : 0)];   // + (mean, rstd) block (LNF == 1) + LAB & 2: a 1-KB sink + LAB & 8: stamps
+  __shared__ __attribute__((aligned(16))) T lds[2 * STAGE + 1024];   // + (mean, rstd) block (LNF == 1)
   typedef __attribute__((address_space(3))) void* lds_ptr;
   typedef const __attribute__((address_space(1))) void* glb_ptr;
 
@@ -117,16 +117,6 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(const asis_gemm_desc d,
   auto dma_b = [&](int stage, int j) {
     __builtin_amdgcn_global_load_lds((glb_ptr)(B + (bsrc[j] + sk0)), (lds_ptr)(lds + stage * STAGE + BM * BK + grp_b(j) * BK), 16, 0, 0);
   };
-  // LAB & 2: the same with a wave-uniform choice of the destination — the stage, or (nothing left to stage: the last K tile of
-  // the workgroup's last tile) a 1-KB sink nobody reads — so that the MFMA bursts that carry these instructions hold no branch
-  auto dma_a2 = [&](int stage, int j, bool real) {
-    const int off = __builtin_amdgcn_readfirstlane(real ? stage * STAGE + grp_a(j) * BK : 2 * STAGE + 1024);
-    __builtin_amdgcn_global_load_lds((glb_ptr)(A + (asrc[j] + sk0)), (lds_ptr)(lds + off), 16, 0, 0);
-  };
-  auto dma_b2 = [&](int stage, int j, bool real) {
-    const int off = __builtin_amdgcn_readfirstlane(real ? stage * STAGE + BM * BK + grp_b(j) * BK : 2 * STAGE + 1024);
-    __builtin_amdgcn_global_load_lds((glb_ptr)(B + (bsrc[j] + sk0)), (lds_ptr)(lds + off), 16, 0, 0);
-  };
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     dma_a(0, j);
@@ -185,48 +175,17 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(const asis_gemm_desc d,
         bf[jj * 2 + ks] = __builtin_bit_cast(v8, *reinterpret_cast<const uint4*>(Bs + col * BK + (((4 * ks + q16) ^ ((col >> 1) & 7)) << 3)));
     }
   };
-  // LAB & 2 (lab, ASIS_P8_DMA_MFMA=1): the two LDS-DMA instructions of a phase are issued INSIDE the wave's MFMA sequence (after
-  // the 4th and the 12th of its 16 MFMAs) instead of in the load part in front of the barrier, whose length sets the barrier
-  // interval (MI355X_MICROARCH.md: an LDS-DMA piece costs 100-185 cycles to issue inside a phase that also carries ds_reads,
-  // ~60 among bare MFMAs).  The counted waits move in front of the issue: vmcnt(N) -> vmcnt(N - 2), the same set of loads.
-  constexpr bool DIM = (LAB & 2) != 0;
-  auto mma = [&](int rh, int ch, const v8* bf, auto&& dma0, auto&& dma1) {
+  auto mma = [&](int rh, int ch, const v8* bf) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_setprio(1);
-    int n = 0;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int t4 = 0; t4 < 4; ++t4)
 #pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
+        for (int jj = 0; jj < 2; ++jj)
           acc[rh * 4 + t4][ch * 2 + jj] = T16<T>::mfma16(bf[jj * 2 + ks], af[t4 >> 1][(t4 & 1) * 2 + ks], acc[rh * 4 + t4][ch * 2 + jj]);
-          ++n;
-          if constexpr (DIM) {
-            if (n == 4) { __builtin_amdgcn_sched_barrier(0); dma0(); __builtin_amdgcn_sched_barrier(0); }
-            if (n == 12) { __builtin_amdgcn_sched_barrier(0); dma1(); __builtin_amdgcn_sched_barrier(0); }
-          }
-        }
     __builtin_amdgcn_s_setprio(0);
-  };
-  auto nop = [] {};
-  // LAB & 8 (lab, scripts/p8_stamps.hip): s_memtime stamps of workgroup 0, the last 8 K tiles of its last tile — per phase: start of the load part (behind
-  // the previous closing barrier), its end (in front of the burst's opening barrier), end of that barrier (burst start).  The stamps are issued
-  // without a wait (scalar memory returns them under the burst) and written to LDS behind the burst: three SMEM issues and three
-  // ds_writes per phase, no extra s_waitcnt.  [wave][64] uint32 in LDS, dumped to d.stats.
-  constexpr bool STAMP = (LAB & 8) != 0;
-  uint32_t* const stamp_lds = reinterpret_cast<uint32_t*>(lds + 2 * STAGE + 1024 + ((LAB & 2) ? 512 : 0));
-  int sidx = 0;
-  uint64_t st_a = 0, st_b = 0, st_c = 0;
-  auto stamp_a = [&]() { if constexpr (STAMP) asm volatile("s_memtime %0" : "=s"(st_a)::"memory"); };
-  auto stamp_b = [&]() { if constexpr (STAMP) asm volatile("s_memtime %0" : "=s"(st_b)::"memory"); };
-  auto stamp_c = [&]() { if constexpr (STAMP) asm volatile("s_memtime %0" : "=s"(st_c)::"memory"); };
-  auto stamp_store = [&]() {   // behind a burst: its opening s_waitcnt lgkmcnt(0) has covered the stamps.  Branch-free (a wave-uniform
-    if constexpr (STAMP) {     // branch in the loop spills the kernel): every lane writes the same words, a ring of 8 K tiles per wave
-      uint32_t* q = stamp_lds + wid * 128 + sidx;
-      q[0] = (uint32_t)st_a; q[1] = (uint32_t)st_b; q[2] = (uint32_t)st_c;
-      sidx = sidx + 3 == 96 ? 0 : sidx + 3;
-    }
   };
 
   const float* const zp = reinterpret_cast<const float*>(g_zero_page);
@@ -249,34 +208,6 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(const asis_gemm_desc d,
       // phase 0
       rd_a(As, 0);
       rd_b(Bs, 0, b0f);
-      if constexpr (DIM) {
-        if (sw) { int ln = lane; asm volatile("" : "+v"(ln)); asrc[0] = a_ptr(0, m0n, ln); asrc[1] = a_ptr(1, m0n, ln); }
-        if (!first) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        mma(0, 0, b0f, [&] { dma_a2(ns, 0, more); }, [&] { dma_a2(ns, 1, more); });
-        __builtin_amdgcn_s_barrier();
-        // phase 1
-        rd_b(Bs, 1, b1f);
-        if (sw) { int ln = lane; asm volatile("" : "+v"(ln)); bsrc[0] = b_ptr(0, n0n, ln); bsrc[1] = b_ptr(1, n0n, ln); }
-        if (!first) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        mma(0, 1, b1f, [&] { dma_b2(ns, 0, more); }, [&] { dma_b2(ns, 1, more); });
-        __builtin_amdgcn_s_barrier();
-        // phase 2
-        rd_a(As, 1);
-        if (sw) { int ln = lane; asm volatile("" : "+v"(ln)); bsrc[2] = b_ptr(2, n0n, ln); bsrc[3] = b_ptr(3, n0n, ln); }
-        __builtin_amdgcn_s_barrier();
-        mma(1, 1, b1f, [&] { dma_b2(ns, 2, more); }, [&] { dma_b2(ns, 3, more); });
-        __builtin_amdgcn_s_barrier();
-        // phase 3
-        if (sw) { int ln = lane; asm volatile("" : "+v"(ln)); asrc[2] = a_ptr(2, m0n, ln); asrc[3] = a_ptr(3, m0n, ln); }
-        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        mma(1, 0, b0f, [&] { dma_a2(ns, 2, more); }, [&] { dma_a2(ns, 3, more); });
-        advance();
-        __builtin_amdgcn_s_barrier();
-        continue;
-      }
       if (more) {
         if (sw) { int ln = lane; asm volatile("" : "+v"(ln)); asrc[0] = a_ptr(0, m0n, ln); asrc[1] = a_ptr(1, m0n, ln); }
         dma_a(ns, 0); dma_a(ns, 1);
@@ -284,13 +215,9 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(const asis_gemm_desc d,
       } else {
         asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
       }
-      stamp_b();
       __builtin_amdgcn_s_barrier();
-      stamp_c();
-      mma(0, 0, b0f, nop, nop);
-      stamp_store();
+      mma(0, 0, b0f);
       __builtin_amdgcn_s_barrier();
-      stamp_a();
       // phase 1
       rd_b(Bs, 1, b1f);
       if (more) {
@@ -300,26 +227,18 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(const asis_gemm_desc d,
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
-      stamp_b();
       __builtin_amdgcn_s_barrier();
-      stamp_c();
-      mma(0, 1, b1f, nop, nop);
-      stamp_store();
+      mma(0, 1, b1f);
       __builtin_amdgcn_s_barrier();
-      stamp_a();
       // phase 2
       rd_a(As, 1);
       if (more) {
         if (sw) { int ln = lane; asm volatile("" : "+v"(ln)); bsrc[2] = b_ptr(2, n0n, ln); bsrc[3] = b_ptr(3, n0n, ln); }
         dma_b(ns, 2); dma_b(ns, 3);
       }
-      stamp_b();
       __builtin_amdgcn_s_barrier();
-      stamp_c();
-      mma(1, 1, b1f, nop, nop);
-      stamp_store();
+      mma(1, 1, b1f);
       __builtin_amdgcn_s_barrier();
-      stamp_a();
       // phase 3
       if (more) {
         if (sw) { int ln = lane; asm volatile("" : "+v"(ln)); asrc[2] = a_ptr(2, m0n, ln); asrc[3] = a_ptr(3, m0n, ln); }
@@ -327,13 +246,9 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(const asis_gemm_desc d,
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       }
       advance();
-      stamp_b();
       __builtin_amdgcn_s_barrier();
-      stamp_c();
-      mma(1, 0, b0f, nop, nop);
-      stamp_store();
+      mma(1, 0, b0f);
       __builtin_amdgcn_s_barrier();
-      stamp_a();
     }
     if (wm == 0) __builtin_amdgcn_s_barrier();  // level the two wave rows: all 8 waves run the epilogue together
 
@@ -347,14 +262,7 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(const asis_gemm_desc d,
     int lane_e = lane;
     asm volatile("" : "+v"(lane_e));
     const int r16 = lane_e & 15, q16 = lane_e >> 4;
-    if constexpr (LAB & 1) {  // lab: main loop only; keep the accumulators live
-      float z = 0.f;
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) z += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
-      if (z == 123.456f) reinterpret_cast<float*>(d.C)[tid] = z;
-    } else if (!d.out_f32 && !d.res && !d.res16 && !d.C_lo && !d.rowstats && !d.scale_n && d.act != ASIS_ACT_GELU_GRAD) {
+    if (!d.out_f32 && !d.res && !d.res16 && !d.C_lo && !d.rowstats && !d.scale_n && d.act != ASIS_ACT_GELU_GRAD) {
       // 16-bit outputs (q|k, fc1 + GELU): bias and activation in the accumulator layout, converted to 16 bits BEFORE the LDS
       // transposition (8-byte writes, 16-byte reads), 16-byte stores of 8 rows x 128 B
       constexpr int SW16 = 72;                          // slab row in 16-bit elements (144 B: conflict-free 8-byte writes)
@@ -531,15 +439,7 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(const asis_gemm_desc d,
         }
       }
     }
-    if (!has_next) {
-      if constexpr (STAMP) {   // the ring now holds the last 8 K tiles of this workgroup's last tile
-        if (blockIdx.x == 0 && d.stats) {
-          __syncthreads();
-          for (int i = tid; i < 8 * 128; i += 512) reinterpret_cast<uint32_t*>(d.stats)[i] = stamp_lds[i];
-        }
-      }
-      break;
-    }
+    if (!has_next) break;
     // next tile: its K tile 0 is in stage g & 1; the slabs are dead once every wave is past this barrier, so the first
     // phase may stage K tile 1 over them
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

@@ -324,41 +324,6 @@ class Attention(_Packed):
         ldv_all = (max(n for _, n in segs) + 63) // 64 * 64
         vt_all = torch.empty((sum(b for b, _ in segs), D, ldv_all), device=xn.device, dtype=xn.dtype) if one_launch else None
         spare = xn.untyped_storage().nbytes() // xn.element_size() - (xn.storage_offset() + xn.shape[0] * D)
-        if ops.GEMM_GROUP and xn.is_cuda and len(segs) <= 7:
-            # q|k and the per-image V^T projections as ONE grouped persistent launch (ops.gemm_group / csrc/gemm_p8g.h): the
-            # partial tile rounds of the three problems (5.19 + 2 x 1.31 rounds of 256 CUs at 12 images) become 7.81 rounds of one
-            # launch, in order on the compute stream.  N is rounded up to 8 (the kernel's 16-byte stores): the extra columns
-            # land in V^T's pad region, which the attention kernel zeroes in registers, and their operand rows are the first
-            # tokens of the next image (the last image reads the spare rows behind ``xn``).
-            probs = [(xn, w[: 2 * D], dict(bias_n=None if bias is None else bias[: 2 * D], b_lo=None if wlo is None else wlo[: 2 * D]))]
-            vts = []
-            r0 = b0 = 0
-            for B, N in segs:
-                r1 = r0 + B * N
-                ldvt = ldv_all if one_launch else (N + 63) // 64 * 64
-                vt = vt_all[b0:b0 + B] if one_launch else torch.empty((B, D, ldvt), device=xn.device, dtype=xn.dtype)
-                N8 = (N + 7) // 8 * 8
-                if spare < (N8 - N) * D:
-                    N8 = (N + 3) // 4 * 4 if spare >= 4 * D else N
-                probs.append((w[2 * D:], xn[r0:r1].as_strided((B, N8, D), (N * D, D, 1)),
-                              dict(out=vt.as_strided((B, D, N8), (D * ldvt, ldvt, 1)), bias_m=None if bias is None else bias[2 * D:],
-                                   a_lo=None if wlo is None else wlo[2 * D:])))
-                vts.append(vt)
-                r0, b0 = r1, b0 + B
-            if r0 != xn.shape[0]:
-                raise ValueError("attend_rows: segments do not cover the rows")
-            qk = ops.gemm_group(probs)[0]
-            if one_launch:
-                (B1, N1), (B2, N2) = segs
-                ops.attention_fwd_seg(qk[:, :D], qk[:, D:], vt_all, B1, N1, B2, N2, self.num_heads, scale, out=o, out_lo=o_lo)
-            else:
-                r0 = 0
-                for (B, N), vt in zip(segs, vts):
-                    r1 = r0 + B * N
-                    ops.attention_fwd(qk[r0:r1, :D], qk[r0:r1, D:], vt, B, self.num_heads, N, scale, out=o[r0:r1],
-                                      out_lo=None if o_lo is None else o_lo[r0:r1])
-                    r0 = r1
-            return o, o_lo
         # stacked form: the V^T GEMMs go to a side stream, the q|k GEMM stays on the compute stream (config.vt_stream)
         side = None
         if one_launch and config.vt_stream and xn.is_cuda:
@@ -563,7 +528,7 @@ class Block(_Packed):
         """the LayerNorm-fold chain (config.ln_fold) applies to this block on ``R`` stacked rows: every GEMM involved lands on
         a kernel that implements the epilogue fields (ops.ln_fold_supported)"""
         if not (config.ln_fold and config.operand_dtype == torch.float16 and config.precise_level < 2 and not config.precise_attention
-                and not config.fused_qkv and not ops.GEMM_GROUP and isinstance(self.mlp, Mlp) and isinstance(self.ls1, LayerScale)
+                and not config.fused_qkv and isinstance(self.mlp, Mlp) and isinstance(self.ls1, LayerScale)
                 and isinstance(self.ls2, LayerScale) and isinstance(self.norm1, nn.LayerNorm) and isinstance(self.norm2, nn.LayerNorm)):
             return False
         D, Hd = self.attn.qkv.weight.shape[1], self.mlp.fc1.weight.shape[0]

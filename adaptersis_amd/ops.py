@@ -164,35 +164,6 @@ def gemm(a: torch.Tensor, b: torch.Tensor, **kw) -> torch.Tensor:
     return out
 
 
-# ASIS_GEMM_GROUP=1: the q|k and V^T projections of an attention as ONE grouped persistent launch (csrc/gemm_p8g.h).  Measured
-# on the headline step (same box, interleaved, profiles/r04_gemm_group_ab.txt): with every launch on one stream the group
-# takes 248 us against 178 + 82 + 67 = 327 us for the three launches (dense launches 875 -> 913 TFLOP/s), but in the timed
-# multi-stream step the V^T GEMMs were already hidden on their side stream next to the other trunk stream's kernels:
-# 209.6 -> 202.3 img/s.  So it is OFF by default and stays available for single-stream callers.
-GEMM_GROUP = os.environ.get("ASIS_GEMM_GROUP", "0") not in ("0", "")
-
-
-def gemm_group(problems):
-    """Independent GEMMs in ONE persistent launch (include/asis_hip.h: asis_gemm_group; csrc/gemm_p8g.h).
-    ``problems`` = [(a, b, kwargs of ``gemm``), ...] -> [out tensors].  Problems the grouped kernel cannot take (its
-    contract is the persistent 8-phase kernel's) are launched one by one instead — same results either way."""
-    built = [_gemm_desc(a, b, **kw) for a, b, kw in problems]
-    outs = [o for _, o, _, _ in built]
-    if GEMM_GROUP and 1 < len(built) <= 8:
-        arr = (GemmDesc * len(built))(*[d for d, _, _, _ in built])
-        flops, nbytes = sum(f for _, _, f, _ in built), sum(nb for _, _, _, nb in built)
-        rc = _launch_timed("gemm", flops, lambda: lib().asis_gemm_group(_stream(), arr, len(built)), nbytes)
-        if rc == 0:
-            return outs
-        if rc != _lib.ASIS_EINVAL:
-            check(rc, "asis_gemm_group")
-        if PROFILE is not None:
-            PROFILE.pop()        # the refused launch timed nothing
-    for d, _, flops, nbytes in built:
-        check(_launch_timed("gemm", flops, lambda d=d: lib().asis_gemm(_stream(), C.byref(d)), nbytes), "asis_gemm")
-    return outs
-
-
 def gemm_tiles_m(M: int) -> int:
     return lib().asis_gemm_tiles_m(int(M))
 
@@ -468,28 +439,6 @@ def transpose_tokens(src: torch.Tensor, B: int, N: int, out: Optional[torch.Tens
     check(lib().asis_transpose_tokens(_stream(), _dt(src.dtype), src.data_ptr(), src.stride(0), out.data_ptr(), ldt, B, N,
                                       Cc), "asis_transpose_tokens")
     return out
-
-
-def attention_bwd(q, k, v, qt, kt, dot, o, dO, lse, B: int, H: int, N: int, scale: float,
-                  dqkv: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """-> dqkv 16-bit [B*N, 3*H*64] = [dQ | dK | dV].  q, k, v: [B*N, H*64] views with one row stride; qt, kt, dot:
-    ``transpose_tokens`` of q, k, dO; o, dO: [B*N, H*64]; lse: fp32 [B,H,N] from the forward."""
-    _dev(q, k, v, qt, kt, dot, o, dO, lse, dqkv)
-    Wd = H * 64
-    if not (q.stride(0) == k.stride(0) == v.stride(0)) or q.stride(1) != 1:
-        raise ValueError("attention_bwd: q, k, v must share a row stride")
-    if not (qt.shape == kt.shape == dot.shape) or qt.shape[-1] != token_ld(N):
-        raise ValueError("attention_bwd: qt, kt, dot must be transpose_tokens images")
-    if dqkv is None:
-        dqkv = torch.empty((B * N, 3 * Wd), device=q.device, dtype=q.dtype)
-    D = torch.empty((B, H, N), device=q.device, dtype=torch.float32)
-    es = dqkv.element_size()
-    check(lib().asis_attention_bwd(_stream(), _dt(q.dtype), q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0),
-                                   qt.data_ptr(), kt.data_ptr(), dot.data_ptr(), qt.shape[-1], o.data_ptr(), o.stride(0),
-                                   dO.data_ptr(), dO.stride(0), lse.data_ptr(), D.data_ptr(), dqkv.data_ptr(),
-                                   dqkv.data_ptr() + Wd * es, dqkv.data_ptr() + 2 * Wd * es, dqkv.stride(0), B, H, N,
-                                   float(scale)), "asis_attention_bwd")
-    return dqkv
 
 
 def attention_bwd_rows(q, k, v, o, dO, lse, segs, H: int, scale: float, dqkv: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -1417,6 +1366,10 @@ def bn_bwd_apply(g: torch.Tensor, x: torch.Tensor, mean, invstd, gamma, dgamma, 
     return (out, lo, partial) if split else (out, partial)
 
 
+# ASIS_WGRAD_HALO=0: the implicit-GEMM form of asis_wgrad for the narrow 3x3 decoder stages too (A/B: profiles/r05_wgrad_halo_ab.txt)
+WGRAD_HALO = os.environ.get("ASIS_WGRAD_HALO", "1") not in ("0", "")
+
+
 def wgrad(dy: torch.Tensor, x_nhwc: torch.Tensor, Cout: int, KH: int, KW: int, stride: int, pad: int,
           inv_scale: float = 1.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """dy 16-bit [B,OH,OW,CoP]; x 16-bit [B,H,W,Cin] -> dW fp32 [Cout,Cin,KH,KW] (scaled by inv_scale)."""
@@ -1434,6 +1387,18 @@ def wgrad(dy: torch.Tensor, x_nhwc: torch.Tensor, Cout: int, KH: int, KW: int, s
         slabs = torch.empty((nblk, Cout * Ntot), device=dy.device, dtype=torch.float32)
         check(lib().asis_conv3x3_smallcout_wgrad(_stream(), _dt(dy.dtype), dy.data_ptr(), CoP, x_nhwc.data_ptr(),
                                                  slabs.data_ptr(), nblk, Bn, H, W, Cin, Cout), "asis_conv3x3_smallcout_wgrad")
+        if out is None:
+            out = torch.empty((Cout, Cin, KH, KW), device=dy.device, dtype=torch.float32)
+        reduce_rows(slabs, inv_scale, out.view(-1))
+        return out
+    if (WGRAD_HALO and KH == 3 and KW == 3 and stride == 1 and pad == 1 and Cout % 64 == 0 and Cout % 256 != 0 and Cin % 128 == 0
+            and H >= 8 and W >= 16):
+        # the narrow decoder stages (128 -> 64 at 336^2, 256 -> 128 at 168^2): halo-tile kernel, pixels as the MFMA K index
+        # through transposing LDS reads, x fetched once per tile instead of once per tap (csrc/convwgrad.hip)
+        nblk = lib().asis_conv3x3_wgrad_halo_nblk(Bn, H, W, Cin, Cout)
+        slabs = torch.empty((nblk, Cout * Ntot), device=dy.device, dtype=torch.float32)
+        check(lib().asis_conv3x3_wgrad_halo(_stream(), _dt(dy.dtype), dy.data_ptr(), CoP, x_nhwc.data_ptr(), slabs.data_ptr(), nblk,
+                                            Bn, H, W, Cin, Cout), "asis_conv3x3_wgrad_halo")
         if out is None:
             out = torch.empty((Cout, Cin, KH, KW), device=dy.device, dtype=torch.float32)
         reduce_rows(slabs, inv_scale, out.view(-1))

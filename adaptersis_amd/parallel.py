@@ -131,8 +131,9 @@ class StageReducer:
     ~15 ms on an xGMI ring) — packed into a staging buffer right before its all-reduce, summed by the
     collective in bf16, unpacked into the fp32 bucket behind it, all on the reducer's side stream.  bf16 keeps fp32's exponent
     range (the unscaled ~1e-7 Dice gradients survive) at 8 significant bits: a relative error <= 2^-9 per rank term, i.e. the
-    torch-side `bf16_compress_hook`.  Off by default (the reference's DDP exchanges fp32, `train.py:84-116`);
-    ``ASIS_GRAD_COMPRESS=bf16`` / ``SegEngine(grad_compress="bf16")`` turn it on for the backbone bucket only."""
+    torch-side `bf16_compress_hook`.  SegEngine uses it for the backbone bucket of the unfrozen flow only (default since round 5;
+    ``ASIS_GRAD_COMPRESS=none`` / ``SegEngine(grad_compress="none")``: fp32 like the reference's DDP, `train.py:84-116`); the
+    two-rank error bound is pinned in tests/test_dist_gloo.py and tests/test_gpu_rccl.py."""
 
     def __init__(self, flat_grad: torch.Tensor, ranges: Sequence[Tuple[int, int]], group=None, compress: Optional[str] = None):
         if compress not in (None, "bf16"):

@@ -146,13 +146,6 @@ int asis_ln_stats_finalize(void* stream, const float* rowstats, int64_t rows, in
 int asis_split_stats(void* stream, int dtype, const float* x, int64_t ldx, void* hi, void* lo, int64_t ld16, float* mr,
                      int64_t rows, int D, float eps);
 int asis_gemm(void* stream, const asis_gemm_desc* d);
-/* GROUPED launch: up to ASIS_GEMM_GROUP_MAX (8) independent dense problems (each optionally batched) in ONE persistent
- * launch — e.g. the q|k projection and the batched V^T projections of one attention (attention.py:58: one qkv Linear, three
- * consumers) — so that their partial tile rounds fill each other without a launch boundary or a side stream (csrc/gemm_p8g.h).
- * Every problem must meet the persistent 8-phase kernel's contract (dense, K % 64 == 0, K >= 128, M, N >= 256, N and leading
- * dimensions multiples of 8, 16-byte aligned pointers, no stats / ksplit; bias_m and batch > 1 are allowed; same dtype);
- * otherwise ASIS_EINVAL and the caller launches the problems one by one.  Results are bit-identical to those launches. */
-int asis_gemm_group(void* stream, const asis_gemm_desc* descs, int n);
 /* number of M tiles asis_gemm uses for M rows (size of the stats buffer = tiles*2*N floats) */
 int asis_gemm_tiles_m(int M);
 /* |x| maximum of an fp32 [rows, cols] tensor (row stride ld, cols % 4 == 0) into *amax (device float; reset != 0 zeroes it
@@ -234,7 +227,7 @@ int asis_attention_fwd_prescaled(void* stream, int dtype, const void* q, const v
  * ignored), as in asis_attention_fwd_prescaled.  o_lo / lse2 as above. */
 int asis_attention_fwd_qkv(void* stream, int dtype, const void* q, const void* k, const void* v, int64_t ld, void* o, void* o_lo,
                            int64_t ldo, int B1, int N1, int B2, int N2, int H, float scale, int prescaled, float* lse2);
-/* same, also writing lse2[B,H,N] = log2 sum_k exp2(log2(e) * scale * q.k) per query (what asis_attention_bwd
+/* same, also writing lse2[B,H,N] = log2 sum_k exp2(log2(e) * scale * q.k) per query (what asis_attention_bwd_rows
  * needs to rebuild the probabilities); lse2 NULL = asis_attention_fwd */
 int asis_attention_fwd_lse(void* stream, int dtype, const void* q, const void* k, int64_t ldqk, const void* vt,
                            int64_t ldvt, void* o, int64_t ldo, int B, int H, int N, float scale, float* lse2);
@@ -244,17 +237,11 @@ int asis_transpose_tokens(void* stream, int dtype, const void* src, int64_t ld, 
                           int C);
 /* Backward of the fused attention (the autograd transpose of attention.py:60-66):
  *   dV = P^T dO, dS = scale * P * (dO V^T - D), D = rowsum(dO * O), dQ = dS K, dK = dS^T Q,
- * scores recomputed from q, k and lse2.  q, k, v: 16-bit [B*N, >= H*64] row-major, row stride ld; qt, kt, dot:
- * their / dO's asis_transpose_tokens images (row stride ldt); o, dO: forward output and its gradient; D: fp32
- * scratch [B,H,N] (written here); dq, dk, dv: 16-bit outputs, row stride lddq (e.g. the three column blocks of one
- * [B*N, 3*H*64] buffer, ready for the qkv weight-gradient / input-gradient GEMMs). */
-int asis_attention_bwd(void* stream, int dtype, const void* q, const void* k, const void* v, int64_t ld, const void* qt,
-                       const void* kt, const void* dot, int64_t ldt, const void* o, int64_t ldo, const void* dO,
-                       int64_t lddo, const float* lse2, float* D, void* dq, void* dk, void* dv, int64_t lddq, int B,
-                       int H, int N, float scale);
-/* The same backward on row-major operands only (round 5): no transposed images — the products that reduce over the token
- * index read the row-major K / Q / dO tiles through transposing LDS reads — and two stacked token batches per launch, laid
- * out as in asis_attention_fwd_split: B1 images of N1 tokens followed by B2 images of N2 tokens (B2 = 0: one batch) in
+ * scores recomputed from q, k and lse2.  q, k, v: 16-bit [tokens, >= H*64] row-major, row stride ld; o, dO: forward output and
+ * its gradient; dq, dk, dv: 16-bit outputs, row stride lddq (e.g. the three column blocks of one [tokens, 3*H*64] buffer, ready
+ * for the qkv weight-gradient / input-gradient GEMMs).  Row-major operands only: the products that reduce over the token index
+ * read the row-major K / Q / dO tiles through transposing LDS reads (rounds 1-4 took transposed images of q, k, dO).  Two
+ * stacked token batches per launch, laid out as in asis_attention_fwd_split: B1 images of N1 tokens followed by B2 images of N2 tokens (B2 = 0: one batch) in
  * every [tokens, *] operand; lse2 and the scratch D are [B1, H, N1] followed by [B2, H, N2] (D receives -scale * rowsum(dO * O),
  * the initial accumulator of the dP chains).  Pipelined LDS-DMA kernels (csrc/attn_bwd_pipe.hip); bit-reproducible. */
 int asis_attention_bwd_rows(void* stream, int dtype, const void* q, const void* k, const void* v, int64_t ld, const void* o,
@@ -631,6 +618,15 @@ typedef struct asis_wgrad_desc {
 } asis_wgrad_desc;
 int asis_wgrad_splits(int64_t P, int Cout, int Ntot);
 int asis_wgrad(void* stream, const asis_wgrad_desc* d);
+/* Weight gradient of a 3x3 / stride 1 / pad 1 convolution with Cout % 64 == 0 and Cin % 128 == 0 on halo tiles (round 5,
+ * csrc/convwgrad.hip; the narrow decoder stages of backbones/decoders.py:109-135, whose 64 / 128 output channels leave the
+ * implicit-GEMM form of asis_wgrad at 0.12 / 0.19 matrix-pipe busy): dy 16-bit [B,H,W,ld_dy] (first Cout channels), x 16-bit
+ * [B,H,W,Cin] -> slabs fp32 [nblk, Cout*Cin*9], each row a partial dW in the parameter's [Cout][Cin][3][3] layout, to be summed
+ * by asis_reduce_rows (fixed order: deterministic).  nblk = asis_conv3x3_wgrad_halo_nblk(...) workgroup columns (x (Cin / 128)
+ * (Cout / 64) channel-block combinations = one workgroup per CU). */
+int asis_conv3x3_wgrad_halo_nblk(int B, int H, int W, int Cin, int Cout);
+int asis_conv3x3_wgrad_halo(void* stream, int dtype, const void* dy, int64_t ld_dy, const void* x, float* slabs, int nblk, int B,
+                            int H, int W, int Cin, int Cout);
 
 /* torch.optim.SGD step (train.py:178-191: momentum, weight decay, dampening 0, no Nesterov) on a flat
  * fp32 parameter buffer; g is multiplied by inv_scale (1/loss_scale) first. */

@@ -182,7 +182,10 @@ def test_bn_relu_upsample_backward(dev, factor):
 @pytest.mark.parametrize("Cin,Cout,H,k,pad", [(16, 24, 11, 3, 1), (64, 128, 20, 3, 1), (8, 2, 33, 3, 1), (32, 40, 10, 1, 0),
                                               (96, 32, 6, 3, 1), (64, 2, 21, 3, 1), (16, 3, 13, 3, 1), (32, 4, 9, 3, 1),
                                               (64, 64, 12, 3, 1), (128, 256, 20, 3, 1), (256, 512, 19, 3, 1),
-                                              (128, 256, 37, 3, 1)])
+                                              (128, 256, 37, 3, 1),
+                                              # the halo-tile weight-gradient kernel (csrc/convwgrad.hip: Cout % 64 == 0, Cin % 128 == 0):
+                                              # ragged tiles both ways, one / several channel-block combinations
+                                              (128, 64, 20, 3, 1), (128, 64, 37, 3, 1), (256, 128, 24, 3, 1), (128, 192, 17, 3, 1)])
 def test_conv_wgrad_and_dgrad(dev, dt, Cin, Cout, H, k, pad):
     """wgrad (transposed-LDS-read GEMM) and dgrad (implicit GEMM with flipped weights) vs autograd."""
     Bn = 3

@@ -60,7 +60,11 @@ CHILD = textwrap.dedent('''
     for k in base:
         assert base[k]["loss"] == forced[k]["loss"], (k, base[k]["loss"], forced[k]["loss"])
         for name in base[k]:
-            if name != "loss":
+            if name == "vit":
+                # the backbone bucket travels as bfloat16 by default (SegEngine grad_compress, round 5): with one rank the
+                # exchange returns every range rounded once to bf16
+                assert torch.equal(base[k][name].to(torch.bfloat16).float(), forced[k][name]), (k, name)
+            elif name != "loss":
                 assert torch.equal(base[k][name], forced[k][name]), (k, name)
     print("RCCL_REHEARSAL_OK", base["frozen"]["loss"], base["e2e"]["loss"])
 ''')
@@ -82,9 +86,14 @@ CHILD2 = textwrap.dedent('''
     import torch.distributed as dist
     sys.path.insert(0, os.environ["ASIS_ROOT"])
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    torch.cuda.set_device(rank)
-    dev = torch.device("cuda", rank)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    backend = os.environ.get("ASIS_2RANK_BACKEND", "nccl")             # "gloo": both ranks share device 0 (one-GPU box)
+    idx = rank if backend == "nccl" else 0
+    torch.cuda.set_device(idx)
+    dev = torch.device("cuda", idx)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     from adaptersis_amd.utils import weights as W
     from tests.test_gpu_e2e import build_e2e_engine
     from tests.test_gpu_step import build_engine
@@ -114,6 +123,28 @@ CHILD2 = textwrap.dedent('''
 ''')
 
 
+def _run_two_ranks(extra_env):
+    env = dict(os.environ, ASIS_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    path = os.path.join(ROOT, "gpurun_out", "_rccl2_child.py")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    with open(path, "w") as f:
+        f.write(CHILD2)
+    return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+                           "--nproc-per-node=2", path], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+
+
+@pytest.mark.parametrize("compress", ["none", "bf16"])
+def test_two_rank_body_over_gloo_on_one_card(compress):
+    """The body of the two-real-rank RCCL test below — two steps of the frozen-backbone engine and of the unfrozen one, then
+    bit-equality of weights, running statistics and reduced gradients across the ranks — with both ranks on the one visible
+    device over gloo, so that its logic executes on the one-GPU box too; ``compress``: the 16-bit gradient
+    transport (ASIS_GRAD_COMPRESS) on every bucket."""
+    r = _run_two_ranks({"ASIS_2RANK_BACKEND": "gloo", "ASIS_GRAD_COMPRESS": compress})
+    assert r.returncode == 0 and "RCCL_2RANK_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
 def test_two_real_ranks_over_rccl_when_two_devices_are_visible():
     """N > 1 on real RCCL: two ranks, one device each, two steps of the frozen-backbone engine and of the
     unfrozen one (SyncBN exchanges, per-stage decoder all-reduces, chunked backbone bucket with blocks_per_bucket <
@@ -122,13 +153,5 @@ def test_two_real_ranks_over_rccl_when_two_devices_are_visible():
     import torch
     if torch.cuda.device_count() < 2:
         pytest.skip("needs >= 2 visible GPUs (the driver's multi-GPU node)")
-    env = dict(os.environ, ASIS_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
-        env.pop(k, None)
-    path = os.path.join(ROOT, "gpurun_out", "_rccl2_child.py")
-    os.makedirs(os.path.dirname(path), exist_ok=True)
-    with open(path, "w") as f:
-        f.write(CHILD2)
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
-                        "--nproc-per-node=2", path], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    r = _run_two_ranks({"ASIS_2RANK_BACKEND": "nccl"})
     assert r.returncode == 0 and "RCCL_2RANK_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])

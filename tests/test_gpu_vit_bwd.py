@@ -11,39 +11,6 @@ from tests.conftest import rel_l2
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("shape", [(2, 2, 100), (1, 3, 257), (2, 1, 64), (1, 2, 1765)])
-def test_attention_backward(dev, shape, dt):
-    B, H, N = shape
-    D = H * 64
-    scale = 64 ** -0.5
-    qkv = W.tensor(f"attnb.qkv{shape}", (B * N, 3 * D), 1.0).to(dt)
-    dO = W.tensor(f"attnb.do{shape}", (B * N, D), 1.0).to(dt)
-    # ---- reference: fp32 softmax attention on the rounded operands, autograd
-    qf, kf, vf = [t.float().view(B, N, H, 64).transpose(1, 2).clone().requires_grad_(True)
-                  for t in (qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:])]
-    p = torch.softmax(qf @ kf.transpose(-1, -2) * scale, -1)
-    o_ref = (p @ vf).transpose(1, 2).reshape(B * N, D)
-    (o_ref * dO.float()).sum().backward()
-    unhead = lambda g: g.transpose(1, 2).reshape(B * N, D)
-    # ---- HIP
-    g = qkv.to(dev)
-    q, k, v = g[:, :D], g[:, D:2 * D], g[:, 2 * D:]
-    vt = ops.transpose_tokens(v, B, N)
-    lse = torch.empty((B, H, N), device=dev, dtype=torch.float32)
-    o = ops.attention_fwd(q, k, vt, B, H, N, scale, lse=lse)
-    assert rel_l2(o, o_ref) < (2e-3 if dt == torch.float16 else 1e-2)
-    lse_ref = torch.logsumexp(qf.detach() @ kf.detach().transpose(-1, -2) * scale, -1) * 1.4426950408889634
-    assert float((lse.cpu() - lse_ref).abs().max()) < 2e-3
-    dOd = dO.to(dev)
-    dqkv = ops.attention_bwd(q, k, v, ops.transpose_tokens(q, B, N), ops.transpose_tokens(k, B, N),
-                             ops.transpose_tokens(dOd, B, N), o, dOd, lse, B, H, N, scale)
-    tol = 4e-3 if dt == torch.float16 else 2.5e-2
-    errs = (rel_l2(dqkv[:, :D], unhead(qf.grad)), rel_l2(dqkv[:, D:2 * D], unhead(kf.grad)), rel_l2(dqkv[:, 2 * D:], unhead(vf.grad)))
-    print(shape, dt, "dq dk dv rel-L2:", ["%.2e" % e for e in errs])
-    assert max(errs) < tol, errs
-
-
 def _attn_ref_grads(qkv, dO, B, H, N, scale):
     """fp32 softmax attention on the rounded operands, autograd -> (o, lse2, dq, dk, dv) as [B*N, H*64] / [B, H, N]"""
     D = H * 64
@@ -110,9 +77,9 @@ def test_attention_backward_rows(dev, segs, dt, scale):
         r0 = r1
 
 
-def test_attention_backward_rows_matches_transposed_form(dev):
-    """the new kernels against the round-1 form (transposed operand images) on the ViT-L geometry: same mathematics, errors
-    of the same size against fp32 (the bar of VERDICT r4: <= 3.0e-4 on this case)"""
+def test_attention_backward_rows_vitl_geometry_error(dev):
+    """the ViT-L geometry (N = 1765) at the bar of VERDICT r4: <= 3.0e-4 against fp32 autograd on the same rounded operands (the
+    round-1 form with transposed operand images measured 3.0e-4 / 3.0e-4 / 2.9e-4 here; profiles/r05_attn_bwd_pmc.txt)"""
     B, H, N = 1, 2, 1765
     D, scale, dt = H * 64, 0.125, torch.float16
     qkv = W.tensor("attnb.qkv(1, 2, 1765)", (B * N, 3 * D), 1.0).to(dt)
@@ -122,13 +89,11 @@ def test_attention_backward_rows_matches_transposed_form(dev):
     q, k, v = g[:, :D], g[:, D:2 * D], g[:, 2 * D:]
     lse = torch.empty((B, H, N), device=dev, dtype=torch.float32)
     o = ops.attention_fwd(q, k, ops.transpose_tokens(v, B, N), B, H, N, scale, lse=lse)
-    old = ops.attention_bwd(q, k, v, ops.transpose_tokens(q, B, N), ops.transpose_tokens(k, B, N),
-                            ops.transpose_tokens(dOd, B, N), o, dOd, lse, B, H, N, scale).cpu()
     new = ops.attention_bwd_rows(q, k, v, o, dOd, lse.view(-1), [(B, N)], H, scale).cpu()
     for name, sl, ref in (("dq", slice(0, D), dq), ("dk", slice(D, 2 * D), dk), ("dv", slice(2 * D, 3 * D), dv)):
-        e_old, e_new = rel_l2(old[:, sl], ref), rel_l2(new[:, sl], ref)
-        print(name, "old %.2e new %.2e" % (e_old, e_new))
-        assert e_new < 3.0e-4 and e_new < 1.15 * e_old + 1e-5
+        e = rel_l2(new[:, sl], ref)
+        print(name, "%.2e" % e)
+        assert e < 3.0e-4
 
 
 def test_transpose_tokens(dev):
