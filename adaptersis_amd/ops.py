@@ -1367,7 +1367,7 @@ def bn_bwd_apply(g: torch.Tensor, x: torch.Tensor, mean, invstd, gamma, dgamma, 
 
 
 # ASIS_WGRAD_HALO=0: the implicit-GEMM form of asis_wgrad for the narrow 3x3 decoder stages too (A/B: profiles/r05_wgrad_halo_ab.txt)
-WGRAD_HALO = os.environ.get("ASIS_WGRAD_HALO", "1") not in ("0", "")
+WGRAD_HALO = int(os.environ.get("ASIS_WGRAD_HALO", "1") or 0)
 
 
 def wgrad(dy: torch.Tensor, x_nhwc: torch.Tensor, Cout: int, KH: int, KW: int, stride: int, pad: int,
@@ -1391,10 +1391,10 @@ def wgrad(dy: torch.Tensor, x_nhwc: torch.Tensor, Cout: int, KH: int, KW: int, s
             out = torch.empty((Cout, Cin, KH, KW), device=dy.device, dtype=torch.float32)
         reduce_rows(slabs, inv_scale, out.view(-1))
         return out
-    if (WGRAD_HALO and KH == 3 and KW == 3 and stride == 1 and pad == 1 and Cout % 64 == 0 and Cout % 256 != 0 and Cin % 128 == 0
-            and H >= 8 and W >= 16):
-        # the narrow decoder stages (128 -> 64 at 336^2, 256 -> 128 at 168^2): halo-tile kernel, pixels as the MFMA K index
-        # through transposing LDS reads, x fetched once per tile instead of once per tap (csrc/convwgrad.hip)
+    if WGRAD_HALO and KH == 3 and KW == 3 and stride == 1 and pad == 1 and Cout % 64 == 0 and Cin % 128 == 0 and H >= 8 and W >= 16:
+        # every 3x3 / stride-1 decoder stage: halo-tile kernel, pixels as the MFMA K index through transposing LDS reads, x fetched
+        # once per tile instead of once per tap (csrc/convwgrad.hip; at 12 images: 128 -> 64 at 336^2 718 -> 286 us, 256 -> 128 at
+        # 168^2 494 -> 244, 512 -> 256 at 84^2 329 -> 240, 3072 -> 512 at 42^2 982 -> 781: profiles/r05_wgrad_halo_ab.txt)
         nblk = lib().asis_conv3x3_wgrad_halo_nblk(Bn, H, W, Cin, Cout)
         slabs = torch.empty((nblk, Cout * Ntot), device=dy.device, dtype=torch.float32)
         check(lib().asis_conv3x3_wgrad_halo(_stream(), _dt(dy.dtype), dy.data_ptr(), CoP, x_nhwc.data_ptr(), slabs.data_ptr(), nblk,

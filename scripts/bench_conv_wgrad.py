@@ -7,12 +7,13 @@ import torch
 from adaptersis_amd import ops
 dev = torch.device("cuda:0")
 B = 12
-for name, Cin, Cout, H in (("decoder_4 (128 -> 64 at 336^2)", 128, 64, 336), ("decoder_3 (256 -> 128 at 168^2)", 256, 128, 168)):
+for name, Cin, Cout, H in (("decoder_4 (128 -> 64 at 336^2)", 128, 64, 336), ("decoder_3 (256 -> 128 at 168^2)", 256, 128, 168),
+                           ("decoder_2 (512 -> 256 at 84^2)", 512, 256, 84), ("decoder_1 (3072 -> 512 at 42^2)", 3072, 512, 42)):
     dy = (torch.rand(B, H, H, Cout, device=dev) * 2 - 1).half()
     x = (torch.rand(B, H, H, Cin, device=dev) * 2 - 1).half()
     res = {}
     for halo in (False, True):
-        ops.WGRAD_HALO = halo
+        ops.WGRAD_HALO = 1 if halo else 0
         out = torch.empty(Cout, Cin, 3, 3, device=dev)
         f = lambda: ops.wgrad(dy, x, Cout, 3, 3, 1, 1, 1.0, out=out)
         for _ in range(3):
@@ -23,7 +24,7 @@ for name, Cin, Cout, H in (("decoder_4 (128 -> 64 at 336^2)", 128, 64, 336), ("d
             f()
         e.record(); torch.cuda.synchronize()
         res[halo] = (s.elapsed_time(e) / 20 * 1e3, out.clone())
-    ops.WGRAD_HALO = True
+    ops.WGRAD_HALO = 1
     fl = 2.0 * B * H * H * Cout * Cin * 9
     err = float((res[True][1] - res[False][1]).norm() / res[False][1].norm())
     print(f"{name:34s} implicit GEMM {res[False][0]:7.1f} us ({fl / res[False][0] / 1e6:5.0f} TFLOP/s)   halo tile {res[True][0]:7.1f} us "
