@@ -92,8 +92,11 @@ def run(img, sds, heads):
             out = O.decoder_mla(*maps, sd={k: v.clone() for k, v in sds["mla"].items()}, img_size=img.shape[-1], update_bn=False)
         return maps[0], maps[3], out
     with torch.no_grad():
-        O.adapter_forward(img, sds["vit"], {k: v.clone() for k, v in sds["enc"].items()}, sds["cv"], sds["cn"], heads, taps=taps)
+        cat = O.adapter_forward(img, sds["vit"], {k: v.clone() for k, v in sds["enc"].items()}, sds["cv"], sds["cn"], heads, taps=taps)
         x = taps["x_stage3"]
+        if HEAD == "fdec":   # the headline head: `train.py:389-406` decoder input -> FeatureDecoder (train-mode BatchNorm) logits
+            y = O.feature_decoder(cat, {k: v.clone() for k, v in sds["fdec"].items()}, update_bn=False)
+            return x, taps["c_stage3"], y
         if HEAD == "unet":
             B, N, D = x.shape
             h = int(N ** 0.5)
@@ -111,6 +114,9 @@ def main():
     if "--mla" in sys.argv:
         sys.argv.remove("--mla")
         HEAD = "mla"
+    if "--fdec" in sys.argv:
+        sys.argv.remove("--fdec")
+        HEAD = "fdec"
     if "--sites" in sys.argv:
         i = sys.argv.index("--sites")
         ONLY = sys.argv[i + 1].split(",")
@@ -126,6 +132,8 @@ def main():
         sds["unet"] = W.make_unet_state_dict(D, 2)
     if HEAD == "mla":
         sds["mla"] = W.make_decoder_mla_state_dict(D, 128, 11)
+    if HEAD == "fdec":
+        sds["fdec"] = W.make_feature_decoder_state_dict(D, 2, features=(D, 512, 256, 128, 64))
     img, _ = W.synthetic_batch(1, size)
     ref = run(img, sds, heads)
     O.attention, O.mlp, O.ms_deform_attn, O.conv_ffn, O.patch_embed = attention, mlp, ms_deform_attn, conv_ffn, patch_embed
@@ -133,7 +141,8 @@ def main():
     def err(tag):
         out = run(img, sds, heads)
         e = [float((a.double() - b.double()).norm() / b.double().norm()) for a, b in zip(out, ref)]
-        names = {"unet": ("x_final", "c_final", "UNet logits"), "mla": ("MLA in0", "MLA in3", "MLA output")}.get(HEAD, ("x_final", "c_final", "passA feat"))
+        names = {"unet": ("x_final", "c_final", "UNet logits"), "mla": ("MLA in0", "MLA in3", "MLA output"),
+                 "fdec": ("x_final", "c_final", "FeatureDecoder logits")}.get(HEAD, ("x_final", "c_final", "passA feat"))
         print(f"{tag:34s} {names[0]} {e[0]:.2e}  {names[1]} {e[1]:.2e}  {names[2]} {e[2]:.2e}", flush=True)
         return e
     print(f"{arch} {size}x{size}, operands {DT}: rounding emulated at the listed sites only")
