@@ -120,6 +120,7 @@ SIGNATURES = {
     "asis_cast_pad": [_vp, _i, _vp, _i64, _vp, _i64, _i64, _i, _f, _i],
     "asis_add_cls_pos": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i],
     "asis_msda_fwd": [_vp, _i, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i],
+    "asis_msda_fwd_split": [_vp, _i, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i],
     "asis_dwconv_gelu": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i],
     "asis_conv3x3_c3": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i],
     "asis_conv3x3_smallcout_fwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i],

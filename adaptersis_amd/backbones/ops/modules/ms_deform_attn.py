@@ -18,7 +18,7 @@ from torch import nn
 from torch.nn.init import constant_, xavier_uniform_
 
 from .... import config, ops
-from ....dinov2.layers.blocks import _Packed
+from ....dinov2.layers.blocks import _Packed, _pack
 
 
 def _is_power_of_2(n):
@@ -84,6 +84,21 @@ class MSDeformAttn(_Packed):
                 self._cache["b_oa"] = torch.cat([srcs[2].detach(), srcs[3].detach()]).float().contiguous()
             self._cache["oa_tag"] = tag
         w_oa = self._cache["w_oa"]
+        if config.precise_adapters_on():
+            # 16 significant bits where tests/precision_probe.py puts the adapters' error in bf16 (weights 9.2e-4 and the sampled
+            # rows 6.2e-4 of 1.43e-3 on the logits): the three weights as hi + lo halves, the sampled rows as a split A operand
+            if self._cache.get("oa_lo_tag") != tag:
+                with torch.no_grad():
+                    w = torch.cat([srcs[0].detach(), srcs[1].detach()], 0).float().contiguous()
+                    self._cache["w_oa_lo"] = ops.cast_pad(w, dtype=dt, part=1)
+                self._cache["oa_lo_tag"] = tag
+            lo = lambda key, p_: _pack(self._cache, key + ".lo", p_, lambda t: ops.cast_pad(t.reshape(t.shape[0], -1).contiguous().float(), dtype=dt, part=1))
+            value = ops.gemm(feat16, self._w16("wv", self.value_proj.weight), bias_n=self._f32("bv", self.value_proj.bias),
+                             b_lo=lo("wv", self.value_proj.weight))
+            offaw = ops.gemm(q16, w_oa, out_f32=True, bias_n=self._cache["b_oa"], b_lo=self._cache["w_oa_lo"])
+            samp, samp_lo = ops.msda_fwd(value.view(B, Lin, self.d_model), offaw, ref, shapes_i32, starts_i32, B, Lq, M, L, P, split=True)
+            return ops.gemm(samp, self._w16("wo", self.output_proj.weight), out_f32=True, bias_n=self._f32("bo", self.output_proj.bias),
+                            scale_n=scale_n, res=res, a_lo=samp_lo, b_lo=lo("wo", self.output_proj.weight))
         value = ops.gemm(feat16, self._w16("wv", self.value_proj.weight), bias_n=self._f32("bv", self.value_proj.bias))
         offaw = ops.gemm(q16, w_oa, out_f32=True, bias_n=self._cache["b_oa"])
         samp = ops.msda_fwd(value.view(B, Lin, self.d_model), offaw, ref, shapes_i32, starts_i32, B, Lq, M, L, P)

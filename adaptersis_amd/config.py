@@ -113,6 +113,19 @@ precise_level = int(precise_level_policy or 0)
 # proj,fc1 8.3e-4 / 58.9;  qkv,proj 1.12e-3 (fails) / 62.1;  proj alone (= level 0 + split_attn_out) 1.21e-3 (fails) / 68.8.
 # SegEngine's automatic policy for that geometry is therefore {proj, fc1}: the attention output and the LayerNorm output in
 # front of the widest GEMM — the two largest terms of tests/precision_probe.py (1.22e-3, 7.5e-4) — and nothing else.
+# The adapters' MSDA linear layers on split operands (weights hi + lo, sampled rows hi + lo): what bfloat16 needs on top of
+# precise_level 2 to hold 1e-3 on the stress golden (tests/precision_probe.py vit_large 588 bf16 --fdec: of the 1.49e-3 left at
+# level 2 the MSDA group carries 1.43e-3 — weights 9.2e-4, sampled rows 6.2e-4).  ASIS_PRECISE_ADAPTERS = 1 / 0 / "auto"
+# (default): on for bfloat16 operands at precise_level >= 2, off otherwise (float16 measures 2.9e-4 for the whole group).
+_pa = os.environ.get("ASIS_PRECISE_ADAPTERS", "auto").lower() or "auto"
+
+
+def precise_adapters_on() -> bool:
+    if _pa != "auto":
+        return _pa not in ("0", "")
+    return operand_dtype == torch.bfloat16 and precise_level >= 2
+
+
 _pp = os.environ.get("ASIS_PRECISE_PARTS", "auto").lower() or "auto"
 precise_parts_policy = None if _pp == "auto" else frozenset(filter(None, _pp.replace("w12", "fc1").replace("w3", "fc2").split(",")))
 precise_parts = precise_parts_policy if precise_parts_policy is not None else frozenset(("qkv", "proj", "fc1", "fc2"))

@@ -21,7 +21,7 @@ template <typename T, int NC = 1>
 __global__ __launch_bounds__(256) void msda_fwd_kernel(const T* __restrict__ value, const float* __restrict__ offaw,
                                                        int64_t ld_offaw, const float* __restrict__ ref,
                                                        const int* __restrict__ shapes, const int* __restrict__ starts,
-                                                       T* __restrict__ out, int B, int Lq, int Lin, int M, int L, int P,
+                                                       T* __restrict__ out, T* __restrict__ out_lo, int B, int Lq, int Lin, int M, int L, int P,
                                                        int Dh) {
   const int D = M * Dh;
   const int cpq = D / (8 * NC);   // thread slots per query
@@ -109,6 +109,14 @@ __global__ __launch_bounds__(256) void msda_fwd_kernel(const T* __restrict__ val
       o.z = pack2<T>(acc[8 * h + 4], acc[8 * h + 5]);
       o.w = pack2<T>(acc[8 * h + 6], acc[8 * h + 7]);
       *reinterpret_cast<uint4*>(out + bq * D + c * 8 * NC + 8 * h) = o;
+      if (out_lo) {   // rounding residuals: samp ~= out + out_lo feeds output_proj as a split A operand (bf16 at 1e-3: DESIGN.md §3)
+        uint4 ol;
+        ol.x = pack2<T>(lo_part<T>(acc[8 * h + 0]), lo_part<T>(acc[8 * h + 1]));
+        ol.y = pack2<T>(lo_part<T>(acc[8 * h + 2]), lo_part<T>(acc[8 * h + 3]));
+        ol.z = pack2<T>(lo_part<T>(acc[8 * h + 4]), lo_part<T>(acc[8 * h + 5]));
+        ol.w = pack2<T>(lo_part<T>(acc[8 * h + 6]), lo_part<T>(acc[8 * h + 7]));
+        *reinterpret_cast<uint4*>(out_lo + bq * D + c * 8 * NC + 8 * h) = ol;
+      }
     }
   }
 }
@@ -165,10 +173,11 @@ inline int grid_for(int64_t total, int block = 256, int cap = 256 * 16) {
 
 }  // namespace
 
-extern "C" int asis_msda_fwd(void* stream, int dtype, const void* value, const float* offaw, int64_t ld_offaw,
-                             const float* ref, const int32_t* shapes, const int32_t* starts, void* out, int B, int Lq,
-                             int Lin, int M, int L, int P, int Dh) {
+extern "C" int asis_msda_fwd_split(void* stream, int dtype, const void* value, const float* offaw, int64_t ld_offaw,
+                                   const float* ref, const int32_t* shapes, const int32_t* starts, void* out, void* out_lo, int B,
+                                   int Lq, int Lin, int M, int L, int P, int Dh) {
   ASIS_REQUIRE(value && offaw && ref && shapes && starts && out, "asis_msda_fwd: null pointer");
+  ASIS_REQUIRE(!out_lo || asis_aligned16(out_lo), "asis_msda_fwd_split: out_lo must be 16-byte aligned");
   ASIS_REQUIRE(B > 0 && Lq > 0 && Lin > 0 && M > 0 && L > 0 && P > 0, "asis_msda_fwd: bad shape");
   ASIS_REQUIRE(Dh % 8 == 0, "asis_msda_fwd: head dim %d must be a multiple of 8", Dh);
   ASIS_REQUIRE(L * P <= MAX_LP, "asis_msda_fwd: n_levels*n_points=%d exceeds %d", L * P, MAX_LP);
@@ -182,13 +191,20 @@ extern "C" int asis_msda_fwd(void* stream, int dtype, const void* value, const f
   const int64_t total = (int64_t)B * Lq * (M * Dh / (8 * nc));
 #define ASIS_MSDA_FWD(TT, NCC)                                                                                              \
   hipLaunchKernelGGL((msda_fwd_kernel<TT, NCC>), dim3(grid_for(total, 256, 1 << 20)), dim3(256), 0, s,                      \
-                     reinterpret_cast<const TT*>(value), offaw, ld_offaw, ref, shapes, starts, reinterpret_cast<TT*>(out), B, \
+                     reinterpret_cast<const TT*>(value), offaw, ld_offaw, ref, shapes, starts, reinterpret_cast<TT*>(out),      \
+                     reinterpret_cast<TT*>(out_lo), B, \
                      Lq, Lin, M, L, P, Dh)
   if (dtype == ASIS_F16) { if (nc == 2) ASIS_MSDA_FWD(f16, 2); else ASIS_MSDA_FWD(f16, 1); }
   else { if (nc == 2) ASIS_MSDA_FWD(bf16, 2); else ASIS_MSDA_FWD(bf16, 1); }
 #undef ASIS_MSDA_FWD
   ASIS_CHECK_LAUNCH("asis_msda_fwd");
   return ASIS_OK;
+}
+
+extern "C" int asis_msda_fwd(void* stream, int dtype, const void* value, const float* offaw, int64_t ld_offaw,
+                             const float* ref, const int32_t* shapes, const int32_t* starts, void* out, int B, int Lq,
+                             int Lin, int M, int L, int P, int Dh) {
+  return asis_msda_fwd_split(stream, dtype, value, offaw, ld_offaw, ref, shapes, starts, out, nullptr, B, Lq, Lin, M, L, P, Dh);
 }
 
 extern "C" int asis_dwconv_gelu(void* stream, int dtype, const float* x, const float* w9, const float* bias,

@@ -601,17 +601,19 @@ def add_cls_pos(x: torch.Tensor, cls: torch.Tensor, pos: torch.Tensor, out: Opti
 # adapters
 # --------------------------------------------------------------------------------------------
 def msda_fwd(value: torch.Tensor, offaw: torch.Tensor, ref: torch.Tensor, shapes_i32: torch.Tensor,
-             starts_i32: torch.Tensor, B: int, Lq: int, M: int, L: int, P: int) -> torch.Tensor:
-    """value 16-bit [B, Lin, D]; offaw fp32 [B*Lq, >= M*L*P*3]; ref fp32 [Lq, 2] -> out 16-bit [B*Lq, D]."""
+             starts_i32: torch.Tensor, B: int, Lq: int, M: int, L: int, P: int, split: bool = False):
+    """value 16-bit [B, Lin, D]; offaw fp32 [B*Lq, >= M*L*P*3]; ref fp32 [Lq, 2] -> out 16-bit [B*Lq, D]; ``split``: -> (out,
+    out_lo) with out_lo the rounding residuals (a split-precision operand pair for output_proj)."""
     _dev(value, offaw, ref, shapes_i32, starts_i32)
     Lin, D = value.shape[1], value.shape[2]
     if not value.is_contiguous() or offaw.stride(1) != 1:
         raise ValueError("msda_fwd: value must be contiguous and offaw contiguous in its last dim")
     out = torch.empty((B * Lq, D), device=value.device, dtype=value.dtype)
-    check(lib().asis_msda_fwd(_stream(), _dt(value.dtype), value.data_ptr(), offaw.data_ptr(), offaw.stride(0),
-                              _f32c(ref).data_ptr(), shapes_i32.data_ptr(), starts_i32.data_ptr(), out.data_ptr(), B, Lq,
-                              Lin, M, L, P, D // M), "asis_msda_fwd")
-    return out
+    lo = torch.empty_like(out) if split else None
+    check(lib().asis_msda_fwd_split(_stream(), _dt(value.dtype), value.data_ptr(), offaw.data_ptr(), offaw.stride(0),
+                                    _f32c(ref).data_ptr(), shapes_i32.data_ptr(), starts_i32.data_ptr(), out.data_ptr(), _p(lo), B,
+                                    Lq, Lin, M, L, P, D // M), "asis_msda_fwd")
+    return (out, lo) if split else out
 
 
 def dwconv_gelu(x: torch.Tensor, w9: torch.Tensor, bias: torch.Tensor, shapes_i32: torch.Tensor,

@@ -460,6 +460,21 @@ def main():
                                      "what": "--operand bf16 (no LayerNorm fold, no MX pass, no halo-tile convolution: f16-only paths); "
                                              "parity of this mode: tests/test_gpu_numerics.py"}
                 del eng_bf
+                # ... and the bf16 configuration that holds north_star's 1e-3 on the stress golden (tests/test_gpu_numerics.py):
+                # precise_level 2 (every linear layer of the blocks on hi + lo bf16 operands) + the adapters' MSDA layers split
+                old_pl = config.precise_level_policy
+                config.precise_level_policy = 2
+                try:
+                    eng_bp = SegEngine(eng.model, eng.backbone_encoder, eng.cross_vit, eng.cross_cnn, eng.seg_decoder, lr=0.01,
+                                       mode="reference_exact")
+                    t_bp = timed(eng_bp, warm=3, steps=6)
+                    secondary["bf16_at_1e-3"] = {"value": round(a.batch * world / t_bp, 3), "unit": "img/s", "ms_per_step": round(t_bp * 1e3, 3),
+                                                 "steps": 6, "warmup": 3,
+                                                 "what": "bf16 operands at precise_level 2 + split adapter layers: the bf16 policy whose stress "
+                                                         "golden meets 1e-3 (three 16-bit K parts per block GEMM)"}
+                    del eng_bp
+                finally:
+                    config.precise_level_policy = old_pl
             finally:
                 config.set_operand_dtype(old_dt)
                 config.loss_scale = old_ls

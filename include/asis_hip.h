@@ -317,6 +317,11 @@ int asis_ls_linear_finish(void* stream, const float* G, const float* W, const fl
 int asis_msda_fwd(void* stream, int dtype, const void* value, const float* offaw, int64_t ld_offaw, const float* ref,
                   const int32_t* shapes, const int32_t* starts, void* out, int B, int Lq, int Lin, int M, int L, int P,
                   int Dh);
+/* same, also writing the 16-bit rounding residuals of the sampled rows (out_lo, laid out like out; NULL = asis_msda_fwd): the split
+ * A operand of output_proj for checkpoints / operand types whose adapters need 16 significant bits (bf16 at 1e-3) */
+int asis_msda_fwd_split(void* stream, int dtype, const void* value, const float* offaw, int64_t ld_offaw, const float* ref,
+                        const int32_t* shapes, const int32_t* starts, void* out, void* out_lo, int B, int Lq, int Lin, int M,
+                        int L, int P, int Dh);
 
 /* DWConv 3x3 depthwise (pad 1, bias) over the token grids of each pyramid level + erf GELU
  * (backbones/adapter_blocks.py:67-80,95-97).  x fp32 [B, Ntok, C]; w9 fp32 [9][C]

@@ -17,7 +17,7 @@ from tests.conftest import golden_err, load_golden, rel_l2
 from tests.test_gpu_step import build_engine
 
 pytestmark = pytest.mark.gpu
-BF16_L2_BOUND = 2e-3      # measured 1.51e-3 (x_final 4.7e-4): single-bf16 q / k / v / P inside the attention and the adapters' GEMMs remain
+BF16_L2_BOUND = 1e-3      # north_star's tolerance; round 4 measured 1.51e-3 here (the adapters' MSDA layers were single-bf16: 1.43e-3 by themselves)
 
 
 @pytest.fixture
@@ -49,14 +49,19 @@ def test_bf16_operand_mode_whole_step_vs_reference_golden(dev, bf16_mode, mode, 
 def test_bf16_stress_golden_on_precise_level_2(dev, bf16_mode):
     """north_star asks for bf16 MFMA operands AND 1e-3 on the logits.  On the stress golden single bf16 operands cannot hold it
     (the activation sites alone put 8.7e-3 on the logits); ``precise_level 2`` (every linear layer of the ViT
-    blocks on hi + lo bf16 operands = 16 significant bits) is the bf16 configuration that can — measured here, with the bound
-    the measurement supports (what remains single-bf16: q, k, v and P inside the fused attention, the adapters' GEMMs)."""
+    blocks on hi + lo bf16 operands = 16 significant bits) plus the adapters' MSDA layers on split operands
+    (config.precise_adapters_on: automatic for bf16 at level 2 — tests/precision_probe.py vit_large 588 bf16 --fdec puts 1.43e-3 of
+    the 1.49e-3 that level 2 leaves into that group: weights 9.2e-4, sampled rows 6.2e-4) is the bf16 configuration that holds
+    north_star's 1e-3.  What remains single-bf16: q, k, v and P inside the fused attention (2.6e-4, 2.0e-4), the ConvFFN (3.5e-4),
+    the MSDA inputs and value tensor (2.8e-4, 2.7e-4)."""
     g = load_golden("step")
     old = config.precise_level_policy
     config.precise_level_policy = 2
     try:
         eng, _ = build_engine("vit_large", "kernel", dev)
         assert eng.precise_level == 2
+        config.precise_level = 2
+        assert config.precise_adapters_on()
         img, tgt = W.synthetic_batch(1, 588)
         taps = {}
         loss = eng.train_step(img.to(dev), tgt.to(dev), taps)
