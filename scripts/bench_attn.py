@@ -55,7 +55,7 @@ def main():
         f()
         err = float((o.float() - ref).norm() / ref.norm())
         ms = timeit(f)
-        print(f"PIPE={os.environ.get('ASIS_ATTN_PIPE', '1')} NOFOLD={os.environ.get('ASIS_ATTN_NOFOLD', '0')} {name:42s} {ms * 1e3:8.1f} us  "
+        print(f"{name:42s} {ms * 1e3:8.1f} us  "
               f"{fl / ms / 1e9:6.0f} TFLOP/s  rel {err:.2e}")
 
 
