@@ -345,11 +345,19 @@ def main():
     build_library()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (HIP device); there is no CPU fallback")
+    # ASIS_BENCH_BACKEND=gloo (rehearsal on a one-GPU box, tests/test_gpu_dist.py): every rank on device 0, collectives over gloo —
+    # the N > 1 code path of this file (barriers, MAX over ranks, secondary passes, one JSON line) without a second device
+    backend = os.environ.get("ASIS_BENCH_BACKEND", "nccl")
+    if backend == "gloo":
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # "nccl" == RCCL on ROCm
+        if backend == "gloo":
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # "nccl" == RCCL on ROCm
 
     # torchrun exports OMP_NUM_THREADS=1: give every rank its share of the host cores for the (CPU, Philox) weight generation
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)

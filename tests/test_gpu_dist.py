@@ -184,3 +184,27 @@ def test_two_rank_syncbn_with_ragged_batches_matches_full_batch(dev):
     assert torch.equal(r0["rm"], r1["rm"])
     for got, ref in ((r0["c"], c[:1]), (r1["c"], c[1:])):
         assert float((got.double() - ref.double()).norm() / ref.double().norm()) < 1e-5
+
+
+def test_bench_two_ranks_rehearsal_over_gloo(dev):
+    """`python bench.py --gpus 2` end to end on the one-GPU box: both ranks on device 0, collectives over gloo
+    (ASIS_BENCH_BACKEND=gloo) — the launcher, the barriers, the MAX-over-ranks timing, the per-stage gradient all-reduce, the
+    secondary passes (each builds a second engine over the same modules on every rank) and the single JSON line of the N > 1
+    path the driver runs on its 8-GPU node.  Small geometry (vit_tiny_test, 224^2, 2 images per rank): a rehearsal, not a
+    measurement."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(ASIS_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--arch",
+                        "vit_tiny_test", "--size", "224", "--batch", "2", "--no-cpu-baseline"], env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["n_ranks_seen"] == 2 and j["config"]["global_batch"] == 4 and j["scaling"] == "weak"
+    assert j["value"] > 0 and j["config"]["skipped_optimizer_steps"] == 0
+    assert set(j["secondary"]) >= {"all_reference_calls", "bf16", "bf16_at_1e-3"} and j["host_enqueue_ms_per_step"] > 0
