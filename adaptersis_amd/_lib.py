@@ -86,6 +86,7 @@ SIGNATURES = {
     "asis_mx_from_pair": [_vp, _i, _vp, _vp, _i64, _vp, _i64, _i64, _i, _vp, _i],
     "asis_bn_relu_upsample_mx": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i],
     "asis_pack_conv_weight_mx": [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i64, _vp],
+    "asis_pack_conv_weight_pair": [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i64, _vp],
     "asis_decoder_input_mx": [_vp, _i, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i],
     "asis_ln_stats_finalize": [_vp, _vp, _i64, _i, _i, _f, _vp],
     "asis_split_stats": [_vp, _i, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _i, _f],

@@ -40,10 +40,10 @@ class _Stage:
 
 def _conv_weights(owner: _Packed, key: str, conv: nn.Conv2d, split: bool):
     dt = config.operand_dtype
-    w_hi = _pack(owner._cache, key + ".w", conv.weight, lambda p: ops.pack_conv_weight(p.float().contiguous(), 0, dt))
-    w_lo = _pack(owner._cache, key + ".wlo", conv.weight,
-                 lambda p: ops.pack_conv_weight(p.float().contiguous(), 0, dt, 1)) if split else None
-    return w_hi, w_lo
+    if split:   # hi + residual in one pass over the fp32 weight
+        w_hi, w_lo, _ = _pack(owner._cache, key + ".wpair", conv.weight, lambda p: ops.pack_conv_weight_pair(p.float().contiguous(), 0, dt))
+        return w_hi, w_lo
+    return _pack(owner._cache, key + ".w", conv.weight, lambda p: ops.pack_conv_weight(p.float().contiguous(), 0, dt)), None
 
 
 _KSPLIT = os.environ.get("ASIS_CONV_KSPLIT", "1") != "0"
@@ -81,11 +81,16 @@ def _conv_ksplit(P: int, Cout: int, Cin: int, split: bool) -> int:
 
 
 def _conv_weights_mx(owner: _Packed, key: str, conv: nn.Conv2d):
-    """(16-bit weight, its MX lo operand (weight side), absolute maximum) — config.mx_conv"""
+    """(16-bit weight, its MX lo operand (weight side), absolute maximum) — config.mx_conv; one absmax pass + one pack pass"""
     dt = config.operand_dtype
-    w_hi = _pack(owner._cache, key + ".w", conv.weight, lambda p: ops.pack_conv_weight(p.float().contiguous(), 0, dt))
-    w_mx, amax = _pack(owner._cache, key + ".wmx", conv.weight, lambda p: ops.pack_conv_weight_mx(p.float().contiguous(), 0, dt))
-    return w_hi, w_mx, amax
+    amax = _w_amax(owner, key, conv)
+    return _pack(owner._cache, key + ".wpairmx", conv.weight,
+                 lambda p: ops.pack_conv_weight_pair(p.float().contiguous(), 0, dt, mx=True, amax=amax))
+
+
+def _w_amax(owner: _Packed, key: str, conv: nn.Conv2d):
+    """the weight's absolute maximum, shared by the forward and the input-gradient MX packs of one step"""
+    return _pack(owner._cache, key + ".wamax", conv.weight, lambda p: ops.conv_weight_absmax(p.float().contiguous()))
 
 
 def conv_bn_relu_up_forward(owner: _Packed, key: str, x16, x_lo, conv: nn.Conv2d, bn: nn.BatchNorm2d, factor: int,
@@ -211,15 +216,16 @@ def _dgrad(owner: _Packed, key: str, conv: nn.Conv2d, d16, d_lo, pad: int = 1):
     """dX = conv_transpose(dY): implicit GEMM on dY with flipped weights; split precision when d_lo is given
     (the next stage's BatchNorm backward subtracts means: 16-bit rounding noise would be amplified)."""
     dt = config.operand_dtype
-    wd = _pack(owner._cache, key + ".wd", conv.weight, lambda p: ops.pack_conv_weight(p.float().contiguous(), 1, dt))
     if d_lo is None:
+        wd = _pack(owner._cache, key + ".wd", conv.weight, lambda p: ops.pack_conv_weight(p.float().contiguous(), 1, dt))
         return ops.conv_gemm(d16, wd, 3, 3, 1, pad)
     mx_in = getattr(d_lo, "_asis_mx_amax", None)
     if mx_in is not None:
-        wd_mx, w_amax = _pack(owner._cache, key + ".wdmx", conv.weight, lambda p: ops.pack_conv_weight_mx(p.float().contiguous(), 1, dt))
+        amax = _w_amax(owner, key, conv)
+        wd, wd_mx, w_amax = _pack(owner._cache, key + ".wdpairmx", conv.weight,
+                                  lambda p: ops.pack_conv_weight_pair(p.float().contiguous(), 1, dt, mx=True, amax=amax))
         return ops.conv_gemm_split(d16, d_lo, wd, wd_mx, 3, 3, 1, pad, mx=(mx_in, w_amax))
-    wd_lo = _pack(owner._cache, key + ".wdlo", conv.weight,
-                  lambda p: ops.pack_conv_weight(p.float().contiguous(), 1, dt, 1))
+    wd, wd_lo, _ = _pack(owner._cache, key + ".wdpair", conv.weight, lambda p: ops.pack_conv_weight_pair(p.float().contiguous(), 1, dt))
     return ops.conv_gemm_split(d16, d_lo, wd, wd_lo, 3, 3, 1, pad)
 
 

@@ -355,7 +355,8 @@ __global__ __launch_bounds__(256) void bn_relu_upsample8_kernel(const float* __r
 template <typename T>
 __global__ __launch_bounds__(256) void pack_conv_weight_kernel(const float* __restrict__ w, T* __restrict__ out,
                                                                int Cout, int Cin, int KH, int KW, int mode, int CoP,
-                                                               int64_t ldo, int rows, int part, const float* __restrict__ mx_amax) {
+                                                               int64_t ldo, int rows, int part, const float* __restrict__ mx_amax,
+                                                               T* __restrict__ out2 = nullptr) {
   const int64_t total = (int64_t)rows * ldo;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int r = (int)(i / ldo);
@@ -374,7 +375,15 @@ __global__ __launch_bounds__(256) void pack_conv_weight_kernel(const float* __re
         if (co < Cout) v = w[(((int64_t)co * Cin + r) * KH + kh) * KW + kw];
       }
     }
-    if (part == 2) {   // MX form of the lo operand, weight side: (lo8, hi8) in the element's two bytes
+    if (out2) {        // pair form (round 5): the 16-bit weight AND its lo operand (residual, or MX when an amax is given) in one pass
+      out[i] = to_t16<T>(v);
+      if (mx_amax) {
+        const uint32_t wd = mx_pack2<T>(v, 0.f, mx_scales<T>(*mx_amax), true);
+        reinterpret_cast<uint16_t*>(out2)[i] = (uint16_t)(wd & 0xFFFFu);
+      } else {
+        out2[i] = to_t16<T>(lo_part<T>(v));
+      }
+    } else if (part == 2) {   // MX form of the lo operand, weight side: (lo8, hi8) in the element's two bytes
       const uint32_t wd = mx_pack2<T>(v, 0.f, mx_scales<T>(*mx_amax), true);
       reinterpret_cast<uint16_t*>(out)[i] = (uint16_t)(wd & 0xFFFFu);
     } else {
@@ -815,6 +824,27 @@ static int pack_conv_weight_impl(void* stream, int dtype, const float* w, void* 
     hipLaunchKernelGGL((pack_conv_weight_kernel<bf16>), dim3(grid_for(total)), dim3(256), 0, s, w,
                        reinterpret_cast<bf16*>(out), Cout, Cin, KH, KW, mode, CoP, ldo, rows, part, mx_amax);
   ASIS_CHECK_LAUNCH("asis_pack_conv_weight");
+  return ASIS_OK;
+}
+
+extern "C" int asis_pack_conv_weight_pair(void* stream, int dtype, const float* w, void* out_hi, void* out_lo, int Cout, int Cin,
+                                          int KH, int KW, int mode, int64_t ldo, const float* amax) {
+  ASIS_REQUIRE(w && out_hi && out_lo, "asis_pack_conv_weight_pair: null pointer");
+  ASIS_REQUIRE(dtype == ASIS_F16 || dtype == ASIS_BF16, "asis_pack_conv_weight_pair: bad dtype %d", dtype);
+  ASIS_REQUIRE(mode == 0 || mode == 1, "asis_pack_conv_weight_pair: mode must be 0 (forward) or 1 (dgrad)");
+  const int CoP = (Cout + 7) / 8 * 8;
+  const int rows = mode == 0 ? Cout : Cin;
+  const int64_t K = mode == 0 ? (int64_t)KH * KW * Cin : (int64_t)KH * KW * CoP;
+  ASIS_REQUIRE(Cout > 0 && Cin > 0 && KH > 0 && KW > 0 && ldo >= K, "asis_pack_conv_weight_pair: bad shape / ldo");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int64_t total = (int64_t)rows * ldo;
+  if (dtype == ASIS_F16)
+    hipLaunchKernelGGL((pack_conv_weight_kernel<f16>), dim3(grid_for(total)), dim3(256), 0, s, w, reinterpret_cast<f16*>(out_hi), Cout,
+                       Cin, KH, KW, mode, CoP, ldo, rows, 0, amax, reinterpret_cast<f16*>(out_lo));
+  else
+    hipLaunchKernelGGL((pack_conv_weight_kernel<bf16>), dim3(grid_for(total)), dim3(256), 0, s, w, reinterpret_cast<bf16*>(out_hi), Cout,
+                       Cin, KH, KW, mode, CoP, ldo, rows, 0, amax, reinterpret_cast<bf16*>(out_lo));
+  ASIS_CHECK_LAUNCH("asis_pack_conv_weight_pair");
   return ASIS_OK;
 }
 

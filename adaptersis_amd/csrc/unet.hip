@@ -181,23 +181,69 @@ __global__ __launch_bounds__(256) void convt2x2_gather_kernel(const float* __res
 }
 
 // partial[blk][co] = sum over this block's rows of the pixels (padT + y, padL + x), y < 2H, x < 2W, of
-// dcat[..., coff + co]: the ConvTranspose2d bias gradient (threads run along channels: coalesced rows)
+// dcat[..., coff + co]: the ConvTranspose2d bias gradient.  64 / 32 / 16 float4 channel lanes (by Cout) x 4 / 8 / 16 row lanes
+// per block: a wave reads whole contiguous channel runs, four rows in flight per thread; the offsets of 256 rows at a time go
+// through LDS (one index division per row, not per element), and the row lanes are folded through LDS in a fixed order.
+// (Round 5: the one-thread-per-channel form — a 64-bit division and ONE 4-byte load in flight per iteration — took 505 us per
+// call, 3 % of the config-2 step.)
 __global__ __launch_bounds__(256) void convt2x2_bias_grad_kernel(const float* __restrict__ dcat, float* __restrict__ partial,
                                                                  int B, int OH, int OW, int Cout, int H2, int W2, int Ctot,
                                                                  int coff, int padT, int padL, int rows_per_blk) {
+  __shared__ int64_t roff[256];
+  __shared__ float4 red[256];
   const int64_t rows = (int64_t)B * OH * OW;
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_blk;
   int64_t r1 = r0 + rows_per_blk;
   if (r1 > rows) r1 = rows;
-  for (int co = threadIdx.x; co < Cout; co += blockDim.x) {
-    float s = 0.f;
-    for (int64_t r = r0; r < r1; ++r) {
-      const int x = (int)(r % OW);
-      const int y = (int)((r / OW) % OH);
-      const int b = (int)(r / ((int64_t)OW * OH));
-      s += dcat[(((int64_t)b * H2 + padT + y) * W2 + padL + x) * Ctot + coff + co];
+  const int c4n = Cout >> 2;
+  const int clog = c4n >= 64 ? 6 : (c4n >= 32 ? 5 : 4);     // channel lanes 64 / 32 / 16 -> row lanes 4 / 8 / 16
+  const int cl = 1 << clog, rl = 256 >> clog;
+  const int cx = threadIdx.x & (cl - 1), ry = threadIdx.x >> clog;
+  for (int cbase = 0; cbase < c4n; cbase += cl) {
+    const int c4 = cbase + cx;
+    const bool cok = c4 < c4n;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t rb = r0; rb < r1; rb += 256) {
+      __syncthreads();
+      {
+        const int64_t r = rb + threadIdx.x;
+        if (r < r1) {
+          const int x = (int)(r % OW);
+          const int64_t t = r / OW;
+          const int y = (int)(t % OH), b = (int)(t / OH);
+          roff[threadIdx.x] = (((int64_t)b * H2 + padT + y) * W2 + padL + x) * Ctot + coff;
+        }
+      }
+      __syncthreads();
+      const int n = (int)((r1 - rb) < 256 ? (r1 - rb) : 256);
+      if (cok) {
+        int i = ry;
+        for (; i + 3 * rl < n; i += 4 * rl) {
+          const float4 a0 = *reinterpret_cast<const float4*>(dcat + roff[i] + 4 * c4);
+          const float4 a1 = *reinterpret_cast<const float4*>(dcat + roff[i + rl] + 4 * c4);
+          const float4 a2 = *reinterpret_cast<const float4*>(dcat + roff[i + 2 * rl] + 4 * c4);
+          const float4 a3 = *reinterpret_cast<const float4*>(dcat + roff[i + 3 * rl] + 4 * c4);
+          s.x += (a0.x + a1.x) + (a2.x + a3.x); s.y += (a0.y + a1.y) + (a2.y + a3.y);
+          s.z += (a0.z + a1.z) + (a2.z + a3.z); s.w += (a0.w + a1.w) + (a2.w + a3.w);
+        }
+        for (; i < n; i += rl) {
+          const float4 a0 = *reinterpret_cast<const float4*>(dcat + roff[i] + 4 * c4);
+          s.x += a0.x; s.y += a0.y; s.z += a0.z; s.w += a0.w;
+        }
+      }
     }
-    partial[(int64_t)blockIdx.x * Cout + co] = s;
+    __syncthreads();
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (ry == 0 && cok) {
+      float4 a = red[cx];
+      for (int j = 1; j < rl; ++j) {          // fixed order: the sum does not depend on the schedule
+        const float4 t = red[(j << clog) + cx];
+        a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+      }
+      float* o = partial + (int64_t)blockIdx.x * Cout + 4 * c4;
+      o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w;
+    }
   }
 }
 

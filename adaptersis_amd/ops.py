@@ -976,6 +976,35 @@ def pack_conv_weight_mx(w: torch.Tensor, mode: int, dtype: torch.dtype):
     return (out[:, :K] if ld != K else out), amax
 
 
+def conv_weight_absmax(w: torch.Tensor) -> torch.Tensor:
+    """absolute maximum of an OIHW fp32 convolution weight -> device float [1] (the MX planes' scale)"""
+    wf = _f32c(w)
+    return absmax_f32(wf.view(w.shape[0], -1) if (wf.numel() // w.shape[0]) % 4 == 0 else wf.view(1, -1))
+
+
+def pack_conv_weight_pair(w: torch.Tensor, mode: int, dtype: torch.dtype, mx: bool = False, amax: Optional[torch.Tensor] = None):
+    """-> (16-bit weight, its lo operand, amax | None) in ONE pass over the fp32 weight: lo = the rounding residual, or (``mx``)
+    the MX form scaled by the weight's absolute maximum (``amax`` if the caller holds it, else one reduction pass).  Same
+    layouts as ``pack_conv_weight``."""
+    _dev(w, amax)
+    Cout, Cin, KH, KW = w.shape
+    CoP = (Cout + 7) // 8 * 8
+    rows, K = (Cout, KH * KW * Cin) if mode == 0 else (Cin, KH * KW * CoP)
+    ld = (K + 7) // 8 * 8
+    wf = _f32c(w)
+    if mx and amax is None:
+        amax = conv_weight_absmax(wf)
+    elif not mx:
+        amax = None
+    hi = torch.empty((rows, ld), device=w.device, dtype=dtype)
+    lo = torch.empty((rows, ld), device=w.device, dtype=dtype)
+    check(lib().asis_pack_conv_weight_pair(_stream(), _dt(dtype), wf.data_ptr(), hi.data_ptr(), lo.data_ptr(), Cout, Cin, KH, KW, mode, ld,
+                                           _p(amax)), "asis_pack_conv_weight_pair")
+    if ld != K:
+        hi, lo = hi[:, :K], lo[:, :K]
+    return hi, lo, amax
+
+
 def _rows3(t: torch.Tensor, D: int, what: str):
     if t.dtype != torch.float32 or t.dim() != 3 or t.stride(2) != 1 or t.stride(1) != D:
         raise ValueError(f"{what}: expected float32 [B, n, {D}] with contiguous rows (batch stride free)")

@@ -436,6 +436,10 @@ int asis_pack_conv_weight(void* stream, int dtype, const float* w, void* out, in
 /* the same with the lo output in the MX form (asis_gemm_desc.mx_amax_a / mx_amax_b); amax = device float, the tensor's absolute maximum */
 int asis_pack_conv_weight_mx(void* stream, int dtype, const float* w, void* out_mx, int Cout, int Cin, int KH, int KW,
                              int mode, int64_t ldo, const float* amax);
+/* both operands of a split convolution in ONE pass over the fp32 weight (round 5): out_hi = asis_pack_conv_weight(part 0),
+ * out_lo = its rounding residual (amax NULL) or its MX form (amax = the weight's absolute maximum, device float) */
+int asis_pack_conv_weight_pair(void* stream, int dtype, const float* w, void* out_hi, void* out_lo, int Cout, int Cin, int KH,
+                               int KW, int mode, int64_t ldo, const float* amax);
 /* decoder input (train.py:389-406): [xs | zero-padded c4 | vit] fp32 tokens -> 16-bit NHWC [B,h,w,3D];
  * every source has its own batch stride (elements) so token slices need no copies */
 int asis_decoder_input(void* stream, int dtype, const float* xs, int64_t xs_bstride, const float* c4,

@@ -122,6 +122,23 @@ def test_pack_dgrad_weight_and_decoder_input(dev):
     assert torch.equal(out.cpu(), ref.half())
 
 
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("shape", [(6, 16, 3, 3), (64, 24, 3, 3), (8, 4, 1, 1)])
+def test_pack_conv_weight_pair_equals_the_single_packs(dev, mode, shape):
+    """the one-pass pair (hi + residual, hi + MX) is bit-identical to the three separate packs it replaces"""
+    w = W.tensor(f"pkp.w{shape}", shape, 1.0).to(dev)
+    for dt in (torch.float16, torch.bfloat16):
+        hi, lo, amax = ops.pack_conv_weight_pair(w, mode, dt)
+        assert amax is None
+        assert torch.equal(hi, ops.pack_conv_weight(w, mode, dt)) and torch.equal(lo, ops.pack_conv_weight(w, mode, dt, 1))
+        hi, mx, amax = ops.pack_conv_weight_pair(w, mode, dt, mx=True)
+        mx_ref, amax_ref = ops.pack_conv_weight_mx(w, mode, dt)
+        assert torch.equal(hi, ops.pack_conv_weight(w, mode, dt)) and torch.equal(amax, amax_ref)
+        assert torch.equal(mx.view(torch.int16), mx_ref.view(torch.int16))
+        hi2, mx2, amax2 = ops.pack_conv_weight_pair(w, mode, dt, mx=True, amax=amax_ref)
+        assert amax2 is amax_ref and torch.equal(mx2.view(torch.int16), mx_ref.view(torch.int16))
+
+
 @pytest.mark.parametrize("C,n_soft", [(2, 2), (2, 1), (11, 2)])
 def test_dice_loss_fwd_bwd(dev, C, n_soft):
     """resize (h->H bilinear) + softmax (x n_soft) + DC, and its gradient wrt the decoder logits."""

@@ -43,7 +43,7 @@ def test_maxpool2_fwd_bwd(dev, shape):
 
 
 @pytest.mark.parametrize("case", [(2, 5, 5, 32, 16, 0, 0, 0), (1, 10, 10, 64, 32, 32, 0, 0), (2, 2, 2, 16, 8, 24, 0, 0),
-                                  (2, 2, 3, 16, 8, 8, 1, 2)])
+                                  (2, 2, 3, 16, 8, 8, 1, 2), (2, 18, 13, 32, 264, 8, 0, 1), (1, 33, 20, 16, 136, 0, 1, 0)])
 def test_convtranspose2x2_as_gemm(dev, case):
     """GEMM + scatter == F.conv_transpose2d written into the (padded) concat buffer; gather/bias == its transpose."""
     B, H, Wd, Cin, Cout, coff, padB, padR = case
