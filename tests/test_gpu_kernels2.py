@@ -251,17 +251,31 @@ def test_conv_ksplit_matches_single_pass(dev, split):
     assert rel_l2(three, one) < 1e-6
 
 
-def test_sgd_momentum_matches_torch(dev):
-    n = 1000
+@pytest.mark.parametrize("n,off", [(1000, 0), (1003, 0), (1 << 20, 0), ((1 << 21) + 7, 0), (4099, 1), (3, 0)])
+def test_sgd_momentum_matches_torch(dev, n, off):
+    """16-byte kernel (aligned buckets, any tail) and the scalar one (``off``: a view one element into the allocation)"""
     p0, g1, g2 = W.tensor("sg.p", (n,), 1.0), W.tensor("sg.g1", (n,), 1.0), W.tensor("sg.g2", (n,), 1.0)
     pt = p0.clone().requires_grad_()
     opt = torch.optim.SGD([pt], lr=0.01, momentum=0.99, weight_decay=3e-5)
-    p, buf = p0.clone().to(dev), torch.zeros(n, device=dev)
+    p, buf = torch.empty(n + off, device=dev)[off:].copy_(p0), torch.full((n + off,), float("nan"), device=dev)[off:]
+    guard = torch.zeros(2, device=dev, dtype=torch.int32)
     for i, g in enumerate((g1, g2)):
         pt.grad = g.clone()
         opt.step()
-        ops.sgd_momentum(p, (g * 64.0).to(dev), buf, 0.01, 0.99, 3e-5, 1.0 / 64.0, i == 0)
-    assert rel_l2(p, pt.detach()) < 1e-6
+        gd = torch.empty(n + off, device=dev)[off:].copy_(g * 64.0)
+        ops.grad_guard(gd, guard, True)
+        ops.sgd_momentum(p, gd, buf, 0.01, 0.99, 3e-5, 1.0 / 64.0, i == 0, guard if i else None, count_skip=True)   # both entry points
+    assert rel_l2(p, pt.detach()) < 1e-6 and guard.tolist() == [0, 0]
+    # the guard sees a single inf / NaN wherever it sits (vector body, remainder loop, the n % 4 tail)
+    for pos in sorted({0, n // 3, n - 1, max(n - 5, 0)}):
+        for bad in (float("inf"), float("-inf"), float("nan")):
+            gd = torch.empty(n + off, device=dev)[off:].copy_(g1)
+            gd[pos] = bad
+            ops.grad_guard(gd, guard, True)
+            assert int(guard[0]) == 1, (pos, bad)
+    gd = torch.empty(n + off, device=dev)[off:].fill_(3e38)       # large but finite: not an overflow
+    ops.grad_guard(gd, guard, True)
+    assert int(guard[0]) == 0
 
 
 def test_split_precision_conv_matches_fp32(dev):
