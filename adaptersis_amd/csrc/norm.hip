@@ -223,22 +223,27 @@ inline int grid_for(int64_t total, int block = 256, int cap = 256 * 16) {
 
 // ---- LayerNorm-fold chain helpers (include/asis_hip.h: asis_gemm_desc.rowstats / ln_mr) ---------------------------------------
 // partial (sum, sum of squares) per 64-column group -> (mean, rstd) per row; partials combined as (count, mean, M2) triples
+// L (16 or 32) lanes per row, one 64-column group each: coalesced reads, xor-butterfly sums inside the L-lane group (a fixed
+// order).  Round 5: the one-thread-per-row form (83 workgroups, 128-byte strided reads) took 36 us x 65 launches per step.
+template <int L>
 __global__ __launch_bounds__(256) void ln_stats_finalize_kernel(const float* __restrict__ st, int64_t rows, int groups, int D,
                                                                 float eps, float* __restrict__ mr) {
-  const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (row >= rows) return;
-  const float2* p = reinterpret_cast<const float2*>(st) + row * groups;
-  float tot = 0.f;
-  for (int g = 0; g < groups; ++g) tot += p[g].x;
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t row = tid / L;
+  const int g = (int)(tid % L);
+  const bool ok = row < rows && g < groups;
+  const float2 v = ok ? reinterpret_cast<const float2*>(st)[row * groups + g] : make_float2(0.f, 0.f);
+  float tot = v.x;
+#pragma unroll
+  for (int o = L / 2; o >= 1; o >>= 1) tot += __shfl_xor(tot, o, L);
   const float mean = tot / (float)D;
-  float m2 = 0.f;
-  for (int g = 0; g < groups; ++g) {
-    const float n = (float)(g + 1 < groups ? 64 : D - 64 * (groups - 1));
-    const float mg = p[g].x / n;
-    const float dm = mg - mean;
-    m2 += fmaxf(p[g].y - p[g].x * mg, 0.f) + n * dm * dm;
-  }
-  reinterpret_cast<float2*>(mr)[row] = make_float2(mean, 1.0f / sqrtf(m2 / (float)D + eps));
+  const float n = (float)(g + 1 < groups ? 64 : D - 64 * (groups - 1));
+  const float mg = v.x / n;
+  const float dm = mg - mean;
+  float m2 = ok ? fmaxf(v.y - v.x * mg, 0.f) + n * dm * dm : 0.f;
+#pragma unroll
+  for (int o = L / 2; o >= 1; o >>= 1) m2 += __shfl_xor(m2, o, L);
+  if (g == 0 && row < rows) reinterpret_cast<float2*>(mr)[row] = make_float2(mean, 1.0f / sqrtf(m2 / (float)D + eps));
 }
 
 // fp32 rows -> hi / lo 16-bit planes + (mean, rstd): one wave per row, the statistics of layernorm_kernel
@@ -282,11 +287,16 @@ __global__ __launch_bounds__(256) void split_stats_kernel(const float* __restric
 }
 
 extern "C" int asis_ln_stats_finalize(void* stream, const float* rowstats, int64_t rows, int groups, int D, float eps, float* mr) {
-  ASIS_REQUIRE(rowstats && mr && rows >= 0 && groups >= 1 && D > 64 * (groups - 1) && D <= 64 * groups,
-               "asis_ln_stats_finalize: bad arguments (rows %ld, groups %d, D %d)", (long)rows, groups, D);
+  ASIS_REQUIRE(rowstats && mr && rows >= 0 && groups >= 1 && groups <= 32 && D > 64 * (groups - 1) && D <= 64 * groups,
+               "asis_ln_stats_finalize: bad arguments (rows %ld, groups %d <= 32, D %d)", (long)rows, groups, D);
   if (rows == 0) return ASIS_OK;
-  hipLaunchKernelGGL(ln_stats_finalize_kernel, dim3((unsigned)asis_cdiv(rows, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                     rowstats, rows, groups, D, eps, mr);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (groups <= 16)
+    hipLaunchKernelGGL((ln_stats_finalize_kernel<16>), dim3((unsigned)asis_cdiv(rows * 16, 256)), dim3(256), 0, s, rowstats, rows, groups, D,
+                       eps, mr);
+  else
+    hipLaunchKernelGGL((ln_stats_finalize_kernel<32>), dim3((unsigned)asis_cdiv(rows * 32, 256)), dim3(256), 0, s, rowstats, rows, groups, D,
+                       eps, mr);
   ASIS_CHECK_LAUNCH("asis_ln_stats_finalize");
   return ASIS_OK;
 }

@@ -65,6 +65,21 @@ def test_planes_rowstats_res16_epilogue(dev, p8, M, N, K):
         ops.gemm_set_option("p8", 1)
 
 
+@pytest.mark.parametrize("rows,D", [(1000, 768), (4097, 1024), (333, 1536), (70, 1000), (5, 64), (129, 2048)])
+def test_ln_stats_finalize_from_group_sums(dev, rows, D):
+    """(sum, sum of squares) per 64-column group -> (mean, rstd): 16 / 32 lanes per row, ragged last group, rows % 16 != 0"""
+    x = (W.tensor(f"lsf.x{rows}.{D}", (rows, D), 1.0) * 3 + W.tensor(f"lsf.m{rows}", (rows, 1), 5.0)).to(dev)
+    groups = (D + 63) // 64
+    xp = torch.nn.functional.pad(x, (0, groups * 64 - D)).view(rows, groups, 64)
+    st = torch.stack((xp.sum(2), (xp * xp).sum(2)), 2).contiguous()
+    mr = ops.ln_stats_finalize(st, D, 1e-6)
+    xd = x.double()
+    assert mr.shape == (rows, 2)
+    assert rel_l2(mr[:, 0], xd.mean(1).float()) < 1e-6
+    assert rel_l2(mr[:, 1], (xd.var(1, unbiased=False) + 1e-6).rsqrt().float()) < 2e-5
+    assert torch.equal(mr, ops.ln_stats_finalize(st, D, 1e-6))
+
+
 @pytest.mark.parametrize("p8,M,N,K,act", [(2, 17645, 2048, 1024, ops.ACT_NONE), (2, 17645, 4096, 1024, ops.ACT_GELU),
                                           (0, 17645, 2048, 1024, ops.ACT_NONE)])
 def test_ln_fold_rows(dev, p8, M, N, K, act):
