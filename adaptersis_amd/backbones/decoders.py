@@ -110,7 +110,7 @@ def conv_bn_relu_up_forward(owner: _Packed, key: str, x16, x_lo, conv: nn.Conv2d
     OH, OW = (H + 2 * pad - 3) // stride + 1, (W + 2 * pad - 3) // stride + 1
     # ``x_lo`` tagged with an absolute maximum: it is in the MX form (two fp8 bytes per element; config.mx_conv) and the
     # weight's lo operand is built likewise — the two correction terms run as one block-scaled fp8 MFMA pass
-    mx_in = getattr(x_lo, "_asis_mx_amax", None) if split else None
+    mx_in = ops.mx_amax_of(x_lo) if split else None
     if mx_in is not None:
         w_hi, w_lo, w_amax = _conv_weights_mx(owner, key, conv)
     else:
@@ -219,7 +219,7 @@ def _dgrad(owner: _Packed, key: str, conv: nn.Conv2d, d16, d_lo, pad: int = 1):
     if d_lo is None:
         wd = _pack(owner._cache, key + ".wd", conv.weight, lambda p: ops.pack_conv_weight(p.float().contiguous(), 1, dt))
         return ops.conv_gemm(d16, wd, 3, 3, 1, pad)
-    mx_in = getattr(d_lo, "_asis_mx_amax", None)
+    mx_in = ops.mx_amax_of(d_lo)
     if mx_in is not None:
         amax = _w_amax(owner, key, conv)
         wd, wd_mx, w_amax = _pack(owner._cache, key + ".wdpairmx", conv.weight,

@@ -64,7 +64,7 @@ class FeatureEncoder(_Packed):
         s, p = conv.stride[0], conv.padding[0]
         OH, OW = (H + 2 * p - 3) // s + 1, (W + 2 * p - 3) // s + 1
         stats = torch.empty((ops.gemm_tiles_m(B * OH * OW), 2, conv.out_channels), device=x16.device, dtype=torch.float32)
-        mx_in = getattr(x_lo, "_asis_mx_amax", None) if x_lo is not None else None
+        mx_in = ops.mx_amax_of(x_lo)
         if mx_in is not None:
             # MX operand planes (the 64 -> 64 stem convolutions at 294^2): the halo-tile kernel, BatchNorm partial sums included
             w_mx, w_amax = _pack(self._cache, f"{key}.mx", conv.weight, lambda q: ops.pack_conv_weight_mx(q.float().contiguous(), 0, config.operand_dtype))

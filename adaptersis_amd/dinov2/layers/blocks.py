@@ -14,7 +14,7 @@ Data flow of one eval-mode block (`block.py:111-113`), residual stream fp32 [B*N
 from __future__ import annotations
 
 import contextlib
-
+import math
 from typing import Callable, Optional, Tuple, Union
 
 import torch
@@ -32,6 +32,9 @@ def _vt_side_stream(device) -> "torch.cuda.Stream":
     if key not in _VT_STREAMS:
         _VT_STREAMS[key] = torch.cuda.Stream(device=device)
     return _VT_STREAMS[key]
+
+
+_LS_POW2_REFRESH = 64   # Block._ls_pow2: parameter changes between two reads of max|gamma|
 
 
 def _pack(cache: dict, key: str, param: torch.Tensor, fn: Callable[[torch.Tensor], torch.Tensor]):
@@ -92,10 +95,26 @@ class _Packed(nn.Module):
         taken out again, exactly, where its gradients are written in fp32 (Block.backward)."""
         if gamma is None:
             return 0
-        def make():
-            m = float(gamma.detach().abs().max())
-            return torch.tensor(0 if not (m > 0.0) else -int(torch.floor(torch.log2(torch.tensor(m))).item()))
-        return int(self._pack2(key, gamma, None, make))
+        # reading max|gamma| is a device-to-host sync: a frozen gamma pays it once; a TRAINED one (``optimize_backbone``) moves a
+        # little every step, and k is only a range choice (any nearby power of two is exact), so it is re-read every
+        # _LS_POW2_REFRESH changes of the parameter instead of 2 syncs per block per step inside the overlapped backward
+        tag = (gamma.data_ptr(), gamma.device, config.operand_dtype)
+        gen = (gamma._version, getattr(gamma, "_asis_gen", 0))
+        ent = self._cache.get(key)
+        if ent is not None and ent[0] == tag:
+            st = ent[1]                       # [k, generation seen at the last read, changes since]
+            if st[1] == gen:
+                return st[0]
+            if st[2] + 1 < _LS_POW2_REFRESH:
+                st[1], st[2] = gen, st[2] + 1
+                return st[0]
+        m = float(gamma.detach().abs().max())
+        k = 0 if not (m > 0.0 and m < float("inf")) else -int(math.floor(math.log2(m)))
+        if ent is not None and ent[0] == tag and ent[1][0] != k:
+            for stale in [c for c in self._cache if c.endswith(f"@{ent[1][0]}") or c.endswith(f"@{-ent[1][0]}")]:
+                del self._cache[stale]        # the 2^k-scaled weight packs of the old k
+        self._cache[key] = (tag, [k, gen, 0])
+        return k
 
     def _nw_pow2(self, key: str, w: torch.Tensor, pow2: int) -> torch.Tensor:
         """fp32 LayerNorm weight times 2^pow2 (exact): takes a branch gradient's power-of-two scale out in the LayerNorm backward"""

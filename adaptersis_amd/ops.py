@@ -236,6 +236,8 @@ def conv_gemm_split(x_hi, x_lo, w_hi, w_lo, KH: int, KW: int, stride: int, pad: 
     """Split-precision convolution: x ~= x_hi + x_lo, w ~= w_hi + w_lo (16-bit halves), fp32 out =
     x_hi*w_hi + x_lo*w_hi + x_hi*w_lo (+ bias), accumulated in fp32 (the dropped x_lo*w_lo term is ~2^-22
     relative): one launch over a virtual 3K reduction on the large-tile kernel, else three accumulate passes."""
+    if mx is None:
+        _not_mx("conv_gemm_split", x_lo, w_lo)
     Bn, H, W, Cin = x_hi.shape
     OH, OW = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
     Cout = w_hi.shape[0]
@@ -820,6 +822,37 @@ def bn_finalize(sums: torch.Tensor, count: float, gamma, beta, eps: float, momen
     return out[0], out[1], out[2], out[3]
 
 
+class MxPlane(torch.Tensor):
+    """The lo half of a split-precision operand in the MX form (two fp8 bytes per element, scaled by the tensor's absolute
+    maximum) instead of a 16-bit rounding residual.  The producers (bn_act, bn_relu_upsample, decoder_input, bn_bwd_apply) tag it
+    with that maximum (``_asis_mx_amax``); the TYPE survives views, slices and copies, the attribute does not, so a consumer
+    that meets an MxPlane without its maximum (``mx_amax_of``), or as a 16-bit lo operand (``_not_mx``), raises instead of
+    reading the fp8 pair as an fp16 residual."""
+
+    @staticmethod
+    def tag(t: torch.Tensor, amax: torch.Tensor) -> "MxPlane":
+        p = t.as_subclass(MxPlane)
+        p._asis_mx_amax = amax
+        return p
+
+
+def mx_amax_of(lo: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    """the absolute maximum an MX-form lo plane was scaled by; None for a 16-bit residual (or no lo plane at all)"""
+    if lo is None:
+        return None
+    amax = getattr(lo, "_asis_mx_amax", None)
+    if amax is None and isinstance(lo, MxPlane):
+        raise ValueError("an MX-form lo plane reached its consumer without its absolute maximum (a view / slice / copy of the "
+                         "producer's tensor drops the tag): pass the producer's tensor itself")
+    return amax
+
+
+def _not_mx(what: str, *planes) -> None:
+    for t in planes:
+        if isinstance(t, MxPlane):
+            raise ValueError(f"{what}: an MX-form lo plane was passed where a 16-bit rounding residual is expected")
+
+
 def _lo(out: torch.Tensor, split: bool):
     return torch.empty_like(out) if split else None
 
@@ -846,8 +879,7 @@ def bn_act(x: torch.Tensor, scale, shift, relu: bool, dtype: torch.dtype, split:
     if mx_amax is not None and split:
         check(lib().asis_bn_act_mx(_stream(), _dt(dtype), _f32c(x).data_ptr(), scale.data_ptr(), shift.data_ptr(), int(relu),
                                    out.data_ptr(), lo.data_ptr(), mx_amax.data_ptr(), x.numel() // Cc, Cc), "asis_bn_act_mx")
-        lo._asis_mx_amax = mx_amax
-        return out, lo
+        return out, MxPlane.tag(lo, mx_amax)
     check(lib().asis_bn_act(_stream(), _dt(dtype), _f32c(x).data_ptr(), scale.data_ptr(), shift.data_ptr(), int(relu),
                             out.data_ptr(), _p(lo), x.numel() // Cc, Cc), "asis_bn_act")
     return (out, lo) if split else out
@@ -915,8 +947,7 @@ def bn_relu_upsample(x: torch.Tensor, scale, shift, factor: int, dtype: torch.dt
         check(lib().asis_bn_relu_upsample_mx(_stream(), _dt(dtype), _f32c(x).data_ptr(), scale.data_ptr(), shift.data_ptr(),
                                              out.data_ptr(), lo.data_ptr(), _f32c(mx_amax).data_ptr(), B, H, W, Cc, factor),
               "asis_bn_relu_upsample_mx")
-        lo._asis_mx_amax = mx_amax
-        return out, lo
+        return out, MxPlane.tag(lo, mx_amax)
     check(lib().asis_bn_relu_upsample(_stream(), _dt(dtype), _f32c(x).data_ptr(), scale.data_ptr(), shift.data_ptr(),
                                       out.data_ptr(), _p(lo), B, H, W, Cc, factor), "asis_bn_relu_upsample")
     return (out, lo) if split else out
@@ -1028,8 +1059,7 @@ def decoder_input(xs: torch.Tensor, c4: torch.Tensor, vit: torch.Tensor, hw, c4_
         check(lib().asis_decoder_input_mx(_stream(), _dt(dtype), xs.data_ptr(), xs.stride(0), c4.data_ptr(), c4.stride(0),
                                           vit.data_ptr(), vit.stride(0), out.data_ptr(), lo.data_ptr(), amax.data_ptr(), B, h, w,
                                           h4, w4, D), "asis_decoder_input_mx")
-        lo._asis_mx_amax = amax
-        return out, lo
+        return out, MxPlane.tag(lo, amax)
     check(lib().asis_decoder_input(_stream(), _dt(dtype), xs.data_ptr(), xs.stride(0), c4.data_ptr(), c4.stride(0),
                                    vit.data_ptr(), vit.stride(0), out.data_ptr(), _p(lo), B, h, w, h4, w4, D),
           "asis_decoder_input")
@@ -1077,6 +1107,7 @@ def add_f32(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None
 def maxpool2_fwd(x: torch.Tensor, x_lo: Optional[torch.Tensor], save_idx: bool = True):
     """MaxPool2d(2) on a split-precision NHWC map: (hi, lo|None) [B,H,W,C] -> (hi, lo|None) [B,H/2,W/2,C], idx uint8."""
     _dev(x, x_lo)
+    _not_mx("maxpool2_fwd", x_lo)
     B, H, W, Cc = x.shape
     if not x.is_contiguous() or (x_lo is not None and (not x_lo.is_contiguous() or x_lo.shape != x.shape)):
         raise ValueError("maxpool2_fwd: contiguous NHWC operands of one shape expected")
@@ -1365,6 +1396,7 @@ def maxpool_bn_relu_bwd(dy: torch.Tensor, x: torch.Tensor, scale, shift, mean, i
 def dilate2(x: torch.Tensor, x_lo: Optional[torch.Tensor], Hd: int, Wd: int):
     """16-bit NHWC [B,OH,OW,C] (+lo) -> [B,Hd,Wd,C] with the input at even positions, zeros elsewhere."""
     _dev(x, x_lo)
+    _not_mx("dilate2", x_lo)
     B, OH, OW, Cc = x.shape
     out = torch.empty((B, Hd, Wd, Cc), device=x.device, dtype=x.dtype)
     out_lo = torch.empty_like(out) if x_lo is not None else None
@@ -1391,8 +1423,7 @@ def bn_bwd_apply(g: torch.Tensor, x: torch.Tensor, mean, invstd, gamma, dgamma, 
         check(lib().asis_bn_bwd_absmax(_stream(), *args, amax.data_ptr(), R, Cc), "asis_bn_bwd_absmax")
         check(lib().asis_bn_bwd_apply_mx(_stream(), _dt(dtype), *args, out.data_ptr(), lo.data_ptr(), amax.data_ptr(), partial.data_ptr(),
                                          R, Cc), "asis_bn_bwd_apply_mx")
-        lo._asis_mx_amax = amax
-        return out, lo, partial
+        return out, MxPlane.tag(lo, amax), partial
     check(lib().asis_bn_bwd_apply(_stream(), _dt(dtype), *args, out.data_ptr(), _p(lo), partial.data_ptr(), R, Cc), "asis_bn_bwd_apply")
     return (out, lo, partial) if split else (out, partial)
 

@@ -34,6 +34,49 @@ def test_ops_refuse_cpu_tensors():
         ops.layernorm(torch.zeros(4, 8), torch.ones(8), torch.zeros(8))
 
 
+def test_mx_plane_tag_is_checked_not_assumed():
+    """an MX-form lo plane (two fp8 bytes per element) must never be read as a 16-bit residual: the type survives views and
+    copies, the absolute maximum does not, and every consumer asks through ops.mx_amax_of / ops._not_mx"""
+    from adaptersis_amd import ops
+    lo = torch.zeros(2, 4, 4, 8, dtype=torch.float16)
+    amax = torch.ones(1)
+    assert ops.mx_amax_of(None) is None and ops.mx_amax_of(lo) is None          # a plain residual
+    mx = ops.MxPlane.tag(lo, amax)
+    assert ops.mx_amax_of(mx) is amax and mx.data_ptr() == lo.data_ptr()
+    for dropped in (mx[:1], mx.clone(), mx.reshape(2, 16, 8), mx.contiguous()[0:1]):
+        assert isinstance(dropped, ops.MxPlane)
+        with pytest.raises(ValueError, match="without its absolute maximum"):
+            ops.mx_amax_of(dropped)
+    with pytest.raises(ValueError, match="16-bit rounding residual is expected"):
+        ops._not_mx("dilate2", mx)
+    ops._not_mx("dilate2", lo, None)
+
+
+def test_layerscale_pow2_is_not_a_host_sync_per_step():
+    """Block._ls_pow2 reads max|gamma| (a device-to-host sync) once for a frozen gamma and once per _LS_POW2_REFRESH changes
+    for a trained one; packs scaled by a retired k are evicted"""
+    from adaptersis_amd.dinov2.layers import blocks as B
+    blk = B.Block(64, 1, qkv_bias=True, init_values=1e-5)
+    g = blk.ls1.gamma
+    assert blk._ls_pow2("ls1.k", g) == 17 and blk._ls_pow2("ls1.k", None) == 0      # 1e-5 * 2^17 = 1.31
+    blk._cache["projT@17"] = ("x", None); blk._cache["n1w@-17"] = ("x", None); blk._cache["qkvT"] = ("x", None)
+    for i in range(B._LS_POW2_REFRESH - 1):
+        with torch.no_grad():
+            g.mul_(1.0 + 1e-3)
+        assert blk._ls_pow2("ls1.k", g) == 17, i
+        assert blk._ls_pow2("ls1.k", g) == 17                                        # same generation: no counting
+    with torch.no_grad():
+        g.fill_(3e-4)                                                                # 3e-4 * 2^12 = 1.23
+    assert blk._ls_pow2("ls1.k", g) == 12
+    assert "projT@17" not in blk._cache and "n1w@-17" not in blk._cache and "qkvT" in blk._cache
+    with torch.no_grad():
+        g.zero_()
+    for _ in range(B._LS_POW2_REFRESH):
+        g._asis_gen = getattr(g, "_asis_gen", 0) + 1                                 # the fused optimizer's change marker
+        k = blk._ls_pow2("ls1.k", g)
+    assert k == 0
+
+
 def test_modules_refuse_cpu_inputs():
     from adaptersis_amd.dinov2.models import vision_transformer as vits
     m = vits.vit_tiny_test(img_size=518, init_values=1e-5)
