@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libasis_hip.so")
 
 ASIS_F16, ASIS_BF16, ASIS_F32 = 0, 1, 2
 ASIS_EINVAL, ASIS_ELAUNCH = -1, -2
-ACT_NONE, ACT_GELU, ACT_RELU, ACT_GELU_GRAD = 0, 1, 2, 4
+ACT_NONE, ACT_GELU, ACT_RELU, ACT_SILU_MUL, ACT_GELU_GRAD = 0, 1, 2, 3, 4
 
 
 class AsisError(RuntimeError):

@@ -199,6 +199,8 @@ __device__ __forceinline__ float gelu_erf(float x) {
   p = __builtin_fmaf(p, a, 6.93082119e-06f - 1.0f);
   return __builtin_fmaf(-ax, __builtin_amdgcn_exp2f(p), fmaxf(x, 0.f));
 }
+// SwiGLU gate `dinov2/layers/swiglu_ffn.py:30-34`: silu(a) * b (the asis_swiglu kernel and the ASIS_ACT_SILU_MUL epilogue: one formula)
+__device__ __forceinline__ float silu_mul(float a, float b) { return a / (1.f + __expf(-a)) * b; }
 // four values at once on the packed-fp32 pipe (v_pk_fma_f32: the Horner steps of two values per instruction)
 __device__ __forceinline__ void gelu_erf4(float& x0, float& x1, float& x2, float& x3) {
   typedef float f32x2_ __attribute__((ext_vector_type(2)));

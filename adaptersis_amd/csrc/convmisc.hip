@@ -550,8 +550,8 @@ __global__ __launch_bounds__(256) void swiglu_kernel(const float* __restrict__ x
     const int c = (int)(i - r * cpr);
     const float4 a = reinterpret_cast<const float4*>(x12 + r * 2 * Hd)[c];
     const float4 b = reinterpret_cast<const float4*>(x12 + r * 2 * Hd + Hd)[c];
-    const float h0 = a.x / (1.f + __expf(-a.x)) * b.x, h1 = a.y / (1.f + __expf(-a.y)) * b.y;
-    const float h2 = a.z / (1.f + __expf(-a.z)) * b.z, h3 = a.w / (1.f + __expf(-a.w)) * b.w;
+    const float h0 = silu_mul(a.x, b.x), h1 = silu_mul(a.y, b.y);
+    const float h2 = silu_mul(a.z, b.z), h3 = silu_mul(a.w, b.w);
     uint2 o;
     o.x = pack2<T>(h0, h1);
     o.y = pack2<T>(h2, h3);

@@ -226,6 +226,21 @@ int launch(hipStream_t s, const asis_gemm_desc& d) {
                     (reinterpret_cast<uintptr_t>(d.C) & 15) == 0 && !d.bias_m;
     if (!ok) return ASIS_EINVAL;
   }
+  if (d.act == ASIS_ACT_SILU_MUL) {
+    // SwiGLU epilogue: lives in the 16-bit fast path of the 8-phase 16x16-MFMA instances (gemm_big.h) — the launch goes there
+    // directly or is refused (a fall-through to another epilogue would write x1 | x2 as if they were outputs)
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    const bool mxs = d.mx_amax_a && d.mx_amax_b && d.A_lo && d.B_lo;
+    const bool ok = big_mode && ph8_m16_on() && !d.conv && (mxs || !split) && !d.out_f32 && !d.res && !d.res16 && !d.C_lo && !d.rowstats &&
+                    !d.stats && !d.scale_n && !d.bias_m && !d.ln_mr && !d.aux && d.batch == 1 && d.ksplit <= 1 && d.K % 64 == 0 && d.M >= 256 &&
+                    d.N >= 256 && d.N % 32 == 0 && d.ldc % 8 == 0 && d.ldc >= d.N / 2 && al16(d.C) && (!d.bias_n || al16(d.bias_n)) &&
+                    (int64_t)d.N * d.ldb < (1ll << 31);
+    if (!ok) return ASIS_EINVAL;
+    dim3 g8(((d.M + 255) / 256) * ((d.N + 255) / 256), 1), block(512);
+    if (mxs) hipLaunchKernelGGL((gemm_big_kernel<T, 2, 4, 4, 2, 2, 0, false, true, 64, 1, true, true, 0, true>), g8, block, 0, s, d, group_m);
+    else hipLaunchKernelGGL((gemm_big_kernel<T, 2, 4, 4, 2, 2, 0, false, false, 64, 1, true, true>), g8, block, 0, s, d, group_m);
+    return 0;
+  }
   if (d.ksplit > 1 && !(big_mode && d.conv)) return ASIS_EINVAL;
   // ASIS_GEMM_P8 (default 1): dense launches with at least one 256x256 tile per CU run on the PERSISTENT form of the 8-phase
   // kernel (gemm_p8.h: one workgroup per CU walks its tiles, the next tile's first K tile is staged during the last K tile of
@@ -414,8 +429,8 @@ extern "C" int asis_gemm(void* stream, const asis_gemm_desc* dp) {
   ASIS_REQUIRE(d.ldb % 8 == 0 && d.ldb >= d.K, "asis_gemm: ldb=%ld must be a multiple of 8 and >= K", (long)d.ldb);
   ASIS_REQUIRE(asis_aligned16(d.A) && asis_aligned16(d.B), "asis_gemm: A and B must be 16-byte aligned");
   ASIS_REQUIRE(d.strideA % 8 == 0 && d.strideB % 8 == 0, "asis_gemm: batch strides must be multiples of 8");
-  ASIS_REQUIRE(d.ldc >= d.N, "asis_gemm: ldc=%ld < N=%d", (long)d.ldc, d.N);
-  ASIS_REQUIRE((d.act >= 0 && d.act <= ASIS_ACT_RELU) || d.act == ASIS_ACT_GELU_GRAD, "asis_gemm: bad act %d", d.act);
+  ASIS_REQUIRE(d.ldc >= (d.act == ASIS_ACT_SILU_MUL ? d.N / 2 : d.N), "asis_gemm: ldc=%ld < N=%d", (long)d.ldc, d.N);
+  ASIS_REQUIRE(d.act >= 0 && d.act <= ASIS_ACT_GELU_GRAD, "asis_gemm: bad act %d", d.act);
   if (d.batch <= 0) d.batch = 1;
   ASIS_REQUIRE(d.batch <= 65535, "asis_gemm: batch %d too large", d.batch);
   if (d.res) ASIS_REQUIRE(d.ldr >= d.N, "asis_gemm: ldr=%ld < N", (long)d.ldr);
@@ -444,6 +459,9 @@ extern "C" int asis_gemm(void* stream, const asis_gemm_desc* dp) {
   ASIS_REQUIRE(!d.conv || (d.A_lo == nullptr) == (d.B_lo == nullptr), "asis_gemm: a split convolution needs both A_lo and B_lo");
   ASIS_REQUIRE((!d.A_lo || asis_aligned16(d.A_lo)) && (!d.B_lo || asis_aligned16(d.B_lo)), "asis_gemm: split halves must be 16-byte aligned");
   const int rc = (d.dtype == ASIS_F16) ? launch<f16>(s, d) : launch<bf16>(s, d);
+  if (rc != 0 && d.act == ASIS_ACT_SILU_MUL)
+    ASIS_FAIL(ASIS_EINVAL, "asis_gemm: ASIS_ACT_SILU_MUL needs a dense 16-bit-output launch on the 8-phase form (include/asis_hip.h: K %% 64 == 0, "
+                           "M >= 256, N >= 256, N %% 32 == 0, ldc %% 8 == 0, plain or MX split operands, bias only)");
   if (rc != 0) ASIS_FAIL(ASIS_EINVAL, "asis_gemm: split-precision operands / ASIS_ACT_GELU_GRAD / ksplit need the large-tile path (K %% 64 "
                                         "== 0 (GELU_GRAD: 32), M >= 256, N >= 32 (128), N and ldc multiples of 4, fp32 output for "
                                         "split; conv: Cin %% 64 == 0)");

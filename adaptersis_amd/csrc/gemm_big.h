@@ -644,8 +644,13 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_big_kernel(const asis_
           if (ln_c) mc[j][e] = mrp[colj + e < d.N ? colj + e : d.N - 1];
         }
       }
-      const int colr = n0 + wn * TN * 32 + c8 * 8;
-      const bool cokr = colr < d.N;
+      // ASIS_ACT_SILU_MUL (SwiGLU in the epilogue; dense launches, routed here by the dispatcher only): B rows come interleaved in
+      // groups of 16 ([x1 rows 16g .. 16g+15 | x2 rows 16g .. 16g+15]), so a lane's 16-column blocks 2t / 2t+1 hold x1 / x2 of the
+      // SAME four hidden columns: h = silu(x1 + b1) * (x2 + b2) in the accumulator layout, half as many 16-bit columns out
+      // ([M, N / 2], row stride ldc) — the fp32 pre-activation [M, N] never reaches HBM.
+      const bool sg = d.act == ASIS_ACT_SILU_MUL;
+      const int colr = sg ? (n0 >> 1) + wn * TN * 16 + (lane & 3) * 8 : n0 + wn * TN * 32 + c8 * 8;
+      const bool cokr = colr < (sg ? (d.N >> 1) : d.N);
       T* const Cw = reinterpret_cast<T*>(d.C) + cbase + colr;
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
@@ -661,6 +666,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_big_kernel(const asis_
             rstd = mr.y;
           }
           if (ln_c) csr = d.ln_cs[rowbc];
+          float4 vg = make_float4(0.f, 0.f, 0.f, 0.f);   // SwiGLU: the gate half (x1) of the current block pair
 #pragma unroll
           for (int j = 0; j < TN * 2; ++j) {
             float4 v;
@@ -678,6 +684,17 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_big_kernel(const asis_
               v = make_float4(acc16[2 * i + ii][j][0] + bj[j].x + bm1, acc16[2 * i + ii][j][1] + bj[j].y + bm1,
                               acc16[2 * i + ii][j][2] + bj[j].z + bm1, acc16[2 * i + ii][j][3] + bj[j].w + bm1);
             }
+            if (sg) {
+              if (j & 1) {
+                uint2 pk;
+                pk.x = pack2<T>(silu_mul(vg.x, v.x), silu_mul(vg.y, v.y));
+                pk.y = pack2<T>(silu_mul(vg.z, v.z), silu_mul(vg.w, v.w));
+                *reinterpret_cast<uint2*>(slab16 + (ii * 16 + r16) * SW16 + 16 * (j >> 1) + 4 * q16) = pk;
+              } else {
+                vg = v;
+              }
+              continue;
+            }
             if (d.act == ASIS_ACT_GELU) gelu_erf4(v.x, v.y, v.z, v.w);
             else if (d.act == ASIS_ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
             uint2 pk;
@@ -685,6 +702,16 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_big_kernel(const asis_
             pk.y = pack2<T>(v.z, v.w);
             *reinterpret_cast<uint2*>(slab16 + (ii * 16 + r16) * SW16 + 16 * j + 4 * q16) = pk;
           }
+        }
+        if (sg) {   // 32 rows x (TN * 16) hidden columns: 4 lanes x 16 bytes per row, 16 rows per instruction
+#pragma unroll
+          for (int p = 0; p < 2; ++p) {
+            const int lrow = p * 16 + (lane >> 2);
+            const int row = m0 + (wm * TM + i) * 32 + lrow;
+            const uint4 w = *reinterpret_cast<const uint4*>(slab16 + lrow * SW16 + (lane & 3) * 8);
+            if (row < d.M && cokr) *reinterpret_cast<uint4*>(Cw + (int64_t)row * d.ldc) = w;
+          }
+          continue;
         }
 #pragma unroll
         for (int p = 0; p < 4; ++p) {

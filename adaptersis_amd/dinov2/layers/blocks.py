@@ -52,7 +52,12 @@ class _Packed(nn.Module):
         super().__init__()
         self._cache = {}
 
-    def _w16(self, key: str, param: torch.Tensor) -> torch.Tensor:
+    def _w16(self, key: str, param: torch.Tensor, rows: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """16-bit [out_features, K] operand of a weight; ``rows``: its rows in that order (the SwiGLU epilogue's interleave),
+        cached under ``key`` + ".sg" """
+        if rows is not None:
+            return _pack(self._cache, key + ".sg", param,
+                         lambda p: ops.cast_pad(p.reshape(p.shape[0], -1).float()[rows].contiguous(), dtype=config.operand_dtype))
         return _pack(self._cache, key, param,
                      lambda p: ops.cast_pad(p.reshape(p.shape[0], -1).contiguous().float(), dtype=config.operand_dtype))
 
@@ -407,6 +412,16 @@ class SwiGLUFFN(_Packed):
         self.w12 = nn.Linear(in_features, 2 * hidden_features, bias=bias)
         self.w3 = nn.Linear(hidden_features, out_features, bias=bias)
 
+    # the SwiGLU epilogue of the w12 GEMM (ops.ACT_SILU_MUL) reads w12 / its bias with x1 and x2 rows interleaved in groups of 16
+    def sg_rows(self) -> torch.Tensor:
+        return _pack(self._cache, "w12.sgrows", self.w12.weight, lambda p: ops.swiglu_rows(p.shape[0] // 2, p.device))
+
+    def sg_bias(self) -> Optional[torch.Tensor]:
+        if self.w12.bias is None:
+            return None
+        rows = self.sg_rows()
+        return _pack(self._cache, "w12_b.sg", self.w12.bias, lambda p: p.float()[rows].contiguous())
+
 
 class SwiGLUFFNFused(SwiGLUFFN):
     """`swiglu_ffn.py:54-72`: hidden = (int(h*2/3)+7)//8*8."""
@@ -443,30 +458,32 @@ class Block(_Packed):
             x2 = x2.float().contiguous()
         return self.forward_rows(x2, [(B, N)]).view(B, N, D)
 
-    def _w16lo_any(self, owner, key: str, w: torch.Tensor):
-        """rounding residual of ``owner._w16(key, w)`` (same layout), whatever config.precise_attention says (precise_level 2)"""
-        return _pack(owner._cache, key + ".lo_any", w,
-                     lambda p: ops.cast_pad(p.reshape(p.shape[0], -1).contiguous().float(), dtype=config.operand_dtype, part=1))
+    def _w16lo_any(self, owner, key: str, w: torch.Tensor, rows: Optional[torch.Tensor] = None):
+        """rounding residual of ``owner._w16(key, w, rows)`` (same layout), whatever config.precise_attention says (precise_level 2)"""
+        sel = (lambda t: t) if rows is None else (lambda t: t[rows])
+        return _pack(owner._cache, key + (".sg" if rows is not None else "") + ".lo_any", w,
+                     lambda p: ops.cast_pad(sel(p.reshape(p.shape[0], -1).float()).contiguous(), dtype=config.operand_dtype, part=1))
 
-    def _w16mx_any(self, owner, key: str, w: torch.Tensor):
+    def _w16mx_any(self, owner, key: str, w: torch.Tensor, rows: Optional[torch.Tensor] = None):
         """(MX plane of the weight's (hi, lo) pair — weight side: (lo8, hi8) per element —, its absolute maximum [1])"""
-        return _pack(owner._cache, key + ".mx_any", w,
-                     lambda p: ops.mx_from_pair(owner._w16(key, w), self._w16lo_any(owner, key, w), wside=True))
+        return _pack(owner._cache, key + (".sg" if rows is not None else "") + ".mx_any", w,
+                     lambda p: ops.mx_from_pair(owner._w16(key, w, rows), self._w16lo_any(owner, key, w, rows), wside=True))
 
     def _mx_ok(self, owner, key: str, lin: nn.Linear, M: int) -> bool:
         N, K = lin.weight.shape
         return config.mx_dense_on() and K % 64 == 0 and N >= 256 and M >= 256 and N * K < (1 << 31)
 
-    def _split_lin(self, owner, key: str, lin: nn.Linear, a_hi, a_lo, a_mx=None, **kw):
+    def _split_lin(self, owner, key: str, lin: nn.Linear, a_hi, a_lo, a_mx=None, rows=None, **kw):
         """one linear layer of precise_level 2: A W^T on hi + lo operands — three 16-bit K parts, or (config.mx_dense_on) the
         16-bit part + ONE block-scaled fp8 pass over the MX planes of both operands.  ``a_mx`` = (plane, amax) made by the
-        producer (LayerNorm), else the plane is made here from the stored (hi, lo) pair."""
-        w = owner._w16(key, lin.weight)
+        producer (LayerNorm), else the plane is made here from the stored (hi, lo) pair.  ``rows``: the weight's rows in that
+        order (w12 for the SwiGLU epilogue)."""
+        w = owner._w16(key, lin.weight, rows)
         if self._mx_ok(owner, key, lin, a_hi.shape[0]):
             a_pl, amax_a = a_mx if a_mx is not None else ops.mx_from_pair(a_hi, a_lo)
-            w_mx, amax_w = self._w16mx_any(owner, key, lin.weight)
+            w_mx, amax_w = self._w16mx_any(owner, key, lin.weight, rows)
             return ops.gemm(a_hi, w, a_lo=a_pl, b_lo=w_mx, mx=(amax_a, amax_w), **kw)
-        return ops.gemm(a_hi, w, a_lo=a_lo, b_lo=self._w16lo_any(owner, key, lin.weight), **kw)
+        return ops.gemm(a_hi, w, a_lo=a_lo, b_lo=self._w16lo_any(owner, key, lin.weight, rows), **kw)
 
     def _ln_split(self, key: str, norm: nn.LayerNorm, x2: torch.Tensor, mx: bool):
         """LayerNorm output as a split-precision A operand: (hi, lo, None), or (hi, None, (MX plane, amax bound)) in ONE pass"""
@@ -515,13 +532,24 @@ class Block(_Packed):
         lin_in, k_in = (m.fc1, "fc1") if isinstance(m, Mlp) else (m.w12, "w12")
         lin_out, k_out = (m.fc2, "fc2") if isinstance(m, Mlp) else (m.w3, "w3")
         ikw = dict(out_f32=True, bias_n=m._f32(k_in + "_b", lin_in.bias))
+        split_out = "fc2" in parts
+        mx_in = "fc1" in parts and self._mx_ok(m, k_in, lin_in, R)
+        # SwiGLU in the w12 GEMM's epilogue (ops.ACT_SILU_MUL: rows of w12 interleaved, the fp32 [R, 2 Hd] pre-activation never
+        # written) wherever the launch form has it and the gate's output is a single 16-bit operand
+        sg = (not isinstance(m, Mlp)) and not split_out and \
+            ops.swiglu_fused_ok(R, lin_in.out_features // 2, lin_in.in_features, "fc1" in parts, mx_in)
+        if sg:
+            rows = m.sg_rows()
+            ikw = dict(bias_n=m.sg_bias(), act=ops.ACT_SILU_MUL, rows=rows)
         if "fc1" in parts:
-            xn2, xn2_lo, xn2_mx = self._ln_split("n2", self.norm2, x1, self._mx_ok(m, k_in, lin_in, R))
+            xn2, xn2_lo, xn2_mx = self._ln_split("n2", self.norm2, x1, mx_in)
             hpre = self._split_lin(m, k_in, lin_in, xn2, xn2_lo, xn2_mx, **ikw)
         else:
-            hpre = ops.gemm(ops.layernorm(x1, n2w, n2b, self.norm2.eps, dt), m._w16(k_in, lin_in.weight), **ikw)
-        split_out = "fc2" in parts
-        if isinstance(m, Mlp):
+            rows = ikw.pop("rows", None)
+            hpre = ops.gemm(ops.layernorm(x1, n2w, n2b, self.norm2.eps, dt), m._w16(k_in, lin_in.weight, rows), **ikw)
+        if sg:
+            h, h_lo = hpre, None
+        elif isinstance(m, Mlp):
             h, h_lo = ops.gelu_split(hpre, dt, split=split_out)
         else:
             h, h_lo = ops.swiglu(hpre, dt, split=True) if split_out else (ops.swiglu(hpre, dt), None)
@@ -619,8 +647,11 @@ class Block(_Packed):
             x3 = ops.gemm(h, m._w16("fc2", m.fc2.weight), out_f32=True, bias_n=m._f32("fc2_b", m.fc2.bias),
                           scale_n=g2, res=x1)
         else:
-            h12 = ops.gemm(xn2, m._w16("w12", m.w12.weight), out_f32=True, bias_n=m._f32("w12_b", m.w12.bias))
-            h = ops.swiglu(h12, dt)
+            if ops.swiglu_fused_ok(xn2.shape[0], m.w12.out_features // 2, m.w12.in_features, False, False):
+                h = ops.gemm(xn2, m._w16("w12", m.w12.weight, m.sg_rows()), bias_n=m.sg_bias(), act=ops.ACT_SILU_MUL)
+            else:
+                h12 = ops.gemm(xn2, m._w16("w12", m.w12.weight), out_f32=True, bias_n=m._f32("w12_b", m.w12.bias))
+                h = ops.swiglu(h12, dt)
             x3 = ops.gemm(h, m._w16("w3", m.w3.weight), out_f32=True, bias_n=m._f32("w3_b", m.w3.bias),
                           scale_n=g2, res=x1)
         return x3

@@ -13,7 +13,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import ACT_GELU, ACT_GELU_GRAD, ACT_NONE, ACT_RELU, GemmDesc, check, lib  # noqa: F401
+from ._lib import ACT_GELU, ACT_GELU_GRAD, ACT_NONE, ACT_RELU, ACT_SILU_MUL, GemmDesc, check, lib  # noqa: F401
 
 T16_DEFAULT = torch.float16
 
@@ -87,13 +87,16 @@ def _gemm_desc(a: torch.Tensor, b: torch.Tensor, *, out: Optional[torch.Tensor] 
         raise ValueError(f"gemm: inner dims differ: a[...,{K}] vs b[...,{b.shape[-1]}]")
     if a.stride(-1) != 1 or b.stride(-1) != 1:
         raise ValueError("gemm: K must be contiguous in both operands")
+    n_out = N // 2 if act == ACT_SILU_MUL else N      # SwiGLU epilogue: b = interleaved w12 (swiglu_rows), out = [M, Hd]
+    if act == ACT_SILU_MUL and (out_f32 or batch != 1 or N % 32):
+        raise ValueError("gemm: ACT_SILU_MUL writes a 16-bit [M, N / 2] matrix of one unbatched launch (N % 32 == 0)")
     if out is None:
-        shape = (batch, M, N) if (a.dim() == 3 or b.dim() == 3) else (M, N)
+        shape = (batch, M, n_out) if (a.dim() == 3 or b.dim() == 3) else (M, n_out)
         out = torch.empty(shape, device=a.device, dtype=torch.float32 if out_f32 else a.dtype)
     else:
         out_f32 = out.dtype == torch.float32
-        if out.stride(-1) != 1:
-            raise ValueError("gemm: out must be contiguous in its last dim")
+        if out.stride(-1) != 1 or out.shape[-1] != n_out:
+            raise ValueError("gemm: out must be contiguous in its last dim, one column per output feature")
     d = GemmDesc()
     d.A, d.B, d.C = a.data_ptr(), b.data_ptr(), out.data_ptr()
     d.lda, d.ldb, d.ldc = a.stride(-2), b.stride(-2), out.stride(-2)
@@ -1064,6 +1067,24 @@ def decoder_input(xs: torch.Tensor, c4: torch.Tensor, vit: torch.Tensor, hw, c4_
                                    vit.data_ptr(), vit.stride(0), out.data_ptr(), _p(lo), B, h, w, h4, w4, D),
           "asis_decoder_input")
     return (out, lo) if split else out
+
+
+def swiglu_rows(Hd: int, device) -> torch.Tensor:
+    """row order of w12 (and its bias) for the ACT_SILU_MUL epilogue of ``gemm``: groups of 16 x1 rows followed by the 16 x2 rows
+    of the same hidden columns (include/asis_hip.h) -> int64 [2 * Hd]"""
+    if Hd % 16:
+        raise ValueError("swiglu_rows: the hidden width must be a multiple of 16")
+    g = torch.arange(Hd, device=device).view(Hd // 16, 1, 16)
+    return torch.cat((g, g + Hd), 1).reshape(-1)
+
+
+def swiglu_fused_ok(M: int, Hd: int, K: int, split: bool, mx: bool) -> bool:
+    """shapes / operand forms the SwiGLU epilogue covers (include/asis_hip.h: ASIS_ACT_SILU_MUL); ASIS_SWIGLU_FUSED=0: never"""
+    return (_SWIGLU_FUSED and Hd % 16 == 0 and 2 * Hd >= 256 and M >= 256 and K % 64 == 0 and (mx or not split)
+            and os.environ.get("ASIS_GEMM_BIG", "1") != "0" and os.environ.get("ASIS_GEMM_8P_M16", "1") != "0")
+
+
+_SWIGLU_FUSED = os.environ.get("ASIS_SWIGLU_FUSED", "1") not in ("0", "")
 
 
 def swiglu(x12: torch.Tensor, dtype: torch.dtype, split: bool = False):

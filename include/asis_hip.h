@@ -42,7 +42,12 @@ extern "C" {
 #define ASIS_ACT_NONE 0
 #define ASIS_ACT_GELU 1 /* exact erf GELU: dinov2/layers/mlp.py:35 (nn.GELU default) */
 #define ASIS_ACT_RELU 2
-#define ASIS_ACT_SILU_MUL 3 /* reserved: SwiGLU dinov2/layers/swiglu_ffn.py:30-34 (separate kernel) */
+#define ASIS_ACT_SILU_MUL 3 /* SwiGLU gate in the epilogue, dinov2/layers/swiglu_ffn.py:30-34: B = w12 with its rows INTERLEAVED in   \
+                               groups of 16 (rows 32g .. 32g+15 = x1 rows 16g .., rows 32g+16 .. 32g+31 = x2 rows 16g ..; bias_n    \
+                               likewise), C = 16-bit [M, N / 2] = silu(x1 + b1) * (x2 + b2).  Dense launches on the 8-phase          \
+                               one-tile-per-workgroup form only (plain or MX split operands): K % 64 == 0, M >= 256, N >= 256,       \
+                               N % 32 == 0, ldc % 8 == 0, no residual / scale / statistics / second plane; else ASIS_EINVAL          \
+                               (the caller then runs asis_swiglu on the fp32 pre-activation) */
 #define ASIS_ACT_GELU_GRAD 4 /* backward of GELU in an input-gradient GEMM: C = (A B^T) * gelu'(aux), aux = 16-bit pre-activation */
 
 const char* asis_last_error(void);

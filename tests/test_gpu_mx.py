@@ -118,6 +118,50 @@ def test_mx_dense_gemm_vs_fp32(dev, M, N, K):
     assert rel_l2(o16, a32 @ w32.t() + bias) < 6e-4
 
 
+@pytest.mark.parametrize("M,Hd,K,with_bias", [(2100, 4096, 1536, True), (517, 160, 128, True), (3000, 1024, 256, False), (257, 144, 64, True)])
+@pytest.mark.parametrize("form", ["mx", "plain"])
+def test_swiglu_epilogue_vs_separate_kernel(dev, M, Hd, K, with_bias, form):
+    """ASIS_ACT_SILU_MUL (`dinov2/layers/swiglu_ffn.py:30-34` in the w12 GEMM's epilogue, rows of w12 interleaved by
+    ops.swiglu_rows): against fp32 torch, and against the unfused pair (fp32 pre-activation + asis_swiglu) — bit-identical
+    where both run the same main loop (the MX split form has one), ragged M and N / 2 tiles included."""
+    dt = torch.float16
+    a32 = (W.tensor(f"sg.a{M}.{K}", (M, K), 1.0)).to(dev)
+    w32 = W.tensor(f"sg.w{Hd}.{K}", (2 * Hd, K), 1.5 / K ** 0.5).to(dev)
+    bias = W.tensor(f"sg.b{Hd}", (2 * Hd,), 0.5).to(dev) if with_bias else None
+    pre = a32 @ w32.t() + (bias if with_bias else 0)
+    ref = F.silu(pre[:, :Hd]) * pre[:, Hd:]
+    rows = ops.swiglu_rows(Hd, dev)
+    assert sorted(rows.tolist()) == list(range(2 * Hd)) and rows[:32].tolist() == list(range(16)) + list(range(Hd, Hd + 16))
+    a_hi, a_lo = ops.cast_pad(a32, K, dt), ops.cast_pad(a32, K, dt, part=1)
+    w_hi, w_lo = ops.cast_pad(w32, K, dt), ops.cast_pad(w32, K, dt, part=1)
+    wi_hi, wi_lo = ops.cast_pad(w32[rows].contiguous(), K, dt), ops.cast_pad(w32[rows].contiguous(), K, dt, part=1)
+    bi = bias[rows].contiguous() if with_bias else None
+    assert ops.swiglu_fused_ok(M, Hd, K, form == "mx", form == "mx")
+    if form == "mx":
+        a_mx, amax_a = ops.mx_from_pair(a_hi, a_lo)
+        w_mx, amax_w = ops.mx_from_pair(w_hi, w_lo, wside=True)
+        wi_mx, amax_wi = ops.mx_from_pair(wi_hi, wi_lo, wside=True)
+        assert torch.equal(amax_w, amax_wi) and torch.equal(wi_mx.view(torch.int16), w_mx.view(torch.int16)[rows])
+        kw, kwi = dict(a_lo=a_mx, b_lo=w_mx, mx=(amax_a, amax_w)), dict(a_lo=a_mx, b_lo=wi_mx, mx=(amax_a, amax_wi))
+        tol = 4e-4
+    else:
+        kw, kwi, tol = {}, {}, 8e-4
+    out = torch.full((M + 1, Hd), 7.0, device=dev, dtype=dt)            # one guard row behind the output
+    fused = ops.gemm(a_hi, wi_hi, bias_n=bi, act=ops.ACT_SILU_MUL, out=out[:M], **kwi)
+    assert fused.shape == (M, Hd) and bool((out[M] == 7.0).all())
+    unfused = ops.swiglu(ops.gemm(a_hi, w_hi, out_f32=True, bias_n=bias, **kw), dt)
+    assert rel_l2(fused, ref) < tol and rel_l2(unfused, ref) < tol
+    if form == "mx":
+        assert torch.equal(fused, unfused)
+    else:
+        assert rel_l2(fused, unfused) < 4e-4
+    assert torch.equal(fused, ops.gemm(a_hi, wi_hi, bias_n=bi, act=ops.ACT_SILU_MUL, **kwi))
+    with pytest.raises(Exception, match="ACT_SILU_MUL"):                   # no fp32 / residual epilogue behind the gate
+        ops.gemm(a_hi, wi_hi, bias_n=bi, act=ops.ACT_SILU_MUL, out_f32=True, **kwi)
+    with pytest.raises(Exception, match="SILU_MUL"):
+        ops.gemm(a_hi, wi_hi, bias_n=bi, act=ops.ACT_SILU_MUL, scale_n=torch.ones(2 * Hd, device=dev), **kwi)
+
+
 def test_layernorm_mx_planes(dev):
     """asis_layernorm_mx: the 16-bit output equals asis_layernorm's, the MX plane decodes to (hi, lo) of the fp32 LayerNorm at
     e4m3 precision under an amax BOUND several binades above the true maximum."""
