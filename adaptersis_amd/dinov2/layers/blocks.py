@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import contextlib
 import math
+import os
 from typing import Callable, Optional, Tuple, Union
 
 import torch
@@ -34,6 +35,7 @@ def _vt_side_stream(device) -> "torch.cuda.Stream":
     return _VT_STREAMS[key]
 
 
+_PRECISE_FOLD_Q = os.environ.get("ASIS_PRECISE_FOLD_Q", "1") not in ("0", "")   # lab: the precise_level-2 path with an unfolded q (round <= 4)
 _LS_POW2_REFRESH = 64   # Block._ls_pow2: parameter changes between two reads of max|gamma|
 
 
@@ -510,22 +512,30 @@ class Block(_Packed):
         g2 = self._f32("g2", self.ls2.gamma) if isinstance(self.ls2, LayerScale) else None
         parts = config.precise_parts      # which of the four linear layers run split (default: all)
         n1w, n1b = self._f32("n1w", self.norm1.weight), self._f32("n1b", self.norm1.bias)
+        fold_q = config.fold_attn_scale and "qkv" not in parts and _PRECISE_FOLD_Q
         if "qkv" in parts:
             xn, xn_lo, xn_mx = self._ln_split("n1", self.norm1, x2, self._mx_ok(a, "qkv", a.qkv, R))
             qkv = self._split_lin(a, "qkv", a.qkv, xn, xn_lo, xn_mx, bias_n=a._f32("qkv_b", a.qkv.bias))     # 16-bit out: q, k, v operands
+        elif fold_q:
+            qw, qb, _ = a._qkv_folded()      # q rows carry scale * log2(e) (folded before the 16-bit rounding): the folded attention kernel
+            qkv = ops.gemm(ops.layernorm(x2, n1w, n1b, self.norm1.eps, dt), qw, bias_n=qb)
         else:
             qkv = ops.gemm(ops.layernorm(x2, n1w, n1b, self.norm1.eps, dt), a._w16("qkv", a.qkv.weight), bias_n=a._f32("qkv_b", a.qkv.bias))
         o = torch.empty((R, D), device=x2.device, dtype=dt)
         o_lo = torch.empty_like(o) if "proj" in parts else None
-        r0 = 0
-        for B, N in segs:
-            r1 = r0 + B * N
-            vt = ops.transpose_tokens(qkv[r0:r1, 2 * D:], B, N)
-            ops.attention_fwd(qkv[r0:r1, :D], qkv[r0:r1, D:2 * D], vt, B, a.num_heads, N, a.scale, out=o[r0:r1],
-                              out_lo=None if o_lo is None else o_lo[r0:r1])
-            r0 = r1
-        if r0 != R:
+        if sum(B * N for B, N in segs) != R:
             raise ValueError("forward_rows: segments do not cover the rows")
+        if fold_q and len(segs) <= 2:
+            # V row-major out of the one qkv GEMM, both stacked token batches in one launch (asis_attention_fwd_qkv)
+            ops.attention_fwd_qkv(qkv, list(segs), a.num_heads, None, o, out_lo=o_lo)
+        else:
+            r0 = 0
+            for B, N in segs:
+                r1 = r0 + B * N
+                vt = ops.transpose_tokens(qkv[r0:r1, 2 * D:], B, N)
+                ops.attention_fwd(qkv[r0:r1, :D], qkv[r0:r1, D:2 * D], vt, B, a.num_heads, N, None if fold_q else a.scale,
+                                  out=o[r0:r1], out_lo=None if o_lo is None else o_lo[r0:r1])
+                r0 = r1
         pkw = dict(out_f32=True, bias_n=a._f32("proj_b", a.proj.bias), scale_n=g1, res=x2)
         x1 = self._split_lin(a, "proj", a.proj, o, o_lo, **pkw) if o_lo is not None else ops.gemm(o, a._w16("proj", a.proj.weight), **pkw)
         n2w, n2b = self._f32("n2w", self.norm2.weight), self._f32("n2b", self.norm2.bias)
