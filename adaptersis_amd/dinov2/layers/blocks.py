@@ -548,16 +548,19 @@ class Block(_Packed):
         # written) wherever the launch form has it and the gate's output is a single 16-bit operand
         sg = (not isinstance(m, Mlp)) and not split_out and \
             ops.swiglu_fused_ok(R, lin_in.out_features // 2, lin_in.in_features, "fc1" in parts, mx_in)
+        ge = isinstance(m, Mlp) and not split_out          # likewise erf-GELU with a single 16-bit output: the GEMM's own epilogue
         if sg:
             rows = m.sg_rows()
             ikw = dict(bias_n=m.sg_bias(), act=ops.ACT_SILU_MUL, rows=rows)
+        elif ge:
+            ikw = dict(bias_n=m._f32(k_in + "_b", lin_in.bias), act=ops.ACT_GELU)
         if "fc1" in parts:
             xn2, xn2_lo, xn2_mx = self._ln_split("n2", self.norm2, x1, mx_in)
             hpre = self._split_lin(m, k_in, lin_in, xn2, xn2_lo, xn2_mx, **ikw)
         else:
             rows = ikw.pop("rows", None)
             hpre = ops.gemm(ops.layernorm(x1, n2w, n2b, self.norm2.eps, dt), m._w16(k_in, lin_in.weight, rows), **ikw)
-        if sg:
+        if sg or ge:
             h, h_lo = hpre, None
         elif isinstance(m, Mlp):
             h, h_lo = ops.gelu_split(hpre, dt, split=split_out)
