@@ -827,6 +827,54 @@ static int pack_conv_weight_impl(void* stream, int dtype, const float* w, void* 
   return ASIS_OK;
 }
 
+// Tiled form of the pair pack for 3x3 weights (round 5: the per-element gather above read 4 bytes at a 36-byte stride and ran
+// the UNet's 250 M parameters at a third of the HBM rate): contiguous fp32 runs in, through LDS, contiguous 16-bit runs out.
+//   mode 0: one block per (co, 128 input channels): 1152 contiguous floats -> 9 runs of 128 (x 2 planes)
+//   mode 1: one block per (64 output channels, 16 input channels): 64 runs of 144 floats -> 144 runs of 64 (rows padded to 145
+//           floats in LDS: the column reads are 2-way conflicted at worst)
+template <typename T>
+__global__ __launch_bounds__(256) void pack_conv3x3_pair_tiled_kernel(const float* __restrict__ w, T* __restrict__ out, T* __restrict__ out2,
+                                                                      int Cout, int Cin, int mode, int64_t ldo,
+                                                                      const float* __restrict__ mx_amax) {
+  __shared__ float tile[64 * 145];
+  const int tid = threadIdx.x;
+  uint32_t* const o1 = reinterpret_cast<uint32_t*>(out);
+  uint32_t* const o2 = reinterpret_cast<uint32_t*>(out2);
+  if (mode == 0) {
+    const int chunks = Cin >> 7;
+    const int co = blockIdx.x / chunks, ci0 = (blockIdx.x - co * chunks) << 7;
+    const float4* src = reinterpret_cast<const float4*>(w + ((int64_t)co * Cin + ci0) * 9);
+    for (int i = tid; i < 288; i += 256) reinterpret_cast<float4*>(tile)[i] = src[i];
+    __syncthreads();
+    for (int p = tid; p < 576; p += 256) {
+      const int tap = p >> 6, c = (p & 63) << 1;
+      const float v0 = tile[c * 9 + tap], v1 = tile[(c + 1) * 9 + tap];
+      const int64_t idx = ((int64_t)co * ldo + (int64_t)tap * Cin + ci0 + c) >> 1;
+      o1[idx] = pack2<T>(v0, v1);
+      o2[idx] = lo_word2<T>(v0, v1, mx_amax, true);
+    }
+  } else {
+    const int chunks = Cin >> 4;
+    const int cb = blockIdx.x / chunks, ci0 = (blockIdx.x - cb * chunks) << 4, co0 = cb << 6;
+    for (int i = tid; i < 64 * 36; i += 256) {
+      const int co = i / 36, j = i - co * 36;
+      const float4 v = reinterpret_cast<const float4*>(w + ((int64_t)(co0 + co) * Cin + ci0) * 9)[j];
+      float* t = tile + co * 145 + 4 * j;
+      t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
+    }
+    __syncthreads();
+    const int pair = tid & 31, slot = tid >> 5;
+    for (int row = slot; row < 144; row += 8) {
+      const int ci = row / 9, tapf = row - ci * 9;       // out[ci][(2 - kh) * 3 + (2 - kw)][co] = w[co][ci][kh][kw]
+      const int k = ci * 9 + (8 - tapf);
+      const float v0 = tile[(2 * pair) * 145 + k], v1 = tile[(2 * pair + 1) * 145 + k];
+      const int64_t idx = ((int64_t)(ci0 + ci) * ldo + (int64_t)tapf * Cout + co0 + 2 * pair) >> 1;
+      o1[idx] = pack2<T>(v0, v1);
+      o2[idx] = lo_word2<T>(v0, v1, mx_amax, true);
+    }
+  }
+}
+
 extern "C" int asis_pack_conv_weight_pair(void* stream, int dtype, const float* w, void* out_hi, void* out_lo, int Cout, int Cin,
                                           int KH, int KW, int mode, int64_t ldo, const float* amax) {
   ASIS_REQUIRE(w && out_hi && out_lo, "asis_pack_conv_weight_pair: null pointer");
@@ -838,6 +886,22 @@ extern "C" int asis_pack_conv_weight_pair(void* stream, int dtype, const float* 
   ASIS_REQUIRE(Cout > 0 && Cin > 0 && KH > 0 && KW > 0 && ldo >= K, "asis_pack_conv_weight_pair: bad shape / ldo");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int64_t total = (int64_t)rows * ldo;
+  static const int tiled_on = [] { const char* e = getenv("ASIS_PACK_TILED"); return e ? atoi(e) : 1; }();
+  const bool tiled = tiled_on && KH == 3 && KW == 3 && ldo == K && ldo % 2 == 0 && asis_aligned16(w) &&
+                     (reinterpret_cast<uintptr_t>(out_hi) & 3) == 0 && (reinterpret_cast<uintptr_t>(out_lo) & 3) == 0 &&
+                     (mode == 0 ? Cin % 128 == 0 : (Cout % 64 == 0 && Cin % 16 == 0));
+  if (tiled) {
+    const int64_t nblk = mode == 0 ? (int64_t)Cout * (Cin / 128) : (int64_t)(Cout / 64) * (Cin / 16);
+    ASIS_REQUIRE(nblk < (1ll << 31), "asis_pack_conv_weight_pair: too many tiles");
+    if (dtype == ASIS_F16)
+      hipLaunchKernelGGL((pack_conv3x3_pair_tiled_kernel<f16>), dim3((unsigned)nblk), dim3(256), 0, s, w, reinterpret_cast<f16*>(out_hi),
+                         reinterpret_cast<f16*>(out_lo), Cout, Cin, mode, ldo, amax);
+    else
+      hipLaunchKernelGGL((pack_conv3x3_pair_tiled_kernel<bf16>), dim3((unsigned)nblk), dim3(256), 0, s, w, reinterpret_cast<bf16*>(out_hi),
+                         reinterpret_cast<bf16*>(out_lo), Cout, Cin, mode, ldo, amax);
+    ASIS_CHECK_LAUNCH("asis_pack_conv_weight_pair");
+    return ASIS_OK;
+  }
   if (dtype == ASIS_F16)
     hipLaunchKernelGGL((pack_conv_weight_kernel<f16>), dim3(grid_for(total)), dim3(256), 0, s, w, reinterpret_cast<f16*>(out_hi), Cout,
                        Cin, KH, KW, mode, CoP, ldo, rows, 0, amax, reinterpret_cast<f16*>(out_lo));

@@ -123,7 +123,7 @@ def test_pack_dgrad_weight_and_decoder_input(dev):
 
 
 @pytest.mark.parametrize("mode", [0, 1])
-@pytest.mark.parametrize("shape", [(6, 16, 3, 3), (64, 24, 3, 3), (8, 4, 1, 1)])
+@pytest.mark.parametrize("shape", [(6, 16, 3, 3), (64, 24, 3, 3), (8, 4, 1, 1), (192, 256, 3, 3), (64, 128, 3, 3), (128, 48, 3, 3)])
 def test_pack_conv_weight_pair_equals_the_single_packs(dev, mode, shape):
     """the one-pass pair (hi + residual, hi + MX) is bit-identical to the three separate packs it replaces"""
     w = W.tensor(f"pkp.w{shape}", shape, 1.0).to(dev)
