@@ -157,6 +157,7 @@ SIGNATURES = {
     "asis_convt2x2_scatter": [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i],
     "asis_convt2x2_gather": [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i],
     "asis_convt2x2_bias_nblk": [_i64],
+    "asis_conv1x1_dgrad_small": [_vp, _i, _vp, _vp, _i64, _vp, _vp, _i64, _i, _i],
     "asis_convt2x2_bias_grad": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i],
     "asis_dice_nblk": [_i, _i],
     "asis_seg_loss_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _f, _vp, _vp, _vp, _vp],

@@ -219,6 +219,10 @@ class UNet(_Packed):
         else:
             ops.reduce_rows(dlogits_f32, 1.0, grads["outc.conv.bias"])
         ops.wgrad(d16, xl, C, 1, 1, 1, 0, inv_scale, out=grads["outc.conv.weight"])
+        if C <= 8 and Cq % 4 == 0 and Cq <= 1024:
+            # a handful of classes: one fp32 pass over dU instead of a K = 8 GEMM (three of them in split precision)
+            w32 = self._f32("outc.w32", oc.weight).view(C, Cq)
+            return ops.conv1x1_dgrad_small(d16.view(-1, CP), None if d_lo is None else d_lo.view(-1, CP), w32, C).view(B, H, W, Cq)
         # dgrad of the 1x1 conv: dY [P, CP] x W^T; B operand [Cq, CP] = weight^T zero-padded to CP columns
         def wt(part):
             return lambda p: ops.cast_pad(p.float().reshape(C, Cq).t().contiguous(), CP, dt, part=part)

@@ -247,6 +247,32 @@ __global__ __launch_bounds__(256) void convt2x2_bias_grad_kernel(const float* __
   }
 }
 
+// dU[m][c] = sum_{k < C} (d_hi[m][k] + d_lo[m][k]) * w[k][c]: the 1x1 classifier's input gradient as one pass over dU.  Lane =
+// 4 consecutive channels (its C x 4 weights stay in registers), 256 / (Cq / 4) rows per block pass; a row's gradient halves are
+// the same 2 x C values for all of its lanes (one cached line).
+template <typename T>
+__global__ __launch_bounds__(256) void conv1x1_dgrad_small_kernel(const T* __restrict__ dh, const T* __restrict__ dl, int64_t ldd,
+                                                                  const float* __restrict__ w, float* __restrict__ dU, int64_t M,
+                                                                  int Cq, int C) {
+  const int cg = Cq >> 2, rpb = 256 / cg;
+  const int c4 = threadIdx.x % cg, rl = threadIdx.x / cg;
+  if (rl >= rpb) return;
+  float4 wr[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) wr[k] = k < C ? *reinterpret_cast<const float4*>(w + (int64_t)k * Cq + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int64_t m = (int64_t)blockIdx.x * rpb + rl; m < M; m += (int64_t)gridDim.x * rpb) {
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (k < C) {
+        const float d = (float)dh[m * ldd + k] + (dl ? (float)dl[m * ldd + k] : 0.f);
+        a.x = __builtin_fmaf(d, wr[k].x, a.x); a.y = __builtin_fmaf(d, wr[k].y, a.y);
+        a.z = __builtin_fmaf(d, wr[k].z, a.z); a.w = __builtin_fmaf(d, wr[k].w, a.w);
+      }
+    *reinterpret_cast<float4*>(dU + m * Cq + 4 * c4) = a;
+  }
+}
+
 // ---- FCUUp + FusionModel of the OR-UNet fuse head (eval/eval_dinov2_or_unet_fuse.py:502-530) -------------------------
 // x <- relu(x + nearest(r)) in place on the split-precision map x [B,H,W,C]; r [B,h,w,C] is the projected ViT map after
 // BatchNorm + ReLU, F.interpolate(size=(H, W)) in its default 'nearest' mode = source pixel (ys[y], xs[x]), the tables made
@@ -389,6 +415,27 @@ extern "C" int asis_convt2x2_gather(void* stream, int dtype, const float* dcat, 
                        reinterpret_cast<bf16*>(dG), reinterpret_cast<bf16*>(dG_lo), B, H, W, Cout, H2, W2, Ctot, coff, padT,
                        padL);
   ASIS_CHECK_LAUNCH("asis_convt2x2_gather");
+  return ASIS_OK;
+}
+
+extern "C" int asis_conv1x1_dgrad_small(void* stream, int dtype, const void* d_hi, const void* d_lo, int64_t ldd, const float* w,
+                                        float* dU, int64_t M, int Cq, int C) {
+  ASIS_REQUIRE(d_hi && w && dU, "asis_conv1x1_dgrad_small: null pointer");
+  DT_OK(dtype, "asis_conv1x1_dgrad_small");
+  ASIS_REQUIRE(M > 0 && C >= 1 && C <= 8 && ldd >= C && Cq > 0 && Cq % 4 == 0 && Cq <= 1024,
+               "asis_conv1x1_dgrad_small: C=%d (1..8), Cq=%d (multiple of 4, <= 1024), ldd=%ld", C, Cq, (long)ldd);
+  ASIS_REQUIRE(asis_aligned16(w) && asis_aligned16(dU), "asis_conv1x1_dgrad_small: w and dU must be 16-byte aligned");
+  const int rpb = 256 / (Cq / 4);
+  int64_t nblk = (M + rpb - 1) / rpb;
+  if (nblk > 256 * 32) nblk = 256 * 32;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == ASIS_F16)
+    hipLaunchKernelGGL((conv1x1_dgrad_small_kernel<f16>), dim3((unsigned)nblk), dim3(256), 0, s, reinterpret_cast<const f16*>(d_hi),
+                       reinterpret_cast<const f16*>(d_lo), ldd, w, dU, M, Cq, C);
+  else
+    hipLaunchKernelGGL((conv1x1_dgrad_small_kernel<bf16>), dim3((unsigned)nblk), dim3(256), 0, s, reinterpret_cast<const bf16*>(d_hi),
+                       reinterpret_cast<const bf16*>(d_lo), ldd, w, dU, M, Cq, C);
+  ASIS_CHECK_LAUNCH("asis_conv1x1_dgrad_small");
   return ASIS_OK;
 }
 

@@ -1268,6 +1268,21 @@ def convt2x2_scatter(G: torch.Tensor, dst: torch.Tensor, dst_lo: Optional[torch.
                                       Cout, H2, W2, Ctot, coff, padT, padL), "asis_convt2x2_scatter")
 
 
+def conv1x1_dgrad_small(d_hi: torch.Tensor, d_lo: Optional[torch.Tensor], w: torch.Tensor, C: int) -> torch.Tensor:
+    """input gradient of a 1x1 convolution with C <= 8 output channels: (d_hi + d_lo)[M, :C] @ w[C, Cq] -> fp32 [M, Cq]"""
+    _dev(d_hi, d_lo, w)
+    _not_mx("conv1x1_dgrad_small", d_lo)
+    M, ldd = d_hi.shape[0], d_hi.stride(0)
+    Cq = w.shape[1]
+    if d_hi.dim() != 2 or d_hi.stride(1) != 1 or (d_lo is not None and (d_lo.stride() != d_hi.stride() or d_lo.dtype != d_hi.dtype)) \
+            or w.dtype != torch.float32 or w.shape[0] != C or not w.is_contiguous():
+        raise ValueError("conv1x1_dgrad_small: d_hi / d_lo 16-bit [M, >= C] row views with one layout, w contiguous float32 [C, Cq]")
+    out = torch.empty((M, Cq), device=d_hi.device, dtype=torch.float32)
+    check(lib().asis_conv1x1_dgrad_small(_stream(), _dt(d_hi.dtype), d_hi.data_ptr(), _p(d_lo), ldd, w.data_ptr(), out.data_ptr(), M, Cq, C),
+          "asis_conv1x1_dgrad_small")
+    return out
+
+
 def convt2x2_gather(dcat: torch.Tensor, B: int, H: int, W: int, Cout: int, coff: int, padT: int, padL: int,
                     dtype: torch.dtype, split: bool):
     """d cat fp32 [B,H2,W2,Ctot] -> (dG hi, dG lo|None 16-bit [B*H*W, 4*Cout], d bias partial sums fp32 [nblk, Cout])."""

@@ -525,6 +525,12 @@ int asis_convt2x2_scatter(void* stream, int dtype, const float* G, void* dst, vo
 int asis_convt2x2_gather(void* stream, int dtype, const float* dcat, void* dG, void* dG_lo, int B, int H, int W, int Cout,
                          int H2, int W2, int Ctot, int coff, int padT, int padL);
 int asis_convt2x2_bias_nblk(int64_t rows);
+/* input gradient of the UNet's 1x1 classifier (OutConv, `backbones/unet_parts.py:95-104` under autograd): dU fp32 [M, Cq] =
+ * (d_hi + d_lo)[M, :C] w, d_hi / d_lo = the 16-bit halves of the logits' gradient (row stride ldd elements, >= C; d_lo may be
+ * NULL), w fp32 [C, Cq] = the conv weight as stored, C <= 8 classes, Cq % 4 == 0, Cq <= 1024.  One pass over dU (round 5: as a
+ * K = 8 GEMM in three split passes this was 1.6 % of the config-2 step). */
+int asis_conv1x1_dgrad_small(void* stream, int dtype, const void* d_hi, const void* d_lo, int64_t ldd, const float* w, float* dU,
+                             int64_t M, int Cq, int C);
 int asis_convt2x2_bias_grad(void* stream, const float* dcat, float* partial, int B, int H, int W, int Cout, int H2, int W2,
                             int Ctot, int coff, int padT, int padL);
 

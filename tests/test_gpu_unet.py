@@ -74,6 +74,24 @@ def test_convtranspose2x2_as_gemm(dev, case):
     assert rel_l2(ops.reduce_rows(bpart), up.reshape(-1, Cout).sum(0)) < 1e-6
 
 
+@pytest.mark.parametrize("M,Cq,C,CP,split", [(3001, 192, 2, 8, True), (70, 48, 2, 8, False), (1000, 96, 11, 16, True), (513, 1024, 8, 8, True)])
+def test_conv1x1_dgrad_small(dev, M, Cq, C, CP, split):
+    """the 1x1 classifier's input gradient (OutConv, `unet_parts.py:95-104` under autograd) as one fp32 pass"""
+    if C > 8:
+        with pytest.raises(Exception, match="conv1x1_dgrad_small"):
+            ops.conv1x1_dgrad_small(torch.zeros(M, CP, device=dev, dtype=DT), None, torch.zeros(C, Cq, device=dev), C)
+        return
+    d = torch.zeros(M, CP, device=dev)
+    d[:, :C] = W.tensor(f"o1.d{M}.{C}", (M, C), 1.0).to(dev)
+    w = W.tensor(f"o1.w{C}.{Cq}", (C, Cq), 0.3).to(dev)
+    dh, dl = _split(d)
+    got = ops.conv1x1_dgrad_small(dh, dl if split else None, w, C)
+    ref = ((dh.float() + dl.float()) if split else dh.float())[:, :C].double() @ w.double()
+    assert got.shape == (M, Cq) and rel_l2(got, ref.float()) < 2e-7
+    if split:
+        assert rel_l2(got, d[:, :C] @ w) < 2e-6
+
+
 def test_unet_module_vs_reference_golden(dev):
     g = load_golden("unet")
     B, hw, HW = 2, 10, 56
