@@ -53,6 +53,48 @@ def test_block_with_fused_qkv_projection(dev, fold):
     assert rel_l2(y1, y0) < 1e-5
 
 
+@pytest.mark.parametrize("level", [0, 2])
+def test_swiglu_block_with_the_gate_in_the_gemm_epilogue(dev, level):
+    """A SwiGLU block (`swiglu_ffn.py:30-34,54-72`; hidden 688 = 43 groups of 16) on stacked rows: the gate in the w12 GEMM's
+    epilogue (ops.ACT_SILU_MUL, default) against the oracle and against the two-kernel form — bit-identical at precise_level 2
+    (one MX split launch form), 16-bit-rounding close at level 0 (another main loop); the precise path's folded q + one-launch
+    row-major-V attention against its unfolded form."""
+    from adaptersis_amd import config, ops
+    from adaptersis_amd.dinov2.layers import blocks as BL
+    torch.manual_seed(3)
+    blk = BL.Block(256, 4, qkv_bias=True, init_values=0.3, ffn_layer=BL.SwiGLUFFNFused).to(dev).eval()
+    with torch.no_grad():
+        for p_ in blk.parameters():
+            if p_.dim() == 1 and p_.numel() == 256 and float(p_.std()) == 0:
+                p_.add_(0.1 * torch.randn_like(p_))
+    sd = {"b." + k: v.detach().cpu() for k, v in blk.state_dict().items()}
+    segs = [(2, 301), (1, 300)]
+    R = sum(b * n for b, n in segs)
+    x = (W.tensor("sgb.x", (R, 256), 1.0)).to(dev)
+    ref = torch.cat([O.block(x[r0:r0 + b * n].cpu().view(b, n, 256), sd, "b", 4).reshape(b * n, 256)
+                     for (b, n), r0 in zip(segs, (0, 602))])
+    keep = (config.precise_level, config.precise_parts, ops._SWIGLU_FUSED, BL._PRECISE_FOLD_Q)
+    try:
+        config.precise_level = level
+        config.precise_parts = frozenset(("proj", "fc1"))
+        assert ops.swiglu_fused_ok(R, 688, 256, level == 2, level == 2 and config.mx_dense_on())
+        y1 = blk.forward_rows(x, segs)
+        ops._SWIGLU_FUSED = False
+        y0 = blk.forward_rows(x, segs)
+        ops._SWIGLU_FUSED = True
+        if level == 2:
+            BL._PRECISE_FOLD_Q = False
+            y2 = blk.forward_rows(x, segs)
+    finally:
+        config.precise_level, config.precise_parts, ops._SWIGLU_FUSED, BL._PRECISE_FOLD_Q = keep
+    assert rel_l2(y1, ref) < (2e-4 if level == 2 else TOL / 2) and rel_l2(y0, ref) < (2e-4 if level == 2 else TOL / 2)
+    if level == 2 and config.mx_dense_on():
+        assert torch.equal(y1, y0)
+        assert rel_l2(y2, ref) < 2e-4 and rel_l2(y2, y1) < 2e-4
+    else:
+        assert rel_l2(y1, y0) < 2e-4
+
+
 def test_patch_embed_vs_oracle(dev):
     m, sd = build("vit_tiny_test", dev)
     img, _ = W.synthetic_batch(2, 224)
