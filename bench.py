@@ -317,6 +317,9 @@ def main():
                     help="skip the short extra passes after the timed region (secondary.all_reference_calls, secondary.bf16, host enqueue time)")
     ap.add_argument("--cpu-baseline-batch", type=int, default=1, help="batch of the timed CPU (oracle) step: 1 or 2")
     a = ap.parse_args()
+    # dmabuf IPC only on this pool: must be in the environment before the HIP runtime starts in THIS process too (a rank started
+    # by the driver's torchrun inherits it from the driver; this is the default for any other launcher)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N`: start the N ranks ourselves, BEFORE this process makes any GPU call (a process that
