@@ -84,12 +84,14 @@ def test_conv1x1_dgrad_small(dev, M, Cq, C, CP, split):
     d = torch.zeros(M, CP, device=dev)
     d[:, :C] = W.tensor(f"o1.d{M}.{C}", (M, C), 1.0).to(dev)
     w = W.tensor(f"o1.w{C}.{Cq}", (C, Cq), 0.3).to(dev)
-    dh, dl = _split(d)
-    got = ops.conv1x1_dgrad_small(dh, dl if split else None, w, C)
-    ref = ((dh.float() + dl.float()) if split else dh.float())[:, :C].double() @ w.double()
-    assert got.shape == (M, Cq) and rel_l2(got, ref.float()) < 2e-7
-    if split:
-        assert rel_l2(got, d[:, :C] @ w) < 2e-6
+    for dt in (DT, torch.bfloat16):
+        dh = d.to(dt)
+        dl = (d - dh.float()).to(dt)
+        got = ops.conv1x1_dgrad_small(dh, dl if split else None, w, C)
+        ref = ((dh.float() + dl.float()) if split else dh.float())[:, :C].double() @ w.double()
+        assert got.shape == (M, Cq) and rel_l2(got, ref.float()) < 2e-7
+        if split:
+            assert rel_l2(got, d[:, :C] @ w) < (2e-6 if dt == DT else 2e-5)
 
 
 def test_unet_module_vs_reference_golden(dev):
