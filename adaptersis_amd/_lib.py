@@ -97,6 +97,7 @@ SIGNATURES = {
     "asis_attention_fwd_split": [_vp, _i, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i, _i, _i, _i, _i, _f, _vp],
     "asis_attention_fwd_prescaled": [_vp, _i, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i, _i, _i, _i, _i, _vp],
     "asis_attention_fwd_qkv": [_vp, _i, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i, _i, _i, _i, _i, _f, _i, _vp],
+    "asis_attention_fwd_qkv_mx": [_vp, _i, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i, _i, _i, _i, _i, _f, _i, _vp, _vp],
     "asis_attention_fwd_lse": [_vp, _i, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _i, _f, _vp],
     "asis_transpose_tokens": [_vp, _i, _vp, _i64, _vp, _i64, _i, _i, _i],
     "asis_attention_bwd_rows": [_vp, _i, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i,

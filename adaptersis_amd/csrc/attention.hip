@@ -53,7 +53,8 @@ template <typename T, int SCHED, bool VROWS = false>
 __global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(const T* __restrict__ q, const T* __restrict__ k, int64_t ldqk,
                                                               const T* __restrict__ vt, int64_t ldvt, T* __restrict__ o, T* __restrict__ o_lo,
                                                               int64_t ldo, int H, int N1, float scale_log2e,
-                                                              float* __restrict__ lse2, int B1, int N2, int prescaled) {
+                                                              float* __restrict__ lse2, int B1, int N2, int prescaled,
+                                                              const float* __restrict__ mx_amax) {
   typedef typename T16<T>::v8 v8;
   typedef __attribute__((address_space(3))) void* lds_ptr;
   typedef const __attribute__((address_space(1))) void* glb_ptr;
@@ -357,15 +358,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(const T* __restri
         w.y = pack2<T>(oacc[db][4 * g + 2] * inv, oacc[db][4 * g + 3] * inv);
         *reinterpret_cast<uint2*>(op + db * 32 + g * 8) = w;
       }
-    if (o_lo) {  // rounding residual of the 16-bit output: o ~= o + o_lo feeds the projection GEMM as a split operand (A_lo)
+    if (o_lo) {  // rounding residual of the 16-bit output: o ~= o + o_lo feeds the projection GEMM as a split operand (A_lo);
+                 // with mx_amax (an upper bound of |o|: o is a convex combination of V rows, so max |V| is one) in the MX form
       T* lp = o_lo + (row0 + qi) * ldo + head * HD + 4 * fh;
 #pragma unroll
       for (int db = 0; db < 2; ++db)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           uint2 w;
-          w.x = pack2<T>(lo_part<T>(oacc[db][4 * g + 0] * inv), lo_part<T>(oacc[db][4 * g + 1] * inv));
-          w.y = pack2<T>(lo_part<T>(oacc[db][4 * g + 2] * inv), lo_part<T>(oacc[db][4 * g + 3] * inv));
+          w.x = lo_word2<T>(oacc[db][4 * g + 0] * inv, oacc[db][4 * g + 1] * inv, mx_amax);
+          w.y = lo_word2<T>(oacc[db][4 * g + 2] * inv, oacc[db][4 * g + 3] * inv, mx_amax);
           *reinterpret_cast<uint2*>(lp + db * 32 + g * 8) = w;
         }
     }
@@ -376,7 +378,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(const T* __restri
 
 static int attention_fwd_impl(void* stream, int dtype, const void* q, const void* k, int64_t ldqk, const void* vt,
                               int64_t ldvt, void* o, void* o_lo, int64_t ldo, int B1, int N1, int B2, int N2, int H,
-                              float scale, float* lse2, int prescaled, int vrows = 0) {
+                              float scale, float* lse2, int prescaled, int vrows = 0, const float* mx_amax = nullptr) {
   const int B = B1 + B2;
   ASIS_REQUIRE(!o_lo || (((uintptr_t)o_lo) & 7) == 0, "asis_attention_fwd: o_lo must be 8-byte aligned");
   const int N = N1 > N2 ? N1 : N2;
@@ -399,7 +401,7 @@ static int attention_fwd_impl(void* stream, int dtype, const void* q, const void
 #define ASIS_ATTN_PIPE_LAUNCH(TT, SC, VR)                                                                                 \
   hipLaunchKernelGGL((attn_fwd_pipe_kernel<TT, SC, VR>), grid, block, 0, s, reinterpret_cast<const TT*>(q),              \
                      reinterpret_cast<const TT*>(k), ldqk, reinterpret_cast<const TT*>(vt), ldvt, reinterpret_cast<TT*>(o), \
-                     reinterpret_cast<TT*>(o_lo), ldo, H, N1, sl, lse2, B1, N2, prescaled)
+                     reinterpret_cast<TT*>(o_lo), ldo, H, N1, sl, lse2, B1, N2, prescaled, mx_amax)
   if (dtype == ASIS_F16) {
     if (vrows) { if (fold) ASIS_ATTN_PIPE_LAUNCH(f16, 3, true); else ASIS_ATTN_PIPE_LAUNCH(f16, 0, true); }
     else { if (fold) ASIS_ATTN_PIPE_LAUNCH(f16, 3, false); else ASIS_ATTN_PIPE_LAUNCH(f16, 0, false); }
@@ -430,6 +432,14 @@ extern "C" int asis_attention_fwd_qkv(void* stream, int dtype, const void* q, co
   ASIS_REQUIRE(v && asis_aligned16(v), "asis_attention_fwd_qkv: v must be a 16-byte aligned pointer");
   return attention_fwd_impl(stream, dtype, q, k, ld, v, ld, o, o_lo, ldo, B1, N1, B2, N2, H, prescaled ? 1.0f : scale, lse2,
                             prescaled, 1);
+}
+
+extern "C" int asis_attention_fwd_qkv_mx(void* stream, int dtype, const void* q, const void* k, const void* v, int64_t ld, void* o,
+                                         void* o_mx, int64_t ldo, int B1, int N1, int B2, int N2, int H, float scale, int prescaled,
+                                         float* lse2, const float* amax) {
+  ASIS_REQUIRE(v && asis_aligned16(v) && o_mx && amax, "asis_attention_fwd_qkv_mx: v (16-byte aligned), o_mx and amax are required");
+  return attention_fwd_impl(stream, dtype, q, k, ld, v, ld, o, o_mx, ldo, B1, N1, B2, N2, H, prescaled ? 1.0f : scale, lse2,
+                            prescaled, 1, amax);
 }
 
 extern "C" int asis_attention_fwd_seg(void* stream, int dtype, const void* q, const void* k, int64_t ldqk, const void* vt,

@@ -36,6 +36,7 @@ def _vt_side_stream(device) -> "torch.cuda.Stream":
 
 
 _PRECISE_FOLD_Q = os.environ.get("ASIS_PRECISE_FOLD_Q", "1") not in ("0", "")   # lab: the precise_level-2 path with an unfolded q (round <= 4)
+_ATTN_MX_OUT = os.environ.get("ASIS_ATTN_MX_OUT", "1") not in ("0", "")          # lab: 0 = (o, o_lo) + absmax16 + mx_from_pair
 _LS_POW2_REFRESH = 64   # Block._ls_pow2: parameter changes between two reads of max|gamma|
 
 
@@ -525,9 +526,14 @@ class Block(_Packed):
         o_lo = torch.empty_like(o) if "proj" in parts else None
         if sum(B * N for B, N in segs) != R:
             raise ValueError("forward_rows: segments do not cover the rows")
+        o_mx = None
         if fold_q and len(segs) <= 2:
-            # V row-major out of the one qkv GEMM, both stacked token batches in one launch (asis_attention_fwd_qkv)
-            ops.attention_fwd_qkv(qkv, list(segs), a.num_heads, None, o, out_lo=o_lo)
+            # V row-major out of the one qkv GEMM, both stacked token batches in one launch (asis_attention_fwd_qkv); when proj
+            # takes MX operands the kernel writes o's lo half in the MX form itself, scaled by max |v| >= max |o| (o is a convex
+            # combination of V rows): no absmax + conversion passes over (o, o_lo)
+            if o_lo is not None and _ATTN_MX_OUT and self._mx_ok(a, "proj", a.proj, R):
+                o_mx = ops.absmax16(qkv[:, 2 * D:3 * D])
+            ops.attention_fwd_qkv(qkv, list(segs), a.num_heads, None, o, out_lo=o_lo, mx_amax=o_mx)
         else:
             r0 = 0
             for B, N in segs:
@@ -537,7 +543,10 @@ class Block(_Packed):
                                   out=o[r0:r1], out_lo=None if o_lo is None else o_lo[r0:r1])
                 r0 = r1
         pkw = dict(out_f32=True, bias_n=a._f32("proj_b", a.proj.bias), scale_n=g1, res=x2)
-        x1 = self._split_lin(a, "proj", a.proj, o, o_lo, **pkw) if o_lo is not None else ops.gemm(o, a._w16("proj", a.proj.weight), **pkw)
+        if o_mx is not None:
+            x1 = self._split_lin(a, "proj", a.proj, o, None, a_mx=(o_lo, o_mx), **pkw)
+        else:
+            x1 = self._split_lin(a, "proj", a.proj, o, o_lo, **pkw) if o_lo is not None else ops.gemm(o, a._w16("proj", a.proj.weight), **pkw)
         n2w, n2b = self._f32("n2w", self.norm2.weight), self._f32("n2b", self.norm2.bias)
         lin_in, k_in = (m.fc1, "fc1") if isinstance(m, Mlp) else (m.w12, "w12")
         lin_out, k_out = (m.fc2, "fc2") if isinstance(m, Mlp) else (m.w3, "w3")

@@ -377,10 +377,13 @@ def _attention_launch(q, k, vt, out, out_lo, B1, N1, B2, N2, H, scale, lse):
 
 
 def attention_fwd_qkv(qkv: torch.Tensor, segs, H: int, scale: Optional[float], out: torch.Tensor,
-                      out_lo: Optional[torch.Tensor] = None, lse: Optional[torch.Tensor] = None) -> torch.Tensor:
+                      out_lo: Optional[torch.Tensor] = None, lse: Optional[torch.Tensor] = None,
+                      mx_amax: Optional[torch.Tensor] = None) -> torch.Tensor:
     """qkv: 16-bit [rows, 3*H*64] = q | k | v of ONE projection GEMM (V row-major: no transposed copy); ``segs`` one or two
-    (B, N) token batches stacked along the rows; ``scale`` None = q carries scale * log2(e) (folded projection)."""
-    _dev(qkv, out, out_lo, lse)
+    (B, N) token batches stacked along the rows; ``scale`` None = q carries scale * log2(e) (folded projection).
+    ``mx_amax`` (device float >= max |v|, e.g. ``absmax16`` of the v columns): ``out_lo`` receives the MX form of the output's lo
+    half instead of the 16-bit residual (include/asis_hip.h: asis_attention_fwd_qkv_mx)."""
+    _dev(qkv, out, out_lo, lse, mx_amax)
     D = H * 64
     if qkv.dim() != 2 or qkv.shape[1] < 3 * D or qkv.stride(1) != 1 or len(segs) not in (1, 2):
         raise ValueError("attention_fwd_qkv: qkv must be [rows, >= 3*H*64] with contiguous rows, one or two segments")
@@ -389,6 +392,14 @@ def attention_fwd_qkv(qkv: torch.Tensor, segs, H: int, scale: Optional[float], o
         raise ValueError("attention_fwd_qkv: segments do not cover the rows")
     _check_out_lo(out, out_lo)
     es = qkv.element_size()
+    if mx_amax is not None:
+        if out_lo is None:
+            raise ValueError("attention_fwd_qkv: mx_amax needs the second output plane")
+        check(lib().asis_attention_fwd_qkv_mx(_stream(), _dt(qkv.dtype), qkv.data_ptr(), qkv.data_ptr() + D * es,
+                                              qkv.data_ptr() + 2 * D * es, qkv.stride(0), out.data_ptr(), out_lo.data_ptr(), out.stride(0),
+                                              B1, N1, B2, N2, H, 0.0 if scale is None else float(scale), int(scale is None), _p(lse),
+                                              mx_amax.data_ptr()), "asis_attention_fwd_qkv_mx")
+        return out
     check(lib().asis_attention_fwd_qkv(_stream(), _dt(qkv.dtype), qkv.data_ptr(), qkv.data_ptr() + D * es,
                                        qkv.data_ptr() + 2 * D * es, qkv.stride(0), out.data_ptr(), _p(out_lo), out.stride(0),
                                        B1, N1, B2, N2, H, 0.0 if scale is None else float(scale), int(scale is None), _p(lse)),

@@ -232,6 +232,13 @@ int asis_attention_fwd_prescaled(void* stream, int dtype, const void* q, const v
  * ignored), as in asis_attention_fwd_prescaled.  o_lo / lse2 as above. */
 int asis_attention_fwd_qkv(void* stream, int dtype, const void* q, const void* k, const void* v, int64_t ld, void* o, void* o_lo,
                            int64_t ldo, int B1, int N1, int B2, int N2, int H, float scale, int prescaled, float* lse2);
+/* asis_attention_fwd_qkv with the second output plane in the MX form (two fp8 bytes per element, activation side; the A_lo + MX
+ * operand of the projection GEMM, asis_gemm_desc.mx_amax_a): amax = device float, an upper bound of |o| — the attention output
+ * is a convex combination of V rows, so max |v| (asis_absmax_16 over the v columns) is one.  Saves the absmax + conversion passes
+ * over (o, o_lo) of the precise_level-2 blocks (round 5). */
+int asis_attention_fwd_qkv_mx(void* stream, int dtype, const void* q, const void* k, const void* v, int64_t ld, void* o, void* o_mx,
+                              int64_t ldo, int B1, int N1, int B2, int N2, int H, float scale, int prescaled, float* lse2,
+                              const float* amax);
 /* same, also writing lse2[B,H,N] = log2 sum_k exp2(log2(e) * scale * q.k) per query (what asis_attention_bwd_rows
  * needs to rebuild the probabilities); lse2 NULL = asis_attention_fwd */
 int asis_attention_fwd_lse(void* stream, int dtype, const void* q, const void* k, int64_t ldqk, const void* vt,

@@ -162,6 +162,28 @@ def test_swiglu_epilogue_vs_separate_kernel(dev, M, Hd, K, with_bias, form):
         ops.gemm(a_hi, wi_hi, bias_n=bi, act=ops.ACT_SILU_MUL, scale_n=torch.ones(2 * Hd, device=dev), **kwi)
 
 
+def test_attention_output_in_mx_form(dev):
+    """asis_attention_fwd_qkv_mx: the second output plane as the MX form of the output's lo half under the bound max |v| >= max |o|
+    (a convex combination of V rows) — the hi plane is unchanged, the plane decodes to (hi, lo) of the fp32 output at e4m3
+    precision, and agrees with mx_from_pair of the two-plane output at its own (tighter) maximum up to that precision."""
+    dt = torch.float16
+    H, D = 4, 256
+    segs = [(2, 300), (1, 301)]
+    R = sum(b * n for b, n in segs)
+    qkv = (W.tensor("amx.qkv", (R, 3 * D), 1.0) * torch.cat([torch.full((D,), 0.4), torch.full((D,), 1.0), torch.full((D,), 3.0)])).to(dev).to(dt)
+    o0, lo0 = torch.empty(R, D, device=dev, dtype=dt), torch.empty(R, D, device=dev, dtype=dt)
+    ops.attention_fwd_qkv(qkv, segs, H, 0.125, o0, out_lo=lo0)
+    amax_v = ops.absmax16(qkv[:, 2 * D:])
+    assert float(amax_v) == float(qkv[:, 2 * D:].float().abs().max()) and float(amax_v) >= float(o0.float().abs().max())
+    o1, mx1 = torch.empty_like(o0), torch.empty_like(o0)
+    ops.attention_fwd_qkv(qkv, segs, H, 0.125, o1, out_lo=mx1, mx_amax=amax_v)
+    assert torch.equal(o1, o0)
+    dh, dl = _decode(mx1, float(amax_v), dt, False)
+    assert rel_l2(dh, o0.float()) < 0.04 and rel_l2(dl, lo0.float()) < 0.06
+    with pytest.raises(ValueError, match="second output plane"):
+        ops.attention_fwd_qkv(qkv, segs, H, 0.125, o1, mx_amax=amax_v)
+
+
 def test_layernorm_mx_planes(dev):
     """asis_layernorm_mx: the 16-bit output equals asis_layernorm's, the MX plane decodes to (hi, lo) of the fp32 LayerNorm at
     e4m3 precision under an amax BOUND several binades above the true maximum."""
